@@ -1,0 +1,145 @@
+/*
+ * raindrop_hip.h -- C-ABI of libraindrop_hip.so, the MI355X (gfx950) implementation of the
+ * Raindrop hot path: Raindrop_v2.forward and its backward.
+ *
+ * The reference (/root/reference, pure Python on PyTorch + PyTorch-Geometric) has NO native
+ * interface for this path; its "FFI" is the set of torch / PyG / torch_scatter op call sites in
+ *   code/models_rd.py:278-387      (Raindrop_v2.forward)
+ *   code/Ob_propagation.py:94-228  (Observation_progation.forward / message / aggregate)
+ *   code/transformer_conv.py:139-207
+ * Each entry point below names the call sites it replaces.  Host binding: ctypes
+ * (raindrop_amd/_lib.py); see INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every tensor pointer is DEVICE memory owned by the caller
+ *     (the library never allocates, frees or retains tensor memory); fp32 unless stated;
+ *     "int64" tensors are torch.int64; masks are 1 byte per element (torch.bool);
+ *   - work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); no host
+ *     synchronisation, no internal streams, safe to capture into a hipGraph;
+ *   - scratch memory comes from the caller: query rd_*_workspace_bytes(), pass a buffer that
+ *     stays alive until the stream has run the call;
+ *   - return 0 on success, RD_EINVAL / RD_EUNSUPPORTED (negative) for argument errors detected
+ *     before any launch, or a positive hipError_t from the launch; rd_last_error() returns a
+ *     thread-local message for the last non-zero return;
+ *   - stateless and re-entrant; results are deterministic (no floating-point atomics).
+ */
+#ifndef RAINDROP_HIP_H
+#define RAINDROP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RD_OK 0
+#define RD_EINVAL (-1)
+#define RD_EUNSUPPORTED (-2)
+
+#define RD_ABI_VERSION 1
+
+/* Problem shape shared by the model-level entry points.
+ * K = T*d_ob (channels per sensor node), Dm = F*d_ob, D = Dm + d_pe (transformer width). */
+typedef struct rd_shape {
+  int32_t B;         /* samples in this batch (columns of src)                                  */
+  int32_t T;         /* time steps == max_len (code/models_rd.py:243: Linear(max_len*d_ob, .))  */
+  int32_t F;         /* sensors, d_inp                                                          */
+  int32_t d_ob;      /* observation-embedding width per sensor (code/Raindrop.py:126 -> 4)      */
+  int32_t d_pe;      /* positional-encoding width (code/models_rd.py:216 -> 16)                 */
+  int32_t nhead;     /* attention heads (code/Raindrop.py:130 -> 2)                             */
+  int32_t nhid;      /* FFN width (code/Raindrop.py:128 -> 2*F*d_ob)                            */
+  int32_t d_static;  /* static feature width, 0 when the model has no static branch            */
+  int32_t n_classes;
+  int32_t max_len;   /* PE timescale base (== T for the shipped configs)                        */
+} rd_shape;
+
+/* ---- library identity -------------------------------------------------------------------- */
+int rd_version(void);             /* RD_ABI_VERSION                                           */
+const char* rd_arch(void);        /* "gfx950"                                                  */
+const char* rd_last_error(void);  /* thread-local; "" if none                                  */
+
+/* ---- a5/a6: integer work (bit-exact contracts) -------------------------------------------- */
+
+/* code/models_rd.py:307-311: adj = global_structure; adj[diag] = 1; edge_index =
+ * nonzero(adj).T (row-major; row 0 = source j, row 1 = target i); edge_weights = adj[r, c].
+ * adj_out [F,F] receives the diagonal-patched adjacency (the reference patches its input in
+ * place); edge_index is int64 [2, F*F] capacity with row stride F*F, edge_weights [F*F],
+ * n_edges int32[1].  Entries beyond n_edges are left untouched. */
+int rd_graph_build(int32_t F, const float* global_structure, float* adj_out, int64_t* edge_index,
+                   float* edge_weights, int32_t* n_edges, void* stream);
+
+/* code/models_rd.py:298-299: mask[b,t] = (t >= lengths[b]) as bytes [B,T];
+ * code/models_rd.py:28-38,292,354: pe[t,b,:] = [sin(times/ts), cos(times/ts)] written into
+ * columns [F*d_ob, F*d_ob + d_pe) of the concat buffer z [T,B,D]; timescales[d_pe/2] are
+ * computed by the host in float64 and passed as fp32, exactly as the reference casts them. */
+int rd_pe_mask(const rd_shape* s, const float* times, const int64_t* lengths,
+               const float* timescales, float* z, uint8_t* mask, void* stream);
+
+/* ---- a7-a13: inter-sensor message passing (kernel K1) ------------------------------------- */
+
+/* PyG `softmax(edge_weights, index=target)` + per-target coefficient sum on the dense sensor
+ * graph (code/Ob_propagation.py:187,195 via models_rd.py:307-311): for the patched adjacency
+ * adj [F,F] (edge j->i exists iff adj[j,i] != 0) writes gamma[j,i] = softmax over sources j of
+ * adj[:,i] (0 where no edge) and ssum[i] = sum_j gamma[j,i].  One wavefront per target node,
+ * wave-shuffle reductions; F <= 1024. */
+int rd_edge_softmax(int32_t F, const float* adj, float* gamma, float* ssum, void* stream);
+
+/* The same softmax over an explicit edge list (duplicate edges allowed): edge_index int64 with
+ * rows [source; target] `row_stride` elements apart, normalised by row `norm_row`
+ * (1 = target: code/Ob_propagation.py:195, code/transformer_conv.py:201; 0 = source: the
+ * use_beta branch, code/Ob_propagation.py:184).  gamma_e [E], ssum [N]. */
+int rd_edge_softmax_list(int32_t N, int32_t E, const int64_t* edge_index, int64_t row_stride,
+                         int32_t norm_row, const float* edge_weights, float* gamma_e, float* ssum,
+                         void* stream);
+
+/* Source-valued aggregate of TransformerConv (code/transformer_conv.py:158,168-175,205-206) on a
+ * dense coefficient matrix: out[i,c] = sum_j gamma[j,i] V[j,c] (+ skip[i,c] if skip != NULL);
+ * backward w.r.t. V: dV[j,c] = sum_i gamma[j,i] dout[i,c]. */
+int rd_aggregate_fwd(int32_t N, int32_t C, const float* gamma, const float* V, const float* skip,
+                     float* out, void* stream);
+int rd_aggregate_bwd(int32_t N, int32_t C, const float* gamma, const float* dout, float* dV,
+                     void* stream);
+
+size_t rd_msgpass_workspace_bytes(const rd_shape* s);
+
+/* Forward of both Observation_progation layers for the whole batch
+ * (code/models_rd.py:285-296,313-343 + code/Ob_propagation.py:157-228, default branch):
+ *   X[b,f,t*d+c]  = relu(src[t,b,f] * R_u[f*d+c])            (observation embedding)
+ *   Y1 = relu(X  W1^T + b1) * ssum[f];   Y2 = relu(Y1 W2^T + b2) * ssum[f]
+ *   z[t,b,f*d+c]  = Y2[b,f,t*d+c]                            (columns [0, F*d) of z, row stride ldz)
+ * src [T,B,2F] (values in the first F columns); xsave/y1save [B,F,K] are saved for backward.
+ * p_drop > 0 applies nn.Dropout to the embedding h (code/models_rd.py:296) with a Philox mask
+ * that is a pure function of (seed, element index); p_drop = 0 in eval mode. */
+int rd_msgpass_fwd(const rd_shape* s, const float* src, const float* R_u, const float* W1,
+                   const float* b1, const float* W2, const float* b2, const float* ssum,
+                   float p_drop, uint64_t seed, float* xsave, float* y1save, float* z, int32_t ldz,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of rd_msgpass_fwd.  dz is the gradient w.r.t. z (row stride ldz; only the first
+ * F*d columns are read).  Writes dW1,db1,dW2,db2 and dR_u [F*d] (overwrite, not accumulate). */
+int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* R_u, const float* W1,
+                   const float* W2, const float* ssum, float p_drop, const float* xsave,
+                   const float* y1save, const float* z, const float* dz, int32_t ldz, float* dW1, float* db1,
+                   float* dW2, float* db2, float* dR_u, void* workspace, size_t workspace_bytes,
+                   void* stream);
+
+/* ---- generic dense pieces (used by the temporal encoder, the head and the large-K path) ---- */
+
+/* y[M,N] = act(x[M,K] W[N,K]^T + b)   (torch.nn.functional.linear; act: 0 none, 1 relu). */
+int rd_linear_fwd(int32_t M, int32_t N, int32_t K, const float* x, int32_t ldx, const float* W,
+                  const float* b, float* y, int32_t ldy, int32_t act, void* stream);
+/* dx[M,K] = dy[M,N] W[N,K]   (optionally masked by relu_src > 0 when relu_src != NULL). */
+int rd_linear_bwd_input(int32_t M, int32_t N, int32_t K, const float* dy, int32_t lddy,
+                        const float* W, float* dx, int32_t lddx, void* stream);
+size_t rd_linear_bwd_weight_workspace_bytes(int32_t M, int32_t N, int32_t K);
+/* dW[N,K] = dy[M,N]^T x[M,K];  db[N] = sum_m dy[m,:]  (db may be NULL).  Deterministic split
+ * over M with a fixed-order reduction. */
+int rd_linear_bwd_weight(int32_t M, int32_t N, int32_t K, const float* dy, int32_t lddy,
+                         const float* x, int32_t ldx, float* dW, float* db, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAINDROP_HIP_H */

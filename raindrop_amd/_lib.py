@@ -1,0 +1,95 @@
+"""ctypes binding of libraindrop_hip.so (the C-ABI declared in include/raindrop_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol cannot be
+resolved, importing/using the ops raises.  Build it with `python -m raindrop_amd.build`
+(or `__graft_entry__.build()`).
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int32, c_size_t, c_void_p
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libraindrop_hip.so")
+
+
+class RdShape(ctypes.Structure):
+    """Mirror of `struct rd_shape` (include/raindrop_hip.h)."""
+    _fields_ = [(n, c_int32) for n in ("B", "T", "F", "d_ob", "d_pe", "nhead", "nhid", "d_static",
+                                       "n_classes", "max_len")]
+
+
+class RaindropHipError(RuntimeError):
+    pass
+
+
+_P = c_void_p
+_SHP = POINTER(RdShape)
+
+# name -> (restype, argtypes); every symbol the header declares appears here, and
+# tests/test_cabi_symbols.py checks the two lists against each other.
+SIGNATURES = {
+    "rd_version": (c_int32, []),
+    "rd_arch": (c_char_p, []),
+    "rd_last_error": (c_char_p, []),
+    "rd_graph_build": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P]),
+    "rd_pe_mask": (c_int32, [_SHP, _P, _P, _P, _P, _P, _P]),
+    "rd_edge_softmax": (c_int32, [c_int32, _P, _P, _P, _P]),
+    "rd_edge_softmax_list": (c_int32, [c_int32, c_int32, _P, ctypes.c_int64, c_int32, _P, _P, _P, _P]),
+    "rd_aggregate_fwd": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _P]),
+    "rd_aggregate_bwd": (c_int32, [c_int32, c_int32, _P, _P, _P, _P]),
+    "rd_msgpass_workspace_bytes": (c_size_t, [_SHP]),
+    "rd_msgpass_fwd": (c_int32, [_SHP] + [_P] * 7 + [c_float, ctypes.c_uint64] + [_P] * 3
+                       + [c_int32, _P, c_size_t, _P]),
+    "rd_msgpass_bwd": (c_int32, [_SHP] + [_P] * 5 + [c_float] + [_P] * 4 + [c_int32] + [_P] * 5
+                       + [_P, c_size_t, _P]),
+    "rd_linear_fwd": (c_int32, [c_int32, c_int32, c_int32, _P, c_int32, _P, _P, _P, c_int32, c_int32, _P]),
+    "rd_linear_bwd_input": (c_int32, [c_int32, c_int32, c_int32, _P, c_int32, _P, _P, c_int32, _P]),
+    "rd_linear_bwd_weight_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "rd_linear_bwd_weight": (c_int32, [c_int32, c_int32, c_int32, _P, c_int32, _P, c_int32, _P, _P,
+                                        _P, c_size_t, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once; raise RaindropHipError (never fall back) if that is impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RaindropHipError(
+            "libraindrop_hip.so not found at %s -- build it with `python -m raindrop_amd.build`; "
+            "there is no CPU / eager fallback for the Raindrop hot path" % LIB_PATH)
+    # PyTorch-ROCm bundles its own libamdhip64; it must be the ONE HIP runtime in the process
+    # (streams and device pointers are shared with torch), so torch is imported before the dlopen.
+    import torch  # noqa: F401
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise RaindropHipError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise RaindropHipError("%s does not export %s (stale build?)" % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    if lib.rd_version() != 1:
+        raise RaindropHipError("ABI version mismatch: library %d, binding 1" % lib.rd_version())
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point and raise on a non-zero status."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.rd_last_error().decode(errors="replace")
+        kind = {-1: "RD_EINVAL", -2: "RD_EUNSUPPORTED"}.get(rc, "hipError %d" % rc)
+        raise RaindropHipError("%s failed (%s): %s" % (name, kind, msg))
+
+
+def shape(B, T, F, d_ob, d_pe=16, nhead=2, nhid=0, d_static=0, n_classes=2, max_len=None):
+    return RdShape(B, T, F, d_ob, d_pe, nhead, nhid, d_static, n_classes, T if max_len is None else max_len)

@@ -1,0 +1,76 @@
+"""Build recipe for libraindrop_hip.so (gfx950 only, in-tree so the .so travels with gpurun).
+
+    python -m raindrop_amd.build            # incremental
+    python -m raindrop_amd.build --force
+
+hipcc cross-compiles without a GPU; each translation unit becomes an object under
+`raindrop_amd/csrc/_build/` and the objects are linked into `raindrop_amd/libraindrop_hip.so`.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(CSRC, "_build")
+LIB = os.path.join(PKG, "libraindrop_hip.so")
+INCLUDE = os.path.join(os.path.dirname(PKG), "include")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
+         "-I", INCLUDE]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _stamp(src):
+    h = hashlib.sha1()
+    for path in [src] + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] \
+            + [os.path.join(INCLUDE, "raindrop_hip.h")]:
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(f for f in FLAGS if not f.startswith("/")).encode())   # path-independent
+    return h.hexdigest()
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+    stamp_file = obj + ".stamp"
+    stamp = _stamp(src)
+    if not force and os.path.exists(obj) and os.path.exists(stamp_file) \
+            and open(stamp_file).read() == stamp:
+        return obj, False
+    cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, res.stdout, res.stderr))
+    if res.stderr.strip():
+        sys.stderr.write(res.stderr)
+    with open(stamp_file, "w") as fh:
+        fh.write(stamp)
+    return obj, True
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sources()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        results = list(ex.map(lambda s: _compile(s, force), srcs))
+    objs = [o for o, _ in results]
+    rebuilt = any(r for _, r in results)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (res.stdout, res.stderr))
+    if verbose:
+        print("libraindrop_hip.so: %s (%d sources, %s)" % (
+            LIB, len(srcs), "rebuilt" if rebuilt else "up to date"))
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,60 @@
+// rd_common.h -- shared host/device helpers for libraindrop_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/raindrop_hip.h"
+
+namespace rd {
+
+// thread-local last-error message (rd_last_error()).
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail((int)e, "%s: %s", what, hipGetErrorString(e));
+  return RD_OK;
+}
+
+#define RD_REQUIRE(cond, ...)                           \
+  do {                                                  \
+    if (!(cond)) return rd::fail(RD_EINVAL, __VA_ARGS__); \
+  } while (0)
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------
+// Generic fp32 GEMM on the f32-input MFMA (v_mfma_f32_16x16x4_f32: exact fp32, == fmaf chain).
+//   C(m,n) = epilogue( sum_k A(m,k) * B(n,k) )
+// A(m,k) lives at A[m*sa_m + k*sa_k], B(n,k) at B[n*sb_n + k*sb_k]; either stride may be the
+// unit one, so NT (x W^T), NN (dy W) and TN (dy^T x) products are the same kernel.
+// ------------------------------------------------------------------------------------------
+struct GemmArgs {
+  const float* A; long sa_m, sa_k;
+  const float* B; long sb_n, sb_k;
+  float* C; long sc_m;            // C(m,n) at C[m*sc_m + n] unless scatter != 0
+  int M, N, K;
+  int nsplit; int k_per_split; long sc_split;   // split-K: partial z goes to C + z*sc_split, raw
+  // epilogue (ignored when nsplit > 1)
+  const float* bias;              // [N]
+  const float* rowscale; int rs_period;          // * rowscale[m % rs_period]
+  const float* posmask; long pm_m;               // * (posmask[m*pm_m + n] > 0)
+  const float* residual; long res_m;             // + residual[m*res_m + n]
+  int relu;
+  // scatter == 1: rows are (b,f) pairs of a [B,F,K] tensor, columns (t,c); element goes to the
+  // [T,B,ldz] layout z[(t*sB + b)*ldz + f*sd + c]   (code/models_rd.py:338-342)
+  int scatter; int sB, sF, sd; long ldz;
+};
+int launch_gemm(const GemmArgs& a, hipStream_t st);
+// sum `nsplit` partials [nsplit][rows*cols] in fixed order into out
+int launch_splitk_reduce(const float* part, int nsplit, long elems, float* out, hipStream_t st);
+// out[n] = sum_m x[m*ldx + n], deterministic two-stage; ws needs colsum_ws_floats(M,N) floats
+long colsum_ws_floats(int M, int N);
+int launch_colsum(const float* x, int M, int N, long ldx, float* out, float* ws, hipStream_t st);
+
+}  // namespace rd

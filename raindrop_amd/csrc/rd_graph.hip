@@ -1,0 +1,216 @@
+// rd_graph.hip -- sensor-graph construction (integer work, bit-exact), per-target edge softmax
+// with wavefront-shuffle reductions, and the positional-encoding / padding-mask kernel.
+#include "rd_common.h"
+
+namespace rd {
+namespace {
+
+// code/models_rd.py:307-311.  One 1024-thread workgroup: thread i owns the contiguous, row-major
+// segment [i*per, (i+1)*per) of the F*F adjacency, counts its non-zeros, an LDS scan turns the
+// counts into output offsets, and each thread then emits its edges in order -- so the edge list
+// has exactly torch.nonzero's row-major order.
+__global__ __launch_bounds__(1024) void k_graph_build(const float* __restrict__ gs, int F,
+                                                      float* __restrict__ adj,
+                                                      int64_t* __restrict__ edge_index,
+                                                      float* __restrict__ edge_weights,
+                                                      int32_t* __restrict__ n_edges) {
+  __shared__ int scan[1024];
+  const int tid = threadIdx.x;
+  const long total = (long)F * F;
+  const long per = (total + 1023) / 1024;
+  const long beg = min(total, tid * per), end = min(total, beg + per);
+  int cnt = 0;
+  for (long e = beg; e < end; ++e) {
+    const int r = (int)(e / F), c = (int)(e - (long)r * F);
+    const float v = (r == c) ? 1.0f : gs[e];
+    adj[e] = v;
+    cnt += (v != 0.0f);
+  }
+  scan[tid] = cnt;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+    const int v = (tid >= off) ? scan[tid - off] : 0;
+    __syncthreads();
+    scan[tid] += v;
+    __syncthreads();
+  }
+  long o = scan[tid] - cnt;
+  for (long e = beg; e < end; ++e) {
+    const int r = (int)(e / F), c = (int)(e - (long)r * F);
+    const float v = (r == c) ? 1.0f : gs[e];
+    if (v != 0.0f) {
+      edge_index[o] = r;              // row 0: source j
+      edge_index[total + o] = c;      // row 1: target i (row stride F*F)
+      edge_weights[o] = v;
+      ++o;
+    }
+  }
+  if (tid == 1023) *n_edges = scan[1023];
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// torch_geometric.utils.softmax(edge_weights, index=target) on the dense adjacency
+// (code/Ob_propagation.py:195): one wavefront per target node i, lanes stride over the sources j.
+__global__ __launch_bounds__(256) void k_edge_softmax(const float* __restrict__ adj, int F,
+                                                      float* __restrict__ gamma,
+                                                      float* __restrict__ ssum) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= F) return;
+  float m = -INFINITY;
+  for (int j = lane; j < F; j += 64) {
+    const float w = adj[(long)j * F + i];
+    if (w != 0.f) m = fmaxf(m, w);
+  }
+  m = wave_max(m);
+  float den = 0.f;
+  for (int j = lane; j < F; j += 64) {
+    const float w = adj[(long)j * F + i];
+    if (w != 0.f) den += expf(w - m);
+  }
+  den = wave_sum(den) + 1e-16f;
+  float tot = 0.f;
+  for (int j = lane; j < F; j += 64) {
+    const float w = adj[(long)j * F + i];
+    const float g = (w != 0.f) ? expf(w - m) / den : 0.f;
+    gamma[(long)j * F + i] = g;
+    tot += g;
+  }
+  tot = wave_sum(tot);
+  if (lane == 0) ssum[i] = tot;
+}
+
+// code/models_rd.py:28-38 (PE) and :298-299 (padding mask).  Thread per (t,b): 2*H transcendental
+// evaluations written straight into the PE columns of the concat buffer (no torch.cat pass).
+__global__ __launch_bounds__(256) void k_pe_mask(const float* __restrict__ times,
+                                                 const int64_t* __restrict__ lengths,
+                                                 const float* __restrict__ ts, float* __restrict__ z,
+                                                 uint8_t* __restrict__ mask, int T, int B, int D,
+                                                 int Dm, int H) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= (long)T * B) return;
+  const int t = (int)(i / B), b = (int)(i - (long)t * B);
+  const float tm = times[i];
+  float* row = z + i * D + Dm;
+  for (int k = 0; k < H; ++k) {
+    const float a = tm / ts[k];
+    row[k] = sinf(a);
+    row[H + k] = cosf(a);
+  }
+  mask[(long)b * T + t] = (uint8_t)((int64_t)t >= lengths[b]);
+}
+
+// torch_geometric.utils.softmax over an explicit edge list (duplicates allowed), normalised by
+// row `norm_row` of edge_index (1 = target: Observation_progation default / TransformerConv,
+// code/Ob_propagation.py:195, code/transformer_conv.py:201; 0 = source: the use_beta branch,
+// code/Ob_propagation.py:184).  One wavefront per node scans the list three times.
+__global__ __launch_bounds__(256) void k_edge_softmax_list(const int64_t* __restrict__ idx, int E,
+                                                           const float* __restrict__ w, int N,
+                                                           float* __restrict__ gamma_e,
+                                                           float* __restrict__ ssum) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float m = -INFINITY;
+  for (int e = lane; e < E; e += 64)
+    if (idx[e] == n) m = fmaxf(m, w[e]);
+  m = wave_max(m);
+  float den = 0.f;
+  for (int e = lane; e < E; e += 64)
+    if (idx[e] == n) den += expf(w[e] - m);
+  den = wave_sum(den) + 1e-16f;
+  float tot = 0.f;
+  for (int e = lane; e < E; e += 64)
+    if (idx[e] == n) {
+      const float g = expf(w[e] - m) / den;
+      gamma_e[e] = g;
+      tot += g;
+    }
+  tot = wave_sum(tot);
+  if (lane == 0) ssum[n] = tot;
+}
+
+}  // namespace
+}  // namespace rd
+
+using namespace rd;
+
+extern "C" int rd_graph_build(int32_t F, const float* global_structure, float* adj_out,
+                              int64_t* edge_index, float* edge_weights, int32_t* n_edges,
+                              void* stream) {
+  RD_REQUIRE(F > 0 && F <= 4096, "F=%d out of range", F);
+  RD_REQUIRE(global_structure && adj_out && edge_index && edge_weights && n_edges, "NULL tensor");
+  hipLaunchKernelGGL(k_graph_build, dim3(1), dim3(1024), 0, (hipStream_t)stream, global_structure,
+                     F, adj_out, edge_index, edge_weights, n_edges);
+  return check_launch("k_graph_build");
+}
+
+extern "C" int rd_edge_softmax(int32_t F, const float* adj, float* gamma, float* ssum, void* stream) {
+  RD_REQUIRE(F > 0 && F <= 4096, "F=%d out of range", F);
+  RD_REQUIRE(adj && gamma && ssum, "NULL tensor");
+  hipLaunchKernelGGL(k_edge_softmax, dim3(cdiv(F, 4)), dim3(256), 0, (hipStream_t)stream, adj, F,
+                     gamma, ssum);
+  return check_launch("k_edge_softmax");
+}
+
+extern "C" int rd_pe_mask(const rd_shape* s, const float* times, const int64_t* lengths,
+                          const float* timescales, float* z, uint8_t* mask, void* stream) {
+  RD_REQUIRE(s && s->T > 0 && s->F > 0 && s->d_ob > 0 && s->B >= 0, "bad rd_shape");
+  RD_REQUIRE(s->d_pe > 0 && (s->d_pe % 2) == 0, "d_pe must be even and positive");
+  RD_REQUIRE(times && lengths && timescales && z && mask, "NULL tensor");
+  if (s->B == 0) return RD_OK;
+  const long n = (long)s->T * s->B;
+  const int Dm = s->F * s->d_ob, D = Dm + s->d_pe;
+  hipLaunchKernelGGL(k_pe_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     times, lengths, timescales, z, mask, s->T, s->B, D, Dm, s->d_pe / 2);
+  return check_launch("k_pe_mask");
+}
+
+extern "C" int rd_edge_softmax_list(int32_t N, int32_t E, const int64_t* edge_index, int64_t row_stride,
+                                    int32_t norm_row, const float* edge_weights, float* gamma_e,
+                                    float* ssum, void* stream) {
+  RD_REQUIRE(N > 0 && E >= 0, "bad N=%d E=%d", N, E);
+  RD_REQUIRE(norm_row == 0 || norm_row == 1, "norm_row must be 0 (source) or 1 (target)");
+  RD_REQUIRE(edge_index && edge_weights && gamma_e && ssum, "NULL tensor");
+  hipLaunchKernelGGL(k_edge_softmax_list, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream,
+                     edge_index + (long)norm_row * row_stride, E, edge_weights, N, gamma_e, ssum);
+  return check_launch("k_edge_softmax_list");
+}
+
+// out[i,c] = sum_j gamma[j,i] * V[j,c] (+ skip[i,c])  -- the source-valued aggregate of
+// TransformerConv (code/transformer_conv.py:158,168-175,205-206) on a dense coefficient matrix.
+extern "C" int rd_aggregate_fwd(int32_t N, int32_t C, const float* gamma, const float* V,
+                                const float* skip, float* out, void* stream) {
+  RD_REQUIRE(N > 0 && C > 0, "bad N=%d C=%d", N, C);
+  RD_REQUIRE(gamma && V && out, "NULL tensor");
+  GemmArgs g{};
+  g.M = N; g.N = C; g.K = N; g.nsplit = 1;
+  g.A = gamma; g.sa_m = 1; g.sa_k = N;     // A(i,j) = gamma[j*N + i]
+  g.B = V; g.sb_n = 1; g.sb_k = C;         // B(c,j) = V[j*C + c]
+  g.C = out; g.sc_m = C;
+  g.residual = skip; g.res_m = C;
+  return launch_gemm(g, (hipStream_t)stream);
+}
+
+// dV[j,c] = sum_i gamma[j,i] * dout[i,c]
+extern "C" int rd_aggregate_bwd(int32_t N, int32_t C, const float* gamma, const float* dout,
+                                float* dV, void* stream) {
+  RD_REQUIRE(N > 0 && C > 0, "bad N=%d C=%d", N, C);
+  RD_REQUIRE(gamma && dout && dV, "NULL tensor");
+  GemmArgs g{};
+  g.M = N; g.N = C; g.K = N; g.nsplit = 1;
+  g.A = gamma; g.sa_m = N; g.sa_k = 1;     // A(j,i) = gamma[j*N + i]
+  g.B = dout; g.sb_n = 1; g.sb_k = C;      // B(c,i) = dout[i*C + c]
+  g.C = dV; g.sc_m = C;
+  return launch_gemm(g, (hipStream_t)stream);
+}

@@ -1,0 +1,235 @@
+// rd_msgpass.hip -- inter-sensor message passing (kernel family K1), general path.
+//
+// Replaces, for the whole batch at once, the reference's per-sample Python loop
+//   code/models_rd.py:285-296   observation embedding  h = relu(repeat_interleave(src) * R_u)
+//   code/models_rd.py:313-343   for unit in range(batch): reshape -> ob_propagation ->
+//                               ob_propagation_layer2 -> reshape back -> output[:, unit, :] = ...
+//   code/Ob_propagation.py:157-228  message(): edge softmax, relu(lin_value(x_i)) * gamma;
+//                               aggregate(): scatter-add onto the target node
+// On the shipped (default) branch the value multiplied by the softmax is the TARGET node's own
+// relu(lin_value(x_i)), so summing the messages into target i gives V[i] * sum_j gamma[j,i]
+// (SURVEY.md fact 2).  The per-target coefficient sum `ssum` comes from rd_edge_softmax (the
+// graph kernel), and lin_value is evaluated once per NODE instead of once per EDGE.
+//
+// This file holds the shape-generic path (any T, F): the [B*F, K] x [K, K] products run on the
+// tiled MFMA GEMM (rd_gemm.hip) with the ReLU / aggregate-scale / layout-scatter fused into its
+// epilogue.  The LDS-resident fused kernel for small K lives in rd_msgpass_fused.hip.
+#include "rd_common.h"
+#include "rd_rng.h"
+
+namespace rd {
+
+namespace {
+
+// X[b,f,t*d+c] = relu(src[t,b,f] * R_u[f*d+c])   (code/models_rd.py:290-291 + the layout change
+// of :326-327).  One workgroup per (sample, sensor-chunk); writes are contiguous in K.
+__global__ __launch_bounds__(256) void k_obs_embed(const float* __restrict__ src,
+                                                   const float* __restrict__ R_u,
+                                                   float* __restrict__ X, int B, int T, int F, int d,
+                                                   float p_drop, uint64_t seed) {
+  const int b = blockIdx.x;
+  const int K = T * d;
+  const long total = (long)F * K;
+  for (long o = blockIdx.y * (long)blockDim.x + threadIdx.x; o < total;
+       o += (long)gridDim.y * blockDim.x) {
+    const int f = (int)(o / K);
+    const int k = (int)(o - (long)f * K);
+    const int t = k / d, c = k - t * d;
+    float v = fmaxf(src[((long)t * B + b) * (2 * F) + f] * R_u[f * d + c], 0.f);
+    // nn.Dropout on h (code/models_rd.py:296); the mask is indexed in h's own [T,B,F*d] order
+    if (p_drop > 0.f && v > 0.f)
+      v *= dropout_scale(seed, SITE_OBS_EMBED, ((uint64_t)t * B + b) * (F * d) + f * d + c, p_drop,
+                         1.0f / (1.0f - p_drop));
+    X[(long)b * total + o] = v;
+  }
+}
+
+// dz2[b,f,t*d+c] = dz[t,b,f*d+c] * ssum[f] * (z[t,b,f*d+c] > 0)
+// (backward of `out * gamma` + scatter-add + ReLU of layer 2, read through the [T,B,ldz] layout).
+__global__ __launch_bounds__(256) void k_msg_dz2(const float* __restrict__ dz,
+                                                 const float* __restrict__ z,
+                                                 const float* __restrict__ ssum,
+                                                 float* __restrict__ dz2, int B, int T, int F, int d,
+                                                 long ldz) {
+  const int b = blockIdx.x;
+  const int Fd = F * d;
+  const long total = (long)T * Fd;
+  // iterate in the SOURCE order (t, f, c) so the strided global reads are coalesced
+  for (long i = blockIdx.y * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.y * blockDim.x) {
+    const int t = (int)(i / Fd);
+    const int fc = (int)(i - (long)t * Fd);
+    const int f = fc / d, c = fc - f * d;
+    const long zi = ((long)t * B + b) * ldz + fc;
+    const float g = (z[zi] > 0.f) ? dz[zi] * ssum[f] : 0.f;
+    dz2[((long)b * F + f) * ((long)T * d) + t * d + c] = g;
+  }
+}
+
+// per-sample partial of dR_u: part[b][f*d+c] = sum_t dx[b,f,t*d+c] * (x>0) * src[t,b,f]
+__global__ __launch_bounds__(256) void k_obs_embed_bwd(const float* __restrict__ dx,
+                                                       const float* __restrict__ X,
+                                                       const float* __restrict__ src,
+                                                       float* __restrict__ part, int B, int T, int F,
+                                                       int d, float keep_scale) {
+  const int b = blockIdx.x;
+  const int K = T * d;
+  for (int fc = threadIdx.x; fc < F * d; fc += blockDim.x) {
+    const int f = fc / d, c = fc - f * d;
+    const long base = ((long)b * F + f) * K + c;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const long o = base + (long)t * d;
+      if (X[o] > 0.f) s += dx[o] * src[((long)t * B + b) * (2 * F) + f];   // X>0 <=> relu open AND kept
+    }
+    part[(long)b * F * d + fc] = s * keep_scale;
+  }
+}
+
+struct MsgWs {
+  float *dz2, *dz1, *dx, *splitk, *colsum, *rupart;
+  size_t bytes;
+  int nsplit, kps;
+};
+
+MsgWs carve(const rd_shape* s, void* base) {
+  const long B = s->B, F = s->F, K = (long)s->T * s->d_ob;
+  const long M = B * F;
+  MsgWs w;
+  // split the B*F reduction of the weight gradients so that ~256+ workgroups exist
+  const int tiles = cdiv((int)K, 64) * cdiv((int)K, 64);
+  int nsplit = cdiv(512, tiles);
+  int kps = (int)align_up((size_t)cdiv((int)M, nsplit), 32);
+  nsplit = cdiv((int)M, kps);
+  w.nsplit = nsplit; w.kps = kps;
+  size_t off = 0;
+  auto take = [&](size_t nfloats) { float* p = base ? (float*)((char*)base + off) : nullptr;
+                                    off += align_up(nfloats * sizeof(float), 256); return p; };
+  w.dz2 = take(M * K); w.dz1 = take(M * K); w.dx = take(M * K);
+  w.splitk = take((size_t)nsplit * K * K);
+  w.colsum = take(colsum_ws_floats((int)M, (int)K));
+  w.rupart = take(B * F * s->d_ob);
+  w.bytes = off;
+  return w;
+}
+
+int check_shape(const rd_shape* s) {
+  RD_REQUIRE(s != nullptr, "rd_shape is NULL");
+  RD_REQUIRE(s->B >= 0 && s->T > 0 && s->F > 0 && s->d_ob > 0, "bad rd_shape (B=%d T=%d F=%d d_ob=%d)",
+             s->B, s->T, s->F, s->d_ob);
+  RD_REQUIRE((long)s->B * s->F * s->T * s->d_ob < (1L << 31), "B*F*T*d_ob exceeds 2^31");
+  return RD_OK;
+}
+
+}  // namespace
+}  // namespace rd
+
+using namespace rd;
+
+extern "C" size_t rd_msgpass_workspace_bytes(const rd_shape* s) {
+  if (!s || s->T <= 0 || s->F <= 0 || s->d_ob <= 0 || s->B < 0) return 0;
+  return carve(s, nullptr).bytes;
+}
+
+extern "C" int rd_msgpass_fwd(const rd_shape* s, const float* src, const float* R_u, const float* W1,
+                              const float* b1, const float* W2, const float* b2, const float* ssum,
+                              float p_drop, uint64_t seed, float* xsave, float* y1save, float* z,
+                              int32_t ldz, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_shape(s);
+  if (rc) return rc;
+  RD_REQUIRE(src && R_u && W1 && b1 && W2 && b2 && ssum && xsave && y1save && z, "NULL tensor");
+  RD_REQUIRE(ldz >= s->F * s->d_ob, "ldz (%d) < F*d_ob", ldz);
+  RD_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "p_drop must be in [0,1)");
+  (void)workspace; (void)workspace_bytes;
+  if (s->B == 0) return RD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = s->B, T = s->T, F = s->F, d = s->d_ob, K = T * d, M = B * F;
+  {
+    const long per = (long)F * K;
+    int gy = (int)((per + 255) / 256); if (gy > 64) gy = 64;
+    hipLaunchKernelGGL(k_obs_embed, dim3(B, gy), dim3(256), 0, st, src, R_u, xsave, B, T, F, d,
+                       p_drop, seed);
+    if ((rc = check_launch("k_obs_embed"))) return rc;
+  }
+  GemmArgs g{};
+  g.M = M; g.N = K; g.K = K; g.nsplit = 1;
+  g.A = xsave; g.sa_m = K; g.sa_k = 1;
+  g.B = W1; g.sb_n = K; g.sb_k = 1;
+  g.C = y1save; g.sc_m = K;
+  g.bias = b1; g.relu = 1; g.rowscale = ssum; g.rs_period = F;
+  if ((rc = launch_gemm(g, st))) return rc;
+  g.A = y1save; g.B = W2; g.bias = b2;
+  g.C = z; g.scatter = 1; g.sB = B; g.sF = F; g.sd = d; g.ldz = ldz;
+  return launch_gemm(g, st);
+}
+
+extern "C" int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* R_u, const float* W1,
+                              const float* W2, const float* ssum, float p_drop, const float* xsave,
+                              const float* y1save, const float* z, const float* dz, int32_t ldz,
+                              float* dW1, float* db1, float* dW2, float* db2, float* dR_u,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_shape(s);
+  if (rc) return rc;
+  RD_REQUIRE(src && R_u && W1 && W2 && ssum && xsave && y1save && z && dz, "NULL tensor");
+  RD_REQUIRE(dW1 && db1 && dW2 && db2 && dR_u, "NULL gradient output");
+  RD_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "p_drop must be in [0,1)");
+  RD_REQUIRE(ldz >= s->F * s->d_ob, "ldz (%d) < F*d_ob", ldz);
+  hipStream_t st = (hipStream_t)stream;
+  const int B = s->B, T = s->T, F = s->F, d = s->d_ob, K = T * d, M = B * F;
+  if (B == 0) {
+    hipMemsetAsync(dW1, 0, sizeof(float) * K * K, st); hipMemsetAsync(dW2, 0, sizeof(float) * K * K, st);
+    hipMemsetAsync(db1, 0, sizeof(float) * K, st); hipMemsetAsync(db2, 0, sizeof(float) * K, st);
+    hipMemsetAsync(dR_u, 0, sizeof(float) * F * d, st);
+    return RD_OK;
+  }
+  MsgWs w = carve(s, workspace);
+  RD_REQUIRE(workspace && workspace_bytes >= w.bytes, "workspace too small: %zu < %zu",
+             workspace_bytes, w.bytes);
+  {
+    const long per = (long)F * K;
+    int gy = (int)((per + 255) / 256); if (gy > 64) gy = 64;
+    hipLaunchKernelGGL(k_msg_dz2, dim3(B, gy), dim3(256), 0, st, dz, z, ssum, w.dz2, B, T, F, d, (long)ldz);
+    if ((rc = check_launch("k_msg_dz2"))) return rc;
+  }
+  // dz1 = (dz2 W2) * ssum[f] * (y1 > 0)
+  GemmArgs g{};
+  g.M = M; g.N = K; g.K = K; g.nsplit = 1;
+  g.A = w.dz2; g.sa_m = K; g.sa_k = 1;
+  g.B = W2; g.sb_n = 1; g.sb_k = K;          // B(n=k_out, k=n_red) = W2[n_red*K + k_out]
+  g.C = w.dz1; g.sc_m = K;
+  g.rowscale = ssum; g.rs_period = F; g.posmask = y1save; g.pm_m = K;
+  if ((rc = launch_gemm(g, st))) return rc;
+  // dx = dz1 W1
+  GemmArgs h{};
+  h.M = M; h.N = K; h.K = K; h.nsplit = 1;
+  h.A = w.dz1; h.sa_m = K; h.sa_k = 1;
+  h.B = W1; h.sb_n = 1; h.sb_k = K;
+  h.C = w.dx; h.sc_m = K;
+  if ((rc = launch_gemm(h, st))) return rc;
+  hipLaunchKernelGGL(k_obs_embed_bwd, dim3(B), dim3(256), 0, st, w.dx, xsave, src, w.rupart, B, T, F, d,
+                     1.0f / (1.0f - p_drop));
+  if ((rc = check_launch("k_obs_embed_bwd"))) return rc;
+  if ((rc = launch_colsum(w.rupart, B, F * d, F * d, dR_u, w.colsum, st))) return rc;
+  // weight gradients: dW[n,k] = sum_m dzL[m,n] * in[m,k], split over m
+  const float* dzs[2] = {w.dz2, w.dz1};
+  const float* ins[2] = {y1save, xsave};
+  float* dWs[2] = {dW2, dW1};
+  float* dbs[2] = {db2, db1};
+  for (int l = 0; l < 2; ++l) {
+    GemmArgs t{};
+    t.M = K; t.N = K; t.K = M;
+    t.A = dzs[l]; t.sa_m = 1; t.sa_k = K;
+    t.B = ins[l]; t.sb_n = 1; t.sb_k = K;
+    t.nsplit = w.nsplit; t.k_per_split = w.kps;
+    if (w.nsplit > 1) {
+      t.C = w.splitk; t.sc_m = K; t.sc_split = (long)K * K;
+      if ((rc = launch_gemm(t, st))) return rc;
+      if ((rc = launch_splitk_reduce(w.splitk, w.nsplit, (long)K * K, dWs[l], st))) return rc;
+    } else {
+      t.C = dWs[l]; t.sc_m = K;
+      if ((rc = launch_gemm(t, st))) return rc;
+    }
+    if ((rc = launch_colsum(dzs[l], M, K, K, dbs[l], w.colsum, st))) return rc;
+  }
+  return RD_OK;
+}

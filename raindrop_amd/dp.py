@@ -1,0 +1,123 @@
+"""Data-parallel training support: one process per GPU, samples sharded along the batch axis,
+ONE flat live-gradient buffer all-reduced over RCCL (xGMI) per step.
+
+The reference is single-process; this is the new multi-GPU layer
+BASELINE.json asks for.  Every stage of `Raindrop_v2.forward` is per-sample (SURVEY.md section
+8e), so the only exchange is the weight-gradient sum.  Design points for MI355X:
+  * dead parameters (72-92 % of the state_dict) never get a gradient and are
+    excluded, so the buffer is 2.0 MB at P19 instead of 7.8 MB;
+  * gradients live IN the flat buffer (each `param.grad` is a view), so there is no pack/unpack
+    copy and the optimizer reads the reduced values in place;
+  * the buffer is split into a few buckets in backward order (head -> encoder -> message passing);
+    each bucket's all-reduce is launched from an autograd hook as soon as its last gradient has
+    been accumulated, overlapping the xGMI transfer with the rest of backward.  At <= 8 MB per
+    bucket a ring all-reduce on the 7x153 GB/s full mesh is latency-, not bandwidth-bound, so few,
+    large buckets win.
+"""
+import torch
+import torch.distributed as dist
+
+
+class FlatGradAllReduce:
+    def __init__(self, params, process_group=None, n_buckets=2, average=True):
+        """params: list of (name, Parameter) that will receive gradients, in FORWARD order
+        (gradients therefore become ready roughly in reverse)."""
+        self.group = process_group
+        self.average = average
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.params = [p for _, p in params]
+        self.names = [n for n, _ in params]
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        self.slices = []
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            self.slices.append((off, off + n))
+            off += n
+        # buckets: contiguous ranges of the flat buffer, balanced by bytes, in forward order
+        n_buckets = max(1, min(n_buckets, len(self.params)))
+        target = total / n_buckets
+        self.bucket_of = []
+        bounds = [0]
+        acc, b = 0, 0
+        for i, p in enumerate(self.params):
+            if acc >= target * (b + 1) and b < n_buckets - 1:
+                bounds.append(self.slices[i][0])
+                b += 1
+            self.bucket_of.append(b)
+            acc += p.numel()
+        bounds.append(total)
+        self.bounds = bounds
+        self.n_buckets = len(bounds) - 1
+        self._pending = [0] * self.n_buckets
+        self._count = [self.bucket_of.count(b) for b in range(self.n_buckets)]
+        self._handles = []
+        self._hooks = []
+        if self.world > 1:
+            for i, p in enumerate(self.params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+
+    # -- per-step protocol -------------------------------------------------------------------
+    def zero(self):
+        """Zero the whole gradient buffer with one memset (replaces optimizer.zero_grad())."""
+        self.flat.zero_()
+        self._pending = [0] * self.n_buckets
+        self._handles = []
+
+    def _launch(self, b):
+        view = self.flat[self.bounds[b]:self.bounds[b + 1]]
+        if self.average and dist.get_backend(self.group) == "nccl":
+            op = dist.ReduceOp.AVG
+        else:
+            op = dist.ReduceOp.SUM
+        h = dist.all_reduce(view, op=op, group=self.group, async_op=True)
+        self._handles.append((h, view, op))
+
+    def _make_hook(self, i):
+        b = self.bucket_of[i]
+
+        def hook(_param):
+            self._pending[b] += 1
+            if self._pending[b] == self._count[b]:
+                self._launch(b)
+        return hook
+
+    def finish(self):
+        """Wait for the in-flight bucket all-reduces (call after backward, before optimizer.step);
+        launches any bucket whose hook did not fire (e.g. a parameter without gradient this step)."""
+        if self.world == 1:
+            return
+        launched = len(self._handles)
+        if launched < self.n_buckets:
+            done = {id(v) for _, v, _ in self._handles}
+            for b in range(self.n_buckets):
+                if self._pending[b] != self._count[b]:
+                    self._launch(b)
+        for h, view, op in self._handles:
+            h.wait()
+            if self.average and op == dist.ReduceOp.SUM:
+                view.div_(self.world)
+        self._handles = []
+
+    def nbytes(self):
+        return self.flat.numel() * 4
+
+
+def shard_batch(batch, rank, world):
+    """Contiguous shard of a global batch along B: src[:, lo:hi], times[:, lo:hi], static[lo:hi] ..."""
+    B = batch["src"].shape[1]
+    assert B % world == 0, "global batch must divide evenly (equal shards keep CE-mean exact)"
+    lo, hi = rank * (B // world), (rank + 1) * (B // world)
+    out = dict(src=batch["src"][:, lo:hi].contiguous(), times=batch["times"][:, lo:hi].contiguous(),
+               static=None if batch["static"] is None else batch["static"][lo:hi].contiguous(),
+               lengths=batch["lengths"][lo:hi].contiguous(), y=batch["y"][lo:hi].contiguous())
+    return out
+
+
+def broadcast_parameters(module, src=0, group=None):
+    """Identical replicas: rank `src`'s parameters and buffers overwrite everyone else's."""
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)

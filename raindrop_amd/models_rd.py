@@ -1,0 +1,171 @@
+"""`models_rd` surface of the reference (code/models_rd.py) on MI355X-native kernels.
+
+Drop-in boundary: `code/Raindrop.py:19` does `from models_rd import *`,
+constructs `Raindrop_v2(...)` positionally (`:245-251`), calls `.cuda()`, `.parameters()`,
+`.train()/.eval()`, `model.forward(P, Pstatic, Ptime, lengths)` (`:319`) and
+`state_dict()/load_state_dict()` (`:374,381`).  The classes below keep those signatures, the
+parameter names/shapes (dead parameters included) and the return tuple; the
+arithmetic is issued as HIP kernels through `raindrop_amd.ops` -- there is no eager fallback.
+
+Differences from the reference, all deliberate and documented in DESIGN.md:
+  * `R_u` is a registered Parameter (the reference loses it on GPU through
+    `Parameter(...).cuda()`, code/models_rd.py:241; on CPU it IS registered);
+  * no host round trips in forward (PE, padding mask and the edge list are built on device);
+  * the caller's `global_structure` is not mutated (the reference writes its diagonal in place
+    on CPU, code/models_rd.py:307-308);
+  * `distance` is the exact constant 0 the reference computes on this path.
+"""
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.parameter import Parameter
+
+from . import _lib, ops
+from .Ob_propagation import Observation_progation, glorot
+from .transformer_conv import TransformerConv
+
+__all__ = ["PositionalEncodingTF", "Raindrop_v2", "Observation_progation", "TransformerConv"]
+
+
+class PositionalEncodingTF(nn.Module):
+    """code/models_rd.py:20-43: sinusoidal encoding of continuous timestamps, timescales
+    `max_len ** linspace(0, 1, d_model/2)`.  Computed on device (the reference goes through the
+    host); returns [T, B, d_model]."""
+
+    def __init__(self, d_model, max_len=500, MAX=10000):
+        super().__init__()
+        self.max_len = max_len
+        self.d_model = d_model
+        self.MAX = MAX
+        self._num_timescales = d_model // 2
+        self._ts = {}
+
+    def timescales(self, device):
+        key = str(device)
+        if key not in self._ts:
+            self._ts[key] = ops.timescales(self.max_len, self.d_model).to(device)
+        return self._ts[key]
+
+    def getPE(self, P_time):
+        T, B = P_time.shape
+        shp = _lib.shape(B, T, 1, 1, d_pe=self.d_model)
+        z = torch.empty((T, B, 1 + self.d_model), dtype=torch.float32, device=P_time.device)
+        mask = torch.empty((B, T), dtype=torch.bool, device=P_time.device)
+        lengths = torch.zeros((B,), dtype=torch.int64, device=P_time.device)
+        times = P_time.contiguous().float()          # keep alive until the launch is enqueued
+        ts = self.timescales(P_time.device)
+        _lib.call("rd_pe_mask", ctypes.byref(shp), ops._ptr(times), ops._ptr(lengths), ops._ptr(ts),
+                  ops._ptr(z), ops._ptr(mask), ops._stream())
+        return z[:, :, 1:]
+
+    def forward(self, P_time):
+        return self.getPE(P_time)
+
+
+class Raindrop_v2(nn.Module):
+    """code/models_rd.py:194-387.  Transformer-over-time on top of per-sample sensor-graph message
+    passing; see the module docstring for the boundary contract."""
+
+    def __init__(self, d_inp=36, d_model=64, nhead=4, nhid=128, nlayers=2, dropout=0.3, max_len=215,
+                 d_static=9, MAX=100, perc=0.5, aggreg='mean', n_classes=2, global_structure=None,
+                 sensor_wise_mask=False, static=True):
+        super().__init__()
+        from torch.nn import TransformerEncoder, TransformerEncoderLayer
+        self.model_type = 'Transformer'
+        self.global_structure = global_structure
+        self.sensor_wise_mask = sensor_wise_mask
+        if sensor_wise_mask:
+            raise _lib.RaindropHipError(
+                "RD_EUNSUPPORTED: sensor_wise_mask=True is broken in the reference itself (shape "
+                "mismatch in mlp_static) and hard-wired off at code/Raindrop.py:103")
+        d_pe = 16
+        self.d_pe = d_pe
+        self.d_inp = d_inp
+        self.d_model = d_model
+        self.static = static
+        self.nhead = nhead
+        self.nhid = nhid
+        self.nlayers = nlayers
+        self.max_len = max_len
+        self.n_classes = n_classes
+        self.d_static = d_static
+        # registration order mirrors code/models_rd.py:223-264
+        if self.static:
+            self.emb = nn.Linear(d_static, d_inp)
+        self.d_ob = int(d_model / d_inp)
+        self.encoder = nn.Linear(d_inp * self.d_ob, self.d_inp * self.d_ob)          # dead (:228)
+        self.pos_encoder = PositionalEncodingTF(d_pe, max_len, MAX)
+        encoder_layers = TransformerEncoderLayer(d_model + 16, nhead, nhid, dropout)
+        self.transformer_encoder = TransformerEncoder(encoder_layers, nlayers, enable_nested_tensor=False)
+        self.R_u = Parameter(torch.Tensor(1, self.d_inp * self.d_ob))
+        self.ob_propagation = Observation_progation(
+            in_channels=max_len * self.d_ob, out_channels=max_len * self.d_ob, heads=1,
+            n_nodes=d_inp, ob_dim=self.d_ob)
+        self.ob_propagation_layer2 = Observation_progation(
+            in_channels=max_len * self.d_ob, out_channels=max_len * self.d_ob, heads=1,
+            n_nodes=d_inp, ob_dim=self.d_ob)
+        d_final = d_model + d_pe + (d_inp if static else 0)
+        self.mlp_static = nn.Sequential(nn.Linear(d_final, d_final), nn.ReLU(), nn.Linear(d_final, n_classes))
+        self.mlp = nn.Sequential(nn.Linear(d_model, d_model), nn.ReLU(), nn.Linear(d_model, n_classes))  # dead
+        self.aggreg = aggreg
+        self.relu = nn.ReLU()
+        self.dropout = nn.Dropout(dropout)
+        self._graph_cache = None
+        self._drop_calls = 0
+        self.init_weights()
+
+    def init_weights(self):
+        """code/models_rd.py:271-276."""
+        initrange = 1e-10
+        self.encoder.weight.data.uniform_(-initrange, initrange)
+        if self.static:
+            self.emb.weight.data.uniform_(-initrange, initrange)
+        glorot(self.R_u)
+
+    # -- sensor graph (code/models_rd.py:307-311), cached per (device, structure version) ------
+    def _graph(self, device):
+        gs = self.global_structure
+        key = (str(device), gs.data_ptr(), gs._version)
+        if self._graph_cache is None or self._graph_cache[0] != key:
+            adj, ei, ew = ops.graph_build(gs.to(device=device, dtype=torch.float32))
+            gamma, ssum = ops.edge_softmax_dense(adj)
+            self._graph_cache = (key, dict(adj=adj, edge_index=ei, edge_weights=ew, gamma=gamma, ssum=ssum))
+        return self._graph_cache[1]
+
+    def forward(self, src, static, times, lengths):
+        """src [T,B,2F] (values | observation mask), static [B,d_static] or None, times [T,B],
+        lengths [B] -> (logits [B,C], distance 0-d, None)   -- code/models_rd.py:278-387."""
+        maxlen, batch_size = src.shape[0], src.shape[1]
+        if not src.is_cuda:
+            raise _lib.RaindropHipError("Raindrop_v2 runs on a ROCm device only; move inputs with .cuda()")
+        dev = src.device
+        g = self._graph(dev)
+        shp = _lib.shape(batch_size, maxlen, self.d_inp, self.d_ob, d_pe=self.d_pe, nhead=self.nhead,
+                         nhid=self.nhid, d_static=self.d_static if self.static else 0,
+                         n_classes=self.n_classes, max_len=self.max_len)
+        if maxlen != self.max_len:
+            raise _lib.RaindropHipError("src.shape[0] (%d) must equal max_len (%d): lin_value is "
+                                        "Linear(max_len*d_ob, .)" % (maxlen, self.max_len))
+        p_drop = float(self.dropout.p) if self.training else 0.0
+        self._drop_calls += 1
+        seed = (torch.initial_seed() * 1000003 + self._drop_calls) & 0x7FFFFFFFFFFFFFFF
+        lengths = lengths.to(device=dev, dtype=torch.int64)
+        z, mask = ops.sensor_stage(
+            src.float(), times.float(), lengths, self.pos_encoder.timescales(dev), g["ssum"], self.R_u,
+            self.ob_propagation.lin_value.weight, self.ob_propagation.lin_value.bias,
+            self.ob_propagation_layer2.lin_value.weight, self.ob_propagation_layer2.lin_value.bias, shp,
+            p_drop, seed)
+        distance = torch.zeros((), dtype=torch.float32, device=dev)
+        # ---- temporal stage (interim: torch modules on the device; being replaced by K2/K3) ----
+        r_out = self.transformer_encoder(z, src_key_padding_mask=mask)
+        keep = (~mask).permute(1, 0).unsqueeze(2).to(r_out.dtype)
+        output = torch.sum(r_out * keep, dim=0) / (lengths.unsqueeze(1) + 1)
+        if static is not None:
+            emb = ops.linear(static.float(), self.emb.weight, self.emb.bias)
+            output = torch.cat([output, emb], dim=1)
+        hid = ops.linear(output, self.mlp_static[0].weight, self.mlp_static[0].bias, act=1)
+        output = ops.linear(hid, self.mlp_static[2].weight, self.mlp_static[2].bias)
+        return output, distance, None

@@ -1,0 +1,228 @@
+"""torch.autograd seams over the C-ABI (libraindrop_hip.so).
+
+PyTorch is plumbing here: it owns device memory, the current HIP stream and the autograd graph.
+Every numerical step of the hot path is a HIP kernel reached through `raindrop_amd._lib.call`.
+Tensors handed to the library must be fp32 (int64 / bool where stated), contiguous, and live on
+a ROCm device; anything else raises -- there is deliberately no eager fallback.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check(*tensors, dtype=torch.float32):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.RaindropHipError(
+                "Raindrop HIP ops need device tensors (got %s); no CPU fallback exists" % t.device)
+        if t.dtype != dtype:
+            raise _lib.RaindropHipError("expected %s tensor, got %s" % (dtype, t.dtype))
+        if not t.is_contiguous():
+            raise _lib.RaindropHipError("tensor must be contiguous")
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------------------
+# integer work
+# ------------------------------------------------------------------------------------------------
+
+def graph_build(global_structure):
+    """code/models_rd.py:307-311 on device.  Returns (adj [F,F], edge_index int64 [2,E],
+    edge_weights [E]); the single host read is the edge count (the reference syncs here too,
+    inside torch.nonzero)."""
+    gs = global_structure.contiguous()
+    _check(gs)
+    F = gs.shape[0]
+    adj = torch.empty_like(gs)
+    ei = torch.empty((2, F * F), dtype=torch.int64, device=gs.device)
+    ew = torch.empty((F * F,), dtype=torch.float32, device=gs.device)
+    n = torch.zeros((1,), dtype=torch.int32, device=gs.device)
+    _lib.call("rd_graph_build", F, _ptr(gs), _ptr(adj), _ptr(ei), _ptr(ew), _ptr(n), _stream())
+    E = int(n.item())
+    return adj, ei[:, :E], ew[:E]
+
+
+def edge_softmax_dense(adj):
+    """Per-target softmax of the dense adjacency + coefficient sums: (gamma [F,F], ssum [F])."""
+    adj = adj.contiguous()
+    _check(adj)
+    F = adj.shape[0]
+    gamma = torch.empty_like(adj)
+    ssum = torch.empty((F,), dtype=torch.float32, device=adj.device)
+    _lib.call("rd_edge_softmax", F, _ptr(adj), _ptr(gamma), _ptr(ssum), _stream())
+    return gamma, ssum
+
+
+def timescales(max_len, d_pe=16):
+    """float64 `max_len ** linspace(0,1,d_pe/2)` cast to fp32 (code/models_rd.py:31,34)."""
+    return torch.from_numpy((max_len ** np.linspace(0, 1, d_pe // 2)).astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------------------
+# sensor stage: observation embedding + 2 x Observation_progation + PE concat + padding mask
+# ------------------------------------------------------------------------------------------------
+
+class _SensorStage(torch.autograd.Function):
+    """z[T,B,D] = cat(message_passing(src), PE(times));  mask[B,T] = t >= lengths.
+
+    Forward : rd_pe_mask + rd_msgpass_fwd write disjoint column ranges of one buffer.
+    Backward: rd_msgpass_bwd (dW1, db1, dW2, db2, dR_u); PE / mask carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, src, times, lengths, ts, ssum, R_u, W1, b1, W2, b2, shp, p_drop, seed):
+        _check(src, times, ts, ssum, R_u, W1, b1, W2, b2)
+        _check(lengths, dtype=torch.int64)
+        T, B, F, d = shp.T, shp.B, shp.F, shp.d_ob
+        K, D = T * d, F * d + shp.d_pe
+        dev = src.device
+        z = torch.empty((T, B, D), dtype=torch.float32, device=dev)
+        mask = torch.empty((B, T), dtype=torch.bool, device=dev)
+        xsave = torch.empty((B, F, K), dtype=torch.float32, device=dev)
+        y1save = torch.empty((B, F, K), dtype=torch.float32, device=dev)
+        sp = ctypes.byref(shp)
+        _lib.call("rd_pe_mask", sp, _ptr(times), _ptr(lengths), _ptr(ts), _ptr(z), _ptr(mask), _stream())
+        _lib.call("rd_msgpass_fwd", sp, _ptr(src), _ptr(R_u), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2),
+                  _ptr(ssum), float(p_drop), int(seed), _ptr(xsave), _ptr(y1save), _ptr(z), D,
+                  _ptr(None), 0, _stream())
+        ctx.shp = shp
+        ctx.p_drop = float(p_drop)
+        ctx.save_for_backward(src, R_u, W1, W2, ssum, xsave, y1save, z)
+        ctx.mark_non_differentiable(mask)
+        return z, mask
+
+    @staticmethod
+    def backward(ctx, dz, _dmask):
+        src, R_u, W1, W2, ssum, xsave, y1save, z = ctx.saved_tensors
+        shp = ctx.shp
+        dz = dz.contiguous()
+        K = shp.T * shp.d_ob
+        D = shp.F * shp.d_ob + shp.d_pe
+        dev = dz.device
+        dW1 = torch.empty((K, K), dtype=torch.float32, device=dev)
+        dW2 = torch.empty((K, K), dtype=torch.float32, device=dev)
+        db1 = torch.empty((K,), dtype=torch.float32, device=dev)
+        db2 = torch.empty((K,), dtype=torch.float32, device=dev)
+        dRu = torch.empty_like(R_u)
+        sp = ctypes.byref(shp)
+        nbytes = _lib.load().rd_msgpass_workspace_bytes(sp)
+        ws = _workspace(nbytes, dev)
+        _lib.call("rd_msgpass_bwd", sp, _ptr(src), _ptr(R_u), _ptr(W1), _ptr(W2), _ptr(ssum),
+                  ctx.p_drop, _ptr(xsave), _ptr(y1save), _ptr(z), _ptr(dz), D, _ptr(dW1), _ptr(db1), _ptr(dW2),
+                  _ptr(db2), _ptr(dRu), _ptr(ws), ws.numel(), _stream())
+        return None, None, None, None, None, dRu, dW1, db1, dW2, db2, None, None, None
+
+
+def sensor_stage(src, times, lengths, ts, ssum, R_u, W1, b1, W2, b2, shp, p_drop=0.0, seed=0):
+    return _SensorStage.apply(src.contiguous(), times.contiguous(), lengths.contiguous(), ts, ssum,
+                              R_u.contiguous(), W1, b1, W2, b2, shp, p_drop, seed)
+
+
+# ------------------------------------------------------------------------------------------------
+# dense layers
+# ------------------------------------------------------------------------------------------------
+
+class _Linear(torch.autograd.Function):
+    """y = act(x W^T + b) through rd_linear_fwd; backward through rd_linear_bwd_{input,weight}."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act):
+        _check(x, W, b)
+        N, K = W.shape
+        x2 = x.reshape(-1, K)
+        M = x2.shape[0]
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        _lib.call("rd_linear_fwd", M, N, K, _ptr(x2), K, _ptr(W), _ptr(b), _ptr(y), N, int(act), _stream())
+        ctx.act = int(act)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x2, W, y if act else None)
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W, y = ctx.saved_tensors
+        N, K = W.shape
+        M = x2.shape[0]
+        dy2 = dy.reshape(M, N)
+        if ctx.act:
+            dy2 = dy2 * (y > 0)          # ReLU gate (elementwise glue)
+        dy2 = dy2.contiguous()
+        dev = dy.device
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=torch.float32, device=dev)
+            _lib.call("rd_linear_bwd_input", M, N, K, _ptr(dy2), N, _ptr(W), _ptr(dx), K, _stream())
+            dx = dx.view(ctx.xshape)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dW = torch.empty((N, K), dtype=torch.float32, device=dev)
+            db = torch.empty((N,), dtype=torch.float32, device=dev) if ctx.has_bias else None
+            nbytes = _lib.load().rd_linear_bwd_weight_workspace_bytes(M, N, K)
+            ws = _workspace(nbytes, dev)
+            _lib.call("rd_linear_bwd_weight", M, N, K, _ptr(dy2), N, _ptr(x2), K, _ptr(dW), _ptr(db),
+                      _ptr(ws), ws.numel(), _stream())
+        return dx, dW, db, None
+
+
+def linear(x, W, b=None, act=0):
+    return _Linear.apply(x.contiguous(), W.contiguous(), None if b is None else b.contiguous(), act)
+
+
+# ------------------------------------------------------------------------------------------------
+# stand-alone graph operators (PyG operator API: one graph per call)
+# ------------------------------------------------------------------------------------------------
+
+def edge_softmax_list(edge_index, edge_weights, n_nodes, norm_row=1):
+    """PyG softmax over an explicit edge list; returns (gamma_e [E], ssum [n_nodes])."""
+    ei = edge_index.contiguous()
+    w = edge_weights.contiguous()
+    _check(ei, dtype=torch.int64)
+    _check(w)
+    E = ei.shape[1]
+    gamma = torch.empty((E,), dtype=torch.float32, device=w.device)
+    ssum = torch.empty((n_nodes,), dtype=torch.float32, device=w.device)
+    _lib.call("rd_edge_softmax_list", int(n_nodes), int(E), _ptr(ei), ei.stride(0), int(norm_row),
+              _ptr(w), _ptr(gamma), _ptr(ssum), _stream())
+    return gamma, ssum
+
+
+class _Aggregate(torch.autograd.Function):
+    """out = gamma^T V (+ skip): source-valued aggregate with fixed (non-learned) coefficients."""
+
+    @staticmethod
+    def forward(ctx, gamma, V, skip):
+        _check(gamma, V, skip)
+        N, C = V.shape
+        out = torch.empty_like(V)
+        _lib.call("rd_aggregate_fwd", N, C, _ptr(gamma), _ptr(V), _ptr(skip), _ptr(out), _stream())
+        ctx.save_for_backward(gamma)
+        ctx.has_skip = skip is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (gamma,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        N, C = dout.shape
+        dV = torch.empty_like(dout)
+        _lib.call("rd_aggregate_bwd", N, C, _ptr(gamma), _ptr(dout), _ptr(dV), _stream())
+        return None, dV, (dout if ctx.has_skip else None)
+
+
+def aggregate(gamma, V, skip=None):
+    return _Aggregate.apply(gamma.contiguous(), V.contiguous(), None if skip is None else skip.contiguous())

@@ -84,23 +84,29 @@ def make_structure(cfg, kind="ones", seed=0):
     return torch.from_numpy(a.astype(np.float32))
 
 
+def param_values(name, shape, seed=0, scale=1.0):
+    """Reproducible values for the parameter called `name`, keyed by (seed, crc32(name)) so they
+    do not depend on registration order: U(-b, b) with b = scale/sqrt(fan_in) for matrices
+    (fan_in = last dim), U(-0.1, 0.1) for vectors, LayerNorm weights centred on 1."""
+    rng = np.random.default_rng([77_000 + seed, zlib.crc32(name.encode())])
+    shape = tuple(shape)
+    if len(shape) >= 2:
+        bound = scale / np.sqrt(shape[-1])
+        v = rng.uniform(-bound, bound, size=shape)
+    else:
+        v = rng.uniform(-0.1, 0.1, size=shape)
+        if "norm" in name and name.endswith("weight"):
+            v = v + 1.0
+    return torch.from_numpy(v.astype(np.float32))
+
+
 def fill_params_(module, seed=0, scale=1.0):
-    """Overwrite EVERY parameter of `module` with reproducible values keyed by (seed, crc32 of the
-    parameter's name) -- independent of registration order: U(-b, b) with b = scale/sqrt(fan_in) for matrices (fan_in = last dim), U(-0.1, 0.1)
-    for vectors, LayerNorm weights centred on 1.  Applied identically to the reference model
-    (oracle side) and to ours so both hold bit-identical weights without shipping a state_dict."""
+    """Overwrite EVERY parameter of `module` with `param_values(name, ...)`.  Applied identically
+    to the reference model (oracle side) and to ours, so both hold bit-identical weights without
+    shipping a state_dict."""
     with torch.no_grad():
         for name, p in module.named_parameters():
-            rng = np.random.default_rng([77_000 + seed, zlib.crc32(name.encode())])
-            shape = tuple(p.shape)
-            if p.dim() >= 2:
-                bound = scale / np.sqrt(shape[-1])
-                v = rng.uniform(-bound, bound, size=shape)
-            else:
-                v = rng.uniform(-0.1, 0.1, size=shape)
-                if "norm" in name and name.endswith("weight"):
-                    v = v + 1.0
-            p.copy_(torch.from_numpy(v.astype(np.float32)).to(p.device))
+            p.copy_(param_values(name, p.shape, seed, scale).to(p.device))
     return module
 
 

@@ -179,6 +179,21 @@ def operator_cases():
     print("operators    -> %s (%.1f KB)" % (os.path.basename(path), os.path.getsize(path) / 1024))
 
 
+def state_dict_surface():
+    """Names and shapes of the reference's state_dict per dataset config (checkpoint surface,
+    code/Raindrop.py:374,381).  Under the CPU shim `R_u` is a registered parameter."""
+    out = {}
+    for cfg_name in ("TINY", "P19", "P12", "PAM"):
+        cfg = synth.make_config(cfg_name)
+        model = ref_loader.build_raindrop_v2(cfg, synth.make_structure(cfg, "ones"))
+        out[cfg_name] = {k: list(v.shape) for k, v in model.state_dict().items()}
+        del model
+    path = os.path.join(HERE, "state_dict_surface.json")
+    with open(path, "w") as fh:
+        json.dump(out, fh, indent=0, sort_keys=True)
+    print("state_dict   -> %s" % os.path.basename(path))
+
+
 if __name__ == "__main__":
     assert ref_loader.available(), "needs the reference tree (build container only)"
     torch.manual_seed(0)
@@ -186,6 +201,8 @@ if __name__ == "__main__":
     only = sys.argv[1:]
     if not only or "operators" in only:
         operator_cases()
+    if not only or "state_dict" in only:
+        state_dict_surface()
     for case in MODEL_CASES:
         if not only or case[0] in only:
             model_case(*case)

@@ -1,0 +1,60 @@
+"""CPU: the C-ABI library builds, loads, and exports exactly what include/raindrop_hip.h declares
+(no compute calls -- there is no GPU here)."""
+import os
+import re
+
+import pytest
+
+from raindrop_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "raindrop_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rd_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        from raindrop_amd import build
+        build.build(verbose=False)
+    return _lib.load()
+
+
+def test_header_and_binding_agree():
+    assert _declared() == sorted(_lib.SIGNATURES)
+
+
+def test_every_declared_symbol_is_exported(lib):
+    for name in _declared():
+        assert hasattr(lib, name), name
+
+
+def test_identity(lib):
+    assert lib.rd_version() == 1
+    assert lib.rd_arch() == b"gfx950"
+
+
+def test_argument_errors_are_reported_before_launch(lib):
+    # NULL tensors / bad dims must come back as RD_EINVAL with a message, without touching a GPU
+    rc = lib.rd_linear_fwd(4, 0, 8, None, 8, None, None, None, 8, 0, None)
+    assert rc == -1 and b"bad dims" in lib.rd_last_error()
+    rc = lib.rd_edge_softmax(0, None, None, None, None)
+    assert rc == -1
+    shp = _lib.shape(2, 5, 3, 4)
+    import ctypes
+    assert lib.rd_msgpass_workspace_bytes(ctypes.byref(shp)) > 0
+    rc = lib.rd_msgpass_fwd(ctypes.byref(shp), *([None] * 7), 0.0, 0, *([None] * 3), 12, None, 0, None)
+    assert rc == -1 and b"NULL" in lib.rd_last_error()
+
+
+def test_product_path_fails_loudly_without_device():
+    import torch
+    from raindrop_amd import ops
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.RaindropHipError):
+        ops.linear(torch.zeros(2, 4), torch.zeros(3, 4), torch.zeros(3))

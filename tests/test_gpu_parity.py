@@ -1,0 +1,183 @@
+"""GPU: parity of the HIP path (through the C-ABI) against the oracle and the golden fixtures.
+Tolerances: integer / boolean work bit-exact; fp32 logits within 1e-4 abs (north-star bound;
+in practice ~1e-6); gradients within 1e-3 of their own max-norm."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import restatement as O2
+from raindrop_amd import synth
+from tests.helpers import MODEL_CASES, build_ours, case_inputs, golden_grad, load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.mark.parametrize("F,kind", [(1, "ones"), (5, "sparse"), (17, "ones"), (34, "sparse"), (36, "ones"),
+                                    (64, "sparse"), (256, "sparse")])
+def test_graph_build_bit_exact(F, kind):
+    from raindrop_amd import ops
+    rng = np.random.default_rng(F)
+    a = np.ones((F, F), np.float32) if kind == "ones" else \
+        (rng.random((F, F)) * (rng.random((F, F)) < 0.3)).astype(np.float32)
+    adj, ei, ew = ops.graph_build(torch.from_numpy(a).to(DEV))
+    ei_ref, ew_ref = O2.build_graph(a)
+    assert np.array_equal(ei.cpu().numpy(), ei_ref)
+    assert np.array_equal(ew.cpu().numpy(), ew_ref)
+    patched = a.copy(); patched[np.arange(F), np.arange(F)] = 1
+    assert np.array_equal(adj.cpu().numpy(), patched)
+    gamma, ssum = ops.edge_softmax_dense(adj)
+    g_ref, s_ref = O2.aggregate_coefficients(a)
+    assert np.abs(gamma.cpu().numpy() - g_ref.numpy()).max() < 1e-6
+    assert np.abs(ssum.cpu().numpy() - s_ref.numpy()).max() < 1e-6
+    # list form agrees with the dense form
+    ge, ss = ops.edge_softmax_list(ei, ew, F)
+    assert np.abs(ss.cpu().numpy() - s_ref.numpy()).max() < 1e-6
+    assert np.abs(ge.cpu().numpy() - g_ref.numpy()[ei_ref[0], ei_ref[1]]).max() < 1e-6
+
+
+@pytest.mark.parametrize("cfg_name,B", [("TINY", 3), ("P19", 33), ("PAM", 2)])
+def test_pe_and_mask(cfg_name, B):
+    from raindrop_amd.models_rd import PositionalEncodingTF
+    from raindrop_amd import _lib, ops
+    import ctypes
+    cfg = synth.make_config(cfg_name)
+    b = synth.make_batch(cfg, B, seed=11)
+    pe = PositionalEncodingTF(16, cfg["max_len"], 100)(b["times"].to(DEV))
+    ref = O2.positional_encoding(b["times"], cfg["max_len"])
+    assert np.abs(pe.cpu().numpy() - ref.numpy()).max() < 2e-6       # sin/cos within a few ulp
+    shp = _lib.shape(B, cfg["max_len"], cfg["d_inp"], 4)
+    z = torch.zeros(cfg["max_len"], B, cfg["d_inp"] * 4 + 16, device=DEV)
+    mask = torch.zeros(B, cfg["max_len"], dtype=torch.bool, device=DEV)
+    times_d, len_d, ts_d = b["times"].to(DEV), b["lengths"].to(DEV), ops.timescales(cfg["max_len"]).to(DEV)
+    _lib.call("rd_pe_mask", ctypes.byref(shp), ops._ptr(times_d), ops._ptr(len_d), ops._ptr(ts_d),
+              ops._ptr(z), ops._ptr(mask), ops._stream())
+    assert np.array_equal(mask.cpu().numpy(), O2.padding_mask(b["lengths"].numpy(), cfg["max_len"]))
+    assert float(z[:, :, : cfg["d_inp"] * 4].abs().max()) == 0.0     # message-passing columns untouched
+
+
+@pytest.mark.parametrize("M,N,K,act", [(1, 1, 1, 0), (7, 5, 3, 1), (64, 64, 32, 0), (130, 186, 186, 1),
+                                       (1000, 456, 152, 0), (257, 34, 6, 0), (513, 272, 152, 1)])
+def test_linear_fwd_bwd(M, N, K, act):
+    from raindrop_amd import ops
+    rng = np.random.default_rng(M * 7 + N)
+    x = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).requires_grad_(True)
+    W = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).requires_grad_(True)
+    b = torch.from_numpy(rng.standard_normal((N,)).astype(np.float32)).requires_grad_(True)
+    dy = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32))
+    y_ref = torch.nn.functional.linear(x, W, b)
+    y_ref = torch.relu(y_ref) if act else y_ref
+    gx, gW, gb = torch.autograd.grad(y_ref, [x, W, b], dy)
+    xd, Wd, bd = (t.detach().to(DEV).requires_grad_(True) for t in (x, W, b))
+    y = ops.linear(xd, Wd, bd, act)
+    hx, hW, hb = torch.autograd.grad(y, [xd, Wd, bd], dy.to(DEV))
+    assert _rel(y.detach().cpu().numpy(), y_ref.detach().numpy()) < 1e-5
+    assert _rel(hx.cpu().numpy(), gx.numpy()) < 1e-5
+    assert _rel(hW.cpu().numpy(), gW.numpy()) < 2e-5
+    assert _rel(hb.cpu().numpy(), gb.numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("cfg_name,B,kind", [("TINY", 1, "sparse"), ("TINY", 5, "ones"), ("P19", 9, "sparse"),
+                                             ("P12", 3, "ones")])
+def test_sensor_stage_vs_oracle(cfg_name, B, kind):
+    """Observation embedding + both Observation_progation layers + PE concat, forward and backward,
+    against the faithful (per-sample, per-edge) restatement of the reference."""
+    from raindrop_amd import _lib, ops
+    cfg = synth.make_config(cfg_name)
+    gs = synth.make_structure(cfg, kind)
+    b = synth.make_batch(cfg, B, seed=21)
+    T, F, d = cfg["max_len"], cfg["d_inp"], 4
+    K = T * d
+    names = ["R_u", "ob_propagation.lin_value.weight", "ob_propagation.lin_value.bias",
+             "ob_propagation_layer2.lin_value.weight", "ob_propagation_layer2.lin_value.bias"]
+    shapes = [(1, F * d), (K, K), (K,), (K, K), (K,)]
+    p = {n: synth.param_values(n, s, seed=5).requires_grad_(True) for n, s in zip(names, shapes)}
+    # oracle: faithful per-edge evaluation of just this stage
+    h = torch.relu(torch.repeat_interleave(b["src"][:, :, :F], d, dim=-1) * p["R_u"])
+    ei_np, ew_np = O2.build_graph(gs.numpy())
+    ei, ew = torch.from_numpy(ei_np), torch.from_numpy(ew_np)
+    cols = []
+    for u in range(B):
+        x = h[:, u, :].reshape(T, F, d).permute(1, 0, 2).reshape(F, K)
+        x, a1 = O2.observation_propagation(x, ei, ew, p[names[1]], p[names[2]])
+        x, _ = O2.observation_propagation(x, ei, a1.squeeze(-1), p[names[3]], p[names[4]])
+        cols.append(x.view(F, T, d).permute(1, 0, 2).reshape(T, F * d))
+    out_ref = torch.stack(cols, dim=1)
+    dz = torch.from_numpy(np.random.default_rng(3).standard_normal((T, B, F * d + 16)).astype(np.float32))
+    g_ref = torch.autograd.grad(out_ref, [p[n] for n in names], dz[:, :, : F * d])
+    # device
+    pd = {n: t.detach().to(DEV).requires_grad_(True) for n, t in p.items()}
+    adj, _, _ = ops.graph_build(gs.to(DEV))
+    _, ssum = ops.edge_softmax_dense(adj)
+    shp = _lib.shape(B, T, F, d)
+    z, mask = ops.sensor_stage(b["src"].to(DEV), b["times"].to(DEV), b["lengths"].to(DEV),
+                               ops.timescales(T).to(DEV), ssum, pd[names[0]], pd[names[1]], pd[names[2]],
+                               pd[names[3]], pd[names[4]], shp)
+    g = torch.autograd.grad(z, [pd[n] for n in names], dz.to(DEV))
+    assert np.abs(z[:, :, : F * d].detach().cpu().numpy() - out_ref.detach().numpy()).max() < 2e-5
+    pe_ref = O2.positional_encoding(b["times"], T)
+    assert np.abs(z[:, :, F * d:].detach().cpu().numpy() - pe_ref.numpy()).max() < 2e-6
+    assert np.array_equal(mask.cpu().numpy(), O2.padding_mask(b["lengths"].numpy(), T))
+    for n, a, r in zip(names, g, g_ref):
+        assert _rel(a.cpu().numpy(), r.numpy()) < 1e-4, n
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_model_vs_golden(name):
+    """Whole Raindrop_v2 forward + CE + backward against the fixtures produced by the reference."""
+    g, meta = load_golden(name)
+    cfg, gs, batch = case_inputs(meta)
+    m = build_ours(cfg, gs, DEV, meta["param_seed"])
+    m.train()
+    dv = {k: (None if v is None else v.to(DEV)) for k, v in batch.items()}
+    logits, distance, third = m(dv["src"], dv["static"], dv["times"], dv["lengths"])
+    assert third is None and float(distance) == float(g["distance"]) == 0.0
+    loss = torch.nn.functional.cross_entropy(logits, dv["y"])
+    loss.backward()
+    assert np.abs(logits.detach().cpu().numpy() - g["logits"]).max() < 1e-4
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    params = dict(m.named_parameters())
+    live = [str(x) for x in g["live"]]
+    assert sorted(n for n, p in params.items() if p.grad is not None) == sorted(live)
+    for n in live:
+        exp, got = golden_grad(g, n, params[n].grad)
+        assert _rel(got, exp) < 1e-3, n
+        gn = float(g["gradnorm/" + n])
+        assert abs(params[n].grad.double().norm().item() - gn) <= 1e-3 * gn + 1e-12, n
+    m.eval()
+    with torch.no_grad():
+        le, _, _ = m(dv["src"], dv["static"], dv["times"], dv["lengths"])
+    assert np.abs(le.cpu().numpy() - g["logits_eval"]).max() < 1e-4
+    # graph artefacts the model cached are the reference's, bit for bit
+    gr = m._graph(torch.device(DEV))
+    assert np.array_equal(gr["edge_index"].cpu().numpy(), g["edge_index"])
+    assert np.array_equal(gr["edge_weights"].cpu().numpy(), g["edge_weights"])
+
+
+def test_operator_goldens_on_device():
+    import os
+    from raindrop_amd.Ob_propagation import Observation_progation
+    from raindrop_amd.transformer_conv import TransformerConv
+    from tests.helpers import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "operators.npz"))
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    op = Observation_progation(20, 20, n_nodes=6, ob_dim=4, heads=1)
+    synth.fill_params_(op, seed=11)
+    op = op.to(DEV)
+    ei, ew = O2.build_graph(g["obp_adj"])
+    y, (ei_o, alpha) = op(t(g["obp_x"]), p_t=t(g["obp_p_t"]), edge_index=t(ei), edge_weights=t(ew),
+                          use_beta=False, edge_attr=None, return_attention_weights=True)
+    assert np.abs(y.detach().cpu().numpy() - g["obp_y"]).max() < 1e-5
+    assert np.array_equal(alpha.cpu().numpy(), g["obp_alpha"]) and np.array_equal(ei_o.cpu().numpy(), g["obp_ei"])
+    tc = TransformerConv(9, 12, heads=1)
+    synth.fill_params_(tc, seed=12)
+    tc = tc.to(DEV)
+    ei2, ew2 = O2.build_graph(g["tc_adj"])
+    y2, (_, a2) = tc(t(g["tc_x"]), edge_index=t(ei2), edge_weights=t(ew2), edge_attr=None,
+                     return_attention_weights=True)
+    assert np.abs(y2.detach().cpu().numpy() - g["tc_y"]).max() < 1e-5
+    assert np.abs(a2.cpu().numpy() - g["tc_alpha"]).max() < 1e-6
