@@ -1,0 +1,228 @@
+#!/usr/bin/env python
+"""Benchmark of the Raindrop hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 256] [--config P19]
+
+Step = one training step of `Raindrop_v2` on one synthetic P19-shaped batch of B=256 samples PER
+GPU, inputs resident in HBM: forward + CrossEntropyLoss + backward (train mode, dropout 0.2)
+[+ flat-gradient all-reduce over RCCL when N>1] + Adam update.  `value` is whole-job samples/s.
+For N>1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.
+
+Extra objects on the JSON line (rank 0):
+  roofline     -- the fused message-passing kernels (K1, forward+backward) timed with HIP events on
+                  the launch stream, against the HBM roofline; algorithmic bytes per SURVEY.md 8(d):
+                  B*32*F*K + 24*K^2 per fwd+bwd.
+  cpu_baseline -- the CPU port of the reference algorithm (oracle/restatement.py, per-sample /
+                  per-edge order) timed on this host on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256, help="samples per GPU")
+    ap.add_argument("--config", default="P19")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optimizer", action="store_true", help="time fwd+CE+bwd(+allreduce) only")
+    ap.add_argument("--cpu-reps", type=int, default=2)
+    return ap.parse_args()
+
+
+def k1_roofline(model, cfg, batch, reps=20):
+    """Time K1 forward and backward in isolation (same tensors the training step uses) with HIP
+    events recorded on the stream the kernels are launched on (torch's current stream)."""
+    from raindrop_amd import _lib, ops
+    dev = batch["src"].device
+    B = batch["src"].shape[1]
+    T, F, d = cfg["max_len"], cfg["d_inp"], cfg["d_ob"]
+    K = T * d
+    g = model._graph(dev)
+    shp = _lib.shape(B, T, F, d)
+    args = (batch["src"], batch["times"], batch["lengths"], model.pos_encoder.timescales(dev), g["ssum"],
+            model.R_u, model.ob_propagation.lin_value.weight, model.ob_propagation.lin_value.bias,
+            model.ob_propagation_layer2.lin_value.weight, model.ob_propagation_layer2.lin_value.bias, shp,
+            0.2, 1234)
+    dz = torch.randn(T, B, F * d + 16, device=dev)
+    fwd_ms, bwd_ms = [], []
+    for i in range(reps + 3):
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        z, _ = ops.sensor_stage(*args)
+        e1.record()
+        torch.autograd.grad(z, [model.R_u, model.ob_propagation.lin_value.weight], dz, allow_unused=True)
+        e2.record()
+        torch.cuda.synchronize()
+        if i >= 3:
+            fwd_ms.append(e0.elapsed_time(e1))
+            bwd_ms.append(e1.elapsed_time(e2))
+    fwd = sorted(fwd_ms)[len(fwd_ms) // 2]
+    bwd = sorted(bwd_ms)[len(bwd_ms) // 2]
+    bytes_fwd = B * 12 * F * K + 8 * (K * K + K)
+    bytes_bwd = B * 20 * F * K + 16 * K * K
+    alg = bytes_fwd + bytes_bwd
+    t = (fwd + bwd) * 1e-3
+    achieved = alg / t / 1e9
+    return {"bound": "hbm", "kernel": "K1 message passing fwd+bwd (rd_msgpass_fwd + rd_msgpass_bwd)",
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "algorithmic_bytes": alg, "fwd_us": round(fwd * 1e3, 2), "bwd_us": round(bwd * 1e3, 2),
+            "fwd_frac": round(bytes_fwd / (fwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "bwd_frac": round(bytes_bwd / (bwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+
+
+def usable_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota (a container
+    can report 256 CPUs and be throttled to 8; an OpenMP team sized by cpu_count() then crawls)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(cfg, gs, B, reps, budget_s=25.0):
+    """CPU port of the reference path in the reference's own evaluation order (per-sample loop,
+    per-edge lin_value) -- oracle/restatement.py faithful=True -- forward + CE + backward, on a
+    sample bounded to about `budget_s` seconds of CPU work."""
+    from oracle import restatement as O2
+    from raindrop_amd import synth
+    threads = usable_cores()
+    torch.set_num_threads(threads)
+    names = synth.live_parameter_names(cfg)
+    import json as _json
+    surf = _json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_surface.json")))[cfg["name"]]
+    p = {n: synth.param_values(n, surf[n], seed=0).requires_grad_(True) for n in names}
+    # probe with 8 samples, then size the timed batch so the whole leg stays inside the budget
+    probe = synth.make_batch(cfg, 8, seed=0)
+    O2.step_fwd_bwd(p, cfg, probe, gs, faithful=True)
+    t0 = time.perf_counter()
+    O2.step_fwd_bwd(p, cfg, probe, gs, faithful=True)
+    per_sample = (time.perf_counter() - t0) / 8
+    B = int(max(8, min(B, budget_s / max(per_sample, 1e-6) / (reps + 1))))
+    batch = synth.make_batch(cfg, B, seed=0)
+    times = []
+    for i in range(reps + 1):
+        t0 = time.perf_counter()
+        O2.step_fwd_bwd(p, cfg, batch, gs, faithful=True)
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": round(B / t, 2), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": "%d x fwd+CE+bwd of one %s-shaped batch of %d samples (after 1 warm-up), "
+                      "reference evaluation order (per-sample loop, per-edge lin_value), dropout off"
+                      % (reps, cfg["name"], B)}
+
+
+def main():
+    import faulthandler
+    faulthandler.dump_traceback_later(900, exit=True)      # never hang a GPU box silently
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                             "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from raindrop_amd import dp, synth
+    from raindrop_amd.models_rd import Raindrop_v2
+
+    cfg = synth.make_config(args.config)
+    gs = synth.make_structure(cfg, "ones")                       # code/Raindrop.py:212
+    torch.manual_seed(1)                                          # code/Raindrop.py:58
+    kw = {} if cfg["static"] else {"static": False}
+    model = Raindrop_v2(cfg["d_inp"], cfg["d_model"], cfg["nhead"], cfg["nhid"], cfg["nlayers"], cfg["dropout"],
+                        cfg["max_len"], cfg["d_static"], cfg["MAX"], 0.5, cfg["aggreg"], cfg["n_classes"], gs,
+                        sensor_wise_mask=False, **kw).to(dev)
+    if world > 1:
+        dp.broadcast_parameters(model, src=0)
+    model.train()
+    B = args.batch
+    batch = synth.make_batch(cfg, B, seed=100 + rank)             # each rank its own shard (weak scaling)
+    batch = {k: (None if v is None else v.to(dev)) for k, v in batch.items()}
+    live = synth.live_parameter_names(cfg)
+    named = dict(model.named_parameters())
+    flat = dp.FlatGradAllReduce([(n, named[n]) for n in live], n_buckets=2)
+    opt = torch.optim.Adam([named[n] for n in live], lr=1e-4, fused=True)   # code/Raindrop.py:256
+    criterion = torch.nn.CrossEntropyLoss()
+
+    def step():
+        flat.zero()
+        out, _, _ = model(batch["src"], batch["static"], batch["times"], batch["lengths"])
+        loss = criterion(out, batch["y"])
+        loss.backward()
+        flat.finish()
+        if not args.no_optimizer:
+            opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(loss).item()
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        line = {
+            "metric": "samples/sec fwd+bwd, P19 34-sensor batch=256; % HBM roofline on msg-pass kernel",
+            "value": round(world * B * args.steps / elapsed, 1), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%s-shaped synthetic batch (F=%d sensors, T=%d steps, d_ob=4, K=%d), "
+                                   "B=%d samples per GPU, Setting-1 (global_structure=ones); step = fwd+CE+bwd"
+                                   "%s%s, train mode dropout %.1f" % (
+                                       cfg["name"], cfg["d_inp"], cfg["max_len"], cfg["max_len"] * 4, B,
+                                       "+RCCL flat-grad all-reduce" if world > 1 else "",
+                                       "" if args.no_optimizer else "+Adam", cfg["dropout"]),
+                       "global_batch": world * B, "parallelism": "dp%d" % world,
+                       "grad_allreduce_bytes": flat.nbytes()},
+        }
+        if world == 1:
+            line["roofline"] = k1_roofline(model, cfg, batch)
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(cfg, gs, B, args.cpu_reps)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
