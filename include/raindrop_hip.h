@@ -124,6 +124,44 @@ int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* R_u, const 
                    float* dW2, float* db2, float* dR_u, void* workspace, size_t workspace_bytes,
                    void* stream);
 
+/* ---- a15/a16: temporal self-attention encoder (kernels K2/K3) and masked mean (K5) --------- */
+
+/* Parameters of one nn.TransformerEncoderLayer(D, nhead, nhid) (code/models_rd.py:235-237),
+ * names as in its state_dict: self_attn.in_proj_{weight[3D,D],bias}, self_attn.out_proj.*,
+ * linear1.{weight[nhid,D],bias}, linear2.{weight[D,nhid],bias}, norm1.*, norm2.* */
+typedef struct rd_encoder_weights {
+  const float *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b, *lin1_w, *lin1_b, *lin2_w, *lin2_b,
+      *norm1_w, *norm1_b, *norm2_w, *norm2_b;
+} rd_encoder_weights;
+typedef struct rd_encoder_grads {
+  float *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b, *lin1_w, *lin1_b, *lin2_w, *lin2_b,
+      *norm1_w, *norm1_b, *norm2_w, *norm2_b;
+} rd_encoder_grads;
+
+size_t rd_encoder_layer_saved_bytes(const rd_shape* s);      /* activations kept for backward */
+size_t rd_encoder_layer_workspace_bytes(const rd_shape* s);  /* scratch, fwd and bwd */
+
+/* One post-norm encoder layer, torch semantics (torch/nn/modules/transformer.py:799-983, used at
+ * code/models_rd.py:358): x,y [T,B,D] with D = F*d_ob + d_pe; mask [B,T] bytes (1 = padded key);
+ * y = LN2(x1 + drop(W2 drop(relu(W1 x1)))) with x1 = LN1(x + drop(out_proj(MHA(x)))).
+ * The four dropout sites use Philox masks keyed by (seed, site, layer). */
+int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const float* x, const uint8_t* mask,
+                         const rd_encoder_weights* w, float p_drop, uint64_t seed, float* y,
+                         void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes,
+                         void* stream);
+/* Backward: dy -> dx and all 12 parameter gradients (overwritten). */
+int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const float* x, const uint8_t* mask,
+                         const rd_encoder_weights* w, float p_drop, uint64_t seed, const void* saved,
+                         size_t saved_bytes, const float* dy, float* dx, const rd_encoder_grads* g,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* code/models_rd.py:366-367,379: out[b, :D] = sum_t r[t,b,:] * (1 - mask[b,t]) / (lengths[b] + 1);
+ * out has row stride ldo (so it can be the left block of the [agg | emb] head input). */
+int rd_masked_mean_fwd(const rd_shape* s, int32_t D, const float* r, const uint8_t* mask,
+                       const int64_t* lengths, float* out, int32_t ldo, void* stream);
+int rd_masked_mean_bwd(const rd_shape* s, int32_t D, const float* dout, int32_t ldo,
+                       const uint8_t* mask, const int64_t* lengths, float* dr, void* stream);
+
 /* ---- generic dense pieces (used by the temporal encoder, the head and the large-K path) ---- */
 
 /* y[M,N] = act(x[M,K] W[N,K]^T + b)   (torch.nn.functional.linear; act: 0 none, 1 relu). */

@@ -22,7 +22,15 @@ class RaindropHipError(RuntimeError):
     pass
 
 
+class RdEncoderPtrs(ctypes.Structure):
+    """Mirror of rd_encoder_weights / rd_encoder_grads (12 device pointers)."""
+    FIELDS = ("in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "lin1_w", "lin1_b", "lin2_w",
+              "lin2_b", "norm1_w", "norm1_b", "norm2_w", "norm2_b")
+    _fields_ = [(n, c_void_p) for n in FIELDS]
+
+
 _P = c_void_p
+_ENC = POINTER(RdEncoderPtrs)
 _SHP = POINTER(RdShape)
 
 # name -> (restype, argtypes); every symbol the header declares appears here, and
@@ -42,6 +50,14 @@ SIGNATURES = {
                        + [c_int32, _P, c_size_t, _P]),
     "rd_msgpass_bwd": (c_int32, [_SHP] + [_P] * 5 + [c_float] + [_P] * 4 + [c_int32] + [_P] * 5
                        + [_P, c_size_t, _P]),
+    "rd_encoder_layer_saved_bytes": (c_size_t, [_SHP]),
+    "rd_encoder_layer_workspace_bytes": (c_size_t, [_SHP]),
+    "rd_encoder_layer_fwd": (c_int32, [_SHP, c_int32, _P, _P, _ENC, c_float, ctypes.c_uint64, _P, _P, c_size_t,
+                                        _P, c_size_t, _P]),
+    "rd_encoder_layer_bwd": (c_int32, [_SHP, c_int32, _P, _P, _ENC, c_float, ctypes.c_uint64, _P, c_size_t, _P, _P,
+                                        _ENC, _P, c_size_t, _P]),
+    "rd_masked_mean_fwd": (c_int32, [_SHP, c_int32, _P, _P, _P, _P, c_int32, _P]),
+    "rd_masked_mean_bwd": (c_int32, [_SHP, c_int32, _P, c_int32, _P, _P, _P, _P]),
     "rd_linear_fwd": (c_int32, [c_int32, c_int32, c_int32, _P, c_int32, _P, _P, _P, c_int32, c_int32, _P]),
     "rd_linear_bwd_input": (c_int32, [c_int32, c_int32, c_int32, _P, c_int32, _P, _P, c_int32, _P]),
     "rd_linear_bwd_weight_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),

@@ -46,6 +46,8 @@ struct GemmArgs {
   const float* posmask; long pm_m;               // * (posmask[m*pm_m + n] > 0)
   const float* residual; long res_m;             // + residual[m*res_m + n]
   int relu;
+  float cscale;                   // * cscale when != 0 (applied with posmask: dropout keep-scale in backward)
+  float drop_p; uint64_t drop_seed; uint32_t drop_site;   // Philox dropout on element m*N+n (after ReLU)
   // scatter == 1: rows are (b,f) pairs of a [B,F,K] tensor, columns (t,c); element goes to the
   // [T,B,ldz] layout z[(t*sB + b)*ldz + f*sd + c]   (code/models_rd.py:338-342)
   int scatter; int sB, sF, sd; long ldz;

@@ -13,6 +13,7 @@
 // summation-order rounding.  Within each 16-wide K chunk lane l consumes k = 4*(l>>4)+j on MFMA
 // step j for BOTH operands, so each lane fetches its four k values with one ds_read_b128.
 #include "rd_common.h"
+#include "rd_rng.h"
 
 namespace rd {
 
@@ -141,6 +142,10 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
           if (g.relu) v = fmaxf(v, 0.f);
           if (g.rowscale) v *= g.rowscale[m % g.rs_period];
           if (g.posmask) v = (g.posmask[(long)m * g.pm_m + n] > 0.f) ? v : 0.f;
+          if (g.cscale != 0.f) v *= g.cscale;
+          if (g.drop_p > 0.f)
+            v *= dropout_scale(g.drop_seed, g.drop_site, (uint64_t)m * g.N + n, g.drop_p,
+                               1.0f / (1.0f - g.drop_p));
           if (g.residual) v += g.residual[(long)m * g.res_m + n];
         }
         if (g.scatter && !raw) {

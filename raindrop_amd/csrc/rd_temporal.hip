@@ -1,0 +1,694 @@
+// rd_temporal.hip -- temporal self-attention stage (kernel families K2/K3/K5):
+//   * masked multi-head attention forward/backward (flash-style: scores never leave the CU),
+//   * residual-add + dropout + LayerNorm forward/backward,
+//   * masked mean over time forward/backward,
+//   * rd_encoder_layer_{fwd,bwd}: one post-norm nn.TransformerEncoderLayer as a chain of launches.
+//
+// Replaces nn.TransformerEncoder (code/models_rd.py:235-237,358; torch semantics in
+// torch/nn/modules/transformer.py:799-983 and F.multi_head_attention_forward): post-norm,
+// ReLU FFN, key-padding mask -> -inf, q.k scaled by 1/sqrt(head_dim), LayerNorm eps 1e-5,
+// dropout on attention probabilities / attention output / FFN hidden / FFN output; and the
+// masked mean of code/models_rd.py:366-367,379.
+//
+// All contractions use v_mfma_f32_16x16x4_f32 (exact fp32).  Sequence tiles are 64 steps; a
+// P19 sample (T=60) is a single tile, P12 (215) / PAM (600) loop over key tiles with an online
+// softmax, so the [T,T] score matrix only ever exists in LDS.
+#include <math.h>
+
+#include "rd_common.h"
+#include "rd_rng.h"
+
+namespace rd {
+namespace {
+
+constexpr int TS = 64;          // sequence tile (queries and keys)
+constexpr int LDP = TS + 4;     // row stride of the 64x64 score / probability tiles in LDS
+
+// acc[j] (16x16 tiles, j < NT) += A[16 x KK] * B[KK x 16*NT]
+// A(i,k) at a[i*a_si + k*a_sk], B(k,n) at b[k*b_sk + n*b_sn]; all LDS.  MFMA lane map: lane l
+// supplies A(i = l&15, k = k0 + (l>>4)) and B(k = k0 + (l>>4), n = l&15).
+template <int NT>
+__device__ __forceinline__ void mma_f32(f32x4 (&acc)[NT], const float* a, int a_si, int a_sk,
+                                        const float* b, int b_sk, int b_sn, int KK, int lane) {
+  const float* ap = a + (lane & 15) * a_si + (lane >> 4) * a_sk;
+  const float* bp = b + (lane >> 4) * b_sk + (lane & 15) * b_sn;
+  for (int k0 = 0; k0 < KK; k0 += 4) {
+    const float av = ap[k0 * a_sk];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[k0 * b_sk + 16 * j * b_sn], acc[j], 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ float group16_max(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+struct AttnArgs {
+  const float* qkv;      // [T,B,3D]
+  const uint8_t* mask;   // [B,T], 1 = padded key
+  float* out;            // fwd: attention output [T,B,D]; bwd: same tensor (read)
+  float* lse;            // [B,H,T] log-sum-exp of the scaled, masked scores
+  const float* dout;     // bwd: grad of out [T,B,D]
+  float* dqkv;           // bwd: [T,B,3D]
+  float* delta;          // bwd: [B,H,T] rowsum(dout * out)
+  int T, B, D, H, hd;
+  float scale, p_drop; uint64_t seed; uint32_t site;
+};
+
+// rows [t0, t0+64) x cols [0, hd) of one head of q / k / v / out / dout -> LDS [64][ldh], zero padded
+__device__ __forceinline__ void load_head_tile(float* dst, int ldh, int hdp, const float* base,
+                                               long row_stride, int t0, int T, int hd, int tid) {
+  for (int idx = tid; idx < TS * hdp; idx += 256) {
+    const int r = idx / hdp, c = idx - r * hdp;
+    const int t = t0 + r;
+    dst[r * ldh + c] = (t < T && c < hd) ? base[(long)t * row_stride + c] : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: grid (q tiles, B*H).  Wave w owns query rows 16w..16w+15 of the tile.
+// ------------------------------------------------------------------------------------------------
+template <int NTH>
+__global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int HDP = 16 * NTH, LDH = HDP + 4;
+  float* Qs = smem;
+  float* Ks = Qs + TS * LDH;
+  float* Vs = Ks + TS * LDH;
+  float* Ps = Vs + TS * LDH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int q0 = blockIdx.x * TS;
+  const long rs = (long)a.B * 3 * a.D;
+  const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
+  load_head_tile(Qs, LDH, HDP, qb, rs, q0, a.T, a.hd, tid);
+  float m_i[4], l_i[4];
+  f32x4 o[NTH];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { m_i[r] = -INFINITY; l_i[r] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < NTH; ++j) o[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float inv_keep = 1.0f / (1.0f - a.p_drop);
+
+  for (int k0 = 0; k0 < a.T; k0 += TS) {
+    __syncthreads();
+    load_head_tile(Ks, LDH, HDP, qb + a.D, rs, k0, a.T, a.hd, tid);
+    load_head_tile(Vs, LDH, HDP, qb + 2 * a.D, rs, k0, a.T, a.hd, tid);
+    __syncthreads();
+    f32x4 s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mma_f32<4>(s, Qs + wave * 16 * LDH, LDH, 1, Ks, 1, LDH, HDP, lane);   // S = Q K^T
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int key = k0 + 16 * j + (lane & 15);
+      const bool dead = key >= a.T || a.mask[(long)b * a.T + key];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[j][r] = dead ? -INFINITY : s[j][r] * a.scale;
+        mx[r] = fmaxf(mx[r], s[j][r]);
+      }
+    }
+    float alpha[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float mn = fmaxf(m_i[r], group16_max(mx[r]));
+      alpha[r] = (m_i[r] == -INFINITY) ? 0.f : expf(m_i[r] - mn);
+      m_i[r] = mn;
+    }
+    float rsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int key = k0 + 16 * j + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wave * 16 + 4 * (lane >> 4) + r;
+        float p = (s[j][r] == -INFINITY) ? 0.f : expf(s[j][r] - m_i[r]);
+        rsum[r] += p;
+        if (a.p_drop > 0.f)   // F.dropout on the attention probabilities (after the softmax sum)
+          p *= dropout_scale(a.seed, a.site, ((uint64_t)bh * a.T + (q0 + row)) * a.T + key, a.p_drop, inv_keep);
+        Ps[row * LDP + 16 * j + (lane & 15)] = p;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) l_i[r] = l_i[r] * alpha[r] + group16_sum(rsum[r]);
+#pragma unroll
+    for (int j = 0; j < NTH; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[j][r] *= alpha[r];
+    __syncthreads();
+    mma_f32<NTH>(o, Ps + wave * 16 * LDP, LDP, 1, Vs, LDH, 1, TS, lane);  // O += P V
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int q = q0 + wave * 16 + 4 * (lane >> 4) + r;
+    if (q >= a.T) continue;
+    const float inv = 1.0f / l_i[r];
+#pragma unroll
+    for (int j = 0; j < NTH; ++j) {
+      const int c = 16 * j + (lane & 15);
+      if (c < a.hd) a.out[((long)q * a.B + b) * a.D + h * a.hd + c] = o[j][r] * inv;
+    }
+    if ((lane & 15) == 0) a.lse[(long)bh * a.T + q] = m_i[r] + logf(l_i[r]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, dQ: grid (q tiles, B*H); also writes delta = rowsum(dout * out).
+// ------------------------------------------------------------------------------------------------
+template <int NTH>
+__global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int HDP = 16 * NTH, LDH = HDP + 4;
+  float* Qs = smem;
+  float* dOs = Qs + TS * LDH;
+  float* Ks = dOs + TS * LDH;
+  float* Vs = Ks + TS * LDH;
+  float* Ps = Vs + TS * LDH;
+  float* lse_s = Ps + TS * LDP;
+  float* dl_s = lse_s + TS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int q0 = blockIdx.x * TS;
+  const long rs = (long)a.B * 3 * a.D, ro = (long)a.B * a.D;
+  const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
+  const float* dob = a.dout + (long)b * a.D + h * a.hd;
+  const float* ob = a.out + (long)b * a.D + h * a.hd;
+  load_head_tile(Qs, LDH, HDP, qb, rs, q0, a.T, a.hd, tid);
+  load_head_tile(dOs, LDH, HDP, dob, ro, q0, a.T, a.hd, tid);
+  __syncthreads();
+  if (tid < TS) {
+    const int q = q0 + tid;
+    float d = 0.f, l = 0.f;
+    if (q < a.T) {
+      for (int c = 0; c < a.hd; ++c) d += dOs[tid * LDH + c] * ob[(long)q * ro + c];
+      l = a.lse[(long)bh * a.T + q];
+      a.delta[(long)bh * a.T + q] = d;
+    }
+    dl_s[tid] = d; lse_s[tid] = l;
+  }
+  f32x4 dq[NTH];
+#pragma unroll
+  for (int j = 0; j < NTH; ++j) dq[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float inv_keep = 1.0f / (1.0f - a.p_drop);
+  for (int k0 = 0; k0 < a.T; k0 += TS) {
+    __syncthreads();
+    load_head_tile(Ks, LDH, HDP, qb + a.D, rs, k0, a.T, a.hd, tid);
+    load_head_tile(Vs, LDH, HDP, qb + 2 * a.D, rs, k0, a.T, a.hd, tid);
+    __syncthreads();
+    f32x4 s[4], dp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[j] = s[j]; }
+    mma_f32<4>(s, Qs + wave * 16 * LDH, LDH, 1, Ks, 1, LDH, HDP, lane);     // S  = Q K^T
+    mma_f32<4>(dp, dOs + wave * 16 * LDH, LDH, 1, Vs, 1, LDH, HDP, lane);   // dP = dO V^T
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int key = k0 + 16 * j + (lane & 15);
+      const bool dead = key >= a.T || a.mask[(long)b * a.T + key];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wave * 16 + 4 * (lane >> 4) + r;
+        float ds = 0.f;
+        if (!dead && q0 + row < a.T) {
+          const float p = expf(s[j][r] * a.scale - lse_s[row]);
+          float g = dp[j][r];
+          if (a.p_drop > 0.f)
+            g *= dropout_scale(a.seed, a.site, ((uint64_t)bh * a.T + (q0 + row)) * a.T + key, a.p_drop, inv_keep);
+          ds = p * (g - dl_s[row]) * a.scale;
+        }
+        Ps[row * LDP + 16 * j + (lane & 15)] = ds;
+      }
+    }
+    __syncthreads();
+    mma_f32<NTH>(dq, Ps + wave * 16 * LDP, LDP, 1, Ks, LDH, 1, TS, lane);   // dQ += dS K
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int q = q0 + wave * 16 + 4 * (lane >> 4) + r;
+    if (q >= a.T) continue;
+#pragma unroll
+    for (int j = 0; j < NTH; ++j) {
+      const int c = 16 * j + (lane & 15);
+      if (c < a.hd) a.dqkv[((long)q * a.B + b) * 3 * a.D + h * a.hd + c] = dq[j][r];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, dK / dV: grid (key tiles, B*H).  Wave w owns key rows 16w..16w+15; scores are formed
+// directly transposed (S^T = K Q^T) so that both products below reduce over the query axis.
+// ------------------------------------------------------------------------------------------------
+template <int NTH>
+__global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int HDP = 16 * NTH, LDH = HDP + 4;
+  float* Ks = smem;
+  float* Vs = Ks + TS * LDH;
+  float* Qs = Vs + TS * LDH;
+  float* dOs = Qs + TS * LDH;
+  float* PTs = dOs + TS * LDH;       // (P o M)^T  [key][q]
+  float* DSTs = PTs + TS * LDP;      // dS^T       [key][q]
+  float* lse_s = DSTs + TS * LDP;
+  float* dl_s = lse_s + TS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int k0 = blockIdx.x * TS;
+  const long rs = (long)a.B * 3 * a.D, ro = (long)a.B * a.D;
+  const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
+  const float* dob = a.dout + (long)b * a.D + h * a.hd;
+  load_head_tile(Ks, LDH, HDP, qb + a.D, rs, k0, a.T, a.hd, tid);
+  load_head_tile(Vs, LDH, HDP, qb + 2 * a.D, rs, k0, a.T, a.hd, tid);
+  f32x4 dk[NTH], dv[NTH];
+#pragma unroll
+  for (int j = 0; j < NTH; ++j) { dk[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[j] = dk[j]; }
+  const float inv_keep = 1.0f / (1.0f - a.p_drop);
+  bool dead[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int key = k0 + wave * 16 + 4 * (lane >> 4) + r;
+    dead[r] = key >= a.T || a.mask[(long)b * a.T + min(key, a.T - 1)];
+  }
+  for (int q0 = 0; q0 < a.T; q0 += TS) {
+    __syncthreads();
+    load_head_tile(Qs, LDH, HDP, qb, rs, q0, a.T, a.hd, tid);
+    load_head_tile(dOs, LDH, HDP, dob, ro, q0, a.T, a.hd, tid);
+    if (tid < TS) {
+      const int q = q0 + tid;
+      lse_s[tid] = q < a.T ? a.lse[(long)bh * a.T + q] : 0.f;
+      dl_s[tid] = q < a.T ? a.delta[(long)bh * a.T + q] : 0.f;
+    }
+    __syncthreads();
+    f32x4 st[4], dpt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { st[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dpt[j] = st[j]; }
+    mma_f32<4>(st, Ks + wave * 16 * LDH, LDH, 1, Qs, 1, LDH, HDP, lane);     // S^T  = K Q^T
+    mma_f32<4>(dpt, Vs + wave * 16 * LDH, LDH, 1, dOs, 1, LDH, HDP, lane);   // dP^T = V dO^T
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int qi = 16 * j + (lane & 15);
+      const int q = q0 + qi;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int krow = wave * 16 + 4 * (lane >> 4) + r;
+        float pm = 0.f, ds = 0.f;
+        if (!dead[r] && q < a.T) {
+          const float p = expf(st[j][r] * a.scale - lse_s[qi]);
+          float keep = 1.f;
+          if (a.p_drop > 0.f)
+            keep = dropout_scale(a.seed, a.site, ((uint64_t)bh * a.T + q) * a.T + (k0 + krow), a.p_drop, inv_keep);
+          pm = p * keep;
+          ds = p * (dpt[j][r] * keep - dl_s[qi]) * a.scale;
+        }
+        PTs[krow * LDP + qi] = pm;
+        DSTs[krow * LDP + qi] = ds;
+      }
+    }
+    __syncthreads();
+    mma_f32<NTH>(dv, PTs + wave * 16 * LDP, LDP, 1, dOs, LDH, 1, TS, lane);  // dV += (P o M)^T dO
+    mma_f32<NTH>(dk, DSTs + wave * 16 * LDP, LDP, 1, Qs, LDH, 1, TS, lane);  // dK += dS^T Q
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int key = k0 + wave * 16 + 4 * (lane >> 4) + r;
+    if (key >= a.T) continue;
+#pragma unroll
+    for (int j = 0; j < NTH; ++j) {
+      const int c = 16 * j + (lane & 15);
+      if (c < a.hd) {
+        float* row = a.dqkv + ((long)key * a.B + b) * 3 * a.D + h * a.hd + c;
+        row[a.D] = dk[j][r];
+        row[2 * a.D] = dv[j][r];
+      }
+    }
+  }
+}
+
+template <int NTH>
+int launch_attn(const AttnArgs& a, int which, hipStream_t st) {
+  constexpr int LDH = 16 * NTH + 4;
+  dim3 grid(cdiv(a.T, TS), a.B * a.H);
+  size_t lds;
+  if (which == 0) {
+    lds = sizeof(float) * (3 * TS * LDH + TS * LDP);
+    hipFuncSetAttribute((const void*)k_attn_fwd<NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_attn_fwd<NTH>, grid, dim3(256), lds, st, a);
+    return check_launch("k_attn_fwd");
+  } else if (which == 1) {
+    lds = sizeof(float) * (4 * TS * LDH + TS * LDP + 2 * TS);
+    hipFuncSetAttribute((const void*)k_attn_bwd_dq<NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_attn_bwd_dq<NTH>, grid, dim3(256), lds, st, a);
+    return check_launch("k_attn_bwd_dq");
+  }
+  lds = sizeof(float) * (4 * TS * LDH + 2 * TS * LDP + 2 * TS);
+  hipFuncSetAttribute((const void*)k_attn_bwd_dkv<NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_attn_bwd_dkv<NTH>, grid, dim3(256), lds, st, a);
+  return check_launch("k_attn_bwd_dkv");
+}
+
+int dispatch_attn(const AttnArgs& a, int which, hipStream_t st) {
+  switch (cdiv(a.hd, 16)) {
+    case 1: return launch_attn<1>(a, which, st);
+    case 2: return launch_attn<2>(a, which, st);
+    case 3: return launch_attn<3>(a, which, st);
+    case 4: return launch_attn<4>(a, which, st);
+    case 5: return launch_attn<5>(a, which, st);
+    case 6: return launch_attn<6>(a, which, st);
+    default: return fail(RD_EUNSUPPORTED, "attention head_dim %d > 96 not built", a.hd);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// s = x + dropout(r);  y = LayerNorm(s) * g + b.   One wavefront per row; three passes over the
+// row (each lane re-reads only what it wrote), exact two-pass variance like torch.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_add_ln_fwd(const float* __restrict__ x, const float* __restrict__ r,
+                                                    const float* __restrict__ g, const float* __restrict__ bta,
+                                                    float* __restrict__ s_out, float* __restrict__ y,
+                                                    float* __restrict__ stats, int M, int D, float p_drop,
+                                                    uint64_t seed, uint32_t site) {
+  const int lane = threadIdx.x & 63;
+  const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float inv_keep = 1.0f / (1.0f - p_drop);
+  const float* xr = x + row * D; const float* rr = r + row * D;
+  float* sr = s_out + row * D; float* yr = y + row * D;
+  float sum = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    float rv = rr[c];
+    if (p_drop > 0.f) rv *= dropout_scale(seed, site, (uint64_t)row * D + c, p_drop, inv_keep);
+    const float s = xr[c] + rv;
+    sr[c] = s;
+    sum += s;
+  }
+  const float mean = wave_sum64(sum) / D;
+  float var = 0.f;
+  for (int c = lane; c < D; c += 64) { const float d = sr[c] - mean; var += d * d; }
+  const float rstd = rsqrtf(wave_sum64(var) / D + 1e-5f);
+  for (int c = lane; c < D; c += 64) yr[c] = (sr[c] - mean) * rstd * g[c] + bta[c];
+  if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+
+// backward: ds = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));  dr = ds o dropout mask;
+// per-block partial sums of dgamma = sum dy*xhat and dbeta = sum dy (64 rows per block).
+constexpr int LN_RPB = 64;
+__global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, const float* __restrict__ s,
+                                                const float* __restrict__ stats, const float* __restrict__ g,
+                                                float* __restrict__ ds_out, float* __restrict__ dr_out,
+                                                float* __restrict__ part, int M, int D, float p_drop,
+                                                uint64_t seed, uint32_t site) {
+  extern __shared__ float red[];             // [4][2*D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float inv_keep = 1.0f / (1.0f - p_drop);
+  for (int c = threadIdx.x; c < 8 * D; c += 256) red[c] = 0.f;
+  __syncthreads();
+  float* myg = red + wave * 2 * D;
+  for (int i = 0; i < LN_RPB / 4; ++i) {
+    const long row = (long)blockIdx.x * LN_RPB + wave * (LN_RPB / 4) + i;
+    if (row >= M) break;
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    const float* dyr = dy + row * D; const float* sr = s + row * D;
+    float c1 = 0.f, c2 = 0.f;
+    for (int c = lane; c < D; c += 64) {
+      const float xh = (sr[c] - mean) * rstd, dg = dyr[c] * g[c];
+      c1 += dg; c2 += dg * xh;
+    }
+    c1 = wave_sum64(c1) / D; c2 = wave_sum64(c2) / D;
+    for (int c = lane; c < D; c += 64) {
+      const float xh = (sr[c] - mean) * rstd, d = dyr[c];
+      const float v = rstd * (d * g[c] - c1 - xh * c2);
+      ds_out[row * D + c] = v;
+      float dv = v;
+      if (p_drop > 0.f) dv *= dropout_scale(seed, site, (uint64_t)row * D + c, p_drop, inv_keep);
+      dr_out[row * D + c] = dv;
+      myg[c] += d * xh;          // each lane owns its columns: no race within the wave
+      myg[D + c] += d;
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * D; c += 256)
+    part[(long)blockIdx.x * 2 * D + c] = (red[c] + red[2 * D + c]) + (red[4 * D + c] + red[6 * D + c]);
+}
+
+// code/models_rd.py:366-367,379: agg[b,c] = sum_t r[t,b,c] * (1 - mask[b,t]) / (lengths[b] + 1)
+__global__ __launch_bounds__(256) void k_masked_mean_fwd(const float* __restrict__ r, const uint8_t* __restrict__ mask,
+                                                         const int64_t* __restrict__ lengths, float* __restrict__ out,
+                                                         int T, int B, int D, int ldo) {
+  const int b = blockIdx.x;
+  const float inv = 1.0f / (float)(lengths[b] + 1);
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    float s = 0.f;
+    for (int t = 0; t < T; ++t)
+      if (!mask[(long)b * T + t]) s += r[((long)t * B + b) * D + c];
+    out[(long)b * ldo + c] = s * inv;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_masked_mean_bwd(const float* __restrict__ dagg, const uint8_t* __restrict__ mask,
+                                                         const int64_t* __restrict__ lengths, float* __restrict__ dr,
+                                                         int T, int B, int D, int ldo) {
+  const long n = (long)T * B * D;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % D);
+    const long tb = i / D;
+    const int b = (int)(tb % B), t = (int)(tb / B);
+    dr[i] = mask[(long)b * T + t] ? 0.f : dagg[(long)b * ldo + c] / (float)(lengths[b] + 1);
+  }
+}
+
+// ---- encoder layer bookkeeping -----------------------------------------------------------------
+struct EncDims { long M; int D, Hd, nhid, H, T, B; };
+
+EncDims enc_dims(const rd_shape* s) {
+  EncDims e;
+  e.T = s->T; e.B = s->B; e.D = s->F * s->d_ob + s->d_pe; e.H = s->nhead; e.Hd = e.D / e.H;
+  e.nhid = s->nhid; e.M = (long)s->T * s->B;
+  return e;
+}
+
+struct EncSaved { float *qkv, *attn, *lse, *s1, *st1, *x1, *h, *s2, *st2; size_t bytes; };
+EncSaved carve_saved(const EncDims& e, void* base) {
+  EncSaved v; size_t off = 0;
+  auto take = [&](size_t n) { float* p = base ? (float*)((char*)base + off) : nullptr;
+                              off += align_up(n * sizeof(float), 256); return p; };
+  v.qkv = take(e.M * 3 * e.D); v.attn = take(e.M * e.D); v.lse = take((size_t)e.B * e.H * e.T);
+  v.s1 = take(e.M * e.D); v.st1 = take(e.M * 2); v.x1 = take(e.M * e.D);
+  v.h = take(e.M * e.nhid); v.s2 = take(e.M * e.D); v.st2 = take(e.M * 2);
+  v.bytes = off;
+  return v;
+}
+
+struct EncWs { float *o, *f, *ds2, *df, *du, *dx1, *ds1, *dout, *da, *dqkv, *delta, *lnpart, *lnred, *splitk, *colsum;
+               size_t bytes; int ns_max; };
+int bw_nsplit(long M, int N, int K, int* kps) {
+  const int tiles = cdiv(N, 64) * cdiv(K, 64);
+  int ns = cdiv(512, tiles);
+  int per = (int)align_up((size_t)cdiv((int)M, ns), 32);
+  *kps = per;
+  return cdiv((int)M, per);
+}
+EncWs carve_ws(const EncDims& e, void* base) {
+  EncWs w; size_t off = 0;
+  auto take = [&](size_t n) { float* p = base ? (float*)((char*)base + off) : nullptr;
+                              off += align_up(n * sizeof(float), 256); return p; };
+  w.o = take(e.M * e.D); w.f = take(e.M * e.D);
+  w.ds2 = take(e.M * e.D); w.df = take(e.M * e.D); w.du = take(e.M * e.nhid); w.dx1 = take(e.M * e.D);
+  w.ds1 = take(e.M * e.D); w.dout = take(e.M * e.D); w.da = take(e.M * e.D); w.dqkv = take(e.M * 3 * e.D);
+  w.delta = take((size_t)e.B * e.H * e.T);
+  w.lnpart = take((size_t)cdiv((int)e.M, LN_RPB) * 2 * e.D);
+  w.lnred = take((size_t)2 * e.D + colsum_ws_floats(cdiv((int)e.M, LN_RPB), 2 * e.D));
+  size_t sk = 0; int kps;
+  const int shapes[4][2] = {{3 * e.D, e.D}, {e.D, e.D}, {e.nhid, e.D}, {e.D, e.nhid}};
+  for (auto& sh : shapes) { size_t v = (size_t)bw_nsplit(e.M, sh[0], sh[1], &kps) * sh[0] * sh[1]; if (v > sk) sk = v; }
+  w.splitk = take(sk);
+  w.colsum = take(colsum_ws_floats((int)e.M, 3 * e.D > e.nhid ? 3 * e.D : e.nhid));
+  w.bytes = off;
+  return w;
+}
+
+int linear_fwd(long M, int N, int K, const float* x, const float* W, const float* b, float* y, int relu,
+               float p, uint64_t seed, uint32_t site, hipStream_t st) {
+  GemmArgs g{};
+  g.M = (int)M; g.N = N; g.K = K; g.nsplit = 1;
+  g.A = x; g.sa_m = K; g.sa_k = 1; g.B = W; g.sb_n = K; g.sb_k = 1; g.C = y; g.sc_m = N;
+  g.bias = b; g.relu = relu; g.drop_p = p; g.drop_seed = seed; g.drop_site = site;
+  return launch_gemm(g, st);
+}
+// dx = dy W (+ residual), optionally gated by posmask > 0 and scaled
+int linear_bwd_x(long M, int N, int K, const float* dy, const float* W, float* dx, const float* posmask,
+                 float cscale, const float* residual, hipStream_t st) {
+  GemmArgs g{};
+  g.M = (int)M; g.N = K; g.K = N; g.nsplit = 1;
+  g.A = dy; g.sa_m = N; g.sa_k = 1; g.B = W; g.sb_n = 1; g.sb_k = K; g.C = dx; g.sc_m = K;
+  g.posmask = posmask; g.pm_m = K; g.cscale = cscale; g.residual = residual; g.res_m = K;
+  return launch_gemm(g, st);
+}
+int linear_bwd_w(long M, int N, int K, const float* dy, const float* x, float* dW, float* db, float* splitk,
+                 float* colsum, hipStream_t st) {
+  int kps; const int ns = bw_nsplit(M, N, K, &kps);
+  GemmArgs t{};
+  t.M = N; t.N = K; t.K = (int)M;
+  t.A = dy; t.sa_m = 1; t.sa_k = N; t.B = x; t.sb_n = 1; t.sb_k = K;
+  t.nsplit = ns; t.k_per_split = kps;
+  int rc;
+  if (ns > 1) {
+    t.C = splitk; t.sc_m = K; t.sc_split = (long)N * K;
+    if ((rc = launch_gemm(t, st))) return rc;
+    if ((rc = launch_splitk_reduce(splitk, ns, (long)N * K, dW, st))) return rc;
+  } else {
+    t.C = dW; t.sc_m = K;
+    if ((rc = launch_gemm(t, st))) return rc;
+  }
+  return launch_colsum(dy, (int)M, N, N, db, colsum, st);
+}
+
+int check_enc(const rd_shape* s) {
+  RD_REQUIRE(s != nullptr, "rd_shape is NULL");
+  RD_REQUIRE(s->B >= 0 && s->T > 0 && s->F > 0 && s->d_ob > 0 && s->d_pe >= 0 && s->nhead > 0 && s->nhid > 0,
+             "bad rd_shape");
+  const int D = s->F * s->d_ob + s->d_pe;
+  RD_REQUIRE(D % s->nhead == 0, "D=%d not divisible by nhead=%d", D, s->nhead);
+  if (D / s->nhead > 96) return fail(RD_EUNSUPPORTED, "head_dim %d > 96 not built", D / s->nhead);
+  RD_REQUIRE((long)s->T * s->B * (3L * D > s->nhid ? 3L * D : s->nhid) < (1L << 31), "tensor exceeds 2^31 elements");
+  return RD_OK;
+}
+
+}  // namespace
+}  // namespace rd
+
+using namespace rd;
+
+extern "C" size_t rd_encoder_layer_saved_bytes(const rd_shape* s) {
+  if (check_enc(s)) return 0;
+  return carve_saved(enc_dims(s), nullptr).bytes;
+}
+extern "C" size_t rd_encoder_layer_workspace_bytes(const rd_shape* s) {
+  if (check_enc(s)) return 0;
+  return carve_ws(enc_dims(s), nullptr).bytes;
+}
+
+extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const float* x, const uint8_t* mask,
+                                    const rd_encoder_weights* w, float p_drop, uint64_t seed, float* y,
+                                    void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  int rc = check_enc(s);
+  if (rc) return rc;
+  RD_REQUIRE(x && mask && w && y && saved && workspace, "NULL tensor");
+  RD_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "p_drop must be in [0,1)");
+  const EncDims e = enc_dims(s);
+  EncSaved v = carve_saved(e, saved);
+  EncWs ws = carve_ws(e, workspace);
+  RD_REQUIRE(saved_bytes >= v.bytes && workspace_bytes >= ws.bytes, "saved/workspace buffer too small");
+  if (e.B == 0) return RD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t L = (uint32_t)layer;
+  if ((rc = linear_fwd(e.M, 3 * e.D, e.D, x, w->in_proj_w, w->in_proj_b, v.qkv, 0, 0.f, 0, 0, st))) return rc;
+  AttnArgs a{};
+  a.qkv = v.qkv; a.mask = mask; a.out = v.attn; a.lse = v.lse;
+  a.T = e.T; a.B = e.B; a.D = e.D; a.H = e.H; a.hd = e.Hd;
+  a.scale = 1.0f / sqrtf((float)e.Hd); a.p_drop = p_drop; a.seed = seed; a.site = SITE_ATTN_PROB + L;
+  if ((rc = dispatch_attn(a, 0, st))) return rc;
+  if ((rc = linear_fwd(e.M, e.D, e.D, v.attn, w->out_proj_w, w->out_proj_b, ws.o, 0, 0.f, 0, 0, st))) return rc;
+  const int lnblocks = cdiv((int)e.M, 4);
+  hipLaunchKernelGGL(k_add_ln_fwd, dim3(lnblocks), dim3(256), 0, st, x, ws.o, w->norm1_w, w->norm1_b, v.s1, v.x1,
+                     v.st1, (int)e.M, e.D, p_drop, seed, SITE_ATTN_OUT + L);
+  if ((rc = check_launch("k_add_ln_fwd"))) return rc;
+  if ((rc = linear_fwd(e.M, e.nhid, e.D, v.x1, w->lin1_w, w->lin1_b, v.h, 1, p_drop, seed, SITE_FFN_HID + L, st)))
+    return rc;
+  if ((rc = linear_fwd(e.M, e.D, e.nhid, v.h, w->lin2_w, w->lin2_b, ws.f, 0, 0.f, 0, 0, st))) return rc;
+  hipLaunchKernelGGL(k_add_ln_fwd, dim3(lnblocks), dim3(256), 0, st, v.x1, ws.f, w->norm2_w, w->norm2_b, v.s2, y,
+                     v.st2, (int)e.M, e.D, p_drop, seed, SITE_FFN_OUT + L);
+  return check_launch("k_add_ln_fwd");
+}
+
+extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const float* x, const uint8_t* mask,
+                                    const rd_encoder_weights* w, float p_drop, uint64_t seed, const void* saved,
+                                    size_t saved_bytes, const float* dy, float* dx, const rd_encoder_grads* g,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_enc(s);
+  if (rc) return rc;
+  RD_REQUIRE(x && mask && w && saved && dy && dx && g && workspace, "NULL tensor");
+  RD_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "p_drop must be in [0,1)");
+  const EncDims e = enc_dims(s);
+  EncSaved v = carve_saved(e, const_cast<void*>(saved));
+  EncWs ws = carve_ws(e, workspace);
+  RD_REQUIRE(saved_bytes >= v.bytes && workspace_bytes >= ws.bytes, "saved/workspace buffer too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (e.B == 0) return RD_OK;
+  const uint32_t L = (uint32_t)layer;
+  const float keep = 1.0f / (1.0f - p_drop);
+  const int lnb = cdiv((int)e.M, LN_RPB);
+  const size_t lnlds = sizeof(float) * 8 * e.D;
+  // ---- LayerNorm 2:  ds2 (residual path), df = ds2 o mask(ffn out) -------------------------------
+  hipLaunchKernelGGL(k_ln_bwd, dim3(lnb), dim3(256), lnlds, st, dy, v.s2, v.st2, w->norm2_w, ws.ds2, ws.df, ws.lnpart,
+                     (int)e.M, e.D, p_drop, seed, SITE_FFN_OUT + L);
+  if ((rc = check_launch("k_ln_bwd"))) return rc;
+  // lnpart is a [blocks, 2D] matrix (dgamma | dbeta per block): column-sum it in fixed order
+  if ((rc = launch_colsum(ws.lnpart, lnb, 2 * e.D, 2 * e.D, ws.lnred, ws.lnred + 2 * e.D, st))) return rc;
+  hipMemcpyAsync(g->norm2_w, ws.lnred, sizeof(float) * e.D, hipMemcpyDeviceToDevice, st);
+  hipMemcpyAsync(g->norm2_b, ws.lnred + e.D, sizeof(float) * e.D, hipMemcpyDeviceToDevice, st);
+  // ---- FFN ---------------------------------------------------------------------------------------
+  if ((rc = linear_bwd_w(e.M, e.D, e.nhid, ws.df, v.h, g->lin2_w, g->lin2_b, ws.splitk, ws.colsum, st))) return rc;
+  if ((rc = linear_bwd_x(e.M, e.D, e.nhid, ws.df, w->lin2_w, ws.du, v.h, p_drop > 0.f ? keep : 0.f, nullptr, st)))
+    return rc;                                                     // du = (df W2) gated by h>0, * keep
+  if ((rc = linear_bwd_w(e.M, e.nhid, e.D, ws.du, v.x1, g->lin1_w, g->lin1_b, ws.splitk, ws.colsum, st))) return rc;
+  if ((rc = linear_bwd_x(e.M, e.nhid, e.D, ws.du, w->lin1_w, ws.dx1, nullptr, 0.f, ws.ds2, st))) return rc;
+  // ---- LayerNorm 1 -------------------------------------------------------------------------------
+  hipLaunchKernelGGL(k_ln_bwd, dim3(lnb), dim3(256), lnlds, st, ws.dx1, v.s1, v.st1, w->norm1_w, ws.ds1, ws.dout,
+                     ws.lnpart, (int)e.M, e.D, p_drop, seed, SITE_ATTN_OUT + L);
+  if ((rc = check_launch("k_ln_bwd"))) return rc;
+  if ((rc = launch_colsum(ws.lnpart, lnb, 2 * e.D, 2 * e.D, ws.lnred, ws.lnred + 2 * e.D, st))) return rc;
+  hipMemcpyAsync(g->norm1_w, ws.lnred, sizeof(float) * e.D, hipMemcpyDeviceToDevice, st);
+  hipMemcpyAsync(g->norm1_b, ws.lnred + e.D, sizeof(float) * e.D, hipMemcpyDeviceToDevice, st);
+  // ---- attention output projection ---------------------------------------------------------------
+  if ((rc = linear_bwd_w(e.M, e.D, e.D, ws.dout, v.attn, g->out_proj_w, g->out_proj_b, ws.splitk, ws.colsum, st)))
+    return rc;
+  if ((rc = linear_bwd_x(e.M, e.D, e.D, ws.dout, w->out_proj_w, ws.da, nullptr, 0.f, nullptr, st))) return rc;
+  // ---- attention core ----------------------------------------------------------------------------
+  AttnArgs a{};
+  a.qkv = v.qkv; a.mask = mask; a.out = v.attn; a.lse = v.lse; a.dout = ws.da; a.dqkv = ws.dqkv; a.delta = ws.delta;
+  a.T = e.T; a.B = e.B; a.D = e.D; a.H = e.H; a.hd = e.Hd;
+  a.scale = 1.0f / sqrtf((float)e.Hd); a.p_drop = p_drop; a.seed = seed; a.site = SITE_ATTN_PROB + L;
+  if ((rc = dispatch_attn(a, 1, st))) return rc;
+  if ((rc = dispatch_attn(a, 2, st))) return rc;
+  // ---- input projection --------------------------------------------------------------------------
+  if ((rc = linear_bwd_w(e.M, 3 * e.D, e.D, ws.dqkv, x, g->in_proj_w, g->in_proj_b, ws.splitk, ws.colsum, st)))
+    return rc;
+  return linear_bwd_x(e.M, 3 * e.D, e.D, ws.dqkv, w->in_proj_w, dx, nullptr, 0.f, ws.ds1, st);
+}
+
+extern "C" int rd_masked_mean_fwd(const rd_shape* s, int32_t D, const float* r, const uint8_t* mask,
+                                  const int64_t* lengths, float* out, int32_t ldo, void* stream) {
+  RD_REQUIRE(s && s->T > 0 && s->B >= 0 && D > 0 && ldo >= D, "bad arguments");
+  RD_REQUIRE(r && mask && lengths && out, "NULL tensor");
+  if (s->B == 0) return RD_OK;
+  hipLaunchKernelGGL(k_masked_mean_fwd, dim3(s->B), dim3(256), 0, (hipStream_t)stream, r, mask, lengths, out, s->T,
+                     s->B, D, ldo);
+  return check_launch("k_masked_mean_fwd");
+}
+
+extern "C" int rd_masked_mean_bwd(const rd_shape* s, int32_t D, const float* dout, int32_t ldo,
+                                  const uint8_t* mask, const int64_t* lengths, float* dr, void* stream) {
+  RD_REQUIRE(s && s->T > 0 && s->B >= 0 && D > 0 && ldo >= D, "bad arguments");
+  RD_REQUIRE(dout && mask && lengths && dr, "NULL tensor");
+  if (s->B == 0) return RD_OK;
+  const long n = (long)s->T * s->B * D;
+  int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_masked_mean_bwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, mask, lengths, dr,
+                     s->T, s->B, D, ldo);
+  return check_launch("k_masked_mean_bwd");
+}

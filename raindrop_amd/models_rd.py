@@ -159,13 +159,18 @@ class Raindrop_v2(nn.Module):
             self.ob_propagation_layer2.lin_value.weight, self.ob_propagation_layer2.lin_value.bias, shp,
             p_drop, seed)
         distance = torch.zeros((), dtype=torch.float32, device=dev)
-        # ---- temporal stage (interim: torch modules on the device; being replaced by K2/K3) ----
-        r_out = self.transformer_encoder(z, src_key_padding_mask=mask)
-        keep = (~mask).permute(1, 0).unsqueeze(2).to(r_out.dtype)
-        output = torch.sum(r_out * keep, dim=0) / (lengths.unsqueeze(1) + 1)
+        # ---- temporal stage: nn.TransformerEncoder semantics on the HIP kernels (K2/K3) ----------
+        r_out = z
+        for i, layer in enumerate(self.transformer_encoder.layers):
+            named = dict(layer.named_parameters())
+            r_out = ops.encoder_layer(r_out, mask, shp, i, p_drop, seed, [named[n] for n in ops.ENC_PARAM_NAMES])
+        # ---- masked mean over time + static embedding + classifier head (K5) ---------------------
         if static is not None:
             emb = ops.linear(static.float(), self.emb.weight, self.emb.bias)
-            output = torch.cat([output, emb], dim=1)
+            agg = ops.masked_mean(r_out, mask, lengths, shp)
+            output = torch.cat([agg, emb], dim=1)                      # code/models_rd.py:384
+        else:
+            output = ops.masked_mean(r_out, mask, lengths, shp)
         hid = ops.linear(output, self.mlp_static[0].weight, self.mlp_static[0].bias, act=1)
         output = ops.linear(hid, self.mlp_static[2].weight, self.mlp_static[2].bias)
         return output, distance, None

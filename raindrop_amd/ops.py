@@ -226,3 +226,87 @@ class _Aggregate(torch.autograd.Function):
 
 def aggregate(gamma, V, skip=None):
     return _Aggregate.apply(gamma.contiguous(), V.contiguous(), None if skip is None else skip.contiguous())
+
+
+# ------------------------------------------------------------------------------------------------
+# temporal stage: nn.TransformerEncoderLayer and the masked mean, on the HIP kernels
+# ------------------------------------------------------------------------------------------------
+
+ENC_PARAM_NAMES = ("self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight",
+                   "self_attn.out_proj.bias", "linear1.weight", "linear1.bias", "linear2.weight",
+                   "linear2.bias", "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")
+
+
+def _enc_ptrs(tensors):
+    return _lib.RdEncoderPtrs(*[t.data_ptr() for t in tensors])
+
+
+class _EncoderLayer(torch.autograd.Function):
+    """One post-norm TransformerEncoderLayer: rd_encoder_layer_fwd / rd_encoder_layer_bwd.
+    Inputs: x [T,B,D], mask [B,T] bool, the 12 parameters in ENC_PARAM_NAMES order."""
+
+    @staticmethod
+    def forward(ctx, x, mask, shp, layer, p_drop, seed, *params):
+        _check(x, *params)
+        _check(mask, dtype=torch.bool)
+        lib = _lib.load()
+        sp = ctypes.byref(shp)
+        dev = x.device
+        saved = _workspace(lib.rd_encoder_layer_saved_bytes(sp), dev)
+        ws = _workspace(lib.rd_encoder_layer_workspace_bytes(sp), dev)
+        y = torch.empty_like(x)
+        w = _enc_ptrs(params)
+        _lib.call("rd_encoder_layer_fwd", sp, int(layer), _ptr(x), _ptr(mask), ctypes.byref(w), float(p_drop),
+                  int(seed), _ptr(y), _ptr(saved), saved.numel(), _ptr(ws), ws.numel(), _stream())
+        ctx.shp, ctx.layer, ctx.p_drop, ctx.seed = shp, int(layer), float(p_drop), int(seed)
+        ctx.save_for_backward(x, mask, saved, *params)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mask, saved, *params = ctx.saved_tensors
+        dy = dy.contiguous()
+        lib = _lib.load()
+        sp = ctypes.byref(ctx.shp)
+        dev = dy.device
+        ws = _workspace(lib.rd_encoder_layer_workspace_bytes(sp), dev)
+        dx = torch.empty_like(x)
+        grads = [torch.empty_like(p) for p in params]
+        w, g = _enc_ptrs(params), _enc_ptrs(grads)
+        _lib.call("rd_encoder_layer_bwd", sp, ctx.layer, _ptr(x), _ptr(mask), ctypes.byref(w), ctx.p_drop, ctx.seed,
+                  _ptr(saved), saved.numel(), _ptr(dy), _ptr(dx), ctypes.byref(g), _ptr(ws), ws.numel(), _stream())
+        return (dx, None, None, None, None, None, *grads)
+
+
+def encoder_layer(x, mask, shp, layer, p_drop, seed, params):
+    return _EncoderLayer.apply(x.contiguous(), mask, shp, layer, p_drop, seed, *[p.contiguous() for p in params])
+
+
+class _MaskedMean(torch.autograd.Function):
+    """code/models_rd.py:366-367,379 -- writes the mean into the left D columns of a [B, D+extra]
+    buffer so the static embedding can be concatenated without a copy."""
+
+    @staticmethod
+    def forward(ctx, r, mask, lengths, shp, extra):
+        _check(r)
+        T, B, D = r.shape
+        out = torch.empty((B, D + extra), dtype=torch.float32, device=r.device)
+        _lib.call("rd_masked_mean_fwd", ctypes.byref(shp), D, _ptr(r), _ptr(mask), _ptr(lengths), _ptr(out),
+                  D + extra, _stream())
+        ctx.shp, ctx.dims = shp, (T, B, D, extra)
+        ctx.save_for_backward(mask, lengths)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        mask, lengths = ctx.saved_tensors
+        T, B, D, extra = ctx.dims
+        dout = dout.contiguous()
+        dr = torch.empty((T, B, D), dtype=torch.float32, device=dout.device)
+        _lib.call("rd_masked_mean_bwd", ctypes.byref(ctx.shp), D, _ptr(dout), D + extra, _ptr(mask), _ptr(lengths),
+                  _ptr(dr), _stream())
+        return dr, None, None, None, None
+
+
+def masked_mean(r, mask, lengths, shp, extra=0):
+    return _MaskedMean.apply(r.contiguous(), mask, lengths, shp, extra)

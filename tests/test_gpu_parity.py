@@ -181,3 +181,102 @@ def test_operator_goldens_on_device():
                      return_attention_weights=True)
     assert np.abs(y2.detach().cpu().numpy() - g["tc_y"]).max() < 1e-5
     assert np.abs(a2.cpu().numpy() - g["tc_alpha"]).max() < 1e-6
+
+
+def _enc_params(D, nhid, seed):
+    from raindrop_amd import ops
+    shapes = {"self_attn.in_proj_weight": (3 * D, D), "self_attn.in_proj_bias": (3 * D,),
+              "self_attn.out_proj.weight": (D, D), "self_attn.out_proj.bias": (D,),
+              "linear1.weight": (nhid, D), "linear1.bias": (nhid,), "linear2.weight": (D, nhid),
+              "linear2.bias": (D,), "norm1.weight": (D,), "norm1.bias": (D,), "norm2.weight": (D,), "norm2.bias": (D,)}
+    return {n: synth.param_values("L." + n, shapes[n], seed=seed) for n in ops.ENC_PARAM_NAMES}
+
+
+@pytest.mark.parametrize("T,B,F,nhead", [(7, 3, 5, 2), (60, 6, 34, 2), (215, 2, 36, 2), (130, 2, 17, 2), (64, 3, 12, 4)])
+def test_encoder_layer_vs_oracle(T, B, F, nhead):
+    """One TransformerEncoderLayer (attention with key-padding mask, LN, FFN) forward and backward
+    against the torch restatement; T=215/130 exercise the multi-tile online softmax."""
+    from raindrop_amd import _lib, ops
+    D, nhid = F * 4 + 16, 2 * F * 4
+    rng = np.random.default_rng(T * 31 + B)
+    x = torch.from_numpy(rng.standard_normal((T, B, D)).astype(np.float32))
+    lengths = torch.from_numpy(rng.integers(1, T + 1, size=B)).long()
+    lengths[0] = T
+    mask = torch.from_numpy(O2.padding_mask(lengths.numpy(), T))
+    dy = torch.from_numpy(rng.standard_normal((T, B, D)).astype(np.float32))
+    p = _enc_params(D, nhid, seed=T)
+    xr = x.clone().requires_grad_(True)
+    pr = {("L." + n): t.clone().requires_grad_(True) for n, t in p.items()}
+    y_ref = O2.encoder_layer(xr, mask, pr, "L.", nhead)
+    g_ref = torch.autograd.grad(y_ref, [xr] + [pr["L." + n] for n in ops.ENC_PARAM_NAMES], dy)
+    xd = x.to(DEV).requires_grad_(True)
+    pd = [p[n].to(DEV).requires_grad_(True) for n in ops.ENC_PARAM_NAMES]
+    shp = _lib.shape(B, T, F, 4, nhead=nhead, nhid=nhid)
+    y = ops.encoder_layer(xd, mask.to(DEV), shp, 0, 0.0, 0, pd)
+    g = torch.autograd.grad(y, [xd] + pd, dy.to(DEV))
+    assert np.abs(y.detach().cpu().numpy() - y_ref.detach().numpy()).max() < 5e-5
+    for name, a, r in zip(["x"] + list(ops.ENC_PARAM_NAMES), g, g_ref):
+        assert _rel(a.cpu().numpy(), r.numpy()) < 2e-4, name
+
+
+def test_encoder_layer_dropout_is_consistent():
+    """With dropout on: (i) same seed -> bit-identical output, different seed -> different;
+    (ii) backward uses the forward's masks: a central finite difference of <y, R> along a random
+    direction of x matches <dx, dir> (the layer is a fixed smooth function once the seed is fixed)."""
+    from raindrop_amd import _lib, ops
+    T, B, F, nhead = 12, 2, 3, 2
+    D, nhid = F * 4 + 16, 2 * F * 4
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.standard_normal((T, B, D)).astype(np.float32)).to(DEV)
+    mask = torch.zeros(B, T, dtype=torch.bool, device=DEV); mask[1, 9:] = True
+    p = _enc_params(D, nhid, seed=3)
+    pd = [p[n].to(DEV) for n in ops.ENC_PARAM_NAMES]
+    shp = _lib.shape(B, T, F, 4, nhead=nhead, nhid=nhid)
+    R = torch.from_numpy(rng.standard_normal((T, B, D)).astype(np.float32)).to(DEV)
+    f = lambda xx, seed=77: ops.encoder_layer(xx, mask, shp, 1, 0.3, seed, pd)
+    y1, y2, y3 = f(x), f(x), f(x, 78)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+    xg = x.clone().requires_grad_(True)
+    (dx,) = torch.autograd.grad((f(xg) * R).sum(), [xg])
+    d = torch.from_numpy(rng.standard_normal((T, B, D)).astype(np.float32)).to(DEV)
+    eps = 2e-2
+    fd = (((f(x + eps * d) - f(x - eps * d)) * R).sum() / (2 * eps)).item()
+    an = (dx * d).sum().item()
+    assert abs(fd - an) < 3e-2 * max(1.0, abs(an)), (fd, an)
+
+
+def test_dropout_keep_fraction():
+    """The Philox masks keep ~ (1-p) of the elements and rescale by 1/(1-p) (observation-embedding site)."""
+    from raindrop_amd import _lib, ops
+    cfg = synth.make_config("P19")
+    B, T, F, d = 16, 60, 34, 4
+    K = T * d
+    src = torch.ones(T, B, 2 * F, device=DEV)
+    shp = _lib.shape(B, T, F, d)
+    ident = torch.eye(K, device=DEV)
+    zero = torch.zeros(K, device=DEV)
+    ones_f = torch.ones(F, device=DEV)
+    z, _ = ops.sensor_stage(src, torch.ones(T, B, device=DEV), torch.full((B,), T, device=DEV), ops.timescales(T).to(DEV),
+                            ones_f, torch.ones(1, F * d, device=DEV), ident, zero, ident, zero, shp, 0.2, 99)
+    v = z[:, :, : F * d]
+    kept = (v > 0).float().mean().item()
+    assert abs(kept - 0.8) < 0.01
+    assert abs(v[v > 0].mean().item() - 1.25) < 1e-5
+
+
+def test_masked_mean():
+    from raindrop_amd import _lib, ops
+    T, B, D = 60, 9, 152
+    rng = np.random.default_rng(8)
+    r = torch.from_numpy(rng.standard_normal((T, B, D)).astype(np.float32)).requires_grad_(True)
+    lengths = torch.from_numpy(rng.integers(1, T + 1, size=B)).long()
+    mask = torch.from_numpy(O2.padding_mask(lengths.numpy(), T))
+    keep = (~mask).permute(1, 0).unsqueeze(2).float()
+    ref = torch.sum(r * keep, dim=0) / (lengths.unsqueeze(1) + 1)
+    dout = torch.from_numpy(rng.standard_normal((B, D)).astype(np.float32))
+    (g_ref,) = torch.autograd.grad(ref, [r], dout)
+    rd = r.detach().to(DEV).requires_grad_(True)
+    out = ops.masked_mean(rd, mask.to(DEV), lengths.to(DEV), _lib.shape(B, T, 34, 4))
+    (g,) = torch.autograd.grad(out, [rd], dout.to(DEV))
+    assert np.abs(out.detach().cpu().numpy() - ref.detach().numpy()).max() < 1e-6
+    assert np.abs(g.cpu().numpy() - g_ref.numpy()).max() < 1e-7
