@@ -39,6 +39,15 @@ extern "C" {
 
 #define RD_ABI_VERSION 1
 
+/* Arithmetic of the dense contractions (inputs, outputs and accumulation are always fp32):
+ *   RD_PREC_FP32   v_mfma_f32_16x16x4_f32, bitwise an fp32 fmaf chain (157 TF/s peak)
+ *   RD_PREC_BF16X3 each fp32 operand split into bf16 hi+lo, products hi*hi + hi*lo + lo*hi on
+ *                  v_mfma_f32_16x16x32_bf16 with fp32 accumulate: ~2^-16 relative per product
+ *                  (fp32-class after accumulation; logits agree with the fp32 path to ~1e-6),
+ *                  5.3x the MFMA throughput.  Default; env RD_PRECISION=fp32 selects the other. */
+#define RD_PREC_FP32 0
+#define RD_PREC_BF16X3 1
+
 /* Problem shape shared by the model-level entry points.
  * K = T*d_ob (channels per sensor node), Dm = F*d_ob, D = Dm + d_pe (transformer width). */
 typedef struct rd_shape {
@@ -58,6 +67,8 @@ typedef struct rd_shape {
 int rd_version(void);             /* RD_ABI_VERSION                                           */
 const char* rd_arch(void);        /* "gfx950"                                                  */
 const char* rd_last_error(void);  /* thread-local; "" if none                                  */
+int rd_set_precision(int32_t mode); /* process-wide; RD_PREC_*                                 */
+int rd_get_precision(void);
 
 /* ---- a5/a6: integer work (bit-exact contracts) -------------------------------------------- */
 
@@ -101,28 +112,32 @@ int rd_aggregate_fwd(int32_t N, int32_t C, const float* gamma, const float* V, c
 int rd_aggregate_bwd(int32_t N, int32_t C, const float* gamma, const float* dout, float* dV,
                      void* stream);
 
-size_t rd_msgpass_workspace_bytes(const rd_shape* s);
+size_t rd_msgpass_workspace_bytes(const rd_shape* s);   /* scratch of rd_msgpass_bwd            */
+size_t rd_msgpass_saved_bytes(const rd_shape* s);       /* forward -> backward hand-over buffer */
 
 /* Forward of both Observation_progation layers for the whole batch
  * (code/models_rd.py:285-296,313-343 + code/Ob_propagation.py:157-228, default branch):
  *   X[b,f,t*d+c]  = relu(src[t,b,f] * R_u[f*d+c])            (observation embedding)
  *   Y1 = relu(X  W1^T + b1) * ssum[f];   Y2 = relu(Y1 W2^T + b2) * ssum[f]
  *   z[t,b,f*d+c]  = Y2[b,f,t*d+c]                            (columns [0, F*d) of z, row stride ldz)
- * src [T,B,2F] (values in the first F columns); xsave/y1save [B,F,K] are saved for backward.
+ * src [T,B,2F] (values in the first F columns).  `saved` (rd_msgpass_saved_bytes) receives what
+ * the backward pass needs: X and Y1 as [B,F,K] and, on the fused path, the split-bf16 weight planes.
  * p_drop > 0 applies nn.Dropout to the embedding h (code/models_rd.py:296) with a Philox mask
- * that is a pure function of (seed, element index); p_drop = 0 in eval mode. */
+ * that is a pure function of (seed, element index); p_drop = 0 in eval mode.
+ * Shapes with F <= 64, d_ob = 4, K = T*d_ob <= 240, K % 16 == 0 (P19) run as ONE fused
+ * LDS-resident kernel per batch (one workgroup per sample); others as tiled GEMMs. */
 int rd_msgpass_fwd(const rd_shape* s, const float* src, const float* R_u, const float* W1,
                    const float* b1, const float* W2, const float* b2, const float* ssum,
-                   float p_drop, uint64_t seed, float* xsave, float* y1save, float* z, int32_t ldz,
-                   void* workspace, size_t workspace_bytes, void* stream);
+                   float p_drop, uint64_t seed, float* z, int32_t ldz, void* saved, size_t saved_bytes,
+                   void* stream);
 
 /* Backward of rd_msgpass_fwd.  dz is the gradient w.r.t. z (row stride ldz; only the first
  * F*d columns are read).  Writes dW1,db1,dW2,db2 and dR_u [F*d] (overwrite, not accumulate). */
 int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* R_u, const float* W1,
-                   const float* W2, const float* ssum, float p_drop, const float* xsave,
-                   const float* y1save, const float* z, const float* dz, int32_t ldz, float* dW1, float* db1,
-                   float* dW2, float* db2, float* dR_u, void* workspace, size_t workspace_bytes,
-                   void* stream);
+                   const float* W2, const float* ssum, float p_drop, const void* saved,
+                   size_t saved_bytes, const float* z, const float* dz, int32_t ldz, float* dW1,
+                   float* db1, float* dW2, float* db2, float* dR_u, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 /* ---- a15/a16: temporal self-attention encoder (kernels K2/K3) and masked mean (K5) --------- */
 

@@ -39,6 +39,8 @@ SIGNATURES = {
     "rd_version": (c_int32, []),
     "rd_arch": (c_char_p, []),
     "rd_last_error": (c_char_p, []),
+    "rd_set_precision": (c_int32, [c_int32]),
+    "rd_get_precision": (c_int32, []),
     "rd_graph_build": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P]),
     "rd_pe_mask": (c_int32, [_SHP, _P, _P, _P, _P, _P, _P]),
     "rd_edge_softmax": (c_int32, [c_int32, _P, _P, _P, _P]),
@@ -46,9 +48,9 @@ SIGNATURES = {
     "rd_aggregate_fwd": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _P]),
     "rd_aggregate_bwd": (c_int32, [c_int32, c_int32, _P, _P, _P, _P]),
     "rd_msgpass_workspace_bytes": (c_size_t, [_SHP]),
-    "rd_msgpass_fwd": (c_int32, [_SHP] + [_P] * 7 + [c_float, ctypes.c_uint64] + [_P] * 3
-                       + [c_int32, _P, c_size_t, _P]),
-    "rd_msgpass_bwd": (c_int32, [_SHP] + [_P] * 5 + [c_float] + [_P] * 4 + [c_int32] + [_P] * 5
+    "rd_msgpass_saved_bytes": (c_size_t, [_SHP]),
+    "rd_msgpass_fwd": (c_int32, [_SHP] + [_P] * 7 + [c_float, ctypes.c_uint64, _P, c_int32, _P, c_size_t, _P]),
+    "rd_msgpass_bwd": (c_int32, [_SHP] + [_P] * 5 + [c_float, _P, c_size_t, _P, _P, c_int32] + [_P] * 5
                        + [_P, c_size_t, _P]),
     "rd_encoder_layer_saved_bytes": (c_size_t, [_SHP]),
     "rd_encoder_layer_workspace_bytes": (c_size_t, [_SHP]),

@@ -1,5 +1,6 @@
 // rd_api.hip -- library identity, error reporting and the generic dense entry points.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "rd_common.h"
@@ -9,6 +10,15 @@ namespace rd {
 char* err_buf() {
   static thread_local char buf[512] = {0};
   return buf;
+}
+
+static int g_precision = -1;
+int precision() {
+  if (g_precision < 0) {
+    const char* e = getenv("RD_PRECISION");
+    g_precision = (e && strcmp(e, "fp32") == 0) ? RD_PREC_FP32 : RD_PREC_BF16X3;
+  }
+  return g_precision;
 }
 
 int fail(int code, const char* fmt, ...) {
@@ -22,6 +32,13 @@ int fail(int code, const char* fmt, ...) {
 }  // namespace rd
 
 using namespace rd;
+
+extern "C" int rd_set_precision(int32_t mode) {
+  RD_REQUIRE(mode == RD_PREC_FP32 || mode == RD_PREC_BF16X3, "unknown precision mode %d", mode);
+  g_precision = mode;
+  return RD_OK;
+}
+extern "C" int rd_get_precision(void) { return precision(); }
 
 extern "C" int rd_version(void) { return RD_ABI_VERSION; }
 extern "C" const char* rd_arch(void) { return "gfx950"; }
@@ -56,22 +73,9 @@ extern "C" int rd_linear_bwd_input(int32_t M, int32_t N, int32_t K, const float*
   return launch_gemm(g, (hipStream_t)stream);
 }
 
-namespace {
-void bwd_weight_plan(int M, int N, int K, int* nsplit, int* kps) {
-  const int tiles = cdiv(N, 64) * cdiv(K, 64);
-  int ns = cdiv(512, tiles);
-  int per = (int)align_up((size_t)cdiv(M > 0 ? M : 1, ns), 32);
-  *kps = per;
-  *nsplit = cdiv(M > 0 ? M : 1, per);
-}
-}  // namespace
-
 extern "C" size_t rd_linear_bwd_weight_workspace_bytes(int32_t M, int32_t N, int32_t K) {
   if (M < 0 || N <= 0 || K <= 0) return 0;
-  int ns, kps;
-  bwd_weight_plan(M, N, K, &ns, &kps);
-  return align_up((size_t)ns * N * K * sizeof(float), 256) +
-         align_up((size_t)colsum_ws_floats(M, N) * sizeof(float), 256) + 256;
+  return align_up((size_t)wgrad_ws_floats(M, N, K) * sizeof(float), 256);
 }
 
 extern "C" int rd_linear_bwd_weight(int32_t M, int32_t N, int32_t K, const float* dy, int32_t lddy,
@@ -88,24 +92,5 @@ extern "C" int rd_linear_bwd_weight(int32_t M, int32_t N, int32_t K, const float
     if (db) hipMemsetAsync(db, 0, sizeof(float) * N, st);
     return RD_OK;
   }
-  int ns, kps;
-  bwd_weight_plan(M, N, K, &ns, &kps);
-  float* part = (float*)workspace;
-  float* csws = (float*)((char*)workspace + align_up((size_t)ns * N * K * sizeof(float), 256));
-  GemmArgs t{};
-  t.M = N; t.N = K; t.K = M;
-  t.A = dy; t.sa_m = 1; t.sa_k = lddy;
-  t.B = x; t.sb_n = 1; t.sb_k = ldx;
-  t.nsplit = ns; t.k_per_split = kps;
-  int rc;
-  if (ns > 1) {
-    t.C = part; t.sc_m = K; t.sc_split = (long)N * K;
-    if ((rc = launch_gemm(t, st))) return rc;
-    if ((rc = launch_splitk_reduce(part, ns, (long)N * K, dW, st))) return rc;
-  } else {
-    t.C = dW; t.sc_m = K;
-    if ((rc = launch_gemm(t, st))) return rc;
-  }
-  if (db) return launch_colsum(dy, M, N, lddy, db, csws, st);
-  return RD_OK;
+  return launch_wgrad(M, N, K, dy, lddy, x, ldx, dW, db, (float*)workspace, st);
 }

@@ -23,6 +23,9 @@ inline int check_launch(const char* what) {
     if (!(cond)) return rd::fail(RD_EINVAL, __VA_ARGS__); \
   } while (0)
 
+// process-wide arithmetic mode of the dense contractions (rd_set_precision / env RD_PRECISION)
+int precision();
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -40,6 +43,8 @@ struct GemmArgs {
   float* C; long sc_m;            // C(m,n) at C[m*sc_m + n] unless scatter != 0
   int M, N, K;
   int nsplit; int k_per_split; long sc_split;   // split-K: partial z goes to C + z*sc_split, raw
+  float* rowsum;                  // optional: rowsum[z*M + m] = sum_k A(m,k) over this split (bias gradients
+                                  // ride along the weight-gradient product instead of a second pass over dy)
   // epilogue (ignored when nsplit > 1)
   const float* bias;              // [N]
   const float* rowscale; int rs_period;          // * rowscale[m % rs_period]
@@ -53,6 +58,13 @@ struct GemmArgs {
   int scatter; int sB, sF, sd; long ldz;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t st);
+// split of the reduction length `red` of a [rows x cols] weight-gradient product into nsplit chunks
+// of k_per_split (a multiple of 64) so that a few hundred workgroups exist; returns nsplit
+int splitk_plan(long red, int rows, int cols, int* k_per_split);
+// weight + bias gradient of a linear layer in one split-K product (ws: wgrad_ws_floats floats)
+long wgrad_ws_floats(long M, int N, int K);
+int launch_wgrad(long M, int N, int K, const float* dy, long lddy, const float* x, long ldx, float* dW,
+                 float* db, float* ws, hipStream_t st);
 // sum `nsplit` partials [nsplit][rows*cols] in fixed order into out
 int launch_splitk_reduce(const float* part, int nsplit, long elems, float* out, hipStream_t st);
 // out[n] = sum_m x[m*ldx + n], deterministic two-stage; ws needs colsum_ws_floats(M,N) floats

@@ -68,6 +68,44 @@ __device__ __forceinline__ void stage_store(const float (&r)[8], float* __restri
   }
 }
 
+// acc[i][j][r] is C(m, n) with m = mw + 16*i + 4*(lane>>4) + r, n = nw + 16*j + (lane&15)
+__device__ __forceinline__ void epilogue(const GemmArgs& g, f32x4 (&acc)[2][2], int mw, int nw, int z, int lane) {
+  float* Cz = g.C + (long)z * g.sc_split;
+  const bool raw = g.nsplit > 1;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = nw + j * 16 + (lane & 15);
+      if (n >= g.N) continue;
+      const float bias = (!raw && g.bias) ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = mw + i * 16 + 4 * (lane >> 4) + r;
+        if (m >= g.M) continue;
+        float v = acc[i][j][r];
+        if (!raw) {
+          v += bias;
+          if (g.relu) v = fmaxf(v, 0.f);
+          if (g.rowscale) v *= g.rowscale[m % g.rs_period];
+          if (g.posmask) v = (g.posmask[(long)m * g.pm_m + n] > 0.f) ? v : 0.f;
+          if (g.cscale != 0.f) v *= g.cscale;
+          if (g.drop_p > 0.f)
+            v *= dropout_scale(g.drop_seed, g.drop_site, (uint64_t)m * g.N + n, g.drop_p,
+                               1.0f / (1.0f - g.drop_p));
+          if (g.residual) v += g.residual[(long)m * g.res_m + n];
+        }
+        if (g.scatter && !raw) {
+          const int b = m / g.sF, f = m - b * g.sF;
+          const int t = n / g.sd, c = n - t * g.sd;
+          g.C[((long)t * g.sB + b) * g.ldz + f * g.sd + c] = v;
+        } else {
+          Cz[(long)m * g.sc_m + n] = v;
+        }
+      }
+    }
+}
+
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float As[BM * LDT];
@@ -89,11 +127,17 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   float ra[8], rb[8];
+  float rsum = 0.f;
+  const bool do_rowsum = !A_KC && g.rowsum != nullptr && blockIdx.x == 0;
   if (kbeg < kend) {
     stage_load<A_KC>(ra, g.A, g.sa_m, g.sa_k, m0, g.M, kbeg, kend, tid, a_vec);
     stage_load<B_KC>(rb, g.B, g.sb_n, g.sb_k, n0, g.N, kbeg, kend, tid, b_vec);
   }
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    if (do_rowsum) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) rsum += ra[i];
+    }
     stage_store<A_KC>(ra, As, tid);
     stage_store<B_KC>(rb, Bs, tid);
     __syncthreads();
@@ -121,42 +165,160 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     }
     __syncthreads();
   }
+  if (do_rowsum) {
+    float* red = As;
+    red[wave * 64 + lane] = rsum;
+    __syncthreads();
+    if (tid < 64 && m0 + tid < g.M)
+      g.rowsum[(long)z * g.M + m0 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+  }
+  epilogue(g, acc, m0 + wy * 32, n0 + wx * 32, z, lane);
+}
 
-  // ---- epilogue: acc[i][j][r] is C(m, n) with m = .. + 4*(lane>>4) + r, n = .. + (lane&15)
-  float* Cz = g.C + (long)z * g.sc_split;
-  const bool raw = g.nsplit > 1;
+// ------------------------------------------------------------------------------------------------
+// Split-bf16 variant: every fp32 operand x is split on the fly into hi = bf16(x), lo = bf16(x - hi)
+// when its tile is stored to LDS, and each product is evaluated as hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation (the dropped lo*lo term is ~2^-16 relative).
+// 3 bf16 MFMAs replace 8 f32 MFMAs per 16x16x32 block: 16x the MFMA rate at 3x the count = 5.3x.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int BK2 = 64, LDB = BK2 + 8;   // bf16 elements; 144-B rows (16-B aligned, conflict-free b128)
+
+// KC: thread owns rows {tid/16 + 16p, p<4}, k quad (tid%16)*4.   MC: row tid%64, k = (tid/64)*16 + i.
+template <bool KC>
+__device__ __forceinline__ void stage_load2(float (&r)[16], const float* __restrict__ P, long s_row,
+                                            long s_k, int row0, int nrows, int k0, int kend, int tid,
+                                            bool vec_ok) {
+  if (KC) {
+    const int kq = k0 + (tid & 15) * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = row0 + p * 16 + (tid >> 4);
+      const bool rok = row < nrows;
+      if (rok && vec_ok && kq + 3 < kend) {
+        const float4 v = *reinterpret_cast<const float4*>(P + (long)row * s_row + kq);
+        r[p * 4 + 0] = v.x; r[p * 4 + 1] = v.y; r[p * 4 + 2] = v.z; r[p * 4 + 3] = v.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          r[p * 4 + j] = (rok && kq + j < kend) ? P[(long)row * s_row + kq + j] : 0.f;
+      }
+    }
+  } else {
+    const int row = row0 + (tid & 63);
+    const bool rok = row < nrows;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = k0 + (tid >> 6) * 16 + i;
+      r[i] = (rok && k < kend) ? P[(long)row * s_row + (long)k * s_k] : 0.f;
+    }
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void stage_store2(const float (&r)[16], __bf16* __restrict__ Th,
+                                             __bf16* __restrict__ Tl, int tid) {
+  if (KC) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      bf16x4 h, l;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x = r[p * 4 + j];
+        h[j] = (__bf16)x;
+        l[j] = (__bf16)(x - (float)h[j]);
+      }
+      const int o = (p * 16 + (tid >> 4)) * LDB + (tid & 15) * 4;
+      *reinterpret_cast<bf16x4*>(Th + o) = h;
+      *reinterpret_cast<bf16x4*>(Tl + o) = l;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      bf16x8 h, l;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = r[q * 8 + j];
+        h[j] = (__bf16)x;
+        l[j] = (__bf16)(x - (float)h[j]);
+      }
+      const int o = (tid & 63) * LDB + (tid >> 6) * 16 + q * 8;
+      *reinterpret_cast<bf16x8*>(Th + o) = h;
+      *reinterpret_cast<bf16x8*>(Tl + o) = l;
+    }
+  }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) __bf16 Ah[BM * LDB];
+  __shared__ __attribute__((aligned(16))) __bf16 Al[BM * LDB];
+  __shared__ __attribute__((aligned(16))) __bf16 Bh[BN * LDB];
+  __shared__ __attribute__((aligned(16))) __bf16 Bl[BN * LDB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wy = wave >> 1, wx = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int z = blockIdx.z;
+  const int kbeg = z * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+  const bool a_vec = A_KC && ((g.sa_m & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
+  const bool b_vec = B_KC && ((g.sb_n & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+  f32x4 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wx * 32 + j * 16 + (lane & 15);
-      if (n >= g.N) continue;
-      const float bias = (!raw && g.bias) ? g.bias[n] : 0.f;
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float ra[16], rb[16];
+  float rsum = 0.f;                                   // MC staging: this thread's row is tid & 63
+  const bool do_rowsum = !A_KC && g.rowsum != nullptr && blockIdx.x == 0;
+  if (kbeg < kend) {
+    stage_load2<A_KC>(ra, g.A, g.sa_m, g.sa_k, m0, g.M, kbeg, kend, tid, a_vec);
+    stage_load2<B_KC>(rb, g.B, g.sb_n, g.sb_k, n0, g.N, kbeg, kend, tid, b_vec);
+  }
+  for (int k0 = kbeg; k0 < kend; k0 += BK2) {
+    if (do_rowsum) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wy * 32 + i * 16 + 4 * (lane >> 4) + r;
-        if (m >= g.M) continue;
-        float v = acc[i][j][r];
-        if (!raw) {
-          v += bias;
-          if (g.relu) v = fmaxf(v, 0.f);
-          if (g.rowscale) v *= g.rowscale[m % g.rs_period];
-          if (g.posmask) v = (g.posmask[(long)m * g.pm_m + n] > 0.f) ? v : 0.f;
-          if (g.cscale != 0.f) v *= g.cscale;
-          if (g.drop_p > 0.f)
-            v *= dropout_scale(g.drop_seed, g.drop_site, (uint64_t)m * g.N + n, g.drop_p,
-                               1.0f / (1.0f - g.drop_p));
-          if (g.residual) v += g.residual[(long)m * g.res_m + n];
-        }
-        if (g.scatter && !raw) {
-          const int b = m / g.sF, f = m - b * g.sF;
-          const int t = n / g.sd, c = n - t * g.sd;
-          g.C[((long)t * g.sB + b) * g.ldz + f * g.sd + c] = v;
-        } else {
-          Cz[(long)m * g.sc_m + n] = v;
-        }
-      }
+      for (int i = 0; i < 16; ++i) rsum += ra[i];
     }
+    stage_store2<A_KC>(ra, Ah, Al, tid);
+    stage_store2<B_KC>(rb, Bh, Bl, tid);
+    __syncthreads();
+    if (k0 + BK2 < kend) {
+      stage_load2<A_KC>(ra, g.A, g.sa_m, g.sa_k, m0, g.M, k0 + BK2, kend, tid, a_vec);
+      stage_load2<B_KC>(rb, g.B, g.sb_n, g.sb_k, n0, g.N, k0 + BK2, kend, tid, b_vec);
+    }
+#pragma unroll
+    for (int kc = 0; kc < BK2; kc += 32) {
+      bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int oa = (wy * 32 + i * 16 + (lane & 15)) * LDB + kc + 8 * (lane >> 4);
+        const int ob = (wx * 32 + i * 16 + (lane & 15)) * LDB + kc + 8 * (lane >> 4);
+        ah[i] = *reinterpret_cast<const bf16x8*>(Ah + oa);
+        al[i] = *reinterpret_cast<const bf16x8*>(Al + oa);
+        bh[i] = *reinterpret_cast<const bf16x8*>(Bh + ob);
+        bl[i] = *reinterpret_cast<const bf16x8*>(Bl + ob);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  if (do_rowsum) {                                    // 4 threads (one per wave) share a row
+    float* red = reinterpret_cast<float*>(Ah);
+    red[wave * 64 + lane] = rsum;
+    __syncthreads();
+    if (tid < 64 && m0 + tid < g.M)
+      g.rowsum[(long)z * g.M + m0 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+  }
+  epilogue(g, acc, m0 + wy * 32, n0 + wx * 32, z, lane);
 }
 
 __global__ void k_splitk_reduce(const float* __restrict__ part, int nsplit, long elems,
@@ -192,17 +354,64 @@ __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ x
 
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0) return RD_OK;
-  const bool akc = (a.sa_k == 1), bkc = (a.sb_k == 1);
+  // a row-sum request rides on the row-contiguous staging; with a 1-wide operand both strides are 1
+  const bool akc = (a.sa_k == 1) && !(a.rowsum && a.sa_m == 1), bkc = (a.sb_k == 1);
   if (!akc && a.sa_m != 1) return fail(RD_EINVAL, "gemm: A needs a unit stride");
   if (!bkc && a.sb_n != 1) return fail(RD_EINVAL, "gemm: B needs a unit stride");
   dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), a.nsplit > 1 ? a.nsplit : 1);
   GemmArgs g = a;
   if (g.nsplit <= 1) { g.nsplit = 1; g.k_per_split = g.K > 0 ? g.K : 1; g.sc_split = 0; }
+  if (precision() == RD_PREC_BF16X3) {
+    if (g.nsplit > 1 && (g.k_per_split % BK2) != 0) return fail(RD_EINVAL, "gemm: k_per_split must be a multiple of 64");
+    if (akc && bkc) hipLaunchKernelGGL((k_gemm_bf16x3<true, true>), grid, dim3(256), 0, st, g);
+    else if (akc && !bkc) hipLaunchKernelGGL((k_gemm_bf16x3<true, false>), grid, dim3(256), 0, st, g);
+    else if (!akc && bkc) hipLaunchKernelGGL((k_gemm_bf16x3<false, true>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((k_gemm_bf16x3<false, false>), grid, dim3(256), 0, st, g);
+    return check_launch("k_gemm_bf16x3");
+  }
   if (akc && bkc) hipLaunchKernelGGL((k_gemm<true, true>), grid, dim3(256), 0, st, g);
   else if (akc && !bkc) hipLaunchKernelGGL((k_gemm<true, false>), grid, dim3(256), 0, st, g);
   else if (!akc && bkc) hipLaunchKernelGGL((k_gemm<false, true>), grid, dim3(256), 0, st, g);
   else hipLaunchKernelGGL((k_gemm<false, false>), grid, dim3(256), 0, st, g);
   return check_launch("k_gemm");
+}
+
+int splitk_plan(long red, int rows, int cols, int* k_per_split) {
+  const int tiles = cdiv(rows, BM) * cdiv(cols, BN);
+  const int want = cdiv(512, tiles);
+  const int r = red > 0 ? (int)red : 1;
+  int per = (int)align_up((size_t)cdiv(r, want), 64);
+  *k_per_split = per;
+  return cdiv(r, per);
+}
+
+// dW[N,K] = dy[M,N]^T x[M,K] and db[N] = sum_m dy[m,:] with ONE pass over dy: the split-K product
+// accumulates the row sums of its A operand (= dy^T) on the side.  ws: nsplit*(N*K + N) floats.
+long wgrad_ws_floats(long M, int N, int K) {
+  int kps; const int ns = splitk_plan(M, N, K, &kps);
+  return (long)ns * ((long)N * K + N);
+}
+int launch_wgrad(long M, int N, int K, const float* dy, long lddy, const float* x, long ldx, float* dW,
+                 float* db, float* ws, hipStream_t st) {
+  int kps; const int ns = splitk_plan(M, N, K, &kps);
+  GemmArgs t{};
+  t.M = N; t.N = K; t.K = (int)M;
+  t.A = dy; t.sa_m = 1; t.sa_k = lddy;
+  t.B = x; t.sb_n = 1; t.sb_k = ldx;
+  t.nsplit = ns; t.k_per_split = kps;
+  float* part = ws;
+  float* rpart = ws + (long)ns * N * K;
+  int rc;
+  if (ns > 1) {
+    t.C = part; t.sc_m = K; t.sc_split = (long)N * K; t.rowsum = db ? rpart : nullptr;
+    if ((rc = launch_gemm(t, st))) return rc;
+    if ((rc = launch_splitk_reduce(part, ns, (long)N * K, dW, st))) return rc;
+    if (db && (rc = launch_splitk_reduce(rpart, ns, N, db, st))) return rc;
+  } else {
+    t.C = dW; t.sc_m = K; t.rowsum = db;
+    if ((rc = launch_gemm(t, st))) return rc;
+  }
+  return RD_OK;
 }
 
 int launch_splitk_reduce(const float* part, int nsplit, long elems, float* out, hipStream_t st) {

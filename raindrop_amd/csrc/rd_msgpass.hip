@@ -19,6 +19,17 @@
 
 namespace rd {
 
+// fused LDS-resident path (rd_msgpass_fused.hip)
+bool fused_msgpass_ok(const rd_shape* s);
+size_t fused_wplanes_bytes(const rd_shape* s);
+int fused_wprep(const rd_shape* s, const float* W1, const float* W2, void* planes, hipStream_t st);
+int fused_msgpass_fwd(const rd_shape* s, const float* src, const float* R_u, const float* b1, const float* b2,
+                      const float* ssum, const void* planes, float p_drop, uint64_t seed, float* xsave,
+                      float* y1save, float* z, int ldz, hipStream_t st);
+int fused_msgpass_bwd(const rd_shape* s, const float* src, const float* ssum, const void* planes, float p_drop,
+                      const float* xsave, const float* y1save, const float* z, const float* dz, int ldz,
+                      float* dz2save, float* dz1save, float* rupart, hipStream_t st);
+
 namespace {
 
 // X[b,f,t*d+c] = relu(src[t,b,f] * R_u[f*d+c])   (code/models_rd.py:290-291 + the layout change
@@ -97,20 +108,31 @@ MsgWs carve(const rd_shape* s, void* base) {
   const long M = B * F;
   MsgWs w;
   // split the B*F reduction of the weight gradients so that ~256+ workgroups exist
-  const int tiles = cdiv((int)K, 64) * cdiv((int)K, 64);
-  int nsplit = cdiv(512, tiles);
-  int kps = (int)align_up((size_t)cdiv((int)M, nsplit), 32);
-  nsplit = cdiv((int)M, kps);
+  int kps;
+  const int nsplit = splitk_plan(M, (int)K, (int)K, &kps);
   w.nsplit = nsplit; w.kps = kps;
   size_t off = 0;
   auto take = [&](size_t nfloats) { float* p = base ? (float*)((char*)base + off) : nullptr;
                                     off += align_up(nfloats * sizeof(float), 256); return p; };
   w.dz2 = take(M * K); w.dz1 = take(M * K); w.dx = take(M * K);
-  w.splitk = take((size_t)nsplit * K * K);
+  w.splitk = take((size_t)wgrad_ws_floats(M, (int)K, (int)K));
   w.colsum = take(colsum_ws_floats((int)M, (int)K));
   w.rupart = take(B * F * s->d_ob);
   w.bytes = off;
   return w;
+}
+
+struct MsgSaved { float *xsave, *y1save; void* planes; size_t bytes; };
+MsgSaved carve_saved(const rd_shape* s, void* base) {
+  const size_t M = (size_t)s->B * s->F, K = (size_t)s->T * s->d_ob;
+  MsgSaved v; size_t off = 0;
+  auto take = [&](size_t bytes) { void* p = base ? (void*)((char*)base + off) : nullptr;
+                                  off += align_up(bytes, 256); return p; };
+  v.xsave = (float*)take(M * K * sizeof(float));
+  v.y1save = (float*)take(M * K * sizeof(float));
+  v.planes = take(fused_wplanes_bytes(s));
+  v.bytes = off;
+  return v;
 }
 
 int check_shape(const rd_shape* s) {
@@ -131,19 +153,30 @@ extern "C" size_t rd_msgpass_workspace_bytes(const rd_shape* s) {
   return carve(s, nullptr).bytes;
 }
 
+extern "C" size_t rd_msgpass_saved_bytes(const rd_shape* s) {
+  if (!s || s->T <= 0 || s->F <= 0 || s->d_ob <= 0 || s->B < 0) return 0;
+  return carve_saved(s, nullptr).bytes;
+}
+
 extern "C" int rd_msgpass_fwd(const rd_shape* s, const float* src, const float* R_u, const float* W1,
                               const float* b1, const float* W2, const float* b2, const float* ssum,
-                              float p_drop, uint64_t seed, float* xsave, float* y1save, float* z,
-                              int32_t ldz, void* workspace, size_t workspace_bytes, void* stream) {
+                              float p_drop, uint64_t seed, float* z, int32_t ldz, void* saved,
+                              size_t saved_bytes, void* stream) {
   int rc = check_shape(s);
   if (rc) return rc;
-  RD_REQUIRE(src && R_u && W1 && b1 && W2 && b2 && ssum && xsave && y1save && z, "NULL tensor");
+  RD_REQUIRE(src && R_u && W1 && b1 && W2 && b2 && ssum && z && saved, "NULL tensor");
   RD_REQUIRE(ldz >= s->F * s->d_ob, "ldz (%d) < F*d_ob", ldz);
   RD_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "p_drop must be in [0,1)");
-  (void)workspace; (void)workspace_bytes;
+  MsgSaved v = carve_saved(s, saved);
+  RD_REQUIRE(saved_bytes >= v.bytes, "saved buffer too small: %zu < %zu", saved_bytes, v.bytes);
   if (s->B == 0) return RD_OK;
   hipStream_t st = (hipStream_t)stream;
   const int B = s->B, T = s->T, F = s->F, d = s->d_ob, K = T * d, M = B * F;
+  float* xsave = v.xsave; float* y1save = v.y1save;
+  if (fused_msgpass_ok(s)) {
+    if ((rc = fused_wprep(s, W1, W2, v.planes, st))) return rc;
+    return fused_msgpass_fwd(s, src, R_u, b1, b2, ssum, v.planes, p_drop, seed, xsave, y1save, z, ldz, st);
+  }
   {
     const long per = (long)F * K;
     int gy = (int)((per + 255) / 256); if (gy > 64) gy = 64;
@@ -164,14 +197,17 @@ extern "C" int rd_msgpass_fwd(const rd_shape* s, const float* src, const float* 
 }
 
 extern "C" int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* R_u, const float* W1,
-                              const float* W2, const float* ssum, float p_drop, const float* xsave,
-                              const float* y1save, const float* z, const float* dz, int32_t ldz,
+                              const float* W2, const float* ssum, float p_drop, const void* saved,
+                              size_t saved_bytes, const float* z, const float* dz, int32_t ldz,
                               float* dW1, float* db1, float* dW2, float* db2, float* dR_u,
                               void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_shape(s);
   if (rc) return rc;
-  RD_REQUIRE(src && R_u && W1 && W2 && ssum && xsave && y1save && z && dz, "NULL tensor");
+  RD_REQUIRE(src && R_u && W1 && W2 && ssum && saved && z && dz, "NULL tensor");
   RD_REQUIRE(dW1 && db1 && dW2 && db2 && dR_u, "NULL gradient output");
+  MsgSaved sv = carve_saved(s, const_cast<void*>(saved));
+  RD_REQUIRE(saved_bytes >= sv.bytes, "saved buffer too small");
+  const float* xsave = sv.xsave; const float* y1save = sv.y1save;
   RD_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "p_drop must be in [0,1)");
   RD_REQUIRE(ldz >= s->F * s->d_ob, "ldz (%d) < F*d_ob", ldz);
   hipStream_t st = (hipStream_t)stream;
@@ -185,6 +221,11 @@ extern "C" int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* 
   MsgWs w = carve(s, workspace);
   RD_REQUIRE(workspace && workspace_bytes >= w.bytes, "workspace too small: %zu < %zu",
              workspace_bytes, w.bytes);
+  if (fused_msgpass_ok(s)) {
+    if ((rc = fused_msgpass_bwd(s, src, ssum, sv.planes, p_drop, xsave, y1save, z, dz, ldz, w.dz2, w.dz1,
+                                w.rupart, st))) return rc;
+    if ((rc = launch_colsum(w.rupart, B, F * d, F * d, dR_u, w.colsum, st))) return rc;
+  } else {
   {
     const long per = (long)F * K;
     int gy = (int)((per + 255) / 256); if (gy > 64) gy = 64;
@@ -210,26 +251,9 @@ extern "C" int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* 
                      1.0f / (1.0f - p_drop));
   if ((rc = check_launch("k_obs_embed_bwd"))) return rc;
   if ((rc = launch_colsum(w.rupart, B, F * d, F * d, dR_u, w.colsum, st))) return rc;
-  // weight gradients: dW[n,k] = sum_m dzL[m,n] * in[m,k], split over m
-  const float* dzs[2] = {w.dz2, w.dz1};
-  const float* ins[2] = {y1save, xsave};
-  float* dWs[2] = {dW2, dW1};
-  float* dbs[2] = {db2, db1};
-  for (int l = 0; l < 2; ++l) {
-    GemmArgs t{};
-    t.M = K; t.N = K; t.K = M;
-    t.A = dzs[l]; t.sa_m = 1; t.sa_k = K;
-    t.B = ins[l]; t.sb_n = 1; t.sb_k = K;
-    t.nsplit = w.nsplit; t.k_per_split = w.kps;
-    if (w.nsplit > 1) {
-      t.C = w.splitk; t.sc_m = K; t.sc_split = (long)K * K;
-      if ((rc = launch_gemm(t, st))) return rc;
-      if ((rc = launch_splitk_reduce(w.splitk, w.nsplit, (long)K * K, dWs[l], st))) return rc;
-    } else {
-      t.C = dWs[l]; t.sc_m = K;
-      if ((rc = launch_gemm(t, st))) return rc;
-    }
-    if ((rc = launch_colsum(dzs[l], M, K, K, dbs[l], w.colsum, st))) return rc;
   }
+  // weight gradients dW_l = dz_l^T in_l (+ bias gradients as row sums of dz_l^T), split over the B*F rows
+  if ((rc = launch_wgrad(M, K, K, w.dz2, K, y1save, K, dW2, db2, w.splitk, st))) return rc;
+  if ((rc = launch_wgrad(M, K, K, w.dz1, K, xsave, K, dW1, db1, w.splitk, st))) return rc;
   return RD_OK;
 }

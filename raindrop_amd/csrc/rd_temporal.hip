@@ -444,6 +444,77 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, co
     part[(long)blockIdx.x * 2 * D + c] = (red[c] + red[2 * D + c]) + (red[4 * D + c] + red[6 * D + c]);
 }
 
+// register-accumulating form for D <= 64*NV: each lane keeps its columns' dgamma/dbeta partials in
+// VGPRs across the wave's rows; the LDS is touched once per block for the 4-wave combine.
+template <int NV>
+__global__ __launch_bounds__(256) void k_ln_bwd_r(const float* __restrict__ dy, const float* __restrict__ s,
+                                                  const float* __restrict__ stats, const float* __restrict__ g,
+                                                  float* __restrict__ ds_out, float* __restrict__ dr_out,
+                                                  float* __restrict__ part, int M, int D, float p_drop,
+                                                  uint64_t seed, uint32_t site) {
+  extern __shared__ float red[];             // [4][2*D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float inv_keep = 1.0f / (1.0f - p_drop);
+  float gg[NV], ag[NV], ab[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    gg[i] = c < D ? g[c] : 0.f; ag[i] = 0.f; ab[i] = 0.f;
+  }
+  for (int it = 0; it < LN_RPB / 4; ++it) {
+    const long row = (long)blockIdx.x * LN_RPB + wave * (LN_RPB / 4) + it;
+    if (row >= M) break;
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    float xh[NV], dv[NV];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      const bool ok = c < D;
+      xh[i] = ok ? (s[row * D + c] - mean) * rstd : 0.f;
+      dv[i] = ok ? dy[row * D + c] : 0.f;
+      const float dg = dv[i] * gg[i];
+      c1 += dg; c2 += dg * xh[i];
+    }
+    c1 = wave_sum64(c1) / D; c2 = wave_sum64(c2) / D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < D) {
+        const float v = rstd * (dv[i] * gg[i] - c1 - xh[i] * c2);
+        ds_out[row * D + c] = v;
+        float dvv = v;
+        if (p_drop > 0.f) dvv *= dropout_scale(seed, site, (uint64_t)row * D + c, p_drop, inv_keep);
+        dr_out[row * D + c] = dvv;
+        ag[i] += dv[i] * xh[i];
+        ab[i] += dv[i];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < D) { red[wave * 2 * D + c] = ag[i]; red[wave * 2 * D + D + c] = ab[i]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * D; c += 256)
+    part[(long)blockIdx.x * 2 * D + c] = (red[c] + red[2 * D + c]) + (red[4 * D + c] + red[6 * D + c]);
+}
+
+int launch_ln_bwd(const float* dy, const float* s, const float* stats, const float* g, float* ds_out, float* dr_out,
+                  float* part, int M, int D, float p_drop, uint64_t seed, uint32_t site, hipStream_t st) {
+  const int lnb = cdiv(M, LN_RPB);
+  const size_t lds = sizeof(float) * 8 * D;
+  const int nv = cdiv(D, 64);
+#define RD_LN(NV) hipLaunchKernelGGL(k_ln_bwd_r<NV>, dim3(lnb), dim3(256), lds, st, dy, s, stats, g, ds_out, dr_out, \
+                                     part, M, D, p_drop, seed, site)
+  if (nv == 1) RD_LN(1); else if (nv == 2) RD_LN(2); else if (nv == 3) RD_LN(3); else if (nv == 4) RD_LN(4);
+  else hipLaunchKernelGGL(k_ln_bwd, dim3(lnb), dim3(256), lds, st, dy, s, stats, g, ds_out, dr_out, part, M, D,
+                          p_drop, seed, site);
+#undef RD_LN
+  return check_launch("k_ln_bwd");
+}
+
 // code/models_rd.py:366-367,379: agg[b,c] = sum_t r[t,b,c] * (1 - mask[b,t]) / (lengths[b] + 1)
 __global__ __launch_bounds__(256) void k_masked_mean_fwd(const float* __restrict__ r, const uint8_t* __restrict__ mask,
                                                          const int64_t* __restrict__ lengths, float* __restrict__ out,
@@ -494,13 +565,7 @@ EncSaved carve_saved(const EncDims& e, void* base) {
 
 struct EncWs { float *o, *f, *ds2, *df, *du, *dx1, *ds1, *dout, *da, *dqkv, *delta, *lnpart, *lnred, *splitk, *colsum;
                size_t bytes; int ns_max; };
-int bw_nsplit(long M, int N, int K, int* kps) {
-  const int tiles = cdiv(N, 64) * cdiv(K, 64);
-  int ns = cdiv(512, tiles);
-  int per = (int)align_up((size_t)cdiv((int)M, ns), 32);
-  *kps = per;
-  return cdiv((int)M, per);
-}
+int bw_nsplit(long M, int N, int K, int* kps) { return splitk_plan(M, N, K, kps); }
 EncWs carve_ws(const EncDims& e, void* base) {
   EncWs w; size_t off = 0;
   auto take = [&](size_t n) { float* p = base ? (float*)((char*)base + off) : nullptr;
@@ -513,7 +578,8 @@ EncWs carve_ws(const EncDims& e, void* base) {
   w.lnred = take((size_t)2 * e.D + colsum_ws_floats(cdiv((int)e.M, LN_RPB), 2 * e.D));
   size_t sk = 0; int kps;
   const int shapes[4][2] = {{3 * e.D, e.D}, {e.D, e.D}, {e.nhid, e.D}, {e.D, e.nhid}};
-  for (auto& sh : shapes) { size_t v = (size_t)bw_nsplit(e.M, sh[0], sh[1], &kps) * sh[0] * sh[1]; if (v > sk) sk = v; }
+  (void)kps;
+  for (auto& sh : shapes) { size_t v = (size_t)wgrad_ws_floats(e.M, sh[0], sh[1]); if (v > sk) sk = v; }
   w.splitk = take(sk);
   w.colsum = take(colsum_ws_floats((int)e.M, 3 * e.D > e.nhid ? 3 * e.D : e.nhid));
   w.bytes = off;
@@ -539,21 +605,8 @@ int linear_bwd_x(long M, int N, int K, const float* dy, const float* W, float* d
 }
 int linear_bwd_w(long M, int N, int K, const float* dy, const float* x, float* dW, float* db, float* splitk,
                  float* colsum, hipStream_t st) {
-  int kps; const int ns = bw_nsplit(M, N, K, &kps);
-  GemmArgs t{};
-  t.M = N; t.N = K; t.K = (int)M;
-  t.A = dy; t.sa_m = 1; t.sa_k = N; t.B = x; t.sb_n = 1; t.sb_k = K;
-  t.nsplit = ns; t.k_per_split = kps;
-  int rc;
-  if (ns > 1) {
-    t.C = splitk; t.sc_m = K; t.sc_split = (long)N * K;
-    if ((rc = launch_gemm(t, st))) return rc;
-    if ((rc = launch_splitk_reduce(splitk, ns, (long)N * K, dW, st))) return rc;
-  } else {
-    t.C = dW; t.sc_m = K;
-    if ((rc = launch_gemm(t, st))) return rc;
-  }
-  return launch_colsum(dy, (int)M, N, N, db, colsum, st);
+  (void)colsum;
+  return launch_wgrad(M, N, K, dy, N, x, K, dW, db, splitk, st);
 }
 
 int check_enc(const rd_shape* s) {
@@ -632,11 +685,9 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   const uint32_t L = (uint32_t)layer;
   const float keep = 1.0f / (1.0f - p_drop);
   const int lnb = cdiv((int)e.M, LN_RPB);
-  const size_t lnlds = sizeof(float) * 8 * e.D;
   // ---- LayerNorm 2:  ds2 (residual path), df = ds2 o mask(ffn out) -------------------------------
-  hipLaunchKernelGGL(k_ln_bwd, dim3(lnb), dim3(256), lnlds, st, dy, v.s2, v.st2, w->norm2_w, ws.ds2, ws.df, ws.lnpart,
-                     (int)e.M, e.D, p_drop, seed, SITE_FFN_OUT + L);
-  if ((rc = check_launch("k_ln_bwd"))) return rc;
+  if ((rc = launch_ln_bwd(dy, v.s2, v.st2, w->norm2_w, ws.ds2, ws.df, ws.lnpart, (int)e.M, e.D, p_drop, seed,
+                          SITE_FFN_OUT + L, st))) return rc;
   // lnpart is a [blocks, 2D] matrix (dgamma | dbeta per block): column-sum it in fixed order
   if ((rc = launch_colsum(ws.lnpart, lnb, 2 * e.D, 2 * e.D, ws.lnred, ws.lnred + 2 * e.D, st))) return rc;
   hipMemcpyAsync(g->norm2_w, ws.lnred, sizeof(float) * e.D, hipMemcpyDeviceToDevice, st);
@@ -648,9 +699,8 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   if ((rc = linear_bwd_w(e.M, e.nhid, e.D, ws.du, v.x1, g->lin1_w, g->lin1_b, ws.splitk, ws.colsum, st))) return rc;
   if ((rc = linear_bwd_x(e.M, e.nhid, e.D, ws.du, w->lin1_w, ws.dx1, nullptr, 0.f, ws.ds2, st))) return rc;
   // ---- LayerNorm 1 -------------------------------------------------------------------------------
-  hipLaunchKernelGGL(k_ln_bwd, dim3(lnb), dim3(256), lnlds, st, ws.dx1, v.s1, v.st1, w->norm1_w, ws.ds1, ws.dout,
-                     ws.lnpart, (int)e.M, e.D, p_drop, seed, SITE_ATTN_OUT + L);
-  if ((rc = check_launch("k_ln_bwd"))) return rc;
+  if ((rc = launch_ln_bwd(ws.dx1, v.s1, v.st1, w->norm1_w, ws.ds1, ws.dout, ws.lnpart, (int)e.M, e.D, p_drop, seed,
+                          SITE_ATTN_OUT + L, st))) return rc;
   if ((rc = launch_colsum(ws.lnpart, lnb, 2 * e.D, 2 * e.D, ws.lnred, ws.lnred + 2 * e.D, st))) return rc;
   hipMemcpyAsync(g->norm1_w, ws.lnred, sizeof(float) * e.D, hipMemcpyDeviceToDevice, st);
   hipMemcpyAsync(g->norm1_b, ws.lnred + e.D, sizeof(float) * e.D, hipMemcpyDeviceToDevice, st);

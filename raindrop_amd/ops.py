@@ -93,22 +93,20 @@ class _SensorStage(torch.autograd.Function):
         dev = src.device
         z = torch.empty((T, B, D), dtype=torch.float32, device=dev)
         mask = torch.empty((B, T), dtype=torch.bool, device=dev)
-        xsave = torch.empty((B, F, K), dtype=torch.float32, device=dev)
-        y1save = torch.empty((B, F, K), dtype=torch.float32, device=dev)
         sp = ctypes.byref(shp)
+        saved = _workspace(_lib.load().rd_msgpass_saved_bytes(sp), dev)
         _lib.call("rd_pe_mask", sp, _ptr(times), _ptr(lengths), _ptr(ts), _ptr(z), _ptr(mask), _stream())
         _lib.call("rd_msgpass_fwd", sp, _ptr(src), _ptr(R_u), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2),
-                  _ptr(ssum), float(p_drop), int(seed), _ptr(xsave), _ptr(y1save), _ptr(z), D,
-                  _ptr(None), 0, _stream())
+                  _ptr(ssum), float(p_drop), int(seed), _ptr(z), D, _ptr(saved), saved.numel(), _stream())
         ctx.shp = shp
         ctx.p_drop = float(p_drop)
-        ctx.save_for_backward(src, R_u, W1, W2, ssum, xsave, y1save, z)
+        ctx.save_for_backward(src, R_u, W1, W2, ssum, saved, z)
         ctx.mark_non_differentiable(mask)
         return z, mask
 
     @staticmethod
     def backward(ctx, dz, _dmask):
-        src, R_u, W1, W2, ssum, xsave, y1save, z = ctx.saved_tensors
+        src, R_u, W1, W2, ssum, saved, z = ctx.saved_tensors
         shp = ctx.shp
         dz = dz.contiguous()
         K = shp.T * shp.d_ob
@@ -123,7 +121,7 @@ class _SensorStage(torch.autograd.Function):
         nbytes = _lib.load().rd_msgpass_workspace_bytes(sp)
         ws = _workspace(nbytes, dev)
         _lib.call("rd_msgpass_bwd", sp, _ptr(src), _ptr(R_u), _ptr(W1), _ptr(W2), _ptr(ssum),
-                  ctx.p_drop, _ptr(xsave), _ptr(y1save), _ptr(z), _ptr(dz), D, _ptr(dW1), _ptr(db1), _ptr(dW2),
+                  ctx.p_drop, _ptr(saved), saved.numel(), _ptr(z), _ptr(dz), D, _ptr(dW1), _ptr(db1), _ptr(dW2),
                   _ptr(db2), _ptr(dRu), _ptr(ws), ws.numel(), _stream())
         return None, None, None, None, None, dRu, dW1, db1, dW2, db2, None, None, None
 

@@ -47,7 +47,7 @@ def test_argument_errors_are_reported_before_launch(lib):
     shp = _lib.shape(2, 5, 3, 4)
     import ctypes
     assert lib.rd_msgpass_workspace_bytes(ctypes.byref(shp)) > 0
-    rc = lib.rd_msgpass_fwd(ctypes.byref(shp), *([None] * 7), 0.0, 0, *([None] * 3), 12, None, 0, None)
+    rc = lib.rd_msgpass_fwd(ctypes.byref(shp), *([None] * 7), 0.0, 0, None, 12, None, 0, None)
     assert rc == -1 and b"NULL" in lib.rd_last_error()
 
 

@@ -11,10 +11,41 @@ from tests.helpers import MODEL_CASES, build_ours, case_inputs, golden_grad, loa
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+TOL = {"x": 1.0}      # op-level tolerance multiplier, set per precision mode by the fixture below
+
+
+@pytest.fixture(autouse=True, params=["bf16x3", "fp32"])
+def precision_mode(request):
+    """Every parity test runs in both arithmetic modes of the dense contractions: the default
+    split-bf16 MFMA path (~2^-16 per product) and the exact fp32 MFMA path."""
+    from raindrop_amd import _lib
+    _lib.call("rd_set_precision", 1 if request.param == "bf16x3" else 0)
+    TOL["x"] = 6.0 if request.param == "bf16x3" else 1.0
+    yield request.param
+    _lib.call("rd_set_precision", 1)
 
 
 def _rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def _rel2(a, b):
+    return float(np.linalg.norm((a - b).ravel().astype(np.float64)) / (np.linalg.norm(b.ravel().astype(np.float64)) + 1e-30))
+
+
+def _grad_close(a, b, tol, name=""):
+    """Gradient comparison.  fp32 mode: max-norm relative error < tol.  Split-bf16 mode: forward
+    values differ from the reference at the 1e-5 level, so the few ReLU gates whose pre-activation
+    lies within ~1e-5 of zero open/close differently.  ReLU's derivative is discontinuous there:
+    ONE flipped gate moves one row of a weight gradient by |dh|*|x| (measured: 3e-3..8e-3 of the
+    matrix's L2 norm at a few hundred tokens) while every other entry agrees to ~1e-5.  The
+    criterion in that mode is therefore a 2 % relative-L2 bound plus a max-norm bound that still
+    catches any layout / indexing bug (those produce O(1) errors); the exact-fp32 mode keeps the
+    tight bound on the very same kernels and code paths."""
+    if TOL["x"] == 1.0:
+        assert _rel(a, b) < tol, (name, _rel(a, b))
+    else:
+        assert _rel2(a, b) < 2e-2 and _rel(a, b) < 0.25, (name, _rel2(a, b), _rel(a, b))
 
 
 @pytest.mark.parametrize("F,kind", [(1, "ones"), (5, "sparse"), (17, "ones"), (34, "sparse"), (36, "ones"),
@@ -75,9 +106,9 @@ def test_linear_fwd_bwd(M, N, K, act):
     xd, Wd, bd = (t.detach().to(DEV).requires_grad_(True) for t in (x, W, b))
     y = ops.linear(xd, Wd, bd, act)
     hx, hW, hb = torch.autograd.grad(y, [xd, Wd, bd], dy.to(DEV))
-    assert _rel(y.detach().cpu().numpy(), y_ref.detach().numpy()) < 1e-5
-    assert _rel(hx.cpu().numpy(), gx.numpy()) < 1e-5
-    assert _rel(hW.cpu().numpy(), gW.numpy()) < 2e-5
+    assert _rel(y.detach().cpu().numpy(), y_ref.detach().numpy()) < 1e-5 * TOL['x']
+    assert _rel(hx.cpu().numpy(), gx.numpy()) < 1e-5 * TOL['x']
+    assert _rel(hW.cpu().numpy(), gW.numpy()) < 2e-5 * TOL['x']
     assert _rel(hb.cpu().numpy(), gb.numpy()) < 2e-5
 
 
@@ -118,12 +149,12 @@ def test_sensor_stage_vs_oracle(cfg_name, B, kind):
                                ops.timescales(T).to(DEV), ssum, pd[names[0]], pd[names[1]], pd[names[2]],
                                pd[names[3]], pd[names[4]], shp)
     g = torch.autograd.grad(z, [pd[n] for n in names], dz.to(DEV))
-    assert np.abs(z[:, :, : F * d].detach().cpu().numpy() - out_ref.detach().numpy()).max() < 2e-5
+    assert np.abs(z[:, :, : F * d].detach().cpu().numpy() - out_ref.detach().numpy()).max() < 2e-5 * TOL['x']
     pe_ref = O2.positional_encoding(b["times"], T)
     assert np.abs(z[:, :, F * d:].detach().cpu().numpy() - pe_ref.numpy()).max() < 2e-6
     assert np.array_equal(mask.cpu().numpy(), O2.padding_mask(b["lengths"].numpy(), T))
     for n, a, r in zip(names, g, g_ref):
-        assert _rel(a.cpu().numpy(), r.numpy()) < 1e-4, n
+        _grad_close(a.cpu().numpy(), r.numpy(), 1e-4, n)
 
 
 @pytest.mark.parametrize("name", MODEL_CASES)
@@ -145,7 +176,7 @@ def test_model_vs_golden(name):
     assert sorted(n for n, p in params.items() if p.grad is not None) == sorted(live)
     for n in live:
         exp, got = golden_grad(g, n, params[n].grad)
-        assert _rel(got, exp) < 1e-3, n
+        _grad_close(got, exp, 1e-3, n)
         gn = float(g["gradnorm/" + n])
         assert abs(params[n].grad.double().norm().item() - gn) <= 1e-3 * gn + 1e-12, n
     m.eval()
@@ -171,7 +202,7 @@ def test_operator_goldens_on_device():
     ei, ew = O2.build_graph(g["obp_adj"])
     y, (ei_o, alpha) = op(t(g["obp_x"]), p_t=t(g["obp_p_t"]), edge_index=t(ei), edge_weights=t(ew),
                           use_beta=False, edge_attr=None, return_attention_weights=True)
-    assert np.abs(y.detach().cpu().numpy() - g["obp_y"]).max() < 1e-5
+    assert np.abs(y.detach().cpu().numpy() - g["obp_y"]).max() < 1e-5 * TOL['x']
     assert np.array_equal(alpha.cpu().numpy(), g["obp_alpha"]) and np.array_equal(ei_o.cpu().numpy(), g["obp_ei"])
     tc = TransformerConv(9, 12, heads=1)
     synth.fill_params_(tc, seed=12)
@@ -179,7 +210,7 @@ def test_operator_goldens_on_device():
     ei2, ew2 = O2.build_graph(g["tc_adj"])
     y2, (_, a2) = tc(t(g["tc_x"]), edge_index=t(ei2), edge_weights=t(ew2), edge_attr=None,
                      return_attention_weights=True)
-    assert np.abs(y2.detach().cpu().numpy() - g["tc_y"]).max() < 1e-5
+    assert np.abs(y2.detach().cpu().numpy() - g["tc_y"]).max() < 1e-5 * TOL['x']
     assert np.abs(a2.cpu().numpy() - g["tc_alpha"]).max() < 1e-6
 
 
@@ -214,9 +245,9 @@ def test_encoder_layer_vs_oracle(T, B, F, nhead):
     shp = _lib.shape(B, T, F, 4, nhead=nhead, nhid=nhid)
     y = ops.encoder_layer(xd, mask.to(DEV), shp, 0, 0.0, 0, pd)
     g = torch.autograd.grad(y, [xd] + pd, dy.to(DEV))
-    assert np.abs(y.detach().cpu().numpy() - y_ref.detach().numpy()).max() < 5e-5
+    assert np.abs(y.detach().cpu().numpy() - y_ref.detach().numpy()).max() < 5e-5 * TOL['x']
     for name, a, r in zip(["x"] + list(ops.ENC_PARAM_NAMES), g, g_ref):
-        assert _rel(a.cpu().numpy(), r.numpy()) < 2e-4, name
+        _grad_close(a.cpu().numpy(), r.numpy(), 2e-4, name)
 
 
 def test_encoder_layer_dropout_is_consistent():
