@@ -141,11 +141,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
                              "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # RD_BENCH_ONE_GPU=1 (testing only): every rank shares cuda:0 and talks over gloo, so the
+    # multi-rank control flow can be exercised on a 1-GPU box; real runs use one GPU per rank + RCCL.
+    one_gpu = os.environ.get("RD_BENCH_ONE_GPU") == "1"
+    dev_index = 0 if one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from raindrop_amd import dp, synth
     from raindrop_amd.models_rd import Raindrop_v2
@@ -166,7 +173,8 @@ def main():
     live = synth.live_parameter_names(cfg)
     named = dict(model.named_parameters())
     flat = dp.FlatGradAllReduce([(n, named[n]) for n in live], n_buckets=2)
-    opt = torch.optim.Adam([named[n] for n in live], lr=1e-4, fused=True)   # code/Raindrop.py:256
+    # code/Raindrop.py:256 (Adam, lr 1e-4) over the live parameters, held in one flat buffer
+    opt = torch.optim.Adam([flat.flatten_parameters()], lr=1e-4, fused=True)
     criterion = torch.nn.CrossEntropyLoss()
 
     def step():

@@ -43,8 +43,8 @@ struct GemmArgs {
   float* C; long sc_m;            // C(m,n) at C[m*sc_m + n] unless scatter != 0
   int M, N, K;
   int nsplit; int k_per_split; long sc_split;   // split-K: partial z goes to C + z*sc_split, raw
-  float* rowsum;                  // optional: rowsum[z*M + m] = sum_k A(m,k) over this split (bias gradients
-                                  // ride along the weight-gradient product instead of a second pass over dy)
+  float* rowsum; long rowsum_split;   // optional: rowsum[z*rowsum_split + m] = sum_k A(m,k) over this split (bias
+                                  // gradients ride along the weight-gradient product: no second pass over dy)
   // epilogue (ignored when nsplit > 1)
   const float* bias;              // [N]
   const float* rowscale; int rs_period;          // * rowscale[m % rs_period]
@@ -67,6 +67,9 @@ int launch_wgrad(long M, int N, int K, const float* dy, long lddy, const float* 
                  float* db, float* ws, hipStream_t st);
 // sum `nsplit` partials [nsplit][rows*cols] in fixed order into out
 int launch_splitk_reduce(const float* part, int nsplit, long elems, float* out, hipStream_t st);
+// same with partials `stride` floats apart; elements [0,e1) go to out1, [e1, e1+e2) to out2
+int launch_splitk_reduce2(const float* part, int nsplit, long stride, long e1, float* out1, long e2, float* out2,
+                          hipStream_t st);
 // out[n] = sum_m x[m*ldx + n], deterministic two-stage; ws needs colsum_ws_floats(M,N) floats
 long colsum_ws_floats(int M, int N);
 int launch_colsum(const float* x, int M, int N, long ldx, float* out, float* ws, hipStream_t st);

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     red[wave * 64 + lane] = rsum;
     __syncthreads();
     if (tid < 64 && m0 + tid < g.M)
-      g.rowsum[(long)z * g.M + m0 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+      g.rowsum[(long)z * g.rowsum_split + m0 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
   }
   epilogue(g, acc, m0 + wy * 32, n0 + wx * 32, z, lane);
 }
@@ -185,140 +185,301 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int BK2 = 64, LDB = BK2 + 8;   // bf16 elements; 144-B rows (16-B aligned, conflict-free b128)
 
-// KC: thread owns rows {tid/16 + 16p, p<4}, k quad (tid%16)*4.   MC: row tid%64, k = (tid/64)*16 + i.
-template <bool KC>
-__device__ __forceinline__ void stage_load2(float (&r)[16], const float* __restrict__ P, long s_row,
-                                            long s_k, int row0, int nrows, int k0, int kend, int tid,
-                                            bool vec_ok) {
-  if (KC) {
-    const int kq = k0 + (tid & 15) * 4;
+// Tile = (32*MI) x (32*NI) outputs per 256-thread workgroup (2x2 waves, each 16*MI x 16*NI), K step 64.
+// Staging of a ROWS x 64 fp32 tile (ROWS = 32*MI or 32*NI):
+//   KC (k contiguous in memory): thread owns rows {tid/16 + 16p}, k quad (tid%16)*4  -> float4 loads;
+//   MC (row contiguous in memory, ROWS in {64,128}): thread owns row tid%ROWS and 64/(256/ROWS)
+//      consecutive k -> dword loads coalesced along the rows, 16-B LDS stores.
+template <bool KC, int ROWS>
+struct Stage {
+  static constexpr int NREG = ROWS / 4;                      // fp32 values per thread per tile
+  static constexpr int TPR = 256 / ROWS;                     // MC: threads per row
+  static constexpr int KPT = 64 / (TPR > 0 ? TPR : 1);       // MC: consecutive k per thread
+  __device__ static __forceinline__ void load(float (&r)[NREG], const float* __restrict__ P, long s_row,
+                                              long s_k, int row0, int nrows, int k0, int kend, int tid,
+                                              bool vec_ok) {
+    if (KC) {
+      const int kq = k0 + (tid & 15) * 4;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int row = row0 + p * 16 + (tid >> 4);
+      for (int p = 0; p < ROWS / 16; ++p) {
+        const int row = row0 + p * 16 + (tid >> 4);
+        const bool rok = row < nrows;
+        if (rok && vec_ok && kq + 3 < kend) {
+          const float4 v = *reinterpret_cast<const float4*>(P + (long)row * s_row + kq);
+          r[p * 4 + 0] = v.x; r[p * 4 + 1] = v.y; r[p * 4 + 2] = v.z; r[p * 4 + 3] = v.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            r[p * 4 + j] = (rok && kq + j < kend) ? P[(long)row * s_row + kq + j] : 0.f;
+        }
+      }
+    } else {
+      const int row = row0 + (tid % ROWS);
       const bool rok = row < nrows;
-      if (rok && vec_ok && kq + 3 < kend) {
-        const float4 v = *reinterpret_cast<const float4*>(P + (long)row * s_row + kq);
-        r[p * 4 + 0] = v.x; r[p * 4 + 1] = v.y; r[p * 4 + 2] = v.z; r[p * 4 + 3] = v.w;
-      } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          r[p * 4 + j] = (rok && kq + j < kend) ? P[(long)row * s_row + kq + j] : 0.f;
+      for (int i = 0; i < NREG; ++i) {
+        const int k = k0 + (tid / ROWS) * KPT + i;
+        r[i] = (rok && k < kend) ? P[(long)row * s_row + (long)k * s_k] : 0.f;
       }
     }
-  } else {
-    const int row = row0 + (tid & 63);
-    const bool rok = row < nrows;
+  }
+  __device__ static __forceinline__ void store(const float (&r)[NREG], __bf16* __restrict__ Th,
+                                               __bf16* __restrict__ Tl, int tid) {
+    if (KC) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int k = k0 + (tid >> 6) * 16 + i;
-      r[i] = (rok && k < kend) ? P[(long)row * s_row + (long)k * s_k] : 0.f;
+      for (int p = 0; p < ROWS / 16; ++p) {
+        bf16x4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float x = r[p * 4 + j];
+          h[j] = (__bf16)x;
+          l[j] = (__bf16)(x - (float)h[j]);
+        }
+        const int o = (p * 16 + (tid >> 4)) * LDB + (tid & 15) * 4;
+        *reinterpret_cast<bf16x4*>(Th + o) = h;
+        *reinterpret_cast<bf16x4*>(Tl + o) = l;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NREG / 8; ++q) {
+        bf16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float x = r[q * 8 + j];
+          h[j] = (__bf16)x;
+          l[j] = (__bf16)(x - (float)h[j]);
+        }
+        const int o = (tid % ROWS) * LDB + (tid / ROWS) * KPT + q * 8;
+        *reinterpret_cast<bf16x8*>(Th + o) = h;
+        *reinterpret_cast<bf16x8*>(Tl + o) = l;
+      }
+    }
+  }
+};
+
+// Tile epilogue through LDS.  The MFMA accumulator layout gives a lane 4 consecutive ROWS of one
+// column, i.e. 64-byte store segments; the tile is therefore transposed through LDS (the operand
+// planes are dead by now) so that each thread owns 4 consecutive COLUMNS of one row: bias /
+// mask / residual reads and the output stores become 16-byte accesses in 256..640-byte runs, and the
+// Philox dropout mask costs one evaluation per 4 elements.
+template <int MI, int NI>
+__device__ __forceinline__ void epilogue_t(const GemmArgs& g, f32x4 (&acc)[MI][NI], float* stage, int m0, int n0,
+                                           int wy, int wx, int z, int tid, int lane) {
+  constexpr int TM = 32 * MI, TN = 32 * NI, LDSG = TN + 4;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        stage[(wy * 16 * MI + i * 16 + 4 * (lane >> 4) + r) * LDSG + wx * 16 * NI + j * 16 + (lane & 15)] = acc[i][j][r];
+  __syncthreads();
+  float* Cz = g.C + (long)z * g.sc_split;
+  const bool raw = g.nsplit > 1;
+  const bool vec = ((g.N & 3) == 0) && ((g.sc_m & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cz) & 15) == 0) &&
+                   !g.scatter && (!g.posmask || (((g.pm_m & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.posmask) & 15) == 0))) &&
+                   (!g.residual || (((g.res_m & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.residual) & 15) == 0)));
+  const float inv_keep = 1.0f / (1.0f - g.drop_p);
+  constexpr int QPR = TN / 4;                         // column quads per tile row
+  for (int e = tid; e < TM * QPR; e += 256) {
+    const int rl = e / QPR, q = e - rl * QPR;
+    const int m = m0 + rl, n = n0 + 4 * q;
+    if (m >= g.M || n >= g.N) continue;
+    const float4 a4 = *reinterpret_cast<const float4*>(stage + rl * LDSG + 4 * q);
+    float v[4] = {a4.x, a4.y, a4.z, a4.w};
+    const int nv = min(4, g.N - n);
+    if (!raw) {
+      const float rsc = g.rowscale ? g.rowscale[m % g.rs_period] : 1.f;
+      float4 du = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (g.drop_p > 0.f) {
+        if (vec) {
+          du = uniform4(g.drop_seed, g.drop_site, ((uint64_t)m * g.N + n) >> 2);
+        } else {
+          float t4[4];
+          for (int c = 0; c < 4; ++c)
+            t4[c] = dropout_scale(g.drop_seed, g.drop_site, (uint64_t)m * g.N + n + c, g.drop_p, 1.f) > 0.f ? 1.f : 0.f;
+          du = make_float4(t4[0], t4[1], t4[2], t4[3]);     // 1 = keep (>= p), 0 = drop (< p)
+        }
+      }
+      const float uu[4] = {du.x, du.y, du.z, du.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c >= nv) break;
+        float x = v[c];
+        if (g.bias) x += g.bias[n + c];
+        if (g.relu) x = fmaxf(x, 0.f);
+        x *= rsc;
+        if (g.posmask) x = (g.posmask[(long)m * g.pm_m + n + c] > 0.f) ? x : 0.f;
+        if (g.cscale != 0.f) x *= g.cscale;
+        if (g.drop_p > 0.f) x = (uu[c] >= g.drop_p) ? x * inv_keep : 0.f;
+        if (g.residual) x += g.residual[(long)m * g.res_m + n + c];
+        v[c] = x;
+      }
+    }
+    if (g.scatter && !raw) {
+      const int b = m / g.sF, f = m - b * g.sF;
+      for (int c = 0; c < nv; ++c) {
+        const int t = (n + c) / g.sd, cc = (n + c) - t * g.sd;
+        g.C[((long)t * g.sB + b) * g.ldz + f * g.sd + cc] = v[c];
+      }
+    } else if (vec) {
+      *reinterpret_cast<float4*>(Cz + (long)m * g.sc_m + n) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      for (int c = 0; c < nv; ++c) Cz[(long)m * g.sc_m + n + c] = v[c];
     }
   }
 }
 
-template <bool KC>
-__device__ __forceinline__ void stage_store2(const float (&r)[16], __bf16* __restrict__ Th,
-                                             __bf16* __restrict__ Tl, int tid) {
-  if (KC) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      bf16x4 h, l;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float x = r[p * 4 + j];
-        h[j] = (__bf16)x;
-        l[j] = (__bf16)(x - (float)h[j]);
-      }
-      const int o = (p * 16 + (tid >> 4)) * LDB + (tid & 15) * 4;
-      *reinterpret_cast<bf16x4*>(Th + o) = h;
-      *reinterpret_cast<bf16x4*>(Tl + o) = l;
-    }
-  } else {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      bf16x8 h, l;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float x = r[q * 8 + j];
-        h[j] = (__bf16)x;
-        l[j] = (__bf16)(x - (float)h[j]);
-      }
-      const int o = (tid & 63) * LDB + (tid >> 6) * 16 + q * 8;
-      *reinterpret_cast<bf16x8*>(Th + o) = h;
-      *reinterpret_cast<bf16x8*>(Tl + o) = l;
-    }
-  }
-}
-
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, int MI, int NI>
 __global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) __bf16 Ah[BM * LDB];
-  __shared__ __attribute__((aligned(16))) __bf16 Al[BM * LDB];
-  __shared__ __attribute__((aligned(16))) __bf16 Bh[BN * LDB];
-  __shared__ __attribute__((aligned(16))) __bf16 Bl[BN * LDB];
+  constexpr int TM = 32 * MI, TN = 32 * NI;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+  __bf16* Ah = reinterpret_cast<__bf16*>(gsm);
+  __bf16* Al = Ah + TM * LDB;
+  __bf16* Bh = Al + TM * LDB;
+  __bf16* Bl = Bh + TN * LDB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wy = wave >> 1, wx = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
   const int z = blockIdx.z;
   const int kbeg = z * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
   const bool a_vec = A_KC && ((g.sa_m & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
   const bool b_vec = B_KC && ((g.sb_n & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
-  f32x4 acc[2][2];
+  f32x4 acc[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float ra[16], rb[16];
-  float rsum = 0.f;                                   // MC staging: this thread's row is tid & 63
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  using SA = Stage<A_KC, TM>;
+  using SB = Stage<B_KC, TN>;
+  float ra[SA::NREG], rb[SB::NREG];
+  float rsum = 0.f;                                   // MC staging: this thread's row is tid % TM
   const bool do_rowsum = !A_KC && g.rowsum != nullptr && blockIdx.x == 0;
   if (kbeg < kend) {
-    stage_load2<A_KC>(ra, g.A, g.sa_m, g.sa_k, m0, g.M, kbeg, kend, tid, a_vec);
-    stage_load2<B_KC>(rb, g.B, g.sb_n, g.sb_k, n0, g.N, kbeg, kend, tid, b_vec);
+    SA::load(ra, g.A, g.sa_m, g.sa_k, m0, g.M, kbeg, kend, tid, a_vec);
+    SB::load(rb, g.B, g.sb_n, g.sb_k, n0, g.N, kbeg, kend, tid, b_vec);
   }
   for (int k0 = kbeg; k0 < kend; k0 += BK2) {
     if (do_rowsum) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) rsum += ra[i];
+      for (int i = 0; i < SA::NREG; ++i) rsum += ra[i];
     }
-    stage_store2<A_KC>(ra, Ah, Al, tid);
-    stage_store2<B_KC>(rb, Bh, Bl, tid);
+    SA::store(ra, Ah, Al, tid);
+    SB::store(rb, Bh, Bl, tid);
     __syncthreads();
     if (k0 + BK2 < kend) {
-      stage_load2<A_KC>(ra, g.A, g.sa_m, g.sa_k, m0, g.M, k0 + BK2, kend, tid, a_vec);
-      stage_load2<B_KC>(rb, g.B, g.sb_n, g.sb_k, n0, g.N, k0 + BK2, kend, tid, b_vec);
+      SA::load(ra, g.A, g.sa_m, g.sa_k, m0, g.M, k0 + BK2, kend, tid, a_vec);
+      SB::load(rb, g.B, g.sb_n, g.sb_k, n0, g.N, k0 + BK2, kend, tid, b_vec);
     }
 #pragma unroll
     for (int kc = 0; kc < BK2; kc += 32) {
-      bf16x8 ah[2], al[2], bh[2], bl[2];
+      bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int oa = (wy * 32 + i * 16 + (lane & 15)) * LDB + kc + 8 * (lane >> 4);
-        const int ob = (wx * 32 + i * 16 + (lane & 15)) * LDB + kc + 8 * (lane >> 4);
+      for (int i = 0; i < MI; ++i) {
+        const int oa = (wy * 16 * MI + i * 16 + (lane & 15)) * LDB + kc + 8 * (lane >> 4);
         ah[i] = *reinterpret_cast<const bf16x8*>(Ah + oa);
         al[i] = *reinterpret_cast<const bf16x8*>(Al + oa);
-        bh[i] = *reinterpret_cast<const bf16x8*>(Bh + ob);
-        bl[i] = *reinterpret_cast<const bf16x8*>(Bl + ob);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < NI; ++j) {
+        const int ob = (wx * 16 * NI + j * 16 + (lane & 15)) * LDB + kc + 8 * (lane >> 4);
+        bh[j] = *reinterpret_cast<const bf16x8*>(Bh + ob);
+        bl[j] = *reinterpret_cast<const bf16x8*>(Bl + ob);
+      }
+      // three passes over independent accumulators: no back-to-back MFMA on the same registers
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
     }
     __syncthreads();
   }
-  if (do_rowsum) {                                    // 4 threads (one per wave) share a row
-    float* red = reinterpret_cast<float*>(Ah);
-    red[wave * 64 + lane] = rsum;
+  if (do_rowsum) {                                    // TPR threads share a row; combine in fixed order
+    float* red = reinterpret_cast<float*>(gsm);
+    red[tid] = rsum;
     __syncthreads();
-    if (tid < 64 && m0 + tid < g.M)
-      g.rowsum[(long)z * g.M + m0 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+    if (tid < TM && m0 + tid < g.M) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < 256 / TM; ++q) v += red[q * TM + tid];
+      g.rowsum[(long)z * g.rowsum_split + m0 + tid] = v;
+    }
+    __syncthreads();
   }
-  epilogue(g, acc, m0 + wy * 32, n0 + wx * 32, z, lane);
+  epilogue_t<MI, NI>(g, acc, reinterpret_cast<float*>(gsm), m0, n0, wy, wx, z, tid, lane);
+}
+
+template <bool A_KC, bool B_KC, int MI, int NI>
+int launch_bf16x3(const GemmArgs& g, hipStream_t st) {
+  constexpr int TM = 32 * MI, TN = 32 * NI;
+  const size_t planes = (size_t)2 * (TM + TN) * LDB * sizeof(__bf16);
+  const size_t stage = (size_t)TM * (TN + 4) * sizeof(float);       // epilogue transpose tile (aliases the planes)
+  const size_t lds = planes > stage ? planes : stage;
+  dim3 grid(cdiv(g.N, TN), cdiv(g.M, TM), g.nsplit > 1 ? g.nsplit : 1);
+  if (lds > 48 * 1024)
+    hipFuncSetAttribute((const void*)k_gemm_bf16x3<A_KC, B_KC, MI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds);
+  hipLaunchKernelGGL((k_gemm_bf16x3<A_KC, B_KC, MI, NI>), grid, dim3(256), lds, st, g);
+  return check_launch("k_gemm_bf16x3");
+}
+
+// padded work / tile efficiency: bigger tiles re-read less and amortise the barrier, but waste
+// more on ragged edges; pick the cheapest legal (MI, NI).
+template <bool A_KC, bool B_KC>
+int dispatch_bf16x3(const GemmArgs& g, hipStream_t st) {
+  static const int cand[][2] = {{2, 2}, {4, 2}, {4, 4}, {2, 4}, {4, 5}, {2, 5}};
+  int best = 0; double bcost = 1e300;
+  for (int c = 0; c < 6; ++c) {
+    const int mi = cand[c][0], ni = cand[c][1];
+    if (ni == 5 && !B_KC) continue;                  // 160-row staging only exists for k-contiguous operands
+    const double tm = 32.0 * mi, tn = 32.0 * ni;
+    const double padded = (double)cdiv(g.M, (int)tm) * tm * cdiv(g.N, (int)tn) * tn;
+    const double blocks = (double)cdiv(g.M, (int)tm) * cdiv(g.N, (int)tn) * (g.nsplit > 1 ? g.nsplit : 1);
+    // measured on MI355X: with this (unpipelined) main loop the 64x64 tile at 4 workgroups/CU beats
+    // the fatter tiles at 1-2 workgroups/CU by 1.5-3x on every shape of the path, so bigger tiles
+    // are only chosen when they are essentially free of padding AND the grid stays >= 8 blocks/CU.
+    double cost = padded * (1.0 + 16.0 / tm + 16.0 / tn);
+    if (blocks < 2048 && (mi > 2 || ni > 2)) cost *= 4.0;
+    if (blocks < 192) cost *= 192.0 / blocks;        // do not starve the 256 CUs
+    if (cost < bcost) { bcost = cost; best = c; }
+  }
+  switch (best) {
+    case 0: return launch_bf16x3<A_KC, B_KC, 2, 2>(g, st);
+    case 1: return launch_bf16x3<A_KC, B_KC, 4, 2>(g, st);
+    case 2: return launch_bf16x3<A_KC, B_KC, 4, 4>(g, st);
+    case 3: return launch_bf16x3<A_KC, B_KC, 2, 4>(g, st);
+    case 4: return launch_bf16x3<A_KC, true, 4, 5>(g, st);
+    default: return launch_bf16x3<A_KC, true, 2, 5>(g, st);
+  }
+}
+
+__global__ void k_splitk_reduce2(const float* __restrict__ part, int nsplit, long stride, long e1,
+                                 float* __restrict__ out1, long e2, float* __restrict__ out2) {
+  const long elems = e1 + e2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < elems;
+       i += (long)gridDim.x * blockDim.x) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+    for (; z + 3 < nsplit; z += 4) {                     // 4 independent chains, combined in fixed order
+      s0 += part[(long)z * stride + i]; s1 += part[(long)(z + 1) * stride + i];
+      s2 += part[(long)(z + 2) * stride + i]; s3 += part[(long)(z + 3) * stride + i];
+    }
+    for (; z < nsplit; ++z) s0 += part[(long)z * stride + i];
+    const float v = (s0 + s1) + (s2 + s3);
+    if (i < e1) out1[i] = v; else out2[i - e1] = v;
+  }
 }
 
 __global__ void k_splitk_reduce(const float* __restrict__ part, int nsplit, long elems,
@@ -350,6 +511,32 @@ __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ x
                                      (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// single-stage column sum for short matrices: 1024 threads = 64 columns x 16 row groups, all of a
+// thread's loads independent (deep memory-level parallelism), fixed-order LDS combine.
+__global__ __launch_bounds__(1024) void k_colsum_small(const float* __restrict__ x, int M, int N, long ldx,
+                                                       float* __restrict__ out) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < N) {
+    int r = rg;
+    for (; r + 48 < M; r += 64) {
+      s0 += x[(long)r * ldx + c]; s1 += x[(long)(r + 16) * ldx + c];
+      s2 += x[(long)(r + 32) * ldx + c]; s3 += x[(long)(r + 48) * ldx + c];
+    }
+    for (; r < M; r += 16) s0 += x[(long)r * ldx + c];
+  }
+  red[rg][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && c < N) {
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += red[q][cl];
+    out[c] = v;
+  }
+}
+
 }  // namespace
 
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
@@ -363,11 +550,10 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (g.nsplit <= 1) { g.nsplit = 1; g.k_per_split = g.K > 0 ? g.K : 1; g.sc_split = 0; }
   if (precision() == RD_PREC_BF16X3) {
     if (g.nsplit > 1 && (g.k_per_split % BK2) != 0) return fail(RD_EINVAL, "gemm: k_per_split must be a multiple of 64");
-    if (akc && bkc) hipLaunchKernelGGL((k_gemm_bf16x3<true, true>), grid, dim3(256), 0, st, g);
-    else if (akc && !bkc) hipLaunchKernelGGL((k_gemm_bf16x3<true, false>), grid, dim3(256), 0, st, g);
-    else if (!akc && bkc) hipLaunchKernelGGL((k_gemm_bf16x3<false, true>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((k_gemm_bf16x3<false, false>), grid, dim3(256), 0, st, g);
-    return check_launch("k_gemm_bf16x3");
+    if (akc && bkc) return dispatch_bf16x3<true, true>(g, st);
+    if (akc && !bkc) return dispatch_bf16x3<true, false>(g, st);
+    if (!akc && bkc) return dispatch_bf16x3<false, true>(g, st);
+    return dispatch_bf16x3<false, false>(g, st);
   }
   if (akc && bkc) hipLaunchKernelGGL((k_gemm<true, true>), grid, dim3(256), 0, st, g);
   else if (akc && !bkc) hipLaunchKernelGGL((k_gemm<true, false>), grid, dim3(256), 0, st, g);
@@ -378,7 +564,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
 
 int splitk_plan(long red, int rows, int cols, int* k_per_split) {
   const int tiles = cdiv(rows, BM) * cdiv(cols, BN);
-  const int want = cdiv(512, tiles);
+  const int want = cdiv(320, tiles);                     // ~1.25 workgroups per CU in total
   const int r = red > 0 ? (int)red : 1;
   int per = (int)align_up((size_t)cdiv(r, want), 64);
   *k_per_split = per;
@@ -399,19 +585,26 @@ int launch_wgrad(long M, int N, int K, const float* dy, long lddy, const float* 
   t.A = dy; t.sa_m = 1; t.sa_k = lddy;
   t.B = x; t.sb_n = 1; t.sb_k = ldx;
   t.nsplit = ns; t.k_per_split = kps;
-  float* part = ws;
-  float* rpart = ws + (long)ns * N * K;
+  const long stride = (long)N * K + N;                 // split z: [dW partial | db partial]
   int rc;
   if (ns > 1) {
-    t.C = part; t.sc_m = K; t.sc_split = (long)N * K; t.rowsum = db ? rpart : nullptr;
+    t.C = ws; t.sc_m = K; t.sc_split = stride;
+    t.rowsum = db ? ws + (long)N * K : nullptr; t.rowsum_split = stride;
     if ((rc = launch_gemm(t, st))) return rc;
-    if ((rc = launch_splitk_reduce(part, ns, (long)N * K, dW, st))) return rc;
-    if (db && (rc = launch_splitk_reduce(rpart, ns, N, db, st))) return rc;
-  } else {
-    t.C = dW; t.sc_m = K; t.rowsum = db;
-    if ((rc = launch_gemm(t, st))) return rc;
+    return launch_splitk_reduce2(ws, ns, stride, (long)N * K, dW, db ? N : 0, db, st);
   }
-  return RD_OK;
+  t.C = dW; t.sc_m = K; t.rowsum = db; t.rowsum_split = 0;
+  return launch_gemm(t, st);
+}
+
+int launch_splitk_reduce2(const float* part, int nsplit, long stride, long e1, float* out1, long e2, float* out2,
+                          hipStream_t st) {
+  const long elems = e1 + e2;
+  if (elems <= 0) return RD_OK;
+  int blocks = (int)((elems + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_splitk_reduce2, dim3(blocks), dim3(256), 0, st, part, nsplit, stride, e1, out1, e2, out2);
+  return check_launch("k_splitk_reduce2");
 }
 
 int launch_splitk_reduce(const float* part, int nsplit, long elems, float* out, hipStream_t st) {
@@ -426,6 +619,10 @@ long colsum_ws_floats(int M, int N) { return (long)cdiv(M, CS_RPB) * N; }
 
 int launch_colsum(const float* x, int M, int N, long ldx, float* out, float* ws, hipStream_t st) {
   if (N <= 0) return RD_OK;
+  if (M <= 8192) {
+    hipLaunchKernelGGL(k_colsum_small, dim3(cdiv(N, 64)), dim3(1024), 0, st, x, M, N, ldx, out);
+    return check_launch("k_colsum_small");
+  }
   const int nby = cdiv(M, CS_RPB);
   hipLaunchKernelGGL(k_colsum_part, dim3(cdiv(N, 64), nby), dim3(256), 0, st, x, M, N, ldx, ws);
   int rc = check_launch("k_colsum_part");

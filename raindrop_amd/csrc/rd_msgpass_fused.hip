@@ -40,7 +40,13 @@ struct FusedArgs {
   float *dz2save, *dz1save, *rupart;
   int B, T, F, d, K, ldz;
   float p_drop; uint64_t seed;
+  unsigned long long* stamps;    // debug: per-phase clock64() of wave 0 of the first 8 workgroups
 };
+
+#define RD_STAMP(i)                                                                              \
+  do {                                                                                           \
+    if (a.stamps && blockIdx.x < 8 && threadIdx.x == 0) a.stamps[blockIdx.x * 16 + (i)] = clock64(); \
+  } while (0)
 
 __device__ __forceinline__ const __bf16* plane(const FusedArgs& a, int layer, int orient, int part) {
   return a.wplanes + ((size_t)((layer * 2 + orient) * 2 + part)) * a.K * KP;
@@ -71,33 +77,35 @@ __global__ __launch_bounds__(256) void k_wprep(const float* __restrict__ W1, con
   }
 }
 
-// acc[jj][rt] (16x16 tiles) += A[rows rt*16.., KP] * Bplanes[cols (w + 8*jj)*16.., KP]^T
-// A planes in LDS (hi/lo), B planes in global/L2 (rows = output column index, KP contiguous).
-// The wave's whole weight panel (2 column tiles x 256 k x hi/lo = 128 VGPRs) is requested up front,
-// so a GEMM exposes ONE L2 round trip instead of one per k-chunk; the MFMAs then drain it in order.
-template <int RT>
-__device__ __forceinline__ void gemm_planes(f32x4 (&acc)[NJ][RT], const __bf16* Ah, const __bf16* Al,
-                                            const __bf16* __restrict__ Bh, const __bf16* __restrict__ Bl,
-                                            int nct, int wave, int lane) {
-  constexpr int NKC = KP / 32;
-  const int aoff = (lane & 15) * LDX + 8 * (lane >> 4);
-  bf16x8 bh[NJ][NKC], bl[NJ][NKC];
-  bool ok[NJ];
+// The wave's weight panel: column tiles {w, w+8} x 256 k x hi/lo = 128 VGPRs per lane, requested
+// in one burst so a GEMM exposes ONE L2 round trip; issued a whole phase before it is consumed
+// (during the observation embedding / the previous layer's epilogue) so that trip is hidden too.
+struct Panel {
+  bf16x8 h[NJ][KP / 32], l[NJ][KP / 32];
+};
+
+__device__ __forceinline__ void load_panel(Panel& p, const __bf16* __restrict__ Bh,
+                                           const __bf16* __restrict__ Bl, int nct, int wave, int lane) {
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
     const int j = wave + NWAVE * jj;
-    ok[jj] = j < nct;
-    const size_t boff = (size_t)(16 * (ok[jj] ? j : 0) + (lane & 15)) * KP + 8 * (lane >> 4);
-    if (ok[jj]) {
+    const size_t boff = (size_t)(16 * (j < nct ? j : 0) + (lane & 15)) * KP + 8 * (lane >> 4);
 #pragma unroll
-      for (int kc = 0; kc < NKC; ++kc) {
-        bh[jj][kc] = *reinterpret_cast<const bf16x8*>(Bh + boff + kc * 32);
-        bl[jj][kc] = *reinterpret_cast<const bf16x8*>(Bl + boff + kc * 32);
-      }
+    for (int kc = 0; kc < KP / 32; ++kc) {
+      p.h[jj][kc] = *reinterpret_cast<const bf16x8*>(Bh + boff + kc * 32);
+      p.l[jj][kc] = *reinterpret_cast<const bf16x8*>(Bl + boff + kc * 32);
     }
   }
+}
+
+// acc[jj][rt] (16x16 tiles) += A[rows rt*16.., KP] * panel^T ; A planes (hi/lo) in LDS.
+// The three split products are issued as three sweeps over independent accumulators.
+template <int RT>
+__device__ __forceinline__ void mma_panel(f32x4 (&acc)[NJ][RT], const __bf16* Ah, const __bf16* Al,
+                                          const Panel& p, int lane) {
+  const int aoff = (lane & 15) * LDX + 8 * (lane >> 4);
 #pragma unroll
-  for (int kc = 0; kc < NKC; ++kc) {
+  for (int kc = 0; kc < KP / 32; ++kc) {
     bf16x8 ah[RT], al[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -106,14 +114,19 @@ __device__ __forceinline__ void gemm_planes(f32x4 (&acc)[NJ][RT], const __bf16* 
     }
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj)
-      if (ok[jj]) {
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], bh[jj][kc], acc[jj][rt], 0, 0, 0);
-          acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], bl[jj][kc], acc[jj][rt], 0, 0, 0);
-          acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], bh[jj][kc], acc[jj][rt], 0, 0, 0);
-        }
-      }
+      for (int rt = 0; rt < RT; ++rt)
+        acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], p.h[jj][kc], acc[jj][rt], 0, 0, 0);
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+        acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.l[jj][kc], acc[jj][rt], 0, 0, 0);
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+        acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.h[jj][kc], acc[jj][rt], 0, 0, 0);
   }
 }
 
@@ -123,6 +136,13 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[NJ][RT]) {
   for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) acc[jj][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
+// zero `bytes` of LDS (multiple of 16) with 16-byte stores, no index arithmetic
+__device__ __forceinline__ void zero_lds(void* p, int bytes, int tid) {
+  float4* q = reinterpret_cast<float4*>(p);
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid; i < bytes / 16; i += NTHR) q[i] = z;
 }
 
 // zero the pad columns [K, KP) of every row and the pad rows [F, RT*16) of two planes
@@ -155,85 +175,141 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   const int T = a.T, F = a.F, d = a.d, K = a.K, B = a.B;
   const int nct = K / 16;
   const float inv_keep = 1.0f / (1.0f - a.p_drop);
+  (void)d;
+
+  RD_STAMP(0);
+  // weight panel of layer 1 is requested first: its L2 round trip overlaps the embedding below
+  Panel pw;
+  load_panel(pw, plane(a, 0, 0, 0), plane(a, 0, 0, 1), nct, wave, lane);
+  float srow[RT][4];                                     // aggregate coefficient of this lane's rows
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rt * 16 + 4 * (lane >> 4) + r;
+      srow[rt][r] = row < F ? a.ssum[row] : 0.f;
+    }
 
   // ---- observation embedding -> X planes (+ fp32 copy for the weight-gradient pass) ------------
-  zero_pads(Xh, Xl, ROWS, F, K, tid);
-  zero_pads(Yh, Yl, ROWS, F, K, tid);
-  if (d == 4) {
-    for (int i = tid; i < F * T; i += NTHR) {
-      const int f = i / T, t = i - f * T;
-      const float v = a.src[((size_t)t * B + b) * (2 * F) + f];
-      float x[4];
+  zero_lds(smem_raw, 4 * ROWS * LDX * (int)sizeof(__bf16), tid);    // pads of all four planes
+  __syncthreads();
+  {
+    // thread -> (f, t) with t fastest: LDS / xsave writes are contiguous; the strided src reads hit
+    // each 128-B line F times within the workgroup (L1).  All of a thread's loads issue together,
+    // and the body is branch-free (one Philox call yields the 4 channel masks of a (t, f) cell).
+    constexpr int UNR = 4;
+    const int total = F * T;
+    for (int base = tid; base < total; base += NTHR * UNR) {
+      float v[UNR]; int fi[UNR], ti[UNR];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        x[c] = fmaxf(v * a.R_u[f * 4 + c], 0.f);
-        if (a.p_drop > 0.f && x[c] > 0.f)
-          x[c] *= dropout_scale(a.seed, SITE_OBS_EMBED, ((uint64_t)t * B + b) * (F * 4) + f * 4 + c, a.p_drop, inv_keep);
+      for (int u = 0; u < UNR; ++u) {
+        const int i = min(base + u * NTHR, total - 1);       // clamped duplicates rewrite the same cell
+        fi[u] = i / T; ti[u] = i - fi[u] * T;
+        v[u] = a.src[((size_t)ti[u] * B + b) * (2 * F) + fi[u]];
       }
-      split_store4(Xh + f * LDX + 4 * t, Xl + f * LDX + 4 * t, x);
-      *reinterpret_cast<float4*>(a.xsave + ((size_t)b * F + f) * K + 4 * t) = make_float4(x[0], x[1], x[2], x[3]);
-    }
-  } else {
-    for (int i = tid; i < F * K; i += NTHR) {
-      const int f = i / K, k = i - f * K, t = k / d, c = k - t * d;
-      float x = fmaxf(a.src[((size_t)t * B + b) * (2 * F) + f] * a.R_u[f * d + c], 0.f);
-      if (a.p_drop > 0.f && x > 0.f)
-        x *= dropout_scale(a.seed, SITE_OBS_EMBED, ((uint64_t)t * B + b) * (F * d) + f * d + c, a.p_drop, inv_keep);
-      const __bf16 h = (__bf16)x;
-      Xh[f * LDX + k] = h; Xl[f * LDX + k] = (__bf16)(x - (float)h);
-      a.xsave[((size_t)b * F + f) * K + k] = x;
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int f = fi[u], t = ti[u];
+        const float4 ru = *reinterpret_cast<const float4*>(a.R_u + f * 4);
+        float x[4] = {fmaxf(v[u] * ru.x, 0.f), fmaxf(v[u] * ru.y, 0.f), fmaxf(v[u] * ru.z, 0.f), fmaxf(v[u] * ru.w, 0.f)};
+        if (a.p_drop > 0.f) {                                   // wave-uniform
+          const float4 uu = uniform4(a.seed, SITE_OBS_EMBED, ((uint64_t)t * B + b) * F + f);
+          x[0] = uu.x >= a.p_drop ? x[0] * inv_keep : 0.f; x[1] = uu.y >= a.p_drop ? x[1] * inv_keep : 0.f;
+          x[2] = uu.z >= a.p_drop ? x[2] * inv_keep : 0.f; x[3] = uu.w >= a.p_drop ? x[3] * inv_keep : 0.f;
+        }
+        split_store4(Xh + f * LDX + 4 * t, Xl + f * LDX + 4 * t, x);
+        *reinterpret_cast<float4*>(a.xsave + ((size_t)b * F + f) * K + 4 * t) = make_float4(x[0], x[1], x[2], x[3]);
+      }
     }
   }
+  RD_STAMP(1);
   __syncthreads();
+  RD_STAMP(2);
 
   // ---- layer 1: Y1 = relu(X W1^T + b1) * ssum ----------------------------------------------------
   f32x4 acc[NJ][RT];
   zero_acc<RT>(acc);
-  gemm_planes<RT>(acc, Xh, Xl, plane(a, 0, 0, 0), plane(a, 0, 0, 1), nct, wave, lane);
+  mma_panel<RT>(acc, Xh, Xl, pw, lane);
+  RD_STAMP(3);
+  // layer-2 weights start streaming while the epilogue below runs
+  load_panel(pw, plane(a, 1, 0, 0), plane(a, 1, 0, 1), nct, wave, lane);
+  // branch-free epilogue: pad rows carry srow == 0 and land in the planes' pad rows
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
     const int j = wave + NWAVE * jj;
-    if (j >= nct) continue;
-    const int n = 16 * j + (lane & 15);
-    const float bias = a.b1[n];
+    if (j < nct) {                                              // wave-uniform
+      const int n = 16 * j + (lane & 15);
+      const float bias = a.b1[n];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+      for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = rt * 16 + 4 * (lane >> 4) + r;
-        if (row >= F) continue;
-        const float y = fmaxf(acc[jj][rt][r] + bias, 0.f) * a.ssum[row];
-        const __bf16 h = (__bf16)y;
-        Yh[row * LDX + n] = h; Yl[row * LDX + n] = (__bf16)(y - (float)h);
-        a.y1save[((size_t)b * F + row) * K + n] = y;
-      }
+        for (int r = 0; r < 4; ++r) {
+          const int row = rt * 16 + 4 * (lane >> 4) + r;
+          const float y = fmaxf(acc[jj][rt][r] + bias, 0.f) * srow[rt][r];
+          const __bf16 h = (__bf16)y;
+          Yh[row * LDX + n] = h; Yl[row * LDX + n] = (__bf16)(y - (float)h);
+        }
+    }
   }
+  RD_STAMP(4);
   __syncthreads();
+  RD_STAMP(5);
+  // Y1 for the backward pass, written row-contiguously from the planes (hi + lo is exactly the
+  // value the split-bf16 products of the backward pass would reconstruct anyway)
+  {
+    const int kq = K / 4;
+    for (int i = tid; i < F * kq; i += NTHR) {
+      const int f = i / kq, k = 4 * (i - f * kq);
+      const bf16x4 h = *reinterpret_cast<const bf16x4*>(Yh + f * LDX + k);
+      const bf16x4 l = *reinterpret_cast<const bf16x4*>(Yl + f * LDX + k);
+      *reinterpret_cast<float4*>(a.y1save + ((size_t)b * F + f) * K + k) =
+          make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2],
+                      (float)h[3] + (float)l[3]);
+    }
+  }
 
   // ---- layer 2: Y2 = relu(Y1 W2^T + b2) * ssum -> fp32 staging -----------------------------------
   zero_acc<RT>(acc);
-  gemm_planes<RT>(acc, Yh, Yl, plane(a, 1, 0, 0), plane(a, 1, 0, 1), nct, wave, lane);
+  mma_panel<RT>(acc, Yh, Yl, pw, lane);
+  RD_STAMP(6);
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
     const int j = wave + NWAVE * jj;
-    if (j >= nct) continue;
-    const int n = 16 * j + (lane & 15);
-    const float bias = a.b2[n];
+    if (j < nct) {                                              // wave-uniform
+      const int n = 16 * j + (lane & 15);
+      const float bias = a.b2[n];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+      for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = rt * 16 + 4 * (lane >> 4) + r;
-        if (row < F) Ys[row * LDS_F + n] = fmaxf(acc[jj][rt][r] + bias, 0.f) * a.ssum[row];
-      }
+        for (int r = 0; r < 4; ++r) {
+          const int row = rt * 16 + 4 * (lane >> 4) + r;      // rows >= F land in the staging tile's slack
+          Ys[row * LDS_F + n] = fmaxf(acc[jj][rt][r] + bias, 0.f) * srow[rt][r];
+        }
+    }
   }
+  RD_STAMP(7);
   __syncthreads();
-  // ---- [F, T*d] -> z[t, b, f*d + c]: consecutive threads write consecutive addresses -----------
-  const int Fd = F * d;
-  for (int i = tid; i < T * Fd; i += NTHR) {
-    const int t = i / Fd, fc = i - t * Fd, f = fc / d, c = fc - f * d;
-    a.z[((size_t)t * B + b) * a.ldz + fc] = Ys[f * LDS_F + t * d + c];
+  RD_STAMP(8);
+  // ---- [F, T*d] -> z[t, b, f*d + c]: consecutive threads write consecutive addresses; the thread's
+  // (f, c) is fixed and t advances by the number of rows the block covers (no divisions in the loop)
+  {
+    const int Fd = F * 4;
+    const int tpb = NTHR / Fd;                           // time steps covered per pass
+    const int t0 = tid / Fd, fc = tid - t0 * Fd;
+    if (tpb > 0) {
+      if (t0 < tpb) {
+        const int f = fc >> 2, c = fc & 3;
+        for (int t = t0; t < T; t += tpb)
+          a.z[((size_t)t * B + b) * a.ldz + fc] = Ys[f * LDS_F + t * 4 + c];
+      }
+    } else {
+      for (int i = tid; i < T * Fd; i += NTHR) {
+        const int t = i / Fd, q = i - t * Fd;
+        a.z[((size_t)t * B + b) * a.ldz + q] = Ys[(q >> 2) * LDS_F + t * 4 + (q & 3)];
+      }
+    }
   }
+  RD_STAMP(9);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -248,109 +324,135 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   __bf16* Dl = Dh + ROWS * LDX;
   __bf16* Eh = Dl + ROWS * LDX;
   __bf16* El = Eh + ROWS * LDX;
-  float* St = reinterpret_cast<float*>(Eh);              // fp32 [F][LDS_F] staging, aliases E planes
-  float* red = reinterpret_cast<float*>(Dh);             // [8 waves][ROWS][4] dR_u partials, aliases D planes
+  float* St = reinterpret_cast<float*>(Eh);              // fp32 [ROWS][LDS_F] staging, aliases the E planes
+  float* Sx = reinterpret_cast<float*>(Dh);              // second staging tile (dX), aliases the D planes
+  unsigned char* Mk = smem_raw + (size_t)4 * ROWS * LDX * sizeof(__bf16);   // [ROWS][KP] bytes: Y1 > 0
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
-  const int T = a.T, F = a.F, d = a.d, K = a.K, B = a.B;
+  const int T = a.T, F = a.F, K = a.K, B = a.B;
   const int nct = K / 16;
-  const int Fd = F * d;
+  const int Fd = F * 4;
+  const int kq = K / 4;
+
+  // W2^T panel first: its L2 round trip overlaps the gradient gather below
+  Panel pw;
+  load_panel(pw, plane(a, 1, 1, 0), plane(a, 1, 1, 1), nct, wave, lane);
+  float srow[RT][4];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rt * 16 + 4 * (lane >> 4) + r;
+      srow[rt][r] = row < F ? a.ssum[row] : 0.f;
+    }
+  zero_lds(smem_raw, 4 * ROWS * LDX * (int)sizeof(__bf16) + ROWS * KP, tid);
+  __syncthreads();
 
   // ---- dZ2 = dz * ssum * (z > 0), read coalesced in [t, f*d+c] order, transposed through LDS ----
-  for (int i = tid; i < T * Fd; i += NTHR) {
-    const int t = i / Fd, fc = i - t * Fd, f = fc / d, c = fc - f * d;
-    const size_t zi = ((size_t)t * B + b) * a.ldz + fc;
-    St[f * LDS_F + t * d + c] = (a.z[zi] > 0.f) ? a.dz[zi] * a.ssum[f] : 0.f;
+  {
+    const int tpb = NTHR / Fd;
+    const int t0 = tid / Fd, fc = tid - t0 * Fd;
+    if (tpb > 0) {
+      if (t0 < tpb) {
+        const int f = fc >> 2, c = fc & 3;
+        const float sf = a.ssum[f];
+        for (int t = t0; t < T; t += tpb) {
+          const size_t zi = ((size_t)t * B + b) * a.ldz + fc;
+          St[f * LDS_F + t * 4 + c] = (a.z[zi] > 0.f) ? a.dz[zi] * sf : 0.f;
+        }
+      }
+    } else {
+      for (int i = tid; i < T * Fd; i += NTHR) {
+        const int t = i / Fd, q = i - t * Fd;
+        const size_t zi = ((size_t)t * B + b) * a.ldz + q;
+        St[(q >> 2) * LDS_F + t * 4 + (q & 3)] = (a.z[zi] > 0.f) ? a.dz[zi] * a.ssum[q >> 2] : 0.f;
+      }
+    }
   }
-  zero_pads(Dh, Dl, ROWS, F, K, tid);
+  // ReLU gate of layer 1 as bytes, from the saved Y1 (row-contiguous float4 reads)
+  for (int i = tid; i < F * kq; i += NTHR) {
+    const int f = i / kq, k = 4 * (i - f * kq);
+    const float4 y = *reinterpret_cast<const float4*>(a.y1save + ((size_t)b * F + f) * K + k);
+    *reinterpret_cast<uchar4*>(Mk + f * KP + k) = make_uchar4(y.x > 0.f, y.y > 0.f, y.z > 0.f, y.w > 0.f);
+  }
   __syncthreads();
-  for (int i = tid; i < F * (K / 4); i += NTHR) {
-    const int f = i / (K / 4), k = 4 * (i - f * (K / 4));
+  for (int i = tid; i < F * kq; i += NTHR) {
+    const int f = i / kq, k = 4 * (i - f * kq);
     const float4 v = *reinterpret_cast<const float4*>(St + f * LDS_F + k);
     const float x[4] = {v.x, v.y, v.z, v.w};
     split_store4(Dh + f * LDX + k, Dl + f * LDX + k, x);
     *reinterpret_cast<float4*>(a.dz2save + ((size_t)b * F + f) * K + k) = v;
   }
   __syncthreads();
-  zero_pads(Eh, El, ROWS, F, K, tid);                    // staging (aliased) is dead from here on
+  zero_lds(Eh, 2 * ROWS * LDX * (int)sizeof(__bf16), tid);   // staging (aliased) is dead: clear the E planes
+  __syncthreads();
 
   // ---- dZ1 = (dZ2 W2) * ssum * (Y1 > 0) ----------------------------------------------------------
   f32x4 acc[NJ][RT];
   zero_acc<RT>(acc);
-  gemm_planes<RT>(acc, Dh, Dl, plane(a, 1, 1, 0), plane(a, 1, 1, 1), nct, wave, lane);
+  mma_panel<RT>(acc, Dh, Dl, pw, lane);
+  load_panel(pw, plane(a, 0, 1, 0), plane(a, 0, 1, 1), nct, wave, lane);   // W1^T streams during the epilogue
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
     const int j = wave + NWAVE * jj;
-    if (j >= nct) continue;
-    const int n = 16 * j + (lane & 15);
+    if (j < nct) {                                              // wave-uniform; body is branch-free
+      const int n = 16 * j + (lane & 15);
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+      for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = rt * 16 + 4 * (lane >> 4) + r;
-        if (row >= F) continue;
-        const size_t o = ((size_t)b * F + row) * K + n;
-        const float g = (a.y1save[o] > 0.f) ? acc[jj][rt][r] * a.ssum[row] : 0.f;
-        const __bf16 h = (__bf16)g;
-        Eh[row * LDX + n] = h; El[row * LDX + n] = (__bf16)(g - (float)h);
-        a.dz1save[o] = g;
-      }
-  }
-  __syncthreads();
-
-  // ---- dX = dZ1 W1;  dR_u[f*d+c] += sum_t dX[f, t*d+c] * (X > 0) * src[t,b,f] * keep -----------
-  zero_acc<RT>(acc);
-  gemm_planes<RT>(acc, Eh, El, plane(a, 0, 1, 0), plane(a, 0, 1, 1), nct, wave, lane);
-  const float keep = 1.0f / (1.0f - a.p_drop);
-  float part[RT][4];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) part[rt][r] = 0.f;
-#pragma unroll
-  for (int jj = 0; jj < NJ; ++jj) {
-    const int j = wave + NWAVE * jj;
-    if (j >= nct) continue;
-    const int n = 16 * j + (lane & 15);
-    const int t = n / d;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = rt * 16 + 4 * (lane >> 4) + r;
-        if (row >= F) continue;
-        if (a.xsave[((size_t)b * F + row) * K + n] > 0.f)
-          part[rt][r] += acc[jj][rt][r] * a.src[((size_t)t * B + b) * (2 * F) + row] * keep;
-      }
-  }
-  // lanes with equal (lane & 3) hold the same channel c (d == 4: n % 4 == lane % 4); general d is
-  // handled by the generic path, so the fused kernel is only dispatched for d == 4.
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v = part[rt][r];
-      v += __shfl_xor(v, 4);
-      v += __shfl_xor(v, 8);
-      part[rt][r] = v;
+        for (int r = 0; r < 4; ++r) {
+          const int row = rt * 16 + 4 * (lane >> 4) + r;      // pad rows: srow == 0 and gate == 0
+          const float g = Mk[row * KP + n] ? acc[jj][rt][r] * srow[rt][r] : 0.f;
+          const __bf16 h = (__bf16)g;
+          Eh[row * LDX + n] = h; El[row * LDX + n] = (__bf16)(g - (float)h);
+        }
     }
-  __syncthreads();                                        // D planes are dead: reuse as reduction scratch
-  if ((lane & 15) < 4) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = rt * 16 + 4 * (lane >> 4) + r;
-        red[(wave * ROWS + row) * 4 + (lane & 3)] = part[rt][r];
-      }
   }
   __syncthreads();
-  for (int i = tid; i < F * 4; i += NTHR) {
-    const int row = i >> 2, c = i & 3;
-    float v = 0.f;
+  // dZ1 for the weight-gradient pass, row-contiguous from the planes
+  for (int i = tid; i < F * kq; i += NTHR) {
+    const int f = i / kq, k = 4 * (i - f * kq);
+    const bf16x4 h = *reinterpret_cast<const bf16x4*>(Eh + f * LDX + k);
+    const bf16x4 l = *reinterpret_cast<const bf16x4*>(El + f * LDX + k);
+    *reinterpret_cast<float4*>(a.dz1save + ((size_t)b * F + f) * K + k) =
+        make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2],
+                    (float)h[3] + (float)l[3]);
+  }
+
+  // ---- dX = dZ1 W1 -> fp32 staging (the D planes are dead) -------------------------------------
+  zero_acc<RT>(acc);
+  mma_panel<RT>(acc, Eh, El, pw, lane);
 #pragma unroll
-    for (int w = 0; w < NWAVE; ++w) v += red[(w * ROWS + row) * 4 + c];      // fixed order
-    a.rupart[(size_t)b * F * 4 + i] = v;
+  for (int jj = 0; jj < NJ; ++jj) {
+    const int j = wave + NWAVE * jj;
+    if (j < nct) {
+      const int n = 16 * j + (lane & 15);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Sx[(rt * 16 + 4 * (lane >> 4) + r) * LDS_F + n] = acc[jj][rt][r];
+    }
+  }
+  __syncthreads();
+  // ---- dR_u[f*4+c] = sum_t dX[f, 4t+c] * (X > 0) * src[t,b,f] * keep -----------------------------
+  // pass 1 (thread per (f,t) cell, in place): P = dX * gate * src * keep
+  const float keep = 1.0f / (1.0f - a.p_drop);
+  for (int i = tid; i < F * T; i += NTHR) {
+    const int f = i / T, t = i - f * T;
+    const float4 xs = *reinterpret_cast<const float4*>(a.xsave + ((size_t)b * F + f) * K + 4 * t);
+    const float sv = a.src[((size_t)t * B + b) * (2 * F) + f] * keep;
+    float4 dx = *reinterpret_cast<float4*>(Sx + f * LDS_F + 4 * t);
+    dx.x = xs.x > 0.f ? dx.x * sv : 0.f; dx.y = xs.y > 0.f ? dx.y * sv : 0.f;
+    dx.z = xs.z > 0.f ? dx.z * sv : 0.f; dx.w = xs.w > 0.f ? dx.w * sv : 0.f;
+    *reinterpret_cast<float4*>(Sx + f * LDS_F + 4 * t) = dx;
+  }
+  __syncthreads();
+  // pass 2 (thread per (f,c)): fixed-order sum over t
+  for (int i = tid; i < Fd; i += NTHR) {
+    const int f = i >> 2, c = i & 3;
+    float v = 0.f;
+    for (int t = 0; t < T; ++t) v += Sx[f * LDS_F + 4 * t + c];
+    a.rupart[(size_t)b * Fd + i] = v;
   }
 }
 
@@ -362,12 +464,16 @@ int launch_fused(const FusedArgs& a, bool bwd, hipStream_t st) {
     hipLaunchKernelGGL(k_msg_fwd_fused<RT>, dim3(a.B), dim3(NTHR), lds, st, a);
     return check_launch("k_msg_fwd_fused");
   }
-  hipFuncSetAttribute((const void*)k_msg_bwd_fused<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_msg_bwd_fused<RT>, dim3(a.B), dim3(NTHR), lds, st, a);
+  const size_t ldsb = lds + (size_t)RT * 16 * KP;                  // + ReLU gate bytes
+  hipFuncSetAttribute((const void*)k_msg_bwd_fused<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+  hipLaunchKernelGGL(k_msg_bwd_fused<RT>, dim3(a.B), dim3(NTHR), ldsb, st, a);
   return check_launch("k_msg_bwd_fused");
 }
 
 }  // namespace
+
+static unsigned long long* g_stamps = nullptr;
+extern "C" void rd_debug_set_stamps(void* p) { g_stamps = (unsigned long long*)p; }   // not part of the ABI
 
 bool fused_msgpass_ok(const rd_shape* s) {
   const int K = s->T * s->d_ob;
@@ -393,7 +499,7 @@ int fused_msgpass_fwd(const rd_shape* s, const float* src, const float* R_u, con
   a.src = src; a.R_u = R_u; a.b1 = b1; a.b2 = b2; a.ssum = ssum; a.wplanes = (const __bf16*)planes;
   a.xsave = xsave; a.y1save = y1save; a.z = z; a.ldz = ldz;
   a.B = s->B; a.T = s->T; a.F = s->F; a.d = s->d_ob; a.K = s->T * s->d_ob;
-  a.p_drop = p_drop; a.seed = seed;
+  a.p_drop = p_drop; a.seed = seed; a.stamps = g_stamps;
   switch (cdiv(s->F, 16)) {
     case 1: return launch_fused<1>(a, false, st);
     case 2: return launch_fused<2>(a, false, st);

@@ -60,6 +60,20 @@ class FlatGradAllReduce:
             for i, p in enumerate(self.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
 
+    def flatten_parameters(self):
+        """Re-home the live parameters themselves in ONE flat buffer (each `p.data` becomes a view) and
+        return a single Parameter over it whose `.grad` is the flat gradient buffer: the optimizer
+        then updates 0.5 M weights with one elementwise kernel instead of a 35-tensor multi-tensor
+        launch.  Adam is elementwise, so this is numerically identical to per-tensor Adam."""
+        total = self.flat.numel()
+        pbuf = torch.empty(total, dtype=torch.float32, device=self.flat.device)
+        for p, (lo, hi) in zip(self.params, self.slices):
+            pbuf[lo:hi].copy_(p.data.reshape(-1))
+            p.data = pbuf[lo:hi].view_as(p)
+        self.flat_param = torch.nn.Parameter(pbuf, requires_grad=True)
+        self.flat_param.grad = self.flat
+        return self.flat_param
+
     # -- per-step protocol -------------------------------------------------------------------
     def zero(self):
         """Zero the whole gradient buffer with one memset (replaces optimizer.zero_grad())."""

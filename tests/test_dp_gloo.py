@@ -69,3 +69,21 @@ def test_shard_batch_is_a_partition():
     assert torch.equal(torch.cat([p["lengths"] for p in parts]), full["lengths"])
     with pytest.raises(AssertionError):
         dp.shard_batch(full, 0, 3)
+
+
+def test_flattened_adam_equals_per_tensor_adam():
+    """One Adam over the flat parameter buffer == Adam over the individual tensors (elementwise)."""
+    torch.manual_seed(0)
+    a = [torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(5))]
+    b = [torch.nn.Parameter(t.detach().clone()) for t in a]
+    flat = dp.FlatGradAllReduce([("w", b[0]), ("v", b[1])], n_buckets=1)
+    opt_a = torch.optim.Adam(a, lr=1e-2)
+    opt_b = torch.optim.Adam([flat.flatten_parameters()], lr=1e-2)
+    for step in range(3):
+        for params, opt, zero in ((a, opt_a, lambda: opt_a.zero_grad()), (b, opt_b, flat.zero)):
+            zero()
+            loss = (params[0] ** 2).sum() * (step + 1) + (params[1] * 3).sum()
+            loss.backward()
+            opt.step()
+    assert torch.allclose(a[0], b[0], atol=1e-7) and torch.allclose(a[1], b[1], atol=1e-7)
+    assert b[0].data_ptr() == flat.flat_param.data_ptr()          # parameters live in the flat buffer

@@ -1,0 +1,31 @@
+"""Debug: per-phase cycle stamps of the fused message-passing forward kernel (first 8 workgroups)."""
+import ctypes, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from raindrop_amd import _lib, ops, synth
+from raindrop_amd.models_rd import Raindrop_v2
+lib = _lib.load()
+dev = torch.device("cuda")
+cfg = synth.make_config("P19")
+B = 256
+gs = synth.make_structure(cfg, "ones")
+m = Raindrop_v2(cfg["d_inp"], cfg["d_model"], 2, cfg["nhid"], 2, 0.2, cfg["max_len"], cfg["d_static"], 100, 0.5, "mean", 2, gs).to(dev)
+b = {k: (None if v is None else v.to(dev)) for k, v in synth.make_batch(cfg, B, seed=0).items()}
+g = m._graph(dev)
+shp = _lib.shape(B, 60, 34, 4)
+stamps = torch.zeros(8 * 16, dtype=torch.int64, device=dev)
+args = (b["src"], b["times"], b["lengths"], m.pos_encoder.timescales(dev), g["ssum"], m.R_u,
+        m.ob_propagation.lin_value.weight, m.ob_propagation.lin_value.bias,
+        m.ob_propagation_layer2.lin_value.weight, m.ob_propagation_layer2.lin_value.bias, shp, 0.2, 1)
+for _ in range(3):
+    ops.sensor_stage(*args)
+lib.rd_debug_set_stamps.argtypes = [ctypes.c_void_p]
+lib.rd_debug_set_stamps(stamps.data_ptr())
+ops.sensor_stage(*args)
+torch.cuda.synchronize()
+lib.rd_debug_set_stamps(None)
+s = stamps.cpu().view(8, 16)
+names = ["start->embed done", "barrier", "mma1", "epi1", "barrier", "mma2", "epi2", "barrier", "scatter"]
+for w in range(8):
+    d = [int(s[w, i + 1] - s[w, i]) for i in range(9)]
+    print("wg%d" % w, " ".join("%s=%d" % (n, x) for n, x in zip(names, d)), "total", int(s[w, 9] - s[w, 0]))
