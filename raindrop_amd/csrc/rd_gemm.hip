@@ -429,8 +429,8 @@ int launch_bf16x3(const GemmArgs& g, hipStream_t st) {
   const size_t lds = planes > stage ? planes : stage;
   dim3 grid(cdiv(g.N, TN), cdiv(g.M, TM), g.nsplit > 1 ? g.nsplit : 1);
   if (lds > 48 * 1024)
-    hipFuncSetAttribute((const void*)k_gemm_bf16x3<A_KC, B_KC, MI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds);
+    { static bool once = false; if (!once) { hipFuncSetAttribute((const void*)k_gemm_bf16x3<A_KC, B_KC, MI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds); once = true; } }
   hipLaunchKernelGGL((k_gemm_bf16x3<A_KC, B_KC, MI, NI>), grid, dim3(256), lds, st, g);
   return check_launch("k_gemm_bf16x3");
 }

@@ -460,12 +460,12 @@ template <int RT>
 int launch_fused(const FusedArgs& a, bool bwd, hipStream_t st) {
   const size_t lds = (size_t)4 * RT * 16 * LDX * sizeof(__bf16);
   if (!bwd) {
-    hipFuncSetAttribute((const void*)k_msg_fwd_fused<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    { static bool once = false; if (!once) { hipFuncSetAttribute((const void*)k_msg_fwd_fused<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } }
     hipLaunchKernelGGL(k_msg_fwd_fused<RT>, dim3(a.B), dim3(NTHR), lds, st, a);
     return check_launch("k_msg_fwd_fused");
   }
   const size_t ldsb = lds + (size_t)RT * 16 * KP;                  // + ReLU gate bytes
-  hipFuncSetAttribute((const void*)k_msg_bwd_fused<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+  { static bool once = false; if (!once) { hipFuncSetAttribute((const void*)k_msg_bwd_fused<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); once = true; } }
   hipLaunchKernelGGL(k_msg_bwd_fused<RT>, dim3(a.B), dim3(NTHR), ldsb, st, a);
   return check_launch("k_msg_bwd_fused");
 }

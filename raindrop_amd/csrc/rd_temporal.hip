@@ -339,17 +339,17 @@ int launch_attn(const AttnArgs& a, int which, hipStream_t st) {
   size_t lds;
   if (which == 0) {
     lds = sizeof(float) * (3 * TS * LDH + TS * LDP);
-    hipFuncSetAttribute((const void*)k_attn_fwd<NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    { static bool once = false; if (!once) { hipFuncSetAttribute((const void*)k_attn_fwd<NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } }
     hipLaunchKernelGGL(k_attn_fwd<NTH>, grid, dim3(256), lds, st, a);
     return check_launch("k_attn_fwd");
   } else if (which == 1) {
     lds = sizeof(float) * (4 * TS * LDH + TS * LDP + 2 * TS);
-    hipFuncSetAttribute((const void*)k_attn_bwd_dq<NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    { static bool once = false; if (!once) { hipFuncSetAttribute((const void*)k_attn_bwd_dq<NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } }
     hipLaunchKernelGGL(k_attn_bwd_dq<NTH>, grid, dim3(256), lds, st, a);
     return check_launch("k_attn_bwd_dq");
   }
   lds = sizeof(float) * (4 * TS * LDH + 2 * TS * LDP + 2 * TS);
-  hipFuncSetAttribute((const void*)k_attn_bwd_dkv<NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  { static bool once = false; if (!once) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv<NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } }
   hipLaunchKernelGGL(k_attn_bwd_dkv<NTH>, grid, dim3(256), lds, st, a);
   return check_launch("k_attn_bwd_dkv");
 }

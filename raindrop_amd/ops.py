@@ -78,6 +78,41 @@ def timescales(max_len, d_pe=16):
 # sensor stage: observation embedding + 2 x Observation_progation + PE concat + padding mask
 # ------------------------------------------------------------------------------------------------
 
+def sensor_stage_fwd_raw(src, times, lengths, ts, ssum, R_u, W1, b1, W2, b2, shp, p_drop, seed):
+    """rd_pe_mask + rd_msgpass_fwd into one [T,B,D] buffer.  Returns (z, mask, saved)."""
+    _check(src, times, ts, ssum, R_u, W1, b1, W2, b2)
+    _check(lengths, dtype=torch.int64)
+    T, B, F, d = shp.T, shp.B, shp.F, shp.d_ob
+    D = F * d + shp.d_pe
+    dev = src.device
+    z = torch.empty((T, B, D), dtype=torch.float32, device=dev)
+    mask = torch.empty((B, T), dtype=torch.bool, device=dev)
+    sp = ctypes.byref(shp)
+    saved = _workspace(_lib.load().rd_msgpass_saved_bytes(sp), dev)
+    _lib.call("rd_pe_mask", sp, _ptr(times), _ptr(lengths), _ptr(ts), _ptr(z), _ptr(mask), _stream())
+    _lib.call("rd_msgpass_fwd", sp, _ptr(src), _ptr(R_u), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2),
+              _ptr(ssum), float(p_drop), int(seed), _ptr(z), D, _ptr(saved), saved.numel(), _stream())
+    return z, mask, saved
+
+
+def sensor_stage_bwd_raw(src, R_u, W1, W2, ssum, saved, z, dz, shp, p_drop):
+    """rd_msgpass_bwd.  Returns (dR_u, dW1, db1, dW2, db2)."""
+    K = shp.T * shp.d_ob
+    D = shp.F * shp.d_ob + shp.d_pe
+    dev = dz.device
+    dW1 = torch.empty((K, K), dtype=torch.float32, device=dev)
+    dW2 = torch.empty((K, K), dtype=torch.float32, device=dev)
+    db1 = torch.empty((K,), dtype=torch.float32, device=dev)
+    db2 = torch.empty((K,), dtype=torch.float32, device=dev)
+    dRu = torch.empty_like(R_u)
+    sp = ctypes.byref(shp)
+    ws = _workspace(_lib.load().rd_msgpass_workspace_bytes(sp), dev)
+    _lib.call("rd_msgpass_bwd", sp, _ptr(src), _ptr(R_u), _ptr(W1), _ptr(W2), _ptr(ssum), float(p_drop),
+              _ptr(saved), saved.numel(), _ptr(z), _ptr(dz), D, _ptr(dW1), _ptr(db1), _ptr(dW2), _ptr(db2),
+              _ptr(dRu), _ptr(ws), ws.numel(), _stream())
+    return dRu, dW1, db1, dW2, db2
+
+
 class _SensorStage(torch.autograd.Function):
     """z[T,B,D] = cat(message_passing(src), PE(times));  mask[B,T] = t >= lengths.
 
@@ -86,18 +121,7 @@ class _SensorStage(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, src, times, lengths, ts, ssum, R_u, W1, b1, W2, b2, shp, p_drop, seed):
-        _check(src, times, ts, ssum, R_u, W1, b1, W2, b2)
-        _check(lengths, dtype=torch.int64)
-        T, B, F, d = shp.T, shp.B, shp.F, shp.d_ob
-        K, D = T * d, F * d + shp.d_pe
-        dev = src.device
-        z = torch.empty((T, B, D), dtype=torch.float32, device=dev)
-        mask = torch.empty((B, T), dtype=torch.bool, device=dev)
-        sp = ctypes.byref(shp)
-        saved = _workspace(_lib.load().rd_msgpass_saved_bytes(sp), dev)
-        _lib.call("rd_pe_mask", sp, _ptr(times), _ptr(lengths), _ptr(ts), _ptr(z), _ptr(mask), _stream())
-        _lib.call("rd_msgpass_fwd", sp, _ptr(src), _ptr(R_u), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2),
-                  _ptr(ssum), float(p_drop), int(seed), _ptr(z), D, _ptr(saved), saved.numel(), _stream())
+        z, mask, saved = sensor_stage_fwd_raw(src, times, lengths, ts, ssum, R_u, W1, b1, W2, b2, shp, p_drop, seed)
         ctx.shp = shp
         ctx.p_drop = float(p_drop)
         ctx.save_for_backward(src, R_u, W1, W2, ssum, saved, z)
@@ -107,22 +131,8 @@ class _SensorStage(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz, _dmask):
         src, R_u, W1, W2, ssum, saved, z = ctx.saved_tensors
-        shp = ctx.shp
-        dz = dz.contiguous()
-        K = shp.T * shp.d_ob
-        D = shp.F * shp.d_ob + shp.d_pe
-        dev = dz.device
-        dW1 = torch.empty((K, K), dtype=torch.float32, device=dev)
-        dW2 = torch.empty((K, K), dtype=torch.float32, device=dev)
-        db1 = torch.empty((K,), dtype=torch.float32, device=dev)
-        db2 = torch.empty((K,), dtype=torch.float32, device=dev)
-        dRu = torch.empty_like(R_u)
-        sp = ctypes.byref(shp)
-        nbytes = _lib.load().rd_msgpass_workspace_bytes(sp)
-        ws = _workspace(nbytes, dev)
-        _lib.call("rd_msgpass_bwd", sp, _ptr(src), _ptr(R_u), _ptr(W1), _ptr(W2), _ptr(ssum),
-                  ctx.p_drop, _ptr(saved), saved.numel(), _ptr(z), _ptr(dz), D, _ptr(dW1), _ptr(db1), _ptr(dW2),
-                  _ptr(db2), _ptr(dRu), _ptr(ws), ws.numel(), _stream())
+        dRu, dW1, db1, dW2, db2 = sensor_stage_bwd_raw(src, R_u, W1, W2, ssum, saved, z, dz.contiguous(), ctx.shp,
+                                                       ctx.p_drop)
         return None, None, None, None, None, dRu, dW1, db1, dW2, db2, None, None, None
 
 
