@@ -246,7 +246,8 @@ def main():
     named = dict(model.named_parameters())
     flat = dp.FlatGradAllReduce([(n, named[n]) for n in live], n_buckets=2)
     # code/Raindrop.py:256 (Adam, lr 1e-4) over the live parameters, held in one flat buffer
-    opt = torch.optim.Adam([flat.flatten_parameters()], lr=1e-4, fused=True)
+    from raindrop_amd.optim import FlatAdam
+    opt = FlatAdam(flat.flatten_parameters(), lr=1e-4)
     criterion = torch.nn.CrossEntropyLoss()
 
     def step():

@@ -177,6 +177,14 @@ int rd_masked_mean_fwd(const rd_shape* s, int32_t D, const float* r, const uint8
 int rd_masked_mean_bwd(const rd_shape* s, int32_t D, const float* dout, int32_t ldo,
                        const uint8_t* mask, const int64_t* lengths, float* dr, void* stream);
 
+/* ---- caller step (a19): the optimizer of code/Raindrop.py:256 ------------------------------- */
+
+/* torch.optim.Adam (no amsgrad; weight_decay added to the gradient) over one flat buffer of n
+ * floats: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).
+ * `step` is t (1-based).  All four buffers 16-byte aligned. */
+int rd_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
+                 float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream);
+
 /* ---- generic dense pieces (used by the temporal encoder, the head and the large-K path) ---- */
 
 /* y[M,N] = act(x[M,K] W[N,K]^T + b)   (torch.nn.functional.linear; act: 0 none, 1 relu). */

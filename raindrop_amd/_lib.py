@@ -60,6 +60,8 @@ SIGNATURES = {
                                         _ENC, _P, c_size_t, _P]),
     "rd_masked_mean_fwd": (c_int32, [_SHP, c_int32, _P, _P, _P, _P, c_int32, _P]),
     "rd_masked_mean_bwd": (c_int32, [_SHP, c_int32, _P, c_int32, _P, _P, _P, _P]),
+    "rd_adam_step": (c_int32, [ctypes.c_int64, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float,
+                                ctypes.c_int64, _P]),
     "rd_linear_fwd": (c_int32, [c_int32, c_int32, c_int32, _P, c_int32, _P, _P, _P, c_int32, c_int32, _P]),
     "rd_linear_bwd_input": (c_int32, [c_int32, c_int32, c_int32, _P, c_int32, _P, _P, c_int32, _P]),
     "rd_linear_bwd_weight_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),

@@ -63,13 +63,47 @@ struct AttnArgs {
   float scale, p_drop; uint64_t seed; uint32_t site;
 };
 
+// Dropout mask of the attention probabilities: element (bh, q, key) is component (q & 3) of the Philox
+// quad (bh*T + key)*ceil(T/4) + (q >> 2): the four query rows a lane holds in an MFMA accumulator
+// (q = q4*4 + r) come from ONE Philox evaluation.
+__device__ __forceinline__ uint64_t attn_quad(int bh, int T, int q, int key) {
+  return ((uint64_t)bh * T + key) * ((T + 3) >> 2) + (q >> 2);
+}
+__device__ __forceinline__ float attn_keep1(uint64_t seed, uint32_t site, int bh, int T, int q, int key, float p,
+                                            float inv_keep) {
+  const float4 u = uniform4(seed, site, attn_quad(bh, T, q, key));
+  const int j = q & 3;
+  const float v = j == 0 ? u.x : (j == 1 ? u.y : (j == 2 ? u.z : u.w));
+  return v >= p ? inv_keep : 0.f;
+}
+// keep-scales of the 4 consecutive query rows q4*4 .. q4*4+3 for one key
+__device__ __forceinline__ void attn_keep4(float (&k4)[4], uint64_t seed, uint32_t site, int bh, int T, int q0,
+                                           int key, float p, float inv_keep) {
+  const float4 u = uniform4(seed, site, attn_quad(bh, T, q0, key));
+  k4[0] = u.x >= p ? inv_keep : 0.f; k4[1] = u.y >= p ? inv_keep : 0.f;
+  k4[2] = u.z >= p ? inv_keep : 0.f; k4[3] = u.w >= p ? inv_keep : 0.f;
+}
+
 // rows [t0, t0+64) x cols [0, hd) of one head of q / k / v / out / dout -> LDS [64][ldh], zero padded
 __device__ __forceinline__ void load_head_tile(float* dst, int ldh, int hdp, const float* base,
                                                long row_stride, int t0, int T, int hd, int tid) {
-  for (int idx = tid; idx < TS * hdp; idx += 256) {
-    const int r = idx / hdp, c = idx - r * hdp;
-    const int t = t0 + r;
-    dst[r * ldh + c] = (t < T && c < hd) ? base[(long)t * row_stride + c] : 0.f;
+  // 4 threads per row; each moves 16-byte chunks c4 = (tid&3), +4, +8, ...: no index division
+  const int r = tid >> 2, t = t0 + r;
+  const bool vec = ((hd & 3) == 0) && ((row_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+  const float* src = base + (long)t * row_stride;
+  float* d = dst + r * ldh;
+  for (int c = 4 * (tid & 3); c < hdp; c += 16) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < T) {
+      if (vec && c + 3 < hd) v = *reinterpret_cast<const float4*>(src + c);
+      else {
+        if (c < hd) v.x = src[c];
+        if (c + 1 < hd) v.y = src[c + 1];
+        if (c + 2 < hd) v.z = src[c + 2];
+        if (c + 3 < hd) v.w = src[c + 3];
+      }
+    }
+    *reinterpret_cast<float4*>(d + c) = v;
   }
 }
 
@@ -129,14 +163,15 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int key = k0 + 16 * j + (lane & 15);
+      float k4[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.p_drop > 0.f)     // F.dropout on the attention probabilities (after the softmax sum)
+        attn_keep4(k4, a.seed, a.site, bh, a.T, q0 + wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = wave * 16 + 4 * (lane >> 4) + r;
-        float p = (s[j][r] == -INFINITY) ? 0.f : expf(s[j][r] - m_i[r]);
+        const float p = (s[j][r] == -INFINITY) ? 0.f : __expf(s[j][r] - m_i[r]);
         rsum[r] += p;
-        if (a.p_drop > 0.f)   // F.dropout on the attention probabilities (after the softmax sum)
-          p *= dropout_scale(a.seed, a.site, ((uint64_t)bh * a.T + (q0 + row)) * a.T + key, a.p_drop, inv_keep);
-        Ps[row * LDP + 16 * j + (lane & 15)] = p;
+        Ps[row * LDP + 16 * j + (lane & 15)] = p * k4[r];
       }
     }
 #pragma unroll
@@ -214,16 +249,16 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
     for (int j = 0; j < 4; ++j) {
       const int key = k0 + 16 * j + (lane & 15);
       const bool dead = key >= a.T || a.mask[(long)b * a.T + key];
+      float k4[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.p_drop > 0.f)
+        attn_keep4(k4, a.seed, a.site, bh, a.T, q0 + wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = wave * 16 + 4 * (lane >> 4) + r;
         float ds = 0.f;
         if (!dead && q0 + row < a.T) {
-          const float p = expf(s[j][r] * a.scale - lse_s[row]);
-          float g = dp[j][r];
-          if (a.p_drop > 0.f)
-            g *= dropout_scale(a.seed, a.site, ((uint64_t)bh * a.T + (q0 + row)) * a.T + key, a.p_drop, inv_keep);
-          ds = p * (g - dl_s[row]) * a.scale;
+          const float p = __expf(s[j][r] * a.scale - lse_s[row]);
+          ds = p * (dp[j][r] * k4[r] - dl_s[row]) * a.scale;
         }
         Ps[row * LDP + 16 * j + (lane & 15)] = ds;
       }
@@ -301,10 +336,9 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
         const int krow = wave * 16 + 4 * (lane >> 4) + r;
         float pm = 0.f, ds = 0.f;
         if (!dead[r] && q < a.T) {
-          const float p = expf(st[j][r] * a.scale - lse_s[qi]);
+          const float p = __expf(st[j][r] * a.scale - lse_s[qi]);
           float keep = 1.f;
-          if (a.p_drop > 0.f)
-            keep = dropout_scale(a.seed, a.site, ((uint64_t)bh * a.T + q) * a.T + (k0 + krow), a.p_drop, inv_keep);
+          if (a.p_drop > 0.f) keep = attn_keep1(a.seed, a.site, bh, a.T, q, k0 + krow, a.p_drop, inv_keep);
           pm = p * keep;
           ds = p * (dpt[j][r] * keep - dl_s[qi]) * a.scale;
         }
@@ -332,6 +366,91 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward, single-tile form (T <= 64: the P19 shape): one workgroup per (sample, head) forms S, P,
+// dP and dS ONCE and produces dQ, dK and dV from them (the two-kernel form above recomputes the
+// scores in each kernel and is kept for longer sequences).  Wave w owns query rows 16w..16w+15 for
+// S / dP / dQ and key rows 16w..16w+15 for dK / dV; dS and P o M are exchanged through LDS.
+// ------------------------------------------------------------------------------------------------
+template <int NTH>
+__global__ __launch_bounds__(256) void k_attn_bwd_one(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int HDP = 16 * NTH, LDH = HDP + 4;
+  float* Qs = smem;
+  float* Ks = Qs + TS * LDH;
+  float* Vs = Ks + TS * LDH;
+  float* dOs = Vs + TS * LDH;
+  float* PMs = dOs + TS * LDH;       // P o M   [q][key]
+  float* DSs = PMs + TS * LDP;       // dS      [q][key]
+  float* lse_s = DSs + TS * LDP;
+  float* dl_s = lse_s + TS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const long rs = (long)a.B * 3 * a.D, ro = (long)a.B * a.D;
+  const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
+  const float* dob = a.dout + (long)b * a.D + h * a.hd;
+  const float* ob = a.out + (long)b * a.D + h * a.hd;
+  load_head_tile(Qs, LDH, HDP, qb, rs, 0, a.T, a.hd, tid);
+  load_head_tile(Ks, LDH, HDP, qb + a.D, rs, 0, a.T, a.hd, tid);
+  load_head_tile(Vs, LDH, HDP, qb + 2 * a.D, rs, 0, a.T, a.hd, tid);
+  load_head_tile(dOs, LDH, HDP, dob, ro, 0, a.T, a.hd, tid);
+  // delta = rowsum(dO * O): 4 threads per row, combined by shuffles
+  {
+    const int r = tid >> 2;
+    float d = 0.f;
+    if (r < a.T)
+      for (int c = (tid & 3); c < a.hd; c += 4) d += dob[(long)r * ro + c] * ob[(long)r * ro + c];
+    d += __shfl_xor(d, 1);
+    d += __shfl_xor(d, 2);
+    if ((tid & 3) == 0) { dl_s[r] = d; lse_s[r] = r < a.T ? a.lse[(long)bh * a.T + r] : 0.f; }
+  }
+  __syncthreads();
+  const float inv_keep = 1.0f / (1.0f - a.p_drop);
+  f32x4 s[4], dp[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { s[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[j] = s[j]; }
+  mma_f32<4>(s, Qs + wave * 16 * LDH, LDH, 1, Ks, 1, LDH, HDP, lane);     // S  = Q K^T
+  mma_f32<4>(dp, dOs + wave * 16 * LDH, LDH, 1, Vs, 1, LDH, HDP, lane);   // dP = dO V^T
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int key = 16 * j + (lane & 15);
+    const bool dead = key >= a.T || a.mask[(long)b * a.T + min(key, a.T - 1)];
+    float k4[4] = {1.f, 1.f, 1.f, 1.f};
+    if (a.p_drop > 0.f)
+      attn_keep4(k4, a.seed, a.site, bh, a.T, wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wave * 16 + 4 * (lane >> 4) + r;
+      float pm = 0.f, ds = 0.f;
+      if (!dead && row < a.T) {
+        const float p = __expf(s[j][r] * a.scale - lse_s[row]);
+        pm = p * k4[r];
+        ds = p * (dp[j][r] * k4[r] - dl_s[row]) * a.scale;
+      }
+      PMs[row * LDP + key] = pm;
+      DSs[row * LDP + key] = ds;
+    }
+  }
+  __syncthreads();
+  f32x4 dq[NTH], dk[NTH], dv[NTH];
+#pragma unroll
+  for (int j = 0; j < NTH; ++j) { dq[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[j] = dq[j]; dv[j] = dq[j]; }
+  mma_f32<NTH>(dq, DSs + wave * 16 * LDP, LDP, 1, Ks, LDH, 1, TS, lane);    // dQ = dS K
+  mma_f32<NTH>(dk, DSs + wave * 16, 1, LDP, Qs, LDH, 1, TS, lane);          // dK = dS^T Q   (A(i,k) = dS[k][i])
+  mma_f32<NTH>(dv, PMs + wave * 16, 1, LDP, dOs, LDH, 1, TS, lane);         // dV = (P o M)^T dO
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int t = wave * 16 + 4 * (lane >> 4) + r;
+    if (t >= a.T) continue;
+    float* row = a.dqkv + ((long)t * a.B + b) * 3 * a.D + h * a.hd;
+#pragma unroll
+    for (int j = 0; j < NTH; ++j) {
+      const int c = 16 * j + (lane & 15);
+      if (c < a.hd) { row[c] = dq[j][r]; row[a.D + c] = dk[j][r]; row[2 * a.D + c] = dv[j][r]; }
+    }
+  }
+}
+
 template <int NTH>
 int launch_attn(const AttnArgs& a, int which, hipStream_t st) {
   constexpr int LDH = 16 * NTH + 4;
@@ -347,6 +466,12 @@ int launch_attn(const AttnArgs& a, int which, hipStream_t st) {
     { static bool once = false; if (!once) { hipFuncSetAttribute((const void*)k_attn_bwd_dq<NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } }
     hipLaunchKernelGGL(k_attn_bwd_dq<NTH>, grid, dim3(256), lds, st, a);
     return check_launch("k_attn_bwd_dq");
+  }
+  if (which == 3) {
+    lds = sizeof(float) * (4 * TS * LDH + 2 * TS * LDP + 2 * TS);
+    { static bool once = false; if (!once) { hipFuncSetAttribute((const void*)k_attn_bwd_one<NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } }
+    hipLaunchKernelGGL(k_attn_bwd_one<NTH>, dim3(a.B * a.H), dim3(256), lds, st, a);
+    return check_launch("k_attn_bwd_one");
   }
   lds = sizeof(float) * (4 * TS * LDH + 2 * TS * LDP + 2 * TS);
   { static bool once = false; if (!once) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv<NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } }
@@ -713,8 +838,12 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   a.qkv = v.qkv; a.mask = mask; a.out = v.attn; a.lse = v.lse; a.dout = ws.da; a.dqkv = ws.dqkv; a.delta = ws.delta;
   a.T = e.T; a.B = e.B; a.D = e.D; a.H = e.H; a.hd = e.Hd;
   a.scale = 1.0f / sqrtf((float)e.Hd); a.p_drop = p_drop; a.seed = seed; a.site = SITE_ATTN_PROB + L;
-  if ((rc = dispatch_attn(a, 1, st))) return rc;
-  if ((rc = dispatch_attn(a, 2, st))) return rc;
+  if (e.T <= TS) {
+    if ((rc = dispatch_attn(a, 3, st))) return rc;          // single tile: S, P, dP, dS formed once
+  } else {
+    if ((rc = dispatch_attn(a, 1, st))) return rc;
+    if ((rc = dispatch_attn(a, 2, st))) return rc;
+  }
   // ---- input projection --------------------------------------------------------------------------
   if ((rc = linear_bwd_w(e.M, 3 * e.D, e.D, ws.dqkv, x, g->in_proj_w, g->in_proj_b, ws.splitk, ws.colsum, st)))
     return rc;

@@ -6,22 +6,29 @@ BASELINE.json asks for.  Every stage of `Raindrop_v2.forward` is per-sample (SUR
 8e), so the only exchange is the weight-gradient sum.  Design points for MI355X:
   * dead parameters (72-92 % of the state_dict) never get a gradient and are
     excluded, so the buffer is 2.0 MB at P19 instead of 7.8 MB;
-  * gradients live IN the flat buffer (each `param.grad` is a view), so there is no pack/unpack
-    copy and the optimizer reads the reduced values in place;
-  * the buffer is split into a few buckets in backward order (head -> encoder -> message passing);
-    each bucket's all-reduce is launched from an autograd hook as soon as its last gradient has
-    been accumulated, overlapping the xGMI transfer with the rest of backward.  At <= 8 MB per
-    bucket a ring all-reduce on the 7x153 GB/s full mesh is latency-, not bandwidth-bound, so few,
-    large buckets win.
+  * after backward the 35 gradient tensors are packed into the flat buffer with one batched copy
+    (autograd's per-parameter accumulate kernels are avoided by dropping old gradients), the buffer
+    is all-reduced in a few large buckets, and the optimizer reads the reduced values in place
+    (each `param.grad` is a view of the buffer; with `flatten_parameters()` the weights are too);
+  * at <= 8 MB per bucket a ring all-reduce on the 7x153 GB/s full mesh is latency-, not
+    bandwidth-bound, so few, large buckets win; the step after backward is only the pack + the
+    collective + one Adam kernel, so there is little left to overlap the collective with.
 """
 import torch
 import torch.distributed as dist
 
 
 class FlatGradAllReduce:
+    """Flat gradient buffer + (for world > 1) its all-reduce.
+
+    Per step:  zero() -> forward/backward -> finish() -> optimizer.
+    `zero()` drops the previous gradients (p.grad = None), so autograd simply hands over each fresh
+    gradient tensor (no 35 read-modify-write accumulate kernels); `finish()` packs them into the flat
+    buffer with ONE batched copy, all-reduces the buffer over RCCL in a few large buckets, and
+    re-points every `p.grad` at its slice of the flat buffer, which is what the optimizer reads."""
+
     def __init__(self, params, process_group=None, n_buckets=2, average=True):
-        """params: list of (name, Parameter) that will receive gradients, in FORWARD order
-        (gradients therefore become ready roughly in reverse)."""
+        """params: list of (name, Parameter) that will receive gradients, in forward order."""
         self.group = process_group
         self.average = average
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -32,33 +39,29 @@ class FlatGradAllReduce:
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         off = 0
         self.slices = []
+        self.views = []
         for p in self.params:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
             self.slices.append((off, off + n))
+            self.views.append(self.flat[off:off + n].view_as(p))
             off += n
-        # buckets: contiguous ranges of the flat buffer, balanced by bytes, in forward order
+        # buckets: contiguous ranges of the flat buffer, balanced by bytes; at <= 8 MB a ring
+        # all-reduce on the xGMI mesh is latency-bound, so few and large
         n_buckets = max(1, min(n_buckets, len(self.params)))
         target = total / n_buckets
-        self.bucket_of = []
         bounds = [0]
         acc, b = 0, 0
         for i, p in enumerate(self.params):
             if acc >= target * (b + 1) and b < n_buckets - 1:
                 bounds.append(self.slices[i][0])
                 b += 1
-            self.bucket_of.append(b)
             acc += p.numel()
         bounds.append(total)
         self.bounds = bounds
         self.n_buckets = len(bounds) - 1
-        self._pending = [0] * self.n_buckets
-        self._count = [self.bucket_of.count(b) for b in range(self.n_buckets)]
-        self._handles = []
-        self._hooks = []
-        if self.world > 1:
-            for i, p in enumerate(self.params):
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+        self.flat_param = None
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     def flatten_parameters(self):
         """Re-home the live parameters themselves in ONE flat buffer (each `p.data` becomes a view) and
@@ -76,45 +79,26 @@ class FlatGradAllReduce:
 
     # -- per-step protocol -------------------------------------------------------------------
     def zero(self):
-        """Zero the whole gradient buffer with one memset (replaces optimizer.zero_grad())."""
-        self.flat.zero_()
-        self._pending = [0] * self.n_buckets
-        self._handles = []
-
-    def _launch(self, b):
-        view = self.flat[self.bounds[b]:self.bounds[b + 1]]
-        if self.average and dist.get_backend(self.group) == "nccl":
-            op = dist.ReduceOp.AVG
-        else:
-            op = dist.ReduceOp.SUM
-        h = dist.all_reduce(view, op=op, group=self.group, async_op=True)
-        self._handles.append((h, view, op))
-
-    def _make_hook(self, i):
-        b = self.bucket_of[i]
-
-        def hook(_param):
-            self._pending[b] += 1
-            if self._pending[b] == self._count[b]:
-                self._launch(b)
-        return hook
+        """Forget last step's gradients (replaces optimizer.zero_grad(set_to_none=True))."""
+        for p in self.params:
+            p.grad = None
 
     def finish(self):
-        """Wait for the in-flight bucket all-reduces (call after backward, before optimizer.step);
-        launches any bucket whose hook did not fire (e.g. a parameter without gradient this step)."""
-        if self.world == 1:
-            return
-        launched = len(self._handles)
-        if launched < self.n_buckets:
-            done = {id(v) for _, v, _ in self._handles}
-            for b in range(self.n_buckets):
-                if self._pending[b] != self._count[b]:
-                    self._launch(b)
-        for h, view, op in self._handles:
-            h.wait()
-            if self.average and op == dist.ReduceOp.SUM:
-                view.div_(self.world)
-        self._handles = []
+        """Pack the fresh gradients into the flat buffer (one batched copy), all-reduce it and leave
+        every p.grad pointing at its slice.  Parameters without a gradient this step contribute 0."""
+        grads = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
+        torch.cat(grads, out=self.flat)
+        if self.world > 1:
+            use_avg = self.average and dist.get_backend(self.group) == "nccl"
+            op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM
+            handles = [dist.all_reduce(self.flat[self.bounds[b]:self.bounds[b + 1]], op=op, group=self.group,
+                                       async_op=True) for b in range(self.n_buckets)]
+            for h in handles:
+                h.wait()
+            if self.average and not use_avg:
+                self.flat.div_(self.world)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     def nbytes(self):
         return self.flat.numel() * 4

@@ -1,0 +1,35 @@
+"""Adam over the flat parameter / gradient buffers (`raindrop_amd.dp.FlatGradAllReduce`).
+
+`code/Raindrop.py:256` uses `torch.optim.Adam(model.parameters(), lr=1e-4)`; that keeps working
+with this model unchanged.  `FlatAdam` is the fast path: because the live parameters and their
+gradients already live in two flat buffers, the whole update is ONE elementwise HIP kernel
+(rd_adam_step) instead of a 35-tensor multi-tensor launch.  Same formula as torch (no amsgrad).
+"""
+import torch
+
+from . import _lib, ops
+
+
+class FlatAdam:
+    def __init__(self, flat_param, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if flat_param.grad is None:
+            raise ValueError("flat_param.grad must be the flat gradient buffer")
+        self.param = flat_param
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.exp_avg = torch.zeros_like(flat_param.data)
+        self.exp_avg_sq = torch.zeros_like(flat_param.data)
+        self.t = 0
+
+    def step(self):
+        self.t += 1
+        p, g = self.param.data, self.param.grad
+        _lib.call("rd_adam_step", p.numel(), ops._ptr(p), ops._ptr(g), ops._ptr(self.exp_avg), ops._ptr(self.exp_avg_sq),
+                  float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
+                  self.t, ops._stream())
+
+    def zero_grad(self, set_to_none=False):
+        self.param.grad.zero_()
+
+    def state_dict(self):
+        return dict(t=self.t, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lr=self.lr, betas=self.betas,
+                    eps=self.eps, weight_decay=self.weight_decay)

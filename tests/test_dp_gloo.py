@@ -80,10 +80,12 @@ def test_flattened_adam_equals_per_tensor_adam():
     opt_a = torch.optim.Adam(a, lr=1e-2)
     opt_b = torch.optim.Adam([flat.flatten_parameters()], lr=1e-2)
     for step in range(3):
-        for params, opt, zero in ((a, opt_a, lambda: opt_a.zero_grad()), (b, opt_b, flat.zero)):
+        for params, opt, zero, fin in ((a, opt_a, lambda: opt_a.zero_grad(), lambda: None),
+                                       (b, opt_b, flat.zero, flat.finish)):
             zero()
             loss = (params[0] ** 2).sum() * (step + 1) + (params[1] * 3).sum()
             loss.backward()
+            fin()
             opt.step()
     assert torch.allclose(a[0], b[0], atol=1e-7) and torch.allclose(a[1], b[1], atol=1e-7)
     assert b[0].data_ptr() == flat.flat_param.data_ptr()          # parameters live in the flat buffer

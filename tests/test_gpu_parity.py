@@ -311,3 +311,20 @@ def test_masked_mean():
     (g,) = torch.autograd.grad(out, [rd], dout.to(DEV))
     assert np.abs(out.detach().cpu().numpy() - ref.detach().numpy()).max() < 1e-6
     assert np.abs(g.cpu().numpy() - g_ref.numpy()).max() < 1e-7
+
+
+def test_flat_adam_matches_torch_adam():
+    from raindrop_amd.optim import FlatAdam
+    rng = np.random.default_rng(1)
+    n = 100003
+    p0 = torch.from_numpy(rng.standard_normal(n).astype(np.float32))
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    mine = torch.nn.Parameter(p0.clone().to(DEV))
+    mine.grad = torch.zeros(n, device=DEV)
+    fa = FlatAdam(mine, lr=1e-3)
+    for s in range(5):
+        g = torch.from_numpy(rng.standard_normal(n).astype(np.float32)) * (0.1 + s)
+        ref.grad = g.clone(); opt.step()
+        mine.grad.copy_(g.to(DEV)); fa.step()
+    assert np.abs(mine.detach().cpu().numpy() - ref.detach().numpy()).max() < 2e-6
