@@ -69,6 +69,12 @@ const char* rd_arch(void);        /* "gfx950"                                   
 const char* rd_last_error(void);  /* thread-local; "" if none                                  */
 int rd_set_precision(int32_t mode); /* process-wide; RD_PREC_*                                 */
 int rd_get_precision(void);
+/* Dropout seeds are passed by value, which a captured hipGraph freezes.  If a device cell is
+ * registered, every dropout kernel adds its content to the seed it was launched with; bumping the
+ * cell (a 1-thread kernel, itself capturable) gives each graph replay fresh masks while forward and
+ * backward of one step still agree.  Pass NULL to unregister.  Process-wide. */
+int rd_set_seed_cell(const uint64_t* device_cell);
+int rd_seed_cell_advance(uint64_t* device_cell, uint64_t delta, void* stream);
 
 /* ---- a5/a6: integer work (bit-exact contracts) -------------------------------------------- */
 

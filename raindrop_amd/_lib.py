@@ -41,6 +41,8 @@ SIGNATURES = {
     "rd_last_error": (c_char_p, []),
     "rd_set_precision": (c_int32, [c_int32]),
     "rd_get_precision": (c_int32, []),
+    "rd_set_seed_cell": (c_int32, [_P]),
+    "rd_seed_cell_advance": (c_int32, [_P, ctypes.c_uint64, _P]),
     "rd_graph_build": (c_int32, [c_int32, _P, _P, _P, _P, _P, _P]),
     "rd_pe_mask": (c_int32, [_SHP, _P, _P, _P, _P, _P, _P]),
     "rd_edge_softmax": (c_int32, [c_int32, _P, _P, _P, _P]),

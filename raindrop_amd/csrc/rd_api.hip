@@ -12,6 +12,9 @@ char* err_buf() {
   return buf;
 }
 
+static const uint64_t* g_seed_cell = nullptr;
+const uint64_t* seed_cell() { return g_seed_cell; }
+
 static int g_precision = -1;
 int precision() {
   if (g_precision < 0) {
@@ -39,6 +42,16 @@ extern "C" int rd_set_precision(int32_t mode) {
   return RD_OK;
 }
 extern "C" int rd_get_precision(void) { return precision(); }
+
+namespace {
+__global__ void k_seed_advance(uint64_t* cell, uint64_t delta) { *cell += delta; }
+}
+extern "C" int rd_set_seed_cell(const uint64_t* device_cell) { g_seed_cell = device_cell; return RD_OK; }
+extern "C" int rd_seed_cell_advance(uint64_t* device_cell, uint64_t delta, void* stream) {
+  RD_REQUIRE(device_cell != nullptr, "NULL cell");
+  hipLaunchKernelGGL(k_seed_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, device_cell, delta);
+  return check_launch("k_seed_advance");
+}
 
 extern "C" int rd_version(void) { return RD_ABI_VERSION; }
 extern "C" const char* rd_arch(void) { return "gfx950"; }

@@ -23,6 +23,9 @@ inline int check_launch(const char* what) {
     if (!(cond)) return rd::fail(RD_EINVAL, __VA_ARGS__); \
   } while (0)
 
+// optional device cell added to every dropout seed (rd_set_seed_cell); nullptr when unset
+const uint64_t* seed_cell();
+
 // process-wide arithmetic mode of the dense contractions (rd_set_precision / env RD_PRECISION)
 int precision();
 
@@ -52,7 +55,7 @@ struct GemmArgs {
   const float* residual; long res_m;             // + residual[m*res_m + n]
   int relu;
   float cscale;                   // * cscale when != 0 (applied with posmask: dropout keep-scale in backward)
-  float drop_p; uint64_t drop_seed; uint32_t drop_site;   // Philox dropout on element m*N+n (after ReLU)
+  float drop_p; uint64_t drop_seed; uint32_t drop_site; const uint64_t* seed_cell;   // Philox dropout on element m*N+n (after ReLU)
   // scatter == 1: rows are (b,f) pairs of a [B,F,K] tensor, columns (t,c); element goes to the
   // [T,B,ldz] layout z[(t*sB + b)*ldz + f*sd + c]   (code/models_rd.py:338-342)
   int scatter; int sB, sF, sd; long ldz;

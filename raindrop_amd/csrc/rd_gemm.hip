@@ -91,7 +91,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x4 (&acc)[2][2], 
           if (g.posmask) v = (g.posmask[(long)m * g.pm_m + n] > 0.f) ? v : 0.f;
           if (g.cscale != 0.f) v *= g.cscale;
           if (g.drop_p > 0.f)
-            v *= dropout_scale(g.drop_seed, g.drop_site, (uint64_t)m * g.N + n, g.drop_p,
+            v *= dropout_scale(eff_seed(g.drop_seed, g.seed_cell), g.drop_site, (uint64_t)m * g.N + n, g.drop_p,
                                1.0f / (1.0f - g.drop_p));
           if (g.residual) v += g.residual[(long)m * g.res_m + n];
         }
@@ -293,11 +293,11 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, f32x4 (&acc)[MI][N
       float4 du = make_float4(1.f, 1.f, 1.f, 1.f);
       if (g.drop_p > 0.f) {
         if (vec) {
-          du = uniform4(g.drop_seed, g.drop_site, ((uint64_t)m * g.N + n) >> 2);
+          du = uniform4(eff_seed(g.drop_seed, g.seed_cell), g.drop_site, ((uint64_t)m * g.N + n) >> 2);
         } else {
           float t4[4];
           for (int c = 0; c < 4; ++c)
-            t4[c] = dropout_scale(g.drop_seed, g.drop_site, (uint64_t)m * g.N + n + c, g.drop_p, 1.f) > 0.f ? 1.f : 0.f;
+            t4[c] = dropout_scale(eff_seed(g.drop_seed, g.seed_cell), g.drop_site, (uint64_t)m * g.N + n + c, g.drop_p, 1.f) > 0.f ? 1.f : 0.f;
           du = make_float4(t4[0], t4[1], t4[2], t4[3]);     // 1 = keep (>= p), 0 = drop (< p)
         }
       }
@@ -547,6 +547,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (!bkc && a.sb_n != 1) return fail(RD_EINVAL, "gemm: B needs a unit stride");
   dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), a.nsplit > 1 ? a.nsplit : 1);
   GemmArgs g = a;
+  g.seed_cell = seed_cell();
   if (g.nsplit <= 1) { g.nsplit = 1; g.k_per_split = g.K > 0 ? g.K : 1; g.sc_split = 0; }
   if (precision() == RD_PREC_BF16X3) {
     if (g.nsplit > 1 && (g.k_per_split % BK2) != 0) return fail(RD_EINVAL, "gemm: k_per_split must be a multiple of 64");

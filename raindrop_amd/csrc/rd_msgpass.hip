@@ -37,7 +37,8 @@ namespace {
 __global__ __launch_bounds__(256) void k_obs_embed(const float* __restrict__ src,
                                                    const float* __restrict__ R_u,
                                                    float* __restrict__ X, int B, int T, int F, int d,
-                                                   float p_drop, uint64_t seed) {
+                                                   float p_drop, uint64_t seed, const uint64_t* cell) {
+  seed = eff_seed(seed, cell);
   const int b = blockIdx.x;
   const int K = T * d;
   const long total = (long)F * K;
@@ -181,7 +182,7 @@ extern "C" int rd_msgpass_fwd(const rd_shape* s, const float* src, const float* 
     const long per = (long)F * K;
     int gy = (int)((per + 255) / 256); if (gy > 64) gy = 64;
     hipLaunchKernelGGL(k_obs_embed, dim3(B, gy), dim3(256), 0, st, src, R_u, xsave, B, T, F, d,
-                       p_drop, seed);
+                       p_drop, seed, seed_cell());
     if ((rc = check_launch("k_obs_embed"))) return rc;
   }
   GemmArgs g{};

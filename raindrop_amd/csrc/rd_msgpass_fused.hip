@@ -39,7 +39,7 @@ struct FusedArgs {
   const float *dz;               // bwd
   float *dz2save, *dz1save, *rupart;
   int B, T, F, d, K, ldz;
-  float p_drop; uint64_t seed;
+  float p_drop; uint64_t seed; const uint64_t* seed_cell;
   unsigned long long* stamps;    // debug: per-phase clock64() of wave 0 of the first 8 workgroups
 };
 
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
         const float4 ru = *reinterpret_cast<const float4*>(a.R_u + f * 4);
         float x[4] = {fmaxf(v[u] * ru.x, 0.f), fmaxf(v[u] * ru.y, 0.f), fmaxf(v[u] * ru.z, 0.f), fmaxf(v[u] * ru.w, 0.f)};
         if (a.p_drop > 0.f) {                                   // wave-uniform
-          const float4 uu = uniform4(a.seed, SITE_OBS_EMBED, ((uint64_t)t * B + b) * F + f);
+          const float4 uu = uniform4(eff_seed(a.seed, a.seed_cell), SITE_OBS_EMBED, ((uint64_t)t * B + b) * F + f);
           x[0] = uu.x >= a.p_drop ? x[0] * inv_keep : 0.f; x[1] = uu.y >= a.p_drop ? x[1] * inv_keep : 0.f;
           x[2] = uu.z >= a.p_drop ? x[2] * inv_keep : 0.f; x[3] = uu.w >= a.p_drop ? x[3] * inv_keep : 0.f;
         }
@@ -499,7 +499,7 @@ int fused_msgpass_fwd(const rd_shape* s, const float* src, const float* R_u, con
   a.src = src; a.R_u = R_u; a.b1 = b1; a.b2 = b2; a.ssum = ssum; a.wplanes = (const __bf16*)planes;
   a.xsave = xsave; a.y1save = y1save; a.z = z; a.ldz = ldz;
   a.B = s->B; a.T = s->T; a.F = s->F; a.d = s->d_ob; a.K = s->T * s->d_ob;
-  a.p_drop = p_drop; a.seed = seed; a.stamps = g_stamps;
+  a.p_drop = p_drop; a.seed = seed; a.seed_cell = seed_cell(); a.stamps = g_stamps;
   switch (cdiv(s->F, 16)) {
     case 1: return launch_fused<1>(a, false, st);
     case 2: return launch_fused<2>(a, false, st);

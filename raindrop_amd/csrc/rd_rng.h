@@ -37,6 +37,12 @@ __device__ __forceinline__ float dropout_scale(uint64_t seed, uint32_t site, uin
   return v >= p ? inv_keep : 0.f;
 }
 
+// effective seed: the by-value seed plus the content of an optional device cell.  A captured hipGraph
+// freezes kernel arguments, so per-replay fresh masks come from bumping the cell (rd_seed_cell_advance).
+__device__ __forceinline__ uint64_t eff_seed(uint64_t seed, const uint64_t* cell) {
+  return cell ? seed + *cell : seed;
+}
+
 enum DropSite : uint32_t { SITE_OBS_EMBED = 1, SITE_ATTN_PROB = 16, SITE_ATTN_OUT = 32, SITE_FFN_HID = 48,
                            SITE_FFN_OUT = 64 };   // + layer index for the encoder sites
 

@@ -60,7 +60,7 @@ struct AttnArgs {
   float* dqkv;           // bwd: [T,B,3D]
   float* delta;          // bwd: [B,H,T] rowsum(dout * out)
   int T, B, D, H, hd;
-  float scale, p_drop; uint64_t seed; uint32_t site;
+  float scale, p_drop; uint64_t seed; uint32_t site; const uint64_t* seed_cell;
 };
 
 // Dropout mask of the attention probabilities: element (bh, q, key) is component (q & 3) of the Philox
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
       const int key = k0 + 16 * j + (lane & 15);
       float k4[4] = {1.f, 1.f, 1.f, 1.f};
       if (a.p_drop > 0.f)     // F.dropout on the attention probabilities (after the softmax sum)
-        attn_keep4(k4, a.seed, a.site, bh, a.T, q0 + wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
+        attn_keep4(k4, eff_seed(a.seed, a.seed_cell), a.site, bh, a.T, q0 + wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = wave * 16 + 4 * (lane >> 4) + r;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
       const bool dead = key >= a.T || a.mask[(long)b * a.T + key];
       float k4[4] = {1.f, 1.f, 1.f, 1.f};
       if (a.p_drop > 0.f)
-        attn_keep4(k4, a.seed, a.site, bh, a.T, q0 + wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
+        attn_keep4(k4, eff_seed(a.seed, a.seed_cell), a.site, bh, a.T, q0 + wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = wave * 16 + 4 * (lane >> 4) + r;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
         if (!dead[r] && q < a.T) {
           const float p = __expf(st[j][r] * a.scale - lse_s[qi]);
           float keep = 1.f;
-          if (a.p_drop > 0.f) keep = attn_keep1(a.seed, a.site, bh, a.T, q, k0 + krow, a.p_drop, inv_keep);
+          if (a.p_drop > 0.f) keep = attn_keep1(eff_seed(a.seed, a.seed_cell), a.site, bh, a.T, q, k0 + krow, a.p_drop, inv_keep);
           pm = p * keep;
           ds = p * (dpt[j][r] * keep - dl_s[qi]) * a.scale;
         }
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_one(AttnArgs a) {
     const bool dead = key >= a.T || a.mask[(long)b * a.T + min(key, a.T - 1)];
     float k4[4] = {1.f, 1.f, 1.f, 1.f};
     if (a.p_drop > 0.f)
-      attn_keep4(k4, a.seed, a.site, bh, a.T, wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
+      attn_keep4(k4, eff_seed(a.seed, a.seed_cell), a.site, bh, a.T, wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = wave * 16 + 4 * (lane >> 4) + r;
@@ -505,7 +505,8 @@ __global__ __launch_bounds__(256) void k_add_ln_fwd(const float* __restrict__ x,
                                                     const float* __restrict__ g, const float* __restrict__ bta,
                                                     float* __restrict__ s_out, float* __restrict__ y,
                                                     float* __restrict__ stats, int M, int D, float p_drop,
-                                                    uint64_t seed, uint32_t site) {
+                                                    uint64_t seed, uint32_t site, const uint64_t* cell) {
+  seed = eff_seed(seed, cell);
   const int lane = threadIdx.x & 63;
   const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -530,12 +531,13 @@ __global__ __launch_bounds__(256) void k_add_ln_fwd(const float* __restrict__ x,
 
 // backward: ds = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));  dr = ds o dropout mask;
 // per-block partial sums of dgamma = sum dy*xhat and dbeta = sum dy (64 rows per block).
-constexpr int LN_RPB = 64;
+constexpr int LN_RPB = 16;    // rows per block (4 per wavefront): ~1000 blocks at 15k tokens keep every CU busy
 __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, const float* __restrict__ s,
                                                 const float* __restrict__ stats, const float* __restrict__ g,
                                                 float* __restrict__ ds_out, float* __restrict__ dr_out,
                                                 float* __restrict__ part, int M, int D, float p_drop,
-                                                uint64_t seed, uint32_t site) {
+                                                uint64_t seed, uint32_t site, const uint64_t* cell) {
+  seed = eff_seed(seed, cell);
   extern __shared__ float red[];             // [4][2*D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float inv_keep = 1.0f / (1.0f - p_drop);
@@ -576,7 +578,8 @@ __global__ __launch_bounds__(256) void k_ln_bwd_r(const float* __restrict__ dy, 
                                                   const float* __restrict__ stats, const float* __restrict__ g,
                                                   float* __restrict__ ds_out, float* __restrict__ dr_out,
                                                   float* __restrict__ part, int M, int D, float p_drop,
-                                                  uint64_t seed, uint32_t site) {
+                                                  uint64_t seed, uint32_t site, const uint64_t* cell) {
+  seed = eff_seed(seed, cell);
   extern __shared__ float red[];             // [4][2*D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float inv_keep = 1.0f / (1.0f - p_drop);
@@ -632,10 +635,10 @@ int launch_ln_bwd(const float* dy, const float* s, const float* stats, const flo
   const size_t lds = sizeof(float) * 8 * D;
   const int nv = cdiv(D, 64);
 #define RD_LN(NV) hipLaunchKernelGGL(k_ln_bwd_r<NV>, dim3(lnb), dim3(256), lds, st, dy, s, stats, g, ds_out, dr_out, \
-                                     part, M, D, p_drop, seed, site)
+                                     part, M, D, p_drop, seed, site, seed_cell())
   if (nv == 1) RD_LN(1); else if (nv == 2) RD_LN(2); else if (nv == 3) RD_LN(3); else if (nv == 4) RD_LN(4);
   else hipLaunchKernelGGL(k_ln_bwd, dim3(lnb), dim3(256), lds, st, dy, s, stats, g, ds_out, dr_out, part, M, D,
-                          p_drop, seed, site);
+                          p_drop, seed, site, seed_cell());
 #undef RD_LN
   return check_launch("k_ln_bwd");
 }
@@ -778,18 +781,18 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
   AttnArgs a{};
   a.qkv = v.qkv; a.mask = mask; a.out = v.attn; a.lse = v.lse;
   a.T = e.T; a.B = e.B; a.D = e.D; a.H = e.H; a.hd = e.Hd;
-  a.scale = 1.0f / sqrtf((float)e.Hd); a.p_drop = p_drop; a.seed = seed; a.site = SITE_ATTN_PROB + L;
+  a.scale = 1.0f / sqrtf((float)e.Hd); a.p_drop = p_drop; a.seed = seed; a.site = SITE_ATTN_PROB + L; a.seed_cell = seed_cell();
   if ((rc = dispatch_attn(a, 0, st))) return rc;
   if ((rc = linear_fwd(e.M, e.D, e.D, v.attn, w->out_proj_w, w->out_proj_b, ws.o, 0, 0.f, 0, 0, st))) return rc;
   const int lnblocks = cdiv((int)e.M, 4);
   hipLaunchKernelGGL(k_add_ln_fwd, dim3(lnblocks), dim3(256), 0, st, x, ws.o, w->norm1_w, w->norm1_b, v.s1, v.x1,
-                     v.st1, (int)e.M, e.D, p_drop, seed, SITE_ATTN_OUT + L);
+                     v.st1, (int)e.M, e.D, p_drop, seed, SITE_ATTN_OUT + L, seed_cell());
   if ((rc = check_launch("k_add_ln_fwd"))) return rc;
   if ((rc = linear_fwd(e.M, e.nhid, e.D, v.x1, w->lin1_w, w->lin1_b, v.h, 1, p_drop, seed, SITE_FFN_HID + L, st)))
     return rc;
   if ((rc = linear_fwd(e.M, e.D, e.nhid, v.h, w->lin2_w, w->lin2_b, ws.f, 0, 0.f, 0, 0, st))) return rc;
   hipLaunchKernelGGL(k_add_ln_fwd, dim3(lnblocks), dim3(256), 0, st, v.x1, ws.f, w->norm2_w, w->norm2_b, v.s2, y,
-                     v.st2, (int)e.M, e.D, p_drop, seed, SITE_FFN_OUT + L);
+                     v.st2, (int)e.M, e.D, p_drop, seed, SITE_FFN_OUT + L, seed_cell());
   return check_launch("k_add_ln_fwd");
 }
 
@@ -837,7 +840,7 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   AttnArgs a{};
   a.qkv = v.qkv; a.mask = mask; a.out = v.attn; a.lse = v.lse; a.dout = ws.da; a.dqkv = ws.dqkv; a.delta = ws.delta;
   a.T = e.T; a.B = e.B; a.D = e.D; a.H = e.H; a.hd = e.Hd;
-  a.scale = 1.0f / sqrtf((float)e.Hd); a.p_drop = p_drop; a.seed = seed; a.site = SITE_ATTN_PROB + L;
+  a.scale = 1.0f / sqrtf((float)e.Hd); a.p_drop = p_drop; a.seed = seed; a.site = SITE_ATTN_PROB + L; a.seed_cell = seed_cell();
   if (e.T <= TS) {
     if ((rc = dispatch_attn(a, 3, st))) return rc;          // single tile: S, P, dP, dS formed once
   } else {

@@ -328,3 +328,31 @@ def test_flat_adam_matches_torch_adam():
         ref.grad = g.clone(); opt.step()
         mine.grad.copy_(g.to(DEV)); fa.step()
     assert np.abs(mine.detach().cpu().numpy() - ref.detach().numpy()).max() < 2e-6
+
+
+def test_seed_cell_changes_masks_per_replay():
+    """The device seed cell (what a captured hipGraph bumps between replays) is added to every
+    by-value dropout seed: same cell value -> identical output, advanced cell -> different masks."""
+    import ctypes
+    from raindrop_amd import _lib, ops
+    T, B, F, nhead = 12, 2, 3, 2
+    D, nhid = F * 4 + 16, 2 * F * 4
+    rng = np.random.default_rng(9)
+    x = torch.from_numpy(rng.standard_normal((T, B, D)).astype(np.float32)).to(DEV)
+    mask = torch.zeros(B, T, dtype=torch.bool, device=DEV)
+    pd = [_enc_params(D, nhid, seed=4)[n].to(DEV) for n in ops.ENC_PARAM_NAMES]
+    shp = _lib.shape(B, T, F, 4, nhead=nhead, nhid=nhid)
+    cell = torch.zeros(1, dtype=torch.int64, device=DEV)
+    f = lambda: ops.encoder_layer(x, mask, shp, 0, 0.3, 5, pd)
+    base = f()
+    try:
+        _lib.call("rd_set_seed_cell", ops._ptr(cell))
+        y0 = f()
+        assert torch.equal(y0, base)                       # cell == 0 is the plain seed
+        _lib.call("rd_seed_cell_advance", ops._ptr(cell), 1, ops._stream())
+        y1, y1b = f(), f()
+        assert not torch.equal(y1, y0) and torch.equal(y1, y1b)
+        assert int(cell.item()) == 1
+    finally:
+        _lib.call("rd_set_seed_cell", None)
+    assert torch.equal(f(), base)
