@@ -61,6 +61,7 @@ extern "C" int rd_linear_fwd(int32_t M, int32_t N, int32_t K, const float* x, in
                              const float* W, const float* b, float* y, int32_t ldy, int32_t act,
                              void* stream) {
   RD_REQUIRE(M >= 0 && N > 0 && K > 0, "bad dims M=%d N=%d K=%d", M, N, K);
+  if (M == 0) return RD_OK;
   RD_REQUIRE(x && W && y, "NULL tensor");
   RD_REQUIRE(ldx >= K && ldy >= N, "leading dimension too small");
   RD_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (relu)");
@@ -76,6 +77,7 @@ extern "C" int rd_linear_fwd(int32_t M, int32_t N, int32_t K, const float* x, in
 extern "C" int rd_linear_bwd_input(int32_t M, int32_t N, int32_t K, const float* dy, int32_t lddy,
                                    const float* W, float* dx, int32_t lddx, void* stream) {
   RD_REQUIRE(M >= 0 && N > 0 && K > 0, "bad dims M=%d N=%d K=%d", M, N, K);
+  if (M == 0) return RD_OK;
   RD_REQUIRE(dy && W && dx, "NULL tensor");
   RD_REQUIRE(lddy >= N && lddx >= K, "leading dimension too small");
   GemmArgs g{};
@@ -95,15 +97,16 @@ extern "C" int rd_linear_bwd_weight(int32_t M, int32_t N, int32_t K, const float
                                     const float* x, int32_t ldx, float* dW, float* db,
                                     void* workspace, size_t workspace_bytes, void* stream) {
   RD_REQUIRE(M >= 0 && N > 0 && K > 0, "bad dims M=%d N=%d K=%d", M, N, K);
-  RD_REQUIRE(dy && x && dW, "NULL tensor");
-  RD_REQUIRE(lddy >= N && ldx >= K, "leading dimension too small");
-  RD_REQUIRE(workspace && workspace_bytes >= rd_linear_bwd_weight_workspace_bytes(M, N, K),
-             "workspace too small");
   hipStream_t st = (hipStream_t)stream;
   if (M == 0) {
+    RD_REQUIRE(dW != nullptr, "NULL tensor");
     hipMemsetAsync(dW, 0, sizeof(float) * N * K, st);
     if (db) hipMemsetAsync(db, 0, sizeof(float) * N, st);
     return RD_OK;
   }
+  RD_REQUIRE(dy && x && dW, "NULL tensor");
+  RD_REQUIRE(lddy >= N && ldx >= K, "leading dimension too small");
+  RD_REQUIRE(workspace && workspace_bytes >= rd_linear_bwd_weight_workspace_bytes(M, N, K),
+             "workspace too small");
   return launch_wgrad(M, N, K, dy, lddy, x, ldx, dW, db, (float*)workspace, st);
 }

@@ -167,8 +167,8 @@ extern "C" int rd_pe_mask(const rd_shape* s, const float* times, const int64_t* 
                           const float* timescales, float* z, uint8_t* mask, void* stream) {
   RD_REQUIRE(s && s->T > 0 && s->F > 0 && s->d_ob > 0 && s->B >= 0, "bad rd_shape");
   RD_REQUIRE(s->d_pe > 0 && (s->d_pe % 2) == 0, "d_pe must be even and positive");
+  if (s->B == 0) return RD_OK;                       // empty batch: nothing to do (and torch hands out NULL data)
   RD_REQUIRE(times && lengths && timescales && z && mask, "NULL tensor");
-  if (s->B == 0) return RD_OK;
   const long n = (long)s->T * s->B;
   const int Dm = s->F * s->d_ob, D = Dm + s->d_pe;
   hipLaunchKernelGGL(k_pe_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,

@@ -165,12 +165,12 @@ extern "C" int rd_msgpass_fwd(const rd_shape* s, const float* src, const float* 
                               size_t saved_bytes, void* stream) {
   int rc = check_shape(s);
   if (rc) return rc;
+  if (s->B == 0) return RD_OK;                       // empty batch
   RD_REQUIRE(src && R_u && W1 && b1 && W2 && b2 && ssum && z && saved, "NULL tensor");
   RD_REQUIRE(ldz >= s->F * s->d_ob, "ldz (%d) < F*d_ob", ldz);
   RD_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "p_drop must be in [0,1)");
   MsgSaved v = carve_saved(s, saved);
   RD_REQUIRE(saved_bytes >= v.bytes, "saved buffer too small: %zu < %zu", saved_bytes, v.bytes);
-  if (s->B == 0) return RD_OK;
   hipStream_t st = (hipStream_t)stream;
   const int B = s->B, T = s->T, F = s->F, d = s->d_ob, K = T * d, M = B * F;
   float* xsave = v.xsave; float* y1save = v.y1save;
@@ -204,8 +204,16 @@ extern "C" int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* 
                               void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_shape(s);
   if (rc) return rc;
-  RD_REQUIRE(src && R_u && W1 && W2 && ssum && saved && z && dz, "NULL tensor");
   RD_REQUIRE(dW1 && db1 && dW2 && db2 && dR_u, "NULL gradient output");
+  if (s->B == 0) {
+    const int K0 = s->T * s->d_ob;
+    hipStream_t st0 = (hipStream_t)stream;
+    hipMemsetAsync(dW1, 0, sizeof(float) * K0 * K0, st0); hipMemsetAsync(dW2, 0, sizeof(float) * K0 * K0, st0);
+    hipMemsetAsync(db1, 0, sizeof(float) * K0, st0); hipMemsetAsync(db2, 0, sizeof(float) * K0, st0);
+    hipMemsetAsync(dR_u, 0, sizeof(float) * s->F * s->d_ob, st0);
+    return RD_OK;
+  }
+  RD_REQUIRE(src && R_u && W1 && W2 && ssum && saved && z && dz, "NULL tensor");
   MsgSaved sv = carve_saved(s, const_cast<void*>(saved));
   RD_REQUIRE(saved_bytes >= sv.bytes, "saved buffer too small");
   const float* xsave = sv.xsave; const float* y1save = sv.y1save;

@@ -768,6 +768,7 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
                                     void* stream) {
   int rc = check_enc(s);
   if (rc) return rc;
+  if (s->B == 0) return RD_OK;                       // empty batch
   RD_REQUIRE(x && mask && w && y && saved && workspace, "NULL tensor");
   RD_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "p_drop must be in [0,1)");
   const EncDims e = enc_dims(s);
@@ -856,8 +857,8 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
 extern "C" int rd_masked_mean_fwd(const rd_shape* s, int32_t D, const float* r, const uint8_t* mask,
                                   const int64_t* lengths, float* out, int32_t ldo, void* stream) {
   RD_REQUIRE(s && s->T > 0 && s->B >= 0 && D > 0 && ldo >= D, "bad arguments");
-  RD_REQUIRE(r && mask && lengths && out, "NULL tensor");
   if (s->B == 0) return RD_OK;
+  RD_REQUIRE(r && mask && lengths && out, "NULL tensor");
   hipLaunchKernelGGL(k_masked_mean_fwd, dim3(s->B), dim3(256), 0, (hipStream_t)stream, r, mask, lengths, out, s->T,
                      s->B, D, ldo);
   return check_launch("k_masked_mean_fwd");
@@ -866,8 +867,8 @@ extern "C" int rd_masked_mean_fwd(const rd_shape* s, int32_t D, const float* r, 
 extern "C" int rd_masked_mean_bwd(const rd_shape* s, int32_t D, const float* dout, int32_t ldo,
                                   const uint8_t* mask, const int64_t* lengths, float* dr, void* stream) {
   RD_REQUIRE(s && s->T > 0 && s->B >= 0 && D > 0 && ldo >= D, "bad arguments");
-  RD_REQUIRE(dout && mask && lengths && dr, "NULL tensor");
   if (s->B == 0) return RD_OK;
+  RD_REQUIRE(dout && mask && lengths && dr, "NULL tensor");
   const long n = (long)s->T * s->B * D;
   int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(k_masked_mean_bwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, mask, lengths, dr,

@@ -356,3 +356,96 @@ def test_seed_cell_changes_masks_per_replay():
     finally:
         _lib.call("rd_set_seed_cell", None)
     assert torch.equal(f(), base)
+
+
+# ------------------------------------------------------------------------------------------------
+# edge cases and size-independent properties
+# ------------------------------------------------------------------------------------------------
+
+def _o2_logits(m, cfg, gs, batch):
+    live = set(synth.live_parameter_names(cfg))
+    p = {n: t.detach().cpu() for n, t in m.named_parameters() if n in live}
+    with torch.no_grad():
+        lg, _ = O2.raindrop_v2_forward(p, cfg, batch["src"], batch["static"], batch["times"], batch["lengths"], gs)
+    return lg
+
+
+@pytest.mark.parametrize("case", ["B1", "full_length", "min_length", "no_observations", "self_loops_only"])
+def test_model_edge_cases(case):
+    cfg = synth.make_config("P19")
+    gs = synth.make_structure(cfg, "sparse")
+    B = 1 if case == "B1" else 5
+    batch = synth.make_batch(cfg, B, seed=31)
+    T, F = cfg["max_len"], cfg["d_inp"]
+    if case == "full_length":            # no padded step at all: mask is all False
+        batch["times"] = torch.cumsum(torch.rand(T, B) + 0.01, 0)
+    if case == "min_length":             # a single valid step per sample
+        batch["times"][1:] = 0
+        batch["src"][1:] = 0
+    if case == "no_observations":        # every sensor unobserved: X == 0, outputs driven by biases only
+        batch["src"].zero_()
+    if case == "self_loops_only":        # empty structure: only the diagonal the model adds itself
+        gs = torch.zeros(F, F)
+    batch["lengths"] = torch.sum(batch["times"] > 0, dim=0)
+    m = build_ours(cfg, gs, DEV, 13).eval()
+    dv = {k: (None if v is None else v.to(DEV)) for k, v in batch.items()}
+    with torch.no_grad():
+        logits, dist, _ = m(dv["src"], dv["static"], dv["times"], dv["lengths"])
+    ref = _o2_logits(m, cfg, gs, batch)
+    assert torch.isfinite(logits).all() and float(dist) == 0.0
+    assert np.abs(logits.cpu().numpy() - ref.numpy()).max() < 1e-4
+
+
+def test_batch_invariance_at_validation_scale():
+    """`evaluate_standard` (code/utils_rd.py:310-320) pushes the whole validation split through ONE
+    forward.  Every stage is per-sample, so a 1500-sample forward must equal the concatenation of
+    its chunks bit-for-bit in the fused path's arithmetic (same kernels, same per-sample order)."""
+    cfg = synth.make_config("P19")
+    gs = synth.make_structure(cfg, "ones")
+    N = 1500
+    batch = synth.make_batch(cfg, N, seed=77)
+    m = build_ours(cfg, gs, DEV, 21).eval()
+    dv = {k: (None if v is None else v.to(DEV)) for k, v in batch.items()}
+    with torch.no_grad():
+        full, _, _ = m(dv["src"], dv["static"], dv["times"], dv["lengths"])
+        parts = []
+        for lo in range(0, N, 500):
+            hi = lo + 500
+            lg, _, _ = m(dv["src"][:, lo:hi].contiguous(), dv["static"][lo:hi].contiguous(),
+                         dv["times"][:, lo:hi].contiguous(), dv["lengths"][lo:hi].contiguous())
+            parts.append(lg)
+    assert full.shape == (N, 2) and torch.isfinite(full).all()
+    assert torch.equal(full, torch.cat(parts, 0))
+    ref = _o2_logits(m, cfg, gs, {k: (v[:, :8] if k in ("src", "times") else (v[:8] if v is not None else None))
+                                  for k, v in batch.items()})
+    assert np.abs(full[:8].cpu().numpy() - ref.numpy()).max() < 1e-4
+
+
+def test_setting3_sensor_removal_is_exact_zeroing():
+    """Setting 3 (code/Raindrop.py:216-226) zeroes random sensor columns of val/test samples; the
+    model must treat a zeroed sensor exactly like an unobserved one (X == 0 -> same logits as the
+    oracle on the same zeroed input)."""
+    cfg = synth.make_config("P19")
+    gs = synth.make_structure(cfg, "ones")
+    batch = synth.make_batch(cfg, 6, seed=5)
+    rng = np.random.default_rng(0)
+    F = cfg["d_inp"]
+    for i in range(6):
+        idx = rng.choice(F, round(0.5 * F), replace=False)
+        batch["src"][:, i, idx] = 0
+    m = build_ours(cfg, gs, DEV, 3).eval()
+    dv = {k: (None if v is None else v.to(DEV)) for k, v in batch.items()}
+    with torch.no_grad():
+        logits, _, _ = m(dv["src"], dv["static"], dv["times"], dv["lengths"])
+    assert np.abs(logits.cpu().numpy() - _o2_logits(m, cfg, gs, batch).numpy()).max() < 1e-4
+
+
+def test_empty_batch_is_a_no_op():
+    from raindrop_amd import _lib, ops
+    cfg = synth.make_config("TINY")
+    m = build_ours(cfg, synth.make_structure(cfg, "ones"), DEV, 1).eval()
+    T, F = cfg["max_len"], cfg["d_inp"]
+    with torch.no_grad():
+        logits, _, _ = m(torch.zeros(T, 0, 2 * F, device=DEV), torch.zeros(0, cfg["d_static"], device=DEV),
+                         torch.zeros(T, 0, device=DEV), torch.zeros(0, dtype=torch.int64, device=DEV))
+    assert logits.shape == (0, cfg["n_classes"])
