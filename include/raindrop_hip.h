@@ -137,6 +137,14 @@ int rd_msgpass_fwd(const rd_shape* s, const float* src, const float* R_u, const 
                    float p_drop, uint64_t seed, float* z, int32_t ldz, void* saved, size_t saved_bytes,
                    void* stream);
 
+/* rd_pe_mask + rd_msgpass_fwd in one call for the model's layout (z [T,B,D], D = F*d_ob + d_pe,
+ * contiguous; mask [B,T]).  On the fused path the positional encoding and the padding mask of a
+ * sample are produced by the same workgroup that owns its message passing. */
+int rd_sensor_stage_fwd(const rd_shape* s, const float* src, const float* times, const int64_t* lengths,
+                        const float* timescales, const float* R_u, const float* W1, const float* b1,
+                        const float* W2, const float* b2, const float* ssum, float p_drop, uint64_t seed,
+                        float* z, uint8_t* mask, void* saved, size_t saved_bytes, void* stream);
+
 /* Backward of rd_msgpass_fwd.  dz is the gradient w.r.t. z (row stride ldz; only the first
  * F*d columns are read).  Writes dW1,db1,dW2,db2 and dR_u [F*d] (overwrite, not accumulate). */
 int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* R_u, const float* W1,

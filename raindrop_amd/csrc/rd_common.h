@@ -46,6 +46,10 @@ struct GemmArgs {
   float* C; long sc_m;            // C(m,n) at C[m*sc_m + n] unless scatter != 0
   int M, N, K;
   int nsplit; int k_per_split; long sc_split;   // split-K: partial z goes to C + z*sc_split, raw
+  // optional second problem of identical shape in the same launch (z in [nsplit, 2*nsplit)): the two
+  // message-passing layers' weight gradients share one grid
+  const float* A2; const float* B2; float* C2; float* rowsum2;
+  int xcd_swizzle;                // set by launch_gemm (env RD_GEMM_XCD, default 1)
   float* rowsum; long rowsum_split;   // optional: rowsum[z*rowsum_split + m] = sum_k A(m,k) over this split (bias
                                   // gradients ride along the weight-gradient product: no second pass over dy)
   // epilogue (ignored when nsplit > 1)
@@ -68,6 +72,9 @@ int splitk_plan(long red, int rows, int cols, int* k_per_split);
 long wgrad_ws_floats(long M, int N, int K);
 int launch_wgrad(long M, int N, int K, const float* dy, long lddy, const float* x, long ldx, float* dW,
                  float* db, float* ws, hipStream_t st);
+// two weight gradients of identical shape in one launch pair (ws: 2 * wgrad_ws_floats floats)
+int launch_wgrad2(long M, int N, int K, const float* dyA, const float* xA, float* dWA, float* dbA,
+                  const float* dyB, const float* xB, float* dWB, float* dbB, float* ws, hipStream_t st);
 // sum `nsplit` partials [nsplit][rows*cols] in fixed order into out
 int launch_splitk_reduce(const float* part, int nsplit, long elems, float* out, hipStream_t st);
 // same with partials `stride` floats apart; elements [0,e1) go to out1, [e1, e1+e2) to out2

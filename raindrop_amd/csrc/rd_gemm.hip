@@ -12,6 +12,8 @@
 // (one rounding per product, bitwise an fmaf chain), so results match a plain fp32 reference to
 // summation-order rounding.  Within each 16-wide K chunk lane l consumes k = 4*(l>>4)+j on MFMA
 // step j for BOTH operands, so each lane fetches its four k values with one ds_read_b128.
+#include <stdlib.h>
+
 #include "rd_common.h"
 #include "rd_rng.h"
 
@@ -263,8 +265,8 @@ struct Stage {
 // mask / residual reads and the output stores become 16-byte accesses in 256..640-byte runs, and the
 // Philox dropout mask costs one evaluation per 4 elements.
 template <int MI, int NI>
-__device__ __forceinline__ void epilogue_t(const GemmArgs& g, f32x4 (&acc)[MI][NI], float* stage, int m0, int n0,
-                                           int wy, int wx, int z, int tid, int lane) {
+__device__ __forceinline__ void epilogue_t(const GemmArgs& g, f32x4 (&acc)[MI][NI], float* stage, const float* bias_s,
+                                           int m0, int n0, int wy, int wx, int z, int tid, int lane) {
   constexpr int TM = 32 * MI, TN = 32 * NI, LDSG = TN + 4;
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -281,7 +283,38 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, f32x4 (&acc)[MI][N
                    (!g.residual || (((g.res_m & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.residual) & 15) == 0)));
   const float inv_keep = 1.0f / (1.0f - g.drop_p);
   constexpr int QPR = TN / 4;                         // column quads per tile row
-  for (int e = tid; e < TM * QPR; e += 256) {
+  constexpr int ITER = TM * QPR / 256;
+  // every global read of the epilogue (mask / residual) is issued before any of them is consumed:
+  // one memory round trip for the whole tile instead of one per row group
+  float4 pm4[ITER], rs4[ITER];
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int e = tid + it * 256;
+    const int rl = e / QPR, q = e - rl * QPR;
+    const int m = m0 + rl, n = n0 + 4 * q;
+    pm4[it] = make_float4(1.f, 1.f, 1.f, 1.f); rs4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!raw && m < g.M && n < g.N) {
+      if (g.posmask) {
+        if (vec) pm4[it] = *reinterpret_cast<const float4*>(g.posmask + (long)m * g.pm_m + n);
+        else {
+          float t4[4] = {0.f, 0.f, 0.f, 0.f};
+          for (int c = 0; c < 4 && n + c < g.N; ++c) t4[c] = g.posmask[(long)m * g.pm_m + n + c];
+          pm4[it] = make_float4(t4[0], t4[1], t4[2], t4[3]);
+        }
+      }
+      if (g.residual) {
+        if (vec) rs4[it] = *reinterpret_cast<const float4*>(g.residual + (long)m * g.res_m + n);
+        else {
+          float t4[4] = {0.f, 0.f, 0.f, 0.f};
+          for (int c = 0; c < 4 && n + c < g.N; ++c) t4[c] = g.residual[(long)m * g.res_m + n + c];
+          rs4[it] = make_float4(t4[0], t4[1], t4[2], t4[3]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int e = tid + it * 256;
     const int rl = e / QPR, q = e - rl * QPR;
     const int m = m0 + rl, n = n0 + 4 * q;
     if (m >= g.M || n >= g.N) continue;
@@ -302,17 +335,19 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, f32x4 (&acc)[MI][N
         }
       }
       const float uu[4] = {du.x, du.y, du.z, du.w};
+      const float pmv[4] = {pm4[it].x, pm4[it].y, pm4[it].z, pm4[it].w};
+      const float rsv[4] = {rs4[it].x, rs4[it].y, rs4[it].z, rs4[it].w};
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         if (c >= nv) break;
         float x = v[c];
-        if (g.bias) x += g.bias[n + c];
+        if (g.bias) x += bias_s[4 * q + c];
         if (g.relu) x = fmaxf(x, 0.f);
         x *= rsc;
-        if (g.posmask) x = (g.posmask[(long)m * g.pm_m + n + c] > 0.f) ? x : 0.f;
+        if (g.posmask) x = (pmv[c] > 0.f) ? x : 0.f;
         if (g.cscale != 0.f) x *= g.cscale;
         if (g.drop_p > 0.f) x = (uu[c] >= g.drop_p) ? x * inv_keep : 0.f;
-        if (g.residual) x += g.residual[(long)m * g.res_m + n + c];
+        if (g.residual) x += rsv[c];
         v[c] = x;
       }
     }
@@ -330,9 +365,21 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, f32x4 (&acc)[MI][N
   }
 }
 
-template <bool A_KC, bool B_KC, int MI, int NI>
+__device__ unsigned long long* g_gemm_stamps = nullptr;     // debug only (tools/gemm_timing.py)
+#define GSTAMP(i)                                                                                    \
+  do {                                                                                               \
+    if (g_gemm_stamps && blockIdx.z == 0 && blockIdx.x < 8 && threadIdx.x == 0)                      \
+      g_gemm_stamps[blockIdx.x * 8 + (i)] = clock64();                                        \
+  } while (0)
+
+// NPRE > 0: the whole K range of the workgroup (<= 64*NPRE) is requested up front, tile by tile into
+// registers, together with the bias: global-memory latency under load is ~3 us on this chip, and a
+// workgroup of these tall-skinny products lives for only a handful of tiles, so every dependent
+// round trip removed is ~10 % of the kernel.  NPRE == 0: generic loop, one tile of lookahead.
+template <bool A_KC, bool B_KC, int MI, int NI, int NPRE>
 __global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
   constexpr int TM = 32 * MI, TN = 32 * NI;
+  GSTAMP(0);
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   __bf16* Ah = reinterpret_cast<__bf16*>(gsm);
   __bf16* Al = Ah + TM * LDB;
@@ -340,8 +387,24 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
   __bf16* Bl = Bh + TN * LDB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wy = wave >> 1, wx = wave & 1;
-  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
-  const int z = blockIdx.z;
+  // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs (each with its own
+  // L2), so the column blocks that share one A row block are given ids that are equal mod 8: the row
+  // block is fetched into ONE L2 and re-read there by its other column blocks, and every XCD keeps
+  // its own copy of the (small) weight matrix.  Pure placement hint: any mapping is correct.
+  const int ncb = (g.N + TN - 1) / TN;
+  const int lin = blockIdx.x, xcd = lin & 7, jj = lin >> 3;
+  // (measured: helps the single-pass products by ~10 %, hurts the split-K weight-gradient products by
+  // ~40 % -- there the z-slices already spread one row block over the XCDs -- so those keep row-major order)
+  const bool swz = g.nsplit <= 1 && g.xcd_swizzle;
+  const int rblk = swz ? 8 * (jj / ncb) + xcd : lin / ncb;
+  const int cblk = swz ? jj - (jj / ncb) * ncb : lin - (lin / ncb) * ncb;
+  const int m0 = rblk * TM, n0 = cblk * TN;
+  if (m0 >= g.M) return;                              // padding blocks of the last group of 8 row blocks
+  int z = blockIdx.z;
+  if (g.A2 != nullptr && z >= g.nsplit) {             // second problem of a batched pair (uniform per block)
+    z -= g.nsplit;
+    g.A = g.A2; g.B = g.B2; g.C = g.C2; g.rowsum = g.rowsum2;
+  }
   const int kbeg = z * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
   const bool a_vec = A_KC && ((g.sa_m & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
@@ -353,25 +416,26 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
     for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   using SA = Stage<A_KC, TM>;
   using SB = Stage<B_KC, TN>;
-  float ra[SA::NREG], rb[SB::NREG];
+  constexpr int NBUF = NPRE > 0 ? NPRE : 1;
+  float ra[NBUF][SA::NREG], rb[NBUF][SB::NREG];
   float rsum = 0.f;                                   // MC staging: this thread's row is tid % TM
-  const bool do_rowsum = !A_KC && g.rowsum != nullptr && blockIdx.x == 0;
-  if (kbeg < kend) {
-    SA::load(ra, g.A, g.sa_m, g.sa_k, m0, g.M, kbeg, kend, tid, a_vec);
-    SB::load(rb, g.B, g.sb_n, g.sb_k, n0, g.N, kbeg, kend, tid, b_vec);
-  }
-  for (int k0 = kbeg; k0 < kend; k0 += BK2) {
-    if (do_rowsum) {
+  const bool do_rowsum = !A_KC && g.rowsum != nullptr && cblk == 0;
+  constexpr size_t PLANES_B = (size_t)2 * (TM + TN) * LDB * sizeof(__bf16), STAGE_B = (size_t)TM * (TN + 4) * sizeof(float);
+  float* bias_s = reinterpret_cast<float*>(gsm + (PLANES_B > STAGE_B ? PLANES_B : STAGE_B));   // [TN], above planes and stage
+  if (NPRE > 0) {
 #pragma unroll
-      for (int i = 0; i < SA::NREG; ++i) rsum += ra[i];
-    }
-    SA::store(ra, Ah, Al, tid);
-    SB::store(rb, Bh, Bl, tid);
-    __syncthreads();
-    if (k0 + BK2 < kend) {
-      SA::load(ra, g.A, g.sa_m, g.sa_k, m0, g.M, k0 + BK2, kend, tid, a_vec);
-      SB::load(rb, g.B, g.sb_n, g.sb_k, n0, g.N, k0 + BK2, kend, tid, b_vec);
-    }
+    for (int t = 0; t < NBUF; ++t)
+      if (kbeg + t * BK2 < kend) {
+        SA::load(ra[t], g.A, g.sa_m, g.sa_k, m0, g.M, kbeg + t * BK2, kend, tid, a_vec);
+        SB::load(rb[t], g.B, g.sb_n, g.sb_k, n0, g.N, kbeg + t * BK2, kend, tid, b_vec);
+      }
+  } else if (kbeg < kend) {
+    SA::load(ra[0], g.A, g.sa_m, g.sa_k, m0, g.M, kbeg, kend, tid, a_vec);
+    SB::load(rb[0], g.B, g.sb_n, g.sb_k, n0, g.N, kbeg, kend, tid, b_vec);
+  }
+  if (tid < TN) bias_s[tid] = (g.bias && n0 + tid < g.N) ? g.bias[n0 + tid] : 0.f;
+
+  auto mma_tile = [&]() {
 #pragma unroll
     for (int kc = 0; kc < BK2; kc += 32) {
       bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
@@ -404,10 +468,46 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
+  };
+
+  if (NPRE > 0) {
+#pragma unroll
+    for (int t = 0; t < NBUF; ++t) {
+      if (kbeg + t * BK2 < kend) {                    // uniform
+        if (do_rowsum) {
+#pragma unroll
+          for (int i = 0; i < SA::NREG; ++i) rsum += ra[t][i];
+        }
+        SA::store(ra[t], Ah, Al, tid);
+        SB::store(rb[t], Bh, Bl, tid);
+        __syncthreads();
+        if (t == 0) GSTAMP(1);
+        mma_tile();
+        __syncthreads();
+      }
+    }
+  } else {
+    for (int k0 = kbeg; k0 < kend; k0 += BK2) {
+      if (do_rowsum) {
+#pragma unroll
+        for (int i = 0; i < SA::NREG; ++i) rsum += ra[0][i];
+      }
+      SA::store(ra[0], Ah, Al, tid);
+      SB::store(rb[0], Bh, Bl, tid);
+      __syncthreads();
+      if (k0 == kbeg) GSTAMP(1);
+      if (k0 + BK2 < kend) {
+        SA::load(ra[0], g.A, g.sa_m, g.sa_k, m0, g.M, k0 + BK2, kend, tid, a_vec);
+        SB::load(rb[0], g.B, g.sb_n, g.sb_k, n0, g.N, k0 + BK2, kend, tid, b_vec);
+      }
+      mma_tile();
+      __syncthreads();
+    }
   }
+  GSTAMP(2);
+  float* stage = reinterpret_cast<float*>(gsm);
   if (do_rowsum) {                                    // TPR threads share a row; combine in fixed order
-    float* red = reinterpret_cast<float*>(gsm);
+    float* red = stage;
     red[tid] = rsum;
     __syncthreads();
     if (tid < TM && m0 + tid < g.M) {
@@ -418,21 +518,32 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
     }
     __syncthreads();
   }
-  epilogue_t<MI, NI>(g, acc, reinterpret_cast<float*>(gsm), m0, n0, wy, wx, z, tid, lane);
+  epilogue_t<MI, NI>(g, acc, stage, bias_s, m0, n0, wy, wx, z, tid, lane);
+  GSTAMP(3);
+}
+
+template <bool A_KC, bool B_KC, int MI, int NI, int NPRE>
+int launch_bf16x3_n(const GemmArgs& g, hipStream_t st) {
+  constexpr int TM = 32 * MI, TN = 32 * NI;
+  const size_t planes = (size_t)2 * (TM + TN) * LDB * sizeof(__bf16);
+  const size_t stage = (size_t)TM * (TN + 4) * sizeof(float);       // epilogue transpose tile (aliases the planes)
+  const size_t lds = (planes > stage ? planes : stage) + TN * sizeof(float);   // + bias
+  dim3 grid((g.nsplit > 1 ? cdiv(g.M, TM) : 8 * cdiv(cdiv(g.M, TM), 8)) * cdiv(g.N, TN), 1,
+            (g.nsplit > 1 ? g.nsplit : 1) * (g.A2 ? 2 : 1));
+  if (lds > 48 * 1024)
+    { static bool once = false; if (!once) { hipFuncSetAttribute((const void*)k_gemm_bf16x3<A_KC, B_KC, MI, NI, NPRE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds); once = true; } }
+  hipLaunchKernelGGL((k_gemm_bf16x3<A_KC, B_KC, MI, NI, NPRE>), grid, dim3(256), lds, st, g);
+  return check_launch("k_gemm_bf16x3");
 }
 
 template <bool A_KC, bool B_KC, int MI, int NI>
 int launch_bf16x3(const GemmArgs& g, hipStream_t st) {
-  constexpr int TM = 32 * MI, TN = 32 * NI;
-  const size_t planes = (size_t)2 * (TM + TN) * LDB * sizeof(__bf16);
-  const size_t stage = (size_t)TM * (TN + 4) * sizeof(float);       // epilogue transpose tile (aliases the planes)
-  const size_t lds = planes > stage ? planes : stage;
-  dim3 grid(cdiv(g.N, TN), cdiv(g.M, TM), g.nsplit > 1 ? g.nsplit : 1);
-  if (lds > 48 * 1024)
-    { static bool once = false; if (!once) { hipFuncSetAttribute((const void*)k_gemm_bf16x3<A_KC, B_KC, MI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds); once = true; } }
-  hipLaunchKernelGGL((k_gemm_bf16x3<A_KC, B_KC, MI, NI>), grid, dim3(256), lds, st, g);
-  return check_launch("k_gemm_bf16x3");
+  // Measured on MI355X (tools/gemm_timing.py, tools/bw_probe.py): requesting all K tiles up front
+  // (NPRE = tiles) is neutral at K=152 and 40 % slower at K=272 (register-limited occupancy), because
+  // these products are bound by operand RE-READS at the L2 level (each 64x64 tile loads 39+39 KB to
+  // write 16 KB), not by dependent latency; the looped form with one tile of lookahead stays.
+  return launch_bf16x3_n<A_KC, B_KC, MI, NI, 0>(g, st);
 }
 
 // padded work / tile efficiency: bigger tiles re-read less and amortise the barrier, but waste
@@ -539,6 +650,11 @@ __global__ __launch_bounds__(1024) void k_colsum_small(const float* __restrict__
 
 }  // namespace
 
+extern "C" void rd_debug_set_gemm_stamps(void* p) {      // not part of the ABI
+  unsigned long long* v = (unsigned long long*)p;
+  hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), &v, sizeof(v));
+}
+
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0) return RD_OK;
   // a row-sum request rides on the row-contiguous staging; with a 1-wide operand both strides are 1
@@ -548,6 +664,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), a.nsplit > 1 ? a.nsplit : 1);
   GemmArgs g = a;
   g.seed_cell = seed_cell();
+  static const int xcd_env = [] { const char* e = getenv("RD_GEMM_XCD"); return e ? atoi(e) : 1; }();
+  g.xcd_swizzle = xcd_env;
   if (g.nsplit <= 1) { g.nsplit = 1; g.k_per_split = g.K > 0 ? g.K : 1; g.sc_split = 0; }
   if (precision() == RD_PREC_BF16X3) {
     if (g.nsplit > 1 && (g.k_per_split % BK2) != 0) return fail(RD_EINVAL, "gemm: k_per_split must be a multiple of 64");
@@ -596,6 +714,30 @@ int launch_wgrad(long M, int N, int K, const float* dy, long lddy, const float* 
   }
   t.C = dW; t.sc_m = K; t.rowsum = db; t.rowsum_split = 0;
   return launch_gemm(t, st);
+}
+
+int launch_wgrad2(long M, int N, int K, const float* dyA, const float* xA, float* dWA, float* dbA,
+                  const float* dyB, const float* xB, float* dWB, float* dbB, float* ws, hipStream_t st) {
+  int kps; const int ns = splitk_plan(M, N, K, &kps);
+  const long stride = (long)N * K + N;
+  if (ns <= 1 || precision() != RD_PREC_BF16X3) {      // the batched form exists for the split bf16x3 kernel only
+    int rc = launch_wgrad(M, N, K, dyA, N, xA, K, dWA, dbA, ws, st);
+    if (rc) return rc;
+    return launch_wgrad(M, N, K, dyB, N, xB, K, dWB, dbB, ws + (long)ns * stride, st);
+  }
+  float* wsB = ws + (long)ns * stride;
+  GemmArgs t{};
+  t.M = N; t.N = K; t.K = (int)M;
+  t.A = dyA; t.sa_m = 1; t.sa_k = N;
+  t.B = xA; t.sb_n = 1; t.sb_k = K;
+  t.nsplit = ns; t.k_per_split = kps;
+  t.C = ws; t.sc_m = K; t.sc_split = stride;
+  t.rowsum = ws + (long)N * K; t.rowsum_split = stride;
+  t.A2 = dyB; t.B2 = xB; t.C2 = wsB; t.rowsum2 = wsB + (long)N * K;
+  int rc;
+  if ((rc = launch_gemm(t, st))) return rc;
+  if ((rc = launch_splitk_reduce2(ws, ns, stride, (long)N * K, dWA, N, dbA, st))) return rc;
+  return launch_splitk_reduce2(wsB, ns, stride, (long)N * K, dWB, N, dbB, st);
 }
 
 int launch_splitk_reduce2(const float* part, int nsplit, long stride, long e1, float* out1, long e2, float* out2,

@@ -25,7 +25,8 @@ size_t fused_wplanes_bytes(const rd_shape* s);
 int fused_wprep(const rd_shape* s, const float* W1, const float* W2, void* planes, hipStream_t st);
 int fused_msgpass_fwd(const rd_shape* s, const float* src, const float* R_u, const float* b1, const float* b2,
                       const float* ssum, const void* planes, float p_drop, uint64_t seed, float* xsave,
-                      float* y1save, float* z, int ldz, hipStream_t st);
+                      float* y1save, float* z, int ldz, hipStream_t st, const float* times = nullptr,
+                      const int64_t* lengths = nullptr, const float* tscale = nullptr, uint8_t* mask = nullptr);
 int fused_msgpass_bwd(const rd_shape* s, const float* src, const float* ssum, const void* planes, float p_drop,
                       const float* xsave, const float* y1save, const float* z, const float* dz, int ldz,
                       float* dz2save, float* dz1save, float* rupart, hipStream_t st);
@@ -116,7 +117,7 @@ MsgWs carve(const rd_shape* s, void* base) {
   auto take = [&](size_t nfloats) { float* p = base ? (float*)((char*)base + off) : nullptr;
                                     off += align_up(nfloats * sizeof(float), 256); return p; };
   w.dz2 = take(M * K); w.dz1 = take(M * K); w.dx = take(M * K);
-  w.splitk = take((size_t)wgrad_ws_floats(M, (int)K, (int)K));
+  w.splitk = take((size_t)2 * wgrad_ws_floats(M, (int)K, (int)K));
   w.colsum = take(colsum_ws_floats((int)M, (int)K));
   w.rupart = take(B * F * s->d_ob);
   w.bytes = off;
@@ -197,6 +198,32 @@ extern "C" int rd_msgpass_fwd(const rd_shape* s, const float* src, const float* 
   return launch_gemm(g, st);
 }
 
+// PE + padding mask + message passing in one call: on the fused path ONE launch (plus the weight
+// split) produces the whole [T,B,D] input of the temporal encoder and the mask.
+extern "C" int rd_sensor_stage_fwd(const rd_shape* s, const float* src, const float* times, const int64_t* lengths,
+                                   const float* timescales, const float* R_u, const float* W1, const float* b1,
+                                   const float* W2, const float* b2, const float* ssum, float p_drop, uint64_t seed,
+                                   float* z, uint8_t* mask, void* saved, size_t saved_bytes, void* stream) {
+  int rc = check_shape(s);
+  if (rc) return rc;
+  if (s->B == 0) return RD_OK;
+  RD_REQUIRE(times && lengths && timescales && mask, "NULL tensor");
+  RD_REQUIRE(s->d_pe > 0 && (s->d_pe % 2) == 0, "d_pe must be even and positive");
+  const int ldz = s->F * s->d_ob + s->d_pe;
+  if (fused_msgpass_ok(s)) {
+    RD_REQUIRE(src && R_u && W1 && b1 && W2 && b2 && ssum && z && saved, "NULL tensor");
+    RD_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "p_drop must be in [0,1)");
+    MsgSaved v = carve_saved(s, saved);
+    RD_REQUIRE(saved_bytes >= v.bytes, "saved buffer too small: %zu < %zu", saved_bytes, v.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = fused_wprep(s, W1, W2, v.planes, st))) return rc;
+    return fused_msgpass_fwd(s, src, R_u, b1, b2, ssum, v.planes, p_drop, seed, v.xsave, v.y1save, z, ldz, st,
+                             times, lengths, timescales, mask);
+  }
+  if ((rc = rd_pe_mask(s, times, lengths, timescales, z, mask, stream))) return rc;
+  return rd_msgpass_fwd(s, src, R_u, W1, b1, W2, b2, ssum, p_drop, seed, z, ldz, saved, saved_bytes, stream);
+}
+
 extern "C" int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* R_u, const float* W1,
                               const float* W2, const float* ssum, float p_drop, const void* saved,
                               size_t saved_bytes, const float* z, const float* dz, int32_t ldz,
@@ -262,7 +289,6 @@ extern "C" int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* 
   if ((rc = launch_colsum(w.rupart, B, F * d, F * d, dR_u, w.colsum, st))) return rc;
   }
   // weight gradients dW_l = dz_l^T in_l (+ bias gradients as row sums of dz_l^T), split over the B*F rows
-  if ((rc = launch_wgrad(M, K, K, w.dz2, K, y1save, K, dW2, db2, w.splitk, st))) return rc;
-  if ((rc = launch_wgrad(M, K, K, w.dz1, K, xsave, K, dW1, db1, w.splitk, st))) return rc;
+  if ((rc = launch_wgrad2(M, K, K, w.dz2, y1save, dW2, db2, w.dz1, xsave, dW1, db1, w.splitk, st))) return rc;
   return RD_OK;
 }

@@ -34,6 +34,7 @@ constexpr int NWAVE = NTHR / 64, NJ = 2;       // fp32 staging row stride (confl
 
 struct FusedArgs {
   const float *src, *R_u, *b1, *b2, *ssum;
+  const float *times, *tscale; const int64_t* lengths; uint8_t* mask; int d_pe;   // optional PE / mask (fwd)
   const __bf16* wplanes;         // [layer 2][orient 2][hi/lo 2][K rows][KP]
   float *xsave, *y1save, *z;
   const float *dz;               // bwd
@@ -309,6 +310,19 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
       }
     }
   }
+  // ---- positional encoding + padding mask of this sample (code/models_rd.py:28-38,298-299) ----
+  if (a.times != nullptr) {
+    const int H = a.d_pe >> 1;
+    for (int i = tid; i < T * H; i += NTHR) {
+      const int t = i / H, k = i - t * H;
+      const float ang = a.times[(size_t)t * B + b] / a.tscale[k];
+      float* row = a.z + ((size_t)t * B + b) * a.ldz + F * 4;
+      row[k] = sinf(ang);
+      row[H + k] = cosf(ang);
+    }
+    const int64_t len = a.lengths[b];
+    for (int t = tid; t < T; t += NTHR) a.mask[(size_t)b * T + t] = (uint8_t)((int64_t)t >= len);
+  }
   RD_STAMP(9);
 }
 
@@ -494,8 +508,10 @@ int fused_wprep(const rd_shape* s, const float* W1, const float* W2, void* plane
 
 int fused_msgpass_fwd(const rd_shape* s, const float* src, const float* R_u, const float* b1, const float* b2,
                       const float* ssum, const void* planes, float p_drop, uint64_t seed, float* xsave,
-                      float* y1save, float* z, int ldz, hipStream_t st) {
+                      float* y1save, float* z, int ldz, hipStream_t st, const float* times,
+                      const int64_t* lengths, const float* tscale, uint8_t* mask) {
   FusedArgs a{};
+  a.times = times; a.lengths = lengths; a.tscale = tscale; a.mask = mask; a.d_pe = s->d_pe;
   a.src = src; a.R_u = R_u; a.b1 = b1; a.b2 = b2; a.ssum = ssum; a.wplanes = (const __bf16*)planes;
   a.xsave = xsave; a.y1save = y1save; a.z = z; a.ldz = ldz;
   a.B = s->B; a.T = s->T; a.F = s->F; a.d = s->d_ob; a.K = s->T * s->d_ob;

@@ -79,7 +79,8 @@ def timescales(max_len, d_pe=16):
 # ------------------------------------------------------------------------------------------------
 
 def sensor_stage_fwd_raw(src, times, lengths, ts, ssum, R_u, W1, b1, W2, b2, shp, p_drop, seed):
-    """rd_pe_mask + rd_msgpass_fwd into one [T,B,D] buffer.  Returns (z, mask, saved)."""
+    """rd_sensor_stage_fwd: PE + padding mask + message passing into one [T,B,D] buffer.
+    Returns (z, mask, saved)."""
     _check(src, times, ts, ssum, R_u, W1, b1, W2, b2)
     _check(lengths, dtype=torch.int64)
     T, B, F, d = shp.T, shp.B, shp.F, shp.d_ob
@@ -89,9 +90,9 @@ def sensor_stage_fwd_raw(src, times, lengths, ts, ssum, R_u, W1, b1, W2, b2, shp
     mask = torch.empty((B, T), dtype=torch.bool, device=dev)
     sp = ctypes.byref(shp)
     saved = _workspace(_lib.load().rd_msgpass_saved_bytes(sp), dev)
-    _lib.call("rd_pe_mask", sp, _ptr(times), _ptr(lengths), _ptr(ts), _ptr(z), _ptr(mask), _stream())
-    _lib.call("rd_msgpass_fwd", sp, _ptr(src), _ptr(R_u), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2),
-              _ptr(ssum), float(p_drop), int(seed), _ptr(z), D, _ptr(saved), saved.numel(), _stream())
+    _lib.call("rd_sensor_stage_fwd", sp, _ptr(src), _ptr(times), _ptr(lengths), _ptr(ts), _ptr(R_u), _ptr(W1),
+              _ptr(b1), _ptr(W2), _ptr(b2), _ptr(ssum), float(p_drop), int(seed), _ptr(z), _ptr(mask), _ptr(saved),
+              saved.numel(), _stream())
     return z, mask, saved
 
 
