@@ -49,6 +49,7 @@ struct GemmArgs {
   // optional second problem of identical shape in the same launch (z in [nsplit, 2*nsplit)): the two
   // message-passing layers' weight gradients share one grid
   const float* A2; const float* B2; float* C2; float* rowsum2;
+  int tile_hint;                  // 1: force the 128x128 tile (split-K weight gradients: halves operand re-reads)
   int xcd_swizzle;                // set by launch_gemm (env RD_GEMM_XCD, default 1)
   float* rowsum; long rowsum_split;   // optional: rowsum[z*rowsum_split + m] = sum_k A(m,k) over this split (bias
                                   // gradients ride along the weight-gradient product: no second pass over dy)

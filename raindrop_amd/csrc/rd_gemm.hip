@@ -551,6 +551,7 @@ int launch_bf16x3(const GemmArgs& g, hipStream_t st) {
 template <bool A_KC, bool B_KC>
 int dispatch_bf16x3(const GemmArgs& g, hipStream_t st) {
   static const int cand[][2] = {{2, 2}, {4, 2}, {4, 4}, {2, 4}, {4, 5}, {2, 5}};
+  if (g.tile_hint == 1) return launch_bf16x3<A_KC, B_KC, 4, 4>(g, st);
   int best = 0; double bcost = 1e300;
   for (int c = 0; c < 6; ++c) {
     const int mi = cand[c][0], ni = cand[c][1];
@@ -681,9 +682,20 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   return check_launch("k_gemm");
 }
 
+// Weight-gradient products are HBM-traffic-bound (PMC: the 64x64-tile form fetches 4x its operands).
+// RD_WGRAD_TILE=128 runs them on 128x128 tiles (half the re-reads) -- measured SLOWER with the present
+// unpipelined main loop (K1 backward 79 -> 89 us: 2 workgroups/CU cannot cover the load latency), so
+// 64 stays the default until the main loop is software-pipelined.
+static int wgrad_tile() {
+  static const int t = [] { const char* e = getenv("RD_WGRAD_TILE"); const int v = e ? atoi(e) : 64;
+                            return v == 128 ? 128 : 64; }();
+  return t;
+}
+
 int splitk_plan(long red, int rows, int cols, int* k_per_split) {
-  const int tiles = cdiv(rows, BM) * cdiv(cols, BN);
-  const int want = cdiv(320, tiles);                     // ~1.25 workgroups per CU in total
+  const int tile = (rows >= 96 && cols >= 96) ? wgrad_tile() : 64;
+  const int tiles = cdiv(rows, tile) * cdiv(cols, tile);
+  const int want = cdiv(tile == 128 ? 256 : 320, tiles);  // ~1 workgroup per CU in total
   const int r = red > 0 ? (int)red : 1;
   int per = (int)align_up((size_t)cdiv(r, want), 64);
   *k_per_split = per;
@@ -704,6 +716,7 @@ int launch_wgrad(long M, int N, int K, const float* dy, long lddy, const float* 
   t.A = dy; t.sa_m = 1; t.sa_k = lddy;
   t.B = x; t.sb_n = 1; t.sb_k = ldx;
   t.nsplit = ns; t.k_per_split = kps;
+  t.tile_hint = (N >= 96 && K >= 96 && wgrad_tile() == 128) ? 1 : 0;
   const long stride = (long)N * K + N;                 // split z: [dW partial | db partial]
   int rc;
   if (ns > 1) {
@@ -731,6 +744,7 @@ int launch_wgrad2(long M, int N, int K, const float* dyA, const float* xA, float
   t.A = dyA; t.sa_m = 1; t.sa_k = N;
   t.B = xA; t.sb_n = 1; t.sb_k = K;
   t.nsplit = ns; t.k_per_split = kps;
+  t.tile_hint = (N >= 96 && K >= 96 && wgrad_tile() == 128) ? 1 : 0;
   t.C = ws; t.sc_m = K; t.sc_split = stride;
   t.rowsum = ws + (long)N * K; t.rowsum_split = stride;
   t.A2 = dyB; t.B2 = xB; t.C2 = wsB; t.rowsum2 = wsB + (long)N * K;

@@ -100,6 +100,19 @@ class FlatGradAllReduce:
         for p, v in zip(self.params, self.views):
             p.grad = v
 
+    def allreduce(self):
+        """All-reduce the flat buffer in place (gradients were written into it directly, e.g. by
+        raindrop_amd.step.TrainStep); no-op for a single process."""
+        if self.world > 1:
+            use_avg = self.average and dist.get_backend(self.group) == "nccl"
+            op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM
+            handles = [dist.all_reduce(self.flat[self.bounds[b]:self.bounds[b + 1]], op=op, group=self.group,
+                                       async_op=True) for b in range(self.n_buckets)]
+            for h in handles:
+                h.wait()
+            if self.average and not use_avg:
+                self.flat.div_(self.world)
+
     def nbytes(self):
         return self.flat.numel() * 4
 

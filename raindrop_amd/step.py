@@ -1,0 +1,190 @@
+"""Static training step for `Raindrop_v2`: forward + CrossEntropyLoss + backward as ONE hipGraph.
+
+`code/Raindrop.py:319-323` runs `model.forward -> criterion -> loss.backward()` through autograd,
+~100 host-side launches per step.  Every stage of this model already has a forward and a backward
+entry point in the C-ABI, so the step can be written out explicitly -- no autograd graph, no
+Python in the replay path, every buffer allocated once:
+
+    z, mask          <- rd_sensor_stage_fwd                     (K1 + PE + mask)
+    x_{l+1}          <- rd_encoder_layer_fwd(x_l)               (K2/K3, per layer)
+    feat = [agg|emb] <- rd_masked_mean_fwd, rd_linear_fwd       (K5; both write into one buffer)
+    logits           <- rd_linear_fwd x2
+    loss, dlogits    <- log-softmax cross entropy (mean)        (tiny torch ops inside the graph)
+    ... the same chain backwards, each gradient written straight into its slice of the flat
+    gradient buffer (raindrop_amd.dp.FlatGradAllReduce): no accumulate kernels, no packing copy.
+
+The captured graph is replayed per step; dropout masks change per replay through the device seed
+cell (`rd_set_seed_cell` / `rd_seed_cell_advance`), which the graph bumps itself.  The gradient
+all-reduce (N > 1) and the Adam kernel stay outside the graph.  The eager model (`models_rd.py`)
+and this step call the SAME kernels in the same order; `tests/test_gpu_parity.py` checks that the
+gradients agree bit for bit.
+"""
+import ctypes
+
+import torch
+
+from . import _lib, ops
+
+
+def _p(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+class TrainStep:
+    def __init__(self, model, flat, batch, p_drop=None, use_graph=True, seed=1234):
+        """model: raindrop_amd.models_rd.Raindrop_v2 on a ROCm device; flat: FlatGradAllReduce over the
+        live parameters (its buffer receives the gradients); batch: dict(src, static, times, lengths, y)
+        of device tensors that are REUSED every step (copy new data into them)."""
+        self.model, self.flat, self.batch = model, flat, batch
+        self.dev = batch["src"].device
+        self.lib = _lib.load()
+        cfgp = float(model.dropout.p) if p_drop is None else float(p_drop)
+        self.p_drop = cfgp if model.training else 0.0
+        self.seed = int(seed)
+        T, B = batch["src"].shape[0], batch["src"].shape[1]
+        self.T, self.B = T, B
+        self.shp = _lib.shape(B, T, model.d_inp, model.d_ob, d_pe=model.d_pe, nhead=model.nhead, nhid=model.nhid,
+                              d_static=model.d_static if model.static else 0, n_classes=model.n_classes,
+                              max_len=model.max_len)
+        self.sp = ctypes.byref(self.shp)
+        self.D = model.d_inp * model.d_ob + model.d_pe
+        self.graph_info = model._graph(self.dev)                 # adjacency / ssum (built eagerly, once)
+        self.ts = model.pos_encoder.timescales(self.dev)
+        named = dict(model.named_parameters())
+        gview = dict(zip(flat.names, flat.views))                # gradient slices in the flat buffer
+        self.P = named
+        self.G = gview
+        self._alloc()
+        self.seed_cell = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.graph = None
+        if use_graph:
+            self._capture()
+
+    # ------------------------------------------------------------------------------------------
+    def _alloc(self):
+        lib, sp, dev, B, T, D = self.lib, self.sp, self.dev, self.B, self.T, self.D
+        m = self.model
+        f32 = dict(dtype=torch.float32, device=dev)
+        u8 = lambda n: torch.empty(max(int(n), 256), dtype=torch.uint8, device=dev)
+        self.z = torch.empty((T, B, D), **f32)
+        self.mask = torch.empty((B, T), dtype=torch.bool, device=dev)
+        self.k1_saved = u8(lib.rd_msgpass_saved_bytes(sp))
+        self.k1_ws = u8(lib.rd_msgpass_workspace_bytes(sp))
+        self.nl = len(m.transformer_encoder.layers)
+        self.x = [self.z] + [torch.empty((T, B, D), **f32) for _ in range(self.nl)]
+        self.enc_saved = [u8(lib.rd_encoder_layer_saved_bytes(sp)) for _ in range(self.nl)]
+        self.enc_ws = u8(lib.rd_encoder_layer_workspace_bytes(sp))
+        self.dx = [torch.empty((T, B, D), **f32) for _ in range(2)]        # ping-pong gradient buffers
+        self.Fe = m.d_inp if m.static else 0
+        self.feat = torch.empty((B, D + self.Fe), **f32)
+        self.dfeat = torch.empty((B, D + self.Fe), **f32)
+        self.hid = torch.empty((B, D + self.Fe), **f32)
+        self.dhid = torch.empty((B, D + self.Fe), **f32)
+        self.logits = torch.empty((B, m.n_classes), **f32)
+        self.dlogits = torch.empty((B, m.n_classes), **f32)
+        self.loss = torch.zeros((), **f32)
+        dh = D + self.Fe
+        self.wg_ws = u8(max(lib.rd_linear_bwd_weight_workspace_bytes(B, dh, dh),
+                            lib.rd_linear_bwd_weight_workspace_bytes(B, m.n_classes, dh),
+                            lib.rd_linear_bwd_weight_workspace_bytes(B, max(self.Fe, 1), max(m.d_static, 1))))
+        self.enc_w = []
+        self.enc_g = []
+        for i, layer in enumerate(m.transformer_encoder.layers):
+            pre = "transformer_encoder.layers.%d." % i
+            self.enc_w.append(_lib.RdEncoderPtrs(*[self.P[pre + n].data_ptr() for n in ops.ENC_PARAM_NAMES]))
+            self.enc_g.append(_lib.RdEncoderPtrs(*[self.G[pre + n].data_ptr() for n in ops.ENC_PARAM_NAMES]))
+
+    # ------------------------------------------------------------------------------------------
+    def _call(self, name, *a):
+        _lib.call(name, *a)
+
+    def _body(self):
+        """Enqueue one forward + loss + backward on the current stream (no host sync)."""
+        m, b, P, G, sp = self.model, self.batch, self.P, self.G, self.sp
+        st = ops._stream()
+        B, T, D, Fe = self.B, self.T, self.D, self.Fe
+        dh = D + Fe
+        c = self._call
+        if self.p_drop > 0.0:
+            c("rd_seed_cell_advance", _p(self.seed_cell), 1, st)           # fresh masks per replay
+        W1, b1 = P["ob_propagation.lin_value.weight"], P["ob_propagation.lin_value.bias"]
+        W2, b2 = P["ob_propagation_layer2.lin_value.weight"], P["ob_propagation_layer2.lin_value.bias"]
+        ssum = self.graph_info["ssum"]
+        # ---------------- forward ----------------
+        c("rd_sensor_stage_fwd", sp, _p(b["src"]), _p(b["times"]), _p(b["lengths"]), _p(self.ts), _p(P["R_u"]), _p(W1),
+          _p(b1), _p(W2), _p(b2), _p(ssum), self.p_drop, self.seed, _p(self.z), _p(self.mask), _p(self.k1_saved),
+          self.k1_saved.numel(), st)
+        for i in range(self.nl):
+            c("rd_encoder_layer_fwd", sp, i, _p(self.x[i]), _p(self.mask), ctypes.byref(self.enc_w[i]), self.p_drop,
+              self.seed, _p(self.x[i + 1]), _p(self.enc_saved[i]), self.enc_saved[i].numel(), _p(self.enc_ws),
+              self.enc_ws.numel(), st)
+        c("rd_masked_mean_fwd", sp, D, _p(self.x[-1]), _p(self.mask), _p(b["lengths"]), _p(self.feat), dh, st)
+        if Fe:
+            emb_out = self.feat[:, D:]                                       # right block of [agg | emb]
+            c("rd_linear_fwd", B, Fe, m.d_static, _p(b["static"]), m.d_static, _p(P["emb.weight"]), _p(P["emb.bias"]),
+              ctypes.c_void_p(emb_out.data_ptr()), dh, 0, st)
+        c("rd_linear_fwd", B, dh, dh, _p(self.feat), dh, _p(P["mlp_static.0.weight"]), _p(P["mlp_static.0.bias"]),
+          _p(self.hid), dh, 1, st)
+        C = m.n_classes
+        c("rd_linear_fwd", B, C, dh, _p(self.hid), dh, _p(P["mlp_static.2.weight"]), _p(P["mlp_static.2.bias"]),
+          _p(self.logits), C, 0, st)
+        # ---------------- loss: mean cross entropy (code/Raindrop.py:255,322) and its gradient ----------
+        logp = torch.log_softmax(self.logits, dim=1)
+        self.loss.copy_(-(logp.gather(1, b["y"].unsqueeze(1)).mean()))
+        torch.exp(logp, out=self.dlogits)
+        self.dlogits.scatter_add_(1, b["y"].unsqueeze(1), torch.full((B, 1), -1.0, device=self.dev))
+        self.dlogits.mul_(1.0 / B)
+        # ---------------- backward ----------------
+        ws, wsn = _p(self.wg_ws), self.wg_ws.numel()
+        c("rd_linear_bwd_weight", B, C, dh, _p(self.dlogits), C, _p(self.hid), dh, _p(G["mlp_static.2.weight"]),
+          _p(G["mlp_static.2.bias"]), ws, wsn, st)
+        c("rd_linear_bwd_input", B, C, dh, _p(self.dlogits), C, _p(P["mlp_static.2.weight"]), _p(self.dhid), dh, st)
+        self.dhid.mul_(self.hid > 0)                                         # ReLU gate of mlp_static[1]
+        c("rd_linear_bwd_weight", B, dh, dh, _p(self.dhid), dh, _p(self.feat), dh, _p(G["mlp_static.0.weight"]),
+          _p(G["mlp_static.0.bias"]), ws, wsn, st)
+        c("rd_linear_bwd_input", B, dh, dh, _p(self.dhid), dh, _p(P["mlp_static.0.weight"]), _p(self.dfeat), dh, st)
+        if Fe:
+            demb = self.dfeat[:, D:]
+            c("rd_linear_bwd_weight", B, Fe, m.d_static, ctypes.c_void_p(demb.data_ptr()), dh, _p(b["static"]),
+              m.d_static, _p(G["emb.weight"]), _p(G["emb.bias"]), ws, wsn, st)
+        cur = self.dx[0]
+        c("rd_masked_mean_bwd", sp, D, _p(self.dfeat), dh, _p(self.mask), _p(b["lengths"]), _p(cur), st)
+        for i in reversed(range(self.nl)):
+            nxt = self.dx[1] if cur is self.dx[0] else self.dx[0]
+            c("rd_encoder_layer_bwd", sp, i, _p(self.x[i]), _p(self.mask), ctypes.byref(self.enc_w[i]), self.p_drop,
+              self.seed, _p(self.enc_saved[i]), self.enc_saved[i].numel(), _p(cur), _p(nxt), ctypes.byref(self.enc_g[i]),
+              _p(self.enc_ws), self.enc_ws.numel(), st)
+            cur = nxt
+        c("rd_msgpass_bwd", sp, _p(b["src"]), _p(P["R_u"]), _p(W1), _p(W2), _p(ssum), self.p_drop, _p(self.k1_saved),
+          self.k1_saved.numel(), _p(self.z), _p(cur), D, _p(G["ob_propagation.lin_value.weight"]),
+          _p(G["ob_propagation.lin_value.bias"]), _p(G["ob_propagation_layer2.lin_value.weight"]),
+          _p(G["ob_propagation_layer2.lin_value.bias"]), _p(G["R_u"]), _p(self.k1_ws), self.k1_ws.numel(), st)
+
+    def _capture(self):
+        _lib.call("rd_set_seed_cell", _p(self.seed_cell))
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):                                             # warm-up: lazy inits happen here
+                self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self._body()
+
+    # ------------------------------------------------------------------------------------------
+    def run(self):
+        """One forward + loss + backward; gradients land in flat.flat (p.grad views point there)."""
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            _lib.call("rd_set_seed_cell", _p(self.seed_cell))
+            with torch.no_grad():
+                self._body()
+        for p, v in zip(self.flat.params, self.flat.views):
+            p.grad = v
+        return self.loss
+
+    def close(self):
+        _lib.call("rd_set_seed_cell", None)
