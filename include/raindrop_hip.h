@@ -207,6 +207,15 @@ int rd_linear_fwd(int32_t M, int32_t N, int32_t K, const float* x, int32_t ldx, 
 /* dx[M,K] = dy[M,N] W[N,K]   (optionally masked by relu_src > 0 when relu_src != NULL). */
 int rd_linear_bwd_input(int32_t M, int32_t N, int32_t K, const float* dy, int32_t lddy,
                         const float* W, float* dx, int32_t lddx, void* stream);
+/* dx = (dy W) where gate[m,k] > 0, else 0: the ReLU of nn.Sequential(Linear, ReLU, Linear)
+ * (mlp_static, code/models_rd.py:254-258) folded into the input-gradient product. */
+int rd_linear_bwd_input_gated(int32_t M, int32_t N, int32_t K, const float* dy, int32_t lddy,
+                              const float* W, const float* gate, int32_t ldgate, float* dx, int32_t lddx,
+                              void* stream);
+/* torch.nn.CrossEntropyLoss() (mean) forward + backward in one launch (code/Raindrop.py:255,322):
+ * loss[0] = mean_b(logsumexp(logits[b]) - logits[b, y[b]]); dlogits = (softmax - onehot) / B. */
+int rd_softmax_xent(int32_t B, int32_t C, const float* logits, const int64_t* y, float* loss,
+                    float* dlogits, void* stream);
 size_t rd_linear_bwd_weight_workspace_bytes(int32_t M, int32_t N, int32_t K);
 /* dW[N,K] = dy[M,N]^T x[M,K];  db[N] = sum_m dy[m,:]  (db may be NULL).  Deterministic split
  * over M with a fixed-order reduction. */

@@ -88,6 +88,60 @@ extern "C" int rd_linear_bwd_input(int32_t M, int32_t N, int32_t K, const float*
   return launch_gemm(g, (hipStream_t)stream);
 }
 
+// dx = (dy W) gated by gate > 0: the ReLU between two Linear layers folded into the dgrad product
+extern "C" int rd_linear_bwd_input_gated(int32_t M, int32_t N, int32_t K, const float* dy, int32_t lddy,
+                                         const float* W, const float* gate, int32_t ldgate, float* dx,
+                                         int32_t lddx, void* stream) {
+  RD_REQUIRE(M >= 0 && N > 0 && K > 0, "bad dims M=%d N=%d K=%d", M, N, K);
+  if (M == 0) return RD_OK;
+  RD_REQUIRE(dy && W && gate && dx, "NULL tensor");
+  RD_REQUIRE(lddy >= N && lddx >= K && ldgate >= K, "leading dimension too small");
+  GemmArgs g{};
+  g.M = M; g.N = K; g.K = N; g.nsplit = 1;
+  g.A = dy; g.sa_m = lddy; g.sa_k = 1;
+  g.B = W; g.sb_n = 1; g.sb_k = K;
+  g.C = dx; g.sc_m = lddx;
+  g.posmask = gate; g.pm_m = ldgate;
+  return launch_gemm(g, (hipStream_t)stream);
+}
+
+namespace {
+// mean cross entropy over B rows of C logits and its gradient (softmax - onehot) / B, one workgroup,
+// fixed-order tree reduction (code/Raindrop.py:255,322: CrossEntropyLoss().forward + backward)
+__global__ __launch_bounds__(256) void k_softmax_xent(const float* __restrict__ logits, const int64_t* __restrict__ y,
+                                                      float* __restrict__ loss, float* __restrict__ dlogits, int B, int C) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  const float invB = 1.0f / (float)B;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float* row = logits + (long)b * C;
+    float m = row[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, row[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(row[c] - m);
+    const float lse = m + logf(se);
+    const int t = (int)y[b];
+    acc += lse - row[t];
+    for (int c = 0; c < C; ++c) dlogits[(long)b * C + c] = (expf(row[c] - lse) - (c == t ? 1.f : 0.f)) * invB;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss = red[0] * invB;
+}
+}  // namespace
+
+extern "C" int rd_softmax_xent(int32_t B, int32_t C, const float* logits, const int64_t* y, float* loss,
+                               float* dlogits, void* stream) {
+  RD_REQUIRE(B > 0 && C > 0, "bad dims B=%d C=%d", B, C);
+  RD_REQUIRE(logits && y && loss && dlogits, "NULL tensor");
+  hipLaunchKernelGGL(k_softmax_xent, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, y, loss, dlogits, B, C);
+  return check_launch("k_softmax_xent");
+}
+
 extern "C" size_t rd_linear_bwd_weight_workspace_bytes(int32_t M, int32_t N, int32_t K) {
   if (M < 0 || N <= 0 || K <= 0) return 0;
   return align_up((size_t)wgrad_ws_floats(M, N, K) * sizeof(float), 256);

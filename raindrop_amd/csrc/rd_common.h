@@ -84,5 +84,7 @@ int launch_splitk_reduce2(const float* part, int nsplit, long stride, long e1, f
 // out[n] = sum_m x[m*ldx + n], deterministic two-stage; ws needs colsum_ws_floats(M,N) floats
 long colsum_ws_floats(int M, int N);
 int launch_colsum(const float* x, int M, int N, long ldx, float* out, float* ws, hipStream_t st);
+// same, columns [0,n1) to out1 and [n1,N) to out2 (M <= 8192)
+int launch_colsum2(const float* x, int M, int N, long ldx, float* out1, int n1, float* out2, float* ws, hipStream_t st);
 
 }  // namespace rd

@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ x
 // single-stage column sum for short matrices: 1024 threads = 64 columns x 16 row groups, all of a
 // thread's loads independent (deep memory-level parallelism), fixed-order LDS combine.
 __global__ __launch_bounds__(1024) void k_colsum_small(const float* __restrict__ x, int M, int N, long ldx,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, int n1, float* __restrict__ out2) {
   __shared__ float red[16][64];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(1024) void k_colsum_small(const float* __restrict__
     float v = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) v += red[q][cl];
-    out[c] = v;
+    if (c < n1) out[c] = v; else out2[c - n1] = v;
   }
 }
 
@@ -772,12 +772,24 @@ int launch_splitk_reduce(const float* part, int nsplit, long elems, float* out, 
   return check_launch("k_splitk_reduce");
 }
 
+int launch_colsum2(const float* x, int M, int N, long ldx, float* out1, int n1, float* out2, float* ws, hipStream_t st) {
+  if (M <= 8192) {
+    hipLaunchKernelGGL(k_colsum_small, dim3(cdiv(N, 64)), dim3(1024), 0, st, x, M, N, ldx, out1, n1, out2);
+    return check_launch("k_colsum_small");
+  }
+  int rc = launch_colsum(x, M, N, ldx, ws, ws + N, st);          // long matrices: two-stage, then split
+  if (rc) return rc;
+  hipMemcpyAsync(out1, ws, sizeof(float) * n1, hipMemcpyDeviceToDevice, st);
+  hipMemcpyAsync(out2, ws + n1, sizeof(float) * (N - n1), hipMemcpyDeviceToDevice, st);
+  return RD_OK;
+}
+
 long colsum_ws_floats(int M, int N) { return (long)cdiv(M, CS_RPB) * N; }
 
 int launch_colsum(const float* x, int M, int N, long ldx, float* out, float* ws, hipStream_t st) {
   if (N <= 0) return RD_OK;
   if (M <= 8192) {
-    hipLaunchKernelGGL(k_colsum_small, dim3(cdiv(N, 64)), dim3(1024), 0, st, x, M, N, ldx, out);
+    hipLaunchKernelGGL(k_colsum_small, dim3(cdiv(N, 64)), dim3(1024), 0, st, x, M, N, ldx, out, N, (float*)nullptr);
     return check_launch("k_colsum_small");
   }
   const int nby = cdiv(M, CS_RPB);

@@ -645,16 +645,24 @@ int launch_ln_bwd(const float* dy, const float* s, const float* stats, const flo
 }
 
 // code/models_rd.py:366-367,379: agg[b,c] = sum_t r[t,b,c] * (1 - mask[b,t]) / (lengths[b] + 1)
-__global__ __launch_bounds__(256) void k_masked_mean_fwd(const float* __restrict__ r, const uint8_t* __restrict__ mask,
-                                                         const int64_t* __restrict__ lengths, float* __restrict__ out,
-                                                         int T, int B, int D, int ldo) {
-  const int b = blockIdx.x;
-  const float inv = 1.0f / (float)(lengths[b] + 1);
-  for (int c = threadIdx.x; c < D; c += blockDim.x) {
-    float s = 0.f;
-    for (int t = 0; t < T; ++t)
+__global__ __launch_bounds__(1024) void k_masked_mean_fwd(const float* __restrict__ r, const uint8_t* __restrict__ mask,
+                                                          const int64_t* __restrict__ lengths, float* __restrict__ out,
+                                                          int T, int B, int D, int ldo) {
+  // block = (sample, 64-column chunk); 16 time groups x 64 columns, fixed-order LDS combine
+  __shared__ float red[16][64];
+  const int b = blockIdx.x, cl = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  float s = 0.f;
+  if (c < D)
+    for (int t = tg; t < T; t += 16)
       if (!mask[(long)b * T + t]) s += r[((long)t * B + b) * D + c];
-    out[(long)b * ldo + c] = s * inv;
+  red[tg][cl] = s;
+  __syncthreads();
+  if (tg == 0 && c < D) {
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += red[q][cl];
+    out[(long)b * ldo + c] = v / (float)(lengths[b] + 1);
   }
 }
 
@@ -845,9 +853,7 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   if ((rc = launch_ln_bwd(dy, v.s2, v.st2, w->norm2_w, ws.ds2, ws.df, ws.lnpart, (int)e.M, e.D, p_drop, seed,
                           SITE_FFN_OUT + L, st))) return rc;
   // lnpart is a [blocks, 2D] matrix (dgamma | dbeta per block): column-sum it in fixed order
-  if ((rc = launch_colsum(ws.lnpart, lnb, 2 * e.D, 2 * e.D, ws.lnred, ws.lnred + 2 * e.D, st))) return rc;
-  hipMemcpyAsync(g->norm2_w, ws.lnred, sizeof(float) * e.D, hipMemcpyDeviceToDevice, st);
-  hipMemcpyAsync(g->norm2_b, ws.lnred + e.D, sizeof(float) * e.D, hipMemcpyDeviceToDevice, st);
+  if ((rc = launch_colsum2(ws.lnpart, lnb, 2 * e.D, 2 * e.D, g->norm2_w, e.D, g->norm2_b, ws.lnred, st))) return rc;
   Aux& ax = aux();
   hipStream_t sw = ax.ok ? ax.s : st;                       // stream of the weight-gradient products
   // ---- FFN ---------------------------------------------------------------------------------------
@@ -861,9 +867,7 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   // ---- LayerNorm 1 -------------------------------------------------------------------------------
   if ((rc = launch_ln_bwd(ws.dx1, v.s1, v.st1, w->norm1_w, ws.ds1, ws.dout, ws.lnpart, (int)e.M, e.D, p_drop, seed,
                           SITE_ATTN_OUT + L, st))) return rc;
-  if ((rc = launch_colsum(ws.lnpart, lnb, 2 * e.D, 2 * e.D, ws.lnred, ws.lnred + 2 * e.D, st))) return rc;
-  hipMemcpyAsync(g->norm1_w, ws.lnred, sizeof(float) * e.D, hipMemcpyDeviceToDevice, st);
-  hipMemcpyAsync(g->norm1_b, ws.lnred + e.D, sizeof(float) * e.D, hipMemcpyDeviceToDevice, st);
+  if ((rc = launch_colsum2(ws.lnpart, lnb, 2 * e.D, 2 * e.D, g->norm1_w, e.D, g->norm1_b, ws.lnred, st))) return rc;
   // ---- attention output projection ---------------------------------------------------------------
   if (ax.ok) chain(st, sw, ax.ev[2]);
   if ((rc = linear_bwd_w(e.M, e.D, e.D, ws.dout, v.attn, g->out_proj_w, g->out_proj_b, ws.splitk, ws.colsum, sw)))
@@ -894,8 +898,8 @@ extern "C" int rd_masked_mean_fwd(const rd_shape* s, int32_t D, const float* r, 
   RD_REQUIRE(s && s->T > 0 && s->B >= 0 && D > 0 && ldo >= D, "bad arguments");
   if (s->B == 0) return RD_OK;
   RD_REQUIRE(r && mask && lengths && out, "NULL tensor");
-  hipLaunchKernelGGL(k_masked_mean_fwd, dim3(s->B), dim3(256), 0, (hipStream_t)stream, r, mask, lengths, out, s->T,
-                     s->B, D, ldo);
+  hipLaunchKernelGGL(k_masked_mean_fwd, dim3(s->B, cdiv(D, 64)), dim3(1024), 0, (hipStream_t)stream, r, mask, lengths,
+                     out, s->T, s->B, D, ldo);
   return check_launch("k_masked_mean_fwd");
 }
 

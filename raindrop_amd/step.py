@@ -9,7 +9,7 @@ Python in the replay path, every buffer allocated once:
     x_{l+1}          <- rd_encoder_layer_fwd(x_l)               (K2/K3, per layer)
     feat = [agg|emb] <- rd_masked_mean_fwd, rd_linear_fwd       (K5; both write into one buffer)
     logits           <- rd_linear_fwd x2
-    loss, dlogits    <- log-softmax cross entropy (mean)        (tiny torch ops inside the graph)
+    loss, dlogits    <- rd_softmax_xent                         (CrossEntropyLoss fwd+bwd, one launch)
     ... the same chain backwards, each gradient written straight into its slice of the flat
     gradient buffer (raindrop_amd.dp.FlatGradAllReduce): no accumulate kernels, no packing copy.
 
@@ -129,17 +129,13 @@ class TrainStep:
         c("rd_linear_fwd", B, C, dh, _p(self.hid), dh, _p(P["mlp_static.2.weight"]), _p(P["mlp_static.2.bias"]),
           _p(self.logits), C, 0, st)
         # ---------------- loss: mean cross entropy (code/Raindrop.py:255,322) and its gradient ----------
-        logp = torch.log_softmax(self.logits, dim=1)
-        self.loss.copy_(-(logp.gather(1, b["y"].unsqueeze(1)).mean()))
-        torch.exp(logp, out=self.dlogits)
-        self.dlogits.scatter_add_(1, b["y"].unsqueeze(1), torch.full((B, 1), -1.0, device=self.dev))
-        self.dlogits.mul_(1.0 / B)
+        c("rd_softmax_xent", B, C, _p(self.logits), _p(b["y"]), _p(self.loss), _p(self.dlogits), st)
         # ---------------- backward ----------------
         ws, wsn = _p(self.wg_ws), self.wg_ws.numel()
         c("rd_linear_bwd_weight", B, C, dh, _p(self.dlogits), C, _p(self.hid), dh, _p(G["mlp_static.2.weight"]),
           _p(G["mlp_static.2.bias"]), ws, wsn, st)
-        c("rd_linear_bwd_input", B, C, dh, _p(self.dlogits), C, _p(P["mlp_static.2.weight"]), _p(self.dhid), dh, st)
-        self.dhid.mul_(self.hid > 0)                                         # ReLU gate of mlp_static[1]
+        c("rd_linear_bwd_input_gated", B, C, dh, _p(self.dlogits), C, _p(P["mlp_static.2.weight"]), _p(self.hid), dh,
+          _p(self.dhid), dh, st)                                             # ReLU gate of mlp_static[1] folded in
         c("rd_linear_bwd_weight", B, dh, dh, _p(self.dhid), dh, _p(self.feat), dh, _p(G["mlp_static.0.weight"]),
           _p(G["mlp_static.0.bias"]), ws, wsn, st)
         c("rd_linear_bwd_input", B, dh, dh, _p(self.dhid), dh, _p(P["mlp_static.0.weight"]), _p(self.dfeat), dh, st)
