@@ -1,0 +1,234 @@
+// rd_rowgemm.hip -- "row-block x all columns" dense layer for the temporal encoder.
+//
+// The encoder's products are tall and skinny (M = T*B = 15360 tokens, N,K <= 456): a 64x64-tiled
+// GEMM re-reads its operands 4-8x below L1 and is bound by that traffic.  Here ONE
+// workgroup owns 64 complete rows: the activation rows are read from HBM exactly once, split to
+// bf16 hi/lo planes in LDS, and every wave streams its slice of the PRE-SPLIT weight planes from L2
+// straight into registers as MFMA B operands -- the same machinery as the fused message-passing
+// kernel (rd_msgpass_fused.hip), so the weight stream is the only repeated traffic.
+//
+//   C[m, n] = epilogue( sum_k A[m, k] * Wp[n, k] ),   Wp = weight planes [NP][KP] (hi, lo), rows = n
+// forward  (x W^T):  Wp = split(W)      [N rows, K cols]
+// dgrad    (dy W):   Wp = split(W^T)    [K rows, N cols]
+// Split-bf16 arithmetic (hi*hi + hi*lo + lo*hi, fp32 accumulate) as everywhere else.
+#include "rd_common.h"
+#include "rd_rng.h"
+
+namespace rd {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RG_ROWS = 64, RG_THR = 512, RG_WAVES = 8, RG_NJ = 2;
+constexpr int RG_CPR = RG_WAVES * RG_NJ * 16;      // 256 output columns per round
+constexpr int RG_LDS_STAGE = RG_CPR + 4;           // fp32 stage row stride
+
+struct RowGemmArgs {
+  const float* A; long lda;                         // [M, K] fp32
+  const __bf16* Wh; const __bf16* Wl;               // [NP16][KP] planes
+  float* C; long ldc;
+  int M, N, K, KP;
+  const float* bias; int relu;
+  const float* posmask; long pm_ld; float cscale;
+  const float* residual; long res_ld;
+  float drop_p; uint64_t drop_seed; uint32_t drop_site; const uint64_t* seed_cell;
+};
+
+// one weight matrix -> hi/lo planes; transpose != 0 writes split(W^T): rows k, cols n
+struct SplitJob { const float* W; int N, K, transpose; __bf16* hi; __bf16* lo; int rows, cols_p; };
+struct SplitJobs { SplitJob j[8]; int n; };
+
+__global__ __launch_bounds__(256) void k_wsplit(SplitJobs jobs) {
+  const SplitJob jb = jobs.j[blockIdx.y];
+  const long total = (long)jb.rows * jb.cols_p;
+  const int src_rows = jb.transpose ? jb.K : jb.N, src_cols = jb.transpose ? jb.N : jb.K;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int r = (int)(i / jb.cols_p), c = (int)(i - (long)r * jb.cols_p);
+    float x = 0.f;
+    if (r < src_rows && c < src_cols) x = jb.transpose ? jb.W[(long)c * jb.K + r] : jb.W[(long)r * jb.K + c];
+    const __bf16 h = (__bf16)x;
+    jb.hi[i] = h;
+    jb.lo[i] = (__bf16)(x - (float)h);
+  }
+}
+
+template <int KC>
+struct RPanel { bf16x8 h[RG_NJ][KC], l[RG_NJ][KC]; };
+
+template <int KC>
+__device__ __forceinline__ void rg_load_panel(RPanel<KC>& p, const __bf16* __restrict__ Wh, const __bf16* __restrict__ Wl,
+                                              int KP, int tile0, int ntiles, int wave, int lane) {
+#pragma unroll
+  for (int jj = 0; jj < RG_NJ; ++jj) {
+    const int j = tile0 + wave + RG_WAVES * jj;
+    const size_t off = (size_t)(16 * (j < ntiles ? j : 0) + (lane & 15)) * KP + 8 * (lane >> 4);
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      p.h[jj][kc] = *reinterpret_cast<const bf16x8*>(Wh + off + kc * 32);
+      p.l[jj][kc] = *reinterpret_cast<const bf16x8*>(Wl + off + kc * 32);
+    }
+  }
+}
+
+template <int KC>
+__global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
+  constexpr int KPc = KC * 32, LDA = KPc + 8;       // bf16 elements per A-plane row
+  __bf16* Ah = reinterpret_cast<__bf16*>(rsm);
+  __bf16* Al = Ah + RG_ROWS * LDA;
+  float* stage = reinterpret_cast<float*>(Al + RG_ROWS * LDA);         // [64][260] fp32
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * RG_ROWS;
+  const int ntiles = (a.N + 15) >> 4;
+  const int nrounds = (ntiles + RG_WAVES * RG_NJ - 1) / (RG_WAVES * RG_NJ);
+
+  RPanel<KC> pw;
+  rg_load_panel<KC>(pw, a.Wh, a.Wl, a.KP, 0, ntiles, wave, lane);      // weight stream starts first
+
+  // ---- A rows -> split planes (zero padded); 16-byte loads, K % 4 == 0 ---------------------------
+  {
+    const int kq = KPc / 4;                                            // float4 slots per row (incl. pad)
+    for (int i = tid; i < RG_ROWS * kq; i += RG_THR) {
+      const int r = i / kq, k = 4 * (i - r * kq);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m0 + r < a.M && k < a.K) v = *reinterpret_cast<const float4*>(a.A + (long)(m0 + r) * a.lda + k);
+      bf16x4 h, l;
+      const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { h[c] = (__bf16)x[c]; l[c] = (__bf16)(x[c] - (float)h[c]); }
+      *reinterpret_cast<bf16x4*>(Ah + r * LDA + k) = h;
+      *reinterpret_cast<bf16x4*>(Al + r * LDA + k) = l;
+    }
+  }
+  __syncthreads();
+
+  const float inv_keep = 1.0f / (1.0f - a.drop_p);
+  const uint64_t seed = eff_seed(a.drop_seed, a.seed_cell);
+  const int aoff = (lane & 15) * LDA + 8 * (lane >> 4);
+  for (int rd = 0; rd < nrounds; ++rd) {
+    const int tile0 = rd * RG_WAVES * RG_NJ;
+    f32x4 acc[RG_NJ][4];
+#pragma unroll
+    for (int jj = 0; jj < RG_NJ; ++jj)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc[jj][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      bf16x8 ah[4], al[4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * LDA + aoff + kc * 32);
+        al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * LDA + aoff + kc * 32);
+      }
+#pragma unroll
+      for (int jj = 0; jj < RG_NJ; ++jj)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+          acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], pw.h[jj][kc], acc[jj][rt], 0, 0, 0);
+#pragma unroll
+      for (int jj = 0; jj < RG_NJ; ++jj)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+          acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], pw.l[jj][kc], acc[jj][rt], 0, 0, 0);
+#pragma unroll
+      for (int jj = 0; jj < RG_NJ; ++jj)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+          acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], pw.h[jj][kc], acc[jj][rt], 0, 0, 0);
+    }
+    // next round's weights stream while this round's epilogue runs
+    if (rd + 1 < nrounds) rg_load_panel<KC>(pw, a.Wh, a.Wl, a.KP, tile0 + RG_WAVES * RG_NJ, ntiles, wave, lane);
+    // ---- accumulators -> stage tile (column = position inside this round's 256-column window) ----
+#pragma unroll
+    for (int jj = 0; jj < RG_NJ; ++jj)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          stage[(rt * 16 + 4 * (lane >> 4) + r) * RG_LDS_STAGE + (wave + RG_WAVES * jj) * 16 + (lane & 15)] = acc[jj][rt][r];
+    __syncthreads();
+    // ---- epilogue over the stage tile: thread = (row, 4 consecutive columns); all global reads first
+    const int n_base = tile0 * 16;
+    const int ncols = min(RG_CPR, a.N - n_base);                       // valid columns this round (multiple of 4)
+    const int qpr = ncols >> 2;
+    for (int e = tid; e < RG_ROWS * qpr; e += RG_THR) {
+      const int rl = e / qpr, q = e - rl * qpr;
+      const int m = m0 + rl, n = n_base + 4 * q;
+      if (m >= a.M) continue;
+      float4 pm = make_float4(1.f, 1.f, 1.f, 1.f), rs = make_float4(0.f, 0.f, 0.f, 0.f), bs = rs;
+      if (a.posmask) pm = *reinterpret_cast<const float4*>(a.posmask + (long)m * a.pm_ld + n);
+      if (a.residual) rs = *reinterpret_cast<const float4*>(a.residual + (long)m * a.res_ld + n);
+      if (a.bias) bs = *reinterpret_cast<const float4*>(a.bias + n);
+      const float4 s4 = *reinterpret_cast<const float4*>(stage + rl * RG_LDS_STAGE + 4 * q);
+      float v[4] = {s4.x + bs.x, s4.y + bs.y, s4.z + bs.z, s4.w + bs.w};
+      const float pmv[4] = {pm.x, pm.y, pm.z, pm.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+      float4 du = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (a.drop_p > 0.f) du = uniform4(seed, a.drop_site, ((uint64_t)m * a.N + n) >> 2);
+      const float uu[4] = {du.x, du.y, du.z, du.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float x = v[c];
+        if (a.relu) x = fmaxf(x, 0.f);
+        if (a.posmask) x = pmv[c] > 0.f ? x : 0.f;
+        if (a.cscale != 0.f) x *= a.cscale;
+        if (a.drop_p > 0.f) x = uu[c] >= a.drop_p ? x * inv_keep : 0.f;
+        v[c] = x + rsv[c];
+      }
+      *reinterpret_cast<float4*>(a.C + (long)m * a.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+  }
+}
+
+template <int KC>
+int launch_rowgemm_kc(const RowGemmArgs& a, hipStream_t st) {
+  const size_t lds = (size_t)2 * RG_ROWS * (KC * 32 + 8) * sizeof(__bf16) + (size_t)RG_ROWS * RG_LDS_STAGE * sizeof(float);
+  { static bool once = false; if (!once) { hipFuncSetAttribute((const void*)k_rowgemm<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } }
+  hipLaunchKernelGGL(k_rowgemm<KC>, dim3(cdiv(a.M, RG_ROWS)), dim3(RG_THR), lds, st, a);
+  return check_launch("k_rowgemm");
+}
+
+}  // namespace
+
+// ---- host interface (used by rd_temporal.hip) -----------------------------------------------------
+bool rowgemm_ok(int N, int K, long lda, long ldc) {
+  static const bool enabled = [] { const char* e = getenv("RD_ROWGEMM"); return !(e && atoi(e) == 0); }();
+  const int kc = (K + 31) / 32;
+  return enabled && precision() == RD_PREC_BF16X3 && (N % 4) == 0 && (K % 4) == 0 && (lda % 4) == 0 && (ldc % 4) == 0 &&
+         (kc == 5 || kc == 9);
+}
+size_t rowgemm_plane_elems(int rows, int cols) { return (size_t)((rows + 15) / 16 * 16) * ((cols + 31) / 32 * 32); }
+
+// split up to 8 weight matrices with one launch; job i: W [N_i, K_i] -> planes at hi_i / lo_i
+int launch_wsplit(int njobs, const float* const* W, const int* N, const int* K, const int* transpose, __bf16* const* hi,
+                  __bf16* const* lo, hipStream_t st) {
+  SplitJobs jobs{};
+  jobs.n = njobs;
+  for (int i = 0; i < njobs; ++i) {
+    SplitJob& j = jobs.j[i];
+    j.W = W[i]; j.N = N[i]; j.K = K[i]; j.transpose = transpose[i]; j.hi = hi[i]; j.lo = lo[i];
+    const int rows = transpose[i] ? K[i] : N[i], cols = transpose[i] ? N[i] : K[i];
+    j.rows = (rows + 15) / 16 * 16; j.cols_p = (cols + 31) / 32 * 32;
+  }
+  hipLaunchKernelGGL(k_wsplit, dim3(64, njobs), dim3(256), 0, st, jobs);
+  return check_launch("k_wsplit");
+}
+
+// C[M,N] = epi(A[M,K] Wp^T): Wp planes [ceil16(N)][ceil32(K)]
+int launch_rowgemm(long M, int N, int K, const float* A, long lda, const void* Wh, const void* Wl, float* C, long ldc,
+                   const float* bias, int relu, const float* posmask, long pm_ld, float cscale, const float* residual,
+                   long res_ld, float drop_p, uint64_t drop_seed, uint32_t drop_site, hipStream_t st) {
+  RowGemmArgs a{};
+  a.A = A; a.lda = lda; a.Wh = (const __bf16*)Wh; a.Wl = (const __bf16*)Wl; a.C = C; a.ldc = ldc;
+  a.M = (int)M; a.N = N; a.K = K; a.KP = (K + 31) / 32 * 32;
+  a.bias = bias; a.relu = relu; a.posmask = posmask; a.pm_ld = pm_ld; a.cscale = cscale;
+  a.residual = residual; a.res_ld = res_ld;
+  a.drop_p = drop_p; a.drop_seed = drop_seed; a.drop_site = drop_site; a.seed_cell = seed_cell();
+  const int kc = a.KP / 32;
+  if (kc == 5) return launch_rowgemm_kc<5>(a, st);
+  if (kc == 9) return launch_rowgemm_kc<9>(a, st);
+  return fail(RD_EUNSUPPORTED, "rowgemm: K=%d not built", K);
+}
+
+}  // namespace rd

@@ -20,6 +20,15 @@
 #include "rd_rng.h"
 
 namespace rd {
+// row-block dense layer on pre-split weight planes (rd_rowgemm.hip)
+bool rowgemm_ok(int N, int K, long lda, long ldc);
+size_t rowgemm_plane_elems(int rows, int cols);
+int launch_wsplit(int njobs, const float* const* W, const int* N, const int* K, const int* transpose, __bf16* const* hi,
+                  __bf16* const* lo, hipStream_t st);
+int launch_rowgemm(long M, int N, int K, const float* A, long lda, const void* Wh, const void* Wl, float* C, long ldc,
+                   const float* bias, int relu, const float* posmask, long pm_ld, float cscale, const float* residual,
+                   long res_ld, float drop_p, uint64_t drop_seed, uint32_t drop_site, hipStream_t st);
+
 namespace {
 
 constexpr int TS = 64;          // sequence tile (queries and keys)
@@ -688,7 +697,8 @@ EncDims enc_dims(const rd_shape* s) {
   return e;
 }
 
-struct EncSaved { float *qkv, *attn, *lse, *s1, *st1, *x1, *h, *s2, *st2; size_t bytes; };
+struct EncSaved { float *qkv, *attn, *lse, *s1, *st1, *x1, *h, *s2, *st2; __bf16* pl[7][2]; size_t bytes; };
+// weight planes kept from forward to backward: 0 in_proj, 1 out_proj, 2 lin1, 3 lin2, 4 out_proj^T, 5 lin2^T, 6 lin1^T
 EncSaved carve_saved(const EncDims& e, void* base) {
   EncSaved v; size_t off = 0;
   auto take = [&](size_t n) { float* p = base ? (float*)((char*)base + off) : nullptr;
@@ -696,6 +706,10 @@ EncSaved carve_saved(const EncDims& e, void* base) {
   v.qkv = take(e.M * 3 * e.D); v.attn = take(e.M * e.D); v.lse = take((size_t)e.B * e.H * e.T);
   v.s1 = take(e.M * e.D); v.st1 = take(e.M * 2); v.x1 = take(e.M * e.D);
   v.h = take(e.M * e.nhid); v.s2 = take(e.M * e.D); v.st2 = take(e.M * 2);
+  const int prow[7] = {3 * e.D, e.D, e.nhid, e.D, e.D, e.nhid, e.D};      // plane rows = output columns
+  const int pcol[7] = {e.D, e.D, e.D, e.nhid, e.D, e.D, e.nhid};          // plane cols = reduction length
+  for (int i = 0; i < 7; ++i)
+    for (int h = 0; h < 2; ++h) v.pl[i][h] = (__bf16*)take((rowgemm_plane_elems(prow[i], pcol[i]) + 1) / 2);
   v.bytes = off;
   return v;
 }
@@ -813,20 +827,43 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
   if (e.B == 0) return RD_OK;
   hipStream_t st = (hipStream_t)stream;
   const uint32_t L = (uint32_t)layer;
-  if ((rc = linear_fwd(e.M, 3 * e.D, e.D, x, w->in_proj_w, w->in_proj_b, v.qkv, 0, 0.f, 0, 0, st))) return rc;
+  // weights -> bf16 hi/lo planes (both orientations needed by this layer's forward and backward), one launch
+  const bool rg = rowgemm_ok(3 * e.D, e.D, e.D, 3 * e.D) && rowgemm_ok(e.D, e.D, e.D, e.D) &&
+                  rowgemm_ok(e.nhid, e.D, e.D, e.nhid) && rowgemm_ok(e.D, e.nhid, e.nhid, e.D);
+  if (rg) {
+    const float* Ws[7] = {w->in_proj_w, w->out_proj_w, w->lin1_w, w->lin2_w, w->out_proj_w, w->lin2_w, w->lin1_w};
+    const int Ns[7] = {3 * e.D, e.D, e.nhid, e.D, e.D, e.D, e.nhid};
+    const int Ks[7] = {e.D, e.D, e.D, e.nhid, e.D, e.nhid, e.D};
+    const int Tr[7] = {0, 0, 0, 0, 1, 1, 1};
+    __bf16* his[7]; __bf16* los[7];
+    for (int i = 0; i < 7; ++i) { his[i] = v.pl[i][0]; los[i] = v.pl[i][1]; }
+    if ((rc = launch_wsplit(7, Ws, Ns, Ks, Tr, his, los, st))) return rc;
+    if ((rc = launch_rowgemm(e.M, 3 * e.D, e.D, x, e.D, v.pl[0][0], v.pl[0][1], v.qkv, 3 * e.D, w->in_proj_b, 0, nullptr, 0,
+                             0.f, nullptr, 0, 0.f, 0, 0, st))) return rc;
+  } else if ((rc = linear_fwd(e.M, 3 * e.D, e.D, x, w->in_proj_w, w->in_proj_b, v.qkv, 0, 0.f, 0, 0, st))) return rc;
   AttnArgs a{};
   a.qkv = v.qkv; a.mask = mask; a.out = v.attn; a.lse = v.lse;
   a.T = e.T; a.B = e.B; a.D = e.D; a.H = e.H; a.hd = e.Hd;
   a.scale = 1.0f / sqrtf((float)e.Hd); a.p_drop = p_drop; a.seed = seed; a.site = SITE_ATTN_PROB + L; a.seed_cell = seed_cell();
   if ((rc = dispatch_attn(a, 0, st))) return rc;
-  if ((rc = linear_fwd(e.M, e.D, e.D, v.attn, w->out_proj_w, w->out_proj_b, ws.o, 0, 0.f, 0, 0, st))) return rc;
+  if (rg) {
+    if ((rc = launch_rowgemm(e.M, e.D, e.D, v.attn, e.D, v.pl[1][0], v.pl[1][1], ws.o, e.D, w->out_proj_b, 0, nullptr, 0, 0.f,
+                             nullptr, 0, 0.f, 0, 0, st))) return rc;
+  } else if ((rc = linear_fwd(e.M, e.D, e.D, v.attn, w->out_proj_w, w->out_proj_b, ws.o, 0, 0.f, 0, 0, st))) return rc;
   const int lnblocks = cdiv((int)e.M, 4);
   hipLaunchKernelGGL(k_add_ln_fwd, dim3(lnblocks), dim3(256), 0, st, x, ws.o, w->norm1_w, w->norm1_b, v.s1, v.x1,
                      v.st1, (int)e.M, e.D, p_drop, seed, SITE_ATTN_OUT + L, seed_cell());
   if ((rc = check_launch("k_add_ln_fwd"))) return rc;
-  if ((rc = linear_fwd(e.M, e.nhid, e.D, v.x1, w->lin1_w, w->lin1_b, v.h, 1, p_drop, seed, SITE_FFN_HID + L, st)))
-    return rc;
-  if ((rc = linear_fwd(e.M, e.D, e.nhid, v.h, w->lin2_w, w->lin2_b, ws.f, 0, 0.f, 0, 0, st))) return rc;
+  if (rg) {
+    if ((rc = launch_rowgemm(e.M, e.nhid, e.D, v.x1, e.D, v.pl[2][0], v.pl[2][1], v.h, e.nhid, w->lin1_b, 1, nullptr, 0, 0.f,
+                             nullptr, 0, p_drop, seed, SITE_FFN_HID + L, st))) return rc;
+    if ((rc = launch_rowgemm(e.M, e.D, e.nhid, v.h, e.nhid, v.pl[3][0], v.pl[3][1], ws.f, e.D, w->lin2_b, 0, nullptr, 0, 0.f,
+                             nullptr, 0, 0.f, 0, 0, st))) return rc;
+  } else {
+    if ((rc = linear_fwd(e.M, e.nhid, e.D, v.x1, w->lin1_w, w->lin1_b, v.h, 1, p_drop, seed, SITE_FFN_HID + L, st)))
+      return rc;
+    if ((rc = linear_fwd(e.M, e.D, e.nhid, v.h, w->lin2_w, w->lin2_b, ws.f, 0, 0.f, 0, 0, st))) return rc;
+  }
   hipLaunchKernelGGL(k_add_ln_fwd, dim3(lnblocks), dim3(256), 0, st, v.x1, ws.f, w->norm2_w, w->norm2_b, v.s2, y,
                      v.st2, (int)e.M, e.D, p_drop, seed, SITE_FFN_OUT + L, seed_cell());
   return check_launch("k_add_ln_fwd");
@@ -859,11 +896,19 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   // ---- FFN ---------------------------------------------------------------------------------------
   if (ax.ok) chain(st, sw, ax.ev[0]);
   if ((rc = linear_bwd_w(e.M, e.D, e.nhid, ws.df, v.h, g->lin2_w, g->lin2_b, ws.splitk, ws.colsum, sw))) return rc;
-  if ((rc = linear_bwd_x(e.M, e.D, e.nhid, ws.df, w->lin2_w, ws.du, v.h, p_drop > 0.f ? keep : 0.f, nullptr, st)))
-    return rc;                                                     // du = (df W2) gated by h>0, * keep
+  const bool rg = rowgemm_ok(3 * e.D, e.D, e.D, 3 * e.D) && rowgemm_ok(e.D, e.D, e.D, e.D) &&
+                  rowgemm_ok(e.nhid, e.D, e.D, e.nhid) && rowgemm_ok(e.D, e.nhid, e.nhid, e.D);
+  if (rg) {                                                        // du = (df W2) gated by h>0, * keep
+    if ((rc = launch_rowgemm(e.M, e.nhid, e.D, ws.df, e.D, v.pl[5][0], v.pl[5][1], ws.du, e.nhid, nullptr, 0, v.h, e.nhid,
+                             p_drop > 0.f ? keep : 0.f, nullptr, 0, 0.f, 0, 0, st))) return rc;
+  } else if ((rc = linear_bwd_x(e.M, e.D, e.nhid, ws.df, w->lin2_w, ws.du, v.h, p_drop > 0.f ? keep : 0.f, nullptr, st)))
+    return rc;
   if (ax.ok) chain(st, sw, ax.ev[1]);
   if ((rc = linear_bwd_w(e.M, e.nhid, e.D, ws.du, v.x1, g->lin1_w, g->lin1_b, ws.splitk, ws.colsum, sw))) return rc;
-  if ((rc = linear_bwd_x(e.M, e.nhid, e.D, ws.du, w->lin1_w, ws.dx1, nullptr, 0.f, ws.ds2, st))) return rc;
+  if (rg) {
+    if ((rc = launch_rowgemm(e.M, e.D, e.nhid, ws.du, e.nhid, v.pl[6][0], v.pl[6][1], ws.dx1, e.D, nullptr, 0, nullptr, 0, 0.f,
+                             ws.ds2, e.D, 0.f, 0, 0, st))) return rc;
+  } else if ((rc = linear_bwd_x(e.M, e.nhid, e.D, ws.du, w->lin1_w, ws.dx1, nullptr, 0.f, ws.ds2, st))) return rc;
   // ---- LayerNorm 1 -------------------------------------------------------------------------------
   if ((rc = launch_ln_bwd(ws.dx1, v.s1, v.st1, w->norm1_w, ws.ds1, ws.dout, ws.lnpart, (int)e.M, e.D, p_drop, seed,
                           SITE_ATTN_OUT + L, st))) return rc;
@@ -872,7 +917,10 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   if (ax.ok) chain(st, sw, ax.ev[2]);
   if ((rc = linear_bwd_w(e.M, e.D, e.D, ws.dout, v.attn, g->out_proj_w, g->out_proj_b, ws.splitk, ws.colsum, sw)))
     return rc;
-  if ((rc = linear_bwd_x(e.M, e.D, e.D, ws.dout, w->out_proj_w, ws.da, nullptr, 0.f, nullptr, st))) return rc;
+  if (rg) {
+    if ((rc = launch_rowgemm(e.M, e.D, e.D, ws.dout, e.D, v.pl[4][0], v.pl[4][1], ws.da, e.D, nullptr, 0, nullptr, 0, 0.f,
+                             nullptr, 0, 0.f, 0, 0, st))) return rc;
+  } else if ((rc = linear_bwd_x(e.M, e.D, e.D, ws.dout, w->out_proj_w, ws.da, nullptr, 0.f, nullptr, st))) return rc;
   // ---- attention core ----------------------------------------------------------------------------
   AttnArgs a{};
   a.qkv = v.qkv; a.mask = mask; a.out = v.attn; a.lse = v.lse; a.dout = ws.da; a.dqkv = ws.dqkv; a.delta = ws.delta;

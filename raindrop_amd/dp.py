@@ -34,17 +34,23 @@ class FlatGradAllReduce:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.params = [p for _, p in params]
         self.names = [n for n, _ in params]
-        total = sum(p.numel() for p in self.params)
+        # every slice starts on a 256-byte boundary: the kernels use 16-byte loads on weights and
+        # biases whenever the pointer allows it (the padding floats stay zero and are harmless to
+        # the all-reduce and to Adam)
+        align = 64
+        offs, off = [], 0
+        for p in self.params:
+            offs.append(off)
+            off += (p.numel() + align - 1) // align * align
+        total = off
         dev = self.params[0].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        off = 0
         self.slices = []
         self.views = []
-        for p in self.params:
+        for p, o in zip(self.params, offs):
             n = p.numel()
-            self.slices.append((off, off + n))
-            self.views.append(self.flat[off:off + n].view_as(p))
-            off += n
+            self.slices.append((o, o + n))
+            self.views.append(self.flat[o:o + n].view_as(p))
         # buckets: contiguous ranges of the flat buffer, balanced by bytes; at <= 8 MB a ring
         # all-reduce on the xGMI mesh is latency-bound, so few and large
         n_buckets = max(1, min(n_buckets, len(self.params)))
@@ -55,7 +61,7 @@ class FlatGradAllReduce:
             if acc >= target * (b + 1) and b < n_buckets - 1:
                 bounds.append(self.slices[i][0])
                 b += 1
-            acc += p.numel()
+            acc = self.slices[i][1]
         bounds.append(total)
         self.bounds = bounds
         self.n_buckets = len(bounds) - 1
@@ -69,7 +75,7 @@ class FlatGradAllReduce:
         then updates 0.5 M weights with one elementwise kernel instead of a 35-tensor multi-tensor
         launch.  Adam is elementwise, so this is numerically identical to per-tensor Adam."""
         total = self.flat.numel()
-        pbuf = torch.empty(total, dtype=torch.float32, device=self.flat.device)
+        pbuf = torch.zeros(total, dtype=torch.float32, device=self.flat.device)
         for p, (lo, hi) in zip(self.params, self.slices):
             pbuf[lo:hi].copy_(p.data.reshape(-1))
             p.data = pbuf[lo:hi].view_as(p)
@@ -86,8 +92,8 @@ class FlatGradAllReduce:
     def finish(self):
         """Pack the fresh gradients into the flat buffer (one batched copy), all-reduce it and leave
         every p.grad pointing at its slice.  Parameters without a gradient this step contribute 0."""
-        grads = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
-        torch.cat(grads, out=self.flat)
+        grads = [(p.grad if p.grad is not None else torch.zeros_like(p)) for p in self.params]
+        torch._foreach_copy_(self.views, grads)                  # one batched copy into the (padded) slices
         if self.world > 1:
             use_avg = self.average and dist.get_backend(self.group) == "nccl"
             op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM
