@@ -692,10 +692,13 @@ static int wgrad_tile() {
   return t;
 }
 
+static int g_splitk_want = [] { const char* e = getenv("RD_SPLITK_WANT"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 640; }();
+extern "C" void rd_debug_set_splitk_want(int v) { g_splitk_want = v > 0 ? v : 640; }   // not part of the ABI
+
 int splitk_plan(long red, int rows, int cols, int* k_per_split) {
   const int tile = (rows >= 96 && cols >= 96) ? wgrad_tile() : 64;
   const int tiles = cdiv(rows, tile) * cdiv(cols, tile);
-  const int want = cdiv(tile == 128 ? 256 : 320, tiles);  // ~1 workgroup per CU in total
+  const int want = cdiv(tile == 128 ? 256 : g_splitk_want, tiles);  // workgroups in flight over the whole product
   const int r = red > 0 ? (int)red : 1;
   int per = (int)align_up((size_t)cdiv(r, want), 64);
   *k_per_split = per;
@@ -705,11 +708,14 @@ int splitk_plan(long red, int rows, int cols, int* k_per_split) {
 // dW[N,K] = dy[M,N]^T x[M,K] and db[N] = sum_m dy[m,:] with ONE pass over dy: the split-K product
 // accumulates the row sums of its A operand (= dy^T) on the side.  ws: nsplit*(N*K + N) floats.
 long wgrad_ws_floats(long M, int N, int K) {
+  if (wgrad_slab_ok(M, N, K)) return wgrad_slab_ws_floats(M, N, K);
   int kps; const int ns = splitk_plan(M, N, K, &kps);
   return (long)ns * ((long)N * K + N);
 }
 int launch_wgrad(long M, int N, int K, const float* dy, long lddy, const float* x, long ldx, float* dW,
                  float* db, float* ws, hipStream_t st) {
+  if (wgrad_slab_ok(M, N, K))
+    return launch_wgrad_slab(M, N, K, dy, lddy, x, ldx, dW, db, nullptr, nullptr, nullptr, nullptr, ws, st);
   int kps; const int ns = splitk_plan(M, N, K, &kps);
   GemmArgs t{};
   t.M = N; t.N = K; t.K = (int)M;
@@ -731,6 +737,7 @@ int launch_wgrad(long M, int N, int K, const float* dy, long lddy, const float* 
 
 int launch_wgrad2(long M, int N, int K, const float* dyA, const float* xA, float* dWA, float* dbA,
                   const float* dyB, const float* xB, float* dWB, float* dbB, float* ws, hipStream_t st) {
+  if (wgrad_slab_ok(M, N, K)) return launch_wgrad_slab(M, N, K, dyA, N, xA, K, dWA, dbA, dyB, xB, dWB, dbB, ws, st);
   int kps; const int ns = splitk_plan(M, N, K, &kps);
   const long stride = (long)N * K + N;
   if (ns <= 1 || precision() != RD_PREC_BF16X3) {      // the batched form exists for the split bf16x3 kernel only

@@ -24,6 +24,12 @@ constexpr int RG_ROWS = 64, RG_THR = 512, RG_WAVES = 8, RG_NJ = 2;
 constexpr int RG_CPR = RG_WAVES * RG_NJ * 16;      // 256 output columns per round
 constexpr int RG_LDS_STAGE = RG_CPR + 4;           // fp32 stage row stride
 
+__device__ unsigned long long* g_rg_stamps = nullptr;          // debug only (tools/rowgemm_timing.py)
+#define RGSTAMP(i)                                                                          \
+  do {                                                                                      \
+    if (g_rg_stamps && blockIdx.x < 8 && threadIdx.x == 0) g_rg_stamps[blockIdx.x * 16 + (i)] = clock64(); \
+  } while (0)
+
 struct RowGemmArgs {
   const float* A; long lda;                         // [M, K] fp32
   const __bf16* Wh; const __bf16* Wl;               // [NP16][KP] planes
@@ -83,25 +89,38 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
   const int ntiles = (a.N + 15) >> 4;
   const int nrounds = (ntiles + RG_WAVES * RG_NJ - 1) / (RG_WAVES * RG_NJ);
 
+  RGSTAMP(0);
   RPanel<KC> pw;
   rg_load_panel<KC>(pw, a.Wh, a.Wl, a.KP, 0, ntiles, wave, lane);      // weight stream starts first
 
-  // ---- A rows -> split planes (zero padded); 16-byte loads, K % 4 == 0 ---------------------------
+  // ---- A rows -> split planes (zero padded); 16-byte loads, K % 4 == 0.  64 rows x KPc/4 quads is
+  // exactly KC quads per thread: all of a thread's loads are issued before the first is consumed
+  // (one HBM round trip for the whole tile instead of one per quad).
   {
-    const int kq = KPc / 4;                                            // float4 slots per row (incl. pad)
-    for (int i = tid; i < RG_ROWS * kq; i += RG_THR) {
+    constexpr int kq = KPc / 4;                                        // float4 slots per row (incl. pad)
+    float4 v[KC];
+#pragma unroll
+    for (int it = 0; it < KC; ++it) {
+      const int i = tid + it * RG_THR;
       const int r = i / kq, k = 4 * (i - r * kq);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m0 + r < a.M && k < a.K) v = *reinterpret_cast<const float4*>(a.A + (long)(m0 + r) * a.lda + k);
+      v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m0 + r < a.M && k < a.K) v[it] = *reinterpret_cast<const float4*>(a.A + (long)(m0 + r) * a.lda + k);
+    }
+#pragma unroll
+    for (int it = 0; it < KC; ++it) {
+      const int i = tid + it * RG_THR;
+      const int r = i / kq, k = 4 * (i - r * kq);
       bf16x4 h, l;
-      const float x[4] = {v.x, v.y, v.z, v.w};
+      const float x[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
 #pragma unroll
       for (int c = 0; c < 4; ++c) { h[c] = (__bf16)x[c]; l[c] = (__bf16)(x[c] - (float)h[c]); }
       *reinterpret_cast<bf16x4*>(Ah + r * LDA + k) = h;
       *reinterpret_cast<bf16x4*>(Al + r * LDA + k) = l;
     }
   }
+  RGSTAMP(1);
   __syncthreads();
+  RGSTAMP(2);
 
   const float inv_keep = 1.0f / (1.0f - a.drop_p);
   const uint64_t seed = eff_seed(a.drop_seed, a.seed_cell);
@@ -137,6 +156,7 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
         for (int rt = 0; rt < 4; ++rt)
           acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], pw.h[jj][kc], acc[jj][rt], 0, 0, 0);
     }
+    if (rd == 0) RGSTAMP(3);
     // next round's weights stream while this round's epilogue runs
     if (rd + 1 < nrounds) rg_load_panel<KC>(pw, a.Wh, a.Wl, a.KP, tile0 + RG_WAVES * RG_NJ, ntiles, wave, lane);
     // ---- accumulators -> stage tile (column = position inside this round's 256-column window) ----
@@ -147,7 +167,9 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           stage[(rt * 16 + 4 * (lane >> 4) + r) * RG_LDS_STAGE + (wave + RG_WAVES * jj) * 16 + (lane & 15)] = acc[jj][rt][r];
+    if (rd == 0) RGSTAMP(4);
     __syncthreads();
+    if (rd == 0) RGSTAMP(5);
     // ---- epilogue over the stage tile: thread = (row, 4 consecutive columns); all global reads first
     const int n_base = tile0 * 16;
     const int ncols = min(RG_CPR, a.N - n_base);                       // valid columns this round (multiple of 4)
@@ -177,8 +199,10 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
       }
       *reinterpret_cast<float4*>(a.C + (long)m * a.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
     }
+    if (rd == 0) RGSTAMP(6);
     __syncthreads();
   }
+  RGSTAMP(7);
 }
 
 template <int KC>
@@ -190,6 +214,11 @@ int launch_rowgemm_kc(const RowGemmArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" void rd_debug_set_rowgemm_stamps(void* p) {   // not part of the ABI
+  unsigned long long* v = (unsigned long long*)p;
+  hipMemcpyToSymbol(HIP_SYMBOL(g_rg_stamps), &v, sizeof(v));
+}
 
 // ---- host interface (used by rd_temporal.hip) -----------------------------------------------------
 bool rowgemm_ok(int N, int K, long lda, long ldc) {

@@ -92,7 +92,10 @@ def test_pe_and_mask(cfg_name, B):
 
 
 @pytest.mark.parametrize("M,N,K,act", [(1, 1, 1, 0), (7, 5, 3, 1), (64, 64, 32, 0), (130, 186, 186, 1),
-                                       (1000, 456, 152, 0), (257, 34, 6, 0), (513, 272, 152, 1)])
+                                       (1000, 456, 152, 0), (257, 34, 6, 0), (513, 272, 152, 1),
+                                       # long reductions (split-K weight gradients), ragged row counts
+                                       (15360, 152, 272, 0), (5000, 272, 152, 0), (4099, 152, 152, 0),
+                                       (3001, 456, 152, 0), (8704, 240, 240, 0), (1025, 64, 48, 0)])
 def test_linear_fwd_bwd(M, N, K, act):
     from raindrop_amd import ops
     rng = np.random.default_rng(M * 7 + N)
@@ -479,6 +482,53 @@ def test_static_train_step_matches_autograd(use_graph):
             assert _rel(got.cpu().numpy(), g.cpu().numpy()) < 1e-5, n
     finally:
         step.close()
+
+
+def test_slab_weight_gradients_match_tiled_split_k():
+    """The slab weight-gradient product (operands read once, whole output per workgroup; also the
+    batched pair of the two message-passing layers) against the tiled split-K form on the same
+    inputs: only the summation order differs."""
+    import ctypes
+    from raindrop_amd import _lib
+    lib = _lib.load()
+    lib.rd_debug_set_wgrad_slabs.argtypes = [ctypes.c_int]
+    cfg = synth.make_config("P19")
+    gs = synth.make_structure(cfg, "sparse")
+    batch = synth.make_batch(cfg, 48, seed=43)                  # B*F = 1632 node rows, T*B = 2880 tokens
+    dv = {k: (None if v is None else v.to(DEV)) for k, v in batch.items()}
+    m = build_ours(cfg, gs, DEV, 9).train()
+    live = synth.live_parameter_names(cfg)
+    named = dict(m.named_parameters())
+    grads = {}
+    try:
+        for slabs in (0, 1, 3):
+            lib.rd_debug_set_wgrad_slabs(slabs)
+            logits, _, _ = m(dv["src"], dv["static"], dv["times"], dv["lengths"])
+            loss = torch.nn.functional.cross_entropy(logits, dv["y"])
+            grads[slabs] = [g.cpu().numpy() for g in torch.autograd.grad(loss, [named[n] for n in live])]
+    finally:
+        lib.rd_debug_set_wgrad_slabs(0)
+    for slabs in (1, 3):
+        for n, a, b in zip(live, grads[slabs], grads[0]):
+            assert _rel(a, b) < 2e-5, (slabs, n, _rel(a, b))
+    # every tile configuration of the kernel, ragged row counts, against fp64
+    from raindrop_amd import ops
+    rng = np.random.default_rng(5)
+    try:
+        lib.rd_debug_set_wgrad_slabs(2)
+        for (M, N, K) in [(15360, 152, 272), (5000, 272, 152), (4099, 152, 152), (3001, 456, 152), (8704, 240, 240),
+                          (1025, 64, 48)]:
+            x = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(DEV).requires_grad_(True)
+            W = torch.from_numpy(rng.standard_normal((N, K)).astype(np.float32)).to(DEV).requires_grad_(True)
+            bb = torch.zeros(N, device=DEV, requires_grad=True)
+            dy = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).to(DEV)
+            _, hW, hb = torch.autograd.grad(ops.linear(x, W, bb, 0), [x, W, bb], dy)
+            refW = (dy.double().t() @ x.detach().double()).cpu().numpy()
+            refb = dy.double().sum(0).cpu().numpy()
+            assert _rel(hW.cpu().numpy(), refW) < 2e-5 * TOL["x"], (M, N, K)
+            assert _rel(hb.cpu().numpy(), refb) < 2e-5, (M, N, K)
+    finally:
+        lib.rd_debug_set_wgrad_slabs(0)
 
 
 def test_static_train_step_dropout_varies_per_replay():
