@@ -698,7 +698,8 @@ extern "C" void rd_debug_set_splitk_want(int v) { g_splitk_want = v > 0 ? v : 64
 int splitk_plan(long red, int rows, int cols, int* k_per_split) {
   const int tile = (rows >= 96 && cols >= 96) ? wgrad_tile() : 64;
   const int tiles = cdiv(rows, tile) * cdiv(cols, tile);
-  const int want = cdiv(tile == 128 ? 256 : g_splitk_want, tiles);  // workgroups in flight over the whole product
+  const int want = cdiv(tile == 128 ? 256 : g_splitk_want, tiles);  // workgroups over the whole product (640: ~2.5 per CU;
+                                                                      // in-step A/B 320 -> 640: 1.182 -> 1.148 ms/step, 1024: 1.144)
   const int r = red > 0 ? (int)red : 1;
   int per = (int)align_up((size_t)cdiv(r, want), 64);
   *k_per_split = per;

@@ -127,7 +127,12 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
   float* Qs = smem;
   float* Ks = Qs + TS * LDH;
   float* Vs = Ks + TS * LDH;
-  float* Ps = Vs + TS * LDH;
+  // single key tile (T <= 64, the P19 shape): Q is dead once S is formed, and each wave writes P rows
+  // 16w..16w+15 only after reading exactly those Q rows -> P overlays Q (same row stride) and two
+  // workgroups fit one CU's LDS (64.5 KB each) instead of one
+  const bool one_tile = a.T <= TS && LDH >= LDP;             // a P row (64 keys) must fit a Q row
+  float* Ps = one_tile ? Qs : Vs + TS * LDH;
+  const int ldp = one_tile ? LDH : LDP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
   const int q0 = blockIdx.x * TS;
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
         const int row = wave * 16 + 4 * (lane >> 4) + r;
         const float p = (s[j][r] == -INFINITY) ? 0.f : __expf(s[j][r] - m_i[r]);
         rsum[r] += p;
-        Ps[row * LDP + 16 * j + (lane & 15)] = p * k4[r];
+        Ps[row * ldp + 16 * j + (lane & 15)] = p * k4[r];
       }
     }
 #pragma unroll
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[j][r] *= alpha[r];
     __syncthreads();
-    mma_f32<NTH>(o, Ps + wave * 16 * LDP, LDP, 1, Vs, LDH, 1, TS, lane);  // O += P V
+    mma_f32<NTH>(o, Ps + wave * 16 * ldp, ldp, 1, Vs, LDH, 1, TS, lane);  // O += P V
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -469,6 +474,7 @@ int launch_attn(const AttnArgs& a, int which, hipStream_t st) {
   if (which == 0) {
     lds = sizeof(float) * (3 * TS * LDH + TS * LDP);
     { static bool once = false; if (!once) { hipFuncSetAttribute((const void*)k_attn_fwd<NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } }
+    if (a.T <= TS && LDH >= LDP) lds = sizeof(float) * (3 * TS * LDH);   // P overlays Q
     hipLaunchKernelGGL(k_attn_fwd<NTH>, grid, dim3(256), lds, st, a);
     return check_launch("k_attn_fwd");
   } else if (which == 1) {
@@ -539,6 +545,81 @@ __global__ __launch_bounds__(256) void k_add_ln_fwd(const float* __restrict__ x,
   if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 }
 
+// register form for D <= 64*NV: two rows per wavefront, every load of both rows issued before the first
+// use (one memory round trip per wave instead of three dependent passes per row); the row lives in VGPRs
+// between the passes.  Same per-lane summation order as the generic kernel above.
+constexpr int LNF_RPW = 2;
+template <int NV>
+__global__ __launch_bounds__(256) void k_add_ln_fwd_r(const float* __restrict__ x, const float* __restrict__ r,
+                                                      const float* __restrict__ g, const float* __restrict__ bta,
+                                                      float* __restrict__ s_out, float* __restrict__ y,
+                                                      float* __restrict__ stats, int M, int D, float p_drop,
+                                                      uint64_t seed, uint32_t site, const uint64_t* cell) {
+  seed = eff_seed(seed, cell);
+  const int lane = threadIdx.x & 63;
+  const long row0 = (blockIdx.x * 4L + (threadIdx.x >> 6)) * LNF_RPW;
+  if (row0 >= M) return;
+  const float inv_keep = 1.0f / (1.0f - p_drop);
+  float xv[LNF_RPW][NV], rv[LNF_RPW][NV], gg[NV], bb[NV];
+#pragma unroll
+  for (int q = 0; q < LNF_RPW; ++q)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      const bool ok = (row0 + q < M) && c < D;
+      xv[q][i] = ok ? x[(row0 + q) * D + c] : 0.f;
+      rv[q][i] = ok ? r[(row0 + q) * D + c] : 0.f;
+    }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    gg[i] = c < D ? g[c] : 0.f; bb[i] = c < D ? bta[c] : 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < LNF_RPW; ++q) {
+    const long row = row0 + q;
+    if (row >= M) break;
+    float sv[NV], sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      sv[i] = 0.f;
+      if (c < D) {
+        float t = rv[q][i];
+        if (p_drop > 0.f) t *= dropout_scale(seed, site, (uint64_t)row * D + c, p_drop, inv_keep);
+        sv[i] = xv[q][i] + t;
+        s_out[row * D + c] = sv[i];
+        sum += sv[i];
+      }
+    }
+    const float mean = wave_sum64(sum) / D;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < D) { const float d = sv[i] - mean; var += d * d; }
+    const float rstd = rsqrtf(wave_sum64(var) / D + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < D) y[row * D + c] = (sv[i] - mean) * rstd * gg[i] + bb[i];
+    }
+    if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+  }
+}
+
+int launch_add_ln_fwd(const float* x, const float* r, const float* g, const float* bta, float* s_out, float* y,
+                      float* stats, int M, int D, float p_drop, uint64_t seed, uint32_t site, hipStream_t st) {
+  const int nv = cdiv(D, 64);
+  const int nb = cdiv(M, 4 * LNF_RPW);
+#define RD_LNF(NV) hipLaunchKernelGGL(k_add_ln_fwd_r<NV>, dim3(nb), dim3(256), 0, st, x, r, g, bta, s_out, y, stats, M, D, \
+                                      p_drop, seed, site, seed_cell())
+  if (nv == 1) RD_LNF(1); else if (nv == 2) RD_LNF(2); else if (nv == 3) RD_LNF(3); else if (nv == 4) RD_LNF(4);
+  else hipLaunchKernelGGL(k_add_ln_fwd, dim3(cdiv(M, 4)), dim3(256), 0, st, x, r, g, bta, s_out, y, stats, M, D, p_drop,
+                          seed, site, seed_cell());
+#undef RD_LNF
+  return check_launch("k_add_ln_fwd");
+}
+
 // backward: ds = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));  dr = ds o dropout mask;
 // per-block partial sums of dgamma = sum dy*xhat and dbeta = sum dy (64 rows per block).
 constexpr int LN_RPB = 16;    // rows per block (4 per wavefront): ~1000 blocks at 15k tokens keep every CU busy
@@ -599,18 +680,36 @@ __global__ __launch_bounds__(256) void k_ln_bwd_r(const float* __restrict__ dy, 
     const int c = lane + 64 * i;
     gg[i] = c < D ? g[c] : 0.f; ag[i] = 0.f; ab[i] = 0.f;
   }
-  for (int it = 0; it < LN_RPB / 4; ++it) {
-    const long row = (long)blockIdx.x * LN_RPB + wave * (LN_RPB / 4) + it;
+  // every load of the wave's rows is issued before the first use (one memory round trip per wave)
+  constexpr int RPW = LN_RPB / 4;
+  const long rbase = (long)blockIdx.x * LN_RPB + wave * RPW;
+  float sraw[RPW][NV], dvr[RPW][NV], mean_r[RPW], rstd_r[RPW];
+#pragma unroll
+  for (int it = 0; it < RPW; ++it) {
+    const long row = rbase + it;
+    const bool rok = row < M;
+    mean_r[it] = rok ? stats[2 * row] : 0.f; rstd_r[it] = rok ? stats[2 * row + 1] : 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      const bool ok = rok && c < D;
+      sraw[it][i] = ok ? s[row * D + c] : 0.f;
+      dvr[it][i] = ok ? dy[row * D + c] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < RPW; ++it) {
+    const long row = rbase + it;
     if (row >= M) break;
-    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    const float mean = mean_r[it], rstd = rstd_r[it];
     float xh[NV], dv[NV];
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
       const bool ok = c < D;
-      xh[i] = ok ? (s[row * D + c] - mean) * rstd : 0.f;
-      dv[i] = ok ? dy[row * D + c] : 0.f;
+      xh[i] = ok ? (sraw[it][i] - mean) * rstd : 0.f;
+      dv[i] = dvr[it][i];
       const float dg = dv[i] * gg[i];
       c1 += dg; c2 += dg * xh[i];
     }
@@ -850,10 +949,8 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
     if ((rc = launch_rowgemm(e.M, e.D, e.D, v.attn, e.D, v.pl[1][0], v.pl[1][1], ws.o, e.D, w->out_proj_b, 0, nullptr, 0, 0.f,
                              nullptr, 0, 0.f, 0, 0, st))) return rc;
   } else if ((rc = linear_fwd(e.M, e.D, e.D, v.attn, w->out_proj_w, w->out_proj_b, ws.o, 0, 0.f, 0, 0, st))) return rc;
-  const int lnblocks = cdiv((int)e.M, 4);
-  hipLaunchKernelGGL(k_add_ln_fwd, dim3(lnblocks), dim3(256), 0, st, x, ws.o, w->norm1_w, w->norm1_b, v.s1, v.x1,
-                     v.st1, (int)e.M, e.D, p_drop, seed, SITE_ATTN_OUT + L, seed_cell());
-  if ((rc = check_launch("k_add_ln_fwd"))) return rc;
+  if ((rc = launch_add_ln_fwd(x, ws.o, w->norm1_w, w->norm1_b, v.s1, v.x1, v.st1, (int)e.M, e.D, p_drop, seed,
+                              SITE_ATTN_OUT + L, st))) return rc;
   if (rg) {
     if ((rc = launch_rowgemm(e.M, e.nhid, e.D, v.x1, e.D, v.pl[2][0], v.pl[2][1], v.h, e.nhid, w->lin1_b, 1, nullptr, 0, 0.f,
                              nullptr, 0, p_drop, seed, SITE_FFN_HID + L, st))) return rc;
@@ -864,9 +961,8 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
       return rc;
     if ((rc = linear_fwd(e.M, e.D, e.nhid, v.h, w->lin2_w, w->lin2_b, ws.f, 0, 0.f, 0, 0, st))) return rc;
   }
-  hipLaunchKernelGGL(k_add_ln_fwd, dim3(lnblocks), dim3(256), 0, st, v.x1, ws.f, w->norm2_w, w->norm2_b, v.s2, y,
-                     v.st2, (int)e.M, e.D, p_drop, seed, SITE_FFN_OUT + L, seed_cell());
-  return check_launch("k_add_ln_fwd");
+  return launch_add_ln_fwd(v.x1, ws.f, w->norm2_w, w->norm2_b, v.s2, y, v.st2, (int)e.M, e.D, p_drop, seed,
+                           SITE_FFN_OUT + L, st);
 }
 
 extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const float* x, const uint8_t* mask,
