@@ -86,6 +86,9 @@ int launch_splitk_reduce(const float* part, int nsplit, long elems, float* out, 
 // same with partials `stride` floats apart; elements [0,e1) go to out1, [e1, e1+e2) to out2
 int launch_splitk_reduce2(const float* part, int nsplit, long stride, long e1, float* out1, long e2, float* out2,
                           hipStream_t st);
+// one or two problems in one launch; picks the wide (float4 x 16 split groups) kernel when alignment allows
+int launch_splitk_reduce_pair(const float* partA, float* out1A, float* out2A, const float* partB, float* out1B,
+                              float* out2B, int nsplit, long stride, long e1, long e2, hipStream_t st);
 // out[n] = sum_m x[m*ldx + n], deterministic two-stage; ws needs colsum_ws_floats(M,N) floats
 long colsum_ws_floats(int M, int N);
 int launch_colsum(const float* x, int M, int N, long ldx, float* out, float* ws, hipStream_t st);

@@ -730,7 +730,7 @@ int launch_wgrad(long M, int N, int K, const float* dy, long lddy, const float* 
     t.C = ws; t.sc_m = K; t.sc_split = stride;
     t.rowsum = db ? ws + (long)N * K : nullptr; t.rowsum_split = stride;
     if ((rc = launch_gemm(t, st))) return rc;
-    return launch_splitk_reduce2(ws, ns, stride, (long)N * K, dW, db ? N : 0, db, st);
+    return launch_splitk_reduce_pair(ws, dW, db, nullptr, nullptr, nullptr, ns, stride, (long)N * K, N, st);
   }
   t.C = dW; t.sc_m = K; t.rowsum = db; t.rowsum_split = 0;
   return launch_gemm(t, st);
@@ -758,8 +758,7 @@ int launch_wgrad2(long M, int N, int K, const float* dyA, const float* xA, float
   t.A2 = dyB; t.B2 = xB; t.C2 = wsB; t.rowsum2 = wsB + (long)N * K;
   int rc;
   if ((rc = launch_gemm(t, st))) return rc;
-  if ((rc = launch_splitk_reduce2(ws, ns, stride, (long)N * K, dWA, N, dbA, st))) return rc;
-  return launch_splitk_reduce2(wsB, ns, stride, (long)N * K, dWB, N, dbB, st);
+  return launch_splitk_reduce_pair(ws, dWA, dbA, wsB, dWB, dbB, ns, stride, (long)N * K, N, st);
 }
 
 int launch_splitk_reduce2(const float* part, int nsplit, long stride, long e1, float* out1, long e2, float* out2,

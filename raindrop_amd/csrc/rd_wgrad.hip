@@ -272,20 +272,32 @@ int launch_wgrad_slab(long M, int N, int K, const float* dy, long lddy, const fl
     default: rc = launch_cfg<4, 4, 2, 4>(a, grid, st); break;
   }
   if (rc) return rc;
-  const long e1 = (long)N * K;
-  const bool both_db = db != nullptr && (dy2 == nullptr || db2 != nullptr);
-  const bool vec = ((reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(dW) | reinterpret_cast<uintptr_t>(db) |
-                     reinterpret_cast<uintptr_t>(dW2) | reinterpret_cast<uintptr_t>(db2)) & 15) == 0 && (db == nullptr || both_db);
-  if (!vec) {                                            // odd alignment: the scalar fixed-order reduce
-    if ((rc = launch_splitk_reduce2(a.part, G, stride, e1, dW, db ? N : 0, db, st))) return rc;
-    return dy2 ? launch_splitk_reduce2(a.part2, G, stride, e1, dW2, db2 ? N : 0, db2, st) : RD_OK;
+  return launch_splitk_reduce_pair(a.part, dW, db, dy2 ? a.part2 : nullptr, dW2, db2, G, stride, (long)N * K, N, st);
+}
+
+// fixed-order sum of `nsplit` partials ([e1 | e2] floats each, `stride` apart) for one or two problems:
+// the wide kernel (16 split groups x float4) when the layout allows 16-byte accesses, else the scalar one
+int launch_splitk_reduce_pair(const float* partA, float* out1A, float* out2A, const float* partB, float* out1B,
+                              float* out2B, int nsplit, long stride, long e1, long e2, hipStream_t st) {
+  const bool two = partB != nullptr;
+  const bool same_e2 = !two || ((out2A != nullptr) == (out2B != nullptr));
+  const long e2a = out2A ? e2 : 0;
+  static const bool wide_on = [] { const char* e = getenv("RD_REDUCE_WIDE"); return !(e && atoi(e) == 0); }();
+  const bool vec = wide_on && same_e2 && ((stride | e1 | e2a) & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(partA) | reinterpret_cast<uintptr_t>(out1A) | reinterpret_cast<uintptr_t>(out2A) |
+                     reinterpret_cast<uintptr_t>(partB) | reinterpret_cast<uintptr_t>(out1B) | reinterpret_cast<uintptr_t>(out2B)) & 15) == 0;
+  if (!vec) {
+    int rc = launch_splitk_reduce2(partA, nsplit, stride, e1, out1A, out2A ? e2 : 0, out2A, st);
+    if (rc || !two) return rc;
+    return launch_splitk_reduce2(partB, nsplit, stride, e1, out1B, out2B ? e2 : 0, out2B, st);
   }
   RedArgs r{};
-  r.j[0] = RedJob{a.part, dW, db};
-  r.j[1] = RedJob{a.part2, dW2, db2};
-  r.nsplit = G; r.stride = stride; r.e1 = e1; r.e2 = db ? N : 0;
+  r.j[0] = RedJob{partA, out1A, out2A};
+  r.j[1] = RedJob{partB, out1B, out2B};
+  r.nsplit = nsplit; r.stride = stride; r.e1 = e1; r.e2 = e2a;
   const long nq = (r.e1 + r.e2) >> 2;
-  hipLaunchKernelGGL(k_reduce_wide, dim3((unsigned)((nq + 63) / 64), dy2 ? 2 : 1), dim3(1024), 0, st, r);
+  if (nq <= 0) return RD_OK;
+  hipLaunchKernelGGL(k_reduce_wide, dim3((unsigned)((nq + 63) / 64), two ? 2 : 1), dim3(1024), 0, st, r);
   return check_launch("k_reduce_wide");
 }
 
