@@ -99,6 +99,41 @@ __device__ __forceinline__ void load_panel(Panel& p, const __bf16* __restrict__ 
   }
 }
 
+// one column tile (jj) of the panel: 16 loads per lane.  The backward kernel requests the first half right
+// after its 44 gather loads and the second once those have been consumed: s_waitcnt counts at most 63
+// outstanding operations in issue order, so "wait for my activations" is only expressible while fewer
+// than 64 younger loads are in flight.
+template <int JJ>
+__device__ __forceinline__ void load_panel_half(Panel& p, const __bf16* __restrict__ Bh,
+                                                const __bf16* __restrict__ Bl, int nct, int wave, int lane) {
+  const int j = wave + NWAVE * JJ;
+  const size_t boff = (size_t)(16 * (j < nct ? j : 0) + (lane & 15)) * KP + 8 * (lane >> 4);
+#pragma unroll
+  for (int kc = 0; kc < KP / 32; ++kc) {
+    p.h[JJ][kc] = *reinterpret_cast<const bf16x8*>(Bh + boff + kc * 32);
+    p.l[JJ][kc] = *reinterpret_cast<const bf16x8*>(Bl + boff + kc * 32);
+  }
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global
+// load and store (s_waitcnt vmcnt(0)): with the weight panel (32 x 16 B per lane, 262 KB per workgroup) in flight that serialises the
+// ~12 k-cycle weight stream with each phase change.  No thread of these kernels reads global memory that
+// another thread of the same launch wrote, so LDS ordering is all the phases need.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// Keeps the first USE of a prefetched value below this point (volatile asm statements stay in program
+// order, so below the preceding lds_barrier): otherwise the scheduler folds the consumer's arithmetic up to
+// the load to save registers and waits for the data before the weight panel has even been requested.
+__device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(float4& x) { asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w)); }
+// uniform 64-bit load through the scalar cache: does not queue behind the vector loads in flight
+__device__ __forceinline__ uint64_t load_uniform_u64(const uint64_t* p) {
+  uint64_t v;
+  asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
+
 // acc[jj][rt] (16x16 tiles) += A[rows rt*16.., KP] * panel^T ; A planes (hi/lo) in LDS.
 // The three split products are issued as three sweeps over independent accumulators.
 template <int RT>
@@ -179,9 +214,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   (void)d;
 
   RD_STAMP(0);
-  // weight panel of layer 1 is requested first: its L2 round trip overlaps the embedding below
   Panel pw;
-  load_panel(pw, plane(a, 0, 0, 0), plane(a, 0, 0, 1), nct, wave, lane);
   float srow[RT][4];                                     // aggregate coefficient of this lane's rows
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -190,41 +223,67 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
       const int row = rt * 16 + 4 * (lane >> 4) + r;
       srow[rt][r] = row < F ? a.ssum[row] : 0.f;
     }
+  float bias1[NJ], bias2[NJ];                            // both layers' biases: ahead of the weight stream
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) {
+    const int n = 16 * min(wave + NWAVE * jj, nct - 1) + (lane & 15);
+    bias1[jj] = a.b1[n]; bias2[jj] = a.b2[n];
+  }
 
   // ---- observation embedding -> X planes (+ fp32 copy for the weight-gradient pass) ------------
-  zero_lds(smem_raw, 4 * ROWS * LDX * (int)sizeof(__bf16), tid);    // pads of all four planes
-  __syncthreads();
-  {
-    // thread -> (f, t) with t fastest: LDS / xsave writes are contiguous; the strided src reads hit
-    // each 128-B line F times within the workgroup (L1).  All of a thread's loads issue together,
-    // and the body is branch-free (one Philox call yields the 4 channel masks of a (t, f) cell).
-    constexpr int UNR = 4;
-    const int total = F * T;
-    for (int base = tid; base < total; base += NTHR * UNR) {
-      float v[UNR]; int fi[UNR], ti[UNR];
+  // thread -> (f, t) with t fastest: LDS / xsave writes are contiguous; the strided src reads hit each
+  // 128-B line F times within the workgroup (L1).  The loads of the first batch (the only one when
+  // F*T <= 2048) are requested BEFORE the layer-1 weight panel: loads return in issue order, and the
+  // embedding is on the critical path while the panel is not needed before the first MFMA.
+  constexpr int UNR = 4;
+  const int total = F * T;
+  uint64_t seed_eff = a.seed;
+  float v[UNR]; int fi[UNR], ti[UNR]; float4 ru[UNR], uu[UNR];
+  auto embed_issue = [&](int base) {
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int i = min(base + u * NTHR, total - 1);       // clamped duplicates rewrite the same cell
-        fi[u] = i / T; ti[u] = i - fi[u] * T;
-        v[u] = a.src[((size_t)ti[u] * B + b) * (2 * F) + fi[u]];
+    for (int u = 0; u < UNR; ++u) {
+      const int i = min(base + u * NTHR, total - 1);          // clamped duplicates rewrite the same cell
+      fi[u] = i / T; ti[u] = i - fi[u] * T;
+      v[u] = a.src[((size_t)ti[u] * B + b) * (2 * F) + fi[u]];
+      ru[u] = *reinterpret_cast<const float4*>(a.R_u + fi[u] * 4);
+    }
+  };
+  auto embed_consume = [&]() {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int f = fi[u], t = ti[u];
+      pin(v[u]); pin(ru[u]);
+      float x[4] = {fmaxf(v[u] * ru[u].x, 0.f), fmaxf(v[u] * ru[u].y, 0.f), fmaxf(v[u] * ru[u].z, 0.f), fmaxf(v[u] * ru[u].w, 0.f)};
+      if (a.p_drop > 0.f) {                                   // wave-uniform
+        x[0] = uu[u].x >= a.p_drop ? x[0] * inv_keep : 0.f; x[1] = uu[u].y >= a.p_drop ? x[1] * inv_keep : 0.f;
+        x[2] = uu[u].z >= a.p_drop ? x[2] * inv_keep : 0.f; x[3] = uu[u].w >= a.p_drop ? x[3] * inv_keep : 0.f;
       }
+      split_store4(Xh + f * LDX + 4 * t, Xl + f * LDX + 4 * t, x);
+      *reinterpret_cast<float4*>(a.xsave + ((size_t)b * F + f) * K + 4 * t) = make_float4(x[0], x[1], x[2], x[3]);
+    }
+  };
+  // dropout masks: one Philox call = the 4 channel masks of a (t, f) cell; ~1 k cycles of integer multiplies per
+  // call and wave, evaluated while the loads above are in flight (they do not depend on the loaded data)
+  auto embed_masks = [&]() {
+    if (a.p_drop > 0.f) {
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
-        const int f = fi[u], t = ti[u];
-        const float4 ru = *reinterpret_cast<const float4*>(a.R_u + f * 4);
-        float x[4] = {fmaxf(v[u] * ru.x, 0.f), fmaxf(v[u] * ru.y, 0.f), fmaxf(v[u] * ru.z, 0.f), fmaxf(v[u] * ru.w, 0.f)};
-        if (a.p_drop > 0.f) {                                   // wave-uniform
-          const float4 uu = uniform4(eff_seed(a.seed, a.seed_cell), SITE_OBS_EMBED, ((uint64_t)t * B + b) * F + f);
-          x[0] = uu.x >= a.p_drop ? x[0] * inv_keep : 0.f; x[1] = uu.y >= a.p_drop ? x[1] * inv_keep : 0.f;
-          x[2] = uu.z >= a.p_drop ? x[2] * inv_keep : 0.f; x[3] = uu.w >= a.p_drop ? x[3] * inv_keep : 0.f;
-        }
-        split_store4(Xh + f * LDX + 4 * t, Xl + f * LDX + 4 * t, x);
-        *reinterpret_cast<float4*>(a.xsave + ((size_t)b * F + f) * K + 4 * t) = make_float4(x[0], x[1], x[2], x[3]);
+        uu[u] = uniform4(seed_eff, SITE_OBS_EMBED, ((uint64_t)ti[u] * B + b) * F + fi[u]);
+        pin(uu[u]);                                           // materialised here, above the barrier
       }
     }
-  }
+  };
+  embed_issue(tid);
+  load_panel(pw, plane(a, 0, 0, 0), plane(a, 0, 0, 1), nct, wave, lane);   // 32 loads per lane, behind the 24 above
+  // device seed cell (rd_set_seed_cell) on the scalar path: a vector load here would sit behind the panel
+  if (a.seed_cell) seed_eff += load_uniform_u64(a.seed_cell);
+  embed_masks();
+  zero_lds(smem_raw, 4 * ROWS * LDX * (int)sizeof(__bf16), tid);    // pads of all four planes
+  lds_barrier();
+  embed_consume();
+  for (int base = tid + NTHR * UNR; base < total; base += NTHR * UNR) { embed_issue(base); embed_masks(); embed_consume(); }
   RD_STAMP(1);
-  __syncthreads();
+  lds_barrier();
   RD_STAMP(2);
 
   // ---- layer 1: Y1 = relu(X W1^T + b1) * ssum ----------------------------------------------------
@@ -240,7 +299,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
     const int j = wave + NWAVE * jj;
     if (j < nct) {                                              // wave-uniform
       const int n = 16 * j + (lane & 15);
-      const float bias = a.b1[n];
+      const float bias = bias1[jj];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -253,7 +312,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
     }
   }
   RD_STAMP(4);
-  __syncthreads();
+  lds_barrier();
   RD_STAMP(5);
   // Y1 for the backward pass, written row-contiguously from the planes (hi + lo is exactly the
   // value the split-bf16 products of the backward pass would reconstruct anyway)
@@ -278,7 +337,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
     const int j = wave + NWAVE * jj;
     if (j < nct) {                                              // wave-uniform
       const int n = 16 * j + (lane & 15);
-      const float bias = a.b2[n];
+      const float bias = bias2[jj];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -289,7 +348,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
     }
   }
   RD_STAMP(7);
-  __syncthreads();
+  lds_barrier();
   RD_STAMP(8);
   // ---- [F, T*d] -> z[t, b, f*d + c]: consecutive threads write consecutive addresses; the thread's
   // (f, c) is fixed and t advances by the number of rows the block covers (no divisions in the loop)
@@ -348,9 +407,8 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   const int Fd = F * 4;
   const int kq = K / 4;
 
-  // W2^T panel first: its L2 round trip overlaps the gradient gather below
+  RD_STAMP(0);
   Panel pw;
-  load_panel(pw, plane(a, 1, 1, 0), plane(a, 1, 1, 1), nct, wave, lane);
   float srow[RT][4];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -359,37 +417,71 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
       const int row = rt * 16 + 4 * (lane >> 4) + r;
       srow[rt][r] = row < F ? a.ssum[row] : 0.f;
     }
-  zero_lds(smem_raw, 4 * ROWS * LDX * (int)sizeof(__bf16) + ROWS * KP, tid);
-  __syncthreads();
 
-  // ---- dZ2 = dz * ssum * (z > 0), read coalesced in [t, f*d+c] order, transposed through LDS ----
-  {
-    const int tpb = NTHR / Fd;
-    const int t0 = tid / Fd, fc = tid - t0 * Fd;
-    if (tpb > 0) {
-      if (t0 < tpb) {
-        const int f = fc >> 2, c = fc & 3;
-        const float sf = a.ssum[f];
-        for (int t = t0; t < T; t += tpb) {
-          const size_t zi = ((size_t)t * B + b) * a.ldz + fc;
-          St[f * LDS_F + t * 4 + c] = (a.z[zi] > 0.f) ? a.dz[zi] * sf : 0.f;
-        }
-      }
-    } else {
-      for (int i = tid; i < T * Fd; i += NTHR) {
-        const int t = i / Fd, q = i - t * Fd;
-        const size_t zi = ((size_t)t * B + b) * a.ldz + q;
-        St[(q >> 2) * LDS_F + t * 4 + (q & 3)] = (a.z[zi] > 0.f) ? a.dz[zi] * a.ssum[q >> 2] : 0.f;
+  // ---- dZ2 = dz * ssum * (z > 0), read coalesced in [t, f*d+c] order, transposed through LDS; and the
+  // ReLU gate of layer 1 as bytes from the saved Y1.  All of a thread's loads (<= 44) are requested in
+  // one burst BEFORE the W2^T panel (loads return in issue order), then half the panel; the other half
+  // follows once the gather has been consumed.
+  const int tpb = NTHR / Fd;                                // >= 2 (F <= 64)
+  const int t0 = tid / Fd, fc = tid - t0 * Fd;
+  const bool gact = t0 < tpb;
+  const int gf = fc >> 2, gc = fc & 3;
+  constexpr int GU = 20;
+  float zz[GU], dd[GU];
+  auto gather_issue = [&](int tb) {
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      const int t = min(tb + u * tpb, T - 1);                   // clamped duplicates are not stored
+      const size_t zi = ((size_t)t * B + b) * a.ldz + fc;
+      zz[u] = a.z[zi]; dd[u] = a.dz[zi];
+    }
+  };
+  auto gather_consume = [&](int tb, float sf) {
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      const int t = tb + u * tpb;
+      pin(zz[u]); pin(dd[u]);
+      if (t < T) St[gf * LDS_F + t * 4 + gc] = (zz[u] > 0.f) ? dd[u] * sf : 0.f;
+    }
+  };
+  constexpr int YU = 4;
+  float4 yv[YU];
+  const int ncell = F * kq;
+  auto gate_issue = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < YU; ++u) {
+      const int i = min(base + u * NTHR, ncell - 1);
+      const int f = i / kq, k = 4 * (i - f * kq);
+      yv[u] = *reinterpret_cast<const float4*>(a.y1save + ((size_t)b * F + f) * K + k);
+    }
+  };
+  auto gate_consume = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < YU; ++u) {
+      const int i = base + u * NTHR;
+      pin(yv[u]);
+      if (i < ncell) {
+        const int f = i / kq, k = 4 * (i - f * kq);
+        *reinterpret_cast<uchar4*>(Mk + f * KP + k) = make_uchar4(yv[u].x > 0.f, yv[u].y > 0.f, yv[u].z > 0.f, yv[u].w > 0.f);
       }
     }
+  };
+  float sf = 0.f;
+  if (gact) { sf = a.ssum[gf]; gather_issue(t0); }
+  gate_issue(tid);
+  load_panel_half<0>(pw, plane(a, 1, 1, 0), plane(a, 1, 1, 1), nct, wave, lane);
+  zero_lds(smem_raw, 4 * ROWS * LDX * (int)sizeof(__bf16) + ROWS * KP, tid);
+  lds_barrier();
+  if (gact) {
+    gather_consume(t0, sf);
+    for (int tb = t0 + GU * tpb; tb < T; tb += GU * tpb) { gather_issue(tb); gather_consume(tb, sf); }
   }
-  // ReLU gate of layer 1 as bytes, from the saved Y1 (row-contiguous float4 reads)
-  for (int i = tid; i < F * kq; i += NTHR) {
-    const int f = i / kq, k = 4 * (i - f * kq);
-    const float4 y = *reinterpret_cast<const float4*>(a.y1save + ((size_t)b * F + f) * K + k);
-    *reinterpret_cast<uchar4*>(Mk + f * KP + k) = make_uchar4(y.x > 0.f, y.y > 0.f, y.z > 0.f, y.w > 0.f);
-  }
-  __syncthreads();
+  gate_consume(tid);
+  for (int base = tid + YU * NTHR; base < ncell; base += YU * NTHR) { gate_issue(base); gate_consume(base); }
+  load_panel_half<1>(pw, plane(a, 1, 1, 0), plane(a, 1, 1, 1), nct, wave, lane);
+  RD_STAMP(1);
+  lds_barrier();
+  RD_STAMP(2);
   for (int i = tid; i < F * kq; i += NTHR) {
     const int f = i / kq, k = 4 * (i - f * kq);
     const float4 v = *reinterpret_cast<const float4*>(St + f * LDS_F + k);
@@ -397,15 +489,31 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
     split_store4(Dh + f * LDX + k, Dl + f * LDX + k, x);
     *reinterpret_cast<float4*>(a.dz2save + ((size_t)b * F + f) * K + k) = v;
   }
-  __syncthreads();
+  lds_barrier();
   zero_lds(Eh, 2 * ROWS * LDX * (int)sizeof(__bf16), tid);   // staging (aliased) is dead: clear the E planes
-  __syncthreads();
+  RD_STAMP(3);
+  lds_barrier();
 
   // ---- dZ1 = (dZ2 W2) * ssum * (Y1 > 0) ----------------------------------------------------------
   f32x4 acc[NJ][RT];
   zero_acc<RT>(acc);
   mma_panel<RT>(acc, Dh, Dl, pw, lane);
+  RD_STAMP(4);
   load_panel(pw, plane(a, 0, 1, 0), plane(a, 0, 1, 1), nct, wave, lane);   // W1^T streams during the epilogue
+  // inputs of the dR_u pass (independent of both products) ride behind the weight stream
+  constexpr int XU = 4;
+  const int ncells = F * T;
+  float4 xs[XU]; float svv[XU];
+  auto ru_issue = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+      const int i = min(base + u * NTHR, ncells - 1);
+      const int f = i / T, t = i - f * T;
+      xs[u] = *reinterpret_cast<const float4*>(a.xsave + ((size_t)b * F + f) * K + 4 * t);
+      svv[u] = a.src[((size_t)t * B + b) * (2 * F) + f];
+    }
+  };
+  ru_issue(tid);
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
     const int j = wave + NWAVE * jj;
@@ -422,7 +530,8 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
         }
     }
   }
-  __syncthreads();
+  RD_STAMP(5);
+  lds_barrier();
   // dZ1 for the weight-gradient pass, row-contiguous from the planes
   for (int i = tid; i < F * kq; i += NTHR) {
     const int f = i / kq, k = 4 * (i - f * kq);
@@ -436,6 +545,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   // ---- dX = dZ1 W1 -> fp32 staging (the D planes are dead) -------------------------------------
   zero_acc<RT>(acc);
   mma_panel<RT>(acc, Eh, El, pw, lane);
+  RD_STAMP(6);
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
     const int j = wave + NWAVE * jj;
@@ -447,20 +557,30 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
         for (int r = 0; r < 4; ++r) Sx[(rt * 16 + 4 * (lane >> 4) + r) * LDS_F + n] = acc[jj][rt][r];
     }
   }
-  __syncthreads();
+  RD_STAMP(7);
+  lds_barrier();
   // ---- dR_u[f*4+c] = sum_t dX[f, 4t+c] * (X > 0) * src[t,b,f] * keep -----------------------------
   // pass 1 (thread per (f,t) cell, in place): P = dX * gate * src * keep
   const float keep = 1.0f / (1.0f - a.p_drop);
-  for (int i = tid; i < F * T; i += NTHR) {
-    const int f = i / T, t = i - f * T;
-    const float4 xs = *reinterpret_cast<const float4*>(a.xsave + ((size_t)b * F + f) * K + 4 * t);
-    const float sv = a.src[((size_t)t * B + b) * (2 * F) + f] * keep;
-    float4 dx = *reinterpret_cast<float4*>(Sx + f * LDS_F + 4 * t);
-    dx.x = xs.x > 0.f ? dx.x * sv : 0.f; dx.y = xs.y > 0.f ? dx.y * sv : 0.f;
-    dx.z = xs.z > 0.f ? dx.z * sv : 0.f; dx.w = xs.w > 0.f ? dx.w * sv : 0.f;
-    *reinterpret_cast<float4*>(Sx + f * LDS_F + 4 * t) = dx;
-  }
-  __syncthreads();
+  auto ru_consume = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+      const int i = base + u * NTHR;
+      pin(xs[u]); pin(svv[u]);
+      if (i < ncells) {
+        const int f = i / T, t = i - f * T;
+        const float sv = svv[u] * keep;
+        float4 dx = *reinterpret_cast<float4*>(Sx + f * LDS_F + 4 * t);
+        dx.x = xs[u].x > 0.f ? dx.x * sv : 0.f; dx.y = xs[u].y > 0.f ? dx.y * sv : 0.f;
+        dx.z = xs[u].z > 0.f ? dx.z * sv : 0.f; dx.w = xs[u].w > 0.f ? dx.w * sv : 0.f;
+        *reinterpret_cast<float4*>(Sx + f * LDS_F + 4 * t) = dx;
+      }
+    }
+  };
+  ru_consume(tid);
+  for (int base = tid + XU * NTHR; base < ncells; base += XU * NTHR) { ru_issue(base); ru_consume(base); }
+  RD_STAMP(8);
+  lds_barrier();
   // pass 2 (thread per (f,c)): fixed-order sum over t
   for (int i = tid; i < Fd; i += NTHR) {
     const int f = i >> 2, c = i & 3;
@@ -468,6 +588,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
     for (int t = 0; t < T; ++t) v += Sx[f * LDS_F + 4 * t + c];
     a.rupart[(size_t)b * Fd + i] = v;
   }
+  RD_STAMP(9);
 }
 
 template <int RT>
@@ -532,7 +653,7 @@ int fused_msgpass_bwd(const rd_shape* s, const float* src, const float* ssum, co
   a.xsave = const_cast<float*>(xsave); a.y1save = const_cast<float*>(y1save); a.z = const_cast<float*>(z);
   a.dz = dz; a.ldz = ldz; a.dz2save = dz2save; a.dz1save = dz1save; a.rupart = rupart;
   a.B = s->B; a.T = s->T; a.F = s->F; a.d = s->d_ob; a.K = s->T * s->d_ob;
-  a.p_drop = p_drop;
+  a.p_drop = p_drop; a.stamps = g_stamps;
   switch (cdiv(s->F, 16)) {
     case 1: return launch_fused<1>(a, true, st);
     case 2: return launch_fused<2>(a, true, st);

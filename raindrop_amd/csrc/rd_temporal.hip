@@ -607,8 +607,70 @@ __global__ __launch_bounds__(256) void k_add_ln_fwd_r(const float* __restrict__ 
   }
 }
 
+// float4 form for D % 4 == 0, D <= 256: lane l owns columns 4l..4l+3 of a row, so the four keep decisions
+// of an element quad come from ONE Philox evaluation (the scalar-column kernels evaluate it once per
+// element, 4x redundantly, and are bound by those integer multiplies, not by memory); 16-byte accesses,
+// LNV_RPW rows per wavefront with every load issued before the first use.  Same masks as the other forms.
+constexpr int LNV_RPW = 4;
+__global__ __launch_bounds__(256) void k_add_ln_fwd_v(const float* __restrict__ x, const float* __restrict__ r,
+                                                      const float* __restrict__ g, const float* __restrict__ bta,
+                                                      float* __restrict__ s_out, float* __restrict__ y,
+                                                      float* __restrict__ stats, int M, int D, float p_drop,
+                                                      uint64_t seed, uint32_t site, const uint64_t* cell) {
+  seed = eff_seed(seed, cell);
+  const int lane = threadIdx.x & 63;
+  const long row0 = (blockIdx.x * 4L + (threadIdx.x >> 6)) * LNV_RPW;
+  if (row0 >= M) return;
+  const int c = 4 * lane;
+  const bool cok = c < D;
+  const float inv_keep = 1.0f / (1.0f - p_drop);
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 xv[LNV_RPW], rv[LNV_RPW];
+#pragma unroll
+  for (int q = 0; q < LNV_RPW; ++q) {
+    const bool ok = cok && (row0 + q < M);
+    xv[q] = ok ? *reinterpret_cast<const float4*>(x + (row0 + q) * D + c) : zero4;
+    rv[q] = ok ? *reinterpret_cast<const float4*>(r + (row0 + q) * D + c) : zero4;
+  }
+  const float4 gg = cok ? *reinterpret_cast<const float4*>(g + c) : zero4;
+  const float4 bb = cok ? *reinterpret_cast<const float4*>(bta + c) : zero4;
+#pragma unroll
+  for (int q = 0; q < LNV_RPW; ++q) {
+    const long row = row0 + q;
+    if (row >= M) break;
+    float4 t = rv[q];
+    if (p_drop > 0.f) {
+      const float4 u = uniform4(seed, site, ((uint64_t)row * D + c) >> 2);
+      t.x *= u.x >= p_drop ? inv_keep : 0.f; t.y *= u.y >= p_drop ? inv_keep : 0.f;
+      t.z *= u.z >= p_drop ? inv_keep : 0.f; t.w *= u.w >= p_drop ? inv_keep : 0.f;
+    }
+    const float4 sv = make_float4(xv[q].x + t.x, xv[q].y + t.y, xv[q].z + t.z, xv[q].w + t.w);   // 0 beyond D
+    if (cok) *reinterpret_cast<float4*>(s_out + row * D + c) = sv;
+    const float mean = wave_sum64((sv.x + sv.y) + (sv.z + sv.w)) / D;
+    float4 d = make_float4(sv.x - mean, sv.y - mean, sv.z - mean, sv.w - mean);
+    if (!cok) d = zero4;
+    const float rstd = rsqrtf(wave_sum64((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) / D + 1e-5f);
+    if (cok)
+      *reinterpret_cast<float4*>(y + row * D + c) =
+          make_float4(d.x * rstd * gg.x + bb.x, d.y * rstd * gg.y + bb.y, d.z * rstd * gg.z + bb.z, d.w * rstd * gg.w + bb.w);
+    if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+  }
+}
+
+static bool ln_vec_ok(int D, const void* a, const void* b, const void* c, const void* d, const void* e, const void* f) {
+  static const bool on = [] { const char* v = getenv("RD_LN_VEC"); return !(v && atoi(v) == 0); }();
+  const uintptr_t m = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+                      reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(e) | reinterpret_cast<uintptr_t>(f);
+  return on && (D % 4) == 0 && D <= 256 && (m & 15) == 0;
+}
+
 int launch_add_ln_fwd(const float* x, const float* r, const float* g, const float* bta, float* s_out, float* y,
                       float* stats, int M, int D, float p_drop, uint64_t seed, uint32_t site, hipStream_t st) {
+  if (ln_vec_ok(D, x, r, g, bta, s_out, y)) {
+    hipLaunchKernelGGL(k_add_ln_fwd_v, dim3(cdiv(M, 4 * LNV_RPW)), dim3(256), 0, st, x, r, g, bta, s_out, y, stats, M, D,
+                       p_drop, seed, site, seed_cell());
+    return check_launch("k_add_ln_fwd_v");
+  }
   const int nv = cdiv(D, 64);
   const int nb = cdiv(M, 4 * LNF_RPW);
 #define RD_LNF(NV) hipLaunchKernelGGL(k_add_ln_fwd_r<NV>, dim3(nb), dim3(256), 0, st, x, r, g, bta, s_out, y, stats, M, D, \
@@ -738,10 +800,77 @@ __global__ __launch_bounds__(256) void k_ln_bwd_r(const float* __restrict__ dy, 
     part[(long)blockIdx.x * 2 * D + c] = (red[c] + red[2 * D + c]) + (red[4 * D + c] + red[6 * D + c]);
 }
 
+// float4 form of the backward (see k_add_ln_fwd_v): one Philox evaluation per lane and row, 16-byte accesses
+__global__ __launch_bounds__(256) void k_ln_bwd_v(const float* __restrict__ dy, const float* __restrict__ s,
+                                                  const float* __restrict__ stats, const float* __restrict__ g,
+                                                  float* __restrict__ ds_out, float* __restrict__ dr_out,
+                                                  float* __restrict__ part, int M, int D, float p_drop,
+                                                  uint64_t seed, uint32_t site, const uint64_t* cell) {
+  seed = eff_seed(seed, cell);
+  extern __shared__ float red[];             // [4][2*D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float inv_keep = 1.0f / (1.0f - p_drop);
+  constexpr int RPW = LN_RPB / 4;
+  const int c = 4 * lane;
+  const bool cok = c < D;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 gg = cok ? *reinterpret_cast<const float4*>(g + c) : zero4;
+  float4 ag = zero4, ab = zero4;
+  const long rbase = (long)blockIdx.x * LN_RPB + wave * RPW;
+  float4 sraw[RPW], dvr[RPW]; float mean_r[RPW], rstd_r[RPW];
+#pragma unroll
+  for (int it = 0; it < RPW; ++it) {
+    const long row = rbase + it;
+    const bool rok = row < M;
+    mean_r[it] = rok ? stats[2 * row] : 0.f; rstd_r[it] = rok ? stats[2 * row + 1] : 0.f;
+    sraw[it] = (rok && cok) ? *reinterpret_cast<const float4*>(s + row * D + c) : zero4;
+    dvr[it] = (rok && cok) ? *reinterpret_cast<const float4*>(dy + row * D + c) : zero4;
+  }
+#pragma unroll
+  for (int it = 0; it < RPW; ++it) {
+    const long row = rbase + it;
+    if (row >= M) break;
+    const float mean = mean_r[it], rstd = rstd_r[it];
+    const float4 dv = dvr[it];
+    float4 xh = make_float4((sraw[it].x - mean) * rstd, (sraw[it].y - mean) * rstd, (sraw[it].z - mean) * rstd,
+                            (sraw[it].w - mean) * rstd);
+    if (!cok) xh = zero4;
+    const float4 dg = make_float4(dv.x * gg.x, dv.y * gg.y, dv.z * gg.z, dv.w * gg.w);
+    const float c1 = wave_sum64((dg.x + dg.y) + (dg.z + dg.w)) / D;
+    const float c2 = wave_sum64((dg.x * xh.x + dg.y * xh.y) + (dg.z * xh.z + dg.w * xh.w)) / D;
+    if (cok) {
+      const float4 v = make_float4(rstd * (dg.x - c1 - xh.x * c2), rstd * (dg.y - c1 - xh.y * c2),
+                                   rstd * (dg.z - c1 - xh.z * c2), rstd * (dg.w - c1 - xh.w * c2));
+      *reinterpret_cast<float4*>(ds_out + row * D + c) = v;
+      float4 dr = v;
+      if (p_drop > 0.f) {
+        const float4 u = uniform4(seed, site, ((uint64_t)row * D + c) >> 2);
+        dr.x *= u.x >= p_drop ? inv_keep : 0.f; dr.y *= u.y >= p_drop ? inv_keep : 0.f;
+        dr.z *= u.z >= p_drop ? inv_keep : 0.f; dr.w *= u.w >= p_drop ? inv_keep : 0.f;
+      }
+      *reinterpret_cast<float4*>(dr_out + row * D + c) = dr;
+      ag.x += dv.x * xh.x; ag.y += dv.y * xh.y; ag.z += dv.z * xh.z; ag.w += dv.w * xh.w;
+      ab.x += dv.x; ab.y += dv.y; ab.z += dv.z; ab.w += dv.w;
+    }
+  }
+  if (cok) {
+    *reinterpret_cast<float4*>(red + wave * 2 * D + c) = ag;
+    *reinterpret_cast<float4*>(red + wave * 2 * D + D + c) = ab;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * D; i += 256)
+    part[(long)blockIdx.x * 2 * D + i] = (red[i] + red[2 * D + i]) + (red[4 * D + i] + red[6 * D + i]);
+}
+
 int launch_ln_bwd(const float* dy, const float* s, const float* stats, const float* g, float* ds_out, float* dr_out,
                   float* part, int M, int D, float p_drop, uint64_t seed, uint32_t site, hipStream_t st) {
   const int lnb = cdiv(M, LN_RPB);
   const size_t lds = sizeof(float) * 8 * D;
+  if (ln_vec_ok(D, dy, s, g, ds_out, dr_out, nullptr)) {
+    hipLaunchKernelGGL(k_ln_bwd_v, dim3(lnb), dim3(256), lds, st, dy, s, stats, g, ds_out, dr_out, part, M, D, p_drop, seed,
+                       site, seed_cell());
+    return check_launch("k_ln_bwd_v");
+  }
   const int nv = cdiv(D, 64);
 #define RD_LN(NV) hipLaunchKernelGGL(k_ln_bwd_r<NV>, dim3(lnb), dim3(256), lds, st, dy, s, stats, g, ds_out, dr_out, \
                                      part, M, D, p_drop, seed, site, seed_cell())

@@ -1,4 +1,4 @@
-"""Debug: per-phase cycle stamps of the fused message-passing forward kernel (first 8 workgroups)."""
+"""Debug: per-phase cycle stamps of the fused message-passing forward and backward kernels (first workgroups)."""
 import ctypes, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -26,6 +26,21 @@ torch.cuda.synchronize()
 lib.rd_debug_set_stamps(None)
 s = stamps.cpu().view(8, 16)
 names = ["start->embed done", "barrier", "mma1", "epi1", "barrier", "mma2", "epi2", "barrier", "scatter"]
-for w in range(8):
+for w in range(4):
     d = [int(s[w, i + 1] - s[w, i]) for i in range(9)]
-    print("wg%d" % w, " ".join("%s=%d" % (n, x) for n, x in zip(names, d)), "total", int(s[w, 9] - s[w, 0]))
+    print("fwd wg%d" % w, " ".join("%s=%d" % (n, x) for n, x in zip(names, d)), "total", int(s[w, 9] - s[w, 0]))
+# backward: same stamp buffer, overwritten by the backward launch
+z = ops.sensor_stage(*args)
+zz = z[0] if isinstance(z, (tuple, list)) else z
+for p_ in m.parameters(): p_.grad = None
+stamps.zero_()
+lib.rd_debug_set_stamps(stamps.data_ptr())
+zz.backward(torch.randn_like(zz))
+torch.cuda.synchronize()
+lib.rd_debug_set_stamps(None)
+s = stamps.cpu().view(8, 16)
+names = ["loads+gather+gate", "barrier", "St->D planes+zero E", "barrier+mma1", "panel issue+epi1", "barrier+dz1save+mma2", "stage dX",
+         "barrier+dR_u pass1", "barrier+pass2"]
+for w in range(4):
+    d = [int(s[w, i + 1] - s[w, i]) for i in range(9)]
+    print("bwd wg%d" % w, " ".join("%s=%d" % (n, x) for n, x in zip(names, d)), "total", int(s[w, 9] - s[w, 0]))
