@@ -127,6 +127,38 @@ __device__ __forceinline__ void lds_barrier() {
 // the load to save registers and waits for the data before the weight panel has even been requested.
 __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(float4& x) { asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w)); }
+// Split value -> hi/lo planes with ONE 4-byte LDS store per lane: the MFMA accumulator layout puts columns
+// n (even lane) and n+1 (odd lane) of a row in neighbouring lanes; the pair swaps one half through a DPP
+// quad permute (no LDS traffic), the even lane stores (hi[n], hi[n+1]) to the hi plane and the odd lane
+// (lo[n], lo[n+1]) to the lo plane.  Replaces two 2-byte stores per lane, which the epilogue stamps showed
+// to dominate (96 sub-dword stores per lane and layer).  Must be called by all 64 lanes; n = column of this lane.
+__device__ __forceinline__ void store_split_pair(__bf16* Ph, __bf16* Pl, int row, int n, int lane, float y) {
+  const __bf16 h = (__bf16)y;
+  const __bf16 l = (__bf16)(y - (float)h);
+  const unsigned hb = __builtin_bit_cast(unsigned short, h), lb = __builtin_bit_cast(unsigned short, l);
+  const bool odd = lane & 1;
+  const unsigned send = odd ? hb : lb;
+  const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, true);   // lane ^ 1
+  const unsigned word = odd ? (recv | (lb << 16)) : (hb | (recv << 16));
+  __bf16* P = odd ? Pl : Ph;
+  *reinterpret_cast<unsigned*>(P + row * LDX + (n & ~1)) = word;
+}
+
+// zero what the products read but no phase writes: pad columns [K, KP) of rows [0, crow) and whole pad rows
+// [prow, rows) of one plane, with 16-byte stores (K % 16 == 0; a row is 528 bytes)
+__device__ __forceinline__ void zero_plane_pads(__bf16* P, int rows, int prow, int crow, int K, int tid) {
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  char* base = reinterpret_cast<char*>(P);
+  const int nrow16 = (rows - prow) * LDX * (int)sizeof(__bf16) / 16;
+  float4* q = reinterpret_cast<float4*>(base + (size_t)prow * LDX * sizeof(__bf16));
+  for (int i = tid; i < nrow16; i += NTHR) q[i] = z;
+  const int n16 = (KP - K) / 8;                           // 16-byte chunks of pad columns per row
+  for (int i = tid; i < crow * n16; i += NTHR) {
+    const int r = i / n16, c = i - r * n16;
+    *reinterpret_cast<float4*>(base + ((size_t)r * LDX + K) * sizeof(__bf16) + 16 * c) = z;
+  }
+}
+
 // uniform 64-bit load through the scalar cache: does not queue behind the vector loads in flight
 __device__ __forceinline__ uint64_t load_uniform_u64(const uint64_t* p) {
   uint64_t v;
@@ -277,9 +309,16 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   load_panel(pw, plane(a, 0, 0, 0), plane(a, 0, 0, 1), nct, wave, lane);   // 32 loads per lane, behind the 24 above
   // device seed cell (rd_set_seed_cell) on the scalar path: a vector load here would sit behind the panel
   if (a.seed_cell) seed_eff += load_uniform_u64(a.seed_cell);
+  RD_STAMP(10);
   embed_masks();
-  zero_lds(smem_raw, 4 * ROWS * LDX * (int)sizeof(__bf16), tid);    // pads of all four planes
+  RD_STAMP(11);
+  // pads only: X rows >= F and columns >= K (the embedding writes the rest); Y columns >= K (its pad rows are
+  // written as zeros by the layer-1 epilogue)
+  zero_plane_pads(Xh, ROWS, F, F, K, tid); zero_plane_pads(Xl, ROWS, F, F, K, tid);
+  zero_plane_pads(Yh, ROWS, ROWS, ROWS, K, tid); zero_plane_pads(Yl, ROWS, ROWS, ROWS, K, tid);
+  RD_STAMP(12);
   lds_barrier();
+  RD_STAMP(13);
   embed_consume();
   for (int base = tid + NTHR * UNR; base < total; base += NTHR * UNR) { embed_issue(base); embed_masks(); embed_consume(); }
   RD_STAMP(1);
@@ -306,8 +345,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
         for (int r = 0; r < 4; ++r) {
           const int row = rt * 16 + 4 * (lane >> 4) + r;
           const float y = fmaxf(acc[jj][rt][r] + bias, 0.f) * srow[rt][r];
-          const __bf16 h = (__bf16)y;
-          Yh[row * LDX + n] = h; Yl[row * LDX + n] = (__bf16)(y - (float)h);
+          store_split_pair(Yh, Yl, row, n, lane, y);
         }
     }
   }
@@ -470,12 +508,16 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   if (gact) { sf = a.ssum[gf]; gather_issue(t0); }
   gate_issue(tid);
   load_panel_half<0>(pw, plane(a, 1, 1, 0), plane(a, 1, 1, 1), nct, wave, lane);
+  RD_STAMP(10);
   zero_lds(smem_raw, 4 * ROWS * LDX * (int)sizeof(__bf16) + ROWS * KP, tid);
+  RD_STAMP(11);
   lds_barrier();
+  RD_STAMP(12);
   if (gact) {
     gather_consume(t0, sf);
     for (int tb = t0 + GU * tpb; tb < T; tb += GU * tpb) { gather_issue(tb); gather_consume(tb, sf); }
   }
+  RD_STAMP(13);
   gate_consume(tid);
   for (int base = tid + YU * NTHR; base < ncell; base += YU * NTHR) { gate_issue(base); gate_consume(base); }
   load_panel_half<1>(pw, plane(a, 1, 1, 0), plane(a, 1, 1, 1), nct, wave, lane);
@@ -525,8 +567,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
         for (int r = 0; r < 4; ++r) {
           const int row = rt * 16 + 4 * (lane >> 4) + r;      // pad rows: srow == 0 and gate == 0
           const float g = Mk[row * KP + n] ? acc[jj][rt][r] * srow[rt][r] : 0.f;
-          const __bf16 h = (__bf16)g;
-          Eh[row * LDX + n] = h; El[row * LDX + n] = (__bf16)(g - (float)h);
+          store_split_pair(Eh, El, row, n, lane, g);
         }
     }
   }

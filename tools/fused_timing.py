@@ -26,9 +26,11 @@ torch.cuda.synchronize()
 lib.rd_debug_set_stamps(None)
 s = stamps.cpu().view(8, 16)
 names = ["start->embed done", "barrier", "mma1", "epi1", "barrier", "mma2", "epi2", "barrier", "scatter"]
-for w in range(4):
+for w in range(2):
     d = [int(s[w, i + 1] - s[w, i]) for i in range(9)]
     print("fwd wg%d" % w, " ".join("%s=%d" % (n, x) for n, x in zip(names, d)), "total", int(s[w, 9] - s[w, 0]))
+    print("      embed phase: issue loads=%d masks=%d zero_lds=%d barrier=%d consume=%d" % (
+        int(s[w, 10] - s[w, 0]), int(s[w, 11] - s[w, 10]), int(s[w, 12] - s[w, 11]), int(s[w, 13] - s[w, 12]), int(s[w, 1] - s[w, 13])))
 # backward: same stamp buffer, overwritten by the backward launch
 z = ops.sensor_stage(*args)
 zz = z[0] if isinstance(z, (tuple, list)) else z
@@ -41,6 +43,8 @@ lib.rd_debug_set_stamps(None)
 s = stamps.cpu().view(8, 16)
 names = ["loads+gather+gate", "barrier", "St->D planes+zero E", "barrier+mma1", "panel issue+epi1", "barrier+dz1save+mma2", "stage dX",
          "barrier+dR_u pass1", "barrier+pass2"]
-for w in range(4):
+for w in range(2):
     d = [int(s[w, i + 1] - s[w, i]) for i in range(9)]
     print("bwd wg%d" % w, " ".join("%s=%d" % (n, x) for n, x in zip(names, d)), "total", int(s[w, 9] - s[w, 0]))
+    print("      first phase: issue loads=%d zero_lds=%d barrier=%d gather consume=%d gate consume=%d" % (
+        int(s[w, 10] - s[w, 0]), int(s[w, 11] - s[w, 10]), int(s[w, 12] - s[w, 11]), int(s[w, 13] - s[w, 12]), int(s[w, 1] - s[w, 13])))
