@@ -34,6 +34,20 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global
+// load and store (s_waitcnt vmcnt(0)): with a register-resident weight panel in flight that serialises
+// the weight stream with each phase change.  Use ONLY where no thread reads global memory that another
+// thread of the same launch wrote before the barrier.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// uniform 64-bit load through the scalar cache: does not queue behind the vector loads in flight
+__device__ __forceinline__ uint64_t load_uniform_u64(const uint64_t* p) {
+  uint64_t v;
+  asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------
 // Generic fp32 GEMM on the f32-input MFMA (v_mfma_f32_16x16x4_f32: exact fp32, == fmaf chain).
 //   C(m,n) = epilogue( sum_k A(m,k) * B(n,k) )
@@ -64,6 +78,7 @@ struct GemmArgs {
   // scatter == 1: rows are (b,f) pairs of a [B,F,K] tensor, columns (t,c); element goes to the
   // [T,B,ldz] layout z[(t*sB + b)*ldz + f*sd + c]   (code/models_rd.py:338-342)
   int scatter; int sB, sF, sd; long ldz;
+  unsigned long long* stamps;     // debug phase stamps (set by launch_gemm; null in normal runs)
 };
 int launch_gemm(const GemmArgs& a, hipStream_t st);
 // split of the reduction length `red` of a [rows x cols] weight-gradient product into nsplit chunks

@@ -365,11 +365,13 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, f32x4 (&acc)[MI][N
   }
 }
 
-__device__ unsigned long long* g_gemm_stamps = nullptr;     // debug only (tools/gemm_timing.py)
+// debug only (tools/gemm_timing.py).  The pointer travels as a KERNEL ARGUMENT (an SGPR): a __device__ global
+// would cost a dependent global load plus s_waitcnt vmcnt(0) at every stamp site even when stamps are off.
+static unsigned long long* g_gemm_stamps = nullptr;
 #define GSTAMP(i)                                                                                    \
   do {                                                                                               \
-    if (g_gemm_stamps && blockIdx.z == 0 && blockIdx.x < 8 && threadIdx.x == 0)                      \
-      g_gemm_stamps[blockIdx.x * 8 + (i)] = clock64();                                        \
+    if (g.stamps && blockIdx.z == 0 && blockIdx.x < 8 && threadIdx.x == 0)                           \
+      g.stamps[blockIdx.x * 8 + (i)] = clock64();                                             \
   } while (0)
 
 // NPRE > 0: the whole K range of the workgroup (<= 64*NPRE) is requested up front, tile by tile into
@@ -652,8 +654,7 @@ __global__ __launch_bounds__(1024) void k_colsum_small(const float* __restrict__
 }  // namespace
 
 extern "C" void rd_debug_set_gemm_stamps(void* p) {      // not part of the ABI
-  unsigned long long* v = (unsigned long long*)p;
-  hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), &v, sizeof(v));
+  g_gemm_stamps = (unsigned long long*)p;
 }
 
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
@@ -665,6 +666,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), a.nsplit > 1 ? a.nsplit : 1);
   GemmArgs g = a;
   g.seed_cell = seed_cell();
+  g.stamps = g_gemm_stamps;
   static const int xcd_env = [] { const char* e = getenv("RD_GEMM_XCD"); return e ? atoi(e) : 1; }();
   g.xcd_swizzle = xcd_env;
   if (g.nsplit <= 1) { g.nsplit = 1; g.k_per_split = g.K > 0 ? g.K : 1; g.sc_split = 0; }

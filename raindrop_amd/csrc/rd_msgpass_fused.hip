@@ -115,13 +115,8 @@ __device__ __forceinline__ void load_panel_half(Panel& p, const __bf16* __restri
   }
 }
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global
-// load and store (s_waitcnt vmcnt(0)): with the weight panel (32 x 16 B per lane, 262 KB per workgroup) in flight that serialises the
-// ~12 k-cycle weight stream with each phase change.  No thread of these kernels reads global memory that
-// another thread of the same launch wrote, so LDS ordering is all the phases need.
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
+// lds_barrier() (rd_common.h): every barrier of these kernels orders LDS traffic only -- no thread reads global
+// memory that another thread of the same launch wrote, and a full __syncthreads() would drain the weight panel.
 // Keeps the first USE of a prefetched value below this point (volatile asm statements stay in program
 // order, so below the preceding lds_barrier): otherwise the scheduler folds the consumer's arithmetic up to
 // the load to save registers and waits for the data before the weight panel has even been requested.
@@ -159,12 +154,6 @@ __device__ __forceinline__ void zero_plane_pads(__bf16* P, int rows, int prow, i
   }
 }
 
-// uniform 64-bit load through the scalar cache: does not queue behind the vector loads in flight
-__device__ __forceinline__ uint64_t load_uniform_u64(const uint64_t* p) {
-  uint64_t v;
-  asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
-  return v;
-}
 
 // acc[jj][rt] (16x16 tiles) += A[rows rt*16.., KP] * panel^T ; A planes (hi/lo) in LDS.
 // The three split products are issued as three sweeps over independent accumulators.

@@ -24,10 +24,10 @@ constexpr int RG_ROWS = 64, RG_THR = 512, RG_WAVES = 8, RG_NJ = 2;
 constexpr int RG_CPR = RG_WAVES * RG_NJ * 16;      // 256 output columns per round
 constexpr int RG_LDS_STAGE = RG_CPR + 4;           // fp32 stage row stride
 
-__device__ unsigned long long* g_rg_stamps = nullptr;          // debug only (tools/rowgemm_timing.py)
+static unsigned long long* g_rg_stamps = nullptr;   // debug only (tools/rowgemm_timing.py); passed as a kernel argument
 #define RGSTAMP(i)                                                                          \
   do {                                                                                      \
-    if (g_rg_stamps && blockIdx.x < 8 && threadIdx.x == 0) g_rg_stamps[blockIdx.x * 16 + (i)] = clock64(); \
+    if (a.stamps && blockIdx.x < 8 && threadIdx.x == 0) a.stamps[blockIdx.x * 16 + (i)] = clock64();       \
   } while (0)
 
 struct RowGemmArgs {
@@ -39,6 +39,7 @@ struct RowGemmArgs {
   const float* posmask; long pm_ld; float cscale;
   const float* residual; long res_ld;
   float drop_p; uint64_t drop_seed; uint32_t drop_site; const uint64_t* seed_cell;
+  unsigned long long* stamps;
 };
 
 // one weight matrix -> hi/lo planes; transpose != 0 writes split(W^T): rows k, cols n
@@ -90,12 +91,12 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
   const int nrounds = (ntiles + RG_WAVES * RG_NJ - 1) / (RG_WAVES * RG_NJ);
 
   RGSTAMP(0);
+  uint64_t seed = a.drop_seed;
+  // ---- A rows -> split planes (zero padded); 16-byte loads, K % 4 == 0.  64 rows x KPc/4 quads is exactly
+  // KC quads per thread: all of them are requested first, THEN the weight panel (loads return in issue
+  // order: the rows are needed now, the panel only at the first MFMA), then the rows are split into LDS
+  // while the panel streams in.
   RPanel<KC> pw;
-  rg_load_panel<KC>(pw, a.Wh, a.Wl, a.KP, 0, ntiles, wave, lane);      // weight stream starts first
-
-  // ---- A rows -> split planes (zero padded); 16-byte loads, K % 4 == 0.  64 rows x KPc/4 quads is
-  // exactly KC quads per thread: all of a thread's loads are issued before the first is consumed
-  // (one HBM round trip for the whole tile instead of one per quad).
   {
     constexpr int kq = KPc / 4;                                        // float4 slots per row (incl. pad)
     float4 v[KC];
@@ -106,6 +107,10 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
       v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m0 + r < a.M && k < a.K) v[it] = *reinterpret_cast<const float4*>(a.A + (long)(m0 + r) * a.lda + k);
     }
+    rg_load_panel<KC>(pw, a.Wh, a.Wl, a.KP, 0, ntiles, wave, lane);
+    __builtin_amdgcn_sched_barrier(0);       // keep every request above the first use (the scheduler otherwise
+                                             // waits for the rows before it has requested the panel)
+    if (a.seed_cell) seed += load_uniform_u64(a.seed_cell);   // scalar path: not queued behind the panel
 #pragma unroll
     for (int it = 0; it < KC; ++it) {
       const int i = tid + it * RG_THR;
@@ -119,11 +124,10 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
     }
   }
   RGSTAMP(1);
-  __syncthreads();
+  lds_barrier();                       // LDS ordering only: do not drain the weight panel (rd_common.h)
   RGSTAMP(2);
 
   const float inv_keep = 1.0f / (1.0f - a.drop_p);
-  const uint64_t seed = eff_seed(a.drop_seed, a.seed_cell);
   const int aoff = (lane & 15) * LDA + 8 * (lane >> 4);
   for (int rd = 0; rd < nrounds; ++rd) {
     const int tile0 = rd * RG_WAVES * RG_NJ;
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
         for (int r = 0; r < 4; ++r)
           stage[(rt * 16 + 4 * (lane >> 4) + r) * RG_LDS_STAGE + (wave + RG_WAVES * jj) * 16 + (lane & 15)] = acc[jj][rt][r];
     if (rd == 0) RGSTAMP(4);
-    __syncthreads();
+    lds_barrier();
     if (rd == 0) RGSTAMP(5);
     // ---- epilogue over the stage tile: thread = (row, 4 consecutive columns); all global reads first
     const int n_base = tile0 * 16;
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
       *reinterpret_cast<float4*>(a.C + (long)m * a.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
     }
     if (rd == 0) RGSTAMP(6);
-    __syncthreads();
+    if (rd + 1 < nrounds) lds_barrier();                                // stage tile is rewritten next round
   }
   RGSTAMP(7);
 }
@@ -216,8 +220,7 @@ int launch_rowgemm_kc(const RowGemmArgs& a, hipStream_t st) {
 }  // namespace
 
 extern "C" void rd_debug_set_rowgemm_stamps(void* p) {   // not part of the ABI
-  unsigned long long* v = (unsigned long long*)p;
-  hipMemcpyToSymbol(HIP_SYMBOL(g_rg_stamps), &v, sizeof(v));
+  g_rg_stamps = (unsigned long long*)p;
 }
 
 // ---- host interface (used by rd_temporal.hip) -----------------------------------------------------
@@ -254,6 +257,7 @@ int launch_rowgemm(long M, int N, int K, const float* A, long lda, const void* W
   a.bias = bias; a.relu = relu; a.posmask = posmask; a.pm_ld = pm_ld; a.cscale = cscale;
   a.residual = residual; a.res_ld = res_ld;
   a.drop_p = drop_p; a.drop_seed = drop_seed; a.drop_site = drop_site; a.seed_cell = seed_cell();
+  a.stamps = g_rg_stamps;
   const int kc = a.KP / 32;
   if (kc == 5) return launch_rowgemm_kc<5>(a, st);
   if (kc == 9) return launch_rowgemm_kc<9>(a, st);

@@ -25,11 +25,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int WG_THR = 512, WG_SLAB = 64;
 constexpr int WG_LD = WG_SLAB + 8;          // bf16 per plane row: 144 B, odd multiple of 16 B -> conflict-free b128
 
-__device__ unsigned long long* g_wg_stamps = nullptr;          // debug only (tools/wgrad_timing.py)
+static unsigned long long* g_wg_stamps = nullptr;   // debug only (tools/wgrad_timing.py); passed as a kernel argument
 #define WGSTAMP(i)                                                                          \
   do {                                                                                      \
-    if (g_wg_stamps && blockIdx.x < 8 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) \
-      g_wg_stamps[a.cfg * 128 + blockIdx.x * 16 + (i)] = clock64();                                       \
+    if (a.stamps && blockIdx.x < 8 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)   \
+      a.stamps[a.cfg * 128 + blockIdx.x * 16 + (i)] = clock64();                                          \
   } while (0)
 
 struct WgArgs {
@@ -42,6 +42,7 @@ struct WgArgs {
   int nb_tiles;                             // 16-row n tiles per n-block (blockIdx.y)
   int want_rowsum;
   int cfg;                                  // configuration index (debug stamps)
+  unsigned long long* stamps;
 };
 
 template <int TN, int TK, int WN, int WK>
@@ -236,8 +237,7 @@ int launch_cfg(const WgArgs& a, dim3 grid, hipStream_t st) {
 
 extern "C" void rd_debug_set_wgrad_slabs(int v) { g_slabs = v; }   // not part of the ABI
 extern "C" void rd_debug_set_wgrad_stamps(void* p) {               // not part of the ABI
-  unsigned long long* v = (unsigned long long*)p;
-  hipMemcpyToSymbol(HIP_SYMBOL(g_wg_stamps), &v, sizeof(v));
+  g_wg_stamps = (unsigned long long*)p;
 }
 
 bool wgrad_slab_ok(long M, int N, int K) {
@@ -261,7 +261,7 @@ int launch_wgrad_slab(long M, int N, int K, const float* dy, long lddy, const fl
   a.part = ws; a.part2 = ws + (long)G * stride; a.stride = stride;
   a.M = (int)M; a.N = N; a.K = K; a.rows_per_wg = WG_SLAB * g_slabs; a.nb_tiles = nb_tiles;
   a.want_rowsum = (db != nullptr || db2 != nullptr) ? 1 : 0;
-  a.cfg = c;
+  a.cfg = c; a.stamps = g_wg_stamps;
   const dim3 grid(G, nblocks, dy2 ? 2 : 1);
   int rc;
   switch (c) {
