@@ -94,27 +94,77 @@ __device__ __forceinline__ void attn_keep4(float (&k4)[4], uint64_t seed, uint32
   k4[2] = u.z >= p ? inv_keep : 0.f; k4[3] = u.w >= p ? inv_keep : 0.f;
 }
 
-// rows [t0, t0+64) x cols [0, hd) of one head of q / k / v / out / dout -> LDS [64][ldh], zero padded
-__device__ __forceinline__ void load_head_tile(float* dst, int ldh, int hdp, const float* base,
-                                               long row_stride, int t0, int T, int hd, int tid) {
-  // 4 threads per row; each moves 16-byte chunks c4 = (tid&3), +4, +8, ...: no index division
-  const int r = tid >> 2, t = t0 + r;
-  const bool vec = ((hd & 3) == 0) && ((row_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
-  const float* src = base + (long)t * row_stride;
-  float* d = dst + r * ldh;
-  for (int c = 4 * (tid & 3); c < hdp; c += 16) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t < T) {
-      if (vec && c + 3 < hd) v = *reinterpret_cast<const float4*>(src + c);
-      else {
-        if (c < hd) v.x = src[c];
-        if (c + 1 < hd) v.y = src[c + 1];
-        if (c + 2 < hd) v.z = src[c + 2];
-        if (c + 3 < hd) v.w = src[c + 3];
+// rows [t0, t0+64) x cols [0, hd) of one head of q / k / v / out / dout: 4 threads per row, thread (r, q) holds
+// the 16-byte chunks q, q+4, q+8, ... of row r (zero padded to 16*NTH columns).  Loading is split from the LDS
+// store so that a kernel can request ALL of its tiles before it consumes the first one: the loop form
+// (load, wait, store per chunk) cost one dependent memory round trip per chunk -- 20 to 40 per workgroup.
+template <int NTH>
+struct HeadRegs { float4 v[NTH]; unsigned ok; };     // ok: bit 4*i+j = component j of chunk i is inside the tile
+
+// VEC: 16-byte loads (head_dim % 4 == 0, row strides % 4 == 0, 16-byte aligned bases -- decided once per kernel
+// by head_vec_ok, a wave-uniform branch); otherwise four 4-byte loads per chunk.  Every load is UNCONDITIONAL
+// from a clamped (always legal) address and the zero padding is applied later by head_mask: a conditional
+// load is a phi of {0, loaded value}, which makes the compiler shuffle registers -- and therefore wait --
+// right behind the request.
+template <int NTH, bool VEC>
+__device__ __forceinline__ void head_load_t(HeadRegs<NTH>& h, const float* base, long row_stride, int t0, int T, int hd,
+                                            int tid) {
+  const int t = t0 + (tid >> 2);
+  const bool rok = t < T;
+  const float* src = base + (long)(rok ? t : t0) * row_stride;
+  unsigned ok = 0;
+#pragma unroll
+  for (int i = 0; i < NTH; ++i) {
+    const int c = 4 * (tid & 3) + 16 * i;
+    if (VEC) {
+      const bool cok = c < hd;
+      h.v[i] = *reinterpret_cast<const float4*>(src + (cok ? c : 0));
+      if (rok && cok) ok |= 0xFu << (4 * i);
+    } else {
+      float e[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool cok = c + j < hd;
+        e[j] = src[cok ? c + j : 0];
+        if (rok && cok) ok |= 1u << (4 * i + j);
       }
+      h.v[i] = make_float4(e[0], e[1], e[2], e[3]);
     }
-    *reinterpret_cast<float4*>(d + c) = v;
   }
+  h.ok = ok;
+}
+__device__ __forceinline__ bool head_vec_ok(int hd, long rs, long ro, const void* p0, const void* p1, const void* p2) {
+  return ((hd & 3) == 0) && ((rs & 3) == 0) && ((ro & 3) == 0) &&
+         (((reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15) == 0);
+}
+// zero padding (rows >= T, columns >= head_dim); call below the point where the loads may complete
+template <int NTH>
+__device__ __forceinline__ void head_mask(HeadRegs<NTH>& h) {
+#pragma unroll
+  for (int i = 0; i < NTH; ++i) {
+    if (!((h.ok >> (4 * i)) & 1u)) h.v[i].x = 0.f;
+    if (!((h.ok >> (4 * i + 1)) & 1u)) h.v[i].y = 0.f;
+    if (!((h.ok >> (4 * i + 2)) & 1u)) h.v[i].z = 0.f;
+    if (!((h.ok >> (4 * i + 3)) & 1u)) h.v[i].w = 0.f;
+  }
+}
+template <int NTH>
+__device__ __forceinline__ void head_store(HeadRegs<NTH>& h, float* dst, int ldh, int tid) {
+  head_mask<NTH>(h);
+  float* d = dst + (tid >> 2) * ldh + 4 * (tid & 3);
+#pragma unroll
+  for (int i = 0; i < NTH; ++i) *reinterpret_cast<float4*>(d + 16 * i) = h.v[i];
+}
+// sum over the row of a[r,:] * b[r,:], combined over the row's 4 threads (every one of them gets the sum)
+template <int NTH>
+__device__ __forceinline__ float head_rowdot(const HeadRegs<NTH>& a, const HeadRegs<NTH>& b) {
+  float d = 0.f;
+#pragma unroll
+  for (int i = 0; i < NTH; ++i)
+    d += (a.v[i].x * b.v[i].x + a.v[i].y * b.v[i].y) + (a.v[i].z * b.v[i].z + a.v[i].w * b.v[i].w);
+  d += __shfl_xor(d, 1);
+  d += __shfl_xor(d, 2);
+  return d;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -138,7 +188,13 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
   const int q0 = blockIdx.x * TS;
   const long rs = (long)a.B * 3 * a.D;
   const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
-  load_head_tile(Qs, LDH, HDP, qb, rs, q0, a.T, a.hd, tid);
+  const bool vec = head_vec_ok(a.hd, rs, a.D, qb, nullptr, nullptr);
+  HeadRegs<NTH> qv;
+  if (vec) {
+    head_load_t<NTH, true>(qv, qb, rs, q0, a.T, a.hd, tid);
+  } else {
+    head_load_t<NTH, false>(qv, qb, rs, q0, a.T, a.hd, tid);
+  }
   float m_i[4], l_i[4];
   f32x4 o[NTH];
 #pragma unroll
@@ -148,9 +204,23 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
   const float inv_keep = 1.0f / (1.0f - a.p_drop);
 
   for (int k0 = 0; k0 < a.T; k0 += TS) {
+    // every load of this key tile (and, first time round, the query tile requested above) is in flight
+    // before the first is consumed
+    HeadRegs<NTH> kv, vv;
+    if (vec) {
+      head_load_t<NTH, true>(kv, qb + a.D, rs, k0, a.T, a.hd, tid);
+      head_load_t<NTH, true>(vv, qb + 2 * a.D, rs, k0, a.T, a.hd, tid);
+    } else {
+      head_load_t<NTH, false>(kv, qb + a.D, rs, k0, a.T, a.hd, tid);
+      head_load_t<NTH, false>(vv, qb + 2 * a.D, rs, k0, a.T, a.hd, tid);
+    }
+    uint8_t mb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mb[j] = a.mask[(long)b * a.T + min(k0 + 16 * j + (lane & 15), a.T - 1)];
     __syncthreads();
-    load_head_tile(Ks, LDH, HDP, qb + a.D, rs, k0, a.T, a.hd, tid);
-    load_head_tile(Vs, LDH, HDP, qb + 2 * a.D, rs, k0, a.T, a.hd, tid);
+    if (k0 == 0) head_store<NTH>(qv, Qs, LDH, tid);
+    head_store<NTH>(kv, Ks, LDH, tid);
+    head_store<NTH>(vv, Vs, LDH, tid);
     __syncthreads();
     f32x4 s[4];
 #pragma unroll
@@ -160,7 +230,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int key = k0 + 16 * j + (lane & 15);
-      const bool dead = key >= a.T || a.mask[(long)b * a.T + key];
+      const bool dead = key >= a.T || mb[j];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         s[j][r] = dead ? -INFINITY : s[j][r] * a.scale;
@@ -233,27 +303,46 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
   const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
   const float* dob = a.dout + (long)b * a.D + h * a.hd;
   const float* ob = a.out + (long)b * a.D + h * a.hd;
-  load_head_tile(Qs, LDH, HDP, qb, rs, q0, a.T, a.hd, tid);
-  load_head_tile(dOs, LDH, HDP, dob, ro, q0, a.T, a.hd, tid);
-  __syncthreads();
-  if (tid < TS) {
-    const int q = q0 + tid;
-    float d = 0.f, l = 0.f;
-    if (q < a.T) {
-      for (int c = 0; c < a.hd; ++c) d += dOs[tid * LDH + c] * ob[(long)q * ro + c];
-      l = a.lse[(long)bh * a.T + q];
-      a.delta[(long)bh * a.T + q] = d;
+  const bool vec = head_vec_ok(a.hd, rs, ro, qb, dob, ob);
+  {
+    HeadRegs<NTH> qv, dov, ov;
+    if (vec) {
+      head_load_t<NTH, true>(qv, qb, rs, q0, a.T, a.hd, tid);
+      head_load_t<NTH, true>(dov, dob, ro, q0, a.T, a.hd, tid);
+      head_load_t<NTH, true>(ov, ob, ro, q0, a.T, a.hd, tid);
+    } else {
+      head_load_t<NTH, false>(qv, qb, rs, q0, a.T, a.hd, tid);
+      head_load_t<NTH, false>(dov, dob, ro, q0, a.T, a.hd, tid);
+      head_load_t<NTH, false>(ov, ob, ro, q0, a.T, a.hd, tid);
     }
-    dl_s[tid] = d; lse_s[tid] = l;
+    const int r = tid >> 2, q = q0 + r;
+    const float l = q < a.T ? a.lse[(long)bh * a.T + q] : 0.f;
+    __builtin_amdgcn_sched_barrier(0);                  // every request above, every use below
+    head_store<NTH>(qv, Qs, LDH, tid);
+    head_store<NTH>(dov, dOs, LDH, tid);
+    head_mask<NTH>(ov);
+    const float d = head_rowdot<NTH>(dov, ov);          // delta = rowsum(dO * O); rows >= T are zero padded
+    if ((tid & 3) == 0) {
+      dl_s[r] = d; lse_s[r] = l;
+      if (q < a.T) a.delta[(long)bh * a.T + q] = d;
+    }
   }
   f32x4 dq[NTH];
 #pragma unroll
   for (int j = 0; j < NTH; ++j) dq[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float inv_keep = 1.0f / (1.0f - a.p_drop);
   for (int k0 = 0; k0 < a.T; k0 += TS) {
+    HeadRegs<NTH> kv, vv;
+    if (vec) {
+      head_load_t<NTH, true>(kv, qb + a.D, rs, k0, a.T, a.hd, tid);
+      head_load_t<NTH, true>(vv, qb + 2 * a.D, rs, k0, a.T, a.hd, tid);
+    } else {
+      head_load_t<NTH, false>(kv, qb + a.D, rs, k0, a.T, a.hd, tid);
+      head_load_t<NTH, false>(vv, qb + 2 * a.D, rs, k0, a.T, a.hd, tid);
+    }
     __syncthreads();
-    load_head_tile(Ks, LDH, HDP, qb + a.D, rs, k0, a.T, a.hd, tid);
-    load_head_tile(Vs, LDH, HDP, qb + 2 * a.D, rs, k0, a.T, a.hd, tid);
+    head_store<NTH>(kv, Ks, LDH, tid);
+    head_store<NTH>(vv, Vs, LDH, tid);
     __syncthreads();
     f32x4 s[4], dp[4];
 #pragma unroll
@@ -315,8 +404,19 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
   const long rs = (long)a.B * 3 * a.D, ro = (long)a.B * a.D;
   const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
   const float* dob = a.dout + (long)b * a.D + h * a.hd;
-  load_head_tile(Ks, LDH, HDP, qb + a.D, rs, k0, a.T, a.hd, tid);
-  load_head_tile(Vs, LDH, HDP, qb + 2 * a.D, rs, k0, a.T, a.hd, tid);
+  const bool vec = head_vec_ok(a.hd, rs, ro, qb, dob, nullptr);
+  {
+    HeadRegs<NTH> kv, vv;
+    if (vec) {
+      head_load_t<NTH, true>(kv, qb + a.D, rs, k0, a.T, a.hd, tid);
+      head_load_t<NTH, true>(vv, qb + 2 * a.D, rs, k0, a.T, a.hd, tid);
+    } else {
+      head_load_t<NTH, false>(kv, qb + a.D, rs, k0, a.T, a.hd, tid);
+      head_load_t<NTH, false>(vv, qb + 2 * a.D, rs, k0, a.T, a.hd, tid);
+    }
+    head_store<NTH>(kv, Ks, LDH, tid);
+    head_store<NTH>(vv, Vs, LDH, tid);
+  }
   f32x4 dk[NTH], dv[NTH];
 #pragma unroll
   for (int j = 0; j < NTH; ++j) { dk[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[j] = dk[j]; }
@@ -328,9 +428,17 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
     dead[r] = key >= a.T || a.mask[(long)b * a.T + min(key, a.T - 1)];
   }
   for (int q0 = 0; q0 < a.T; q0 += TS) {
+    HeadRegs<NTH> qv, dov;
+    if (vec) {
+      head_load_t<NTH, true>(qv, qb, rs, q0, a.T, a.hd, tid);
+      head_load_t<NTH, true>(dov, dob, ro, q0, a.T, a.hd, tid);
+    } else {
+      head_load_t<NTH, false>(qv, qb, rs, q0, a.T, a.hd, tid);
+      head_load_t<NTH, false>(dov, dob, ro, q0, a.T, a.hd, tid);
+    }
     __syncthreads();
-    load_head_tile(Qs, LDH, HDP, qb, rs, q0, a.T, a.hd, tid);
-    load_head_tile(dOs, LDH, HDP, dob, ro, q0, a.T, a.hd, tid);
+    head_store<NTH>(qv, Qs, LDH, tid);
+    head_store<NTH>(dov, dOs, LDH, tid);
     if (tid < TS) {
       const int q = q0 + tid;
       lse_s[tid] = q < a.T ? a.lse[(long)bh * a.T + q] : 0.f;
@@ -405,19 +513,36 @@ __global__ __launch_bounds__(256) void k_attn_bwd_one(AttnArgs a) {
   const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
   const float* dob = a.dout + (long)b * a.D + h * a.hd;
   const float* ob = a.out + (long)b * a.D + h * a.hd;
-  load_head_tile(Qs, LDH, HDP, qb, rs, 0, a.T, a.hd, tid);
-  load_head_tile(Ks, LDH, HDP, qb + a.D, rs, 0, a.T, a.hd, tid);
-  load_head_tile(Vs, LDH, HDP, qb + 2 * a.D, rs, 0, a.T, a.hd, tid);
-  load_head_tile(dOs, LDH, HDP, dob, ro, 0, a.T, a.hd, tid);
-  // delta = rowsum(dO * O): 4 threads per row, combined by shuffles
+  // all five tiles (Q, K, V, dO, O), the LSE row and the key mask are requested in one burst
+  const bool vec = head_vec_ok(a.hd, rs, ro, qb, dob, ob);
+  uint8_t mb[4];
   {
+    HeadRegs<NTH> qv, kv, vv, dov, ov;
+    if (vec) {
+      head_load_t<NTH, true>(qv, qb, rs, 0, a.T, a.hd, tid);
+      head_load_t<NTH, true>(kv, qb + a.D, rs, 0, a.T, a.hd, tid);
+      head_load_t<NTH, true>(vv, qb + 2 * a.D, rs, 0, a.T, a.hd, tid);
+      head_load_t<NTH, true>(dov, dob, ro, 0, a.T, a.hd, tid);
+      head_load_t<NTH, true>(ov, ob, ro, 0, a.T, a.hd, tid);
+    } else {
+      head_load_t<NTH, false>(qv, qb, rs, 0, a.T, a.hd, tid);
+      head_load_t<NTH, false>(kv, qb + a.D, rs, 0, a.T, a.hd, tid);
+      head_load_t<NTH, false>(vv, qb + 2 * a.D, rs, 0, a.T, a.hd, tid);
+      head_load_t<NTH, false>(dov, dob, ro, 0, a.T, a.hd, tid);
+      head_load_t<NTH, false>(ov, ob, ro, 0, a.T, a.hd, tid);
+    }
     const int r = tid >> 2;
-    float d = 0.f;
-    if (r < a.T)
-      for (int c = (tid & 3); c < a.hd; c += 4) d += dob[(long)r * ro + c] * ob[(long)r * ro + c];
-    d += __shfl_xor(d, 1);
-    d += __shfl_xor(d, 2);
-    if ((tid & 3) == 0) { dl_s[r] = d; lse_s[r] = r < a.T ? a.lse[(long)bh * a.T + r] : 0.f; }
+    const float l = r < a.T ? a.lse[(long)bh * a.T + r] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mb[j] = a.mask[(long)b * a.T + min(16 * j + (lane & 15), a.T - 1)];
+    __builtin_amdgcn_sched_barrier(0);                  // every request above, every use below
+    head_store<NTH>(qv, Qs, LDH, tid);
+    head_store<NTH>(kv, Ks, LDH, tid);
+    head_store<NTH>(vv, Vs, LDH, tid);
+    head_store<NTH>(dov, dOs, LDH, tid);
+    head_mask<NTH>(ov);
+    const float d = head_rowdot<NTH>(dov, ov);          // delta = rowsum(dO * O)
+    if ((tid & 3) == 0) { dl_s[r] = d; lse_s[r] = l; }
   }
   __syncthreads();
   const float inv_keep = 1.0f / (1.0f - a.p_drop);
@@ -429,7 +554,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_one(AttnArgs a) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int key = 16 * j + (lane & 15);
-    const bool dead = key >= a.T || a.mask[(long)b * a.T + min(key, a.T - 1)];
+    const bool dead = key >= a.T || mb[j];
     float k4[4] = {1.f, 1.f, 1.f, 1.f};
     if (a.p_drop > 0.f)
       attn_keep4(k4, eff_seed(a.seed, a.seed_cell), a.site, bh, a.T, wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
