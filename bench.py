@@ -292,7 +292,12 @@ def main():
         torch.cuda.synchronize()
         print("GRAPHPROBE ok %.6f" % float(ts_.loss), flush=True)
         return
-    if use_graph and graph_probe_ok(args, world):
+    probe_ok = bool(use_graph and graph_probe_ok(args, world))
+    if world > 1:                               # the step mode is a collective decision: every rank must take
+        pk = torch.tensor([1.0 if probe_ok else 0.0], dtype=torch.float64, device=dev)   # the same branches below
+        dist.all_reduce(pk, op=dist.ReduceOp.MIN)
+        probe_ok = bool(pk.item() > 0.5)
+    if probe_ok:
         from raindrop_amd.step import TrainStep
         tstep = TrainStep(model, flat, batch)
 

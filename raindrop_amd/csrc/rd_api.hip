@@ -154,8 +154,8 @@ extern "C" int rd_linear_bwd_weight(int32_t M, int32_t N, int32_t K, const float
   hipStream_t st = (hipStream_t)stream;
   if (M == 0) {
     RD_REQUIRE(dW != nullptr, "NULL tensor");
-    hipMemsetAsync(dW, 0, sizeof(float) * N * K, st);
-    if (db) hipMemsetAsync(db, 0, sizeof(float) * N, st);
+    RD_HIP(hipMemsetAsync(dW, 0, sizeof(float) * N * K, st));
+    if (db) RD_HIP(hipMemsetAsync(db, 0, sizeof(float) * N, st));
     return RD_OK;
   }
   RD_REQUIRE(dy && x && dW, "NULL tensor");

@@ -18,6 +18,19 @@ inline int check_launch(const char* what) {
   return RD_OK;
 }
 
+// runtime call that must succeed: returns the hipError_t (positive) through the C-ABI error channel
+#define RD_HIP(call)                                                                      \
+  do {                                                                                    \
+    hipError_t rd_e_ = (call);                                                            \
+    if (rd_e_ != hipSuccess) return rd::fail((int)rd_e_, "%s: %s", #call, hipGetErrorString(rd_e_)); \
+  } while (0)
+// dynamic-LDS opt-in of a kernel, done once per process (never inside a stream capture after the first call)
+#define RD_LDS_ATTR(kernel, bytes)                                                        \
+  do {                                                                                    \
+    static const hipError_t rd_attr_ = hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+    if (rd_attr_ != hipSuccess) return rd::fail((int)rd_attr_, "hipFuncSetAttribute(%s): %s", #kernel, hipGetErrorString(rd_attr_)); \
+  } while (0)
+
 #define RD_REQUIRE(cond, ...)                           \
   do {                                                  \
     if (!(cond)) return rd::fail(RD_EINVAL, __VA_ARGS__); \

@@ -533,8 +533,7 @@ int launch_bf16x3_n(const GemmArgs& g, hipStream_t st) {
   dim3 grid((g.nsplit > 1 ? cdiv(g.M, TM) : 8 * cdiv(cdiv(g.M, TM), 8)) * cdiv(g.N, TN), 1,
             (g.nsplit > 1 ? g.nsplit : 1) * (g.A2 ? 2 : 1));
   if (lds > 48 * 1024)
-    { static bool once = false; if (!once) { hipFuncSetAttribute((const void*)k_gemm_bf16x3<A_KC, B_KC, MI, NI, NPRE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds); once = true; } }
+    RD_LDS_ATTR((k_gemm_bf16x3<A_KC, B_KC, MI, NI, NPRE>), lds);
   hipLaunchKernelGGL((k_gemm_bf16x3<A_KC, B_KC, MI, NI, NPRE>), grid, dim3(256), lds, st, g);
   return check_launch("k_gemm_bf16x3");
 }
@@ -788,8 +787,8 @@ int launch_colsum2(const float* x, int M, int N, long ldx, float* out1, int n1, 
   }
   int rc = launch_colsum(x, M, N, ldx, ws, ws + N, st);          // long matrices: two-stage, then split
   if (rc) return rc;
-  hipMemcpyAsync(out1, ws, sizeof(float) * n1, hipMemcpyDeviceToDevice, st);
-  hipMemcpyAsync(out2, ws + n1, sizeof(float) * (N - n1), hipMemcpyDeviceToDevice, st);
+  RD_HIP(hipMemcpyAsync(out1, ws, sizeof(float) * n1, hipMemcpyDeviceToDevice, st));
+  RD_HIP(hipMemcpyAsync(out2, ws + n1, sizeof(float) * (N - n1), hipMemcpyDeviceToDevice, st));
   return RD_OK;
 }
 

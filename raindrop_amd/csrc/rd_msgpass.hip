@@ -235,9 +235,9 @@ extern "C" int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* 
   if (s->B == 0) {
     const int K0 = s->T * s->d_ob;
     hipStream_t st0 = (hipStream_t)stream;
-    hipMemsetAsync(dW1, 0, sizeof(float) * K0 * K0, st0); hipMemsetAsync(dW2, 0, sizeof(float) * K0 * K0, st0);
-    hipMemsetAsync(db1, 0, sizeof(float) * K0, st0); hipMemsetAsync(db2, 0, sizeof(float) * K0, st0);
-    hipMemsetAsync(dR_u, 0, sizeof(float) * s->F * s->d_ob, st0);
+    RD_HIP(hipMemsetAsync(dW1, 0, sizeof(float) * K0 * K0, st0)); RD_HIP(hipMemsetAsync(dW2, 0, sizeof(float) * K0 * K0, st0));
+    RD_HIP(hipMemsetAsync(db1, 0, sizeof(float) * K0, st0)); RD_HIP(hipMemsetAsync(db2, 0, sizeof(float) * K0, st0));
+    RD_HIP(hipMemsetAsync(dR_u, 0, sizeof(float) * s->F * s->d_ob, st0));
     return RD_OK;
   }
   RD_REQUIRE(src && R_u && W1 && W2 && ssum && saved && z && dz, "NULL tensor");
@@ -249,9 +249,9 @@ extern "C" int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* 
   hipStream_t st = (hipStream_t)stream;
   const int B = s->B, T = s->T, F = s->F, d = s->d_ob, K = T * d, M = B * F;
   if (B == 0) {
-    hipMemsetAsync(dW1, 0, sizeof(float) * K * K, st); hipMemsetAsync(dW2, 0, sizeof(float) * K * K, st);
-    hipMemsetAsync(db1, 0, sizeof(float) * K, st); hipMemsetAsync(db2, 0, sizeof(float) * K, st);
-    hipMemsetAsync(dR_u, 0, sizeof(float) * F * d, st);
+    RD_HIP(hipMemsetAsync(dW1, 0, sizeof(float) * K * K, st)); RD_HIP(hipMemsetAsync(dW2, 0, sizeof(float) * K * K, st));
+    RD_HIP(hipMemsetAsync(db1, 0, sizeof(float) * K, st)); RD_HIP(hipMemsetAsync(db2, 0, sizeof(float) * K, st));
+    RD_HIP(hipMemsetAsync(dR_u, 0, sizeof(float) * F * d, st));
     return RD_OK;
   }
   MsgWs w = carve(s, workspace);

@@ -202,18 +202,6 @@ __device__ __forceinline__ void zero_lds(void* p, int bytes, int tid) {
   for (int i = tid; i < bytes / 16; i += NTHR) q[i] = z;
 }
 
-// zero the pad columns [K, KP) of every row and the pad rows [F, RT*16) of two planes
-__device__ __forceinline__ void zero_pads(__bf16* Ph, __bf16* Pl, int rows, int F, int K, int tid) {
-  const int padc = KP - K;
-  for (int i = tid; i < rows * padc; i += NTHR) {
-    const int r = i / padc, c = K + (i - r * padc);
-    Ph[r * LDX + c] = (__bf16)0.f; Pl[r * LDX + c] = (__bf16)0.f;
-  }
-  for (int i = tid; i < (rows - F) * K; i += NTHR) {
-    const int r = F + i / K, c = i % K;
-    Ph[r * LDX + c] = (__bf16)0.f; Pl[r * LDX + c] = (__bf16)0.f;
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // forward
@@ -625,12 +613,12 @@ template <int RT>
 int launch_fused(const FusedArgs& a, bool bwd, hipStream_t st) {
   const size_t lds = (size_t)4 * RT * 16 * LDX * sizeof(__bf16);
   if (!bwd) {
-    { static bool once = false; if (!once) { hipFuncSetAttribute((const void*)k_msg_fwd_fused<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } }
+    RD_LDS_ATTR((k_msg_fwd_fused<RT>), lds);
     hipLaunchKernelGGL(k_msg_fwd_fused<RT>, dim3(a.B), dim3(NTHR), lds, st, a);
     return check_launch("k_msg_fwd_fused");
   }
   const size_t ldsb = lds + (size_t)RT * 16 * KP;                  // + ReLU gate bytes
-  { static bool once = false; if (!once) { hipFuncSetAttribute((const void*)k_msg_bwd_fused<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); once = true; } }
+  RD_LDS_ATTR((k_msg_bwd_fused<RT>), ldsb);
   hipLaunchKernelGGL(k_msg_bwd_fused<RT>, dim3(a.B), dim3(NTHR), ldsb, st, a);
   return check_launch("k_msg_bwd_fused");
 }

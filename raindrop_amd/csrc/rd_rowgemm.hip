@@ -212,7 +212,7 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
 template <int KC>
 int launch_rowgemm_kc(const RowGemmArgs& a, hipStream_t st) {
   const size_t lds = (size_t)2 * RG_ROWS * (KC * 32 + 8) * sizeof(__bf16) + (size_t)RG_ROWS * RG_LDS_STAGE * sizeof(float);
-  { static bool once = false; if (!once) { hipFuncSetAttribute((const void*)k_rowgemm<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } }
+  RD_LDS_ATTR((k_rowgemm<KC>), lds);
   hipLaunchKernelGGL(k_rowgemm<KC>, dim3(cdiv(a.M, RG_ROWS)), dim3(RG_THR), lds, st, a);
   return check_launch("k_rowgemm");
 }

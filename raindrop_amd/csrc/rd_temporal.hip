@@ -195,6 +195,10 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
   } else {
     head_load_t<NTH, false>(qv, qb, rs, q0, a.T, a.hd, tid);
   }
+  // device seed cell on the scalar path (a vector load would queue behind the tile loads and be waited for
+  // in the middle of the softmax)
+  uint64_t seedv = a.seed;
+  if (a.p_drop > 0.f && a.seed_cell) seedv += load_uniform_u64(a.seed_cell);
   float m_i[4], l_i[4];
   f32x4 o[NTH];
 #pragma unroll
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
       const int key = k0 + 16 * j + (lane & 15);
       float k4[4] = {1.f, 1.f, 1.f, 1.f};
       if (a.p_drop > 0.f)     // F.dropout on the attention probabilities (after the softmax sum)
-        attn_keep4(k4, eff_seed(a.seed, a.seed_cell), a.site, bh, a.T, q0 + wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
+        attn_keep4(k4, seedv, a.site, bh, a.T, q0 + wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = wave * 16 + 4 * (lane >> 4) + r;
@@ -327,6 +331,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
       if (q < a.T) a.delta[(long)bh * a.T + q] = d;
     }
   }
+  uint64_t seedv = a.seed;
+  if (a.p_drop > 0.f && a.seed_cell) seedv += load_uniform_u64(a.seed_cell);
   f32x4 dq[NTH];
 #pragma unroll
   for (int j = 0; j < NTH; ++j) dq[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
       const bool dead = key >= a.T || a.mask[(long)b * a.T + key];
       float k4[4] = {1.f, 1.f, 1.f, 1.f};
       if (a.p_drop > 0.f)
-        attn_keep4(k4, eff_seed(a.seed, a.seed_cell), a.site, bh, a.T, q0 + wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
+        attn_keep4(k4, seedv, a.site, bh, a.T, q0 + wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = wave * 16 + 4 * (lane >> 4) + r;
@@ -417,6 +423,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
     head_store<NTH>(kv, Ks, LDH, tid);
     head_store<NTH>(vv, Vs, LDH, tid);
   }
+  uint64_t seedv = a.seed;
+  if (a.p_drop > 0.f && a.seed_cell) seedv += load_uniform_u64(a.seed_cell);
   f32x4 dk[NTH], dv[NTH];
 #pragma unroll
   for (int j = 0; j < NTH; ++j) { dk[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[j] = dk[j]; }
@@ -461,7 +469,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
         if (!dead[r] && q < a.T) {
           const float p = __expf(st[j][r] * a.scale - lse_s[qi]);
           float keep = 1.f;
-          if (a.p_drop > 0.f) keep = attn_keep1(eff_seed(a.seed, a.seed_cell), a.site, bh, a.T, q, k0 + krow, a.p_drop, inv_keep);
+          if (a.p_drop > 0.f) keep = attn_keep1(seedv, a.site, bh, a.T, q, k0 + krow, a.p_drop, inv_keep);
           pm = p * keep;
           ds = p * (dpt[j][r] * keep - dl_s[qi]) * a.scale;
         }
@@ -515,6 +523,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_one(AttnArgs a) {
   const float* ob = a.out + (long)b * a.D + h * a.hd;
   // all five tiles (Q, K, V, dO, O), the LSE row and the key mask are requested in one burst
   const bool vec = head_vec_ok(a.hd, rs, ro, qb, dob, ob);
+  uint64_t seedv = a.seed;
   uint8_t mb[4];
   {
     HeadRegs<NTH> qv, kv, vv, dov, ov;
@@ -535,6 +544,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_one(AttnArgs a) {
     const float l = r < a.T ? a.lse[(long)bh * a.T + r] : 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) mb[j] = a.mask[(long)b * a.T + min(16 * j + (lane & 15), a.T - 1)];
+    if (a.p_drop > 0.f && a.seed_cell) seedv += load_uniform_u64(a.seed_cell);   // scalar path, under the tile loads
     __builtin_amdgcn_sched_barrier(0);                  // every request above, every use below
     head_store<NTH>(qv, Qs, LDH, tid);
     head_store<NTH>(kv, Ks, LDH, tid);
@@ -557,7 +567,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_one(AttnArgs a) {
     const bool dead = key >= a.T || mb[j];
     float k4[4] = {1.f, 1.f, 1.f, 1.f};
     if (a.p_drop > 0.f)
-      attn_keep4(k4, eff_seed(a.seed, a.seed_cell), a.site, bh, a.T, wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
+      attn_keep4(k4, seedv, a.site, bh, a.T, wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = wave * 16 + 4 * (lane >> 4) + r;
@@ -598,24 +608,24 @@ int launch_attn(const AttnArgs& a, int which, hipStream_t st) {
   size_t lds;
   if (which == 0) {
     lds = sizeof(float) * (3 * TS * LDH + TS * LDP);
-    { static bool once = false; if (!once) { hipFuncSetAttribute((const void*)k_attn_fwd<NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } }
+    RD_LDS_ATTR((k_attn_fwd<NTH>), lds);
     if (a.T <= TS && LDH >= LDP) lds = sizeof(float) * (3 * TS * LDH);   // P overlays Q
     hipLaunchKernelGGL(k_attn_fwd<NTH>, grid, dim3(256), lds, st, a);
     return check_launch("k_attn_fwd");
   } else if (which == 1) {
     lds = sizeof(float) * (4 * TS * LDH + TS * LDP + 2 * TS);
-    { static bool once = false; if (!once) { hipFuncSetAttribute((const void*)k_attn_bwd_dq<NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } }
+    RD_LDS_ATTR((k_attn_bwd_dq<NTH>), lds);
     hipLaunchKernelGGL(k_attn_bwd_dq<NTH>, grid, dim3(256), lds, st, a);
     return check_launch("k_attn_bwd_dq");
   }
   if (which == 3) {
     lds = sizeof(float) * (4 * TS * LDH + 2 * TS * LDP + 2 * TS);
-    { static bool once = false; if (!once) { hipFuncSetAttribute((const void*)k_attn_bwd_one<NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } }
+    RD_LDS_ATTR((k_attn_bwd_one<NTH>), lds);
     hipLaunchKernelGGL(k_attn_bwd_one<NTH>, dim3(a.B * a.H), dim3(256), lds, st, a);
     return check_launch("k_attn_bwd_one");
   }
   lds = sizeof(float) * (4 * TS * LDH + 2 * TS * LDP + 2 * TS);
-  { static bool once = false; if (!once) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv<NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } }
+  RD_LDS_ATTR((k_attn_bwd_dkv<NTH>), lds);
   hipLaunchKernelGGL(k_attn_bwd_dkv<NTH>, grid, dim3(256), lds, st, a);
   return check_launch("k_attn_bwd_dkv");
 }
@@ -1069,7 +1079,6 @@ EncSaved carve_saved(const EncDims& e, void* base) {
 
 struct EncWs { float *o, *f, *ds2, *df, *du, *dx1, *ds1, *dout, *da, *dqkv, *delta, *lnpart, *lnred, *splitk, *colsum;
                size_t bytes; int ns_max; };
-int bw_nsplit(long M, int N, int K, int* kps) { return splitk_plan(M, N, K, kps); }
 EncWs carve_ws(const EncDims& e, void* base) {
   EncWs w; size_t off = 0;
   auto take = [&](size_t n) { float* p = base ? (float*)((char*)base + off) : nullptr;
@@ -1134,9 +1143,10 @@ struct Aux {
 };
 Aux& aux() { static Aux a; return a; }
 // make `to` wait for everything enqueued on `from` so far
-void chain(hipStream_t from, hipStream_t to, hipEvent_t ev) {
-  hipEventRecord(ev, from);
-  hipStreamWaitEvent(to, ev, 0);
+int chain(hipStream_t from, hipStream_t to, hipEvent_t ev) {
+  RD_HIP(hipEventRecord(ev, from));
+  RD_HIP(hipStreamWaitEvent(to, ev, 0));
+  return RD_OK;
 }
 
 int check_enc(const rd_shape* s) {
@@ -1244,7 +1254,7 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   Aux& ax = aux();
   hipStream_t sw = ax.ok ? ax.s : st;                       // stream of the weight-gradient products
   // ---- FFN ---------------------------------------------------------------------------------------
-  if (ax.ok) chain(st, sw, ax.ev[0]);
+  if (ax.ok && (rc = chain(st, sw, ax.ev[0]))) return rc;
   if ((rc = linear_bwd_w(e.M, e.D, e.nhid, ws.df, v.h, g->lin2_w, g->lin2_b, ws.splitk, ws.colsum, sw))) return rc;
   const bool rg = rowgemm_ok(3 * e.D, e.D, e.D, 3 * e.D) && rowgemm_ok(e.D, e.D, e.D, e.D) &&
                   rowgemm_ok(e.nhid, e.D, e.D, e.nhid) && rowgemm_ok(e.D, e.nhid, e.nhid, e.D);
@@ -1253,7 +1263,7 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
                              p_drop > 0.f ? keep : 0.f, nullptr, 0, 0.f, 0, 0, st))) return rc;
   } else if ((rc = linear_bwd_x(e.M, e.D, e.nhid, ws.df, w->lin2_w, ws.du, v.h, p_drop > 0.f ? keep : 0.f, nullptr, st)))
     return rc;
-  if (ax.ok) chain(st, sw, ax.ev[1]);
+  if (ax.ok && (rc = chain(st, sw, ax.ev[1]))) return rc;
   if ((rc = linear_bwd_w(e.M, e.nhid, e.D, ws.du, v.x1, g->lin1_w, g->lin1_b, ws.splitk, ws.colsum, sw))) return rc;
   if (rg) {
     if ((rc = launch_rowgemm(e.M, e.D, e.nhid, ws.du, e.nhid, v.pl[6][0], v.pl[6][1], ws.dx1, e.D, nullptr, 0, nullptr, 0, 0.f,
@@ -1264,7 +1274,7 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
                           SITE_ATTN_OUT + L, st))) return rc;
   if ((rc = launch_colsum2(ws.lnpart, lnb, 2 * e.D, 2 * e.D, g->norm1_w, e.D, g->norm1_b, ws.lnred, st))) return rc;
   // ---- attention output projection ---------------------------------------------------------------
-  if (ax.ok) chain(st, sw, ax.ev[2]);
+  if (ax.ok && (rc = chain(st, sw, ax.ev[2]))) return rc;
   if ((rc = linear_bwd_w(e.M, e.D, e.D, ws.dout, v.attn, g->out_proj_w, g->out_proj_b, ws.splitk, ws.colsum, sw)))
     return rc;
   if (rg) {
@@ -1283,11 +1293,11 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
     if ((rc = dispatch_attn(a, 2, st))) return rc;
   }
   // ---- input projection --------------------------------------------------------------------------
-  if (ax.ok) chain(st, sw, ax.ev[3]);
+  if (ax.ok && (rc = chain(st, sw, ax.ev[3]))) return rc;
   if ((rc = linear_bwd_w(e.M, 3 * e.D, e.D, ws.dqkv, x, g->in_proj_w, g->in_proj_b, ws.splitk, ws.colsum, sw)))
     return rc;
   rc = linear_bwd_x(e.M, 3 * e.D, e.D, ws.dqkv, w->in_proj_w, dx, nullptr, 0.f, ws.ds1, st);
-  if (ax.ok) chain(sw, st, ax.ev[4]);                        // join: the caller's stream owns every result
+  if (ax.ok && (rc = chain(sw, st, ax.ev[4]))) return rc;                        // join: the caller's stream owns every result
   return rc;
 }
 

@@ -228,7 +228,7 @@ int pick_cfg(int N, int K, int* nblocks, int* nb_tiles) {
 template <int TN, int TK, int WN, int WK>
 int launch_cfg(const WgArgs& a, dim3 grid, hipStream_t st) {
   const size_t lds = (size_t)2 * (WN * TN + WK * TK) * 16 * WG_LD * sizeof(__bf16);
-  { static bool once = false; if (!once) { hipFuncSetAttribute((const void*)k_wgrad_slab<TN, TK, WN, WK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } }
+  RD_LDS_ATTR((k_wgrad_slab<TN, TK, WN, WK>), lds);
   hipLaunchKernelGGL((k_wgrad_slab<TN, TK, WN, WK>), grid, dim3(WG_THR), lds, st, a);
   return check_launch("k_wgrad_slab");
 }
