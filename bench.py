@@ -146,7 +146,23 @@ def k1_roofline_events(model, cfg, batch, reps=20):
     return _roofline_dict(B, F, K, fwd, bwd, "eager launches timed with HIP events (includes host launch gaps)")
 
 
+def _pmc_traffic(B, F, K):
+    """HBM bytes per K1 step from the committed PMC passes (rocprofv3 --pmc cannot run inside the timed
+    process: FETCH_SIZE and WRITE_SIZE need separate passes; tools/k1_traffic_json.py).  Only valid for the
+    shape it was collected on; None otherwise."""
+    try:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "raindrop_amd", "k1_pmc_traffic.json")
+        with open(path) as fh:
+            d = json.load(fh)
+        if (B, F, K) == (256, 34, 240):
+            return int(d["bytes_per_step"]), d["source"]
+    except Exception:
+        pass
+    return None, None
+
+
 def _roofline_dict(B, F, K, fwd, bwd, how):
+    traffic, traffic_src = _pmc_traffic(B, F, K)
     bytes_fwd = B * 12 * F * K + 8 * (K * K + K)
     bytes_bwd = B * 20 * F * K + 16 * K * K
     alg = bytes_fwd + bytes_bwd
@@ -154,7 +170,7 @@ def _roofline_dict(B, F, K, fwd, bwd, how):
     return {"bound": "hbm", "kernel": "K1 message passing fwd+bwd (rd_msgpass_fwd + rd_msgpass_bwd incl. PE/mask, "
                                       "weight split, dW/db reductions); " + how,
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes": alg, "fwd_us": round(fwd * 1e3, 2), "bwd_us": round(bwd * 1e3, 2),
             "fwd_frac": round(bytes_fwd / (fwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             "bwd_frac": round(bytes_bwd / (bwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
