@@ -223,6 +223,20 @@ int rd_linear_bwd_weight(int32_t M, int32_t N, int32_t K, const float* dy, int32
                          const float* x, int32_t ldx, float* dW, float* db, void* workspace,
                          size_t workspace_bytes, void* stream);
 
+/* ---- batch feed: the caller's per-step slice, code/Raindrop.py:310-317 ---------------- */
+
+/* `P = Ptrain_tensor[:, idx, :]`, `Ptime = Ptrain_time_tensor[:, idx]`, `Pstatic = Ptrain_static_tensor[idx]`,
+ * `y = ytrain_tensor[idx]` (host fancy-index + H2D in the reference, :310-315) and
+ * `lengths = torch.sum(Ptime > 0, dim=0)` (:317) in ONE launch over a dataset that is resident in HBM:
+ * P_all [T,N,W] (W = 2F), time_all [T,N], static_all [N,d_static] or NULL, y_all [N] or NULL, idx [B] int64
+ * (device) -> src [T,B,W], times [T,B], static_out [B,d_static], y_out [B], lengths [B] int64.  Pure copies:
+ * bit-exact.  An index outside [0,N) is clamped and ADDED to *bad_index_count (device int32, may be NULL; the
+ * caller zeroes it -- the library enqueues nothing but the one kernel). */
+int rd_batch_gather(int32_t T, int32_t B, int32_t W, int32_t d_static, int64_t N, const float* P_all,
+                    const float* time_all, const float* static_all, const int64_t* y_all, const int64_t* idx,
+                    float* src, float* times, float* static_out, int64_t* y_out, int64_t* lengths,
+                    int32_t* bad_index_count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,7 @@ SIGNATURES = {
     "rd_linear_bwd_input": (c_int32, [c_int32, c_int32, c_int32, _P, c_int32, _P, _P, c_int32, _P]),
     "rd_linear_bwd_input_gated": (c_int32, [c_int32, c_int32, c_int32, _P, c_int32, _P, _P, c_int32, _P, c_int32, _P]),
     "rd_softmax_xent": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _P]),
+    "rd_batch_gather": (c_int32, [c_int32, c_int32, c_int32, c_int32, ctypes.c_int64] + [_P] * 12),
     "rd_linear_bwd_weight_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "rd_linear_bwd_weight": (c_int32, [c_int32, c_int32, c_int32, _P, c_int32, _P, c_int32, _P, _P,
                                         _P, c_size_t, _P]),
