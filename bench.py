@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--k1-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--graph-probe", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--feed", action="store_true",
+                    help="draw every step's batch from a device-resident dataset with rd_batch_gather (SURVEY 8f "
+                         "rank 1) instead of re-using one resident batch (the default, as the metric is defined)")
     ap.add_argument("--no-graph", action="store_true",
                     help="eager autograd step instead of the hipGraph-captured static step")
     return ap.parse_args()
@@ -284,7 +287,27 @@ def main():
     opt = FlatAdam(flat.flatten_parameters(), lr=1e-4)
     criterion = torch.nn.CrossEntropyLoss()
 
+    # --feed: every step first gathers a fresh batch INTO the resident buffers (one extra launch) from a
+    # device-resident dataset, the way code/Raindrop.py:310-317 slices its training tensors on the host
+    feed_next = None
+    if args.feed and not args.k1_child and not args.graph_probe:
+        from raindrop_amd import feed as rfeed
+        n_feed = 8192
+        big = synth.make_batch(cfg, n_feed, seed=200 + rank)
+        dset = rfeed.DeviceDataset(big["src"], big["times"], big["static"], big["y"], device=dev)
+        gen = torch.Generator().manual_seed(rank)
+        idxs = [torch.randint(0, n_feed, (B,), generator=gen).to(dev) for _ in range(64)]
+        fbuf = {"P": batch["src"], "Ptime": batch["times"], "Pstatic": batch["static"], "y": batch["y"],
+                "lengths": batch["lengths"]}
+        fcount = [0]
+
+        def feed_next():
+            dset.batch(idxs[fcount[0] % len(idxs)], out=fbuf)
+            fcount[0] += 1
+
     def eager_step():
+        if feed_next is not None:
+            feed_next()
         flat.zero()
         out, _, _ = model(batch["src"], batch["static"], batch["times"], batch["lengths"])
         loss = criterion(out, batch["y"])
@@ -318,6 +341,8 @@ def main():
         tstep = TrainStep(model, flat, batch)
 
     def graph_step():
+        if feed_next is not None:
+            feed_next()
         loss = tstep.run()
         flat.allreduce()
         if not args.no_optimizer:
@@ -389,6 +414,8 @@ def main():
                                        "+RCCL flat-grad all-reduce" if world > 1 else "",
                                        "" if args.no_optimizer else "+Adam", cfg["dropout"]),
                        "step_mode": "hipGraph(fwd+CE+bwd) + eager all-reduce/Adam" if tstep is not None else "eager autograd",
+                       "batch_source": ("rd_batch_gather from a device-resident dataset (N=8192) every step" if feed_next
+                                        else "one resident batch re-used (inputs in HBM before the timed region)"),
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "grad_allreduce_bytes": flat.nbytes()},
         }
