@@ -197,22 +197,41 @@ struct Stage {
   static constexpr int NREG = ROWS / 4;                      // fp32 values per thread per tile
   static constexpr int TPR = 256 / ROWS;                     // MC: threads per row
   static constexpr int KPT = 64 / (TPR > 0 ? TPR : 1);       // MC: consecutive k per thread
-  __device__ static __forceinline__ void load(float (&r)[NREG], const float* __restrict__ P, long s_row,
-                                              long s_k, int row0, int nrows, int k0, int kend, int tid,
+  // `ok`: validity bits of r[] (KC staging only).  The k-contiguous loads are UNCONDITIONAL from clamped, always
+  // legal addresses and the zero padding is applied in store(): a conditional load is a phi of {0, value} and
+  // its two arms (16-byte / scalar tail) write the same registers, which made the compiler wait for the A tile
+  // before it had requested the B tile (one extra memory round trip per workgroup in every prologue).
+  __device__ static __forceinline__ void load(float (&r)[NREG], unsigned long long& ok, const float* __restrict__ P,
+                                              long s_row, long s_k, int row0, int nrows, int k0, int kend, int tid,
                                               bool vec_ok) {
+    ok = 0ull;
     if (KC) {
       const int kq = k0 + (tid & 15) * 4;
+      if (vec_ok) {                 // uniform.  Row stride % 4 == 0 and 16-byte aligned base: a quad that starts below
+        const bool kok = kq < kend; // kend stays inside its row's stride even when K % 4 != 0 (tail masked below)
+        const int kc = kok ? kq : k0;
+        const unsigned long long kbits = (kq < kend ? 1ull : 0ull) | (kq + 1 < kend ? 2ull : 0ull) |
+                                         (kq + 2 < kend ? 4ull : 0ull) | (kq + 3 < kend ? 8ull : 0ull);
 #pragma unroll
-      for (int p = 0; p < ROWS / 16; ++p) {
-        const int row = row0 + p * 16 + (tid >> 4);
-        const bool rok = row < nrows;
-        if (rok && vec_ok && kq + 3 < kend) {
-          const float4 v = *reinterpret_cast<const float4*>(P + (long)row * s_row + kq);
+        for (int p = 0; p < ROWS / 16; ++p) {
+          const int row = row0 + p * 16 + (tid >> 4);
+          const bool rok = row < nrows;
+          const float4 v = *reinterpret_cast<const float4*>(P + (long)(rok ? row : row0) * s_row + kc);
           r[p * 4 + 0] = v.x; r[p * 4 + 1] = v.y; r[p * 4 + 2] = v.z; r[p * 4 + 3] = v.w;
-        } else {
+          if (rok) ok |= kbits << (4 * p);
+        }
+      } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            r[p * 4 + j] = (rok && kq + j < kend) ? P[(long)row * s_row + kq + j] : 0.f;
+        for (int p = 0; p < ROWS / 16; ++p) {
+          const int row = row0 + p * 16 + (tid >> 4);
+          const bool rok = row < nrows;
+          const float* src = P + (long)(rok ? row : row0) * s_row;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool kok = kq + j < kend;
+            r[p * 4 + j] = src[kok ? kq + j : k0];
+            if (rok && kok) ok |= 1ull << (4 * p + j);
+          }
         }
       }
     } else {
@@ -225,7 +244,7 @@ struct Stage {
       }
     }
   }
-  __device__ static __forceinline__ void store(const float (&r)[NREG], __bf16* __restrict__ Th,
+  __device__ static __forceinline__ void store(const float (&r)[NREG], unsigned long long ok, __bf16* __restrict__ Th,
                                                __bf16* __restrict__ Tl, int tid) {
     if (KC) {
 #pragma unroll
@@ -233,7 +252,7 @@ struct Stage {
         bf16x4 h, l;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float x = r[p * 4 + j];
+          const float x = ((ok >> (4 * p + j)) & 1ull) ? r[p * 4 + j] : 0.f;
           h[j] = (__bf16)x;
           l[j] = (__bf16)(x - (float)h[j]);
         }
@@ -420,6 +439,7 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
   using SB = Stage<B_KC, TN>;
   constexpr int NBUF = NPRE > 0 ? NPRE : 1;
   float ra[NBUF][SA::NREG], rb[NBUF][SB::NREG];
+  unsigned long long oka[NBUF], okb[NBUF];               // validity bits of the k-contiguous staging (see Stage::load)
   float rsum = 0.f;                                   // MC staging: this thread's row is tid % TM
   const bool do_rowsum = !A_KC && g.rowsum != nullptr && cblk == 0;
   constexpr size_t PLANES_B = (size_t)2 * (TM + TN) * LDB * sizeof(__bf16), STAGE_B = (size_t)TM * (TN + 4) * sizeof(float);
@@ -428,12 +448,12 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
 #pragma unroll
     for (int t = 0; t < NBUF; ++t)
       if (kbeg + t * BK2 < kend) {
-        SA::load(ra[t], g.A, g.sa_m, g.sa_k, m0, g.M, kbeg + t * BK2, kend, tid, a_vec);
-        SB::load(rb[t], g.B, g.sb_n, g.sb_k, n0, g.N, kbeg + t * BK2, kend, tid, b_vec);
+        SA::load(ra[t], oka[t], g.A, g.sa_m, g.sa_k, m0, g.M, kbeg + t * BK2, kend, tid, a_vec);
+        SB::load(rb[t], okb[t], g.B, g.sb_n, g.sb_k, n0, g.N, kbeg + t * BK2, kend, tid, b_vec);
       }
   } else if (kbeg < kend) {
-    SA::load(ra[0], g.A, g.sa_m, g.sa_k, m0, g.M, kbeg, kend, tid, a_vec);
-    SB::load(rb[0], g.B, g.sb_n, g.sb_k, n0, g.N, kbeg, kend, tid, b_vec);
+    SA::load(ra[0], oka[0], g.A, g.sa_m, g.sa_k, m0, g.M, kbeg, kend, tid, a_vec);
+    SB::load(rb[0], okb[0], g.B, g.sb_n, g.sb_k, n0, g.N, kbeg, kend, tid, b_vec);
   }
   if (tid < TN) bias_s[tid] = (g.bias && n0 + tid < g.N) ? g.bias[n0 + tid] : 0.f;
 
@@ -480,8 +500,8 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
 #pragma unroll
           for (int i = 0; i < SA::NREG; ++i) rsum += ra[t][i];
         }
-        SA::store(ra[t], Ah, Al, tid);
-        SB::store(rb[t], Bh, Bl, tid);
+        SA::store(ra[t], oka[t], Ah, Al, tid);
+        SB::store(rb[t], okb[t], Bh, Bl, tid);
         __syncthreads();
         if (t == 0) GSTAMP(1);
         mma_tile();
@@ -494,13 +514,13 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < SA::NREG; ++i) rsum += ra[0][i];
       }
-      SA::store(ra[0], Ah, Al, tid);
-      SB::store(rb[0], Bh, Bl, tid);
+      SA::store(ra[0], oka[0], Ah, Al, tid);
+      SB::store(rb[0], okb[0], Bh, Bl, tid);
       __syncthreads();
       if (k0 == kbeg) GSTAMP(1);
       if (k0 + BK2 < kend) {
-        SA::load(ra[0], g.A, g.sa_m, g.sa_k, m0, g.M, k0 + BK2, kend, tid, a_vec);
-        SB::load(rb[0], g.B, g.sb_n, g.sb_k, n0, g.N, k0 + BK2, kend, tid, b_vec);
+        SA::load(ra[0], oka[0], g.A, g.sa_m, g.sa_k, m0, g.M, k0 + BK2, kend, tid, a_vec);
+        SB::load(rb[0], okb[0], g.B, g.sb_n, g.sb_k, n0, g.N, k0 + BK2, kend, tid, b_vec);
       }
       mma_tile();
       __syncthreads();
