@@ -10,6 +10,18 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The CPU suite is thousands of tiny tensor ops (per-sample / per-edge oracle loops).  With the default one thread
+# per core their OpenMP fork/join dominates, and on a busy or virtualised host it degrades by 10-100x (measured
+# here: 2000 [34x240]@[240x240] products take 1.0 s on 1 thread, 25 s on 4, 132 s on 8 while a neighbour is
+# active).  One thread is both faster and predictable; RD_TEST_THREADS overrides.
+_NT = str(max(1, int(os.environ.get("RD_TEST_THREADS", "1"))))
+os.environ.setdefault("OMP_NUM_THREADS", _NT)    # inherited by the world-size-2 gloo worker processes
+try:
+    import torch
+    torch.set_num_threads(int(_NT))
+except Exception:                                # torch-free collection (e.g. symbol tests only)
+    pass
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run via gpurun / the round-end driver)")
