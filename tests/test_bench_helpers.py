@@ -45,3 +45,23 @@ def test_usable_cores_respects_affinity(bench):
     assert 1 <= n <= (os.cpu_count() or 1)
     if hasattr(os, "sched_getaffinity"):
         assert n <= len(os.sched_getaffinity(0))
+
+
+def test_cpu_baseline_is_bounded_by_wall_clock(bench):
+    """The CPU leg must never stretch the benchmark: chunks until the sample cap or the wall-clock budget."""
+    import time
+    from raindrop_amd import synth
+    cfg = synth.make_config("P19")
+    gs = synth.make_structure(cfg, "ones")
+    import torch
+    nt = torch.get_num_threads()
+    t0 = time.perf_counter()
+    try:
+        d = bench.cpu_baseline(cfg, gs, 256, 1000, budget_s=2.0)    # cap far beyond the budget
+    finally:
+        torch.set_num_threads(nt)                                    # the leg picks its own thread count
+    wall = time.perf_counter() - t0
+    assert d["unit"] == "samples/s" and d["kind"] == "port" and d["value"] > 0
+    assert 1 <= d["cores"] <= bench.usable_cores()
+    assert "chunks of 32" in d["sample"]
+    assert wall < 60.0                                               # probes + warm-up + <= 2 s of timed chunks (+ one chunk)
