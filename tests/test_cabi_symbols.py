@@ -49,6 +49,12 @@ def test_argument_errors_are_reported_before_launch(lib):
     assert lib.rd_msgpass_workspace_bytes(ctypes.byref(shp)) > 0
     rc = lib.rd_msgpass_fwd(ctypes.byref(shp), *([None] * 7), 0.0, 0, None, 12, None, 0, None)
     assert rc == -1 and b"NULL" in lib.rd_last_error()
+    # batch feed: bad dims, NULL tensors; an empty batch is a no-op that needs no device
+    assert lib.rd_batch_gather(5, 2, 0, 0, 10, *([None] * 12)) == -1 and b"bad dims" in lib.rd_last_error()
+    assert lib.rd_batch_gather(5, 2, 6, 0, 10, *([None] * 12)) == -1 and b"NULL" in lib.rd_last_error()
+    assert lib.rd_batch_gather(5, 0, 6, 0, 10, *([None] * 12)) == 0
+    # weight-gradient workspace query is pure host arithmetic and grows with the reduction length
+    assert lib.rd_linear_bwd_weight_workspace_bytes(15360, 152, 272) >= lib.rd_linear_bwd_weight_workspace_bytes(256, 152, 272) > 0
 
 
 def test_product_path_fails_loudly_without_device():
