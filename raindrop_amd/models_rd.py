@@ -16,11 +16,9 @@ Differences from the reference, all deliberate and documented in DESIGN.md:
   * `distance` is the exact constant 0 the reference computes on this path.
 """
 import ctypes
-import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 from torch.nn.parameter import Parameter
 
 from . import _lib, ops

@@ -3,7 +3,6 @@
 model (`code/Raindrop.py:232-238,310-317`).  Needs the reference tree; skipped on the GPU box."""
 import importlib.util
 import os
-import sys
 
 import numpy as np
 import pytest

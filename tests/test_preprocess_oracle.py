@@ -62,7 +62,6 @@ def test_setting3_removal_matches_the_script_loop():
 
 @pytest.mark.skipif(not ref_loader.available(), reason="reference tree not present")
 def test_restatement_matches_reference_functions_live():
-    import importlib.util
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
