@@ -428,6 +428,11 @@ def main():
                        "step_mode": "hipGraph(fwd+CE+bwd) + eager all-reduce/Adam" if tstep is not None else "eager autograd",
                        "batch_source": ("rd_batch_gather from a device-resident dataset (N=8192) every step" if feed_next
                                         else "one resident batch re-used (inputs in HBM before the timed region)"),
+                       "arithmetic": "fp32 tensors everywhere; dense contractions as split-bf16 (hi+lo, 3 products) on "
+                                     "v_mfma_f32_16x16x32_bf16 with fp32 accumulation (~2^-16 per product; logits within "
+                                     "1e-4 of the fp32 reference, tests/test_gpu_parity.py); attention, softmax, "
+                                     "LayerNorm and reductions in fp32 (RD_PRECISION=fp32 switches the contractions to "
+                                     "the exact-fp32 MFMA)",
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "grad_allreduce_bytes": flat.nbytes()},
         }
