@@ -9,7 +9,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int32, c_size_t, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libraindrop_hip.so")
+LIB_PATH = os.environ.get("RD_LIB_PATH") or os.path.join(_PKG, "libraindrop_hip.so")   # RD_LIB_PATH: A/B builds (tools/ab_build.sh)
 
 
 class RdShape(ctypes.Structure):

@@ -15,21 +15,24 @@
 // tiled MFMA GEMM (rd_gemm.hip) with the ReLU / aggregate-scale / layout-scatter fused into its
 // epilogue.  The LDS-resident fused kernel for small K lives in rd_msgpass_fused.hip.
 #include "rd_common.h"
+#include "rd_k1_layout.h"
 #include "rd_rng.h"
 
 namespace rd {
 
-// fused LDS-resident path (rd_msgpass_fused.hip)
+// fused LDS-resident path (rd_msgpass_fused.hip) and its weight-gradient kernels (rd_msgpass_dw.hip)
 bool fused_msgpass_ok(const rd_shape* s);
-size_t fused_wplanes_bytes(const rd_shape* s);
-int fused_wprep(const rd_shape* s, const float* W1, const float* W2, void* planes, hipStream_t st);
-int fused_msgpass_fwd(const rd_shape* s, const float* src, const float* R_u, const float* b1, const float* b2,
-                      const float* ssum, const void* planes, float p_drop, uint64_t seed, float* xsave,
-                      float* y1save, float* z, int ldz, hipStream_t st, const float* times = nullptr,
-                      const int64_t* lengths = nullptr, const float* tscale = nullptr, uint8_t* mask = nullptr);
-int fused_msgpass_bwd(const rd_shape* s, const float* src, const float* ssum, const void* planes, float p_drop,
-                      const float* xsave, const float* y1save, const float* z, const float* dz, int ldz,
-                      float* dz2save, float* dz1save, float* rupart, hipStream_t st);
+int fused_wprep(const k1::Layout& L, const float* W1, const float* W2, void* wt, hipStream_t st);
+int fused_msgpass_fwd(const k1::Layout& L, const float* src, const float* R_u, const float* b1, const float* b2,
+                      const float* ssum, const void* wt, float p_drop, uint64_t seed, void* tpX, void* tpY1,
+                      void* m1, void* m2, void* mx, float* z, int ldz, hipStream_t st, const float* times,
+                      const int64_t* lengths, const float* tscale, uint8_t* mask, int d_pe);
+int fused_msgpass_bwd(const k1::Layout& L, const float* src, const float* ssum, const void* wt, float p_drop,
+                      const void* m1, const void* m2, const void* mx, const float* dz, int ldz, void* tpD1, void* tpD2,
+                      void* ones, float* rupart, hipStream_t st);
+int fused_dw(const k1::Layout& L, const k1::DwPlan& P, const void* tpX, const void* tpY1, const void* tpD1,
+             const void* tpD2, const void* ones, float* part, const float* rupart, float* dW1, float* db1, float* dW2, float* db2,
+             float* dRu, hipStream_t st);
 
 namespace {
 
@@ -105,6 +108,7 @@ struct MsgWs {
   int nsplit, kps;
 };
 
+// generic (tiled-GEMM) path
 MsgWs carve(const rd_shape* s, void* base) {
   const long B = s->B, F = s->F, K = (long)s->T * s->d_ob;
   const long M = B * F;
@@ -124,7 +128,7 @@ MsgWs carve(const rd_shape* s, void* base) {
   return w;
 }
 
-struct MsgSaved { float *xsave, *y1save; void* planes; size_t bytes; };
+struct MsgSaved { float *xsave, *y1save; size_t bytes; };
 MsgSaved carve_saved(const rd_shape* s, void* base) {
   const size_t M = (size_t)s->B * s->F, K = (size_t)s->T * s->d_ob;
   MsgSaved v; size_t off = 0;
@@ -132,9 +136,36 @@ MsgSaved carve_saved(const rd_shape* s, void* base) {
                                   off += align_up(bytes, 256); return p; };
   v.xsave = (float*)take(M * K * sizeof(float));
   v.y1save = (float*)take(M * K * sizeof(float));
-  v.planes = take(fused_wplanes_bytes(s));
   v.bytes = off;
   return v;
+}
+
+// fused path (rd_k1_layout.h): forward -> backward hand-over and backward scratch
+struct FusedSaved { void *wt, *tpX, *tpY1, *m1, *m2, *mx; size_t bytes; };
+FusedSaved carve_fused_saved(const k1::Layout& L, void* base) {
+  FusedSaved v; size_t off = 0;
+  auto take = [&](size_t bytes) { void* p = base ? (void*)((char*)base + off) : nullptr;
+                                  off += align_up(bytes, 256); return p; };
+  v.wt = take(L.wt_bytes); v.tpX = take(L.tp_bytes); v.tpY1 = take(L.tp_bytes);
+  v.m1 = take(L.gate_bytes); v.m2 = take(L.gate_bytes); v.mx = take(L.mx_bytes);
+  v.bytes = off;
+  return v;
+}
+struct FusedWs { void *tpD1, *tpD2, *ones; float *part, *rupart; size_t bytes; };
+FusedWs carve_fused_ws(const k1::Layout& L, const k1::DwPlan& P, void* base) {
+  FusedWs w; size_t off = 0;
+  auto take = [&](size_t bytes) { void* p = base ? (void*)((char*)base + off) : nullptr;
+                                  off += align_up(bytes, 256); return p; };
+  w.tpD1 = take(L.tp_bytes); w.tpD2 = take(L.tp_bytes);
+  w.part = (float*)take(P.part_floats * sizeof(float));
+  w.rupart = (float*)take((size_t)L.B * L.F * 4 * sizeof(float));
+  w.ones = take(3 * k1::TILE * 2);
+  w.bytes = off;
+  return w;
+}
+bool fused_envelope(const rd_shape* s) {      // shape part of fused_msgpass_ok (sizes must not depend on the precision mode)
+  const int K = s->T * s->d_ob;
+  return s->d_ob == 4 && s->F <= 64 && K <= 240 && (K % 16) == 0 && K >= 16;
 }
 
 int check_shape(const rd_shape* s) {
@@ -152,12 +183,23 @@ using namespace rd;
 
 extern "C" size_t rd_msgpass_workspace_bytes(const rd_shape* s) {
   if (!s || s->T <= 0 || s->F <= 0 || s->d_ob <= 0 || s->B < 0) return 0;
-  return carve(s, nullptr).bytes;
+  size_t n = carve(s, nullptr).bytes;
+  if (fused_envelope(s)) {
+    const k1::Layout L = k1::make_layout(s->B, s->T, s->F);
+    const size_t f = carve_fused_ws(L, k1::make_dw_plan(L), nullptr).bytes;
+    if (f > n) n = f;
+  }
+  return n;
 }
 
 extern "C" size_t rd_msgpass_saved_bytes(const rd_shape* s) {
   if (!s || s->T <= 0 || s->F <= 0 || s->d_ob <= 0 || s->B < 0) return 0;
-  return carve_saved(s, nullptr).bytes;
+  size_t n = carve_saved(s, nullptr).bytes;
+  if (fused_envelope(s)) {
+    const size_t f = carve_fused_saved(k1::make_layout(s->B, s->T, s->F), nullptr).bytes;
+    if (f > n) n = f;
+  }
+  return n;
 }
 
 extern "C" int rd_msgpass_fwd(const rd_shape* s, const float* src, const float* R_u, const float* W1,
@@ -176,8 +218,12 @@ extern "C" int rd_msgpass_fwd(const rd_shape* s, const float* src, const float* 
   const int B = s->B, T = s->T, F = s->F, d = s->d_ob, K = T * d, M = B * F;
   float* xsave = v.xsave; float* y1save = v.y1save;
   if (fused_msgpass_ok(s)) {
-    if ((rc = fused_wprep(s, W1, W2, v.planes, st))) return rc;
-    return fused_msgpass_fwd(s, src, R_u, b1, b2, ssum, v.planes, p_drop, seed, xsave, y1save, z, ldz, st);
+    const k1::Layout L = k1::make_layout(B, T, F);
+    FusedSaved fv = carve_fused_saved(L, saved);
+    RD_REQUIRE(saved_bytes >= fv.bytes, "saved buffer too small: %zu < %zu", saved_bytes, fv.bytes);
+    if ((rc = fused_wprep(L, W1, W2, fv.wt, st))) return rc;
+    return fused_msgpass_fwd(L, src, R_u, b1, b2, ssum, fv.wt, p_drop, seed, fv.tpX, fv.tpY1, fv.m1, fv.m2, fv.mx, z, ldz,
+                             st, nullptr, nullptr, nullptr, nullptr, 0);
   }
   {
     const long per = (long)F * K;
@@ -213,12 +259,13 @@ extern "C" int rd_sensor_stage_fwd(const rd_shape* s, const float* src, const fl
   if (fused_msgpass_ok(s)) {
     RD_REQUIRE(src && R_u && W1 && b1 && W2 && b2 && ssum && z && saved, "NULL tensor");
     RD_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "p_drop must be in [0,1)");
-    MsgSaved v = carve_saved(s, saved);
-    RD_REQUIRE(saved_bytes >= v.bytes, "saved buffer too small: %zu < %zu", saved_bytes, v.bytes);
+    const k1::Layout L = k1::make_layout(s->B, s->T, s->F);
+    FusedSaved fv = carve_fused_saved(L, saved);
+    RD_REQUIRE(saved_bytes >= fv.bytes, "saved buffer too small: %zu < %zu", saved_bytes, fv.bytes);
     hipStream_t st = (hipStream_t)stream;
-    if ((rc = fused_wprep(s, W1, W2, v.planes, st))) return rc;
-    return fused_msgpass_fwd(s, src, R_u, b1, b2, ssum, v.planes, p_drop, seed, v.xsave, v.y1save, z, ldz, st,
-                             times, lengths, timescales, mask);
+    if ((rc = fused_wprep(L, W1, W2, fv.wt, st))) return rc;
+    return fused_msgpass_fwd(L, src, R_u, b1, b2, ssum, fv.wt, p_drop, seed, fv.tpX, fv.tpY1, fv.m1, fv.m2, fv.mx, z, ldz,
+                             st, times, lengths, timescales, mask, s->d_pe);
   }
   if ((rc = rd_pe_mask(s, times, lengths, timescales, z, mask, stream))) return rc;
   return rd_msgpass_fwd(s, src, R_u, W1, b1, W2, b2, ssum, p_drop, seed, z, ldz, saved, saved_bytes, stream);
@@ -254,14 +301,22 @@ extern "C" int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* 
     RD_HIP(hipMemsetAsync(dR_u, 0, sizeof(float) * F * d, st));
     return RD_OK;
   }
+  if (fused_msgpass_ok(s)) {
+    // chain kernel (dz -> dZ2 -> dZ1 -> dX -> dR_u partials; dZ as row tiles) + streamed weight-gradient product + reduce
+    const k1::Layout L = k1::make_layout(B, T, F);
+    const k1::DwPlan P = k1::make_dw_plan(L);
+    FusedSaved fv = carve_fused_saved(L, const_cast<void*>(saved));
+    RD_REQUIRE(saved_bytes >= fv.bytes, "saved buffer too small");
+    FusedWs fw = carve_fused_ws(L, P, workspace);
+    RD_REQUIRE(workspace && workspace_bytes >= fw.bytes, "workspace too small: %zu < %zu", workspace_bytes, fw.bytes);
+    if ((rc = fused_msgpass_bwd(L, src, ssum, fv.wt, p_drop, fv.m1, fv.m2, fv.mx, dz, ldz, fw.tpD1, fw.tpD2, fw.ones, fw.rupart, st)))
+      return rc;
+    return fused_dw(L, P, fv.tpX, fv.tpY1, fw.tpD1, fw.tpD2, fw.ones, fw.part, fw.rupart, dW1, db1, dW2, db2, dR_u, st);
+  }
   MsgWs w = carve(s, workspace);
   RD_REQUIRE(workspace && workspace_bytes >= w.bytes, "workspace too small: %zu < %zu",
              workspace_bytes, w.bytes);
-  if (fused_msgpass_ok(s)) {
-    if ((rc = fused_msgpass_bwd(s, src, ssum, sv.planes, p_drop, xsave, y1save, z, dz, ldz, w.dz2, w.dz1,
-                                w.rupart, st))) return rc;
-    if ((rc = launch_colsum(w.rupart, B, F * d, F * d, dR_u, w.colsum, st))) return rc;
-  } else {
+  {
   {
     const long per = (long)F * K;
     int gy = (int)((per + 255) / 256); if (gy > 64) gy = 64;

@@ -1,5 +1,5 @@
 // rd_msgpass_fused.hip -- kernel K1, fused LDS-resident form for small sensor graphs
-// (F <= 64 sensors, K = T*d_ob <= 256 and a multiple of 16: the P19 shape, K = 240).
+// (F <= 64 sensors, K = T*d_ob <= 240 and a multiple of 16: the P19 shape, K = 240).
 //
 // One workgroup owns one sample.  Its sensor graph node features X [F, K] are built in LDS straight
 // from src (observation embedding, code/models_rd.py:290-296 + the [T,F*d] -> [F,T*d] re-layout of
@@ -10,47 +10,77 @@
 //
 // Arithmetic: the two K x K contractions use split-bf16 on v_mfma_f32_16x16x32_bf16
 // (x = hi + lo in bf16; hi*hi + hi*lo + lo*hi, fp32 accumulate).  The weights are split ONCE per
-// step by k_wprep into bf16 planes (both orientations, K padded to 256) that stay L2-resident and
-// are streamed by every workgroup as MFMA B operands; activations are split when they are
-// written to LDS.  Per sample the MFMA work is (RT*16 rows) x K x 256 x 3 products x 2 layers.
+// step by k_wprep into native MFMA operand tiles (rd_k1_layout.h: every wave-load is one contiguous
+// kilobyte -- 4x the L2->CU rate of a row-major plane) that stay L2-resident; activations are split
+// when they are written to LDS.
+//
+// What the backward pass needs is handed over in the form it is consumed in (rd_k1_layout.h):
+//   * X and Y1 (the layer inputs of dW_l = dZ_l^T In_l) as split-bf16 ROW tiles, transposed on the way
+//     out, so the weight-gradient kernel (rd_msgpass_dw.hip) streams pure MFMA operands;
+//   * the three ReLU gates (X > 0, Y1 > 0, Y2 > 0) as bit masks: 5 KB per sample instead of re-reading
+//     96 KB of activations.
+// The backward kernel here does the activation-side chain dz -> dZ2 -> dZ1 -> dX -> dR_u and emits dZ2, dZ1
+// as row tiles; no fp32 copy of X, Y1, dZ1 or dZ2 exists in HBM.
 //
 // Layout in LDS (RT = ceil(F/16) row tiles): four bf16 planes [RT*16][264] (X hi/lo, Y1 hi/lo;
-// 528-B rows keep ds_read_b128 conflict-free) plus an fp32 staging tile aliased onto the X planes
-// for the coalesced [F,K] <-> [T,F*d] transposes.
+// 528-B rows keep ds_read_b128 conflict-free) plus fp32 staging tiles [F][244] aliased on top of the plane
+// pair that is dead at that point (coalesced [F,K] <-> [T,F*d] transposes and the row-tile transposes).
+#include <stdlib.h>
+
 #include "rd_common.h"
+#include "rd_k1_layout.h"
 #include "rd_rng.h"
 
 namespace rd {
 namespace {
 
+using k1::KP;
+using k1::NKC;
+using k1::TILE;
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int KP = 256;          // padded reduction length of every plane
 constexpr int LDX = KP + 8;      // bf16 elements per LDS plane row (528 B)
-constexpr int LDS_F = 244;
-constexpr int NTHR = 512;         // 8 wavefronts: wave w owns output column tiles {w, w+8}
-constexpr int NWAVE = NTHR / 64, NJ = 2;       // fp32 staging row stride (conflict-free for both access orders)
+constexpr int LDS_F = 244;       // fp32 staging row stride (conflict-free for both access orders)
+constexpr int NTHR = 512;        // 8 wavefronts: wave w owns output column tiles {w, w+8}
+constexpr int NWAVE = NTHR / 64, NJ = 2;
 
 struct FusedArgs {
   const float *src, *R_u, *b1, *b2, *ssum;
   const float *times, *tscale; const int64_t* lengths; uint8_t* mask; int d_pe;   // optional PE / mask (fwd)
-  const __bf16* wplanes;         // [layer 2][orient 2][hi/lo 2][K rows][KP]
-  float *xsave, *y1save, *z;
-  const float *dz;               // bwd
-  float *dz2save, *dz1save, *rupart;
-  int B, T, F, d, K, ldz;
+  const __bf16* wt;              // weight tiles [layer 2][orient 2][nct][NKC][hi/lo][64][8]
+  __bf16* ones;                  // bwd writes the constant bias-gradient operand tile of rd_msgpass_dw.hip here
+  __bf16 *tpX, *tpY1, *tpD1, *tpD2;   // row tiles of X, Y1 (fwd writes) and dZ1, dZ2 (bwd writes)
+  uint16_t *m1, *m2; uint8_t* mx;     // gates: Y1 > 0, Y2 > 0 (bit per element), X > 0 (byte per (f,t))
+  float* z;
+  const float* dz;               // bwd
+  float* rupart;
+  int B, T, F, K, ldz, nct, q, rem, per;
   float p_drop; uint64_t seed; const uint64_t* seed_cell;
-  unsigned long long* stamps;    // debug: per-phase clock64() of wave 0 of the first 8 workgroups
+  unsigned long long* stamps;    // debug: per-phase clock64() of every wave of the first 4 workgroups
 };
 
 #define RD_STAMP(i)                                                                              \
   do {                                                                                           \
-    if (a.stamps && blockIdx.x < 8 && threadIdx.x == 0) a.stamps[blockIdx.x * 16 + (i)] = clock64(); \
+    if (a.stamps && blockIdx.x < 4 && (threadIdx.x & 63) == 0)                                   \
+      a.stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = clock64();                    \
   } while (0)
 
-__device__ __forceinline__ const __bf16* plane(const FusedArgs& a, int layer, int orient, int part) {
-  return a.wplanes + ((size_t)((layer * 2 + orient) * 2 + part)) * a.K * KP;
+__device__ __forceinline__ const __bf16* wtiles(const FusedArgs& a, int layer, int orient) {
+  return a.wt + (size_t)((layer * 2 + orient) * a.nct) * (NKC * 2 * TILE);
+}
+
+// bulk-output stores (row tiles, z).  A write-through (sc1, inline asm) variant was measured: no gain at the kernel
+// boundary and it broke parity, so these are plain stores.
+__device__ __forceinline__ void st16(void* p, const bf16x8& v) { *reinterpret_cast<bf16x8*>(p) = v; }
+__device__ __forceinline__ void st16f(void* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st8(void* p, const bf16x4& v) { *reinterpret_cast<bf16x4*>(p) = v; }
+__device__ __forceinline__ void st2(__bf16* p, __bf16 v) { *p = v; }
+
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& h, bf16x8& l) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { h[e] = (__bf16)v[e]; l[e] = (__bf16)(v[e] - (float)h[e]); }
 }
 
 __device__ __forceinline__ void split_store4(__bf16* ph, __bf16* pl, const float (&v)[4]) {
@@ -61,75 +91,72 @@ __device__ __forceinline__ void split_store4(__bf16* ph, __bf16* pl, const float
   *reinterpret_cast<bf16x4*>(pl) = l;
 }
 
-// W [K,K] fp32 -> four bf16 planes: orient 0 rows n (k contiguous, == W), orient 1 rows k (== W^T).
+// W [K,K] fp32 -> native operand tiles, both orientations (rd_k1_layout.h).  One workgroup per (layer, orient,
+// column tile j); wave w converts reduction steps kc = w, w+4.  Every store is a contiguous kilobyte per wave.
 __global__ __launch_bounds__(256) void k_wprep(const float* __restrict__ W1, const float* __restrict__ W2,
-                                               __bf16* __restrict__ planes, int K) {
-  const int layer = blockIdx.y >> 1, orient = blockIdx.y & 1;
+                                               __bf16* __restrict__ wt, int K, int nct) {
+  const int j = blockIdx.x % nct, lo_ = blockIdx.x / nct, orient = lo_ & 1, layer = lo_ >> 1;
   const float* W = layer ? W2 : W1;
-  __bf16* ph = planes + ((size_t)((layer * 2 + orient) * 2 + 0)) * K * KP;
-  __bf16* pl = ph + (size_t)K * KP;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < K * KP; i += gridDim.x * 256) {
-    const int r = i / KP, c = i - r * KP;
-    float x = 0.f;
-    if (c < K) x = orient ? W[(size_t)c * K + r] : W[(size_t)r * K + c];
-    const __bf16 h = (__bf16)x;
-    ph[i] = h;
-    pl[i] = (__bf16)(x - (float)h);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, G = lane >> 4;
+  __bf16* base = wt + (size_t)blockIdx.x * (NKC * 2 * TILE) + lane * 8;
+  const int fr = 16 * j + c;                         // free index: n (orient 0) or k (orient 1)
+  for (int kc = wave; kc < NKC; kc += 4) {
+    const int r0 = 32 * kc + 8 * G;                  // first reduction index of this lane (multiple of 8; K % 8 == 0)
+    float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r0 < K) {
+      if (orient == 0) {
+        const float4 u = *reinterpret_cast<const float4*>(W + (size_t)fr * K + r0);
+        const float4 v = *reinterpret_cast<const float4*>(W + (size_t)fr * K + r0 + 4);
+        x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = W[(size_t)(r0 + e) * K + fr];
+      }
+    }
+    bf16x8 h, l;
+    split8(x, h, l);
+    *reinterpret_cast<bf16x8*>(base + (kc * 2 + 0) * TILE) = h;
+    *reinterpret_cast<bf16x8*>(base + (kc * 2 + 1) * TILE) = l;
   }
 }
 
-// The wave's weight panel: column tiles {w, w+8} x 256 k x hi/lo = 128 VGPRs per lane, requested
-// in one burst so a GEMM exposes ONE L2 round trip; issued a whole phase before it is consumed
-// (during the observation embedding / the previous layer's epilogue) so that trip is hidden too.
+// The wave's weight panel: column tiles {w, w+8} x 256 k x hi/lo = 128 VGPRs per lane, requested in one
+// burst of 32 contiguous 1-KB wave-loads and issued a whole phase before it is consumed.
 struct Panel {
-  bf16x8 h[NJ][KP / 32], l[NJ][KP / 32];
+  bf16x8 h[NJ][NKC], l[NJ][NKC];
 };
 
-__device__ __forceinline__ void load_panel(Panel& p, const __bf16* __restrict__ Bh,
-                                           const __bf16* __restrict__ Bl, int nct, int wave, int lane) {
+// reduction steps [KC0, KC1) of both column tiles
+template <int KC0, int KC1>
+__device__ __forceinline__ void load_panel_kc(Panel& p, const __bf16* __restrict__ wl, int nct, int wave, int lane) {
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
     const int j = wave + NWAVE * jj;
-    const size_t boff = (size_t)(16 * (j < nct ? j : 0) + (lane & 15)) * KP + 8 * (lane >> 4);
+    const __bf16* t = wl + (size_t)(j < nct ? j : 0) * (NKC * 2 * TILE) + lane * 8;
 #pragma unroll
-    for (int kc = 0; kc < KP / 32; ++kc) {
-      p.h[jj][kc] = *reinterpret_cast<const bf16x8*>(Bh + boff + kc * 32);
-      p.l[jj][kc] = *reinterpret_cast<const bf16x8*>(Bl + boff + kc * 32);
+    for (int kc = KC0; kc < KC1; ++kc) {
+      p.h[jj][kc] = *reinterpret_cast<const bf16x8*>(t + (kc * 2 + 0) * TILE);
+      p.l[jj][kc] = *reinterpret_cast<const bf16x8*>(t + (kc * 2 + 1) * TILE);
     }
   }
 }
-
-// one column tile (jj) of the panel: 16 loads per lane.  The backward kernel requests the first half right
-// after its 44 gather loads and the second once those have been consumed: s_waitcnt counts at most 63
-// outstanding operations in issue order, so "wait for my activations" is only expressible while fewer
-// than 64 younger loads are in flight.
-template <int JJ>
-__device__ __forceinline__ void load_panel_half(Panel& p, const __bf16* __restrict__ Bh,
-                                                const __bf16* __restrict__ Bl, int nct, int wave, int lane) {
-  const int j = wave + NWAVE * JJ;
-  const size_t boff = (size_t)(16 * (j < nct ? j : 0) + (lane & 15)) * KP + 8 * (lane >> 4);
-#pragma unroll
-  for (int kc = 0; kc < KP / 32; ++kc) {
-    p.h[JJ][kc] = *reinterpret_cast<const bf16x8*>(Bh + boff + kc * 32);
-    p.l[JJ][kc] = *reinterpret_cast<const bf16x8*>(Bl + boff + kc * 32);
-  }
+__device__ __forceinline__ void load_panel(Panel& p, const __bf16* __restrict__ wl, int nct, int wave, int lane) {
+  load_panel_kc<0, NKC>(p, wl, nct, wave, lane);
 }
 
 // lds_barrier() (rd_common.h): every barrier of these kernels orders LDS traffic only -- no thread reads global
 // memory that another thread of the same launch wrote, and a full __syncthreads() would drain the weight panel.
-// Keeps the first USE of a prefetched value below this point (volatile asm statements stay in program
+// pin(): keeps the first USE of a prefetched value below this point (volatile asm statements stay in program
 // order, so below the preceding lds_barrier): otherwise the scheduler folds the consumer's arithmetic up to
 // the load to save registers and waits for the data before the weight panel has even been requested.
 __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(float4& x) { asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w)); }
+__device__ __forceinline__ void pin(unsigned& x) { asm volatile("" : "+v"(x)); }
 // Split value -> hi/lo planes with ONE 4-byte LDS store per lane: the MFMA accumulator layout puts columns
 // n (even lane) and n+1 (odd lane) of a row in neighbouring lanes; the pair swaps one half through a DPP
 // quad permute (no LDS traffic), the even lane stores (hi[n], hi[n+1]) to the hi plane and the odd lane
-// (lo[n], lo[n+1]) to the lo plane.  Replaces two 2-byte stores per lane, which the epilogue stamps showed
-// to dominate (96 sub-dword stores per lane and layer).  Must be called by all 64 lanes; n = column of this lane.
-__device__ __forceinline__ void store_split_pair(__bf16* Ph, __bf16* Pl, int row, int n, int lane, float y) {
-  const __bf16 h = (__bf16)y;
-  const __bf16 l = (__bf16)(y - (float)h);
+// (lo[n], lo[n+1]) to the lo plane.  Must be called by all 64 lanes; n = column of this lane.
+__device__ __forceinline__ void store_split_pair(__bf16* Ph, __bf16* Pl, int row, int n, int lane, __bf16 h, __bf16 l) {
   const unsigned hb = __builtin_bit_cast(unsigned short, h), lb = __builtin_bit_cast(unsigned short, l);
   const bool odd = lane & 1;
   const unsigned send = odd ? hb : lb;
@@ -154,15 +181,16 @@ __device__ __forceinline__ void zero_plane_pads(__bf16* P, int rows, int prow, i
   }
 }
 
-
-// acc[jj][rt] (16x16 tiles) += A[rows rt*16.., KP] * panel^T ; A planes (hi/lo) in LDS.
-// The three split products are issued as three sweeps over independent accumulators.
-template <int RT>
-__device__ __forceinline__ void mma_panel(f32x4 (&acc)[NJ][RT], const __bf16* Ah, const __bf16* Al,
+// acc[jj][rt] (16x16 tiles) += A[rows rt*16.., 32 KC0 .. 32 KC1) * panel^T ; A planes (hi/lo) in LDS.
+// The three split products are issued as three sweeps over independent accumulators.  A product runs as two
+// halves of the reduction (KC = 0..3, 4..7): the registers of the first half are free while the second half
+// multiplies, so the NEXT layer's first half-panel streams in underneath it.
+template <int RT, int KC0, int KC1>
+__device__ __forceinline__ void mma_steps(f32x4 (&acc)[NJ][RT], const __bf16* Ah, const __bf16* Al,
                                           const Panel& p, int lane) {
   const int aoff = (lane & 15) * LDX + 8 * (lane >> 4);
 #pragma unroll
-  for (int kc = 0; kc < KP / 32; ++kc) {
+  for (int kc = KC0; kc < KC1; ++kc) {
     bf16x8 ah[RT], al[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -186,6 +214,29 @@ __device__ __forceinline__ void mma_panel(f32x4 (&acc)[NJ][RT], const __bf16* Ah
         acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.h[jj][kc], acc[jj][rt], 0, 0, 0);
   }
 }
+template <int RT>
+__device__ __forceinline__ void mma_panel(f32x4 (&acc)[NJ][RT], const __bf16* Ah, const __bf16* Al,
+                                          const Panel& p, int lane) {
+  mma_steps<RT, 0, NKC>(acc, Ah, Al, p, lane);
+}
+
+// srow[rt][r] = ssum[16 rt + 4 g + r] (0 beyond F): one 16-byte load per row tile when F % 4 == 0 puts the quad inside
+// the array, scalar loads otherwise (every VMEM instruction costs the address unit 16 cycles whatever its width)
+template <int RT>
+__device__ __forceinline__ void load_srow(float (&srow)[RT][4], const float* __restrict__ ssum, int F, int lane) {
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int row0 = rt * 16 + 4 * (lane >> 4);
+    if ((F & 3) == 0 && (reinterpret_cast<uintptr_t>(ssum) & 15) == 0) {
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 < F) q = *reinterpret_cast<const float4*>(ssum + row0);
+      srow[rt][0] = q.x; srow[rt][1] = q.y; srow[rt][2] = q.z; srow[rt][3] = q.w;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) srow[rt][r] = row0 + r < F ? ssum[row0 + r] : 0.f;
+    }
+  }
+}
 
 template <int RT>
 __device__ __forceinline__ void zero_acc(f32x4 (&acc)[NJ][RT]) {
@@ -195,6 +246,15 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[NJ][RT]) {
     for (int rt = 0; rt < RT; ++rt) acc[jj][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
+// cell index i -> (t, f) = (i / F, i % F) for i < 2^15, F <= 64: exact with one fp32 reciprocal multiply + fix-up
+// (an integer division is ~40 instructions; the embedding does four per thread)
+__device__ __forceinline__ void cell_tf(int i, int F, int& t, int& f) {
+  t = (int)((float)i * (1.0f / (float)F));
+  f = i - t * F;
+  if (f < 0) { f += F; --t; }
+  if (f >= F) { f -= F; ++t; }
+}
+
 // zero `bytes` of LDS (multiple of 16) with 16-byte stores, no index arithmetic
 __device__ __forceinline__ void zero_lds(void* p, int bytes, int tid) {
   float4* q = reinterpret_cast<float4*>(p);
@@ -202,36 +262,125 @@ __device__ __forceinline__ void zero_lds(void* p, int bytes, int tid) {
   for (int i = tid; i < bytes / 16; i += NTHR) q[i] = z;
 }
 
+// ------------------------------------------------------------------------------------------------
+// row tiles for the weight-gradient kernel (rd_k1_layout.h)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ __bf16* tp_tile(__bf16* tp, int nct, int s, int j) {
+  return tp + ((size_t)s * nct + j) * (2 * TILE);
+}
+
+// Staging-sourced: S = fp32 [F][LDS_F] tile of sample b in LDS -> row tiles.  A slot = 8 consecutive graph rows of
+// one column: read down the column (conflict-free across the 16 columns of a lane group), split, one 16-byte
+// store per part; consecutive lanes write consecutive 16-byte slots of a tile.
+__device__ __forceinline__ void tstore_stage(const float* S, __bf16* tp, const FusedArgs& a, int b, int tid) {
+  const int nct = a.nct, K = a.K;
+  const int nslot = a.q * nct * 64;
+  for (int idx = tid; idx < nslot; idx += NTHR) {
+    const int L = idx & 63, t2 = idx >> 6;
+    const int m = t2 / nct, j = t2 - m * nct;
+    const float* p = S + (32 * m + 8 * (L >> 4)) * LDS_F + 16 * j + (L & 15);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = p[e * LDS_F];
+    bf16x8 h, l;
+    split8(v, h, l);
+    __bf16* dst = tp_tile(tp, nct, b * a.q + m, j) + L * 8;
+    st16(dst, h);
+    st16(dst + TILE, l);
+  }
+  if (a.rem) {
+    const int s = a.B * a.q + b / a.per, slot = b % a.per;
+    for (int idx = tid; idx < a.rem * K; idx += NTHR) {
+      const int li = idx / K, n = idx - li * K;
+      const float x = S[(32 * a.q + li) * LDS_F + n];
+      const int r = slot * a.rem + li;
+      const __bf16 h = (__bf16)x, l = (__bf16)(x - (float)h);
+      __bf16* dst = tp_tile(tp, nct, s, n >> 4) + ((n & 15) + 16 * (r >> 3)) * 8 + (r & 7);
+      st2(dst, h); st2(dst + TILE, l);
+    }
+  }
+}
+
+// positions of a leftover tile that no sample covers: zeros, written by the workgroup whose sample sits at position 0
+__device__ __forceinline__ void tzero_uncovered(__bf16* tp, const FusedArgs& a, int b, int tid) {
+  if (a.rem == 0 || (b % a.per) != 0) return;
+  const int first = b / a.per * a.per;
+  const int nvalid = min(a.per, a.B - first);
+  const int r0 = nvalid * a.rem;
+  const int s = a.B * a.q + b / a.per;
+  const __bf16 zero = (__bf16)0.f;
+  for (int idx = tid; idx < (32 - r0) * a.K; idx += NTHR) {
+    const int rr = idx / a.K, n = idx - rr * a.K;
+    const int r = r0 + rr;
+    __bf16* dst = tp_tile(tp, a.nct, s, n >> 4) + ((n & 15) + 16 * (r >> 3)) * 8 + (r & 7);
+    st2(dst, zero); st2(dst + TILE, zero);
+  }
+}
+
+// Accumulator-sourced, main tiles: the MFMA C layout gives each lane 4 consecutive rows of one column = half a slot.
+// h/l[i] = split value at (row 16 rt + 4 g + i, column 16 j + c).  Row tiles rt >= 2 q hold leftover rows: those are
+// stored from the LDS planes after the epilogue's barrier (tstore_leftover_planes), two store instructions per wave
+// instead of sixteen mostly-masked ones.
+__device__ __forceinline__ void tstore_acc(__bf16* tp, const FusedArgs& a, int b, int j, int rt, int lane,
+                                           const __bf16 (&h)[4], const __bf16 (&l)[4]) {
+  const int c = lane & 15, g = lane >> 4;
+  if (rt < 2 * a.q) {                                    // uniform: this row tile is half of a main tile
+    bf16x4 hv, lv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { hv[i] = h[i]; lv[i] = l[i]; }
+    __bf16* dst = tp_tile(tp, a.nct, b * a.q + (rt >> 1), j) + (c + 16 * (2 * (rt & 1) + (g >> 1))) * 8 + 4 * (g & 1);
+    st8(dst, hv);
+    st8(dst + TILE, lv);
+  }
+}
+// leftover rows (32 q + li, li < rem) of a tensor whose split planes [row][LDX] are complete in LDS
+__device__ __forceinline__ void tstore_leftover_planes(const __bf16* Ph, const __bf16* Pl, __bf16* tp, const FusedArgs& a,
+                                                       int b, int tid) {
+  if (a.rem == 0) return;
+  const int s = a.B * a.q + b / a.per, slot = b % a.per;
+  for (int idx = tid; idx < a.rem * a.K; idx += NTHR) {
+    const int li = idx / a.K, n = idx - li * a.K;
+    const int r = slot * a.rem + li;
+    __bf16* dst = tp_tile(tp, a.nct, s, n >> 4) + ((n & 15) + 16 * (r >> 3)) * 8 + (r & 7);
+    st2(dst, Ph[(32 * a.q + li) * LDX + n]);
+    st2(dst + TILE, Pl[(32 * a.q + li) * LDX + n]);
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+// Schedule.  The 8 waves form two groups (waves 0-3 / 4-7; wave w and w+4 share a SIMD).  Wherever a phase consists
+// of a matrix-core part and a VALU / LDS / memory part, the two groups run the parts in OPPOSITE order, so each
+// SIMD's matrix pipe works for one wave while its partner wave splits, stores or issues loads (measured: a
+// GEMM of the two waves of a SIMD is pipe-bound, 2 x 144 MFMA x 16 cycles; a wave blocks while it issues a
+// 32-load weight panel, ~2 k cycles for half the workgroup).
 template <int RT>
 __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int ROWS = RT * 16;
+  constexpr bool ALIAS = RT > 3;                         // F > 48: the fp32 copy of X has to share the Y planes' space
+  constexpr size_t PLANES = (size_t)4 * ROWS * LDX * sizeof(__bf16);
+  constexpr size_t XS_BYTES = ALIAS ? 0 : (size_t)ROWS * LDS_F * sizeof(float);
   __bf16* Xh = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* Xl = Xh + ROWS * LDX;
   __bf16* Yh = Xl + ROWS * LDX;
   __bf16* Yl = Yh + ROWS * LDX;
-  float* Ys = reinterpret_cast<float*>(smem_raw);        // fp32 [F][LDS_F] staging, aliases X planes
+  float* Ys = reinterpret_cast<float*>(smem_raw);        // fp32 [F][LDS_F] staging of Y2, aliases the X planes
+  float* Xs = ALIAS ? reinterpret_cast<float*>(Yh) : reinterpret_cast<float*>(smem_raw + PLANES);   // fp32 copy of X
+  uint16_t* M1 = reinterpret_cast<uint16_t*>(smem_raw + PLANES + XS_BYTES);                          // [ROWS][16]
+  uint16_t* M2 = M1 + ROWS * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool grpB = __builtin_amdgcn_readfirstlane(wave) >= NWAVE / 2;   // scalar: the group branches are real branches
   const int b = blockIdx.x;
-  const int T = a.T, F = a.F, d = a.d, K = a.K, B = a.B;
-  const int nct = K / 16;
+  const int T = a.T, F = a.F, K = a.K, B = a.B;
+  const int nct = a.nct;
   const float inv_keep = 1.0f / (1.0f - a.p_drop);
-  (void)d;
 
   RD_STAMP(0);
   Panel pw;
   float srow[RT][4];                                     // aggregate coefficient of this lane's rows
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = rt * 16 + 4 * (lane >> 4) + r;
-      srow[rt][r] = row < F ? a.ssum[row] : 0.f;
-    }
+  load_srow<RT>(srow, a.ssum, F, lane);
   float bias1[NJ], bias2[NJ];                            // both layers' biases: ahead of the weight stream
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
@@ -239,20 +388,20 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
     bias1[jj] = a.b1[n]; bias2[jj] = a.b2[n];
   }
 
-  // ---- observation embedding -> X planes (+ fp32 copy for the weight-gradient pass) ------------
-  // thread -> (f, t) with t fastest: LDS / xsave writes are contiguous; the strided src reads hit each
-  // 128-B line F times within the workgroup (L1).  The loads of the first batch (the only one when
-  // F*T <= 2048) are requested BEFORE the layer-1 weight panel: loads return in issue order, and the
-  // embedding is on the critical path while the panel is not needed before the first MFMA.
+  // ---- observation embedding -> X planes (+ fp32 copy for the row-tile transpose, + gate byte) ----
+  // thread -> cell (t, f) with f fastest: a wave-load of src covers two or three 136-byte row segments (with t
+  // fastest it touched 64 cache lines, and the 64 such loads of the workgroup cost more tag look-ups than the
+  // whole weight panel).  LDS: the 16-byte fp32 stores are conflict-free at stride 244, the 8-byte plane
+  // stores 2-way.
   constexpr int UNR = 4;
   const int total = F * T;
   uint64_t seed_eff = a.seed;
-  float v[UNR]; int fi[UNR], ti[UNR]; float4 ru[UNR], uu[UNR];
+  float v[UNR]; int fi[UNR], ti[UNR]; float4 ru[UNR]; unsigned km[UNR];     // km: keep bits of the 4 channels
   auto embed_issue = [&](int base) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int i = min(base + u * NTHR, total - 1);          // clamped duplicates rewrite the same cell
-      fi[u] = i / T; ti[u] = i - fi[u] * T;
+      cell_tf(i, F, ti[u], fi[u]);
       v[u] = a.src[((size_t)ti[u] * B + b) * (2 * F) + fi[u]];
       ru[u] = *reinterpret_cast<const float4*>(a.R_u + fi[u] * 4);
     }
@@ -264,51 +413,72 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
       pin(v[u]); pin(ru[u]);
       float x[4] = {fmaxf(v[u] * ru[u].x, 0.f), fmaxf(v[u] * ru[u].y, 0.f), fmaxf(v[u] * ru[u].z, 0.f), fmaxf(v[u] * ru[u].w, 0.f)};
       if (a.p_drop > 0.f) {                                   // wave-uniform
-        x[0] = uu[u].x >= a.p_drop ? x[0] * inv_keep : 0.f; x[1] = uu[u].y >= a.p_drop ? x[1] * inv_keep : 0.f;
-        x[2] = uu[u].z >= a.p_drop ? x[2] * inv_keep : 0.f; x[3] = uu[u].w >= a.p_drop ? x[3] * inv_keep : 0.f;
+        x[0] = (km[u] & 1) ? x[0] * inv_keep : 0.f; x[1] = (km[u] & 2) ? x[1] * inv_keep : 0.f;
+        x[2] = (km[u] & 4) ? x[2] * inv_keep : 0.f; x[3] = (km[u] & 8) ? x[3] * inv_keep : 0.f;
       }
       split_store4(Xh + f * LDX + 4 * t, Xl + f * LDX + 4 * t, x);
-      *reinterpret_cast<float4*>(a.xsave + ((size_t)b * F + f) * K + 4 * t) = make_float4(x[0], x[1], x[2], x[3]);
+      *reinterpret_cast<float4*>(Xs + f * LDS_F + 4 * t) = make_float4(x[0], x[1], x[2], x[3]);
+      a.mx[(size_t)b * total + t * F + f] =                   // [b][t][f]: consecutive lanes, consecutive bytes
+          (uint8_t)((x[0] > 0.f ? 1 : 0) | (x[1] > 0.f ? 2 : 0) | (x[2] > 0.f ? 4 : 0) | (x[3] > 0.f ? 8 : 0));
     }
   };
-  // dropout masks: one Philox call = the 4 channel masks of a (t, f) cell; ~1 k cycles of integer multiplies per
-  // call and wave, evaluated while the loads above are in flight (they do not depend on the loaded data)
+  // dropout masks: one Philox call = the 4 channel masks of a (t, f) cell; ~0.5 k cycles of integer multiplies per
+  // call and wave, no memory traffic
   auto embed_masks = [&]() {
     if (a.p_drop > 0.f) {
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
-        uu[u] = uniform4(seed_eff, SITE_OBS_EMBED, ((uint64_t)ti[u] * B + b) * F + fi[u]);
-        pin(uu[u]);                                           // materialised here, above the barrier
+        const float4 q4 = uniform4(seed_eff, SITE_OBS_EMBED, ((uint64_t)ti[u] * B + b) * F + fi[u]);
+        km[u] = (q4.x >= a.p_drop ? 1u : 0u) | (q4.y >= a.p_drop ? 2u : 0u) | (q4.z >= a.p_drop ? 4u : 0u) | (q4.w >= a.p_drop ? 8u : 0u);
+        pin(km[u]);
       }
     }
   };
   embed_issue(tid);
-  load_panel(pw, plane(a, 0, 0, 0), plane(a, 0, 0, 1), nct, wave, lane);   // 32 loads per lane, behind the 24 above
-  // device seed cell (rd_set_seed_cell) on the scalar path: a vector load here would sit behind the panel
+  // device seed cell (rd_set_seed_cell) on the scalar path: a vector load would queue behind the panel
   if (a.seed_cell) seed_eff += load_uniform_u64(a.seed_cell);
-  RD_STAMP(10);
-  embed_masks();
-  RD_STAMP(11);
-  // pads only: X rows >= F and columns >= K (the embedding writes the rest); Y columns >= K (its pad rows are
-  // written as zeros by the layer-1 epilogue)
+  // pads only: X rows >= F and columns >= K (the embedding writes the rest)
   zero_plane_pads(Xh, ROWS, F, F, K, tid); zero_plane_pads(Xl, ROWS, F, F, K, tid);
-  zero_plane_pads(Yh, ROWS, ROWS, ROWS, K, tid); zero_plane_pads(Yl, ROWS, ROWS, ROWS, K, tid);
-  RD_STAMP(12);
-  lds_barrier();
-  RD_STAMP(13);
-  embed_consume();
+  if (!ALIAS) { zero_plane_pads(Yh, ROWS, ROWS, ROWS, K, tid); zero_plane_pads(Yl, ROWS, ROWS, ROWS, K, tid); }
+  // group B does its arithmetic BEFORE requesting its weight panel, group A after: one-sided uniform branches around
+  // a single panel load (an if/else with the panel in both arms makes the allocator spill the panel)
+  if (grpB) { embed_masks(); embed_consume(); }
+  RD_STAMP(10);
+  load_panel(pw, wtiles(a, 0, 0), nct, wave, lane);
+  RD_STAMP(11);
+  if (!grpB) { embed_masks(); embed_consume(); }
   for (int base = tid + NTHR * UNR; base < total; base += NTHR * UNR) { embed_issue(base); embed_masks(); embed_consume(); }
   RD_STAMP(1);
   lds_barrier();
   RD_STAMP(2);
 
-  // ---- layer 1: Y1 = relu(X W1^T + b1) * ssum ----------------------------------------------------
+  // ---- layer 1: Y1 = relu(X W1^T + b1) * ssum;  X leaves as row tiles for dW1 (reads the fp32 copy) --------
   f32x4 acc[NJ][RT];
   zero_acc<RT>(acc);
-  mma_panel<RT>(acc, Xh, Xl, pw, lane);
+  if (grpB) {                                                // group B transposes while group A multiplies ...
+    tstore_stage(Xs, a.tpX, a, b, tid);
+    tzero_uncovered(a.tpX, a, b, tid);
+    tzero_uncovered(a.tpY1, a, b, tid);
+  }
+  RD_STAMP(13);
+  mma_steps<RT, 0, NKC / 2>(acc, Xh, Xl, pw, lane);
+  __builtin_amdgcn_sched_barrier(0);                                   // the scheduler otherwise sinks these loads below the second half
+  load_panel_kc<0, NKC / 2>(pw, wtiles(a, 1, 0), nct, wave, lane);     // layer-2 weights, first half of the reduction
+  __builtin_amdgcn_sched_barrier(0);
+  mma_steps<RT, NKC / 2, NKC>(acc, Xh, Xl, pw, lane);
   RD_STAMP(3);
-  // layer-2 weights start streaming while the epilogue below runs
-  load_panel(pw, plane(a, 1, 0, 0), plane(a, 1, 0, 1), nct, wave, lane);
+  load_panel_kc<NKC / 2, NKC>(pw, wtiles(a, 1, 0), nct, wave, lane);   // second half
+  RD_STAMP(12);
+  if (!grpB) {                                               // ... and the other way round
+    tstore_stage(Xs, a.tpX, a, b, tid);
+    tzero_uncovered(a.tpX, a, b, tid);
+    tzero_uncovered(a.tpY1, a, b, tid);
+  }
+  if (ALIAS) {                                               // the fp32 copy of X lives in the Y planes: everybody must be done with it
+    lds_barrier();
+    zero_plane_pads(Yh, ROWS, ROWS, ROWS, K, tid); zero_plane_pads(Yl, ROWS, ROWS, ROWS, K, tid);
+  }
+  RD_STAMP(14);
   // branch-free epilogue: pad rows carry srow == 0 and land in the planes' pad rows
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
@@ -317,31 +487,28 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
       const int n = 16 * j + (lane & 15);
       const float bias = bias1[jj];
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
+      for (int rt = 0; rt < RT; ++rt) {
+        __bf16 hh[4], ll[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = rt * 16 + 4 * (lane >> 4) + r;
           const float y = fmaxf(acc[jj][rt][r] + bias, 0.f) * srow[rt][r];
-          store_split_pair(Yh, Yl, row, n, lane, y);
+          hh[r] = (__bf16)y; ll[r] = (__bf16)(y - (float)hh[r]);
+          store_split_pair(Yh, Yl, row, n, lane, hh[r], ll[r]);
+          const unsigned long long bal = __ballot(y > 0.f);
+          if ((lane & 15) == 0) M1[row * 16 + j] = (uint16_t)(bal >> (16 * (lane >> 4)));
         }
+        tstore_acc(a.tpY1, a, b, j, rt, lane, hh, ll);
+      }
     }
   }
   RD_STAMP(4);
   lds_barrier();
   RD_STAMP(5);
-  // Y1 for the backward pass, written row-contiguously from the planes (hi + lo is exactly the
-  // value the split-bf16 products of the backward pass would reconstruct anyway)
-  {
-    const int kq = K / 4;
-    for (int i = tid; i < F * kq; i += NTHR) {
-      const int f = i / kq, k = 4 * (i - f * kq);
-      const bf16x4 h = *reinterpret_cast<const bf16x4*>(Yh + f * LDX + k);
-      const bf16x4 l = *reinterpret_cast<const bf16x4*>(Yl + f * LDX + k);
-      *reinterpret_cast<float4*>(a.y1save + ((size_t)b * F + f) * K + k) =
-          make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2],
-                      (float)h[3] + (float)l[3]);
-    }
-  }
+  // gate bits of layer 1 -> global (rows < F: 32 bytes each); leftover rows of Y1 -> row tiles
+  for (int i = tid; i < 2 * F; i += NTHR)
+    reinterpret_cast<uint4*>(a.m1 + (size_t)b * F * 16)[i] = reinterpret_cast<const uint4*>(M1)[i];
+  tstore_leftover_planes(Yh, Yl, a.tpY1, a, b, tid);
 
   // ---- layer 2: Y2 = relu(Y1 W2^T + b2) * ssum -> fp32 staging -----------------------------------
   zero_acc<RT>(acc);
@@ -358,30 +525,30 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = rt * 16 + 4 * (lane >> 4) + r;      // rows >= F land in the staging tile's slack
-          Ys[row * LDS_F + n] = fmaxf(acc[jj][rt][r] + bias, 0.f) * srow[rt][r];
+          const float y = fmaxf(acc[jj][rt][r] + bias, 0.f) * srow[rt][r];
+          Ys[row * LDS_F + n] = y;
+          const unsigned long long bal = __ballot(y > 0.f);
+          if ((lane & 15) == 0) M2[row * 16 + j] = (uint16_t)(bal >> (16 * (lane >> 4)));
         }
     }
   }
   RD_STAMP(7);
   lds_barrier();
   RD_STAMP(8);
-  // ---- [F, T*d] -> z[t, b, f*d + c]: consecutive threads write consecutive addresses; the thread's
-  // (f, c) is fixed and t advances by the number of rows the block covers (no divisions in the loop)
-  {
+  for (int i = tid; i < 2 * F; i += NTHR)
+    reinterpret_cast<uint4*>(a.m2 + (size_t)b * F * 16)[i] = reinterpret_cast<const uint4*>(M2)[i];
+  // ---- [F, T*d] -> z[t, b, f*d + c]: thread -> (t, f) with f fastest moves the 4 channels of a cell as one 16-byte
+  // LDS read (conflict-free at stride 244) and one 16-byte store; consecutive lanes write consecutive addresses
+  if ((a.ldz & 3) == 0) {
+    for (int i = tid; i < total; i += NTHR) {
+      const int t = i / F, f = i - t * F;
+      st16f(a.z + ((size_t)t * B + b) * a.ldz + 4 * f, *reinterpret_cast<const float4*>(Ys + f * LDS_F + 4 * t));
+    }
+  } else {
     const int Fd = F * 4;
-    const int tpb = NTHR / Fd;                           // time steps covered per pass
-    const int t0 = tid / Fd, fc = tid - t0 * Fd;
-    if (tpb > 0) {
-      if (t0 < tpb) {
-        const int f = fc >> 2, c = fc & 3;
-        for (int t = t0; t < T; t += tpb)
-          a.z[((size_t)t * B + b) * a.ldz + fc] = Ys[f * LDS_F + t * 4 + c];
-      }
-    } else {
-      for (int i = tid; i < T * Fd; i += NTHR) {
-        const int t = i / Fd, q = i - t * Fd;
-        a.z[((size_t)t * B + b) * a.ldz + q] = Ys[(q >> 2) * LDS_F + t * 4 + (q & 3)];
-      }
+    for (int i = tid; i < T * Fd; i += NTHR) {
+      const int t = i / Fd, q = i - t * Fd;
+      a.z[((size_t)t * B + b) * a.ldz + q] = Ys[(q >> 2) * LDS_F + t * 4 + (q & 3)];
     }
   }
   // ---- positional encoding + padding mask of this sample (code/models_rd.py:28-38,298-299) ----
@@ -401,164 +568,174 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward (activation side): dZ2 -> dZ1 -> dX -> per-sample dR_u partial.  The weight gradients
-// dW_l = dZ_l^T In_l reduce over all B*F rows and run as split-K GEMMs on the saved dZ tensors.
+// backward (activation side): dZ2 -> dZ1 -> dX -> per-sample dR_u partial; dZ2 and dZ1 leave as row tiles.
+// The weight gradients dW_l = dZ_l^T In_l reduce over all B*F rows: rd_msgpass_dw.hip.
+// Same two-group schedule as the forward kernel.
 // ------------------------------------------------------------------------------------------------
 template <int RT>
 __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int ROWS = RT * 16;
+  constexpr bool ALIAS = RT > 3;
+  constexpr size_t PLANES = (size_t)4 * ROWS * LDX * sizeof(__bf16);
+  constexpr size_t ST_BYTES = ALIAS ? 0 : (size_t)ROWS * LDS_F * sizeof(float);
   __bf16* Dh = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* Dl = Dh + ROWS * LDX;
   __bf16* Eh = Dl + ROWS * LDX;
   __bf16* El = Eh + ROWS * LDX;
-  float* St = reinterpret_cast<float*>(Eh);              // fp32 [ROWS][LDS_F] staging, aliases the E planes
+  float* St = ALIAS ? reinterpret_cast<float*>(Eh) : reinterpret_cast<float*>(smem_raw + PLANES);   // fp32 [F][LDS_F]: dZ2
   float* Sx = reinterpret_cast<float*>(Dh);              // second staging tile (dX), aliases the D planes
-  unsigned char* Mk = smem_raw + (size_t)4 * ROWS * LDX * sizeof(__bf16);   // [ROWS][KP] bytes: Y1 > 0
+  uint16_t* M1 = reinterpret_cast<uint16_t*>(smem_raw + PLANES + ST_BYTES);   // [ROWS][16]: Y1 > 0
+  uint16_t* M2 = M1 + ROWS * 16;                                               // [ROWS][16]: Y2 > 0
+  float* Ss = reinterpret_cast<float*>(M2 + ROWS * 16);                        // [ROWS]: ssum
+  float* Rp = reinterpret_cast<float*>(Eh);              // dR_u partial sums [groups][F*4], aliases the E planes (dead by then)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool grpB = __builtin_amdgcn_readfirstlane(wave) >= NWAVE / 2;   // scalar: the group branches are real branches
   const int b = blockIdx.x;
   const int T = a.T, F = a.F, K = a.K, B = a.B;
-  const int nct = K / 16;
+  const int nct = a.nct;
   const int Fd = F * 4;
   const int kq = K / 4;
 
   RD_STAMP(0);
+  if (b == 0 && tid < 192) {                                 // constant operand tiles [ones][zeros][zeros]: column 0 of the 16 is one
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (tid < 64 && (tid & 15) == 0) ? (__bf16)1.f : (__bf16)0.f;
+    *reinterpret_cast<bf16x8*>(a.ones + tid * 8) = o;
+  }
   Panel pw;
   float srow[RT][4];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = rt * 16 + 4 * (lane >> 4) + r;
-      srow[rt][r] = row < F ? a.ssum[row] : 0.f;
-    }
+  load_srow<RT>(srow, a.ssum, F, lane);
 
-  // ---- dZ2 = dz * ssum * (z > 0), read coalesced in [t, f*d+c] order, transposed through LDS; and the
-  // ReLU gate of layer 1 as bytes from the saved Y1.  All of a thread's loads (<= 44) are requested in
-  // one burst BEFORE the W2^T panel (loads return in issue order), then half the panel; the other half
-  // follows once the gather has been consumed.
-  const int tpb = NTHR / Fd;                                // >= 2 (F <= 64)
-  const int t0 = tid / Fd, fc = tid - t0 * Fd;
-  const bool gact = t0 < tpb;
-  const int gf = fc >> 2, gc = fc & 3;
-  constexpr int GU = 20;
-  float zz[GU], dd[GU];
-  auto gather_issue = [&](int tb) {
+  // ---- dZ2 = dz * ssum * (Y2 > 0), dz read coalesced in [t, f*d+c] order and transposed through LDS; the gate
+  // bits of both layers come from the forward pass (2 x 32 bytes per graph row).
+  // thread -> cell (t, f), f fastest: one 16-byte load per cell (the 4 channels), one 16-byte LDS store
+  constexpr int GU = 4;
+  const int total = F * T;
+  const bool vec4 = (a.ldz & 3) == 0;
+  float4 dd[GU]; int gt[GU], gfi[GU];
+  auto gather_issue = [&](int base) {
 #pragma unroll
     for (int u = 0; u < GU; ++u) {
-      const int t = min(tb + u * tpb, T - 1);                   // clamped duplicates are not stored
-      const size_t zi = ((size_t)t * B + b) * a.ldz + fc;
-      zz[u] = a.z[zi]; dd[u] = a.dz[zi];
+      const int i = min(base + u * NTHR, total - 1);            // clamped duplicates rewrite the same cell
+      cell_tf(i, F, gt[u], gfi[u]);
+      const float* p = a.dz + ((size_t)gt[u] * B + b) * a.ldz + 4 * gfi[u];
+      if (vec4) dd[u] = *reinterpret_cast<const float4*>(p);
+      else dd[u] = make_float4(p[0], p[1], p[2], p[3]);
     }
   };
-  auto gather_consume = [&](int tb, float sf) {
+  auto gather_consume = [&]() {
 #pragma unroll
     for (int u = 0; u < GU; ++u) {
-      const int t = tb + u * tpb;
-      pin(zz[u]); pin(dd[u]);
-      if (t < T) St[gf * LDS_F + t * 4 + gc] = (zz[u] > 0.f) ? dd[u] * sf : 0.f;
+      pin(dd[u]);
+      const int f = gfi[u], k = 4 * gt[u];
+      const float sf = Ss[f];
+      const unsigned bits = (unsigned)M2[f * 16 + (k >> 4)] >> (k & 15);     // 4 consecutive gate bits (k % 4 == 0)
+      *reinterpret_cast<float4*>(St + f * LDS_F + k) =
+          make_float4((bits & 1) ? dd[u].x * sf : 0.f, (bits & 2) ? dd[u].y * sf : 0.f, (bits & 4) ? dd[u].z * sf : 0.f,
+                      (bits & 8) ? dd[u].w * sf : 0.f);
     }
   };
-  constexpr int YU = 4;
-  float4 yv[YU];
-  const int ncell = F * kq;
-  auto gate_issue = [&](int base) {
-#pragma unroll
-    for (int u = 0; u < YU; ++u) {
-      const int i = min(base + u * NTHR, ncell - 1);
-      const int f = i / kq, k = 4 * (i - f * kq);
-      yv[u] = *reinterpret_cast<const float4*>(a.y1save + ((size_t)b * F + f) * K + k);
-    }
-  };
-  auto gate_consume = [&](int base) {
-#pragma unroll
-    for (int u = 0; u < YU; ++u) {
-      const int i = base + u * NTHR;
-      pin(yv[u]);
-      if (i < ncell) {
-        const int f = i / kq, k = 4 * (i - f * kq);
-        *reinterpret_cast<uchar4*>(Mk + f * KP + k) = make_uchar4(yv[u].x > 0.f, yv[u].y > 0.f, yv[u].z > 0.f, yv[u].w > 0.f);
-      }
-    }
-  };
-  float sf = 0.f;
-  if (gact) { sf = a.ssum[gf]; gather_issue(t0); }
-  gate_issue(tid);
-  load_panel_half<0>(pw, plane(a, 1, 1, 0), plane(a, 1, 1, 1), nct, wave, lane);
+  uint4 mw = make_uint4(0, 0, 0, 0);
+  if (tid < 4 * F)                                           // threads [0,2F): M1 rows, [2F,4F): M2 rows
+    mw = tid < 2 * F ? reinterpret_cast<const uint4*>(a.m1 + (size_t)b * F * 16)[tid]
+                     : reinterpret_cast<const uint4*>(a.m2 + (size_t)b * F * 16)[tid - 2 * F];
+  float sfv = 0.f;
+  if (tid >= NTHR - 64 && tid - (NTHR - 64) < F) sfv = a.ssum[tid - (NTHR - 64)];      // last wave: ssum -> LDS
+  gather_issue(tid);
+  load_panel(pw, wtiles(a, 1, 1), nct, wave, lane);          // W2^T panel queues behind the gather
   RD_STAMP(10);
-  zero_lds(smem_raw, 4 * ROWS * LDX * (int)sizeof(__bf16) + ROWS * KP, tid);
+  // D planes: zero the pads (rows >= F, columns >= K); the staging tile is fully written for rows < F, columns < K
+  zero_plane_pads(Dh, ROWS, F, F, K, tid); zero_plane_pads(Dl, ROWS, F, F, K, tid);
+  if (!ALIAS) { zero_plane_pads(Eh, ROWS, ROWS, ROWS, K, tid); zero_plane_pads(El, ROWS, ROWS, ROWS, K, tid); }
+  if (tid < 4 * F) {
+    pin(mw.x); pin(mw.y); pin(mw.z); pin(mw.w);
+    if (tid < 2 * F) reinterpret_cast<uint4*>(M1)[tid] = mw;
+    else reinterpret_cast<uint4*>(M2)[tid - 2 * F] = mw;
+  }
+  if (tid >= NTHR - 64 && tid - (NTHR - 64) < F) { pin(sfv); Ss[tid - (NTHR - 64)] = sfv; }
   RD_STAMP(11);
   lds_barrier();
   RD_STAMP(12);
-  if (gact) {
-    gather_consume(t0, sf);
-    for (int tb = t0 + GU * tpb; tb < T; tb += GU * tpb) { gather_issue(tb); gather_consume(tb, sf); }
-  }
+  gather_consume();
+  for (int base = tid + GU * NTHR; base < total; base += GU * NTHR) { gather_issue(base); gather_consume(); }
   RD_STAMP(13);
-  gate_consume(tid);
-  for (int base = tid + YU * NTHR; base < ncell; base += YU * NTHR) { gate_issue(base); gate_consume(base); }
-  load_panel_half<1>(pw, plane(a, 1, 1, 0), plane(a, 1, 1, 1), nct, wave, lane);
-  RD_STAMP(1);
   lds_barrier();
-  RD_STAMP(2);
+  RD_STAMP(1);
+  // staging -> D planes (row-major, the A operand of the next product)
   for (int i = tid; i < F * kq; i += NTHR) {
     const int f = i / kq, k = 4 * (i - f * kq);
     const float4 v = *reinterpret_cast<const float4*>(St + f * LDS_F + k);
     const float x[4] = {v.x, v.y, v.z, v.w};
     split_store4(Dh + f * LDX + k, Dl + f * LDX + k, x);
-    *reinterpret_cast<float4*>(a.dz2save + ((size_t)b * F + f) * K + k) = v;
   }
+  RD_STAMP(2);
   lds_barrier();
-  zero_lds(Eh, 2 * ROWS * LDX * (int)sizeof(__bf16), tid);   // staging (aliased) is dead: clear the E planes
   RD_STAMP(3);
-  lds_barrier();
 
-  // ---- dZ1 = (dZ2 W2) * ssum * (Y1 > 0) ----------------------------------------------------------
-  f32x4 acc[NJ][RT];
-  zero_acc<RT>(acc);
-  mma_panel<RT>(acc, Dh, Dl, pw, lane);
-  RD_STAMP(4);
-  load_panel(pw, plane(a, 0, 1, 0), plane(a, 0, 1, 1), nct, wave, lane);   // W1^T streams during the epilogue
-  // inputs of the dR_u pass (independent of both products) ride behind the weight stream
+  // ---- dZ1 = (dZ2 W2) * ssum * (Y1 > 0); dZ2 leaves as row tiles for dW2 (reads the staging tile) ---------
+  // inputs of the dR_u pass: thread -> (time group tg, sensor f), f fastest (coalesced); its cells are t = tg, tg+TG, ...
+  const int TG = NTHR / F;                                   // >= 8
+  const int rtg = tid / F, rf = tid - rtg * F;
+  const bool ract = rtg < TG;
   constexpr int XU = 4;
-  const int ncells = F * T;
-  float4 xs[XU]; float svv[XU];
-  auto ru_issue = [&](int base) {
+  unsigned xb[XU]; float svv[XU];
+  auto ru_issue = [&](int tb) {
 #pragma unroll
     for (int u = 0; u < XU; ++u) {
-      const int i = min(base + u * NTHR, ncells - 1);
-      const int f = i / T, t = i - f * T;
-      xs[u] = *reinterpret_cast<const float4*>(a.xsave + ((size_t)b * F + f) * K + 4 * t);
-      svv[u] = a.src[((size_t)t * B + b) * (2 * F) + f];
+      const int t = min(tb + u * TG, T - 1);
+      xb[u] = a.mx[((size_t)b * T + t) * F + rf];
+      svv[u] = a.src[((size_t)t * B + b) * (2 * F) + rf];
     }
   };
-  ru_issue(tid);
+  f32x4 acc[NJ][RT];
+  zero_acc<RT>(acc);
+  if (grpB) {
+    tstore_stage(St, a.tpD2, a, b, tid);
+    tzero_uncovered(a.tpD2, a, b, tid);
+    tzero_uncovered(a.tpD1, a, b, tid);
+  }
+  mma_steps<RT, 0, NKC / 2>(acc, Dh, Dl, pw, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  load_panel_kc<0, NKC / 2>(pw, wtiles(a, 0, 1), nct, wave, lane);     // W1^T, first half of the reduction
+  __builtin_amdgcn_sched_barrier(0);
+  mma_steps<RT, NKC / 2, NKC>(acc, Dh, Dl, pw, lane);
+  RD_STAMP(4);
+  load_panel_kc<NKC / 2, NKC>(pw, wtiles(a, 0, 1), nct, wave, lane);
+  if (ract) ru_issue(rtg);
+  RD_STAMP(14);
+  if (!grpB) {
+    tstore_stage(St, a.tpD2, a, b, tid);
+    tzero_uncovered(a.tpD2, a, b, tid);
+    tzero_uncovered(a.tpD1, a, b, tid);
+  }
+  if (ALIAS) lds_barrier();                                    // staging tile lives in the E planes: everybody must be done with it
+  if (ALIAS) { zero_plane_pads(Eh, ROWS, ROWS, ROWS, K, tid); zero_plane_pads(El, ROWS, ROWS, ROWS, K, tid); }
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
     const int j = wave + NWAVE * jj;
     if (j < nct) {                                              // wave-uniform; body is branch-free
       const int n = 16 * j + (lane & 15);
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
+      for (int rt = 0; rt < RT; ++rt) {
+        __bf16 hh[4], ll[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = rt * 16 + 4 * (lane >> 4) + r;      // pad rows: srow == 0 and gate == 0
-          const float g = Mk[row * KP + n] ? acc[jj][rt][r] * srow[rt][r] : 0.f;
-          store_split_pair(Eh, El, row, n, lane, g);
+          const int row = rt * 16 + 4 * (lane >> 4) + r;      // pad rows: srow == 0
+          const bool open = (M1[row * 16 + j] >> (lane & 15)) & 1;
+          const float g = open ? acc[jj][rt][r] * srow[rt][r] : 0.f;
+          hh[r] = (__bf16)g; ll[r] = (__bf16)(g - (float)hh[r]);
+          store_split_pair(Eh, El, row, n, lane, hh[r], ll[r]);
         }
+        tstore_acc(a.tpD1, a, b, j, rt, lane, hh, ll);
+      }
     }
   }
   RD_STAMP(5);
   lds_barrier();
-  // dZ1 for the weight-gradient pass, row-contiguous from the planes
-  for (int i = tid; i < F * kq; i += NTHR) {
-    const int f = i / kq, k = 4 * (i - f * kq);
-    const bf16x4 h = *reinterpret_cast<const bf16x4*>(Eh + f * LDX + k);
-    const bf16x4 l = *reinterpret_cast<const bf16x4*>(El + f * LDX + k);
-    *reinterpret_cast<float4*>(a.dz1save + ((size_t)b * F + f) * K + k) =
-        make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2],
-                    (float)h[3] + (float)l[3]);
-  }
+  RD_STAMP(15);
+  tstore_leftover_planes(Eh, El, a.tpD1, a, b, tid);
 
   // ---- dX = dZ1 W1 -> fp32 staging (the D planes are dead) -------------------------------------
   zero_acc<RT>(acc);
@@ -578,32 +755,32 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   RD_STAMP(7);
   lds_barrier();
   // ---- dR_u[f*4+c] = sum_t dX[f, 4t+c] * (X > 0) * src[t,b,f] * keep -----------------------------
-  // pass 1 (thread per (f,t) cell, in place): P = dX * gate * src * keep
+  // pass 1: thread (tg, f) sums its time steps (fixed order) into Rp[tg][f*4 + c]
   const float keep = 1.0f / (1.0f - a.p_drop);
-  auto ru_consume = [&](int base) {
+  if (ract) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int tb = rtg; tb < T; tb += XU * TG) {
+      if (tb != rtg) ru_issue(tb);
 #pragma unroll
-    for (int u = 0; u < XU; ++u) {
-      const int i = base + u * NTHR;
-      pin(xs[u]); pin(svv[u]);
-      if (i < ncells) {
-        const int f = i / T, t = i - f * T;
-        const float sv = svv[u] * keep;
-        float4 dx = *reinterpret_cast<float4*>(Sx + f * LDS_F + 4 * t);
-        dx.x = xs[u].x > 0.f ? dx.x * sv : 0.f; dx.y = xs[u].y > 0.f ? dx.y * sv : 0.f;
-        dx.z = xs[u].z > 0.f ? dx.z * sv : 0.f; dx.w = xs[u].w > 0.f ? dx.w * sv : 0.f;
-        *reinterpret_cast<float4*>(Sx + f * LDS_F + 4 * t) = dx;
+      for (int u = 0; u < XU; ++u) {
+        const int t = tb + u * TG;
+        pin(xb[u]); pin(svv[u]);
+        if (t < T) {
+          const float sv = svv[u] * keep;
+          const float4 dx = *reinterpret_cast<const float4*>(Sx + rf * LDS_F + 4 * t);
+          s.x += (xb[u] & 1) ? dx.x * sv : 0.f; s.y += (xb[u] & 2) ? dx.y * sv : 0.f;
+          s.z += (xb[u] & 4) ? dx.z * sv : 0.f; s.w += (xb[u] & 8) ? dx.w * sv : 0.f;
+        }
       }
     }
-  };
-  ru_consume(tid);
-  for (int base = tid + XU * NTHR; base < ncells; base += XU * NTHR) { ru_issue(base); ru_consume(base); }
+    *reinterpret_cast<float4*>(Rp + (size_t)rtg * Fd + 4 * rf) = s;
+  }
   RD_STAMP(8);
   lds_barrier();
-  // pass 2 (thread per (f,c)): fixed-order sum over t
+  // pass 2 (thread per (f,c)): fixed-order sum over the time groups
   for (int i = tid; i < Fd; i += NTHR) {
-    const int f = i >> 2, c = i & 3;
     float v = 0.f;
-    for (int t = 0; t < T; ++t) v += Sx[f * LDS_F + 4 * t + c];
+    for (int g = 0; g < TG; ++g) v += Rp[g * Fd + i];
     a.rupart[(size_t)b * Fd + i] = v;
   }
   RD_STAMP(9);
@@ -611,16 +788,20 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
 
 template <int RT>
 int launch_fused(const FusedArgs& a, bool bwd, hipStream_t st) {
-  const size_t lds = (size_t)4 * RT * 16 * LDX * sizeof(__bf16);
+  const size_t lds = (size_t)4 * RT * 16 * LDX * sizeof(__bf16) + (RT > 3 ? 0 : (size_t)RT * 16 * LDS_F * sizeof(float)) +
+                     (size_t)2 * RT * 16 * 16 * sizeof(uint16_t) + (size_t)RT * 16 * sizeof(float);
   if (!bwd) {
     RD_LDS_ATTR((k_msg_fwd_fused<RT>), lds);
     hipLaunchKernelGGL(k_msg_fwd_fused<RT>, dim3(a.B), dim3(NTHR), lds, st, a);
     return check_launch("k_msg_fwd_fused");
   }
-  const size_t ldsb = lds + (size_t)RT * 16 * KP;                  // + ReLU gate bytes
-  RD_LDS_ATTR((k_msg_bwd_fused<RT>), ldsb);
-  hipLaunchKernelGGL(k_msg_bwd_fused<RT>, dim3(a.B), dim3(NTHR), ldsb, st, a);
+  RD_LDS_ATTR((k_msg_bwd_fused<RT>), lds);
+  hipLaunchKernelGGL(k_msg_bwd_fused<RT>, dim3(a.B), dim3(NTHR), lds, st, a);
   return check_launch("k_msg_bwd_fused");
+}
+
+void fill_layout(FusedArgs& a, const k1::Layout& L) {
+  a.B = L.B; a.T = L.T; a.F = L.F; a.K = L.K; a.nct = L.nct; a.q = L.q; a.rem = L.rem; a.per = L.per;
 }
 
 }  // namespace
@@ -629,33 +810,32 @@ static unsigned long long* g_stamps = nullptr;
 extern "C" void rd_debug_set_stamps(void* p) { g_stamps = (unsigned long long*)p; }   // not part of the ABI
 
 bool fused_msgpass_ok(const rd_shape* s) {
+  // RD_K1_FUSED=0 routes the fused envelope through the generic tiled path (read per call: the parity tests compare
+  // the two paths in one process)
+  const char* e = getenv("RD_K1_FUSED");
+  const bool enabled = !(e && atoi(e) == 0);
   const int K = s->T * s->d_ob;
   // staging tile [F][244] fp32 must fit inside two bf16 planes [RT*16][264]; d_ob == 4 only
-  return precision() == RD_PREC_BF16X3 && s->d_ob == 4 && s->F <= 64 && K <= 240 && (K % 16) == 0 && K >= 16;
+  return enabled && precision() == RD_PREC_BF16X3 && s->d_ob == 4 && s->F <= 64 && K <= 240 && (K % 16) == 0 && K >= 16;
 }
 
-size_t fused_wplanes_bytes(const rd_shape* s) {
-  const size_t K = (size_t)s->T * s->d_ob;
-  return align_up(8 * K * KP * sizeof(__bf16), 256);
-}
-
-int fused_wprep(const rd_shape* s, const float* W1, const float* W2, void* planes, hipStream_t st) {
-  const int K = s->T * s->d_ob;
-  hipLaunchKernelGGL(k_wprep, dim3(32, 4), dim3(256), 0, st, W1, W2, (__bf16*)planes, K);
+int fused_wprep(const k1::Layout& L, const float* W1, const float* W2, void* wt, hipStream_t st) {
+  hipLaunchKernelGGL(k_wprep, dim3(4 * L.nct), dim3(256), 0, st, W1, W2, (__bf16*)wt, L.K, L.nct);
   return check_launch("k_wprep");
 }
 
-int fused_msgpass_fwd(const rd_shape* s, const float* src, const float* R_u, const float* b1, const float* b2,
-                      const float* ssum, const void* planes, float p_drop, uint64_t seed, float* xsave,
-                      float* y1save, float* z, int ldz, hipStream_t st, const float* times,
-                      const int64_t* lengths, const float* tscale, uint8_t* mask) {
+int fused_msgpass_fwd(const k1::Layout& L, const float* src, const float* R_u, const float* b1, const float* b2,
+                      const float* ssum, const void* wt, float p_drop, uint64_t seed, void* tpX, void* tpY1,
+                      void* m1, void* m2, void* mx, float* z, int ldz, hipStream_t st, const float* times,
+                      const int64_t* lengths, const float* tscale, uint8_t* mask, int d_pe) {
   FusedArgs a{};
-  a.times = times; a.lengths = lengths; a.tscale = tscale; a.mask = mask; a.d_pe = s->d_pe;
-  a.src = src; a.R_u = R_u; a.b1 = b1; a.b2 = b2; a.ssum = ssum; a.wplanes = (const __bf16*)planes;
-  a.xsave = xsave; a.y1save = y1save; a.z = z; a.ldz = ldz;
-  a.B = s->B; a.T = s->T; a.F = s->F; a.d = s->d_ob; a.K = s->T * s->d_ob;
+  fill_layout(a, L);
+  a.times = times; a.lengths = lengths; a.tscale = tscale; a.mask = mask; a.d_pe = d_pe;
+  a.src = src; a.R_u = R_u; a.b1 = b1; a.b2 = b2; a.ssum = ssum; a.wt = (const __bf16*)wt;
+  a.tpX = (__bf16*)tpX; a.tpY1 = (__bf16*)tpY1; a.m1 = (uint16_t*)m1; a.m2 = (uint16_t*)m2; a.mx = (uint8_t*)mx;
+  a.z = z; a.ldz = ldz;
   a.p_drop = p_drop; a.seed = seed; a.seed_cell = seed_cell(); a.stamps = g_stamps;
-  switch (cdiv(s->F, 16)) {
+  switch (L.RT) {
     case 1: return launch_fused<1>(a, false, st);
     case 2: return launch_fused<2>(a, false, st);
     case 3: return launch_fused<3>(a, false, st);
@@ -663,16 +843,16 @@ int fused_msgpass_fwd(const rd_shape* s, const float* src, const float* R_u, con
   }
 }
 
-int fused_msgpass_bwd(const rd_shape* s, const float* src, const float* ssum, const void* planes, float p_drop,
-                      const float* xsave, const float* y1save, const float* z, const float* dz, int ldz,
-                      float* dz2save, float* dz1save, float* rupart, hipStream_t st) {
+int fused_msgpass_bwd(const k1::Layout& L, const float* src, const float* ssum, const void* wt, float p_drop,
+                      const void* m1, const void* m2, const void* mx, const float* dz, int ldz, void* tpD1, void* tpD2,
+                      void* ones, float* rupart, hipStream_t st) {
   FusedArgs a{};
-  a.src = src; a.ssum = ssum; a.wplanes = (const __bf16*)planes;
-  a.xsave = const_cast<float*>(xsave); a.y1save = const_cast<float*>(y1save); a.z = const_cast<float*>(z);
-  a.dz = dz; a.ldz = ldz; a.dz2save = dz2save; a.dz1save = dz1save; a.rupart = rupart;
-  a.B = s->B; a.T = s->T; a.F = s->F; a.d = s->d_ob; a.K = s->T * s->d_ob;
+  fill_layout(a, L);
+  a.src = src; a.ssum = ssum; a.wt = (const __bf16*)wt;
+  a.m1 = (uint16_t*)const_cast<void*>(m1); a.m2 = (uint16_t*)const_cast<void*>(m2); a.mx = (uint8_t*)const_cast<void*>(mx);
+  a.dz = dz; a.ldz = ldz; a.tpD1 = (__bf16*)tpD1; a.tpD2 = (__bf16*)tpD2; a.ones = (__bf16*)ones; a.rupart = rupart;
   a.p_drop = p_drop; a.stamps = g_stamps;
-  switch (cdiv(s->F, 16)) {
+  switch (L.RT) {
     case 1: return launch_fused<1>(a, true, st);
     case 2: return launch_fused<2>(a, true, st);
     case 3: return launch_fused<3>(a, true, st);

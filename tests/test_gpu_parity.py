@@ -552,3 +552,51 @@ def test_static_train_step_dropout_varies_per_replay():
             step.close()
     assert len(set(seqs[0])) == 4                 # four replays, four different masks
     assert seqs[0] == seqs[1]                     # and the sequence is reproducible
+
+
+@pytest.mark.parametrize("F,T,B,kind", [(34, 60, 9, "sparse"), (34, 60, 256, "ones"), (34, 60, 100, "sparse"), (16, 60, 3, "ones"),
+                                        (17, 32, 5, "sparse"), (48, 60, 4, "ones"), (64, 60, 3, "sparse"), (33, 16, 7, "ones")])
+def test_k1_fused_vs_generic_same_arithmetic(F, T, B, kind, precision_mode, monkeypatch):
+    """The fused K1 kernels (rd_msgpass_fused.hip + rd_msgpass_dw.hip: row tiles, bit-mask gates, streamed dW)
+    against the generic tiled-GEMM path IN THE SAME split-bf16 ARITHMETIC.  Both evaluate relu(x W^T + b) with
+    the same 3-product split and fp32 accumulation and differ only in summation order (~1e-6), so the bound is
+    tight: forward 5e-6 of max-norm; every gradient entry within 2e-5 of the tensor's max-norm, except the rows a
+    ReLU gate flip can move (a pre-activation within ~1e-6 of zero opening on one path only): at most 0.1 % of the
+    entries may exceed the bound and the relative L2 error stays below 1e-3.  A dropped or mis-indexed term -- the
+    two leftover graph rows of a sample, a missing dW slice, a wrong gate bit -- fails these by orders of magnitude."""
+    if precision_mode != "bf16x3":
+        pytest.skip("the fused path exists in split-bf16 mode only")
+    from raindrop_amd import _lib, ops
+    d, K = 4, T * 4
+    rng = np.random.default_rng(F * 1000 + T * 10 + B)
+    cfgF = dict(d_inp=F, max_len=T, static=True, d_static=3, n_classes=2)
+    b = synth.make_batch(cfgF, B, seed=F + B, density=0.5)
+    gs = torch.ones(F, F) if kind == "ones" else synth.make_structure(dict(d_inp=F), "sparse")
+    names = ["R_u", "W1", "b1", "W2", "b2"]
+    shapes = [(1, F * d), (K, K), (K,), (K, K), (K,)]
+    p = {n: synth.param_values("k1." + n, s, seed=3) for n, s in zip(names, shapes)}
+    p["R_u"] = p["R_u"] * 3.0
+    dz = torch.from_numpy(rng.standard_normal((T, B, F * d + 16)).astype(np.float32)).to(DEV)
+    adj, _, _ = ops.graph_build(gs.to(DEV))
+    _, ssum = ops.edge_softmax_dense(adj)
+    shp = _lib.shape(B, T, F, d)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RD_K1_FUSED", mode)
+        pd = {n: t.detach().to(DEV).requires_grad_(True) for n, t in p.items()}
+        z, mask = ops.sensor_stage(b["src"].to(DEV), b["times"].to(DEV), b["lengths"].to(DEV), ops.timescales(T).to(DEV),
+                                   ssum, pd["R_u"], pd["W1"], pd["b1"], pd["W2"], pd["b2"], shp)
+        g = torch.autograd.grad(z, [pd[n] for n in names], dz)
+        torch.cuda.synchronize()
+        out[mode] = (z.detach().cpu().numpy(), mask.cpu().numpy(), [x.cpu().numpy() for x in g])
+    monkeypatch.delenv("RD_K1_FUSED")
+    zf, mf, gf = out["1"]
+    zg, mg, gg = out["0"]
+    assert np.array_equal(mf, mg)
+    assert np.array_equal(zf[:, :, F * d:], zg[:, :, F * d:])                     # PE columns: same arithmetic, bit-equal
+    assert np.abs(zf - zg).max() <= 5e-6 * np.abs(zg).max(), np.abs(zf - zg).max() / np.abs(zg).max()
+    for n, a, r in zip(names, gf, gg):
+        scale = np.abs(r).max() + 1e-30
+        bad = np.abs(a - r) > 2e-5 * scale
+        assert bad.mean() <= 1e-3, (n, float(bad.mean()), float(np.abs(a - r).max() / scale))
+        assert _rel2(a, r) < 1e-3, (n, _rel2(a, r))
