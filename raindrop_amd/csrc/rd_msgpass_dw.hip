@@ -8,7 +8,7 @@
 // the main loop, no padding in the reduction (272 tiles of 32 rows = 8704 rows at P19).
 //
 // Decomposition: the [K x (K+16)] output of a layer (the extra 16 columns hold the bias gradient in column 0: a
-// constant "ones" operand tile) is cut into 4 x 4-tile blocks; the S reduction tiles into `nslice` slices;
+// constant "ones" operand tile) is cut into 4 x 4-tile blocks; the S reduction tiles into `nslice` interleaved slices;
 // workgroup = (layer, block, slice).  Its 4 waves each own the WHOLE 4 x 4 block (64 accumulator registers) and
 // take every 4th reduction tile, double-buffered in registers: no barrier and no LDS until the final in-workgroup
 // sum (wave order: deterministic).  What bounds it: every operand tile is read by the 4 workgroups of a block row /
@@ -49,7 +49,11 @@ __global__ __launch_bounds__(DW_THR) void k_dw(DwArgs a) {
   const int layer = gidx / a.nslice, sl = gidx - layer * a.nslice;
   const int bn = mi / a.nbk, bk = mi - bn * a.nbk;
   const int nct = a.nct;
-  const int s0 = (int)((long)sl * a.S / a.nslice), s1 = (int)((long)(sl + 1) * a.S / a.nslice);
+  // slice sl = reduction tiles sl, sl + nslice, sl + 2 nslice, ...: with nslice == 8 these are the samples b = sl (mod 8),
+  // i.e. the row tiles the backward kernel's workgroups on XCD sl wrote a moment ago -- and this group runs on XCD sl
+  const int nsl = a.nslice;
+  const int ntile = a.S > sl ? (a.S - sl + nsl - 1) / nsl : 0;        // tiles of this slice
+  const int s0 = 0, s1 = ntile;                                       // wave tiling below runs over slice-local indices
   const __bf16* tA = layer ? a.tpD2 : a.tpD1;
   const __bf16* tB = layer ? a.tpY1 : a.tpX;
 
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(DW_THR) void k_dw(DwArgs a) {
   const __bf16* zt = a.ones + TILE + lane * 8;                          // [ones hi][zeros][zeros]
   auto load = [&](Frag& f, int i) {
     const bool ghost = i >= nst;
-    const size_t s = (size_t)(ghost ? s0 : s0 + wave + 4 * i);
+    const size_t s = (size_t)(ghost ? sl : sl + nsl * (wave + 4 * i));
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const __bf16* qa = ghost ? zt : pa[t] + s * step;
