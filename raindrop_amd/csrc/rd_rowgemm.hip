@@ -32,7 +32,7 @@ static unsigned long long* g_rg_stamps = nullptr;   // debug only (tools/rowgemm
 
 struct RowGemmArgs {
   const float* A; long lda;                         // [M, K] fp32
-  const __bf16* Wh; const __bf16* Wl;               // [NP16][KP] planes
+  const __bf16* Wh; const __bf16* Wl;               // Wh: native operand tiles [NP16/16][KP/32][hi,lo][64][8]; Wl unused
   float* C; long ldc;
   int M, N, K, KP;
   const float* bias; int relu;
@@ -46,17 +46,30 @@ struct RowGemmArgs {
 struct SplitJob { const float* W; int N, K, transpose; __bf16* hi; __bf16* lo; int rows, cols_p; };
 struct SplitJobs { SplitJob j[8]; int n; };
 
+// Output: NATIVE MFMA operand tiles [ntile = rows/16][kc = cols_p/32][hi, lo][64 lanes][8] (one contiguous kilobyte per
+// wave-load; rd_k1_layout.h has the measurement: 61 B/clk/CU against 16 B/clk for a row-major plane).  `hi` is the
+// base of the tile array, `lo` is unused (kept for the job layout).  One workgroup row per job; a wave converts one
+// (ntile, kc) tile per iteration.
 __global__ __launch_bounds__(256) void k_wsplit(SplitJobs jobs) {
   const SplitJob jb = jobs.j[blockIdx.y];
-  const long total = (long)jb.rows * jb.cols_p;
+  const int ntile = jb.rows >> 4, nkc = jb.cols_p >> 5;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, G = lane >> 4;
   const int src_rows = jb.transpose ? jb.K : jb.N, src_cols = jb.transpose ? jb.N : jb.K;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int r = (int)(i / jb.cols_p), c = (int)(i - (long)r * jb.cols_p);
-    float x = 0.f;
-    if (r < src_rows && c < src_cols) x = jb.transpose ? jb.W[(long)c * jb.K + r] : jb.W[(long)r * jb.K + c];
-    const __bf16 h = (__bf16)x;
-    jb.hi[i] = h;
-    jb.lo[i] = (__bf16)(x - (float)h);
+  for (int t = blockIdx.x * 4 + wave; t < ntile * nkc; t += gridDim.x * 4) {
+    const int j = t / nkc, kc = t - j * nkc;
+    const int r = 16 * j + c, c0 = 32 * kc + 8 * G;          // plane row (free index), first plane column (reduction)
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int cc = c0 + e;
+      x[e] = (r < src_rows && cc < src_cols) ? (jb.transpose ? jb.W[(long)cc * jb.K + r] : jb.W[(long)r * jb.K + cc]) : 0.f;
+    }
+    bf16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { h[e] = (__bf16)x[e]; l[e] = (__bf16)(x[e] - (float)h[e]); }
+    __bf16* dst = jb.hi + ((size_t)t * 2) * 512 + lane * 8;
+    *reinterpret_cast<bf16x8*>(dst) = h;
+    *reinterpret_cast<bf16x8*>(dst + 512) = l;
   }
 }
 
@@ -64,16 +77,16 @@ template <int KC>
 struct RPanel { bf16x8 h[RG_NJ][KC], l[RG_NJ][KC]; };
 
 template <int KC>
-__device__ __forceinline__ void rg_load_panel(RPanel<KC>& p, const __bf16* __restrict__ Wh, const __bf16* __restrict__ Wl,
-                                              int KP, int tile0, int ntiles, int wave, int lane) {
+__device__ __forceinline__ void rg_load_panel(RPanel<KC>& p, const __bf16* __restrict__ Wt, int tile0, int ntiles, int wave,
+                                              int lane) {
 #pragma unroll
   for (int jj = 0; jj < RG_NJ; ++jj) {
     const int j = tile0 + wave + RG_WAVES * jj;
-    const size_t off = (size_t)(16 * (j < ntiles ? j : 0) + (lane & 15)) * KP + 8 * (lane >> 4);
+    const __bf16* t = Wt + (size_t)(j < ntiles ? j : 0) * (KC * 2 * 512) + lane * 8;
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
-      p.h[jj][kc] = *reinterpret_cast<const bf16x8*>(Wh + off + kc * 32);
-      p.l[jj][kc] = *reinterpret_cast<const bf16x8*>(Wl + off + kc * 32);
+      p.h[jj][kc] = *reinterpret_cast<const bf16x8*>(t + (kc * 2 + 0) * 512);
+      p.l[jj][kc] = *reinterpret_cast<const bf16x8*>(t + (kc * 2 + 1) * 512);
     }
   }
 }
@@ -107,7 +120,7 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
       v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m0 + r < a.M && k < a.K) v[it] = *reinterpret_cast<const float4*>(a.A + (long)(m0 + r) * a.lda + k);
     }
-    rg_load_panel<KC>(pw, a.Wh, a.Wl, a.KP, 0, ntiles, wave, lane);
+    rg_load_panel<KC>(pw, a.Wh, 0, ntiles, wave, lane);
     __builtin_amdgcn_sched_barrier(0);       // keep every request above the first use (the scheduler otherwise
                                              // waits for the rows before it has requested the panel)
     if (a.seed_cell) seed += load_uniform_u64(a.seed_cell);   // scalar path: not queued behind the panel
@@ -162,7 +175,7 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
     }
     if (rd == 0) RGSTAMP(3);
     // next round's weights stream while this round's epilogue runs
-    if (rd + 1 < nrounds) rg_load_panel<KC>(pw, a.Wh, a.Wl, a.KP, tile0 + RG_WAVES * RG_NJ, ntiles, wave, lane);
+    if (rd + 1 < nrounds) rg_load_panel<KC>(pw, a.Wh, tile0 + RG_WAVES * RG_NJ, ntiles, wave, lane);
     // ---- accumulators -> stage tile (column = position inside this round's 256-column window) ----
 #pragma unroll
     for (int jj = 0; jj < RG_NJ; ++jj)

@@ -1,0 +1,25 @@
+"""Run the hipGraph training step bench.py times (TrainStep.run + flat Adam), nothing else: the target for
+rocprofv3 --kernel-trace of the GRAPH step (not the eager autograd step).   python tools/step_only.py [steps] [B]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from raindrop_amd import dp, synth
+from raindrop_amd.models_rd import Raindrop_v2
+from raindrop_amd.optim import FlatAdam
+from raindrop_amd.step import TrainStep
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+dev = torch.device("cuda")
+cfg = synth.make_config("P19")
+torch.manual_seed(1)
+m = Raindrop_v2(cfg["d_inp"], cfg["d_model"], 2, cfg["nhid"], 2, 0.2, cfg["max_len"], cfg["d_static"], 100, 0.5, "mean", 2,
+                synth.make_structure(cfg, "ones")).to(dev).train()
+b = {k: (None if v is None else v.to(dev)) for k, v in synth.make_batch(cfg, B, seed=100).items()}
+named = dict(m.named_parameters())
+flat = dp.FlatGradAllReduce([(n, named[n]) for n in synth.live_parameter_names(cfg)], n_buckets=2)
+opt = FlatAdam(flat.flatten_parameters(), lr=1e-4)
+ts = TrainStep(m, flat, b)
+for _ in range(steps):
+    ts.run(); flat.allreduce(); opt.step()
+torch.cuda.synchronize()
+print("loss", float(ts.loss))
