@@ -21,7 +21,9 @@
  *   - return 0 on success, RD_EINVAL / RD_EUNSUPPORTED (negative) for argument errors detected
  *     before any launch, or a positive hipError_t from the launch; rd_last_error() returns a
  *     thread-local message for the last non-zero return;
- *   - stateless and re-entrant; results are deterministic (no floating-point atomics).
+ *   - re-entrant; results are deterministic (no floating-point atomics).  The library keeps no per-call state.  Two
+ *     settings exist outside the call arguments: the arithmetic mode (rd_set_precision, process-wide, meant to be chosen
+ *     once at start-up) and the dropout seed cell (rd_set_seed_cell, per host thread, read at enqueue time).
  */
 #ifndef RAINDROP_HIP_H
 #define RAINDROP_HIP_H
@@ -72,7 +74,10 @@ int rd_get_precision(void);
 /* Dropout seeds are passed by value, which a captured hipGraph freezes.  If a device cell is
  * registered, every dropout kernel adds its content to the seed it was launched with; bumping the
  * cell (a 1-thread kernel, itself capturable) gives each graph replay fresh masks while forward and
- * backward of one step still agree.  Pass NULL to unregister.  Process-wide. */
+ * backward of one step still agree.  Pass NULL to unregister.  The registration is per HOST THREAD and is consumed
+ * when a call is ENQUEUED (the pointer is passed to the kernels as an argument): register it around the enqueue or the
+ * stream capture of a step and unregister afterwards -- a captured graph keeps using the cell it was captured with, and
+ * calls made while no cell is registered are unaffected by it.  The cell must outlive every launch that received it. */
 int rd_set_seed_cell(const uint64_t* device_cell);
 int rd_seed_cell_advance(uint64_t* device_cell, uint64_t delta, void* stream);
 

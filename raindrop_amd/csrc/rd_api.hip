@@ -12,7 +12,9 @@ char* err_buf() {
   return buf;
 }
 
-static const uint64_t* g_seed_cell = nullptr;
+// Registered per HOST THREAD and read when a call is ENQUEUED (the pointer becomes a kernel argument): a captured hipGraph
+// keeps the pointer it was captured with, so callers register the cell around the enqueue / capture only.
+static thread_local const uint64_t* g_seed_cell = nullptr;
 const uint64_t* seed_cell() { return g_seed_cell; }
 
 static int g_precision = -1;

@@ -156,18 +156,30 @@ class TrainStep:
           _p(G["ob_propagation.lin_value.bias"]), _p(G["ob_propagation_layer2.lin_value.weight"]),
           _p(G["ob_propagation_layer2.lin_value.bias"]), _p(G["R_u"]), _p(self.k1_ws), self.k1_ws.numel(), st)
 
-    def _capture(self):
+    def _with_cell(self, fn):
+        """Run `fn` with this step's seed cell registered.  The registration is read when a kernel is ENQUEUED (the pointer
+        travels as a kernel argument), so it is scoped to the enqueue / the capture: a captured graph keeps the cell it was
+        captured with, and nothing else in the process (an eager model, another TrainStep) ever sees this step's cell --
+        dropping a TrainStep can no longer leave a dangling pointer behind."""
         _lib.call("rd_set_seed_cell", _p(self.seed_cell))
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(2):                                             # warm-up: lazy inits happen here
+        try:
+            return fn()
+        finally:
+            _lib.call("rd_set_seed_cell", None)
+
+    def _capture(self):
+        def cap():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(2):                                         # warm-up: lazy inits happen here
+                    self._body()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(self.graph):
                 self._body()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
-            self._body()
+        self._with_cell(cap)
 
     # ------------------------------------------------------------------------------------------
     def run(self):
@@ -175,12 +187,14 @@ class TrainStep:
         if self.graph is not None:
             self.graph.replay()
         else:
-            _lib.call("rd_set_seed_cell", _p(self.seed_cell))
-            with torch.no_grad():
-                self._body()
+            def eager():
+                with torch.no_grad():
+                    self._body()
+            self._with_cell(eager)
         for p, v in zip(self.flat.params, self.flat.views):
             p.grad = v
         return self.loss
 
     def close(self):
-        _lib.call("rd_set_seed_cell", None)
+        """Kept for callers of the round-1 API: the seed cell is no longer registered outside run() / capture."""
+        self.graph = None

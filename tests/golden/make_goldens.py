@@ -36,12 +36,17 @@ MODEL_CASES = [
     ("p19_sparse", "P19", 32, "sparse", 3, 5),
     ("p12_ones", "P12", 8, "ones", 4, 6),
     ("pam_ones", "PAM", 4, "ones", 5, 7),
+    # the benchmark's batch (B = 256: the B*F = 8704-row weight-gradient reduction, every dW slice of the fused path) and a
+    # larger P12 batch on the generic-K path; gradients stored as strided samples only (FULL_LIMIT) to stay small
+    ("p19_b256", "P19", 256, "ones", 6, 8),
+    ("p12_b32", "P12", 32, "sparse", 7, 9),
 ]
+FULL_LIMIT = {"p19_b256": 4096, "p12_b32": 4096}
 
 
-def strided(t, n=SAMPLE):
+def strided(t, n=SAMPLE, full_limit=70_000):
     flat = t.detach().reshape(-1)
-    if flat.numel() <= 70_000:
+    if flat.numel() <= full_limit:
         return flat.numpy().copy(), 1
     stride = max(1, flat.numel() // n)
     return flat[::stride].numpy().copy(), stride
@@ -98,13 +103,14 @@ def model_case(name, cfg_name, B, kind, pseed, bseed):
         edge_index=ei, edge_weights=ew, lengths=b["lengths"].numpy(),
         live=np.array(live),
     )
+    fl = FULL_LIMIT.get(name, 70_000)
     for key in ("msg_out", "pe", "agg"):
-        s, st = strided(inter[key])
+        s, st = strided(inter[key], full_limit=fl)
         out["inter_" + key] = s
         out["inter_" + key + "_stride"] = np.int64(st)
     for n in live:
         g = params[n].grad
-        s, st = strided(g)
+        s, st = strided(g, full_limit=fl)
         out["grad/" + n] = s
         out["gradstride/" + n] = np.int64(st)
         out["gradsum/" + n] = np.float64(g.double().sum().item())

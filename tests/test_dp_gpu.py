@@ -1,0 +1,85 @@
+"""GPU, world_size 2 on ONE device (gloo): the data-parallel training step as bench.py runs it at N > 1 --
+`TrainStep` (HIP forward + CE + backward into the flat gradient buffer) -> `flat.allreduce()` -> `FlatAdam` --
+gives every rank the parameters a single process gets from the full batch.  An 8-GPU node is not available to
+this repo's tests; the collective here is gloo on two processes that share cuda:0, the product code path
+(raindrop_amd/step.py, dp.py, optim.py and every kernel) is the one bench.py --gpus N uses with RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+STEPS = 2
+B_GLOBAL = 16
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _run_steps(batch, world_rank=None):
+    """STEPS training steps on `batch`; returns (flat all-reduced gradient of the first step, flat parameters after the last)."""
+    from raindrop_amd import dp, synth
+    from raindrop_amd.models_rd import Raindrop_v2
+    from raindrop_amd.optim import FlatAdam
+    from raindrop_amd.step import TrainStep
+    dev = torch.device("cuda", 0)
+    cfg = synth.make_config("P19")
+    gs = synth.make_structure(cfg, "sparse")
+    m = Raindrop_v2(cfg["d_inp"], cfg["d_model"], cfg["nhead"], cfg["nhid"], cfg["nlayers"], cfg["dropout"],
+                    cfg["max_len"], cfg["d_static"], cfg["MAX"], 0.5, cfg["aggreg"], cfg["n_classes"], gs,
+                    sensor_wise_mask=False)
+    synth.fill_params_(m, seed=21)
+    m = m.to(dev).train()
+    named = dict(m.named_parameters())
+    flat = dp.FlatGradAllReduce([(n, named[n]) for n in synth.live_parameter_names(cfg)], n_buckets=2)
+    opt = FlatAdam(flat.flatten_parameters(), lr=1e-3)
+    b = {k: (None if v is None else v.to(dev)) for k, v in batch.items()}
+    ts = TrainStep(m, flat, b, p_drop=0.0, use_graph=False)
+    g_first = None
+    for i in range(STEPS):
+        ts.run()
+        flat.allreduce()
+        if i == 0:
+            g_first = flat.flat.detach().cpu().numpy().copy()
+        opt.step()
+    torch.cuda.synchronize()
+    ts.close()
+    return g_first, flat.flat_param.detach().cpu().numpy().copy()
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from raindrop_amd import dp, synth
+    full = synth.make_batch(synth.make_config("P19"), B_GLOBAL, seed=33)
+    g, p = _run_steps(dp.shard_batch(full, rank, world))
+    ret[rank] = (g, p)
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_full_batch_step():
+    from raindrop_amd import synth
+    full = synth.make_batch(synth.make_config("P19"), B_GLOBAL, seed=33)
+    g_ref, p_ref = _run_steps(full)                               # this process: no process group, world == 1
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    g0, p0 = ret[0]
+    g1, p1 = ret[1]
+    assert np.array_equal(g0, g1) and np.array_equal(p0, p1)      # replicas stay bit-identical
+    gscale = np.abs(g_ref).max()
+    assert np.abs(g0 - g_ref).max() <= 3e-5 * gscale, np.abs(g0 - g_ref).max() / gscale
+    # Adam's update is lr * m / (sqrt(v) + eps): a 1e-5 relative gradient difference moves a weight by ~1e-5 * lr.  Adam
+    # also normalises away the magnitude, so an entry whose gradient is pure summation noise (|g| far below 1e-5 of the
+    # largest) can take a different sign and move by up to 2 lr per step: those may exist, but only as a tiny fraction.
+    dp_ = np.abs(p0 - p_ref)
+    assert (dp_ > 1e-3 * 1e-3 * STEPS).mean() < 1e-3, float((dp_ > 2e-6).mean())
+    assert dp_.max() <= 2.1 * 1e-3 * STEPS

@@ -600,3 +600,53 @@ def test_k1_fused_vs_generic_same_arithmetic(F, T, B, kind, precision_mode, monk
         bad = np.abs(a - r) > 2e-5 * scale
         assert bad.mean() <= 1e-3, (n, float(bad.mean()), float(np.abs(a - r).max() / scale))
         assert _rel2(a, r) < 1e-3, (n, _rel2(a, r))
+
+
+def test_k1_fused_dropout_backward_uses_forward_mask(precision_mode, monkeypatch):
+    """Dropout on the observation embedding, fused path: the forward pass hands its keep mask to the backward pass as
+    gate bits (no regeneration).  Same seed -> identical output, another seed -> another mask; the generic path draws
+    the SAME Philox mask (same (seed, site, cell) function), so output and all five gradients must agree with it as
+    tightly as without dropout; and dR_u matches a central finite difference of <z, R> (once the seed is fixed the
+    stage is a fixed piecewise-linear function of R_u with few kinks near the sample)."""
+    if precision_mode != "bf16x3":
+        pytest.skip("the fused path exists in split-bf16 mode only")
+    from raindrop_amd import _lib, ops
+    F, T, B, d = 34, 60, 5, 4
+    K = T * d
+    rng = np.random.default_rng(77)
+    b = synth.make_batch(dict(d_inp=F, max_len=T, static=True, d_static=3, n_classes=2), B, seed=5, density=0.6)
+    names = ["R_u", "W1", "b1", "W2", "b2"]
+    shapes = [(1, F * d), (K, K), (K,), (K, K), (K,)]
+    p = {n: synth.param_values("k1d." + n, s, seed=4).to(DEV) for n, s in zip(names, shapes)}
+    p["R_u"] = p["R_u"] * 3.0
+    adj, _, _ = ops.graph_build(torch.ones(F, F, device=DEV))
+    _, ssum = ops.edge_softmax_dense(adj)
+    shp = _lib.shape(B, T, F, d)
+    R = torch.from_numpy(rng.standard_normal((T, B, F * d + 16)).astype(np.float32)).to(DEV)
+    src, times, lengths, ts = b["src"].to(DEV), b["times"].to(DEV), b["lengths"].to(DEV), ops.timescales(T).to(DEV)
+
+    def f(q, seed=9):
+        z, _ = ops.sensor_stage(src, times, lengths, ts, ssum, q["R_u"], q["W1"], q["b1"], q["W2"], q["b2"], shp, 0.3, seed)
+        return z
+    z1, z2, z3 = f(p), f(p), f(p, 10)
+    assert torch.equal(z1, z2) and not torch.equal(z1, z3)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RD_K1_FUSED", mode)
+        q = {n: t.clone().requires_grad_(True) for n, t in p.items()}
+        z = f(q)
+        g = torch.autograd.grad((z * R).sum(), [q[n] for n in names])
+        res[mode] = (z.detach().cpu().numpy(), [x.cpu().numpy() for x in g])
+    monkeypatch.delenv("RD_K1_FUSED")
+    (zf, gf), (zg, gg) = res["1"], res["0"]
+    assert np.abs(zf - zg).max() <= 5e-6 * np.abs(zg).max()
+    for n, a, r in zip(names, gf, gg):
+        scale = np.abs(r).max() + 1e-30
+        assert (np.abs(a - r) > 2e-5 * scale).mean() <= 1e-3 and _rel2(a, r) < 1e-3, (n, _rel2(a, r))
+    eps = 1e-2
+    dirn = torch.from_numpy(rng.standard_normal(tuple(p["R_u"].shape)).astype(np.float32)).to(DEV)
+    pp = dict(p); pm = dict(p)
+    pp["R_u"] = p["R_u"] + eps * dirn; pm["R_u"] = p["R_u"] - eps * dirn
+    fd = (((f(pp) - f(pm)) * R).sum() / (2 * eps)).item()
+    an = float((torch.from_numpy(gf[0]).to(DEV) * dirn).sum())
+    assert abs(fd - an) < 3e-2 * max(1.0, abs(an)), (fd, an)
