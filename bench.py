@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--feed", action="store_true",
                     help="draw every step's batch from a device-resident dataset with rd_batch_gather (SURVEY 8f "
                          "rank 1) instead of re-using one resident batch (the default, as the metric is defined)")
+    ap.add_argument("--no-roofline", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-graph", action="store_true",
                     help="eager autograd step instead of the hipGraph-captured static step")
     return ap.parse_args()
@@ -150,19 +151,37 @@ def k1_roofline_events(model, cfg, batch, reps=20):
     return _roofline_dict(B, F, K, fwd, bwd, "eager launches timed with HIP events (includes host launch gaps)")
 
 
+K1_SOURCES = ("rd_msgpass_fused.hip", "rd_msgpass_dw.hip", "rd_msgpass.hip", "rd_k1_layout.h")
+
+
+def k1_source_hash():
+    """sha1 over the K1 kernel sources: the committed PMC traffic figure is only valid for the kernels it was measured on."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in K1_SOURCES:
+        with open(os.path.join(ROOT, "raindrop_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def _pmc_traffic(B, F, K):
     """HBM bytes per K1 step from the committed PMC passes (rocprofv3 --pmc cannot run inside the timed
     process: FETCH_SIZE and WRITE_SIZE need separate passes; tools/k1_traffic_json.py).  Only valid for the
-    shape it was collected on; None otherwise."""
+    shape AND the kernel sources it was collected on (sha1 stamp); None otherwise."""
     try:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "raindrop_amd", "k1_pmc_traffic.json")
+        path = os.path.join(ROOT, "raindrop_amd", "k1_pmc_traffic.json")
         with open(path) as fh:
             d = json.load(fh)
-        if (B, F, K) == (256, 34, 240):
-            return int(d["bytes_per_step"]), d["source"]
-    except Exception:
-        pass
-    return None, None
+        if (B, F, K) != (256, 34, 240):
+            return None, "PMC passes exist for the P19 B=256 shape only"
+        if d.get("source_sha1") != k1_source_hash():
+            return None, "stale: the K1 kernel sources changed since the PMC passes (re-run tools/k1_profile.sh pmc + tools/k1_traffic_json.py)"
+        return int(d["bytes_per_step"]), d["source"]
+    except Exception as e:
+        return None, "unavailable: %r" % (e,)
+
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
 
 
 def _roofline_dict(B, F, K, fwd, bwd, how):
@@ -171,13 +190,51 @@ def _roofline_dict(B, F, K, fwd, bwd, how):
     bytes_bwd = B * 20 * F * K + 16 * K * K
     alg = bytes_fwd + bytes_bwd
     achieved = alg / ((fwd + bwd) * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "K1 message passing fwd+bwd (rd_msgpass_fwd + rd_msgpass_bwd incl. PE/mask, "
-                                      "weight split, dW/db reductions); " + how,
+    # 12 F K^2 fp32-equivalent flops per sample fwd+bwd; the split-bf16 path issues 3 MFMA products per flop
+    flops = 12.0 * F * K * K * B
+    tf = flops / ((fwd + bwd) * 1e-3) / 1e12
+    return {"bound": "hbm" if 0.375 * K < 314 else "mfma",
+            "kernel": "K1 message passing fwd+bwd (rd_msgpass_fwd + rd_msgpass_bwd incl. PE/mask, "
+                      "weight split, dW/db reductions); " + how,
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes": alg, "fwd_us": round(fwd * 1e3, 2), "bwd_us": round(bwd * 1e3, 2),
             "fwd_frac": round(bytes_fwd / (fwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-            "bwd_frac": round(bytes_bwd / (bwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+            "bwd_frac": round(bytes_bwd / (bwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "mfma": {"algorithmic_tflops": round(tf, 2), "issued_bf16_tflops": round(3 * tf, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                     "frac_issued": round(3 * tf / MFMA_BF16_PEAK_TFLOPS, 5),
+                     "note": "12 F K^2 flops per sample fwd+bwd (SURVEY 8d); x3 MFMA products in split-bf16 mode; "
+                             "arithmetic intensity 0.375 K flop/B: HBM-bound below K ~ 314 with bf16 MFMA, MFMA-bound above"}}
+
+
+def fp32_mode_ms(args):
+    """ms per step of the same training step with the dense contractions on the exact-fp32 MFMA (RD_PRECISION=fp32),
+    measured in a child process (the arithmetic mode is process-wide); None if the child fails."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--batch", str(args.batch), "--config",
+           args.config, "--no-cpu-baseline", "--no-roofline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["RD_PRECISION"] = "fp32"
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+        for ln in res.stdout.splitlines():
+            if ln.startswith("{"):
+                return json.loads(ln)["ms_per_step"]
+    except Exception:
+        pass
+    return None
+
+
+def recorded_o1(cfg_name, B):
+    """The reference's OWN files (oracle O1, under the PyG shim) timed in the build container, train mode, dropout 0.2:
+    /root/reference does not exist on the GPU box, so this figure is recorded (raindrop_amd/o1_cpu_baseline.json, made by
+    tools/o1_cpu_time.py) rather than measured beside the GPU number."""
+    try:
+        with open(os.path.join(ROOT, "raindrop_amd", "o1_cpu_baseline.json")) as fh:
+            d = json.load(fh)
+        return d.get("%s_B%d" % (cfg_name, B))
+    except Exception:
+        return None
 
 
 def graph_probe_ok(args, world):
@@ -438,12 +495,16 @@ def main():
         }
         # K1 roofline: rank 0's own launches (hipGraph replays in an isolated child process, else HIP events in
         # this one), after the timed region -- the other ranks are idle by then; never allowed to cost the line
-        try:
-            line["roofline"] = roofline_isolated(args) or k1_roofline_events(model, cfg, batch)
-        except Exception as e:                                       # pragma: no cover
-            line["roofline"] = {"error": repr(e)[:200]}
+        if not args.no_roofline:
+            try:
+                line["roofline"] = roofline_isolated(args) or k1_roofline_events(model, cfg, batch)
+            except Exception as e:                                       # pragma: no cover
+                line["roofline"] = {"error": repr(e)[:200]}
+            if world == 1:
+                line["config"]["fp32_mode_ms_per_step"] = fp32_mode_ms(args)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, gs, B, args.cpu_reps)
+            line["cpu_baseline"]["reference_o1"] = recorded_o1(cfg["name"], B)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()                           # rank 0 measured the roofline after the timed region: tear down together

@@ -14,7 +14,7 @@ import sqlite3
 import sys
 from collections import defaultdict
 
-K1_KERNELS = ("k_wprep", "k_msg_fwd_fused", "k_msg_bwd_fused", "k_gemm_bf16x3<false, false", "k_reduce_wide",
+K1_KERNELS = ("k_wprep", "k_msg_fwd_fused", "k_msg_bwd_fused", "k_dw(", "k_dw_reduce", "k_gemm_bf16x3<false, false", "k_reduce_wide",
               "k_splitk_reduce2", "k_colsum_small", "k_wgrad_slab", "k_pe_mask", "k_obs_embed", "k_msg_dz2")
 
 
@@ -48,7 +48,10 @@ def main(fetch_db, write_db, steps=10):
         m = re.search(r"(k_\w+(?:<[^>]*>)?)", name)
         rows.append({"kernel": m.group(1) if m else name[:80], "calls_per_step": calls,
                      "fetch_kb": round(fk, 1), "write_kb": round(wk, 1), "bytes_per_step": round(b)})
-    print(json.dumps({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/k1_only.py; "
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    print(json.dumps({"source_sha1": bench.k1_source_hash(), "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/k1_only.py; "
                                 "FETCH_SIZE doubled for gfx950; P19 shape, B=256",
                       "bytes_per_step": round(total), "kernels": rows}, indent=1))
 
