@@ -43,8 +43,12 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int LDX = KP + 8;      // bf16 elements per LDS plane row (528 B)
 constexpr int LDS_F = 244;       // fp32 staging row stride (conflict-free for both access orders)
-constexpr int NTHR = 512;        // 8 wavefronts: wave w owns output column tiles {w, w+8}
-constexpr int NWAVE = NTHR / 64, NJ = 2;
+#ifndef RD_K1_NTHR
+#define RD_K1_NTHR 512
+#endif
+constexpr int NTHR = RD_K1_NTHR; // 512: 8 wavefronts, wave w owns output column tiles {w, w+8}; 1024: 16 wavefronts, one tile each
+constexpr int NWAVE = NTHR / 64, NJ = 16 / NWAVE;
+constexpr int CPT = 2048 / NTHR; // cells (t, f) per thread and batch of loads (F*T <= 2048 needs one batch)
 
 struct FusedArgs {
   const float *src, *R_u, *b1, *b2, *ssum;
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   // fastest it touched 64 cache lines, and the 64 such loads of the workgroup cost more tag look-ups than the
   // whole weight panel).  LDS: the 16-byte fp32 stores are conflict-free at stride 244, the 8-byte plane
   // stores 2-way.
-  constexpr int UNR = 4;
+  constexpr int UNR = CPT;
   const int total = F * T;
   uint64_t seed_eff = a.seed;
   float v[UNR]; int fi[UNR], ti[UNR]; float4 ru[UNR]; unsigned km[UNR];     // km: keep bits of the 4 channels
@@ -611,7 +615,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   // ---- dZ2 = dz * ssum * (Y2 > 0), dz read coalesced in [t, f*d+c] order and transposed through LDS; the gate
   // bits of both layers come from the forward pass (2 x 32 bytes per graph row).
   // thread -> cell (t, f), f fastest: one 16-byte load per cell (the 4 channels), one 16-byte LDS store
-  constexpr int GU = 4;
+  constexpr int GU = CPT;
   const int total = F * T;
   const bool vec4 = (a.ldz & 3) == 0;
   float4 dd[GU]; int gt[GU], gfi[GU];
@@ -679,7 +683,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   const int TG = NTHR / F;                                   // >= 8
   const int rtg = tid / F, rf = tid - rtg * F;
   const bool ract = rtg < TG;
-  constexpr int XU = 4;
+  constexpr int XU = CPT;
   unsigned xb[XU]; float svv[XU];
   auto ru_issue = [&](int tb) {
 #pragma unroll
