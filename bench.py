@@ -28,6 +28,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+ARITH = {
+    "bf16x3": "fp32 tensors everywhere; dense contractions as split-bf16 (hi+lo, 3 products) on v_mfma_f32_16x16x32_bf16 with "
+              "fp32 accumulation (~2^-16 per product; logits within 1e-4 of the fp32 reference, tests/test_gpu_parity.py); "
+              "attention, softmax, LayerNorm and reductions in fp32 (RD_PRECISION=fp32 switches the contractions to the "
+              "exact-fp32 MFMA)",
+    "fp32": "fp32 everywhere: dense contractions on v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain)",
+    "bf16": "fp32 tensors in HBM; dense contractions with operands rounded to bf16, ONE product per step on "
+            "v_mfma_f32_16x16x32_bf16, fp32 accumulation (logits within 3e-2 of the fp32 reference); message passing on the "
+            "generic tiled path; attention, softmax, LayerNorm and reductions in fp32",
+}
 
 
 def parse():
@@ -46,6 +56,9 @@ def parse():
     ap.add_argument("--feed", action="store_true",
                     help="draw every step's batch from a device-resident dataset with rd_batch_gather (SURVEY 8f "
                          "rank 1) instead of re-using one resident batch (the default, as the metric is defined)")
+    ap.add_argument("--precision", default=None, choices=["bf16x3", "fp32", "bf16"],
+                    help="arithmetic of the dense contractions (default: RD_PRECISION or bf16x3); bf16 = one product, the "
+                         "'P12 bf16' configuration of BASELINE.json")
     ap.add_argument("--no-roofline", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-graph", action="store_true",
                     help="eager autograd step instead of the hipGraph-captured static step")
@@ -312,6 +325,9 @@ def main():
     import faulthandler
     faulthandler.dump_traceback_later(900, exit=True)      # never hang a GPU box silently
     args = parse()
+    if args.precision:
+        os.environ["RD_PRECISION"] = args.precision           # read by the library at its first call; children inherit it
+    prec = os.environ.get("RD_PRECISION", "bf16x3")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -474,7 +490,7 @@ def main():
             "metric": "samples/sec fwd+bwd, P19 34-sensor batch=256; % HBM roofline on msg-pass kernel",
             "value": round(world * B * args.steps / elapsed, 1), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if prec == "bf16" else "f32",
             "data": "synthetic",
             "config": {"workload": "%s-shaped synthetic batch (F=%d sensors, T=%d steps, d_ob=4, K=%d), "
                                    "B=%d samples per GPU, Setting-1 (global_structure=ones); step = fwd+CE+bwd"
@@ -485,11 +501,7 @@ def main():
                        "step_mode": "hipGraph(fwd+CE+bwd) + eager all-reduce/Adam" if tstep is not None else "eager autograd",
                        "batch_source": ("rd_batch_gather from a device-resident dataset (N=8192) every step" if feed_next
                                         else "one resident batch re-used (inputs in HBM before the timed region)"),
-                       "arithmetic": "fp32 tensors everywhere; dense contractions as split-bf16 (hi+lo, 3 products) on "
-                                     "v_mfma_f32_16x16x32_bf16 with fp32 accumulation (~2^-16 per product; logits within "
-                                     "1e-4 of the fp32 reference, tests/test_gpu_parity.py); attention, softmax, "
-                                     "LayerNorm and reductions in fp32 (RD_PRECISION=fp32 switches the contractions to "
-                                     "the exact-fp32 MFMA)",
+                       "arithmetic": ARITH[prec],
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "grad_allreduce_bytes": flat.nbytes()},
         }

@@ -49,6 +49,11 @@ extern "C" {
  *                  5.3x the MFMA throughput.  Default; env RD_PRECISION=fp32 selects the other. */
 #define RD_PREC_FP32 0
 #define RD_PREC_BF16X3 1
+/*   RD_PREC_BF16   operands rounded to bf16 (hi part only), ONE product per MFMA step, fp32 accumulate: the arithmetic of
+ *                  BASELINE.json's "P12 ... bf16" configuration (~2^-9 per product; logits within 3e-2 of the fp32
+ *                  reference).  Dense layers of the encoder / head / generic message passing only; the fused
+ *                  K1 path, attention, softmax, LayerNorm stay as in the other modes.  env RD_PRECISION=bf16. */
+#define RD_PREC_BF16 2
 
 /* Problem shape shared by the model-level entry points.
  * K = T*d_ob (channels per sensor node), Dm = F*d_ob, D = Dm + d_pe (transformer width). */

@@ -21,7 +21,7 @@ static int g_precision = -1;
 int precision() {
   if (g_precision < 0) {
     const char* e = getenv("RD_PRECISION");
-    g_precision = (e && strcmp(e, "fp32") == 0) ? RD_PREC_FP32 : RD_PREC_BF16X3;
+    g_precision = (e && strcmp(e, "fp32") == 0) ? RD_PREC_FP32 : ((e && strcmp(e, "bf16") == 0) ? RD_PREC_BF16 : RD_PREC_BF16X3);
   }
   return g_precision;
 }
@@ -39,7 +39,7 @@ int fail(int code, const char* fmt, ...) {
 using namespace rd;
 
 extern "C" int rd_set_precision(int32_t mode) {
-  RD_REQUIRE(mode == RD_PREC_FP32 || mode == RD_PREC_BF16X3, "unknown precision mode %d", mode);
+  RD_REQUIRE(mode == RD_PREC_FP32 || mode == RD_PREC_BF16X3 || mode == RD_PREC_BF16, "unknown precision mode %d", mode);
   g_precision = mode;
   return RD_OK;
 }

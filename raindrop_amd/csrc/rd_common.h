@@ -92,6 +92,7 @@ struct GemmArgs {
   // [T,B,ldz] layout z[(t*sB + b)*ldz + f*sd + c]   (code/models_rd.py:338-342)
   int scatter; int sB, sF, sd; long ldz;
   unsigned long long* stamps;     // debug phase stamps (set by launch_gemm; null in normal runs)
+  int one_product;                // RD_PREC_BF16: hi*hi only (set by launch_gemm)
 };
 int launch_gemm(const GemmArgs& a, hipStream_t st);
 // split of the reduction length `red` of a [rows x cols] weight-gradient product into nsplit chunks

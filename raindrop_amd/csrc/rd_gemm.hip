@@ -474,16 +474,18 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
         bl[j] = *reinterpret_cast<const bf16x8*>(Bl + ob);
       }
       // three passes over independent accumulators: no back-to-back MFMA on the same registers
+      if (!g.one_product) {                             // uniform: RD_PREC_BF16 keeps the hi*hi product only
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -689,7 +691,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   static const int xcd_env = [] { const char* e = getenv("RD_GEMM_XCD"); return e ? atoi(e) : 1; }();
   g.xcd_swizzle = xcd_env;
   if (g.nsplit <= 1) { g.nsplit = 1; g.k_per_split = g.K > 0 ? g.K : 1; g.sc_split = 0; }
-  if (precision() == RD_PREC_BF16X3) {
+  if (precision() != RD_PREC_FP32) {
+    g.one_product = precision() == RD_PREC_BF16;
     if (g.nsplit > 1 && (g.k_per_split % BK2) != 0) return fail(RD_EINVAL, "gemm: k_per_split must be a multiple of 64");
     if (akc && bkc) return dispatch_bf16x3<true, true>(g, st);
     if (akc && !bkc) return dispatch_bf16x3<true, false>(g, st);
@@ -762,7 +765,7 @@ int launch_wgrad2(long M, int N, int K, const float* dyA, const float* xA, float
   if (wgrad_slab_ok(M, N, K)) return launch_wgrad_slab(M, N, K, dyA, N, xA, K, dWA, dbA, dyB, xB, dWB, dbB, ws, st);
   int kps; const int ns = splitk_plan(M, N, K, &kps);
   const long stride = (long)N * K + N;
-  if (ns <= 1 || precision() != RD_PREC_BF16X3) {      // the batched form exists for the split bf16x3 kernel only
+  if (ns <= 1 || precision() == RD_PREC_FP32) {        // the batched form exists for the bf16 MFMA kernel only
     int rc = launch_wgrad(M, N, K, dyA, N, xA, K, dWA, dbA, ws, st);
     if (rc) return rc;
     return launch_wgrad(M, N, K, dyB, N, xB, K, dWB, dbB, ws + (long)ns * stride, st);

@@ -40,6 +40,7 @@ struct RowGemmArgs {
   const float* residual; long res_ld;
   float drop_p; uint64_t drop_seed; uint32_t drop_site; const uint64_t* seed_cell;
   unsigned long long* stamps;
+  int one_product;                                  // RD_PREC_BF16
 };
 
 // one weight matrix -> hi/lo planes; transpose != 0 writes split(W^T): rows k, cols n
@@ -157,16 +158,18 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
         ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * LDA + aoff + kc * 32);
         al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * LDA + aoff + kc * 32);
       }
+      if (!a.one_product) {                              // uniform: RD_PREC_BF16 keeps the hi*hi product only
 #pragma unroll
-      for (int jj = 0; jj < RG_NJ; ++jj)
+        for (int jj = 0; jj < RG_NJ; ++jj)
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
-          acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], pw.h[jj][kc], acc[jj][rt], 0, 0, 0);
+          for (int rt = 0; rt < 4; ++rt)
+            acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], pw.h[jj][kc], acc[jj][rt], 0, 0, 0);
 #pragma unroll
-      for (int jj = 0; jj < RG_NJ; ++jj)
+        for (int jj = 0; jj < RG_NJ; ++jj)
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
-          acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], pw.l[jj][kc], acc[jj][rt], 0, 0, 0);
+          for (int rt = 0; rt < 4; ++rt)
+            acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], pw.l[jj][kc], acc[jj][rt], 0, 0, 0);
+      }
 #pragma unroll
       for (int jj = 0; jj < RG_NJ; ++jj)
 #pragma unroll
@@ -240,7 +243,7 @@ extern "C" void rd_debug_set_rowgemm_stamps(void* p) {   // not part of the ABI
 bool rowgemm_ok(int N, int K, long lda, long ldc) {
   static const bool enabled = [] { const char* e = getenv("RD_ROWGEMM"); return !(e && atoi(e) == 0); }();
   const int kc = (K + 31) / 32;
-  return enabled && precision() == RD_PREC_BF16X3 && (N % 4) == 0 && (K % 4) == 0 && (lda % 4) == 0 && (ldc % 4) == 0 &&
+  return enabled && precision() != RD_PREC_FP32 && (N % 4) == 0 && (K % 4) == 0 && (lda % 4) == 0 && (ldc % 4) == 0 &&
          (kc == 5 || kc == 9);
 }
 size_t rowgemm_plane_elems(int rows, int cols) { return (size_t)((rows + 15) / 16 * 16) * ((cols + 31) / 32 * 32); }
@@ -271,6 +274,7 @@ int launch_rowgemm(long M, int N, int K, const float* A, long lda, const void* W
   a.residual = residual; a.res_ld = res_ld;
   a.drop_p = drop_p; a.drop_seed = drop_seed; a.drop_site = drop_site; a.seed_cell = seed_cell();
   a.stamps = g_rg_stamps;
+  a.one_product = precision() == RD_PREC_BF16;
   const int kc = a.KP / 32;
   if (kc == 5) return launch_rowgemm_kc<5>(a, st);
   if (kc == 9) return launch_rowgemm_kc<9>(a, st);
