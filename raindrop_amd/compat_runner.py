@@ -17,9 +17,12 @@ scalar max (`code/utils_rd.py:160` fails on numpy >= 1.24), numpy is seeded (the
 torch), and `wandb` stays disabled.
 
 The writer half (`write_dataset`) is validated against the reference's own loader in
-`tests/test_compat_dataset.py`; the end-to-end run needs BOTH a GPU and the reference tree, which
-no single machine of the build environment has (GPU boxes receive only this repo), so it is not
-part of the automated tests.
+`tests/test_compat_dataset.py`.  The end-to-end run with the HIP model needs BOTH a GPU and the reference
+tree, which no single machine of the build environment has (GPU boxes receive only this repo); what IS
+automated: `tests/test_compat_e2e.py` runs this runner end-to-end on CPU with the reference's own model
+behind the shim (script plumbing, scheduler patch, dataset files, checkpoint save/load, all five splits),
+and `tests/test_train_loop_gpu.py` drives the script's loop body (`code/Raindrop.py:290-324`) on the GPU
+through `DeviceDataset` with the HIP model.
 """
 import argparse
 import os
@@ -80,7 +83,14 @@ def write_dataset(root, dataset, n_samples, seed=0):
     return base
 
 
-def make_workspace(root, dataset, n_samples, reference, seed=0):
+HIP_SHIM = ("# drop-in shim: the training script does `from models_rd import *`\n"
+            "from raindrop_amd.models_rd import *  # noqa: F401,F403\n"
+            "from raindrop_amd.models_rd import Raindrop_v2, PositionalEncodingTF  # noqa: F401\n")
+
+
+def make_workspace(root, dataset, n_samples, reference, seed=0, model_shim=None):
+    """`model_shim`: source text of `<ws>/code/models_rd.py` (default: re-export raindrop_amd.models_rd).  The CPU plumbing
+    test passes a shim that re-exports the reference's own model instead (tests/test_compat_e2e.py)."""
     write_dataset(root, dataset, n_samples, seed)
     code = os.path.join(root, "code")
     os.makedirs(code, exist_ok=True)
@@ -90,9 +100,7 @@ def make_workspace(root, dataset, n_samples, reference, seed=0):
         if not os.path.lexists(dst):
             os.symlink(os.path.join(reference, "code", f), dst)
     with open(os.path.join(code, "models_rd.py"), "w") as fh:
-        fh.write("# drop-in shim: the training script does `from models_rd import *`\n"
-                 "from raindrop_amd.models_rd import *  # noqa: F401,F403\n"
-                 "from raindrop_amd.models_rd import Raindrop_v2, PositionalEncodingTF  # noqa: F401\n")
+        fh.write(HIP_SHIM if model_shim is None else model_shim)
     return code
 
 
@@ -123,20 +131,30 @@ def _compat_patches(seed):
     torch.optim.lr_scheduler.ReduceLROnPlateau.__init__ = init
 
 
-def run(root, dataset, n_samples, reference, seed=0, extra_argv=()):
-    code = make_workspace(root, dataset, n_samples, reference, seed)
+def run(root, dataset, n_samples, reference, seed=0, extra_argv=(), model_shim=None):
+    """Execute the reference's `code/Raindrop.py` byte-for-byte in the workspace; returns the script's globals
+    (`acc_arr`, `auprc_arr`, ... as the script leaves them)."""
+    code = make_workspace(root, dataset, n_samples, reference, seed, model_shim)
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path[:0] = [code, repo]
+    added = [code, repo]
+    sys.path[:0] = added
+    for m in ("models_rd", "utils_rd"):          # a previous run's (or the oracle's) modules of the same top-level name
+        sys.modules.pop(m, None)
     _compat_patches(seed)
     cwd = os.getcwd()
     os.chdir(code)                               # the script uses '../P19data', '../models/' (Raindrop.py:74-86)
     argv = sys.argv
     sys.argv = ["Raindrop.py", "--dataset", dataset, "--splittype", "random"] + list(extra_argv)
     try:
-        runpy.run_path(os.path.join(code, "Raindrop.py"), run_name="__main__")
+        return runpy.run_path(os.path.join(code, "Raindrop.py"), run_name="__main__")
     finally:
         sys.argv = argv
         os.chdir(cwd)
+        for a in added:
+            if a in sys.path:
+                sys.path.remove(a)
+        for m in ("models_rd", "utils_rd"):
+            sys.modules.pop(m, None)
 
 
 if __name__ == "__main__":

@@ -133,3 +133,38 @@ def evaluate_chunked(model, ds, chunk=2048):
     finally:
         model.train(was_training)
     return torch.cat(outs, 0) if outs else torch.empty((0, 0), device=ds.dev)
+
+
+@torch.no_grad()
+def evaluate_sharded(model, ds, chunk=2048, group=None):
+    """`utils_rd.evaluate_standard` (`code/utils_rd.py:310-320`) over a process group: rank r runs the
+    contiguous shard [r*ceil(N/W), ...) of the split through `evaluate_chunked`'s per-chunk forward and the logits are
+    all-gathered (RCCL over xGMI with the nccl backend) into the full [N, C] tensor on every rank -- identical to the
+    single-process result because every stage of the model is per-sample.  Without an initialised process group this
+    is `evaluate_chunked`."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return evaluate_chunked(model, ds, chunk)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    per = (ds.N + world - 1) // world
+    lo, hi = min(ds.N, rank * per), min(ds.N, (rank + 1) * per)
+    was_training = model.training
+    model.eval()
+    outs = []
+    try:
+        for a in range(lo, hi, chunk):
+            b = min(hi, a + chunk)
+            P = ds.P[:, a:b].contiguous()
+            Ptime = ds.Ptime[:, a:b].contiguous()
+            Pstatic = None if ds.Pstatic is None else ds.Pstatic[a:b].contiguous()
+            out, _, _ = model.forward(P, Pstatic, Ptime, torch.sum(Ptime > 0, dim=0))
+            outs.append(out)
+    finally:
+        model.train(was_training)
+    C = int(model.n_classes)
+    mine = torch.zeros((per, C), dtype=torch.float32, device=ds.dev)          # equal-sized shards for the collective
+    if outs:
+        mine[: hi - lo] = torch.cat(outs, 0)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    return torch.cat(parts, 0)[: ds.N]

@@ -83,3 +83,33 @@ def test_two_rank_step_equals_full_batch_step():
     dp_ = np.abs(p0 - p_ref)
     assert (dp_ > 1e-3 * 1e-3 * STEPS).mean() < 1e-3, float((dp_ > 2e-6).mean())
     assert dp_.max() <= 2.1 * 1e-3 * STEPS
+
+
+def _eval_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ret[rank] = _eval_logits(sharded=True)
+    dist.destroy_process_group()
+
+
+def _eval_logits(sharded):
+    from raindrop_amd import feed, synth
+    from tests.helpers import build_ours
+    cfg = synth.make_config("P19")
+    val = synth.make_batch(cfg, 101, seed=90)                              # odd size: the last shard is shorter
+    ds = feed.DeviceDataset(val["src"], val["times"], val["static"], None, device="cuda:0")
+    m = build_ours(cfg, synth.make_structure(cfg, "sparse"), "cuda:0", 5).eval()
+    out = feed.evaluate_sharded(m, ds, chunk=32) if sharded else feed.evaluate_chunked(m, ds, chunk=32)
+    return out.cpu().numpy().copy()
+
+
+def test_sharded_evaluate_standard_all_gathers_the_same_logits():
+    """`utils_rd.evaluate_standard` sharded over 2 ranks + logits all-gather == the single-process result, bit for bit."""
+    ref = _eval_logits(sharded=False)
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_eval_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert ret[0].shape == (101, 2)
+    assert np.array_equal(ret[0], ref) and np.array_equal(ret[1], ref)
