@@ -85,9 +85,43 @@ class DeviceDataset:
         return n
 
 
+class EpochPlanner:
+    """The reference's batch plan over a whole RUN (`code/Raindrop.py:261-307`): `idx_0` and the 3x-expanded `idx_1` are
+    created once per run and shuffled IN PLACE at the start of every epoch, so epoch k's permutation is applied on top of
+    epoch k-1's.  `next_epoch()` returns the batches of the next epoch; with the same `np.random.seed` the sequence of
+    batches over ALL epochs equals the script's (`epoch_index_plan` rebuilds the arrays and therefore only reproduces the
+    FIRST epoch of a run)."""
+
+    def __init__(self, ytrain, batch_size=128, strategy=2, n_total=None):
+        y = np.asarray(ytrain).reshape(-1)
+        self.idx_0 = np.where(y == 0)[0]
+        self.idx_1 = np.where(y == 1)[0]
+        self.expanded = np.concatenate([self.idx_1, self.idx_1, self.idx_1], axis=0)
+        self.batch_size, self.strategy = int(batch_size), int(strategy)
+        self.n = len(y) if n_total is None else int(n_total)
+        half = int(batch_size / 2)
+        self.n_batches = {1: 10, 3: 30}.get(self.strategy) if self.strategy != 2 else \
+            int(np.min([len(self.idx_0) // half, len(self.expanded) // half]))
+        if self.strategy not in (1, 2, 3):
+            raise ValueError("strategy must be 1, 2 or 3")
+
+    def next_epoch(self):
+        half = int(self.batch_size / 2)
+        if self.strategy == 2:
+            np.random.shuffle(self.expanded)                     # in place, cumulative over epochs (Raindrop.py:293-296)
+            np.random.shuffle(self.idx_0)
+            return [np.concatenate([self.idx_0[n * half:(n + 1) * half], self.expanded[n * half:(n + 1) * half]], axis=0)
+                    for n in range(self.n_batches)]
+        if self.strategy == 3:
+            return [np.random.choice(list(range(self.n)), size=self.batch_size, replace=False) for _ in range(30)]
+        return [np.concatenate([np.random.choice(self.idx_0, size=half, replace=False),
+                                np.random.choice(self.idx_1, size=half, replace=False)], axis=0) for _ in range(10)]
+
+
 def epoch_index_plan(ytrain, batch_size=128, strategy=2, n_total=None):
-    """The batches of ONE epoch as the reference draws them (`code/Raindrop.py:262-307`), using the global
-    numpy RNG exactly like the script (call `np.random.seed` first for reproducibility).
+    """The batches of the FIRST epoch of a run as the reference draws them (`code/Raindrop.py:262-307`), using the global
+    numpy RNG exactly like the script (call `np.random.seed` first for reproducibility).  Later epochs of the script
+    shuffle the arrays of the previous epoch in place: use `EpochPlanner` for a multi-epoch run.
       strategy 2 (P12/P19): minority class repeated 3x, both classes shuffled (positives first, then
         negatives -- the order of the two `np.random.shuffle` calls matters), batch n = batch_size/2
         negatives ++ batch_size/2 positives, `min(n0, 3*n1) // (batch_size/2)` batches;

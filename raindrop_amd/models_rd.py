@@ -69,7 +69,11 @@ class Raindrop_v2(nn.Module):
 
     def __init__(self, d_inp=36, d_model=64, nhead=4, nhid=128, nlayers=2, dropout=0.3, max_len=215,
                  d_static=9, MAX=100, perc=0.5, aggreg='mean', n_classes=2, global_structure=None,
-                 sensor_wise_mask=False, static=True):
+                 sensor_wise_mask=False, static=True, freeze_R_u=False):
+        """Positional signature of code/models_rd.py:208-209.  `freeze_R_u` (keyword, not in the reference): the
+        upstream GPU run builds `R_u = Parameter(...).cuda()`, a NON-leaf tensor -- it never reaches the optimizer or
+        the state_dict and keeps its initial value.  Here R_u is a registered, trained Parameter
+        (the evident intent); `freeze_R_u=True` restores the upstream dynamics (requires_grad=False, still saved)."""
         super().__init__()
         from torch.nn import TransformerEncoder, TransformerEncoderLayer
         self.model_type = 'Transformer'
@@ -114,6 +118,17 @@ class Raindrop_v2(nn.Module):
         self._graph_cache = None
         self._drop_calls = 0
         self.init_weights()
+        if freeze_R_u:
+            self.R_u.requires_grad_(False)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """Checkpoints written by the reference on a GPU have no `R_u` entry (non-leaf tensor, see __init__): loading
+        them keeps this model's R_u instead of failing `strict=True`."""
+        key = prefix + "R_u"
+        if key not in state_dict:
+            state_dict = dict(state_dict)
+            state_dict[key] = self.R_u.detach()
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
     def init_weights(self):
         """code/models_rd.py:271-276."""
@@ -149,7 +164,7 @@ class Raindrop_v2(nn.Module):
                                         "Linear(max_len*d_ob, .)" % (maxlen, self.max_len))
         p_drop = float(self.dropout.p) if self.training else 0.0
         self._drop_calls += 1
-        seed = (torch.initial_seed() * 1000003 + self._drop_calls) & 0x7FFFFFFFFFFFFFFF
+        seed = (torch.initial_seed() * 1000003 + self._drop_calls + ops.rank_seed_offset()) & 0x7FFFFFFFFFFFFFFF
         lengths = lengths.to(device=dev, dtype=torch.int64)
         z, mask = ops.sensor_stage(
             src.float(), times.float(), lengths, self.pos_encoder.timescales(dev), g["ssum"], self.R_u,

@@ -34,6 +34,16 @@ def _check(*tensors, dtype=torch.float32):
             raise _lib.RaindropHipError("tensor must be contiguous")
 
 
+def rank_seed_offset():
+    """Added to every dropout seed: data-parallel ranks must draw DIFFERENT masks (the masks are functions of
+    (seed, site, local element index), so equal seeds would give sample b of every rank the same mask, which is not
+    what one process with the global batch does)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank() * 0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFFF
+    return 0
+
+
 def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 

@@ -40,7 +40,8 @@ class TrainStep:
         self.lib = _lib.load()
         cfgp = float(model.dropout.p) if p_drop is None else float(p_drop)
         self.p_drop = cfgp if model.training else 0.0
-        self.seed = int(seed)
+        self.seed = (int(seed) + ops.rank_seed_offset()) & 0x7FFFFFFFFFFFFFFF     # ranks draw different dropout masks
+        self._validate(model, batch)
         T, B = batch["src"].shape[0], batch["src"].shape[1]
         self.T, self.B = T, B
         self.shp = _lib.shape(B, T, model.d_inp, model.d_ob, d_pe=model.d_pe, nhead=model.nhead, nhid=model.nhid,
@@ -56,9 +57,37 @@ class TrainStep:
         self.G = gview
         self._alloc()
         self.seed_cell = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self._ptrs = self._param_ptrs()                          # the captured graph / cached structs hold these addresses
         self.graph = None
         if use_graph:
             self._capture()
+
+    @staticmethod
+    def _validate(model, batch):
+        """The step hands raw data_ptr()s to the C-ABI: everything the autograd wrappers check per call is checked here
+        once (dtype, contiguity, device, shapes, label range).  Labels are read on the host ONCE, at construction."""
+        T, B = batch["src"].shape[0], batch["src"].shape[1]
+        want = {"src": (torch.float32, (T, B, 2 * model.d_inp)), "times": (torch.float32, (T, B)),
+                "lengths": (torch.int64, (B,)), "y": (torch.int64, (B,))}
+        if model.static:
+            want["static"] = (torch.float32, (B, model.d_static))
+        dev = batch["src"].device
+        for k, (dt, shape) in want.items():
+            t = batch.get(k)
+            if t is None or not t.is_cuda or t.device != dev:
+                raise _lib.RaindropHipError("TrainStep: batch[%r] must be a tensor on %s" % (k, dev))
+            if t.dtype != dt or tuple(t.shape) != shape or not t.is_contiguous():
+                raise _lib.RaindropHipError("TrainStep: batch[%r] must be contiguous %s %s, got %s %s" % (
+                    k, dt, shape, t.dtype, tuple(t.shape)))
+        if T != model.max_len:
+            raise _lib.RaindropHipError("TrainStep: src.shape[0] (%d) must equal max_len (%d)" % (T, model.max_len))
+        if B > 0:
+            lo, hi = int(batch["y"].min()), int(batch["y"].max())
+            if lo < 0 or hi >= model.n_classes:
+                raise _lib.RaindropHipError("TrainStep: labels must lie in [0, %d), got [%d, %d]" % (model.n_classes, lo, hi))
+
+    def _param_ptrs(self):
+        return tuple(p.data_ptr() for p in self.P.values()) + tuple(g.data_ptr() for g in self.G.values())
 
     # ------------------------------------------------------------------------------------------
     def _alloc(self):
@@ -184,6 +213,9 @@ class TrainStep:
     # ------------------------------------------------------------------------------------------
     def run(self):
         """One forward + loss + backward; gradients land in flat.flat (p.grad views point there)."""
+        if self._param_ptrs() != self._ptrs:
+            raise _lib.RaindropHipError("TrainStep: a parameter or gradient buffer moved since construction (model.to(), "
+                                        "flatten_parameters() or a re-assignment): build a new TrainStep")
         if self.graph is not None:
             self.graph.replay()
         else:

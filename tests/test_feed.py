@@ -64,6 +64,47 @@ def test_index_plan_matches_reference_script_lines():
         assert np.array_equal(a, b)
 
 
+@pytest.mark.skipif(not os.path.isfile(REF), reason="reference tree not present (GPU box)")
+def test_epoch_planner_matches_reference_script_over_several_epochs():
+    """The script shuffles `expanded_idx_1` / `idx_0` IN PLACE every epoch (`code/Raindrop.py:292-296`): epoch k's order is
+    a permutation of epoch k-1's.  `feed.EpochPlanner` must reproduce the batches of every epoch, not only the first;
+    checked against the reference's own statements, extracted at test time and executed in the script's nesting."""
+    src = open(REF).read().splitlines()
+    def grab(pat):
+        hits = [ln.strip() for ln in src if re.match(pat, ln)]
+        assert hits, pat
+        return hits[0]
+    setup = [grab(p) for p in (r"^\s*idx_0 = np\.where\(ytrain == 0\)\[0\]", r"^\s*idx_1 = np\.where\(ytrain == 1\)\[0\]",
+                               r"^\s*n0, n1 = len\(idx_0\), len\(idx_1\)", r"^\s*expanded_idx_1 = np\.concatenate",
+                               r"^\s*expanded_n1 = len\(expanded_idx_1\)", r"^\s*K0 = n0 //", r"^\s*K1 = expanded_n1 //",
+                               r"^\s*n_batches = np\.min\(\[K0, K1\]\)")]
+    per_epoch = [grab(p) for p in (r"^\s*np\.random\.shuffle\(expanded_idx_1\)", r"^\s*I1 = expanded_idx_1",
+                                   r"^\s*np\.random\.shuffle\(idx_0\)", r"^\s*I0 = idx_0")]
+    per_batch = [ln.strip() for ln in src if re.match(r"^\s*idx[01]_batch = I[01]\[n \* int\(batch_size / 2\)", ln)]
+    per_batch.append(grab(r"^\s*idx = np\.concatenate\(\[idx0_batch, idx1_batch\], axis=0\)"))
+    rng = np.random.default_rng(8)
+    ytrain = (rng.random(900) < 0.08).astype(np.int64)
+    env = {"np": np, "ytrain": ytrain, "batch_size": 64}
+    np.random.seed(31)
+    exec("\n".join(setup), env)
+    ref = []
+    for epoch in range(3):
+        exec("\n".join(per_epoch), env)
+        for n in range(int(env["n_batches"])):
+            env["n"] = n
+            exec("\n".join(per_batch), env)
+            ref.append(env["idx"].copy())
+    np.random.seed(31)
+    planner = feed.EpochPlanner(ytrain, batch_size=64, strategy=2)
+    mine = [b for _ in range(3) for b in planner.next_epoch()]
+    assert len(mine) == len(ref) == 3 * planner.n_batches > 0
+    for a, b in zip(mine, ref):
+        assert np.array_equal(a, b)
+    np.random.seed(31)
+    first = feed.epoch_index_plan(ytrain, 64, 2)                 # the one-epoch helper: first epoch only
+    assert all(np.array_equal(a, b) for a, b in zip(first, ref[: len(first)]))
+
+
 def test_gather_oracle_is_fancy_indexing():
     rng = np.random.default_rng(0)
     P = rng.standard_normal((5, 9, 4)).astype(np.float32)
