@@ -247,6 +247,31 @@ int rd_batch_gather(int32_t T, int32_t B, int32_t W, int32_t d_static, int64_t N
                     float* src, float* times, float* static_out, int64_t* y_out, int64_t* lengths,
                     int32_t* bad_index_count, void* stream);
 
+/* ---- host preprocessing on the device: code/utils_rd.py:149-257, code/Raindrop.py:215-231 ------------
+ * Inputs are float64 (the reference's numpy arrays), outputs float32 (its torch.Tensor casts).  Every result is
+ * bit-identical to the reference: elementwise steps use the same IEEE float64 operations in the same order, and the
+ * statistics reproduce numpy's pairwise summation tree (raindrop_amd/csrc/rd_preprocess.hip). */
+
+/* utils_rd.getStats (:149-161): P [NT, F] (any [N,T,F] flattened) -> mf [F], stdf [F] = mean / max(population std, 1e-7)
+ * of the values > 0 of every sensor.  NT < 2^31. */
+size_t rd_prep_stats_workspace_bytes(int64_t NT, int32_t F);
+int rd_prep_stats(int64_t NT, int32_t F, const double* P, double* mf, double* stdf, void* workspace,
+                  size_t workspace_bytes, void* stream);
+/* utils_rd.mask_normalize (:164-175) + the float32 cast of tensorize_normalize (:232): P [N,T,F] f64 -> out f32 with the
+ * normalised values in channels [0,F) and the observation mask in [F,2F).  layout 0: out [N,T,2F]; layout 1: out
+ * [T,N,2F], i.e. the permute of code/Raindrop.py:232-238 fused into the store. */
+int rd_prep_mask_normalize(int64_t N, int32_t T, int32_t F, const double* P, const double* mf, const double* stdf,
+                           float* out, int32_t layout, void* stream);
+/* utils_rd.mask_normalize_static (:206-219) + float32 cast: S [N,D] f64 -> out [N,D] f32. */
+int rd_prep_static(int64_t N, int32_t D, const double* S, const double* ms, const double* ss, float* out, void* stream);
+/* `torch.Tensor(P_time) / 60.0` (:235,253): minutes [N,T] f64 -> hours f32, [N,T] (layout 0) or [T,N] (layout 1). */
+int rd_prep_time(int64_t N, int32_t T, const double* minutes, float* hours, int32_t layout, void* stream);
+/* Setting 2 / 3 (code/Raindrop.py:215-231): zero k value channels of every sample of P f32 ([N,T,2F] layout 0 or
+ * [T,N,2F] layout 1) in place; idx int32 [N,k] (per_sample = 1: the per-patient np.random.choice draws, made by the
+ * host in the reference's order) or [k] (per_sample = 0: the same top-ranked set for every sample). */
+int rd_prep_remove_features(int64_t N, int32_t T, int32_t F, float* P, const int32_t* idx, int32_t k, int32_t per_sample,
+                            int32_t layout, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

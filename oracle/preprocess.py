@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's host preprocessing.
 
-Only `tests/` may import this module.  No device kernel exists for this row yet: this file and its pinning
-tests are the oracle the device version will be built against (the order the tier prescribes: oracle first).
+Only `tests/` may import this module.  The device version is `raindrop_amd/preprocess.py` over `rd_prep_*`
+(raindrop_amd/csrc/rd_preprocess.hip); `tests/test_preprocess_gpu.py` compares it with this file bit for bit.
 
 Follows `code/utils_rd.py:149-257` (statistics, masking normalisation, tensorisation) and the Setting-2/3
 feature removal of `code/Raindrop.py:215-231`, vectorised, with every quirk of the originals kept:

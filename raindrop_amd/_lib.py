@@ -70,6 +70,12 @@ SIGNATURES = {
     "rd_linear_bwd_input_gated": (c_int32, [c_int32, c_int32, c_int32, _P, c_int32, _P, _P, c_int32, _P, c_int32, _P]),
     "rd_softmax_xent": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _P]),
     "rd_batch_gather": (c_int32, [c_int32, c_int32, c_int32, c_int32, ctypes.c_int64] + [_P] * 12),
+    "rd_prep_stats_workspace_bytes": (c_size_t, [ctypes.c_int64, c_int32]),
+    "rd_prep_stats": (c_int32, [ctypes.c_int64, c_int32, _P, _P, _P, _P, c_size_t, _P]),
+    "rd_prep_mask_normalize": (c_int32, [ctypes.c_int64, c_int32, c_int32, _P, _P, _P, _P, c_int32, _P]),
+    "rd_prep_static": (c_int32, [ctypes.c_int64, c_int32, _P, _P, _P, _P, _P]),
+    "rd_prep_time": (c_int32, [ctypes.c_int64, c_int32, _P, _P, c_int32, _P]),
+    "rd_prep_remove_features": (c_int32, [ctypes.c_int64, c_int32, c_int32, _P, _P, c_int32, c_int32, c_int32, _P]),
     "rd_linear_bwd_weight_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "rd_linear_bwd_weight": (c_int32, [c_int32, c_int32, c_int32, _P, c_int32, _P, c_int32, _P, _P,
                                         _P, c_size_t, _P]),
