@@ -247,6 +247,31 @@ int rd_batch_gather(int32_t T, int32_t B, int32_t W, int32_t d_static, int64_t N
                     float* src, float* times, float* static_out, int64_t* y_out, int64_t* lengths,
                     int32_t* bad_index_count, void* stream);
 
+/* ---- paper-faithful graph operator: the use_beta branch of Observation_progation.message,
+ * code/Ob_propagation.py:161-185,190-191,195,200,207-208,227, batched over B sample graphs that share an edge list.
+ *   V [B,N,K] = relu(lin_value(x)),  H [B,N,T*32] = increase_dim(x)   (both per NODE: rd_linear_fwd)
+ *   beta[i,t] = mean_c H[i,t,c] * cat(map_weights[i], p_t[t])[c];  gamma[e,t] = beta[tgt(e),t] * w[e]
+ *   keep the int(E*0.5) edges with the largest mean score, in descending order (ties: lower edge id first);
+ *   softmax of gamma per channel over the kept edges of one SOURCE node;  out[n] = sum_{kept e: src(e)=n} softmax[e] (.) V[tgt(e)]
+ * edge_index int64, rows [source; target] `row_stride` apart; edge_weights [E] per sample (stride w_bstride floats, 0 =
+ * shared); p_t [T,16] per sample (stride pt_bstride floats, 0 = shared).  Outputs: out [B,N,K]; edge_index_out
+ * [B][2,Kk] int64 and alpha_out [B][Kk] (the pruned edges in pruning order and their mean scores: what the reference
+ * returns as (self.edge_index, self._alpha)), Kk = rd_graph_beta_kept(E); beta_save [B,N,T] and kept int32 [B,Kk] are
+ * handed to the backward.  N <= 64, E <= 4096 (one workgroup per graph, graph staged in LDS); d_ob must be 4. */
+int32_t rd_graph_beta_kept(int32_t E);
+int rd_graph_beta_fwd(int32_t B, int32_t N, int32_t K, int32_t T, int32_t d_ob, int32_t E, const float* V, const float* H,
+                      const float* map_weights, const float* p_t, int64_t pt_bstride, const int64_t* edge_index,
+                      int64_t row_stride, const float* edge_weights, int64_t w_bstride, float* out, int64_t* edge_index_out,
+                      float* alpha_out, float* beta_save, int32_t* kept, void* stream);
+/* Backward: dout [B,N,K] -> dV [B,N,K], dH [B,N,T*32], dmap_part [B,N,16] (sum over B = d map_weights), dw [B,E] or NULL. */
+int rd_graph_beta_bwd(int32_t B, int32_t N, int32_t K, int32_t T, int32_t d_ob, int32_t E, const float* V, const float* H,
+                      const float* map_weights, const float* p_t, int64_t pt_bstride, const int64_t* edge_index,
+                      int64_t row_stride, const float* edge_weights, int64_t w_bstride, const float* beta_save,
+                      const int32_t* kept, const float* dout, float* dV, float* dH, float* dmap_part, float* dw, void* stream);
+/* code/models_rd.py:345-346: distance = mean(cdist(alpha_all.T, alpha_all.T, p=2)) for alpha_all [E,B] (one column of edge
+ * scores per sample); workspace B floats.  Identically 0 on the shipped path (equal columns); evaluated here in general. */
+int rd_structure_distance(int32_t E, int32_t B, const float* alpha_all, float* workspace, float* distance, void* stream);
+
 /* ---- host preprocessing on the device: code/utils_rd.py:149-257, code/Raindrop.py:215-231 ------------
  * Inputs are float64 (the reference's numpy arrays), outputs float32 (its torch.Tensor casts).  Every result is
  * bit-identical to the reference: elementwise steps use the same IEEE float64 operations in the same order, and the

@@ -88,9 +88,7 @@ class Observation_progation(nn.Module):
         if isinstance(x, (tuple, list)):
             x = x[1]
         if use_beta:
-            raise _lib.RaindropHipError(
-                "RD_EUNSUPPORTED: the use_beta branch (code/Ob_propagation.py:161-185) is dead by "
-                "flag in the shipped model (code/models_rd.py:317) and not built yet")
+            return self._forward_beta(x, p_t, edge_index, edge_weights, return_attention_weights)
         if edge_weights is None:
             raise ValueError("edge_weights is required (the reference raises UnboundLocalError at "
                              "code/Ob_propagation.py:193 without it)")
@@ -103,6 +101,25 @@ class Observation_progation(nn.Module):
         out = out.view(-1, self.heads * self.out_channels) if self.concat else out
         if isinstance(return_attention_weights, bool):
             return out, (edge_index, edge_weights.unsqueeze(-1))
+        return out
+
+    def _forward_beta(self, x, p_t, edge_index, edge_weights, return_attention_weights):
+        """use_beta branch (code/Ob_propagation.py:161-185,190-191,195,200,207-208,227): per-time-step edge scores
+        beta * w, pruning to the top half of the edges, per-channel softmax over the edges of a SOURCE node, aggregation
+        of the TARGETS' values.  lin_value and increase_dim run once per node (rd_linear_fwd); the graph part is
+        rd_graph_beta_fwd.  Returns out [N,K] or (out, (edge_index' [2,E/2], alpha [E/2])) like the reference."""
+        if edge_weights is None:
+            raise ValueError("edge_weights is required on the use_beta branch")
+        if self.heads != 1:
+            raise _lib.RaindropHipError("RD_EUNSUPPORTED: heads != 1")
+        V = ops.linear(x, self.lin_value.weight, self.lin_value.bias, act=1)
+        H = ops.linear(x, self.increase_dim.weight, self.increase_dim.bias)
+        out, ei2, alpha = ops.graph_beta(V.unsqueeze(0), H.unsqueeze(0), self.map_weights, p_t.unsqueeze(0).float(), edge_index,
+                                         edge_weights.reshape(1, -1).float(), self.ob_dim)
+        out = out[0]
+        out = out.view(-1, self.heads * self.out_channels) if self.concat else out
+        if isinstance(return_attention_weights, bool):
+            return out, (ei2[0], alpha[0])
         return out
 
     def __repr__(self):

@@ -70,6 +70,12 @@ SIGNATURES = {
     "rd_linear_bwd_input_gated": (c_int32, [c_int32, c_int32, c_int32, _P, c_int32, _P, _P, c_int32, _P, c_int32, _P]),
     "rd_softmax_xent": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _P]),
     "rd_batch_gather": (c_int32, [c_int32, c_int32, c_int32, c_int32, ctypes.c_int64] + [_P] * 12),
+    "rd_graph_beta_kept": (c_int32, [c_int32]),
+    "rd_graph_beta_fwd": (c_int32, [c_int32] * 6 + [_P, _P, _P, _P, ctypes.c_int64, _P, ctypes.c_int64, _P, ctypes.c_int64]
+                          + [_P] * 5 + [_P]),
+    "rd_graph_beta_bwd": (c_int32, [c_int32] * 6 + [_P, _P, _P, _P, ctypes.c_int64, _P, ctypes.c_int64, _P, ctypes.c_int64]
+                          + [_P] * 7 + [_P]),
+    "rd_structure_distance": (c_int32, [c_int32, c_int32, _P, _P, _P, _P]),
     "rd_prep_stats_workspace_bytes": (c_size_t, [ctypes.c_int64, c_int32]),
     "rd_prep_stats": (c_int32, [ctypes.c_int64, c_int32, _P, _P, _P, _P, c_size_t, _P]),
     "rd_prep_mask_normalize": (c_int32, [ctypes.c_int64, c_int32, c_int32, _P, _P, _P, _P, c_int32, _P]),

@@ -1,0 +1,360 @@
+// rd_graph_beta.hip -- the paper-faithful graph operator of Observation_progation as ONE batched
+// kernel, one workgroup per sample graph with the graph staged in LDS:
+//   code/Ob_propagation.py:161-185  per-edge, per-time-step scores  gamma[e, t] = beta[tgt(e), t] * w[e]
+//                                   beta[i, t] = mean_c( increase_dim(x_i)[t, c] * cat(map_weights[i], p_t[t])[c] )   (32 channels)
+//   :179-185                        prune to the top half of the edges by mean score (descending), REORDER them that way
+//   :184,195                        softmax of the kept scores per channel, normalised over the edges of one SOURCE node
+//   :200,208,227                    out[n] = sum_{kept e: src(e) = n} softmax(gamma)[e] (.) relu(lin_value(x_tgt(e)))
+// Every per-edge quantity of the reference depends on the edge only through (target, weight), so lin_value and
+// increase_dim run once per NODE (rd_linear_fwd) and this kernel does the genuinely graph-shaped part: scores, an LDS
+// bitonic sort for the pruning, per-source per-time-step softmax, neighbour aggregation; backward likewise.
+// Also here: the structure-distance regulariser of code/models_rd.py:345-346, mean pairwise L2 distance between the
+// samples' edge-score vectors (identically 0 on the shipped path, non-trivial as soon as the scores differ per sample).
+// Ties in the pruning sort are broken by edge order (lower edge id first).
+#include "rd_common.h"
+
+namespace rd {
+namespace {
+
+constexpr int GB_THR = 256;
+constexpr int GB_MAXE = 4096;            // edges per graph held in LDS (N <= 64 nodes)
+constexpr int GB_MAXN = 64;
+
+struct BetaArgs {
+  const float *V, *H;                    // [B,N,K] relu(lin_value(x)),  [B,N,T*32] increase_dim(x)
+  const float *map_w, *p_t;              // [N,16], [B or 1][T,16]
+  const int64_t* ei; int64_t ei_stride;  // edge_index rows (source; target), shared by the batch
+  const float* w; long w_bstride;        // [E] edge weights (per-sample stride, 0 = shared)
+  long pt_bstride;
+  float* out;                            // [B,N,K]
+  int64_t* ei_out; float* alpha_out;     // [B][2,Kk] kept edges in pruning order, [B][Kk] mean kept score
+  float* beta_save;                      // [B,N,T]
+  int32_t* kept;                         // [B][Kk] original edge ids in pruning order (for backward)
+  // backward
+  const float* dout; float *dV, *dH, *dmap_part, *dw;   // dmap_part [B,N,16]; dw [B,E] or null
+  int B, N, K, T, d, E, Kk;
+};
+
+__device__ __forceinline__ unsigned sortable_desc(float x) {          // larger float -> smaller key
+  unsigned u = __float_as_uint(x);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);                     // ascending order-preserving map
+  return ~u;
+}
+
+// shared LDS layout helpers
+struct Lds {
+  float* beta;              // [N][T]
+  unsigned long long* keys; // [P2]
+  int* ksrc; int* ktgt; float* kw;   // kept edges, pruning order [Kk]
+  int* soff; int* slist;    // per-source lists of kept positions: soff [N+1], slist [Kk]
+  int* toff; int* tlist;    // per-target lists
+  float* mx; float* inv;    // [N][T] softmax max / 1/(Z + 1e-16) per source and time step
+  float* S; float* db;      // backward: [N][T] sum_e weight * dweight per source; dbeta / 32 per target
+};
+
+__device__ Lds carve(unsigned char* base, int N, int T, int P2, int Kk) {
+  Lds l; size_t off = 0;
+  auto take = [&](size_t bytes) { void* p = base + off; off += (bytes + 15) & ~(size_t)15; return p; };
+  l.beta = (float*)take((size_t)N * T * 4);
+  l.keys = (unsigned long long*)take((size_t)P2 * 8);
+  l.ksrc = (int*)take((size_t)Kk * 4); l.ktgt = (int*)take((size_t)Kk * 4); l.kw = (float*)take((size_t)Kk * 4);
+  l.soff = (int*)take((size_t)(N + 1) * 4); l.slist = (int*)take((size_t)Kk * 4);
+  l.toff = (int*)take((size_t)(N + 1) * 4); l.tlist = (int*)take((size_t)Kk * 4);
+  l.mx = (float*)take((size_t)N * T * 4); l.inv = (float*)take((size_t)N * T * 4);
+  l.S = (float*)take((size_t)N * T * 4); l.db = (float*)take((size_t)N * T * 4);
+  return l;
+}
+size_t lds_bytes(int N, int T, int P2, int Kk) {
+  auto r = [](size_t b) { return (b + 15) & ~(size_t)15; };
+  return r((size_t)N * T * 4) * 5 + r((size_t)P2 * 8) + r((size_t)Kk * 4) * 5 + r((size_t)(N + 1) * 4) * 2;
+}
+
+// per-node lists (by source or by target) of kept positions, in pruning order: thread n scans the kept edges
+__device__ void build_lists(const int* key, int Kk, int N, int* off, int* list, int tid) {
+  // counts
+  for (int n = tid; n < N; n += GB_THR) {
+    int c = 0;
+    for (int e = 0; e < Kk; ++e) c += key[e] == n;
+    off[n + 1] = c;
+  }
+  __syncthreads();
+  if (tid == 0) { off[0] = 0; for (int n = 0; n < N; ++n) off[n + 1] += off[n]; }
+  __syncthreads();
+  for (int n = tid; n < N; n += GB_THR) {
+    int w = off[n];
+    for (int e = 0; e < Kk; ++e) if (key[e] == n) list[w++] = e;
+  }
+  __syncthreads();
+}
+
+// softmax statistics per (source n, time step t) over n's kept edges: mx, inv = 1 / (sum exp(g - mx) + 1e-16)
+__device__ void softmax_stats(const Lds& l, int N, int T, int tid) {
+  for (int i = tid; i < N * T; i += GB_THR) {
+    const int n = i / T, t = i - n * T;
+    float m = -INFINITY;
+    for (int q = l.soff[n]; q < l.soff[n + 1]; ++q) { const int e = l.slist[q]; m = fmaxf(m, l.beta[l.ktgt[e] * T + t] * l.kw[e]); }
+    float z = 0.f;
+    for (int q = l.soff[n]; q < l.soff[n + 1]; ++q) { const int e = l.slist[q]; z += expf(l.beta[l.ktgt[e] * T + t] * l.kw[e] - m); }
+    l.mx[i] = m; l.inv[i] = 1.0f / (z + 1e-16f);
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(GB_THR) void k_graph_beta_fwd(BetaArgs a, int P2) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int N = a.N, T = a.T, K = a.K, d = a.d, E = a.E, Kk = a.Kk;
+  Lds l = carve(gsm, N, T, P2, Kk);
+  const float* H = a.H + (size_t)b * N * T * 32;
+  const float* V = a.V + (size_t)b * N * K;
+  const float* pt = a.p_t + (size_t)b * a.pt_bstride;
+  const float* w = a.w + (size_t)b * a.w_bstride;
+  // ---- beta[i][t] = mean over 32 channels of increase_dim(x_i)[t] * cat(map_weights[i], p_t[t]) ----
+  for (int i = tid; i < N * T; i += GB_THR) {
+    const int n = i / T, t = i - n * T;
+    const float* h = H + ((size_t)n * T + t) * 32;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) s += h[c] * a.map_w[n * 16 + c];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) s += h[16 + c] * pt[t * 16 + c];
+    const float bt = s * (1.0f / 32.0f);
+    l.beta[i] = bt;
+    a.beta_save[(size_t)b * N * T + i] = bt;
+  }
+  __syncthreads();
+  // ---- mean score of every edge, descending bitonic sort (ties: lower edge id first) ----
+  for (int e = tid; e < P2; e += GB_THR) {
+    unsigned long long key = ~0ull;                                   // padding sorts last
+    if (e < E) {
+      const int tg = (int)a.ei[a.ei_stride + e];
+      float s = 0.f;
+      for (int t = 0; t < T; ++t) s += l.beta[tg * T + t] * w[e];
+      s = s / (float)T;                                               // == mean over the K = T*d repeated channels
+      key = ((unsigned long long)sortable_desc(s) << 32) | (unsigned)e;
+    }
+    l.keys[e] = key;
+  }
+  __syncthreads();
+  for (int k = 2; k <= P2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < P2; i += GB_THR) {
+        const int p = i ^ j;
+        if (p > i) {
+          const unsigned long long x = l.keys[i], y = l.keys[p];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) { l.keys[i] = y; l.keys[p] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  // ---- kept edges in pruning order ----
+  for (int q = tid; q < Kk; q += GB_THR) {
+    const int e = (int)(l.keys[q] & 0xFFFFFFFFu);
+    const int sr = (int)a.ei[e], tg = (int)a.ei[a.ei_stride + e];
+    l.ksrc[q] = sr; l.ktgt[q] = tg; l.kw[q] = w[e];
+    a.kept[(size_t)b * Kk + q] = e;
+    a.ei_out[(size_t)b * 2 * Kk + q] = sr; a.ei_out[(size_t)b * 2 * Kk + Kk + q] = tg;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += l.beta[tg * T + t] * w[e];
+    a.alpha_out[(size_t)b * Kk + q] = s / (float)T;                  // self._alpha = mean(gamma[top], -1)  (:191)
+  }
+  __syncthreads();
+  build_lists(l.ksrc, Kk, N, l.soff, l.slist, tid);
+  softmax_stats(l, N, T, tid);
+  // ---- out[n][k] = sum over n's kept out-edges of softmax weight[e][t(k)] * V[tgt(e)][k] ----
+  float* out = a.out + (size_t)b * N * K;
+  for (int i = tid; i < N * K; i += GB_THR) {
+    const int n = i / K, k = i - n * K, t = k / d;
+    const float m = l.mx[n * T + t], iv = l.inv[n * T + t];
+    float acc = 0.f;
+    for (int q = l.soff[n]; q < l.soff[n + 1]; ++q) {
+      const int e = l.slist[q], tg = l.ktgt[e];
+      acc += expf(l.beta[tg * T + t] * l.kw[e] - m) * iv * V[(size_t)tg * K + k];
+    }
+    out[i] = acc;
+  }
+}
+
+__global__ __launch_bounds__(GB_THR) void k_graph_beta_bwd(BetaArgs a, int P2) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int N = a.N, T = a.T, K = a.K, d = a.d, Kk = a.Kk;
+  Lds l = carve(gsm, N, T, P2, Kk);
+  float* S = l.S;
+  const float* H = a.H + (size_t)b * N * T * 32;
+  const float* V = a.V + (size_t)b * N * K;
+  const float* dout = a.dout + (size_t)b * N * K;
+  const float* pt = a.p_t + (size_t)b * a.pt_bstride;
+  const float* w = a.w + (size_t)b * a.w_bstride;
+  for (int i = tid; i < N * T; i += GB_THR) l.beta[i] = a.beta_save[(size_t)b * N * T + i];
+  for (int q = tid; q < Kk; q += GB_THR) {
+    const int e = a.kept[(size_t)b * Kk + q];
+    l.ksrc[q] = (int)a.ei[e]; l.ktgt[q] = (int)a.ei[a.ei_stride + e]; l.kw[q] = w[e];
+  }
+  __syncthreads();
+  build_lists(l.ksrc, Kk, N, l.soff, l.slist, tid);
+  build_lists(l.ktgt, Kk, N, l.toff, l.tlist, tid);
+  softmax_stats(l, N, T, tid);
+  auto weight = [&](int e, int t) {
+    const int n = l.ksrc[e];
+    return expf(l.beta[l.ktgt[e] * T + t] * l.kw[e] - l.mx[n * T + t]) * l.inv[n * T + t];
+  };
+  auto dwgt = [&](int e, int t) {                                    // d loss / d weight[e][t] = sum_c dout[src][td+c] * V[tgt][td+c]
+    const float* po = dout + (size_t)l.ksrc[e] * K + t * d;
+    const float* pv = V + (size_t)l.ktgt[e] * K + t * d;
+    float s = 0.f;
+    for (int c = 0; c < d; ++c) s += po[c] * pv[c];
+    return s;
+  };
+  // S[n][t] = sum over n's out-edges of weight * dweight
+  for (int i = tid; i < N * T; i += GB_THR) {
+    const int n = i / T, t = i - n * T;
+    float s = 0.f;
+    for (int q = l.soff[n]; q < l.soff[n + 1]; ++q) { const int e = l.slist[q]; s += weight(e, t) * dwgt(e, t); }
+    S[i] = s;
+  }
+  __syncthreads();
+  // dV[i][k] = sum over kept edges INTO i of weight[e][t(k)] * dout[src(e)][k]
+  float* dV = a.dV + (size_t)b * N * K;
+  for (int i = tid; i < N * K; i += GB_THR) {
+    const int n = i / K, k = i - n * K, t = k / d;
+    float acc = 0.f;
+    for (int q = l.toff[n]; q < l.toff[n + 1]; ++q) { const int e = l.tlist[q]; acc += weight(e, t) * dout[(size_t)l.ksrc[e] * K + k]; }
+    dV[i] = acc;
+  }
+  // dbeta[i][t] = sum over kept edges into i of w[e] * dg[e][t],  dg = weight * (dweight - S[src])
+  // dH[i][t][c] = dbeta * aa[c] / 32;  dmap[i][c<16] = sum_t dbeta * H[i][t][c] / 32
+  float* dH = a.dH + (size_t)b * N * T * 32;
+  for (int i = tid; i < N * T; i += GB_THR) {
+    const int n = i / T, t = i - n * T;
+    float s = 0.f;
+    for (int q = l.toff[n]; q < l.toff[n + 1]; ++q) {
+      const int e = l.tlist[q];
+      s += l.kw[e] * (weight(e, t) * (dwgt(e, t) - S[l.ksrc[e] * T + t]));
+    }
+    const float db = s * (1.0f / 32.0f);
+    float* ph = dH + ((size_t)n * T + t) * 32;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) ph[c] = db * a.map_w[n * 16 + c];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) ph[16 + c] = db * pt[t * 16 + c];
+    l.db[i] = db;
+  }
+  __syncthreads();
+  for (int i = tid; i < N * 16; i += GB_THR) {
+    const int n = i >> 4, c = i & 15;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += l.db[n * T + t] * H[((size_t)n * T + t) * 32 + c];
+    a.dmap_part[(size_t)b * N * 16 + i] = s;
+  }
+  // d loss / d w[e] = sum_t dg[e][t] * beta[tgt][t] for kept edges, 0 for pruned ones
+  if (a.dw) {
+    float* dw = a.dw + (size_t)b * a.E;
+    for (int e = tid; e < a.E; e += GB_THR) dw[e] = 0.f;
+    __syncthreads();
+    for (int q = tid; q < Kk; q += GB_THR) {
+      float s = 0.f;
+      for (int t = 0; t < T; ++t) s += weight(q, t) * (dwgt(q, t) - S[l.ksrc[q] * T + t]) * l.beta[l.ktgt[q] * T + t];
+      dw[a.kept[(size_t)b * Kk + q]] = s;
+    }
+  }
+}
+
+// mean pairwise L2 distance between the B columns of alpha_all [E, B]  (code/models_rd.py:345-346: cdist(a.T, a.T).mean()).
+// part[b] = sum_c ||alpha[:, b] - alpha[:, c]||, fixed order; k_distance_reduce sums the rows and divides by B*B.
+__global__ __launch_bounds__(256) void k_distance_rows(const float* __restrict__ alpha, int E, int B, float* __restrict__ part) {
+  __shared__ float red[256];
+  const int b = blockIdx.x;
+  float acc = 0.f;
+  for (int c = threadIdx.x; c < B; c += 256) {
+    float s = 0.f;
+    for (int e = 0; e < E; ++e) { const float df = alpha[(size_t)e * B + b] - alpha[(size_t)e * B + c]; s += df * df; }
+    acc += sqrtf(s);
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) part[b] = red[0];
+}
+__global__ __launch_bounds__(256) void k_distance_reduce(const float* __restrict__ part, int B, float* __restrict__ out) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) acc += part[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) *out = red[0] / ((float)B * (float)B);
+}
+
+int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+int check_beta(int B, int N, int K, int T, int d, int E) {
+  RD_REQUIRE(B >= 0 && N > 0 && K > 0 && T > 0 && d > 0 && E >= 0, "bad dims");
+  RD_REQUIRE(T * d == K, "K (%d) must equal T*d_ob (%d*%d)", K, T, d);
+  if (d * 8 != 32) return fail(RD_EUNSUPPORTED, "the beta branch needs d_ob == 4 (increase_dim output viewed as [T, 32], Ob_propagation.py:165)");
+  if (N > GB_MAXN || E > GB_MAXE) return fail(RD_EUNSUPPORTED, "graph too large for the LDS-staged kernel (N <= %d, E <= %d)", GB_MAXN, GB_MAXE);
+  return RD_OK;
+}
+
+}  // namespace
+}  // namespace rd
+
+using namespace rd;
+
+extern "C" int32_t rd_graph_beta_kept(int32_t E) { return (int32_t)((double)E * 0.5); }      /* K = int(E * 0.5), :180 */
+
+extern "C" int rd_graph_beta_fwd(int32_t B, int32_t N, int32_t K, int32_t T, int32_t d_ob, int32_t E, const float* V,
+                                 const float* H, const float* map_weights, const float* p_t, int64_t pt_bstride,
+                                 const int64_t* edge_index, int64_t row_stride, const float* edge_weights, int64_t w_bstride,
+                                 float* out, int64_t* edge_index_out, float* alpha_out, float* beta_save, int32_t* kept,
+                                 void* stream) {
+  int rc = check_beta(B, N, K, T, d_ob, E);
+  if (rc) return rc;
+  if (B == 0) return RD_OK;
+  RD_REQUIRE(V && H && map_weights && p_t && edge_index && edge_weights && out && edge_index_out && alpha_out && beta_save && kept,
+             "NULL tensor");
+  BetaArgs a{};
+  a.V = V; a.H = H; a.map_w = map_weights; a.p_t = p_t; a.pt_bstride = pt_bstride; a.ei = edge_index; a.ei_stride = row_stride;
+  a.w = edge_weights; a.w_bstride = w_bstride; a.out = out; a.ei_out = edge_index_out; a.alpha_out = alpha_out;
+  a.beta_save = beta_save; a.kept = kept;
+  a.B = B; a.N = N; a.K = K; a.T = T; a.d = d_ob; a.E = E; a.Kk = rd_graph_beta_kept(E);
+  const int P2 = next_pow2(E > 1 ? E : 2);
+  const size_t lds = lds_bytes(N, T, P2, a.Kk > 0 ? a.Kk : 1);
+  RD_REQUIRE(lds <= 160 * 1024, "graph does not fit LDS (%zu bytes)", lds);
+  RD_LDS_ATTR(k_graph_beta_fwd, 160 * 1024);
+  hipLaunchKernelGGL(k_graph_beta_fwd, dim3(B), dim3(GB_THR), lds, (hipStream_t)stream, a, P2);
+  return check_launch("k_graph_beta_fwd");
+}
+
+extern "C" int rd_graph_beta_bwd(int32_t B, int32_t N, int32_t K, int32_t T, int32_t d_ob, int32_t E, const float* V,
+                                 const float* H, const float* map_weights, const float* p_t, int64_t pt_bstride,
+                                 const int64_t* edge_index, int64_t row_stride, const float* edge_weights, int64_t w_bstride,
+                                 const float* beta_save, const int32_t* kept, const float* dout, float* dV, float* dH,
+                                 float* dmap_part, float* dw, void* stream) {
+  int rc = check_beta(B, N, K, T, d_ob, E);
+  if (rc) return rc;
+  if (B == 0) return RD_OK;
+  RD_REQUIRE(V && H && map_weights && p_t && edge_index && edge_weights && beta_save && kept && dout && dV && dH && dmap_part,
+             "NULL tensor");
+  BetaArgs a{};
+  a.V = V; a.H = H; a.map_w = map_weights; a.p_t = p_t; a.pt_bstride = pt_bstride; a.ei = edge_index; a.ei_stride = row_stride;
+  a.w = edge_weights; a.w_bstride = w_bstride; a.beta_save = const_cast<float*>(beta_save); a.kept = const_cast<int32_t*>(kept);
+  a.dout = dout; a.dV = dV; a.dH = dH; a.dmap_part = dmap_part; a.dw = dw;
+  a.B = B; a.N = N; a.K = K; a.T = T; a.d = d_ob; a.E = E; a.Kk = rd_graph_beta_kept(E);
+  const int P2 = next_pow2(E > 1 ? E : 2);
+  const size_t lds = lds_bytes(N, T, P2, a.Kk > 0 ? a.Kk : 1);
+  RD_REQUIRE(lds <= 160 * 1024, "graph does not fit LDS (%zu bytes)", lds);
+  RD_LDS_ATTR(k_graph_beta_bwd, 160 * 1024);
+  hipLaunchKernelGGL(k_graph_beta_bwd, dim3(B), dim3(GB_THR), lds, (hipStream_t)stream, a, P2);
+  return check_launch("k_graph_beta_bwd");
+}
+
+extern "C" int rd_structure_distance(int32_t E, int32_t B, const float* alpha_all, float* workspace, float* distance,
+                                     void* stream) {
+  RD_REQUIRE(E >= 0 && B > 0, "bad dims E=%d B=%d", E, B);
+  RD_REQUIRE(alpha_all && workspace && distance, "NULL tensor");
+  hipLaunchKernelGGL(k_distance_rows, dim3(B), dim3(256), 0, (hipStream_t)stream, alpha_all, E, B, workspace);
+  hipLaunchKernelGGL(k_distance_reduce, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, B, distance);
+  return check_launch("rd_structure_distance");
+}

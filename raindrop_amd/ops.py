@@ -247,6 +247,82 @@ def aggregate(gamma, V, skip=None):
     return _Aggregate.apply(gamma.contiguous(), V.contiguous(), None if skip is None else skip.contiguous())
 
 
+class _GraphBeta(torch.autograd.Function):
+    """The use_beta graph operator (rd_graph_beta_fwd / _bwd), batched: V [B,N,K], H [B,N,T*32], map_w [N,16],
+    p_t [B or 1, T, 16], edge_index int64 [2,E], edge_weights [B or 1, E] -> out [B,N,K], edge_index' [B,2,Kk], alpha [B,Kk]."""
+
+    @staticmethod
+    def forward(ctx, V, H, map_w, p_t, edge_index, edge_weights, d_ob):
+        _check(V, H, map_w, p_t, edge_weights)
+        _check(edge_index, dtype=torch.int64)
+        B, N, K = V.shape
+        T = K // d_ob
+        E = edge_index.shape[1]
+        lib = _lib.load()
+        Kk = int(lib.rd_graph_beta_kept(E))
+        dev = V.device
+        out = torch.empty_like(V)
+        ei_out = torch.empty((B, 2, Kk), dtype=torch.int64, device=dev)
+        alpha = torch.empty((B, Kk), dtype=torch.float32, device=dev)
+        beta = torch.empty((B, N, T), dtype=torch.float32, device=dev)
+        kept = torch.empty((B, max(Kk, 1)), dtype=torch.int32, device=dev)
+        pts = 0 if p_t.shape[0] == 1 else T * 16
+        ws = 0 if edge_weights.shape[0] == 1 else E
+        _lib.call("rd_graph_beta_fwd", B, N, K, T, d_ob, E, _ptr(V), _ptr(H), _ptr(map_w), _ptr(p_t), pts, _ptr(edge_index),
+                  edge_index.stride(0), _ptr(edge_weights), ws, _ptr(out), _ptr(ei_out), _ptr(alpha), _ptr(beta), _ptr(kept),
+                  _stream())
+        ctx.save_for_backward(V, H, map_w, p_t, edge_index, edge_weights, beta, kept)
+        ctx.dims = (B, N, K, T, d_ob, E, pts, ws)
+        ctx.mark_non_differentiable(ei_out, alpha)
+        return out, ei_out, alpha
+
+    @staticmethod
+    def backward(ctx, dout, _dei, _dalpha):
+        V, H, map_w, p_t, edge_index, edge_weights, beta, kept = ctx.saved_tensors
+        B, N, K, T, d_ob, E, pts, ws = ctx.dims
+        dout = dout.contiguous()
+        dV, dH = torch.empty_like(V), torch.empty_like(H)
+        dmap_part = torch.empty((B, N, 16), dtype=torch.float32, device=V.device)
+        want_dw = ctx.needs_input_grad[5]
+        dw = torch.empty((B, E), dtype=torch.float32, device=V.device) if want_dw else None
+        _lib.call("rd_graph_beta_bwd", B, N, K, T, d_ob, E, _ptr(V), _ptr(H), _ptr(map_w), _ptr(p_t), pts, _ptr(edge_index),
+                  edge_index.stride(0), _ptr(edge_weights), ws, _ptr(beta), _ptr(kept), _ptr(dout), _ptr(dV), _ptr(dH),
+                  _ptr(dmap_part), _ptr(dw), _stream())
+        dmap = dmap_part[0] if B == 1 else _colsum_rows(dmap_part.view(B, N * 16)).view(N, 16)
+        if want_dw and edge_weights.shape[0] == 1 and B > 1:
+            dw = _colsum_rows(dw).view(1, E)
+        return dV, dH, dmap, None, None, dw, None
+
+
+def _colsum_rows(x):
+    """Deterministic sum over the rows of a small [B, n] matrix on the device: rd_linear_bwd_weight with a ones column
+    (dW[1, n] = ones[B,1]^T x[B,n]), i.e. the library's fixed-order split reduction -- no torch math in the product."""
+    B, n = x.shape
+    ones = torch.ones((B, 1), dtype=torch.float32, device=x.device)
+    dW = torch.empty((1, n), dtype=torch.float32, device=x.device)
+    ws = _workspace(_lib.load().rd_linear_bwd_weight_workspace_bytes(B, 1, n), x.device)
+    _lib.call("rd_linear_bwd_weight", B, 1, n, _ptr(ones), 1, _ptr(x.contiguous()), n, _ptr(dW), _ptr(None), _ptr(ws), ws.numel(),
+              _stream())
+    return dW
+
+
+def graph_beta(V, H, map_w, p_t, edge_index, edge_weights, d_ob=4):
+    return _GraphBeta.apply(V.contiguous(), H.contiguous(), map_w.contiguous(), p_t.contiguous(), edge_index.contiguous(),
+                            edge_weights.contiguous(), int(d_ob))
+
+
+def structure_distance(alpha_all):
+    """code/models_rd.py:345-346: mean(cdist(alpha_all.T, alpha_all.T, p=2)) for alpha_all [E,B] (no gradient: the
+    reference's training loss does not use it, code/Raindrop.py:319-322)."""
+    a = alpha_all.detach().contiguous()
+    _check(a)
+    E, B = a.shape
+    ws = torch.empty((B,), dtype=torch.float32, device=a.device)
+    out = torch.empty((), dtype=torch.float32, device=a.device)
+    _lib.call("rd_structure_distance", E, B, _ptr(a), _ptr(ws), _ptr(out), _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # temporal stage: nn.TransformerEncoderLayer and the masked mean, on the HIP kernels
 # ------------------------------------------------------------------------------------------------

@@ -185,6 +185,48 @@ def operator_cases():
     print("operators    -> %s (%.1f KB)" % (os.path.basename(path), os.path.getsize(path) / 1024))
 
 
+def beta_batched_case():
+    """The use_beta operator applied to B sample graphs that share an edge list (what `Raindrop_v2.forward` would do per
+    sample with `use_beta=True`, code/models_rd.py:313-343), by the REFERENCE class: outputs, pruned edge lists, returned
+    scores, gradients of <y, R> w.r.t. the inputs and the four live parameter tensors, and the structure distance of the
+    returned scores (code/models_rd.py:345-346)."""
+    ref = ref_loader.load()
+    rng = np.random.default_rng(321)
+    n, T, d, B = 12, 15, 4, 5
+    K = T * d
+    op = ref.run(ref.Ob_propagation.Observation_progation, in_channels=K, out_channels=K, heads=1, n_nodes=n, ob_dim=d)
+    synth.fill_params_(op, seed=21)
+    adj = (rng.random((n, n)) * (rng.random((n, n)) < 0.6)).astype(np.float32)
+    ei, ew = O2.build_graph(adj)
+    X = torch.from_numpy(rng.standard_normal((B, n, K)).astype(np.float32)).requires_grad_(True)
+    PT = torch.from_numpy(rng.standard_normal((B, T, 16)).astype(np.float32))
+    R = torch.from_numpy(rng.standard_normal((B, n, K)).astype(np.float32))
+    ys, eis, alphas = [], [], []
+    for b in range(B):
+        y, (ei_b, a_b) = ref.run(op.forward, X[b], p_t=PT[b], edge_index=torch.from_numpy(ei), edge_weights=torch.from_numpy(ew),
+                                 use_beta=True, edge_attr=None, return_attention_weights=True)
+        ys.append(y); eis.append(ei_b); alphas.append(a_b)
+    Y = torch.stack(ys)
+    params = [op.lin_value.weight, op.lin_value.bias, op.increase_dim.weight, op.increase_dim.bias, op.map_weights]
+    grads = torch.autograd.grad((Y * R).sum(), [X] + params)
+    alpha_all = torch.stack([a.detach() for a in alphas], dim=1)                    # [Kk, B]
+    dist = torch.mean(torch.cdist(alpha_all.T, alpha_all.T, p=2))
+    # the restatement must agree sample by sample
+    for b in range(B):
+        y2, (ei2, a2) = O2.observation_propagation_beta(X[b].detach(), PT[b], torch.from_numpy(ei), torch.from_numpy(ew),
+                                                        op.lin_value.weight.detach(), op.lin_value.bias.detach(),
+                                                        op.increase_dim.weight.detach(), op.increase_dim.bias.detach(),
+                                                        op.map_weights.detach(), d)
+        assert float((y2 - ys[b].detach()).abs().max()) < 1e-6 and torch.equal(ei2, eis[b])
+    out = dict(adj=adj, X=X.detach().numpy(), PT=PT.numpy(), R=R.numpy(), Y=Y.detach().numpy(),
+               ei=torch.stack(eis).numpy(), alpha=torch.stack([a.detach() for a in alphas]).numpy(), distance=np.float32(dist.item()),
+               gX=grads[0].numpy(), gWv=grads[1].numpy(), gbv=grads[2].numpy(), gWi=grads[3].numpy(), gbi=grads[4].numpy(),
+               gmap=grads[5].numpy(), dims=np.array([n, T, d, B]))
+    path = os.path.join(HERE, "beta_batched.npz")
+    np.savez_compressed(path, **out)
+    print("beta_batched -> %s (%.1f KB), distance %.6f" % (os.path.basename(path), os.path.getsize(path) / 1024, dist.item()))
+
+
 def state_dict_surface():
     """Names and shapes of the reference's state_dict per dataset config (checkpoint surface,
     code/Raindrop.py:374,381).  Under the CPU shim `R_u` is a registered parameter."""
@@ -209,6 +251,8 @@ if __name__ == "__main__":
         operator_cases()
     if not only or "state_dict" in only:
         state_dict_surface()
+    if not only or "beta_batched" in only:
+        beta_batched_case()
     for case in MODEL_CASES:
         if not only or case[0] in only:
             model_case(*case)
