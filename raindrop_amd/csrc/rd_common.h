@@ -78,6 +78,7 @@ struct GemmArgs {
   const float* A2; const float* B2; float* C2; float* rowsum2;
   int tile_hint;                  // 1: force the 128x128 tile (split-K weight gradients: halves operand re-reads)
   int xcd_swizzle;                // set by launch_gemm (env RD_GEMM_XCD, default 1)
+  int slice_xcd;                  // set by launch_gemm: split-K slices pinned to XCDs (env RD_SPLITK_XCD, default 1)
   float* rowsum; long rowsum_split;   // optional: rowsum[z*rowsum_split + m] = sum_k A(m,k) over this split (bias
                                   // gradients ride along the weight-gradient product: no second pass over dy)
   // epilogue (ignored when nsplit > 1)

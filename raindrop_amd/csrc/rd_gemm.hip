@@ -413,15 +413,26 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
   // block is fetched into ONE L2 and re-read there by its other column blocks, and every XCD keeps
   // its own copy of the (small) weight matrix.  Pure placement hint: any mapping is correct.
   const int ncb = (g.N + TN - 1) / TN;
-  const int lin = blockIdx.x, xcd = lin & 7, jj = lin >> 3;
+  int lin = blockIdx.x;
+  const int xcd = lin & 7, jj = lin >> 3;
   // (measured: helps the single-pass products by ~10 %, hurts the split-K weight-gradient products by
   // ~40 % -- there the z-slices already spread one row block over the XCDs -- so those keep row-major order)
   const bool swz = g.nsplit <= 1 && g.xcd_swizzle;
+  // Split-K products (weight gradients): ALL output tiles of one reduction slice z run on XCD z % 8, so the slice's
+  // operand rows are fetched from HBM into one L2 once and re-read there by the other tiles (with the plain
+  // (tile, z) grid every XCD held a third of the tiles of EVERY slice and fetched most of both operands: PMC
+  // 90 MB fetched for 19-38 MB of operands).  Grid: 8 * ceil(nz / 8) * tiles workgroups in x, surplus slices exit.
+  int z = blockIdx.z;
+  if (g.slice_xcd) {
+    const int tiles = ncb * ((g.M + TM - 1) / TM);
+    z = (jj / tiles) * 8 + xcd;
+    lin = jj - (jj / tiles) * tiles;
+    if (z >= g.nsplit * (g.A2 != nullptr ? 2 : 1)) return;
+  }
   const int rblk = swz ? 8 * (jj / ncb) + xcd : lin / ncb;
   const int cblk = swz ? jj - (jj / ncb) * ncb : lin - (lin / ncb) * ncb;
   const int m0 = rblk * TM, n0 = cblk * TN;
   if (m0 >= g.M) return;                              // padding blocks of the last group of 8 row blocks
-  int z = blockIdx.z;
   if (g.A2 != nullptr && z >= g.nsplit) {             // second problem of a batched pair (uniform per block)
     z -= g.nsplit;
     g.A = g.A2; g.B = g.B2; g.C = g.C2; g.rowsum = g.rowsum2;
@@ -552,8 +563,9 @@ int launch_bf16x3_n(const GemmArgs& g, hipStream_t st) {
   const size_t planes = (size_t)2 * (TM + TN) * LDB * sizeof(__bf16);
   const size_t stage = (size_t)TM * (TN + 4) * sizeof(float);       // epilogue transpose tile (aliases the planes)
   const size_t lds = (planes > stage ? planes : stage) + TN * sizeof(float);   // + bias
-  dim3 grid((g.nsplit > 1 ? cdiv(g.M, TM) : 8 * cdiv(cdiv(g.M, TM), 8)) * cdiv(g.N, TN), 1,
-            (g.nsplit > 1 ? g.nsplit : 1) * (g.A2 ? 2 : 1));
+  const int nz = (g.nsplit > 1 ? g.nsplit : 1) * (g.A2 ? 2 : 1);
+  dim3 grid((g.nsplit > 1 ? cdiv(g.M, TM) : 8 * cdiv(cdiv(g.M, TM), 8)) * cdiv(g.N, TN), 1, nz);
+  if (g.slice_xcd) grid = dim3(8 * cdiv(nz, 8) * cdiv(g.M, TM) * cdiv(g.N, TN), 1, 1);
   if (lds > 48 * 1024)
     RD_LDS_ATTR((k_gemm_bf16x3<A_KC, B_KC, MI, NI, NPRE>), lds);
   hipLaunchKernelGGL((k_gemm_bf16x3<A_KC, B_KC, MI, NI, NPRE>), grid, dim3(256), lds, st, g);
@@ -566,6 +578,15 @@ int launch_bf16x3(const GemmArgs& g, hipStream_t st) {
   // (NPRE = tiles) is neutral at K=152 and 40 % slower at K=272 (register-limited occupancy), because
   // these products are bound by operand RE-READS at the L2 level (each 64x64 tile loads 39+39 KB to
   // write 16 KB), not by dependent latency; the looped form with one tile of lookahead stays.
+  // ... except for the handful-of-workgroups products of the classifier head (M = B = 256 rows: 12 workgroups, 3 K tiles):
+  // those are pure dependent-latency chains (measured 14-35 us for a 256 x 186 x 186 product), so the whole K range is
+  // requested up front.
+  static const bool npre_on = [] { const char* e = getenv("RD_GEMM_NPRE"); return !(e && atoi(e) == 0); }();
+  if (MI == 2 && NI == 2 && npre_on) {
+    const long blocks = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * (g.nsplit > 1 ? g.nsplit : 1) * (g.A2 ? 2 : 1);
+    const int kspan = g.nsplit > 1 ? g.k_per_split : g.K;
+    if (blocks <= 128 && kspan <= 256) return launch_bf16x3_n<A_KC, B_KC, 2, 2, 4>(g, st);
+  }
   return launch_bf16x3_n<A_KC, B_KC, MI, NI, 0>(g, st);
 }
 
@@ -693,6 +714,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (g.nsplit <= 1) { g.nsplit = 1; g.k_per_split = g.K > 0 ? g.K : 1; g.sc_split = 0; }
   if (precision() != RD_PREC_FP32) {
     g.one_product = precision() == RD_PREC_BF16;
+    static const int sx_env = [] { const char* e = getenv("RD_SPLITK_XCD"); return e ? atoi(e) : 1; }();
+    g.slice_xcd = (g.nsplit > 1 && sx_env) ? 1 : 0;
     if (g.nsplit > 1 && (g.k_per_split % BK2) != 0) return fail(RD_EINVAL, "gemm: k_per_split must be a multiple of 64");
     if (akc && bkc) return dispatch_bf16x3<true, true>(g, st);
     if (akc && !bkc) return dispatch_bf16x3<true, false>(g, st);

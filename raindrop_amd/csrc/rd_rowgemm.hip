@@ -20,9 +20,8 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int RG_ROWS = 64, RG_THR = 512, RG_WAVES = 8, RG_NJ = 2;
-constexpr int RG_CPR = RG_WAVES * RG_NJ * 16;      // 256 output columns per round
-constexpr int RG_LDS_STAGE = RG_CPR + 4;           // fp32 stage row stride
+constexpr int RG_THR = 512, RG_WAVES = 8;   // rows per workgroup: template parameter (64; 32 for the long reduction K = 3D)
+// per kernel instance: NJ column tiles per wave and round, RG_CPR = 8 * NJ * 16 output columns per round, stage row stride RG_CPR + 4
 
 static unsigned long long* g_rg_stamps = nullptr;   // debug only (tools/rowgemm_timing.py); passed as a kernel argument
 #define RGSTAMP(i)                                                                          \
@@ -41,6 +40,10 @@ struct RowGemmArgs {
   float drop_p; uint64_t drop_seed; uint32_t drop_site; const uint64_t* seed_cell;
   unsigned long long* stamps;
   int one_product;                                  // RD_PREC_BF16
+  // LayerNorm epilogue (N <= one round of columns): s = residual + dropout(A W^T + bias) -> ln_s (saved for the backward),
+  // C = LayerNorm(s) * ln_g + ln_b, (mean, rstd) -> ln_stats.  Replaces the separate add+LayerNorm kernel of the encoder
+  // layer (rd_temporal.hip k_add_ln_fwd_v: same lane <-> column assignment, same reduction order, same dropout quads).
+  const float* ln_g; const float* ln_b; float* ln_s; float* ln_stats;
 };
 
 // one weight matrix -> hi/lo planes; transpose != 0 writes split(W^T): rows k, cols n
@@ -74,11 +77,17 @@ __global__ __launch_bounds__(256) void k_wsplit(SplitJobs jobs) {
   }
 }
 
-template <int KC>
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <int KC, int RG_NJ>
 struct RPanel { bf16x8 h[RG_NJ][KC], l[RG_NJ][KC]; };
 
-template <int KC>
-__device__ __forceinline__ void rg_load_panel(RPanel<KC>& p, const __bf16* __restrict__ Wt, int tile0, int ntiles, int wave,
+template <int KC, int RG_NJ>
+__device__ __forceinline__ void rg_load_panel(RPanel<KC, RG_NJ>& p, const __bf16* __restrict__ Wt, int tile0, int ntiles, int wave,
                                               int lane) {
 #pragma unroll
   for (int jj = 0; jj < RG_NJ; ++jj) {
@@ -92,8 +101,9 @@ __device__ __forceinline__ void rg_load_panel(RPanel<KC>& p, const __bf16* __res
   }
 }
 
-template <int KC>
+template <int KC, int RG_ROWS, int RG_NJ, bool LN>
 __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
+  constexpr int RT = RG_ROWS / 16, RG_CPR = RG_WAVES * RG_NJ * 16, RG_LDS_STAGE = RG_CPR + 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
   constexpr int KPc = KC * 32, LDA = KPc + 8;       // bf16 elements per A-plane row
   __bf16* Ah = reinterpret_cast<__bf16*>(rsm);
@@ -110,31 +120,34 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
   // KC quads per thread: all of them are requested first, THEN the weight panel (loads return in issue
   // order: the rows are needed now, the panel only at the first MFMA), then the rows are split into LDS
   // while the panel streams in.
-  RPanel<KC> pw;
+  RPanel<KC, RG_NJ> pw;
   {
     constexpr int kq = KPc / 4;                                        // float4 slots per row (incl. pad)
-    float4 v[KC];
+    constexpr int NIT = (RG_ROWS * kq + RG_THR - 1) / RG_THR;          // KC at 64 rows, ceil(KC / 2) at 32
+    float4 v[NIT];
 #pragma unroll
-    for (int it = 0; it < KC; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const int i = tid + it * RG_THR;
       const int r = i / kq, k = 4 * (i - r * kq);
       v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m0 + r < a.M && k < a.K) v[it] = *reinterpret_cast<const float4*>(a.A + (long)(m0 + r) * a.lda + k);
+      if (r < RG_ROWS && m0 + r < a.M && k < a.K) v[it] = *reinterpret_cast<const float4*>(a.A + (long)(m0 + r) * a.lda + k);
     }
-    rg_load_panel<KC>(pw, a.Wh, 0, ntiles, wave, lane);
+    rg_load_panel<KC, RG_NJ>(pw, a.Wh, 0, ntiles, wave, lane);
     __builtin_amdgcn_sched_barrier(0);       // keep every request above the first use (the scheduler otherwise
                                              // waits for the rows before it has requested the panel)
     if (a.seed_cell) seed += load_uniform_u64(a.seed_cell);   // scalar path: not queued behind the panel
 #pragma unroll
-    for (int it = 0; it < KC; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const int i = tid + it * RG_THR;
       const int r = i / kq, k = 4 * (i - r * kq);
       bf16x4 h, l;
       const float x[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
 #pragma unroll
       for (int c = 0; c < 4; ++c) { h[c] = (__bf16)x[c]; l[c] = (__bf16)(x[c] - (float)h[c]); }
-      *reinterpret_cast<bf16x4*>(Ah + r * LDA + k) = h;
-      *reinterpret_cast<bf16x4*>(Al + r * LDA + k) = l;
+      if (r < RG_ROWS) {
+        *reinterpret_cast<bf16x4*>(Ah + r * LDA + k) = h;
+        *reinterpret_cast<bf16x4*>(Al + r * LDA + k) = l;
+      }
     }
   }
   RGSTAMP(1);
@@ -145,16 +158,16 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
   const int aoff = (lane & 15) * LDA + 8 * (lane >> 4);
   for (int rd = 0; rd < nrounds; ++rd) {
     const int tile0 = rd * RG_WAVES * RG_NJ;
-    f32x4 acc[RG_NJ][4];
+    f32x4 acc[RG_NJ][RT];
 #pragma unroll
     for (int jj = 0; jj < RG_NJ; ++jj)
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) acc[jj][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int rt = 0; rt < RT; ++rt) acc[jj][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
-      bf16x8 ah[4], al[4];
+      bf16x8 ah[RT], al[RT];
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
+      for (int rt = 0; rt < RT; ++rt) {
         ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * LDA + aoff + kc * 32);
         al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * LDA + aoff + kc * 32);
       }
@@ -162,34 +175,80 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
 #pragma unroll
         for (int jj = 0; jj < RG_NJ; ++jj)
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt)
+          for (int rt = 0; rt < RT; ++rt)
             acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], pw.h[jj][kc], acc[jj][rt], 0, 0, 0);
 #pragma unroll
         for (int jj = 0; jj < RG_NJ; ++jj)
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt)
+          for (int rt = 0; rt < RT; ++rt)
             acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], pw.l[jj][kc], acc[jj][rt], 0, 0, 0);
       }
 #pragma unroll
       for (int jj = 0; jj < RG_NJ; ++jj)
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
           acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], pw.h[jj][kc], acc[jj][rt], 0, 0, 0);
     }
     if (rd == 0) RGSTAMP(3);
     // next round's weights stream while this round's epilogue runs
-    if (rd + 1 < nrounds) rg_load_panel<KC>(pw, a.Wh, tile0 + RG_WAVES * RG_NJ, ntiles, wave, lane);
+    if (rd + 1 < nrounds) rg_load_panel<KC, RG_NJ>(pw, a.Wh, tile0 + RG_WAVES * RG_NJ, ntiles, wave, lane);
     // ---- accumulators -> stage tile (column = position inside this round's 256-column window) ----
 #pragma unroll
     for (int jj = 0; jj < RG_NJ; ++jj)
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt)
+      for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           stage[(rt * 16 + 4 * (lane >> 4) + r) * RG_LDS_STAGE + (wave + RG_WAVES * jj) * 16 + (lane & 15)] = acc[jj][rt][r];
     if (rd == 0) RGSTAMP(4);
     lds_barrier();
     if (rd == 0) RGSTAMP(5);
+    if constexpr (LN) {
+      // ---- LayerNorm epilogue: wave w owns rows w, w + 8, ...; lane l owns columns 4l .. 4l+3 of the row
+      constexpr int RPW = RG_ROWS / RG_WAVES;
+      const int c = 4 * lane;
+      const bool cok = c < a.N;
+      const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 xr[RPW];
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) {
+        const int m = m0 + wave + RG_WAVES * q;
+        xr[q] = zero4;
+        if (cok && m < a.M) xr[q] = *reinterpret_cast<const float4*>(a.residual + (long)m * a.res_ld + c);
+      }
+      float4 gg = zero4, bb = zero4, bs = zero4;       // (no `cond ? *p : zero4`: that becomes a pointer select + flat load)
+      if (cok) {
+        gg = *reinterpret_cast<const float4*>(a.ln_g + c);
+        bb = *reinterpret_cast<const float4*>(a.ln_b + c);
+        if (a.bias) bs = *reinterpret_cast<const float4*>(a.bias + c);
+      }
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) {
+        const int rl = wave + RG_WAVES * q;
+        const long m = m0 + rl;
+        if (m >= a.M) continue;
+        float4 t = zero4;
+        if (cok) t = *reinterpret_cast<const float4*>(stage + rl * RG_LDS_STAGE + c);
+        t.x += bs.x; t.y += bs.y; t.z += bs.z; t.w += bs.w;
+        if (a.drop_p > 0.f) {
+          const float4 u = uniform4(seed, a.drop_site, ((uint64_t)m * a.N + c) >> 2);
+          t.x *= u.x >= a.drop_p ? inv_keep : 0.f; t.y *= u.y >= a.drop_p ? inv_keep : 0.f;
+          t.z *= u.z >= a.drop_p ? inv_keep : 0.f; t.w *= u.w >= a.drop_p ? inv_keep : 0.f;
+        }
+        const float4 sv = make_float4(xr[q].x + t.x, xr[q].y + t.y, xr[q].z + t.z, xr[q].w + t.w);   // 0 beyond N
+        if (cok) *reinterpret_cast<float4*>(a.ln_s + m * a.ldc + c) = sv;
+        const float mean = wave_sum64((sv.x + sv.y) + (sv.z + sv.w)) / a.N;
+        float4 d = make_float4(sv.x - mean, sv.y - mean, sv.z - mean, sv.w - mean);
+        if (!cok) d = zero4;
+        const float rstd = rsqrtf(wave_sum64((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) / a.N + 1e-5f);
+        if (cok)
+          *reinterpret_cast<float4*>(a.C + m * a.ldc + c) =
+              make_float4(d.x * rstd * gg.x + bb.x, d.y * rstd * gg.y + bb.y, d.z * rstd * gg.z + bb.z, d.w * rstd * gg.w + bb.w);
+        if (lane == 0) { a.ln_stats[2 * m] = mean; a.ln_stats[2 * m + 1] = rstd; }
+      }
+      RGSTAMP(6);
+      break;                                                            // one round by construction
+    } else {
     // ---- epilogue over the stage tile: thread = (row, 4 consecutive columns); all global reads first
     const int n_base = tile0 * 16;
     const int ncols = min(RG_CPR, a.N - n_base);                       // valid columns this round (multiple of 4)
@@ -221,15 +280,16 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
     }
     if (rd == 0) RGSTAMP(6);
     if (rd + 1 < nrounds) lds_barrier();                                // stage tile is rewritten next round
+    }
   }
   RGSTAMP(7);
 }
 
-template <int KC>
+template <int KC, int ROWS, int NJ, bool LN = false>
 int launch_rowgemm_kc(const RowGemmArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)2 * RG_ROWS * (KC * 32 + 8) * sizeof(__bf16) + (size_t)RG_ROWS * RG_LDS_STAGE * sizeof(float);
-  RD_LDS_ATTR((k_rowgemm<KC>), lds);
-  hipLaunchKernelGGL(k_rowgemm<KC>, dim3(cdiv(a.M, RG_ROWS)), dim3(RG_THR), lds, st, a);
+  const size_t lds = (size_t)2 * ROWS * (KC * 32 + 8) * sizeof(__bf16) + (size_t)ROWS * (RG_WAVES * NJ * 16 + 4) * sizeof(float);
+  RD_LDS_ATTR((k_rowgemm<KC, ROWS, NJ, LN>), lds);
+  hipLaunchKernelGGL((k_rowgemm<KC, ROWS, NJ, LN>), dim3(cdiv(a.M, ROWS)), dim3(RG_THR), lds, st, a);
   return check_launch("k_rowgemm");
 }
 
@@ -244,7 +304,7 @@ bool rowgemm_ok(int N, int K, long lda, long ldc) {
   static const bool enabled = [] { const char* e = getenv("RD_ROWGEMM"); return !(e && atoi(e) == 0); }();
   const int kc = (K + 31) / 32;
   return enabled && precision() != RD_PREC_FP32 && (N % 4) == 0 && (K % 4) == 0 && (lda % 4) == 0 && (ldc % 4) == 0 &&
-         (kc == 5 || kc == 9);
+         (kc == 5 || kc == 9 || kc == 15);
 }
 size_t rowgemm_plane_elems(int rows, int cols) { return (size_t)((rows + 15) / 16 * 16) * ((cols + 31) / 32 * 32); }
 
@@ -263,6 +323,24 @@ int launch_wsplit(int njobs, const float* const* W, const int* N, const int* K, 
   return check_launch("k_wsplit");
 }
 
+// s = residual + dropout(A Wp^T + bias) -> s_out;  y = LayerNorm(s) g + b;  stats[m] = (mean, rstd).  N <= 256, N % 4 == 0,
+// all row strides N.  Same values as launch_rowgemm(.. -> o) followed by the add+LayerNorm kernel.
+bool rowgemm_ln_ok(int N, int K) { return rowgemm_ok(N, K, K, N) && N <= 256 && ((K + 31) / 32 == 5 || (K + 31) / 32 == 9); }
+int launch_rowgemm_ln(long M, int N, int K, const float* A, const void* Wh, const float* bias, const float* residual,
+                      const float* ln_g, const float* ln_b, float* s_out, float* y, float* stats, float drop_p,
+                      uint64_t drop_seed, uint32_t drop_site, hipStream_t st) {
+  RowGemmArgs a{};
+  a.A = A; a.lda = K; a.Wh = (const __bf16*)Wh; a.C = y; a.ldc = N;
+  a.M = (int)M; a.N = N; a.K = K; a.KP = (K + 31) / 32 * 32;
+  a.bias = bias; a.residual = residual; a.res_ld = N;
+  a.drop_p = drop_p; a.drop_seed = drop_seed; a.drop_site = drop_site; a.seed_cell = seed_cell();
+  a.stamps = g_rg_stamps;
+  a.one_product = precision() == RD_PREC_BF16;
+  a.ln_g = ln_g; a.ln_b = ln_b; a.ln_s = s_out; a.ln_stats = stats;
+  if (a.KP == 160) return launch_rowgemm_kc<5, 64, 2, true>(a, st);
+  return launch_rowgemm_kc<9, 64, 2, true>(a, st);
+}
+
 // C[M,N] = epi(A[M,K] Wp^T): Wp planes [ceil16(N)][ceil32(K)]
 int launch_rowgemm(long M, int N, int K, const float* A, long lda, const void* Wh, const void* Wl, float* C, long ldc,
                    const float* bias, int relu, const float* posmask, long pm_ld, float cscale, const float* residual,
@@ -276,8 +354,10 @@ int launch_rowgemm(long M, int N, int K, const float* A, long lda, const void* W
   a.stamps = g_rg_stamps;
   a.one_product = precision() == RD_PREC_BF16;
   const int kc = a.KP / 32;
-  if (kc == 5) return launch_rowgemm_kc<5>(a, st);
-  if (kc == 9) return launch_rowgemm_kc<9>(a, st);
+  if (kc == 5) return launch_rowgemm_kc<5, 64, 2>(a, st);
+  if (kc == 9) return launch_rowgemm_kc<9, 64, 2>(a, st);
+  // K = 3D (QKV dgrad): 32 rows keep planes + stage inside 160 KB; one column tile per wave keeps the 15-step panel in 120 VGPRs
+  if (kc == 15) return launch_rowgemm_kc<15, 32, 1>(a, st);
   return fail(RD_EUNSUPPORTED, "rowgemm: K=%d not built", K);
 }
 

@@ -25,6 +25,10 @@ bool rowgemm_ok(int N, int K, long lda, long ldc);
 size_t rowgemm_plane_elems(int rows, int cols);
 int launch_wsplit(int njobs, const float* const* W, const int* N, const int* K, const int* transpose, __bf16* const* hi,
                   __bf16* const* lo, hipStream_t st);
+bool rowgemm_ln_ok(int N, int K);
+int launch_rowgemm_ln(long M, int N, int K, const float* A, const void* Wh, const float* bias, const float* residual,
+                      const float* ln_g, const float* ln_b, float* s_out, float* y, float* stats, float drop_p,
+                      uint64_t drop_seed, uint32_t drop_site, hipStream_t st);
 int launch_rowgemm(long M, int N, int K, const float* A, long lda, const void* Wh, const void* Wl, float* C, long ldc,
                    const float* bias, int relu, const float* posmask, long pm_ld, float cscale, const float* residual,
                    long res_ld, float drop_p, uint64_t drop_seed, uint32_t drop_site, hipStream_t st);
@@ -764,11 +768,14 @@ __global__ __launch_bounds__(256) void k_add_ln_fwd_v(const float* __restrict__ 
 #pragma unroll
   for (int q = 0; q < LNV_RPW; ++q) {
     const bool ok = cok && (row0 + q < M);
-    xv[q] = ok ? *reinterpret_cast<const float4*>(x + (row0 + q) * D + c) : zero4;
-    rv[q] = ok ? *reinterpret_cast<const float4*>(r + (row0 + q) * D + c) : zero4;
+    xv[q] = zero4; rv[q] = zero4;              // (`ok ? *p : zero4` compiles to a pointer select + flat load from scratch)
+    if (ok) {
+      xv[q] = *reinterpret_cast<const float4*>(x + (row0 + q) * D + c);
+      rv[q] = *reinterpret_cast<const float4*>(r + (row0 + q) * D + c);
+    }
   }
-  const float4 gg = cok ? *reinterpret_cast<const float4*>(g + c) : zero4;
-  const float4 bb = cok ? *reinterpret_cast<const float4*>(bta + c) : zero4;
+  float4 gg = zero4, bb = zero4;
+  if (cok) { gg = *reinterpret_cast<const float4*>(g + c); bb = *reinterpret_cast<const float4*>(bta + c); }
 #pragma unroll
   for (int q = 0; q < LNV_RPW; ++q) {
     const long row = row0 + q;
@@ -949,7 +956,8 @@ __global__ __launch_bounds__(256) void k_ln_bwd_v(const float* __restrict__ dy, 
   const int c = 4 * lane;
   const bool cok = c < D;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 gg = cok ? *reinterpret_cast<const float4*>(g + c) : zero4;
+  float4 gg = zero4;
+  if (cok) gg = *reinterpret_cast<const float4*>(g + c);
   float4 ag = zero4, ab = zero4;
   const long rbase = (long)blockIdx.x * LN_RPB + wave * RPW;
   float4 sraw[RPW], dvr[RPW]; float mean_r[RPW], rstd_r[RPW];
@@ -958,8 +966,11 @@ __global__ __launch_bounds__(256) void k_ln_bwd_v(const float* __restrict__ dy, 
     const long row = rbase + it;
     const bool rok = row < M;
     mean_r[it] = rok ? stats[2 * row] : 0.f; rstd_r[it] = rok ? stats[2 * row + 1] : 0.f;
-    sraw[it] = (rok && cok) ? *reinterpret_cast<const float4*>(s + row * D + c) : zero4;
-    dvr[it] = (rok && cok) ? *reinterpret_cast<const float4*>(dy + row * D + c) : zero4;
+    sraw[it] = zero4; dvr[it] = zero4;
+    if (rok && cok) {
+      sraw[it] = *reinterpret_cast<const float4*>(s + row * D + c);
+      dvr[it] = *reinterpret_cast<const float4*>(dy + row * D + c);
+    }
   }
 #pragma unroll
   for (int it = 0; it < RPW; ++it) {
@@ -1060,8 +1071,8 @@ EncDims enc_dims(const rd_shape* s) {
   return e;
 }
 
-struct EncSaved { float *qkv, *attn, *lse, *s1, *st1, *x1, *h, *s2, *st2; __bf16* pl[7][2]; size_t bytes; };
-// weight planes kept from forward to backward: 0 in_proj, 1 out_proj, 2 lin1, 3 lin2, 4 out_proj^T, 5 lin2^T, 6 lin1^T
+struct EncSaved { float *qkv, *attn, *lse, *s1, *st1, *x1, *h, *s2, *st2; __bf16* pl[8][2]; size_t bytes; };
+// weight tiles kept from forward to backward: 0 in_proj, 1 out_proj, 2 lin1, 3 lin2, 4 out_proj^T, 5 lin2^T, 6 lin1^T, 7 in_proj^T
 EncSaved carve_saved(const EncDims& e, void* base) {
   EncSaved v; size_t off = 0;
   auto take = [&](size_t n) { float* p = base ? (float*)((char*)base + off) : nullptr;
@@ -1069,9 +1080,9 @@ EncSaved carve_saved(const EncDims& e, void* base) {
   v.qkv = take(e.M * 3 * e.D); v.attn = take(e.M * e.D); v.lse = take((size_t)e.B * e.H * e.T);
   v.s1 = take(e.M * e.D); v.st1 = take(e.M * 2); v.x1 = take(e.M * e.D);
   v.h = take(e.M * e.nhid); v.s2 = take(e.M * e.D); v.st2 = take(e.M * 2);
-  const int prow[7] = {3 * e.D, e.D, e.nhid, e.D, e.D, e.nhid, e.D};      // plane rows = output columns
-  const int pcol[7] = {e.D, e.D, e.D, e.nhid, e.D, e.D, e.nhid};          // plane cols = reduction length
-  for (int i = 0; i < 7; ++i)
+  const int prow[8] = {3 * e.D, e.D, e.nhid, e.D, e.D, e.nhid, e.D, e.D};      // plane rows = output columns
+  const int pcol[8] = {e.D, e.D, e.D, e.nhid, e.D, e.D, e.nhid, 3 * e.D};      // plane cols = reduction length
+  for (int i = 0; i < 8; ++i)
     for (int h = 0; h < 2; ++h) v.pl[i][h] = (__bf16*)take((rowgemm_plane_elems(prow[i], pcol[i]) + 1) / 2);
   v.bytes = off;
   return v;
@@ -1194,13 +1205,14 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
   const bool rg = rowgemm_ok(3 * e.D, e.D, e.D, 3 * e.D) && rowgemm_ok(e.D, e.D, e.D, e.D) &&
                   rowgemm_ok(e.nhid, e.D, e.D, e.nhid) && rowgemm_ok(e.D, e.nhid, e.nhid, e.D);
   if (rg) {
-    const float* Ws[7] = {w->in_proj_w, w->out_proj_w, w->lin1_w, w->lin2_w, w->out_proj_w, w->lin2_w, w->lin1_w};
-    const int Ns[7] = {3 * e.D, e.D, e.nhid, e.D, e.D, e.D, e.nhid};
-    const int Ks[7] = {e.D, e.D, e.D, e.nhid, e.D, e.nhid, e.D};
-    const int Tr[7] = {0, 0, 0, 0, 1, 1, 1};
-    __bf16* his[7]; __bf16* los[7];
-    for (int i = 0; i < 7; ++i) { his[i] = v.pl[i][0]; los[i] = v.pl[i][1]; }
-    if ((rc = launch_wsplit(7, Ws, Ns, Ks, Tr, his, los, st))) return rc;
+    const float* Ws[8] = {w->in_proj_w, w->out_proj_w, w->lin1_w, w->lin2_w, w->out_proj_w, w->lin2_w, w->lin1_w, w->in_proj_w};
+    const int Ns[8] = {3 * e.D, e.D, e.nhid, e.D, e.D, e.D, e.nhid, 3 * e.D};
+    const int Ks[8] = {e.D, e.D, e.D, e.nhid, e.D, e.nhid, e.D, e.D};
+    const int Tr[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+    __bf16* his[8]; __bf16* los[8];
+    for (int i = 0; i < 8; ++i) { his[i] = v.pl[i][0]; los[i] = v.pl[i][1]; }
+    const int njobs = rowgemm_ok(e.D, 3 * e.D, 3 * e.D, e.D) ? 8 : 7;
+    if ((rc = launch_wsplit(njobs, Ws, Ns, Ks, Tr, his, los, st))) return rc;
     if ((rc = launch_rowgemm(e.M, 3 * e.D, e.D, x, e.D, v.pl[0][0], v.pl[0][1], v.qkv, 3 * e.D, w->in_proj_b, 0, nullptr, 0,
                              0.f, nullptr, 0, 0.f, 0, 0, st))) return rc;
   } else if ((rc = linear_fwd(e.M, 3 * e.D, e.D, x, w->in_proj_w, w->in_proj_b, v.qkv, 0, 0.f, 0, 0, st))) return rc;
@@ -1209,15 +1221,26 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
   a.T = e.T; a.B = e.B; a.D = e.D; a.H = e.H; a.hd = e.Hd;
   a.scale = 1.0f / sqrtf((float)e.Hd); a.p_drop = p_drop; a.seed = seed; a.site = SITE_ATTN_PROB + L; a.seed_cell = seed_cell();
   if ((rc = dispatch_attn(a, 0, st))) return rc;
-  if (rg) {
-    if ((rc = launch_rowgemm(e.M, e.D, e.D, v.attn, e.D, v.pl[1][0], v.pl[1][1], ws.o, e.D, w->out_proj_b, 0, nullptr, 0, 0.f,
-                             nullptr, 0, 0.f, 0, 0, st))) return rc;
-  } else if ((rc = linear_fwd(e.M, e.D, e.D, v.attn, w->out_proj_w, w->out_proj_b, ws.o, 0, 0.f, 0, 0, st))) return rc;
-  if ((rc = launch_add_ln_fwd(x, ws.o, w->norm1_w, w->norm1_b, v.s1, v.x1, v.st1, (int)e.M, e.D, p_drop, seed,
-                              SITE_ATTN_OUT + L, st))) return rc;
+  // out-projection / second FFN layer with the residual add + LayerNorm in their epilogue (a workgroup owns complete rows)
+  static const bool ln_fuse_env = [] { const char* e = getenv("RD_LN_FUSE"); return !(e && atoi(e) == 0); }();
+  const bool lnf1 = rg && ln_fuse_env && rowgemm_ln_ok(e.D, e.D), lnf2 = rg && ln_fuse_env && rowgemm_ln_ok(e.D, e.nhid);
+  if (lnf1) {
+    if ((rc = launch_rowgemm_ln(e.M, e.D, e.D, v.attn, v.pl[1][0], w->out_proj_b, x, w->norm1_w, w->norm1_b, v.s1, v.x1, v.st1,
+                                p_drop, seed, SITE_ATTN_OUT + L, st))) return rc;
+  } else {
+    if (rg) {
+      if ((rc = launch_rowgemm(e.M, e.D, e.D, v.attn, e.D, v.pl[1][0], v.pl[1][1], ws.o, e.D, w->out_proj_b, 0, nullptr, 0, 0.f,
+                               nullptr, 0, 0.f, 0, 0, st))) return rc;
+    } else if ((rc = linear_fwd(e.M, e.D, e.D, v.attn, w->out_proj_w, w->out_proj_b, ws.o, 0, 0.f, 0, 0, st))) return rc;
+    if ((rc = launch_add_ln_fwd(x, ws.o, w->norm1_w, w->norm1_b, v.s1, v.x1, v.st1, (int)e.M, e.D, p_drop, seed,
+                                SITE_ATTN_OUT + L, st))) return rc;
+  }
   if (rg) {
     if ((rc = launch_rowgemm(e.M, e.nhid, e.D, v.x1, e.D, v.pl[2][0], v.pl[2][1], v.h, e.nhid, w->lin1_b, 1, nullptr, 0, 0.f,
                              nullptr, 0, p_drop, seed, SITE_FFN_HID + L, st))) return rc;
+    if (lnf2)
+      return launch_rowgemm_ln(e.M, e.D, e.nhid, v.h, v.pl[3][0], w->lin2_b, v.x1, w->norm2_w, w->norm2_b, v.s2, y, v.st2,
+                               p_drop, seed, SITE_FFN_OUT + L, st);
     if ((rc = launch_rowgemm(e.M, e.D, e.nhid, v.h, e.nhid, v.pl[3][0], v.pl[3][1], ws.f, e.D, w->lin2_b, 0, nullptr, 0, 0.f,
                              nullptr, 0, 0.f, 0, 0, st))) return rc;
   } else {
@@ -1296,7 +1319,11 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   if (ax.ok && (rc = chain(st, sw, ax.ev[3]))) return rc;
   if ((rc = linear_bwd_w(e.M, 3 * e.D, e.D, ws.dqkv, x, g->in_proj_w, g->in_proj_b, ws.splitk, ws.colsum, sw)))
     return rc;
-  rc = linear_bwd_x(e.M, 3 * e.D, e.D, ws.dqkv, w->in_proj_w, dx, nullptr, 0.f, ws.ds1, st);
+  if (rg && rowgemm_ok(e.D, 3 * e.D, 3 * e.D, e.D))           // dx = dqkv W_in + ds1: row-block form, K = 3D (was 70 us as a tiled GEMM)
+    rc = launch_rowgemm(e.M, e.D, 3 * e.D, ws.dqkv, 3 * e.D, v.pl[7][0], v.pl[7][1], dx, e.D, nullptr, 0, nullptr, 0, 0.f, ws.ds1,
+                        e.D, 0.f, 0, 0, st);
+  else
+    rc = linear_bwd_x(e.M, 3 * e.D, e.D, ws.dqkv, w->in_proj_w, dx, nullptr, 0.f, ws.ds1, st);
   if (ax.ok && (rc = chain(sw, st, ax.ev[4]))) return rc;                        // join: the caller's stream owns every result
   return rc;
 }

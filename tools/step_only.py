@@ -19,7 +19,11 @@ named = dict(m.named_parameters())
 flat = dp.FlatGradAllReduce([(n, named[n]) for n in synth.live_parameter_names(cfg)], n_buckets=2)
 opt = FlatAdam(flat.flatten_parameters(), lr=1e-4)
 ts = TrainStep(m, flat, b)
+import time
+for _ in range(3):
+    ts.run(); flat.allreduce(); opt.step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(steps):
     ts.run(); flat.allreduce(); opt.step()
-torch.cuda.synchronize()
-print("loss", float(ts.loss))
+torch.cuda.synchronize(); t1 = time.perf_counter()
+print("loss", float(ts.loss), "ms/step %.4f" % ((t1 - t0) * 1e3 / steps))
