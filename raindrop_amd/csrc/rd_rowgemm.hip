@@ -44,11 +44,14 @@ struct RowGemmArgs {
   // C = LayerNorm(s) * ln_g + ln_b, (mean, rstd) -> ln_stats.  Replaces the separate add+LayerNorm kernel of the encoder
   // layer (rd_temporal.hip k_add_ln_fwd_v: same lane <-> column assignment, same reduction order, same dropout quads).
   const float* ln_g; const float* ln_b; float* ln_s; float* ln_stats;
+  // Tile export (rd_tile_wgrad.hip): the split A planes, transposed into MFMA operand tiles whose reduction index is the
+  // ROW -- [chunk of 32 rows][column tile of 16][hi, lo][64][8] -- the operand format of the weight-gradient stream.
+  __bf16* xt; int xt_nct;
 };
 
 // one weight matrix -> hi/lo planes; transpose != 0 writes split(W^T): rows k, cols n
 struct SplitJob { const float* W; int N, K, transpose; __bf16* hi; __bf16* lo; int rows, cols_p; };
-struct SplitJobs { SplitJob j[8]; int n; };
+struct SplitJobs { SplitJob j[8]; int n; __bf16* ones; };   // ones: constant tiles of the weight-gradient stream (or null)
 
 // Output: NATIVE MFMA operand tiles [ntile = rows/16][kc = cols_p/32][hi, lo][64 lanes][8] (one contiguous kilobyte per
 // wave-load; rd_k1_layout.h has the measurement: 61 B/clk/CU against 16 B/clk for a row-major plane).  `hi` is the
@@ -59,6 +62,15 @@ __global__ __launch_bounds__(256) void k_wsplit(SplitJobs jobs) {
   const int ntile = jb.rows >> 4, nkc = jb.cols_p >> 5;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, G = lane >> 4;
   const int src_rows = jb.transpose ? jb.K : jb.N, src_cols = jb.transpose ? jb.N : jb.K;
+  if (jobs.ones && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0) {
+    // [ones hi: column 0 = 1][zeros][zeros] (rd_tile_wgrad.hip: the B operand whose output column is the bias gradient)
+    bf16x8 o, z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { o[e] = (__bf16)(c == 0 ? 1.f : 0.f); z[e] = (__bf16)0.f; }
+    *reinterpret_cast<bf16x8*>(jobs.ones + lane * 8) = o;
+    *reinterpret_cast<bf16x8*>(jobs.ones + 512 + lane * 8) = z;
+    *reinterpret_cast<bf16x8*>(jobs.ones + 1024 + lane * 8) = z;
+  }
   for (int t = blockIdx.x * 4 + wave; t < ntile * nkc; t += gridDim.x * 4) {
     const int j = t / nkc, kc = t - j * nkc;
     const int r = 16 * j + c, c0 = 32 * kc + 8 * G;          // plane row (free index), first plane column (reduction)
@@ -153,6 +165,25 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
   RGSTAMP(1);
   lds_barrier();                       // LDS ordering only: do not drain the weight panel (rd_common.h)
   RGSTAMP(2);
+  if (a.xt) {
+    // ds_read_b64_tr_b16 (tools/probe_tr16.hip): in a 16-lane group lane i passes the address of 4 consecutive shorts --
+    // row i>>2, columns 4(i&3).. of a 4 x 16 block -- and receives column i of the block.  Two reads give lane
+    // (column c = lane & 15, G = lane >> 4) the 8 rows 8G .. 8G+7 of its column: one tile part, stored as a contiguous KB.
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    typedef short v8s __attribute__((ext_vector_type(8)));
+    const int nct = a.xt_nct, ntp = (RG_ROWS / 32) * nct * 2;
+    const int i16 = lane & 15, G = lane >> 4;
+    for (int t = wave; t < ntp; t += RG_WAVES) {
+      const int plane = t & 1, cj = t >> 1;
+      const int c = cj / nct, j = cj - c * nct;
+      if (m0 + 32 * c >= a.M) continue;
+      const __bf16* src = (plane ? Al : Ah) + (32 * c + 8 * G + (i16 >> 2)) * LDA + 16 * j + 4 * (i16 & 3);
+      const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(src));
+      const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(src + 4 * LDA));
+      const v8s o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      *reinterpret_cast<v8s*>(a.xt + (((size_t)(m0 / 32 + c) * nct + j) * 2 + plane) * 512 + lane * 8) = o;
+    }
+  }
 
   const float inv_keep = 1.0f / (1.0f - a.drop_p);
   const int aoff = (lane & 15) * LDA + 8 * (lane >> 4);
@@ -310,9 +341,9 @@ size_t rowgemm_plane_elems(int rows, int cols) { return (size_t)((rows + 15) / 1
 
 // split up to 8 weight matrices with one launch; job i: W [N_i, K_i] -> planes at hi_i / lo_i
 int launch_wsplit(int njobs, const float* const* W, const int* N, const int* K, const int* transpose, __bf16* const* hi,
-                  __bf16* const* lo, hipStream_t st) {
+                  __bf16* const* lo, void* ones, hipStream_t st) {
   SplitJobs jobs{};
-  jobs.n = njobs;
+  jobs.n = njobs; jobs.ones = (__bf16*)ones;
   for (int i = 0; i < njobs; ++i) {
     SplitJob& j = jobs.j[i];
     j.W = W[i]; j.N = N[i]; j.K = K[i]; j.transpose = transpose[i]; j.hi = hi[i]; j.lo = lo[i];
@@ -322,6 +353,12 @@ int launch_wsplit(int njobs, const float* const* W, const int* N, const int* K, 
   hipLaunchKernelGGL(k_wsplit, dim3(64, njobs), dim3(256), 0, st, jobs);
   return check_launch("k_wsplit");
 }
+
+// The next launch_rowgemm / launch_rowgemm_ln call also exports its A operand as row tiles (nct = ceil(K / 16) column
+// tiles per 32-row chunk) to `tiles`; one-shot.
+static thread_local void* g_export = nullptr;
+void rowgemm_export_next(void* tiles) { g_export = tiles; }
+static void take_export(RowGemmArgs& a) { a.xt = (__bf16*)g_export; a.xt_nct = (a.K + 15) / 16; g_export = nullptr; }
 
 // s = residual + dropout(A Wp^T + bias) -> s_out;  y = LayerNorm(s) g + b;  stats[m] = (mean, rstd).  N <= 256, N % 4 == 0,
 // all row strides N.  Same values as launch_rowgemm(.. -> o) followed by the add+LayerNorm kernel.
@@ -337,6 +374,7 @@ int launch_rowgemm_ln(long M, int N, int K, const float* A, const void* Wh, cons
   a.stamps = g_rg_stamps;
   a.one_product = precision() == RD_PREC_BF16;
   a.ln_g = ln_g; a.ln_b = ln_b; a.ln_s = s_out; a.ln_stats = stats;
+  take_export(a);
   if (a.KP == 160) return launch_rowgemm_kc<5, 64, 2, true>(a, st);
   return launch_rowgemm_kc<9, 64, 2, true>(a, st);
 }
@@ -353,6 +391,7 @@ int launch_rowgemm(long M, int N, int K, const float* A, long lda, const void* W
   a.drop_p = drop_p; a.drop_seed = drop_seed; a.drop_site = drop_site; a.seed_cell = seed_cell();
   a.stamps = g_rg_stamps;
   a.one_product = precision() == RD_PREC_BF16;
+  take_export(a);
   const int kc = a.KP / 32;
   if (kc == 5) return launch_rowgemm_kc<5, 64, 2>(a, st);
   if (kc == 9) return launch_rowgemm_kc<9, 64, 2>(a, st);

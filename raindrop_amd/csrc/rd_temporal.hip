@@ -24,7 +24,17 @@ namespace rd {
 bool rowgemm_ok(int N, int K, long lda, long ldc);
 size_t rowgemm_plane_elems(int rows, int cols);
 int launch_wsplit(int njobs, const float* const* W, const int* N, const int* K, const int* transpose, __bf16* const* hi,
-                  __bf16* const* lo, hipStream_t st);
+                  __bf16* const* lo, void* ones, hipStream_t st);
+// weight gradients from exported row tiles (rd_tile_wgrad.hip)
+struct TileWgradJob { const void *tA, *tB; float* part; float *dW, *db; int N, K; };
+size_t tile_elems(long M, int cols);
+size_t tile_wgrad_ones_elems();
+size_t tile_wgrad_part_floats(int N, int K);
+bool tile_wgrad_ok(int N, int K);
+struct TileColsumJob { const float* x; int M, N, n1; float *out1, *out2; };
+int launch_tile_wgrad(long M, int njobs, const TileWgradJob* jobs, const void* ones, int ncs, const TileColsumJob* cs,
+                      hipStream_t st);
+void rowgemm_export_next(void* tiles);
 bool rowgemm_ln_ok(int N, int K);
 int launch_rowgemm_ln(long M, int N, int K, const float* A, const void* Wh, const float* bias, const float* residual,
                       const float* ln_g, const float* ln_b, float* s_out, float* y, float* stats, float drop_p,
@@ -1071,7 +1081,9 @@ EncDims enc_dims(const rd_shape* s) {
   return e;
 }
 
-struct EncSaved { float *qkv, *attn, *lse, *s1, *st1, *x1, *h, *s2, *st2; __bf16* pl[8][2]; size_t bytes; };
+struct EncSaved { float *qkv, *attn, *lse, *s1, *st1, *x1, *h, *s2, *st2; __bf16* pl[8][2];
+                  __bf16* xt[4]; __bf16* ones;        // row tiles of x, attn, x1, h (operands of the weight-gradient stream)
+                  size_t bytes; };
 // weight tiles kept from forward to backward: 0 in_proj, 1 out_proj, 2 lin1, 3 lin2, 4 out_proj^T, 5 lin2^T, 6 lin1^T, 7 in_proj^T
 EncSaved carve_saved(const EncDims& e, void* base) {
   EncSaved v; size_t off = 0;
@@ -1084,11 +1096,15 @@ EncSaved carve_saved(const EncDims& e, void* base) {
   const int pcol[8] = {e.D, e.D, e.D, e.nhid, e.D, e.D, e.nhid, 3 * e.D};      // plane cols = reduction length
   for (int i = 0; i < 8; ++i)
     for (int h = 0; h < 2; ++h) v.pl[i][h] = (__bf16*)take((rowgemm_plane_elems(prow[i], pcol[i]) + 1) / 2);
+  const int xcols[4] = {e.D, e.D, e.D, e.nhid};
+  for (int i = 0; i < 4; ++i) v.xt[i] = (__bf16*)take((tile_elems(e.M, xcols[i]) + 1) / 2);
+  v.ones = (__bf16*)take((tile_wgrad_ones_elems() + 1) / 2);
   v.bytes = off;
   return v;
 }
 
-struct EncWs { float *o, *f, *ds2, *df, *du, *dx1, *ds1, *dout, *da, *dqkv, *delta, *lnpart, *lnred, *splitk, *colsum;
+struct EncWs { float *o, *f, *ds2, *df, *du, *dx1, *ds1, *dout, *da, *dqkv, *delta, *lnpart, *lnpart1, *lnred, *splitk, *colsum;
+               __bf16* dt[4]; float* twpart[4];   // row tiles of df, du, dout, dqkv; slice partials of lin2, lin1, out_proj, in_proj
                size_t bytes; int ns_max; };
 EncWs carve_ws(const EncDims& e, void* base) {
   EncWs w; size_t off = 0;
@@ -1099,6 +1115,7 @@ EncWs carve_ws(const EncDims& e, void* base) {
   w.ds1 = take(e.M * e.D); w.dout = take(e.M * e.D); w.da = take(e.M * e.D); w.dqkv = take(e.M * 3 * e.D);
   w.delta = take((size_t)e.B * e.H * e.T);
   w.lnpart = take((size_t)cdiv((int)e.M, LN_RPB) * 2 * e.D);
+  w.lnpart1 = take((size_t)cdiv((int)e.M, LN_RPB) * 2 * e.D);
   w.lnred = take((size_t)2 * e.D + colsum_ws_floats(cdiv((int)e.M, LN_RPB), 2 * e.D));
   size_t sk = 0; int kps;
   const int shapes[4][2] = {{3 * e.D, e.D}, {e.D, e.D}, {e.nhid, e.D}, {e.D, e.nhid}};
@@ -1106,8 +1123,19 @@ EncWs carve_ws(const EncDims& e, void* base) {
   for (auto& sh : shapes) { size_t v = (size_t)wgrad_ws_floats(e.M, sh[0], sh[1]); if (v > sk) sk = v; }
   w.splitk = take(sk);
   w.colsum = take(colsum_ws_floats((int)e.M, 3 * e.D > e.nhid ? 3 * e.D : e.nhid));
+  const int dcols[4] = {e.D, e.nhid, e.D, 3 * e.D};
+  for (int i = 0; i < 4; ++i) w.dt[i] = (__bf16*)take((tile_elems(e.M, dcols[i]) + 1) / 2);
+  const int pn[4] = {e.D, e.nhid, e.D, 3 * e.D}, pk[4] = {e.nhid, e.D, e.D, e.D};
+  for (int i = 0; i < 4; ++i) w.twpart[i] = take(tile_wgrad_part_floats(pn[i], pk[i]));
   w.bytes = off;
   return w;
+}
+
+// the whole layer runs on row-block products and all four weight gradients can take the tile stream
+static bool tile_path(const EncDims& e) {
+  return rowgemm_ok(3 * e.D, e.D, e.D, 3 * e.D) && rowgemm_ok(e.D, e.D, e.D, e.D) && rowgemm_ok(e.nhid, e.D, e.D, e.nhid) &&
+         rowgemm_ok(e.D, e.nhid, e.nhid, e.D) && rowgemm_ok(e.D, 3 * e.D, 3 * e.D, e.D) && tile_wgrad_ok(3 * e.D, e.D) &&
+         tile_wgrad_ok(e.D, e.D) && tile_wgrad_ok(e.nhid, e.D) && tile_wgrad_ok(e.D, e.nhid);
 }
 
 int linear_fwd(long M, int N, int K, const float* x, const float* W, const float* b, float* y, int relu,
@@ -1204,6 +1232,7 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
   // weights -> bf16 hi/lo planes (both orientations needed by this layer's forward and backward), one launch
   const bool rg = rowgemm_ok(3 * e.D, e.D, e.D, 3 * e.D) && rowgemm_ok(e.D, e.D, e.D, e.D) &&
                   rowgemm_ok(e.nhid, e.D, e.D, e.nhid) && rowgemm_ok(e.D, e.nhid, e.nhid, e.D);
+  const bool tw = rg && tile_path(e) && !aux().ok;
   if (rg) {
     const float* Ws[8] = {w->in_proj_w, w->out_proj_w, w->lin1_w, w->lin2_w, w->out_proj_w, w->lin2_w, w->lin1_w, w->in_proj_w};
     const int Ns[8] = {3 * e.D, e.D, e.nhid, e.D, e.D, e.D, e.nhid, 3 * e.D};
@@ -1212,7 +1241,8 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
     __bf16* his[8]; __bf16* los[8];
     for (int i = 0; i < 8; ++i) { his[i] = v.pl[i][0]; los[i] = v.pl[i][1]; }
     const int njobs = rowgemm_ok(e.D, 3 * e.D, 3 * e.D, e.D) ? 8 : 7;
-    if ((rc = launch_wsplit(njobs, Ws, Ns, Ks, Tr, his, los, st))) return rc;
+    if ((rc = launch_wsplit(njobs, Ws, Ns, Ks, Tr, his, los, tw ? v.ones : nullptr, st))) return rc;
+    if (tw) rowgemm_export_next(v.xt[0]);
     if ((rc = launch_rowgemm(e.M, 3 * e.D, e.D, x, e.D, v.pl[0][0], v.pl[0][1], v.qkv, 3 * e.D, w->in_proj_b, 0, nullptr, 0,
                              0.f, nullptr, 0, 0.f, 0, 0, st))) return rc;
   } else if ((rc = linear_fwd(e.M, 3 * e.D, e.D, x, w->in_proj_w, w->in_proj_b, v.qkv, 0, 0.f, 0, 0, st))) return rc;
@@ -1224,6 +1254,7 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
   // out-projection / second FFN layer with the residual add + LayerNorm in their epilogue (a workgroup owns complete rows)
   static const bool ln_fuse_env = [] { const char* e = getenv("RD_LN_FUSE"); return !(e && atoi(e) == 0); }();
   const bool lnf1 = rg && ln_fuse_env && rowgemm_ln_ok(e.D, e.D), lnf2 = rg && ln_fuse_env && rowgemm_ln_ok(e.D, e.nhid);
+  if (tw) rowgemm_export_next(v.xt[1]);
   if (lnf1) {
     if ((rc = launch_rowgemm_ln(e.M, e.D, e.D, v.attn, v.pl[1][0], w->out_proj_b, x, w->norm1_w, w->norm1_b, v.s1, v.x1, v.st1,
                                 p_drop, seed, SITE_ATTN_OUT + L, st))) return rc;
@@ -1236,8 +1267,10 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
                                 SITE_ATTN_OUT + L, st))) return rc;
   }
   if (rg) {
+    if (tw) rowgemm_export_next(v.xt[2]);
     if ((rc = launch_rowgemm(e.M, e.nhid, e.D, v.x1, e.D, v.pl[2][0], v.pl[2][1], v.h, e.nhid, w->lin1_b, 1, nullptr, 0, 0.f,
                              nullptr, 0, p_drop, seed, SITE_FFN_HID + L, st))) return rc;
+    if (tw) rowgemm_export_next(v.xt[3]);
     if (lnf2)
       return launch_rowgemm_ln(e.M, e.D, e.nhid, v.h, v.pl[3][0], w->lin2_b, v.x1, w->norm2_w, w->norm2_b, v.s2, y, v.st2,
                                p_drop, seed, SITE_FFN_OUT + L, st);
@@ -1269,38 +1302,45 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   const uint32_t L = (uint32_t)layer;
   const float keep = 1.0f / (1.0f - p_drop);
   const int lnb = cdiv((int)e.M, LN_RPB);
+  Aux& ax = aux();
+  hipStream_t sw = ax.ok ? ax.s : st;                       // stream of the weight-gradient products
+  const bool rg = rowgemm_ok(3 * e.D, e.D, e.D, 3 * e.D) && rowgemm_ok(e.D, e.D, e.D, e.D) &&
+                  rowgemm_ok(e.nhid, e.D, e.D, e.nhid) && rowgemm_ok(e.D, e.nhid, e.nhid, e.D);
+  // tw: the input-gradient products below export their A operand (df, du, dout, dqkv) as row tiles and the four weight
+  // gradients run as one streaming launch at the end of the layer (rd_tile_wgrad.hip), instead of four split-K GEMMs;
+  // its reduce launch also column-sums the two LayerNorm partial matrices
+  const bool tw = rg && tile_path(e) && !ax.ok;
   // ---- LayerNorm 2:  ds2 (residual path), df = ds2 o mask(ffn out) -------------------------------
   if ((rc = launch_ln_bwd(dy, v.s2, v.st2, w->norm2_w, ws.ds2, ws.df, ws.lnpart, (int)e.M, e.D, p_drop, seed,
                           SITE_FFN_OUT + L, st))) return rc;
   // lnpart is a [blocks, 2D] matrix (dgamma | dbeta per block): column-sum it in fixed order
-  if ((rc = launch_colsum2(ws.lnpart, lnb, 2 * e.D, 2 * e.D, g->norm2_w, e.D, g->norm2_b, ws.lnred, st))) return rc;
-  Aux& ax = aux();
-  hipStream_t sw = ax.ok ? ax.s : st;                       // stream of the weight-gradient products
+  if (!tw && (rc = launch_colsum2(ws.lnpart, lnb, 2 * e.D, 2 * e.D, g->norm2_w, e.D, g->norm2_b, ws.lnred, st))) return rc;
   // ---- FFN ---------------------------------------------------------------------------------------
   if (ax.ok && (rc = chain(st, sw, ax.ev[0]))) return rc;
-  if ((rc = linear_bwd_w(e.M, e.D, e.nhid, ws.df, v.h, g->lin2_w, g->lin2_b, ws.splitk, ws.colsum, sw))) return rc;
-  const bool rg = rowgemm_ok(3 * e.D, e.D, e.D, 3 * e.D) && rowgemm_ok(e.D, e.D, e.D, e.D) &&
-                  rowgemm_ok(e.nhid, e.D, e.D, e.nhid) && rowgemm_ok(e.D, e.nhid, e.nhid, e.D);
+  if (!tw && (rc = linear_bwd_w(e.M, e.D, e.nhid, ws.df, v.h, g->lin2_w, g->lin2_b, ws.splitk, ws.colsum, sw))) return rc;
   if (rg) {                                                        // du = (df W2) gated by h>0, * keep
+    if (tw) rowgemm_export_next(ws.dt[0]);
     if ((rc = launch_rowgemm(e.M, e.nhid, e.D, ws.df, e.D, v.pl[5][0], v.pl[5][1], ws.du, e.nhid, nullptr, 0, v.h, e.nhid,
                              p_drop > 0.f ? keep : 0.f, nullptr, 0, 0.f, 0, 0, st))) return rc;
   } else if ((rc = linear_bwd_x(e.M, e.D, e.nhid, ws.df, w->lin2_w, ws.du, v.h, p_drop > 0.f ? keep : 0.f, nullptr, st)))
     return rc;
   if (ax.ok && (rc = chain(st, sw, ax.ev[1]))) return rc;
-  if ((rc = linear_bwd_w(e.M, e.nhid, e.D, ws.du, v.x1, g->lin1_w, g->lin1_b, ws.splitk, ws.colsum, sw))) return rc;
+  if (!tw && (rc = linear_bwd_w(e.M, e.nhid, e.D, ws.du, v.x1, g->lin1_w, g->lin1_b, ws.splitk, ws.colsum, sw))) return rc;
   if (rg) {
+    if (tw) rowgemm_export_next(ws.dt[1]);
     if ((rc = launch_rowgemm(e.M, e.D, e.nhid, ws.du, e.nhid, v.pl[6][0], v.pl[6][1], ws.dx1, e.D, nullptr, 0, nullptr, 0, 0.f,
                              ws.ds2, e.D, 0.f, 0, 0, st))) return rc;
   } else if ((rc = linear_bwd_x(e.M, e.nhid, e.D, ws.du, w->lin1_w, ws.dx1, nullptr, 0.f, ws.ds2, st))) return rc;
   // ---- LayerNorm 1 -------------------------------------------------------------------------------
-  if ((rc = launch_ln_bwd(ws.dx1, v.s1, v.st1, w->norm1_w, ws.ds1, ws.dout, ws.lnpart, (int)e.M, e.D, p_drop, seed,
-                          SITE_ATTN_OUT + L, st))) return rc;
-  if ((rc = launch_colsum2(ws.lnpart, lnb, 2 * e.D, 2 * e.D, g->norm1_w, e.D, g->norm1_b, ws.lnred, st))) return rc;
+  if ((rc = launch_ln_bwd(ws.dx1, v.s1, v.st1, w->norm1_w, ws.ds1, ws.dout, tw ? ws.lnpart1 : ws.lnpart, (int)e.M, e.D, p_drop,
+                          seed, SITE_ATTN_OUT + L, st))) return rc;
+  if (!tw && (rc = launch_colsum2(ws.lnpart, lnb, 2 * e.D, 2 * e.D, g->norm1_w, e.D, g->norm1_b, ws.lnred, st))) return rc;
   // ---- attention output projection ---------------------------------------------------------------
   if (ax.ok && (rc = chain(st, sw, ax.ev[2]))) return rc;
-  if ((rc = linear_bwd_w(e.M, e.D, e.D, ws.dout, v.attn, g->out_proj_w, g->out_proj_b, ws.splitk, ws.colsum, sw)))
+  if (!tw && (rc = linear_bwd_w(e.M, e.D, e.D, ws.dout, v.attn, g->out_proj_w, g->out_proj_b, ws.splitk, ws.colsum, sw)))
     return rc;
   if (rg) {
+    if (tw) rowgemm_export_next(ws.dt[2]);
     if ((rc = launch_rowgemm(e.M, e.D, e.D, ws.dout, e.D, v.pl[4][0], v.pl[4][1], ws.da, e.D, nullptr, 0, nullptr, 0, 0.f,
                              nullptr, 0, 0.f, 0, 0, st))) return rc;
   } else if ((rc = linear_bwd_x(e.M, e.D, e.D, ws.dout, w->out_proj_w, ws.da, nullptr, 0.f, nullptr, st))) return rc;
@@ -1317,13 +1357,25 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   }
   // ---- input projection --------------------------------------------------------------------------
   if (ax.ok && (rc = chain(st, sw, ax.ev[3]))) return rc;
-  if ((rc = linear_bwd_w(e.M, 3 * e.D, e.D, ws.dqkv, x, g->in_proj_w, g->in_proj_b, ws.splitk, ws.colsum, sw)))
+  if (!tw && (rc = linear_bwd_w(e.M, 3 * e.D, e.D, ws.dqkv, x, g->in_proj_w, g->in_proj_b, ws.splitk, ws.colsum, sw)))
     return rc;
+  if (tw) rowgemm_export_next(ws.dt[3]);
   if (rg && rowgemm_ok(e.D, 3 * e.D, 3 * e.D, e.D))           // dx = dqkv W_in + ds1: row-block form, K = 3D (was 70 us as a tiled GEMM)
     rc = launch_rowgemm(e.M, e.D, 3 * e.D, ws.dqkv, 3 * e.D, v.pl[7][0], v.pl[7][1], dx, e.D, nullptr, 0, nullptr, 0, 0.f, ws.ds1,
                         e.D, 0.f, 0, 0, st);
   else
     rc = linear_bwd_x(e.M, 3 * e.D, e.D, ws.dqkv, w->in_proj_w, dx, nullptr, 0.f, ws.ds1, st);
+  if (rc) return rc;
+  if (tw) {
+    const TileWgradJob jobs[4] = {
+        {ws.dt[3], v.xt[0], ws.twpart[3], g->in_proj_w, g->in_proj_b, 3 * e.D, e.D},      // dqkv^T x
+        {ws.dt[1], v.xt[2], ws.twpart[1], g->lin1_w, g->lin1_b, e.nhid, e.D},             // du^T x1
+        {ws.dt[0], v.xt[3], ws.twpart[0], g->lin2_w, g->lin2_b, e.D, e.nhid},             // df^T h
+        {ws.dt[2], v.xt[1], ws.twpart[2], g->out_proj_w, g->out_proj_b, e.D, e.D}};       // dout^T attn
+    const TileColsumJob cs[2] = {{ws.lnpart, lnb, 2 * e.D, e.D, g->norm2_w, g->norm2_b},
+                                 {ws.lnpart1, lnb, 2 * e.D, e.D, g->norm1_w, g->norm1_b}};
+    return launch_tile_wgrad(e.M, 4, jobs, v.ones, 2, cs, st);
+  }
   if (ax.ok && (rc = chain(sw, st, ax.ev[4]))) return rc;                        // join: the caller's stream owns every result
   return rc;
 }

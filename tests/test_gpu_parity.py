@@ -253,6 +253,43 @@ def test_encoder_layer_vs_oracle(T, B, F, nhead):
         _grad_close(a.cpu().numpy(), r.numpy(), 2e-4, name)
 
 
+@pytest.mark.parametrize("T,B", [(60, 37), (60, 256), (33, 5)])
+def test_encoder_tile_weight_gradients_match_split_k(T, B, precision_mode, monkeypatch):
+    """The streamed weight gradients (rd_tile_wgrad.hip: operands exported as split-bf16 row tiles by the row-block
+    products, one launch for the layer's four dW/db) against the tiled split-K products they replace, in the SAME
+    split-bf16 arithmetic and with the same dropout masks: only the summation order differs, so every entry must agree
+    within 2e-5 of the tensor's max-norm.  dx and the LayerNorm gradients do not depend on the path: bit-equal.
+    T*B = 2220 / 165 rows end in a partial 32-row chunk."""
+    if precision_mode != "bf16x3":
+        pytest.skip("the tile stream exists in split-bf16 mode only")
+    from raindrop_amd import _lib, ops
+    F, nhead = 34, 2
+    D, nhid = F * 4 + 16, 2 * F * 4
+    rng = np.random.default_rng(T + B)
+    x = torch.from_numpy(rng.standard_normal((T, B, D)).astype(np.float32)).to(DEV)
+    lengths = torch.from_numpy(rng.integers(1, T + 1, size=B)).long()
+    mask = torch.from_numpy(O2.padding_mask(lengths.numpy(), T)).to(DEV)
+    dy = torch.from_numpy(rng.standard_normal((T, B, D)).astype(np.float32)).to(DEV)
+    p = _enc_params(D, nhid, seed=B)
+    shp = _lib.shape(B, T, F, 4, nhead=nhead, nhid=nhid)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RD_TILE_WGRAD", mode)
+        xd = x.clone().requires_grad_(True)
+        pd = [p[n].to(DEV).requires_grad_(True) for n in ops.ENC_PARAM_NAMES]
+        y = ops.encoder_layer(xd, mask, shp, 1, 0.2, 1234, pd)
+        g = torch.autograd.grad(y, [xd] + pd, dy)
+        torch.cuda.synchronize()
+        out[mode] = (y.detach().cpu().numpy(), [t.cpu().numpy() for t in g])
+    monkeypatch.delenv("RD_TILE_WGRAD")
+    assert np.array_equal(out["1"][0], out["0"][0])
+    for name, a, r in zip(["x"] + list(ops.ENC_PARAM_NAMES), out["1"][1], out["0"][1]):
+        if name == "x" or "norm" in name:
+            assert np.array_equal(a, r), name
+        else:
+            assert np.abs(a - r).max() <= 2e-5 * np.abs(r).max(), (name, float(np.abs(a - r).max() / np.abs(r).max()))
+
+
 def test_encoder_layer_dropout_is_consistent():
     """With dropout on: (i) same seed -> bit-identical output, different seed -> different;
     (ii) backward uses the forward's masks: a central finite difference of <y, R> along a random
