@@ -226,6 +226,23 @@ int rd_linear_bwd_input_gated(int32_t M, int32_t N, int32_t K, const float* dy, 
  * loss[0] = mean_b(logsumexp(logits[b]) - logits[b, y[b]]); dlogits = (softmax - onehot) / B. */
 int rd_softmax_xent(int32_t B, int32_t C, const float* logits, const int64_t* y, float* loss,
                     float* dlogits, void* stream);
+/* Classifier head + loss, forward and backward, in two launches (training step; rd_head.hip).
+ *   agg = masked mean over time of r [T,B,D] (code/models_rd.py:366-367,379); feat = [agg | static W_emb^T + b_emb]
+ *   (:381-384; Fe = 0: no static branch); logits = W2 relu(W0 feat + b0) + b2 (mlp_static, :263-267,385);
+ *   loss = mean cross entropy against y (code/Raindrop.py:255,322).
+ * Outputs: loss[1], logits [B,C], the six parameter gradients (overwritten, not accumulated) and dr [T,B,D], the
+ * gradient entering the encoder stack.  fp32 FMA arithmetic in every precision mode.  Replaces the sequence
+ * rd_masked_mean_fwd, rd_linear_fwd x3, rd_softmax_xent, rd_linear_bwd_weight x3, rd_linear_bwd_input(_gated),
+ * rd_masked_mean_bwd of the same quantities.  rd_head_train_supported: D % 4 == 0, D + Fe <= 256, C <= 16 (and the
+ * environment switch RD_HEAD_FUSED=0 reports 0); workspace: rd_head_train_workspace_bytes(B, D + Fe, C). */
+int rd_head_train_supported(int32_t D, int32_t Fe, int32_t C);
+size_t rd_head_train_workspace_bytes(int32_t B, int32_t dh, int32_t C);
+int rd_head_train(const rd_shape* s, int32_t D, int32_t d_static, int32_t Fe, int32_t C, const float* r,
+                  const uint8_t* mask, const int64_t* lengths, const float* stat, const float* emb_w,
+                  const float* emb_b, const float* w0, const float* b0, const float* w2, const float* b2,
+                  const int64_t* y, float* loss, float* logits, float* g_emb_w, float* g_emb_b, float* g_w0,
+                  float* g_b0, float* g_w2, float* g_b2, float* dr, void* workspace, size_t workspace_bytes,
+                  void* stream);
 size_t rd_linear_bwd_weight_workspace_bytes(int32_t M, int32_t N, int32_t K);
 /* dW[N,K] = dy[M,N]^T x[M,K];  db[N] = sum_m dy[m,:]  (db may be NULL).  Deterministic split
  * over M with a fixed-order reduction. */

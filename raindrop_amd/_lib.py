@@ -69,6 +69,9 @@ SIGNATURES = {
     "rd_linear_bwd_input": (c_int32, [c_int32, c_int32, c_int32, _P, c_int32, _P, _P, c_int32, _P]),
     "rd_linear_bwd_input_gated": (c_int32, [c_int32, c_int32, c_int32, _P, c_int32, _P, _P, c_int32, _P, c_int32, _P]),
     "rd_softmax_xent": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _P]),
+    "rd_head_train_supported": (c_int32, [c_int32, c_int32, c_int32]),
+    "rd_head_train_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "rd_head_train": (c_int32, [_SHP, c_int32, c_int32, c_int32, c_int32] + [_P] * 20 + [_P, c_size_t, _P]),
     "rd_batch_gather": (c_int32, [c_int32, c_int32, c_int32, c_int32, ctypes.c_int64] + [_P] * 12),
     "rd_graph_beta_kept": (c_int32, [c_int32]),
     "rd_graph_beta_fwd": (c_int32, [c_int32] * 6 + [_P, _P, _P, _P, ctypes.c_int64, _P, ctypes.c_int64, _P, ctypes.c_int64]

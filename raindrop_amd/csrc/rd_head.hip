@@ -1,0 +1,312 @@
+// rd_head.hip -- the classifier head of Raindrop_v2 with its loss, forward AND backward, in two launches.
+//
+//   agg[b]   = sum_t r[t,b,:] (1 - mask[b,t]) / (lengths[b] + 1)                 code/models_rd.py:366-367,379
+//   feat[b]  = [agg[b] | emb(static[b])]                                          code/models_rd.py:381-384 (static model)
+//   logits   = mlp_static(feat) = W2 relu(W0 feat + b0) + b2                      code/models_rd.py:385 (mlp_static: :263-267)
+//   loss     = mean_b CrossEntropy(logits[b], y[b])                               code/Raindrop.py:255,322
+// and every gradient of `loss`: dW0, db0, dW2, db2, d emb.weight, d emb.bias and dr [T,B,D] (the masked mean's backward,
+// the entry gradient of the encoder stack).
+//
+// Why: the head is 256 rows x 186 features -- about 50 MFLOP -- but as separate operators it was 15 launches of
+// latency-bound kernels (three forward products, the loss, two input-gradient and three weight-gradient products
+// with their split-K reduces, the masked mean and its backward): ~114 us of a 0.85 ms step at ~4.5 us of fixed cost per
+// launch.  Here a workgroup owns RB samples end to end:
+//   k_head_rows   masked mean -> emb -> W0 (+ReLU) -> W2 -> softmax/loss -> dlogits -> dhid -> dfeat -> dr.
+//                 W0 is read ONCE per workgroup, coalesced, into registers: wave w holds rows j = w, w+16, ... with lane l
+//                 owning columns l, l+64, ...; the forward product reduces over lanes (one wave sum per output), the
+//                 input gradient reuses the same registers and reduces over the 16 waves through LDS.  fp32 FMA
+//                 arithmetic (at these sizes the matrix cores would idle behind the launch latency anyway).
+//   k_head_wgrad  the three weight/bias gradients as 16 x 16 output tiles over the B rows (operands staged in LDS), and
+//                 the mean of the per-sample losses -- all fixed-order sums, no atomics.
+#include "rd_common.h"
+
+namespace rd {
+namespace {
+
+constexpr int HR_THR = 1024, HR_WAVES = 16;
+constexpr int HR_RJ = 16, HR_KI = 4;               // W0 rows per wave (dh <= 256), column slots per lane (dh <= 256)
+constexpr int HR_LD = 256;                         // row stride of the per-sample vectors in LDS
+
+struct HeadArgs {
+  const float* r; const uint8_t* mask; const int64_t* lengths; const float* stat;
+  const float *emb_w, *emb_b, *w0, *b0, *w2, *b2;
+  const int64_t* y;
+  float *logits, *dr;
+  float *feat, *hid, *dhid, *demb, *dlog, *lossr;   // workspace: [B,dh] x3, [B,Fe], [B,C], [B]
+  int T, B, D, ds, Fe, dh, C;
+};
+
+__device__ __forceinline__ float wsum64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <int RB>
+__global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
+  __shared__ __attribute__((aligned(16))) float feat[RB][HR_LD], hid[RB][HR_LD], dhid[RB][HR_LD], dfeat[RB][HR_LD];
+  __shared__ __attribute__((aligned(16))) float red[HR_WAVES * RB * HR_LD];     // mean-phase and wave partials
+  __shared__ float lg[RB][16], dl[RB][16], invl[RB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = blockIdx.x * RB;
+  const int T = a.T, B = a.B, D = a.D, dh = a.dh, C = a.C, D4 = D >> 2;
+
+  // ---- W0 rows of this wave -> registers (requested first: they are needed after the masked mean) ----
+  float w[HR_RJ][HR_KI];
+#pragma unroll
+  for (int jj = 0; jj < HR_RJ; ++jj) {
+    const int j = wave + HR_WAVES * jj;
+#pragma unroll
+    for (int i = 0; i < HR_KI; ++i) {
+      const int k = lane + 64 * i;
+      w[jj][i] = 0.f;
+      if (j < dh && k < dh) w[jj][i] = a.w0[(long)j * dh + k];
+    }
+  }
+  // ---- masked mean: thread = (sample r, column quad c4, time group tg) ----
+  const int P = RB * D4;
+  const int ntg = min(HR_THR / P, 16);
+  {
+    const int pair = tid % P, tg = tid / P;
+    const int r = pair / D4, c4 = pair - r * D4, b = b0 + r;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tg < ntg && b < B)
+      for (int t = tg; t < T; t += ntg)
+        if (!a.mask[(long)b * T + t]) {
+          const float4 v = *reinterpret_cast<const float4*>(a.r + ((long)t * B + b) * D + 4 * c4);
+          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    if (tg < ntg) *reinterpret_cast<float4*>(red + ((size_t)tg * P + pair) * 4) = s;
+    if (tid < RB) invl[tid] = (b0 + tid < B) ? 1.0f / (float)(a.lengths[b0 + tid] + 1) : 0.f;
+  }
+  __syncthreads();
+  if (tid < P) {
+    const int r = tid / D4, c4 = tid - r * D4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = 0; g < ntg; ++g) {
+      const float4 v = *reinterpret_cast<const float4*>(red + ((size_t)g * P + tid) * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const float il = invl[r];
+    *reinterpret_cast<float4*>(&feat[r][4 * c4]) = make_float4(s.x * il, s.y * il, s.z * il, s.w * il);
+  }
+  // ---- static embedding into the right block (code/models_rd.py:381): thread = (r, j) ----
+  for (int e = tid; e < RB * a.Fe; e += HR_THR) {
+    const int r = e / a.Fe, j = e - r * a.Fe, b = b0 + r;
+    float s = a.emb_b[j];
+    if (b < B)
+      for (int q = 0; q < a.ds; ++q) s += a.stat[(long)b * a.ds + q] * a.emb_w[(long)j * a.ds + q];
+    feat[r][D + j] = s;
+  }
+  __syncthreads();
+  // ---- hid = relu(W0 feat + b0): wave w owns outputs j = w, w+16, ...; lanes split the reduction ----
+#pragma unroll
+  for (int jj = 0; jj < HR_RJ; ++jj) {
+    const int j = wave + HR_WAVES * jj;
+    if (j < dh) {                                      // wave-uniform
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        float p = 0.f;
+#pragma unroll
+        for (int i = 0; i < HR_KI; ++i) {
+          const int k = lane + 64 * i;
+          if (k < dh) p += feat[r][k] * w[jj][i];
+        }
+        p = wsum64(p);
+        if (lane == 0) hid[r][j] = fmaxf(p + a.b0[j], 0.f);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- logits: wave = (r, c) ----
+  for (int o = wave; o < RB * C; o += HR_WAVES) {
+    const int r = o / C, c = o - r * C;
+    float p = 0.f;
+    for (int k = lane; k < dh; k += 64) p += hid[r][k] * a.w2[(long)c * dh + k];
+    p = wsum64(p);
+    if (lane == 0) lg[r][c] = p + a.b2[c];
+  }
+  __syncthreads();
+  // ---- softmax cross entropy per sample, dlogits = (softmax - onehot) / B ----
+  if (tid < RB && b0 + tid < B) {
+    const int r = tid, b = b0 + r;
+    float m = lg[r][0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, lg[r][c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(lg[r][c] - m);
+    const float lse = m + logf(se);
+    const int t = (int)a.y[b];
+    a.lossr[b] = lse - lg[r][t];
+    const float invB = 1.0f / (float)B;
+    for (int c = 0; c < C; ++c) {
+      const float d = (expf(lg[r][c] - lse) - (c == t ? 1.f : 0.f)) * invB;
+      dl[r][c] = d;
+      a.dlog[(long)b * C + c] = d;
+      a.logits[(long)b * C + c] = lg[r][c];
+    }
+  } else if (tid < RB) {
+    for (int c = 0; c < C; ++c) dl[tid][c] = 0.f;
+  }
+  __syncthreads();
+  // ---- dhid = (dlogits W2) gated by hid > 0: thread = (r, j); rows out to the workspace for the weight gradients ----
+  for (int e = tid; e < RB * dh; e += HR_THR) {
+    const int r = e / dh, j = e - r * dh, b = b0 + r;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += dl[r][c] * a.w2[(long)c * dh + j];
+    const float h = hid[r][j];
+    s = h > 0.f ? s : 0.f;
+    dhid[r][j] = s;
+    if (b < B) {
+      a.dhid[(long)b * dh + j] = s;
+      a.hid[(long)b * dh + j] = h;
+      a.feat[(long)b * dh + j] = feat[r][j];
+    }
+  }
+  __syncthreads();
+  // ---- dfeat = dhid W0: the same registers; this wave's rows give a partial for every column, waves combined in order ----
+  {
+    float acc[RB][HR_KI];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int i = 0; i < HR_KI; ++i) acc[r][i] = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < HR_RJ; ++jj) {
+      const int j = wave + HR_WAVES * jj;
+      if (j < dh) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const float d = dhid[r][j];
+#pragma unroll
+          for (int i = 0; i < HR_KI; ++i) acc[r][i] += d * w[jj][i];
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int i = 0; i < HR_KI; ++i) red[((size_t)wave * RB + r) * HR_LD + lane + 64 * i] = acc[r][i];
+  }
+  __syncthreads();
+  for (int e = tid; e < RB * HR_LD; e += HR_THR) {
+    const int r = e / HR_LD, k = e - r * HR_LD;
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < HR_WAVES; ++q) s += red[((size_t)q * RB + r) * HR_LD + k];
+    dfeat[r][k] = s;
+    const int b = b0 + r;
+    if (k >= D && k < dh && b < B) a.demb[(long)b * a.Fe + (k - D)] = s;   // gradient of the static embedding's output
+  }
+  __syncthreads();
+  // ---- masked mean backward: dr[t,b,:] = valid ? dfeat[b,:D] / (len + 1) : 0   (code/models_rd.py:379, autograd) ----
+  for (int e = tid; e < RB * T * D4; e += HR_THR) {
+    const int c4 = e % D4, rt = e / D4;
+    const int t = rt % T, r = rt / T, b = b0 + r;
+    if (b >= B) continue;
+    const float il = a.mask[(long)b * T + t] ? 0.f : invl[r];
+    const float4 v = *reinterpret_cast<const float4*>(&dfeat[r][4 * c4]);
+    *reinterpret_cast<float4*>(a.dr + ((long)t * B + b) * D + 4 * c4) = make_float4(v.x * il, v.y * il, v.z * il, v.w * il);
+  }
+}
+
+// dW[n,k] = sum_b u[b,n] v[b,k], db[n] = sum_b u[b,n]: 16 x 16 output tile per workgroup, thread = one output
+struct HwJob { const float* u; const float* v; float *dW, *db; int ldu, ldv, N, K, tiles_k, blk0; };
+struct HwArgs { HwJob j[3]; int n, B; const float* lossr; float* loss; };
+
+__global__ __launch_bounds__(256) void k_head_wgrad(HwArgs a) {
+  __shared__ float us[256][16], vs[256][17];
+  HwJob J = a.j[0];
+#pragma unroll
+  for (int i = 1; i < 3; ++i)
+    if (i < a.n && (int)blockIdx.x >= a.j[i].blk0) J = a.j[i];
+  const int local = blockIdx.x - J.blk0;
+  const int tn = local / J.tiles_k, tk = local - tn * J.tiles_k;
+  const int tid = threadIdx.x, ni = tid >> 4, ki = tid & 15;
+  const int n = 16 * tn + ni, k = 16 * tk + ki;
+  float acc = 0.f, bacc = 0.f;
+  for (int bb = 0; bb < a.B; bb += 256) {
+    float ur[16], vr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + 256 * i, row = e >> 4, col = e & 15, b = bb + row;
+      ur[i] = 0.f; vr[i] = 0.f;
+      if (b < a.B && 16 * tn + col < J.N) ur[i] = J.u[(long)b * J.ldu + 16 * tn + col];
+      if (b < a.B && 16 * tk + col < J.K) vr[i] = J.v[(long)b * J.ldv + 16 * tk + col];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + 256 * i, row = e >> 4, col = e & 15;
+      us[row][col] = ur[i]; vs[row][col] = vr[i];
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int b = 0; b < 256; ++b) { acc += us[b][ni] * vs[b][ki]; bacc += us[b][ni]; }
+  }
+  if (n < J.N && k < J.K) J.dW[(long)n * J.K + k] = acc;
+  if (tk == 0 && ki == 0 && n < J.N && J.db) J.db[n] = bacc;
+  if (blockIdx.x == 0 && tid < 64) {                  // loss = mean of the per-sample losses (lane-strided, then lanes in order)
+    float s = 0.f;
+    for (int b = tid; b < a.B; b += 64) s += a.lossr[b];
+    s = wsum64(s);
+    if (tid == 0) *a.loss = s / (float)a.B;
+  }
+}
+
+}  // namespace
+}  // namespace rd
+
+using namespace rd;
+
+extern "C" size_t rd_head_train_workspace_bytes(int32_t B, int32_t dh, int32_t C) {
+  if (B < 0 || dh <= 0 || C <= 0) return 0;
+  return align_up(((size_t)4 * B * dh + (size_t)B * C + B) * sizeof(float), 256);
+}
+
+extern "C" int rd_head_train_supported(int32_t D, int32_t Fe, int32_t C) {
+  const char* e = getenv("RD_HEAD_FUSED");
+  if (e && atoi(e) == 0) return 0;
+  return (D % 4) == 0 && D > 0 && Fe >= 0 && D + Fe <= 256 && C >= 1 && C <= 16 && 2 * (D / 4) <= HR_THR;
+}
+
+extern "C" int rd_head_train(const rd_shape* s, int32_t D, int32_t d_static, int32_t Fe, int32_t C, const float* r,
+                             const uint8_t* mask, const int64_t* lengths, const float* stat, const float* emb_w,
+                             const float* emb_b, const float* w0, const float* b0, const float* w2, const float* b2,
+                             const int64_t* y, float* loss, float* logits, float* g_emb_w, float* g_emb_b, float* g_w0,
+                             float* g_b0, float* g_w2, float* g_b2, float* dr, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+  RD_REQUIRE(s && s->T > 0 && s->B > 0, "bad shape");
+  RD_REQUIRE(rd_head_train_supported(D, Fe, C), "head_train: unsupported sizes D=%d Fe=%d C=%d", D, Fe, C);
+  RD_REQUIRE(r && mask && lengths && w0 && b0 && w2 && b2 && y && loss && logits && g_w0 && g_b0 && g_w2 && g_b2 && dr && workspace,
+             "NULL tensor");
+  RD_REQUIRE(Fe == 0 || (stat && emb_w && emb_b && g_emb_w && g_emb_b && d_static > 0), "static embedding tensors missing");
+  const int B = s->B, dh = D + Fe;
+  RD_REQUIRE(workspace_bytes >= rd_head_train_workspace_bytes(B, dh, C), "workspace too small");
+  RD_REQUIRE((reinterpret_cast<uintptr_t>(r) & 15) == 0 && (reinterpret_cast<uintptr_t>(dr) & 15) == 0, "r / dr must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  HeadArgs a{};
+  a.r = r; a.mask = mask; a.lengths = lengths; a.stat = stat; a.emb_w = emb_w; a.emb_b = emb_b; a.w0 = w0; a.b0 = b0; a.w2 = w2;
+  a.b2 = b2; a.y = y; a.logits = logits; a.dr = dr;
+  float* ws = (float*)workspace;
+  a.feat = ws; a.hid = a.feat + (size_t)B * dh; a.dhid = a.hid + (size_t)B * dh; a.demb = a.dhid + (size_t)B * dh;
+  a.dlog = a.demb + (size_t)B * dh; a.lossr = a.dlog + (size_t)B * C;
+  a.T = s->T; a.B = B; a.D = D; a.ds = d_static; a.Fe = Fe; a.dh = dh; a.C = C;
+  constexpr int RB = 2;
+  hipLaunchKernelGGL(k_head_rows<RB>, dim3(cdiv(B, RB)), dim3(HR_THR), 0, st, a);
+  int rc = check_launch("k_head_rows");
+  if (rc) return rc;
+  HwArgs h{};
+  h.B = B; h.lossr = a.lossr; h.loss = loss;
+  int blk = 0, n = 0;
+  auto add = [&](const float* u, int ldu, int N, const float* v, int ldv, int K, float* dW, float* db) {
+    HwJob& J = h.j[n++];
+    J.u = u; J.ldu = ldu; J.N = N; J.v = v; J.ldv = ldv; J.K = K; J.dW = dW; J.db = db;
+    J.tiles_k = cdiv(K, 16); J.blk0 = blk; blk += cdiv(N, 16) * J.tiles_k;
+  };
+  add(a.dhid, dh, dh, a.feat, dh, dh, g_w0, g_b0);                       // d mlp_static[0]
+  add(a.dlog, C, C, a.hid, dh, dh, g_w2, g_b2);                          // d mlp_static[2]
+  if (Fe) add(a.demb, Fe, Fe, stat, d_static, d_static, g_emb_w, g_emb_b);   // d emb
+  h.n = n;
+  hipLaunchKernelGGL(k_head_wgrad, dim3(blk), dim3(256), 0, st, h);
+  return check_launch("k_head_wgrad");
+}

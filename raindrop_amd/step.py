@@ -116,6 +116,9 @@ class TrainStep:
         self.wg_ws = u8(max(lib.rd_linear_bwd_weight_workspace_bytes(B, dh, dh),
                             lib.rd_linear_bwd_weight_workspace_bytes(B, m.n_classes, dh),
                             lib.rd_linear_bwd_weight_workspace_bytes(B, max(self.Fe, 1), max(m.d_static, 1))))
+        # classifier head + loss + their backward as two launches (rd_head.hip) when the sizes fit, else operator by operator
+        self.head_fused = bool(lib.rd_head_train_supported(D, self.Fe, m.n_classes))
+        self.head_ws = u8(lib.rd_head_train_workspace_bytes(B, dh, m.n_classes)) if self.head_fused else None
         self.enc_w = []
         self.enc_g = []
         for i, layer in enumerate(m.transformer_encoder.layers):
@@ -147,6 +150,34 @@ class TrainStep:
             c("rd_encoder_layer_fwd", sp, i, _p(self.x[i]), _p(self.mask), ctypes.byref(self.enc_w[i]), self.p_drop,
               self.seed, _p(self.x[i + 1]), _p(self.enc_saved[i]), self.enc_saved[i].numel(), _p(self.enc_ws),
               self.enc_ws.numel(), st)
+        cur = self.dx[0]
+        if self.head_fused:
+            e = (lambda n: _p(P[n]) if Fe else None)
+            ge = (lambda n: _p(G[n]) if Fe else None)
+            c("rd_head_train", sp, D, m.d_static if Fe else 0, Fe, m.n_classes, _p(self.x[-1]), _p(self.mask), _p(b["lengths"]),
+              _p(b["static"]) if Fe else None, e("emb.weight"), e("emb.bias"), _p(P["mlp_static.0.weight"]),
+              _p(P["mlp_static.0.bias"]), _p(P["mlp_static.2.weight"]), _p(P["mlp_static.2.bias"]), _p(b["y"]), _p(self.loss),
+              _p(self.logits), ge("emb.weight"), ge("emb.bias"), _p(G["mlp_static.0.weight"]), _p(G["mlp_static.0.bias"]),
+              _p(G["mlp_static.2.weight"]), _p(G["mlp_static.2.bias"]), _p(cur), _p(self.head_ws), self.head_ws.numel(), st)
+        else:
+            self._head_by_operator(cur, st)
+        for i in reversed(range(self.nl)):
+            nxt = self.dx[1] if cur is self.dx[0] else self.dx[0]
+            c("rd_encoder_layer_bwd", sp, i, _p(self.x[i]), _p(self.mask), ctypes.byref(self.enc_w[i]), self.p_drop,
+              self.seed, _p(self.enc_saved[i]), self.enc_saved[i].numel(), _p(cur), _p(nxt), ctypes.byref(self.enc_g[i]),
+              _p(self.enc_ws), self.enc_ws.numel(), st)
+            cur = nxt
+        c("rd_msgpass_bwd", sp, _p(b["src"]), _p(P["R_u"]), _p(W1), _p(W2), _p(ssum), self.p_drop, _p(self.k1_saved),
+          self.k1_saved.numel(), _p(self.z), _p(cur), D, _p(G["ob_propagation.lin_value.weight"]),
+          _p(G["ob_propagation.lin_value.bias"]), _p(G["ob_propagation_layer2.lin_value.weight"]),
+          _p(G["ob_propagation_layer2.lin_value.bias"]), _p(G["R_u"]), _p(self.k1_ws), self.k1_ws.numel(), st)
+
+    def _head_by_operator(self, cur, st):
+        """masked mean -> [agg | emb] -> mlp_static -> cross entropy and their backward, one C-ABI call per operator."""
+        m, b, P, G, sp = self.model, self.batch, self.P, self.G, self.sp
+        B, D, Fe = self.B, self.D, self.Fe
+        dh = D + Fe
+        c = self._call
         c("rd_masked_mean_fwd", sp, D, _p(self.x[-1]), _p(self.mask), _p(b["lengths"]), _p(self.feat), dh, st)
         if Fe:
             emb_out = self.feat[:, D:]                                       # right block of [agg | emb]
@@ -172,18 +203,7 @@ class TrainStep:
             demb = self.dfeat[:, D:]
             c("rd_linear_bwd_weight", B, Fe, m.d_static, ctypes.c_void_p(demb.data_ptr()), dh, _p(b["static"]),
               m.d_static, _p(G["emb.weight"]), _p(G["emb.bias"]), ws, wsn, st)
-        cur = self.dx[0]
         c("rd_masked_mean_bwd", sp, D, _p(self.dfeat), dh, _p(self.mask), _p(b["lengths"]), _p(cur), st)
-        for i in reversed(range(self.nl)):
-            nxt = self.dx[1] if cur is self.dx[0] else self.dx[0]
-            c("rd_encoder_layer_bwd", sp, i, _p(self.x[i]), _p(self.mask), ctypes.byref(self.enc_w[i]), self.p_drop,
-              self.seed, _p(self.enc_saved[i]), self.enc_saved[i].numel(), _p(cur), _p(nxt), ctypes.byref(self.enc_g[i]),
-              _p(self.enc_ws), self.enc_ws.numel(), st)
-            cur = nxt
-        c("rd_msgpass_bwd", sp, _p(b["src"]), _p(P["R_u"]), _p(W1), _p(W2), _p(ssum), self.p_drop, _p(self.k1_saved),
-          self.k1_saved.numel(), _p(self.z), _p(cur), D, _p(G["ob_propagation.lin_value.weight"]),
-          _p(G["ob_propagation.lin_value.bias"]), _p(G["ob_propagation_layer2.lin_value.weight"]),
-          _p(G["ob_propagation_layer2.lin_value.bias"]), _p(G["R_u"]), _p(self.k1_ws), self.k1_ws.numel(), st)
 
     def _with_cell(self, fn):
         """Run `fn` with this step's seed cell registered.  The registration is read when a kernel is ENQUEUED (the pointer
