@@ -85,7 +85,13 @@ struct AttnArgs {
   float* delta;          // bwd: [B,H,T] rowsum(dout * out)
   int T, B, D, H, hd;
   float scale, p_drop; uint64_t seed; uint32_t site; const uint64_t* seed_cell;
+  unsigned long long* stamps;   // debug only (tools/attn_timing.py)
 };
+static unsigned long long* g_attn_stamps = nullptr;
+#define ASTAMP(i)                                                                                         \
+  do {                                                                                                    \
+    if (a.stamps && blockIdx.x < 8 && threadIdx.x == 0) a.stamps[blockIdx.x * 16 + (i)] = clock64();      \
+  } while (0)
 
 // Dropout mask of the attention probabilities: element (bh, q, key) is component (q & 3) of the Philox
 // quad (bh*T + key)*ceil(T/4) + (q >> 2): the four query rows a lane holds in an MFMA accumulator
@@ -615,6 +621,330 @@ __global__ __launch_bounds__(256) void k_attn_bwd_one(AttnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Single-tile attention (T <= 64: the P19 shape) on the split-bf16 matrix path.  The kernels above contract in exact
+// fp32 (v_mfma_f32_16x16x4_f32: 1/16 of the bf16 rate, and one 4-byte LDS read per operand and MFMA); here the
+// Q / K / V / dO tiles are split ONCE into bf16 hi/lo planes while they are stored to LDS, every contraction is
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 (fp32 accumulate, ~2^-16 per product like every dense product of
+// the path), and an operand fragment is one 16-byte LDS read -- or, where the reduction index runs along the plane's
+// ROWS (P V, dS K, dS^T Q, P^T dO), two transposing reads (ds_read_b64_tr_b16).  P o M and dS are stored TRANSPOSED
+// ([key][query]): the four query rows a lane holds in an accumulator become one 8-byte store.
+// Same masks, same dropout quads (attn_keep4), same saved LSE as the fp32 kernels; used in the bf16 modes only.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 abf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 abf4 __attribute__((ext_vector_type(4)));
+typedef short as4 __attribute__((ext_vector_type(4)));
+typedef short as8 __attribute__((ext_vector_type(8)));
+constexpr int LDT = TS + 8;                     // row stride (bf16) of the transposed score planes [key][query]
+
+// fragment with the reduction index along the plane's columns: lane -> row row0 + (lane & 15), columns k0 + 8 (lane >> 4) ..
+__device__ __forceinline__ abf8 frag_n(const __bf16* P, int ld, int row0, int k0, int lane) {
+  return *reinterpret_cast<const abf8*>(P + (row0 + (lane & 15)) * ld + k0 + 8 * (lane >> 4));
+}
+// fragment with the reduction index along the plane's rows: lane -> column col0 + (lane & 15), rows k0 + 8 (lane >> 4) ..
+__device__ __forceinline__ abf8 frag_t(const __bf16* P, int ld, int k0, int col0, int lane) {
+  const int i = lane & 15, G = lane >> 4;
+  const __bf16* src = P + (k0 + 8 * G + (i >> 2)) * ld + col0 + 4 * (i & 3);
+  const as4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((as4 __attribute__((address_space(3)))*)(src));
+  const as4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((as4 __attribute__((address_space(3)))*)(src + 4 * ld));
+  const as8 o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(abf8, o);
+}
+// acc[j] += A(16 x KK) B(KK x 16 NT), split-bf16.  AT / BT: operand read transposed (reduction along plane rows).
+// a0: first row (AT: first column) of A's 16-wide slice; B tile j starts at row (BT: column) 16 j.
+template <int NT, bool AT, bool BT>
+__device__ __forceinline__ void mma_b16(f32x4 (&acc)[NT], const __bf16* Ah, const __bf16* Al, int lda, int a0,
+                                        const __bf16* Bh, const __bf16* Bl, int ldb, int KK, int lane, bool one) {
+  for (int k0 = 0; k0 < KK; k0 += 32) {
+    const abf8 ah = AT ? frag_t(Ah, lda, k0, a0, lane) : frag_n(Ah, lda, a0, k0, lane);
+    const abf8 al = AT ? frag_t(Al, lda, k0, a0, lane) : frag_n(Al, lda, a0, k0, lane);
+    abf8 bh[NT], bl[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      bh[j] = BT ? frag_t(Bh, ldb, k0, 16 * j, lane) : frag_n(Bh, ldb, 16 * j, k0, lane);
+      bl[j] = BT ? frag_t(Bl, ldb, k0, 16 * j, lane) : frag_n(Bl, ldb, 16 * j, k0, lane);
+    }
+    if (!one) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[j], 0, 0, 0);
+  }
+}
+// head tile (fp32 registers) -> hi/lo planes [64][ldb], columns [16 NTH, hdp) zeroed
+template <int NTH>
+__device__ __forceinline__ void head_store_b16(HeadRegs<NTH>& h, __bf16* Ph, __bf16* Pl, int ldb, int hdp, int tid) {
+  head_mask<NTH>(h);
+  const int o = (tid >> 2) * ldb + 4 * (tid & 3);
+#pragma unroll
+  for (int i = 0; i < NTH; ++i) {
+    const float x[4] = {h.v[i].x, h.v[i].y, h.v[i].z, h.v[i].w};
+    abf4 hi, lo;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { hi[c] = (__bf16)x[c]; lo[c] = (__bf16)(x[c] - (float)hi[c]); }
+    *reinterpret_cast<abf4*>(Ph + o + 16 * i) = hi;
+    *reinterpret_cast<abf4*>(Pl + o + 16 * i) = lo;
+  }
+  if (16 * NTH < hdp) {                                   // at most 16 tail columns (hdp = round-up to 32)
+    abf4 z;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) z[c] = (__bf16)0.f;
+    *reinterpret_cast<abf4*>(Ph + o + 16 * NTH) = z;
+    *reinterpret_cast<abf4*>(Pl + o + 16 * NTH) = z;
+  }
+}
+// the four accumulator rows of a lane (consecutive queries) -> transposed planes [key][query], one 8-byte store each
+__device__ __forceinline__ void store_t4(__bf16* Ph, __bf16* Pl, int key, int q4, const float (&v)[4]) {
+  abf4 hi, lo;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { hi[r] = (__bf16)v[r]; lo[r] = (__bf16)(v[r] - (float)hi[r]); }
+  *reinterpret_cast<abf4*>(Ph + key * LDT + q4) = hi;
+  *reinterpret_cast<abf4*>(Pl + key * LDT + q4) = lo;
+}
+
+template <int NTH>
+__global__ __launch_bounds__(256) void k_attn_fwd_one_b16(AttnArgs a, int one) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8;
+  __bf16* Qh = reinterpret_cast<__bf16*>(bsm);
+  __bf16* Ql = Qh + TS * LDB;
+  __bf16* Kh = Ql + TS * LDB;
+  __bf16* Kl = Kh + TS * LDB;
+  __bf16* Vh = Kl + TS * LDB;
+  __bf16* Vl = Vh + TS * LDB;
+  constexpr bool OVL = LDB >= LDT;                  // P^T overlays Q (dead once S is formed; barrier below) when it fits
+  __bf16* Ph = OVL ? Qh : Vl + TS * LDB;
+  __bf16* Pl = Ph + TS * LDT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const long rs = (long)a.B * 3 * a.D;
+  const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
+  const bool vec = head_vec_ok(a.hd, rs, a.D, qb, nullptr, nullptr);
+  ASTAMP(0);
+  uint64_t seedv = a.seed;
+  uint8_t mb[4];
+  {
+    HeadRegs<NTH> qv, kv, vv;
+    if (vec) {
+      head_load_t<NTH, true>(qv, qb, rs, 0, a.T, a.hd, tid);
+      head_load_t<NTH, true>(kv, qb + a.D, rs, 0, a.T, a.hd, tid);
+      head_load_t<NTH, true>(vv, qb + 2 * a.D, rs, 0, a.T, a.hd, tid);
+    } else {
+      head_load_t<NTH, false>(qv, qb, rs, 0, a.T, a.hd, tid);
+      head_load_t<NTH, false>(kv, qb + a.D, rs, 0, a.T, a.hd, tid);
+      head_load_t<NTH, false>(vv, qb + 2 * a.D, rs, 0, a.T, a.hd, tid);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mb[j] = a.mask[(long)b * a.T + min(16 * j + (lane & 15), a.T - 1)];
+    if (a.p_drop > 0.f && a.seed_cell) seedv += load_uniform_u64(a.seed_cell);
+    __builtin_amdgcn_sched_barrier(0);
+    ASTAMP(1);
+    head_store_b16<NTH>(qv, Qh, Ql, LDB, HDP, tid);
+    head_store_b16<NTH>(kv, Kh, Kl, LDB, HDP, tid);
+    head_store_b16<NTH>(vv, Vh, Vl, LDB, HDP, tid);
+  }
+  ASTAMP(2);
+  __syncthreads();
+  ASTAMP(3);
+  const float inv_keep = 1.0f / (1.0f - a.p_drop);
+  f32x4 s[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  mma_b16<4, false, false>(s, Qh, Ql, LDB, wave * 16, Kh, Kl, LDB, HDP, lane, one);      // S = Q K^T
+  ASTAMP(4);
+  float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int key = 16 * j + (lane & 15);
+    const bool dead = key >= a.T || mb[j];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s[j][r] = dead ? -INFINITY : s[j][r] * a.scale;
+      mx[r] = fmaxf(mx[r], s[j][r]);
+    }
+  }
+  float m_i[4], l_i[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) m_i[r] = group16_max(mx[r]);
+  __syncthreads();                                  // every wave is done with Q before P^T overwrites it
+  float rsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int key = 16 * j + (lane & 15);
+    float k4[4] = {1.f, 1.f, 1.f, 1.f};
+    if (a.p_drop > 0.f)
+      attn_keep4(k4, seedv, a.site, bh, a.T, wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
+    float pv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float p = (s[j][r] == -INFINITY) ? 0.f : __expf(s[j][r] - m_i[r]);
+      rsum[r] += p;
+      pv[r] = p * k4[r];
+    }
+    store_t4(Ph, Pl, key, wave * 16 + 4 * (lane >> 4), pv);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) l_i[r] = group16_sum(rsum[r]);
+  __syncthreads();
+  ASTAMP(5);
+  f32x4 o[NTH];
+#pragma unroll
+  for (int j = 0; j < NTH; ++j) o[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  mma_b16<NTH, true, true>(o, Ph, Pl, LDT, wave * 16, Vh, Vl, LDB, TS, lane, one);        // O = P V
+  ASTAMP(6);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int q = wave * 16 + 4 * (lane >> 4) + r;
+    if (q >= a.T) continue;
+    const float inv = 1.0f / l_i[r];
+#pragma unroll
+    for (int j = 0; j < NTH; ++j) {
+      const int c = 16 * j + (lane & 15);
+      if (c < a.hd) a.out[((long)q * a.B + b) * a.D + h * a.hd + c] = o[j][r] * inv;
+    }
+    if ((lane & 15) == 0) a.lse[(long)bh * a.T + q] = m_i[r] + logf(l_i[r]);
+  }
+  ASTAMP(7);
+}
+
+template <int NTH>
+__global__ __launch_bounds__(256) void k_attn_bwd_one_b16(AttnArgs a, int one) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8;
+  __bf16* Qh = reinterpret_cast<__bf16*>(bsm);
+  __bf16* Ql = Qh + TS * LDB;
+  __bf16* Kh = Ql + TS * LDB;
+  __bf16* Kl = Kh + TS * LDB;
+  __bf16* Vh = Kl + TS * LDB;
+  __bf16* Vl = Vh + TS * LDB;
+  __bf16* Oh = Vl + TS * LDB;                       // dO
+  __bf16* Ol = Oh + TS * LDB;
+  __bf16* Ph = Ol + TS * LDB;                       // (P o M)^T  [key][query]
+  __bf16* Pl = Ph + TS * LDT;
+  __bf16* Sh = Pl + TS * LDT;                       // dS^T       [key][query]
+  __bf16* Sl = Sh + TS * LDT;
+  float* lse_s = reinterpret_cast<float*>(Sl + TS * LDT);
+  float* dl_s = lse_s + TS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const long rs = (long)a.B * 3 * a.D, ro = (long)a.B * a.D;
+  const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
+  const float* dob = a.dout + (long)b * a.D + h * a.hd;
+  const float* ob = a.out + (long)b * a.D + h * a.hd;
+  const bool vec = head_vec_ok(a.hd, rs, ro, qb, dob, ob);
+  ASTAMP(0);
+  uint64_t seedv = a.seed;
+  uint8_t mb[4];
+  {
+    HeadRegs<NTH> qv, kv, vv, dov, ov;
+    if (vec) {
+      head_load_t<NTH, true>(qv, qb, rs, 0, a.T, a.hd, tid);
+      head_load_t<NTH, true>(kv, qb + a.D, rs, 0, a.T, a.hd, tid);
+      head_load_t<NTH, true>(vv, qb + 2 * a.D, rs, 0, a.T, a.hd, tid);
+      head_load_t<NTH, true>(dov, dob, ro, 0, a.T, a.hd, tid);
+      head_load_t<NTH, true>(ov, ob, ro, 0, a.T, a.hd, tid);
+    } else {
+      head_load_t<NTH, false>(qv, qb, rs, 0, a.T, a.hd, tid);
+      head_load_t<NTH, false>(kv, qb + a.D, rs, 0, a.T, a.hd, tid);
+      head_load_t<NTH, false>(vv, qb + 2 * a.D, rs, 0, a.T, a.hd, tid);
+      head_load_t<NTH, false>(dov, dob, ro, 0, a.T, a.hd, tid);
+      head_load_t<NTH, false>(ov, ob, ro, 0, a.T, a.hd, tid);
+    }
+    const int r = tid >> 2;
+    const float l = r < a.T ? a.lse[(long)bh * a.T + r] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mb[j] = a.mask[(long)b * a.T + min(16 * j + (lane & 15), a.T - 1)];
+    if (a.p_drop > 0.f && a.seed_cell) seedv += load_uniform_u64(a.seed_cell);
+    __builtin_amdgcn_sched_barrier(0);
+    ASTAMP(1);
+    head_store_b16<NTH>(qv, Qh, Ql, LDB, HDP, tid);
+    head_store_b16<NTH>(kv, Kh, Kl, LDB, HDP, tid);
+    head_store_b16<NTH>(vv, Vh, Vl, LDB, HDP, tid);
+    head_mask<NTH>(ov);
+    head_mask<NTH>(dov);
+    const float d = head_rowdot<NTH>(dov, ov);          // delta = rowsum(dO * O), in fp32
+    head_store_b16<NTH>(dov, Oh, Ol, LDB, HDP, tid);
+    if ((tid & 3) == 0) { dl_s[r] = d; lse_s[r] = l; }
+  }
+  ASTAMP(2);
+  __syncthreads();
+  ASTAMP(3);
+  const float inv_keep = 1.0f / (1.0f - a.p_drop);
+  f32x4 s[4], dp[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { s[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[j] = s[j]; }
+  mma_b16<4, false, false>(s, Qh, Ql, LDB, wave * 16, Kh, Kl, LDB, HDP, lane, one);      // S  = Q K^T
+  mma_b16<4, false, false>(dp, Oh, Ol, LDB, wave * 16, Vh, Vl, LDB, HDP, lane, one);     // dP = dO V^T
+  ASTAMP(4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int key = 16 * j + (lane & 15);
+    const bool dead = key >= a.T || mb[j];
+    float k4[4] = {1.f, 1.f, 1.f, 1.f};
+    if (a.p_drop > 0.f)
+      attn_keep4(k4, seedv, a.site, bh, a.T, wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
+    float pm[4], ds[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wave * 16 + 4 * (lane >> 4) + r;
+      pm[r] = 0.f; ds[r] = 0.f;
+      if (!dead && row < a.T) {
+        const float p = __expf(s[j][r] * a.scale - lse_s[row]);
+        pm[r] = p * k4[r];
+        ds[r] = p * (dp[j][r] * k4[r] - dl_s[row]) * a.scale;
+      }
+    }
+    store_t4(Ph, Pl, key, wave * 16 + 4 * (lane >> 4), pm);
+    store_t4(Sh, Sl, key, wave * 16 + 4 * (lane >> 4), ds);
+  }
+  ASTAMP(5);
+  __syncthreads();
+  f32x4 dq[NTH], dk[NTH], dv[NTH];
+#pragma unroll
+  for (int j = 0; j < NTH; ++j) { dq[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[j] = dq[j]; dv[j] = dq[j]; }
+  mma_b16<NTH, true, true>(dq, Sh, Sl, LDT, wave * 16, Kh, Kl, LDB, TS, lane, one);      // dQ = dS K       (rows: queries)
+  mma_b16<NTH, false, true>(dk, Sh, Sl, LDT, wave * 16, Qh, Ql, LDB, TS, lane, one);     // dK = dS^T Q     (rows: keys)
+  mma_b16<NTH, false, true>(dv, Ph, Pl, LDT, wave * 16, Oh, Ol, LDB, TS, lane, one);     // dV = (P o M)^T dO
+  ASTAMP(6);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int t = wave * 16 + 4 * (lane >> 4) + r;
+    if (t >= a.T) continue;
+    float* row = a.dqkv + ((long)t * a.B + b) * 3 * a.D + h * a.hd;
+#pragma unroll
+    for (int j = 0; j < NTH; ++j) {
+      const int c = 16 * j + (lane & 15);
+      if (c < a.hd) { row[c] = dq[j][r]; row[a.D + c] = dk[j][r]; row[2 * a.D + c] = dv[j][r]; }
+    }
+  }
+  ASTAMP(7);
+}
+
+static bool attn_b16_ok(const AttnArgs& a) {
+  const char* e = getenv("RD_ATTN_B16");              // read per call (tests compare both paths in one process)
+  return !(e && atoi(e) == 0) && precision() != RD_PREC_FP32 && a.T <= TS && a.hd <= 96;
+}
+template <int NTH>
+int launch_attn_b16(const AttnArgs& a_in, int which, hipStream_t st) {
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8;
+  const int one = precision() == RD_PREC_BF16;
+  AttnArgs a = a_in;
+  a.stamps = g_attn_stamps;
+  if (which == 0) {
+    const size_t lds = (size_t)(6 * TS * LDB + (LDB >= LDT ? 0 : 2 * TS * LDT)) * sizeof(__bf16);
+    RD_LDS_ATTR((k_attn_fwd_one_b16<NTH>), lds);
+    hipLaunchKernelGGL(k_attn_fwd_one_b16<NTH>, dim3(a.B * a.H), dim3(256), lds, st, a, one);
+    return check_launch("k_attn_fwd_one_b16");
+  }
+  const size_t lds = (size_t)(8 * TS * LDB + 4 * TS * LDT) * sizeof(__bf16) + 2 * TS * sizeof(float);
+  RD_LDS_ATTR((k_attn_bwd_one_b16<NTH>), lds);
+  hipLaunchKernelGGL(k_attn_bwd_one_b16<NTH>, dim3(a.B * a.H), dim3(256), lds, st, a, one);
+  return check_launch("k_attn_bwd_one_b16");
+}
+
 template <int NTH>
 int launch_attn(const AttnArgs& a, int which, hipStream_t st) {
   constexpr int LDH = 16 * NTH + 4;
@@ -645,6 +975,16 @@ int launch_attn(const AttnArgs& a, int which, hipStream_t st) {
 }
 
 int dispatch_attn(const AttnArgs& a, int which, hipStream_t st) {
+  if ((which == 0 || which == 3) && attn_b16_ok(a)) {
+    switch (cdiv(a.hd, 16)) {
+      case 1: return launch_attn_b16<1>(a, which, st);
+      case 2: return launch_attn_b16<2>(a, which, st);
+      case 3: return launch_attn_b16<3>(a, which, st);
+      case 4: return launch_attn_b16<4>(a, which, st);
+      case 5: return launch_attn_b16<5>(a, which, st);
+      default: return launch_attn_b16<6>(a, which, st);
+    }
+  }
   switch (cdiv(a.hd, 16)) {
     case 1: return launch_attn<1>(a, which, st);
     case 2: return launch_attn<2>(a, which, st);
@@ -1212,6 +1552,8 @@ extern "C" size_t rd_encoder_layer_workspace_bytes(const rd_shape* s) {
   if (check_enc(s)) return 0;
   return carve_ws(enc_dims(s), nullptr).bytes;
 }
+
+extern "C" void rd_debug_set_attn_stamps(void* p) { g_attn_stamps = (unsigned long long*)p; }   // not part of the ABI
 
 extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const float* x, const uint8_t* mask,
                                     const rd_encoder_weights* w, float p_drop, uint64_t seed, float* y,
