@@ -115,7 +115,12 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wy = wave >> 1, wx = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int z = blockIdx.z;
+  int z = blockIdx.z;
+  if (g.nbatch > 1) {                                 // batched: z selects the problem, no split
+    const int o = z / g.batch_inner, i = z - o * g.batch_inner;
+    g.A += o * g.a_bo + i * g.a_bi; g.B += o * g.b_bo + i * g.b_bi; g.C += o * g.c_bo + i * g.c_bi;
+    z = 0;
+  }
   const int kbeg = z * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
 
@@ -433,6 +438,11 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
   const int cblk = swz ? jj - (jj / ncb) * ncb : lin - (lin / ncb) * ncb;
   const int m0 = rblk * TM, n0 = cblk * TN;
   if (m0 >= g.M) return;                              // padding blocks of the last group of 8 row blocks
+  if (g.nbatch > 1) {                                 // batched: z selects the problem, no split
+    const int o = z / g.batch_inner, i = z - o * g.batch_inner;
+    g.A += o * g.a_bo + i * g.a_bi; g.B += o * g.b_bo + i * g.b_bi; g.C += o * g.c_bo + i * g.c_bi;
+    z = 0;
+  }
   if (g.A2 != nullptr && z >= g.nsplit) {             // second problem of a batched pair (uniform per block)
     z -= g.nsplit;
     g.A = g.A2; g.B = g.B2; g.C = g.C2; g.rowsum = g.rowsum2;
@@ -563,7 +573,7 @@ int launch_bf16x3_n(const GemmArgs& g, hipStream_t st) {
   const size_t planes = (size_t)2 * (TM + TN) * LDB * sizeof(__bf16);
   const size_t stage = (size_t)TM * (TN + 4) * sizeof(float);       // epilogue transpose tile (aliases the planes)
   const size_t lds = (planes > stage ? planes : stage) + TN * sizeof(float);   // + bias
-  const int nz = (g.nsplit > 1 ? g.nsplit : 1) * (g.A2 ? 2 : 1);
+  const int nz = g.nbatch > 1 ? g.nbatch : (g.nsplit > 1 ? g.nsplit : 1) * (g.A2 ? 2 : 1);
   dim3 grid((g.nsplit > 1 ? cdiv(g.M, TM) : 8 * cdiv(cdiv(g.M, TM), 8)) * cdiv(g.N, TN), 1, nz);
   if (g.slice_xcd) grid = dim3(8 * cdiv(nz, 8) * cdiv(g.M, TM) * cdiv(g.N, TN), 1, 1);
   if (lds > 48 * 1024)
@@ -705,7 +715,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   const bool akc = (a.sa_k == 1) && !(a.rowsum && a.sa_m == 1), bkc = (a.sb_k == 1);
   if (!akc && a.sa_m != 1) return fail(RD_EINVAL, "gemm: A needs a unit stride");
   if (!bkc && a.sb_n != 1) return fail(RD_EINVAL, "gemm: B needs a unit stride");
-  dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), a.nsplit > 1 ? a.nsplit : 1);
+  if (a.nbatch > 1 && (a.nsplit > 1 || a.A2 || a.rowsum || a.scatter || a.batch_inner < 1))
+    return fail(RD_EINVAL, "gemm: the batched form takes plain single-pass products only");
+  dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), a.nbatch > 1 ? a.nbatch : (a.nsplit > 1 ? a.nsplit : 1));
   GemmArgs g = a;
   g.seed_cell = seed_cell();
   g.stamps = g_gemm_stamps;

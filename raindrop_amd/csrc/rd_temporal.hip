@@ -64,6 +64,16 @@ __device__ __forceinline__ void mma_f32(f32x4 (&acc)[NT], const float* a, int a_
   }
 }
 
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
 __device__ __forceinline__ float group16_max(float v) {
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -974,6 +984,114 @@ int launch_attn(const AttnArgs& a, int which, hipStream_t st) {
   return check_launch("k_attn_bwd_dkv");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide heads (head_dim > 96: the 256-sensor stress shape, D = 1040, 2 heads of 520): the score matrix is MATERIALISED.
+// At head_dim 520 and T = 512 the products are large square GEMMs (MFMA-bound), so the flash-style
+// tiling above buys nothing: S = scale Q K^T, P = softmax(S + key mask), O = dropout(P) V run as batched tiled GEMMs
+// (one problem per (sample, head), rd_gemm.hip) around a row-softmax kernel; P and dropout(P) are saved for the backward
+// (2 B H T^2 floats).  Same masks and the same Philox quads (attn_quad) as the tiled kernels.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_softmax_rows(float* __restrict__ S, float* __restrict__ PD, const uint8_t* __restrict__ mask,
+                                                      int T, int H, long rows, float p_drop, uint64_t seed, uint32_t site,
+                                                      const uint64_t* cell) {
+  const int lane = threadIdx.x & 63;
+  const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  seed = eff_seed(seed, cell);
+  const int bh = (int)(row / T), q = (int)(row - (long)bh * T), b = bh / H;
+  float* s = S + row * T;
+  float m = -INFINITY;
+  for (int k = lane; k < T; k += 64)
+    if (!mask[(long)b * T + k]) m = fmaxf(m, s[k]);
+  m = wave_max64(m);
+  float sum = 0.f;
+  for (int k = lane; k < T; k += 64)
+    if (!mask[(long)b * T + k]) sum += __expf(s[k] - m);
+  sum = wave_sum64(sum);
+  const float inv = 1.0f / sum, inv_keep = 1.0f / (1.0f - p_drop);
+  for (int k = lane; k < T; k += 64) {
+    const float p = mask[(long)b * T + k] ? 0.f : __expf(s[k] - m) * inv;
+    s[k] = p;
+    PD[row * T + k] = p_drop > 0.f ? p * attn_keep1(seed, site, bh, T, q, k, p_drop, inv_keep) : p;
+  }
+}
+// dS = P o (dP - rowsum(P o dP)) * scale with dP = dPD o keep, in place over dPD
+__global__ __launch_bounds__(256) void k_softmax_bwd_rows(const float* __restrict__ P, float* __restrict__ dPD, int T, long rows,
+                                                          float scale, float p_drop, uint64_t seed, uint32_t site,
+                                                          const uint64_t* cell) {
+  const int lane = threadIdx.x & 63;
+  const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  seed = eff_seed(seed, cell);
+  const int bh = (int)(row / T), q = (int)(row - (long)bh * T);
+  const float* p = P + row * T;
+  float* d = dPD + row * T;
+  const float inv_keep = 1.0f / (1.0f - p_drop);
+  float delta = 0.f;
+  for (int k = lane; k < T; k += 64) {
+    float dp = d[k];
+    if (p_drop > 0.f) dp *= attn_keep1(seed, site, bh, T, q, k, p_drop, inv_keep);
+    d[k] = dp;
+    delta += p[k] * dp;
+  }
+  delta = wave_sum64(delta);
+  for (int k = lane; k < T; k += 64) d[k] = p[k] * (d[k] - delta) * scale;
+}
+
+static GemmArgs bh_gemm(const AttnArgs& a, int M, int N, int K) {
+  GemmArgs g{};
+  g.M = M; g.N = N; g.K = K; g.nsplit = 1; g.nbatch = a.B * a.H; g.batch_inner = a.H;
+  return g;
+}
+// P, PD: [B*H][T][T] each (saved)
+int attn_big_fwd(const AttnArgs& a, float* P, float* PD, hipStream_t st) {
+  const long rs = (long)a.B * 3 * a.D, TT = (long)a.T * a.T;
+  int rc;
+  GemmArgs g = bh_gemm(a, a.T, a.T, a.hd);                                  // S = scale Q K^T
+  g.A = a.qkv; g.sa_m = rs; g.sa_k = 1; g.a_bo = 3 * a.D; g.a_bi = a.hd;
+  g.B = a.qkv + a.D; g.sb_n = rs; g.sb_k = 1; g.b_bo = 3 * a.D; g.b_bi = a.hd;
+  g.C = P; g.sc_m = a.T; g.c_bo = (long)a.H * TT; g.c_bi = TT; g.cscale = a.scale;
+  if ((rc = launch_gemm(g, st))) return rc;
+  const long rows = (long)a.B * a.H * a.T;
+  hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, P, PD, a.mask, a.T, a.H, rows, a.p_drop,
+                     a.seed, a.site, a.seed_cell);
+  if ((rc = check_launch("k_softmax_rows"))) return rc;
+  g = bh_gemm(a, a.T, a.hd, a.T);                                           // O = PD V
+  g.A = PD; g.sa_m = a.T; g.sa_k = 1; g.a_bo = (long)a.H * TT; g.a_bi = TT;
+  g.B = a.qkv + 2 * a.D; g.sb_n = 1; g.sb_k = rs; g.b_bo = 3 * a.D; g.b_bi = a.hd;
+  g.C = a.out; g.sc_m = (long)a.B * a.D; g.c_bo = a.D; g.c_bi = a.hd;
+  return launch_gemm(g, st);
+}
+// dS: [B*H][T][T] workspace
+int attn_big_bwd(const AttnArgs& a, const float* P, const float* PD, float* dS, hipStream_t st) {
+  const long rs = (long)a.B * 3 * a.D, ro = (long)a.B * a.D, TT = (long)a.T * a.T;
+  int rc;
+  GemmArgs g = bh_gemm(a, a.T, a.T, a.hd);                                  // dPD = dO V^T
+  g.A = a.dout; g.sa_m = ro; g.sa_k = 1; g.a_bo = a.D; g.a_bi = a.hd;
+  g.B = a.qkv + 2 * a.D; g.sb_n = rs; g.sb_k = 1; g.b_bo = 3 * a.D; g.b_bi = a.hd;
+  g.C = dS; g.sc_m = a.T; g.c_bo = (long)a.H * TT; g.c_bi = TT;
+  if ((rc = launch_gemm(g, st))) return rc;
+  g = bh_gemm(a, a.T, a.hd, a.T);                                           // dV = PD^T dO
+  g.A = PD; g.sa_m = 1; g.sa_k = a.T; g.a_bo = (long)a.H * TT; g.a_bi = TT;
+  g.B = a.dout; g.sb_n = 1; g.sb_k = ro; g.b_bo = a.D; g.b_bi = a.hd;
+  g.C = a.dqkv + 2 * a.D; g.sc_m = rs; g.c_bo = 3 * a.D; g.c_bi = a.hd;
+  if ((rc = launch_gemm(g, st))) return rc;
+  const long rows = (long)a.B * a.H * a.T;
+  hipLaunchKernelGGL(k_softmax_bwd_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, P, dS, a.T, rows, a.scale, a.p_drop,
+                     a.seed, a.site, a.seed_cell);
+  if ((rc = check_launch("k_softmax_bwd_rows"))) return rc;
+  g = bh_gemm(a, a.T, a.hd, a.T);                                           // dQ = dS K
+  g.A = dS; g.sa_m = a.T; g.sa_k = 1; g.a_bo = (long)a.H * TT; g.a_bi = TT;
+  g.B = a.qkv + a.D; g.sb_n = 1; g.sb_k = rs; g.b_bo = 3 * a.D; g.b_bi = a.hd;
+  g.C = a.dqkv; g.sc_m = rs; g.c_bo = 3 * a.D; g.c_bi = a.hd;
+  if ((rc = launch_gemm(g, st))) return rc;
+  g = bh_gemm(a, a.T, a.hd, a.T);                                           // dK = dS^T Q
+  g.A = dS; g.sa_m = 1; g.sa_k = a.T; g.a_bo = (long)a.H * TT; g.a_bi = TT;
+  g.B = a.qkv; g.sb_n = 1; g.sb_k = rs; g.b_bo = 3 * a.D; g.b_bi = a.hd;
+  g.C = a.dqkv + a.D; g.sc_m = rs; g.c_bo = 3 * a.D; g.c_bi = a.hd;
+  return launch_gemm(g, st);
+}
+
 int dispatch_attn(const AttnArgs& a, int which, hipStream_t st) {
   if ((which == 0 || which == 3) && attn_b16_ok(a)) {
     switch (cdiv(a.hd, 16)) {
@@ -1000,12 +1118,6 @@ int dispatch_attn(const AttnArgs& a, int which, hipStream_t st) {
 // s = x + dropout(r);  y = LayerNorm(s) * g + b.   One wavefront per row; three passes over the
 // row (each lane re-reads only what it wrote), exact two-pass variance like torch.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum64(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
 __global__ __launch_bounds__(256) void k_add_ln_fwd(const float* __restrict__ x, const float* __restrict__ r,
                                                     const float* __restrict__ g, const float* __restrict__ bta,
                                                     float* __restrict__ s_out, float* __restrict__ y,
@@ -1421,8 +1533,16 @@ EncDims enc_dims(const rd_shape* s) {
   return e;
 }
 
+// wide heads take the materialised-score attention; RD_ATTN_BIG=1 forces it for every shape (tests: it must agree with the
+// tiled kernels, masks included).  Read per call: saved / workspace sizes depend on it.
+static bool attn_big(const EncDims& e) {
+  const char* v = getenv("RD_ATTN_BIG");
+  return e.Hd > 96 || (v && atoi(v) != 0);
+}
+
 struct EncSaved { float *qkv, *attn, *lse, *s1, *st1, *x1, *h, *s2, *st2; __bf16* pl[8][2];
                   __bf16* xt[4]; __bf16* ones;        // row tiles of x, attn, x1, h (operands of the weight-gradient stream)
+                  float *pbig, *pdbig;                // wide heads only: P and dropout(P), [B*H][T][T] each
                   size_t bytes; };
 // weight tiles kept from forward to backward: 0 in_proj, 1 out_proj, 2 lin1, 3 lin2, 4 out_proj^T, 5 lin2^T, 6 lin1^T, 7 in_proj^T
 EncSaved carve_saved(const EncDims& e, void* base) {
@@ -1439,11 +1559,14 @@ EncSaved carve_saved(const EncDims& e, void* base) {
   const int xcols[4] = {e.D, e.D, e.D, e.nhid};
   for (int i = 0; i < 4; ++i) v.xt[i] = (__bf16*)take((tile_elems(e.M, xcols[i]) + 1) / 2);
   v.ones = (__bf16*)take((tile_wgrad_ones_elems() + 1) / 2);
+  const size_t big = attn_big(e) ? (size_t)e.B * e.H * e.T * e.T : 0;
+  v.pbig = take(big); v.pdbig = take(big);
   v.bytes = off;
   return v;
 }
 
 struct EncWs { float *o, *f, *ds2, *df, *du, *dx1, *ds1, *dout, *da, *dqkv, *delta, *lnpart, *lnpart1, *lnred, *splitk, *colsum;
+               float* dsbig;                      // wide heads only: dS [B*H][T][T]
                __bf16* dt[4]; float* twpart[4];   // row tiles of df, du, dout, dqkv; slice partials of lin2, lin1, out_proj, in_proj
                size_t bytes; int ns_max; };
 EncWs carve_ws(const EncDims& e, void* base) {
@@ -1467,6 +1590,7 @@ EncWs carve_ws(const EncDims& e, void* base) {
   for (int i = 0; i < 4; ++i) w.dt[i] = (__bf16*)take((tile_elems(e.M, dcols[i]) + 1) / 2);
   const int pn[4] = {e.D, e.nhid, e.D, 3 * e.D}, pk[4] = {e.nhid, e.D, e.D, e.D};
   for (int i = 0; i < 4; ++i) w.twpart[i] = take(tile_wgrad_part_floats(pn[i], pk[i]));
+  w.dsbig = take(attn_big(e) ? (size_t)e.B * e.H * e.T * e.T : 0);
   w.bytes = off;
   return w;
 }
@@ -1534,7 +1658,7 @@ int check_enc(const rd_shape* s) {
              "bad rd_shape");
   const int D = s->F * s->d_ob + s->d_pe;
   RD_REQUIRE(D % s->nhead == 0, "D=%d not divisible by nhead=%d", D, s->nhead);
-  if (D / s->nhead > 96) return fail(RD_EUNSUPPORTED, "head_dim %d > 96 not built", D / s->nhead);
+  RD_REQUIRE((long)s->B * s->nhead * s->T * s->T < (1L << 31) || D / s->nhead <= 96, "score tensor exceeds 2^31 elements");
   RD_REQUIRE((long)s->T * s->B * (3L * D > s->nhid ? 3L * D : s->nhid) < (1L << 31), "tensor exceeds 2^31 elements");
   return RD_OK;
 }
@@ -1592,7 +1716,8 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
   a.qkv = v.qkv; a.mask = mask; a.out = v.attn; a.lse = v.lse;
   a.T = e.T; a.B = e.B; a.D = e.D; a.H = e.H; a.hd = e.Hd;
   a.scale = 1.0f / sqrtf((float)e.Hd); a.p_drop = p_drop; a.seed = seed; a.site = SITE_ATTN_PROB + L; a.seed_cell = seed_cell();
-  if ((rc = dispatch_attn(a, 0, st))) return rc;
+  if (attn_big(e)) { if ((rc = attn_big_fwd(a, v.pbig, v.pdbig, st))) return rc; }
+  else if ((rc = dispatch_attn(a, 0, st))) return rc;
   // out-projection / second FFN layer with the residual add + LayerNorm in their epilogue (a workgroup owns complete rows)
   static const bool ln_fuse_env = [] { const char* e = getenv("RD_LN_FUSE"); return !(e && atoi(e) == 0); }();
   const bool lnf1 = rg && ln_fuse_env && rowgemm_ln_ok(e.D, e.D), lnf2 = rg && ln_fuse_env && rowgemm_ln_ok(e.D, e.nhid);
@@ -1691,7 +1816,9 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   a.qkv = v.qkv; a.mask = mask; a.out = v.attn; a.lse = v.lse; a.dout = ws.da; a.dqkv = ws.dqkv; a.delta = ws.delta;
   a.T = e.T; a.B = e.B; a.D = e.D; a.H = e.H; a.hd = e.Hd;
   a.scale = 1.0f / sqrtf((float)e.Hd); a.p_drop = p_drop; a.seed = seed; a.site = SITE_ATTN_PROB + L; a.seed_cell = seed_cell();
-  if (e.T <= TS) {
+  if (attn_big(e)) {
+    if ((rc = attn_big_bwd(a, v.pbig, v.pdbig, ws.dsbig, st))) return rc;
+  } else if (e.T <= TS) {
     if ((rc = dispatch_attn(a, 3, st))) return rc;          // single tile: S, P, dP, dS formed once
   } else {
     if ((rc = dispatch_attn(a, 1, st))) return rc;

@@ -40,8 +40,11 @@ MODEL_CASES = [
     # larger P12 batch on the generic-K path; gradients stored as strided samples only (FULL_LIMIT) to stay small
     ("p19_b256", "P19", 256, "ones", 6, 8),
     ("p12_b32", "P12", 32, "sparse", 7, 9),
+    # BASELINE.json configs[4], the 256-sensor x 512-step stress shape (K = 2048 message-passing features, two attention
+    # heads of 520): two samples are what the CPU reference finishes in minutes
+    ("syn256_b2", "SYN256", 2, "sparse", 8, 10),
 ]
-FULL_LIMIT = {"p19_b256": 4096, "p12_b32": 4096}
+FULL_LIMIT = {"p19_b256": 4096, "p12_b32": 4096, "syn256_b2": 4096}
 
 
 def strided(t, n=SAMPLE, full_limit=70_000):
@@ -231,7 +234,7 @@ def state_dict_surface():
     """Names and shapes of the reference's state_dict per dataset config (checkpoint surface,
     code/Raindrop.py:374,381).  Under the CPU shim `R_u` is a registered parameter."""
     out = {}
-    for cfg_name in ("TINY", "P19", "P12", "PAM"):
+    for cfg_name in ("TINY", "P19", "P12", "PAM", "SYN256"):
         cfg = synth.make_config(cfg_name)
         model = ref_loader.build_raindrop_v2(cfg, synth.make_structure(cfg, "ones"))
         out[cfg_name] = {k: list(v.shape) for k, v in model.state_dict().items()}

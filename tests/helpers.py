@@ -8,7 +8,7 @@ import torch
 from raindrop_amd import synth
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-MODEL_CASES = ["tiny_sparse", "p19_ones", "p19_sparse", "p12_ones", "pam_ones", "p19_b256", "p12_b32"]
+MODEL_CASES = ["tiny_sparse", "p19_ones", "p19_sparse", "p12_ones", "pam_ones", "p19_b256", "p12_b32", "syn256_b2"]
 
 
 def load_golden(name):

@@ -228,10 +228,12 @@ def _enc_params(D, nhid, seed):
     return {n: synth.param_values("L." + n, shapes[n], seed=seed) for n in ops.ENC_PARAM_NAMES}
 
 
-@pytest.mark.parametrize("T,B,F,nhead", [(7, 3, 5, 2), (60, 6, 34, 2), (215, 2, 36, 2), (130, 2, 17, 2), (64, 3, 12, 4)])
+@pytest.mark.parametrize("T,B,F,nhead", [(7, 3, 5, 2), (60, 6, 34, 2), (215, 2, 36, 2), (130, 2, 17, 2), (64, 3, 12, 4),
+                                         (70, 2, 256, 2), (40, 3, 60, 2)])
 def test_encoder_layer_vs_oracle(T, B, F, nhead):
     """One TransformerEncoderLayer (attention with key-padding mask, LN, FFN) forward and backward
-    against the torch restatement; T=215/130 exercise the multi-tile online softmax."""
+    against the torch restatement; T=215/130 exercise the multi-tile online softmax, F=256 / 60 (head_dim 520 / 128) the
+    materialised-score attention of wide heads."""
     from raindrop_amd import _lib, ops
     D, nhid = F * 4 + 16, 2 * F * 4
     rng = np.random.default_rng(T * 31 + B)
@@ -292,10 +294,43 @@ def test_encoder_tile_weight_gradients_match_split_k(T, B, precision_mode, monke
             assert np.abs(a - r).max() <= 2e-5 * np.abs(r).max(), (name, float(np.abs(a - r).max() / np.abs(r).max()))
 
 
+@pytest.mark.parametrize("T,B,F", [(60, 5, 34), (130, 2, 17), (12, 3, 3)])
+def test_materialised_attention_matches_tiled(T, B, F, monkeypatch):
+    """The materialised-score attention of wide heads (batched GEMMs around a row softmax; RD_ATTN_BIG=1 forces it at any
+    head size) against the flash-style tiled kernels on the same layer WITH dropout: both draw the same Philox quads, so
+    output and every gradient agree to the arithmetic's rounding (2e-5 of max-norm in fp32 mode, 1.2e-4 in split-bf16)."""
+    from raindrop_amd import _lib, ops
+    nhead = 2
+    D, nhid = F * 4 + 16, 2 * F * 4
+    rng = np.random.default_rng(T + B)
+    x = torch.from_numpy(rng.standard_normal((T, B, D)).astype(np.float32)).to(DEV)
+    lengths = torch.from_numpy(rng.integers(1, T + 1, size=B)).long()
+    mask = torch.from_numpy(O2.padding_mask(lengths.numpy(), T)).to(DEV)
+    dy = torch.from_numpy(rng.standard_normal((T, B, D)).astype(np.float32)).to(DEV)
+    p = _enc_params(D, nhid, seed=B)
+    shp = _lib.shape(B, T, F, 4, nhead=nhead, nhid=nhid)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RD_ATTN_BIG", mode)
+        xd = x.clone().requires_grad_(True)
+        pd = [p[n].to(DEV).requires_grad_(True) for n in ops.ENC_PARAM_NAMES]
+        y = ops.encoder_layer(xd, mask, shp, 1, 0.25, 99, pd)
+        g = torch.autograd.grad(y, [xd] + pd, dy)
+        torch.cuda.synchronize()
+        out[mode] = (y.detach().cpu().numpy(), [t.cpu().numpy() for t in g])
+    monkeypatch.delenv("RD_ATTN_BIG")
+    tol = 2e-5 * TOL["x"]
+    assert np.abs(out["1"][0] - out["0"][0]).max() <= tol * np.abs(out["0"][0]).max()
+    for name, a, r in zip(["x"] + list(ops.ENC_PARAM_NAMES), out["1"][1], out["0"][1]):
+        assert np.abs(a - r).max() <= tol * np.abs(r).max(), (name, float(np.abs(a - r).max() / np.abs(r).max()))
+
+
 def test_encoder_layer_dropout_is_consistent():
     """With dropout on: (i) same seed -> bit-identical output, different seed -> different;
     (ii) backward uses the forward's masks: a central finite difference of <y, R> along a random
-    direction of x matches <dx, dir> (the layer is a fixed smooth function once the seed is fixed)."""
+    direction of x matches <dx, dir> (the layer is a fixed smooth function once the seed is fixed).
+    (The materialised-score attention of wide heads is tied to these kernels, masks included, by
+    test_materialised_attention_matches_tiled.)"""
     from raindrop_amd import _lib, ops
     T, B, F, nhead = 12, 2, 3, 2
     D, nhid = F * 4 + 16, 2 * F * 4
