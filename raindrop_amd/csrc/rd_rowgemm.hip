@@ -47,6 +47,12 @@ struct RowGemmArgs {
   // Tile export (rd_tile_wgrad.hip): the split A planes, transposed into MFMA operand tiles whose reduction index is the
   // ROW -- [chunk of 32 rows][column tile of 16][hi, lo][64][8] -- the operand format of the weight-gradient stream.
   __bf16* xt; int xt_nct;
+  // LayerNorm-backward prologue (template flag LNB): the A operand is not read but COMPUTED -- A = dropout-masked gradient of the
+  // LayerNorm input, from dy (lnb_dy), the saved pre-norm sum (lnb_s), (mean, rstd) (lnb_stats) and gamma (lnb_g); the
+  // unmasked gradient goes to lnb_ds (the residual branch), per-workgroup dgamma | dbeta partials to lnb_part
+  // [workgroup][2K].  Same arithmetic and lane <-> column assignment as k_ln_bwd_v (rd_temporal.hip), which it replaces
+  // together with the write + re-read of its second output.
+  const float *lnb_dy, *lnb_s, *lnb_stats, *lnb_g; float *lnb_ds, *lnb_part; float lnb_p; uint32_t lnb_site; uint64_t lnb_seed;
 };
 
 // one weight matrix -> hi/lo planes; transpose != 0 writes split(W^T): rows k, cols n
@@ -113,7 +119,7 @@ __device__ __forceinline__ void rg_load_panel(RPanel<KC, RG_NJ>& p, const __bf16
   }
 }
 
-template <int KC, int RG_ROWS, int RG_NJ, bool LN>
+template <int KC, int RG_ROWS, int RG_NJ, bool LN, bool LNB>
 __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
   constexpr int RT = RG_ROWS / 16, RG_CPR = RG_WAVES * RG_NJ * 16, RG_LDS_STAGE = RG_CPR + 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
@@ -121,6 +127,7 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
   __bf16* Ah = reinterpret_cast<__bf16*>(rsm);
   __bf16* Al = Ah + RG_ROWS * LDA;
   float* stage = reinterpret_cast<float*>(Al + RG_ROWS * LDA);         // [64][260] fp32
+  float* lnred = stage + RG_ROWS * RG_LDS_STAGE;                       // LNB only: [8 waves][2K] dgamma | dbeta partials
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * RG_ROWS;
   const int ntiles = (a.N + 15) >> 4;
@@ -133,7 +140,74 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
   // order: the rows are needed now, the panel only at the first MFMA), then the rows are split into LDS
   // while the panel streams in.
   RPanel<KC, RG_NJ> pw;
-  {
+  if constexpr (LNB) {
+    // ---- LayerNorm backward per row (wave w: rows 8w .. 8w+7 of the block; lane l: columns 4l .. 4l+3) -> split planes ----
+    constexpr int RPW = RG_ROWS / RG_WAVES;
+    const int c = 4 * lane;
+    const bool cok = c < a.K, cpl = c < KPc;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gg = zero4;
+    if (cok) gg = *reinterpret_cast<const float4*>(a.lnb_g + c);
+    float4 sraw[RPW], dvr[RPW]; float mean_r[RPW], rstd_r[RPW];
+#pragma unroll
+    for (int it = 0; it < RPW; ++it) {
+      const long row = m0 + wave * RPW + it;
+      const bool rok = row < a.M;
+      mean_r[it] = rok ? a.lnb_stats[2 * row] : 0.f; rstd_r[it] = rok ? a.lnb_stats[2 * row + 1] : 0.f;
+      sraw[it] = zero4; dvr[it] = zero4;
+      if (rok && cok) {
+        sraw[it] = *reinterpret_cast<const float4*>(a.lnb_s + row * a.K + c);
+        dvr[it] = *reinterpret_cast<const float4*>(a.lnb_dy + row * a.K + c);
+      }
+    }
+    rg_load_panel<KC, RG_NJ>(pw, a.Wh, 0, ntiles, wave, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    uint64_t lseed = a.lnb_seed;
+    if (a.seed_cell) { const uint64_t cv = load_uniform_u64(a.seed_cell); lseed += cv; seed += cv; }
+    const float inv_keep_l = 1.0f / (1.0f - a.lnb_p);
+    float4 ag = zero4, ab = zero4;
+#pragma unroll
+    for (int it = 0; it < RPW; ++it) {
+      const int rl = wave * RPW + it;
+      const long row = m0 + rl;
+      float4 dr = zero4;
+      if (row < a.M) {                                   // wave-uniform
+        const float mean = mean_r[it], rstd = rstd_r[it];
+        const float4 dv = dvr[it];
+        float4 xh = make_float4((sraw[it].x - mean) * rstd, (sraw[it].y - mean) * rstd, (sraw[it].z - mean) * rstd,
+                                (sraw[it].w - mean) * rstd);
+        if (!cok) xh = zero4;
+        const float4 dg = make_float4(dv.x * gg.x, dv.y * gg.y, dv.z * gg.z, dv.w * gg.w);
+        const float c1 = wave_sum64((dg.x + dg.y) + (dg.z + dg.w)) / a.K;
+        const float c2 = wave_sum64((dg.x * xh.x + dg.y * xh.y) + (dg.z * xh.z + dg.w * xh.w)) / a.K;
+        if (cok) {
+          const float4 v = make_float4(rstd * (dg.x - c1 - xh.x * c2), rstd * (dg.y - c1 - xh.y * c2),
+                                       rstd * (dg.z - c1 - xh.z * c2), rstd * (dg.w - c1 - xh.w * c2));
+          *reinterpret_cast<float4*>(a.lnb_ds + row * a.K + c) = v;
+          dr = v;
+          if (a.lnb_p > 0.f) {
+            const float4 u = uniform4(lseed, a.lnb_site, ((uint64_t)row * a.K + c) >> 2);
+            dr.x *= u.x >= a.lnb_p ? inv_keep_l : 0.f; dr.y *= u.y >= a.lnb_p ? inv_keep_l : 0.f;
+            dr.z *= u.z >= a.lnb_p ? inv_keep_l : 0.f; dr.w *= u.w >= a.lnb_p ? inv_keep_l : 0.f;
+          }
+          ag.x += dv.x * xh.x; ag.y += dv.y * xh.y; ag.z += dv.z * xh.z; ag.w += dv.w * xh.w;
+          ab.x += dv.x; ab.y += dv.y; ab.z += dv.z; ab.w += dv.w;
+        }
+      }
+      if (cpl) {
+        bf16x4 h, l;
+        const float x[4] = {dr.x, dr.y, dr.z, dr.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { h[q] = (__bf16)x[q]; l[q] = (__bf16)(x[q] - (float)h[q]); }
+        *reinterpret_cast<bf16x4*>(Ah + rl * LDA + c) = h;
+        *reinterpret_cast<bf16x4*>(Al + rl * LDA + c) = l;
+      }
+    }
+    if (cok) {
+      *reinterpret_cast<float4*>(lnred + wave * 2 * a.K + c) = ag;
+      *reinterpret_cast<float4*>(lnred + wave * 2 * a.K + a.K + c) = ab;
+    }
+  } else {
     constexpr int kq = KPc / 4;                                        // float4 slots per row (incl. pad)
     constexpr int NIT = (RG_ROWS * kq + RG_THR - 1) / RG_THR;          // KC at 64 rows, ceil(KC / 2) at 32
     float4 v[NIT];
@@ -165,6 +239,12 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
   RGSTAMP(1);
   lds_barrier();                       // LDS ordering only: do not drain the weight panel (rd_common.h)
   RGSTAMP(2);
+  if constexpr (LNB) {                 // this workgroup's dgamma | dbeta partial: the 8 waves in fixed order
+    const int K2 = 2 * a.K;
+    for (int i = tid; i < K2; i += RG_THR)
+      a.lnb_part[(long)blockIdx.x * K2 + i] = ((lnred[i] + lnred[K2 + i]) + (lnred[2 * K2 + i] + lnred[3 * K2 + i])) +
+                                              ((lnred[4 * K2 + i] + lnred[5 * K2 + i]) + (lnred[6 * K2 + i] + lnred[7 * K2 + i]));
+  }
   if (a.xt) {
     // ds_read_b64_tr_b16 (tools/probe_tr16.hip): in a 16-lane group lane i passes the address of 4 consecutive shorts --
     // row i>>2, columns 4(i&3).. of a 4 x 16 block -- and receives column i of the block.  Two reads give lane
@@ -316,11 +396,12 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
   RGSTAMP(7);
 }
 
-template <int KC, int ROWS, int NJ, bool LN = false>
+template <int KC, int ROWS, int NJ, bool LN = false, bool LNB = false>
 int launch_rowgemm_kc(const RowGemmArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)2 * ROWS * (KC * 32 + 8) * sizeof(__bf16) + (size_t)ROWS * (RG_WAVES * NJ * 16 + 4) * sizeof(float);
-  RD_LDS_ATTR((k_rowgemm<KC, ROWS, NJ, LN>), lds);
-  hipLaunchKernelGGL((k_rowgemm<KC, ROWS, NJ, LN>), dim3(cdiv(a.M, ROWS)), dim3(RG_THR), lds, st, a);
+  const size_t lds = (size_t)2 * ROWS * (KC * 32 + 8) * sizeof(__bf16) + (size_t)ROWS * (RG_WAVES * NJ * 16 + 4) * sizeof(float) +
+                     (LNB ? (size_t)RG_WAVES * 2 * KC * 32 * sizeof(float) : 0);
+  RD_LDS_ATTR((k_rowgemm<KC, ROWS, NJ, LN, LNB>), lds);
+  hipLaunchKernelGGL((k_rowgemm<KC, ROWS, NJ, LN, LNB>), dim3(cdiv(a.M, ROWS)), dim3(RG_THR), lds, st, a);
   return check_launch("k_rowgemm");
 }
 
@@ -377,6 +458,26 @@ int launch_rowgemm_ln(long M, int N, int K, const float* A, const void* Wh, cons
   take_export(a);
   if (a.KP == 160) return launch_rowgemm_kc<5, 64, 2, true>(a, st);
   return launch_rowgemm_kc<9, 64, 2, true>(a, st);
+}
+
+// C = epi(A Wp^T) with A = LayerNorm-backward of (dy, s, stats, gamma) computed in the prologue (K = LayerNorm width <= 160);
+// ds_out [M,K]: gradient of the pre-norm sum; part [ceil(M/64)][2K]: dgamma | dbeta partials.  Epilogue: posmask/cscale only.
+bool rowgemm_lnb_ok(int N, int K) { return rowgemm_ok(N, K, K, N) && (K + 31) / 32 == 5; }
+int rowgemm_lnb_part_rows(long M) { return (int)((M + 63) / 64); }
+int launch_rowgemm_lnb(long M, int N, int K, const float* dy, const float* s, const float* stats, const float* g, float* ds_out,
+                       float* part, float p_drop, uint64_t seed, uint32_t site, const void* Wh, float* C, long ldc,
+                       const float* posmask, long pm_ld, float cscale, hipStream_t st) {
+  RowGemmArgs a{};
+  a.lda = K; a.Wh = (const __bf16*)Wh; a.C = C; a.ldc = ldc;
+  a.M = (int)M; a.N = N; a.K = K; a.KP = (K + 31) / 32 * 32;
+  a.posmask = posmask; a.pm_ld = pm_ld; a.cscale = cscale;
+  a.seed_cell = seed_cell();
+  a.stamps = g_rg_stamps;
+  a.one_product = precision() == RD_PREC_BF16;
+  a.lnb_dy = dy; a.lnb_s = s; a.lnb_stats = stats; a.lnb_g = g; a.lnb_ds = ds_out; a.lnb_part = part;
+  a.lnb_p = p_drop; a.lnb_site = site; a.lnb_seed = seed;
+  take_export(a);
+  return launch_rowgemm_kc<5, 64, 2, false, true>(a, st);
 }
 
 // C[M,N] = epi(A[M,K] Wp^T): Wp planes [ceil16(N)][ceil32(K)]

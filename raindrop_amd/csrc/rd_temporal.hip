@@ -35,6 +35,11 @@ struct TileColsumJob { const float* x; int M, N, n1; float *out1, *out2; };
 int launch_tile_wgrad(long M, int njobs, const TileWgradJob* jobs, const void* ones, int ncs, const TileColsumJob* cs,
                       hipStream_t st);
 void rowgemm_export_next(void* tiles);
+bool rowgemm_lnb_ok(int N, int K);
+int rowgemm_lnb_part_rows(long M);
+int launch_rowgemm_lnb(long M, int N, int K, const float* dy, const float* s, const float* stats, const float* g, float* ds_out,
+                       float* part, float p_drop, uint64_t seed, uint32_t site, const void* Wh, float* C, long ldc,
+                       const float* posmask, long pm_ld, float cscale, hipStream_t st);
 bool rowgemm_ln_ok(int N, int K);
 int launch_rowgemm_ln(long M, int N, int K, const float* A, const void* Wh, const float* bias, const float* residual,
                       const float* ln_g, const float* ln_b, float* s_out, float* y, float* stats, float drop_p,
@@ -1777,9 +1782,14 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   // gradients run as one streaming launch at the end of the layer (rd_tile_wgrad.hip), instead of four split-K GEMMs;
   // its reduce launch also column-sums the two LayerNorm partial matrices
   const bool tw = rg && tile_path(e) && !ax.ok;
+  // lnf: the LayerNorm backward runs as the PROLOGUE of the input-gradient product that consumes its output (its second
+  // output, the dropout-masked gradient, is only ever that product's A operand and -- as row tiles -- the weight gradient's)
+  static const bool lnb_env = [] { const char* v = getenv("RD_LNB_FUSE"); return !(v && atoi(v) == 0); }();
+  const bool lnf = tw && lnb_env && rowgemm_lnb_ok(e.nhid, e.D) && rowgemm_lnb_ok(e.D, e.D);
+  const int lnrows = lnf ? rowgemm_lnb_part_rows(e.M) : lnb;
   // ---- LayerNorm 2:  ds2 (residual path), df = ds2 o mask(ffn out) -------------------------------
-  if ((rc = launch_ln_bwd(dy, v.s2, v.st2, w->norm2_w, ws.ds2, ws.df, ws.lnpart, (int)e.M, e.D, p_drop, seed,
-                          SITE_FFN_OUT + L, st))) return rc;
+  if (!lnf && (rc = launch_ln_bwd(dy, v.s2, v.st2, w->norm2_w, ws.ds2, ws.df, ws.lnpart, (int)e.M, e.D, p_drop, seed,
+                                  SITE_FFN_OUT + L, st))) return rc;
   // lnpart is a [blocks, 2D] matrix (dgamma | dbeta per block): column-sum it in fixed order
   if (!tw && (rc = launch_colsum2(ws.lnpart, lnb, 2 * e.D, 2 * e.D, g->norm2_w, e.D, g->norm2_b, ws.lnred, st))) return rc;
   // ---- FFN ---------------------------------------------------------------------------------------
@@ -1787,8 +1797,11 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   if (!tw && (rc = linear_bwd_w(e.M, e.D, e.nhid, ws.df, v.h, g->lin2_w, g->lin2_b, ws.splitk, ws.colsum, sw))) return rc;
   if (rg) {                                                        // du = (df W2) gated by h>0, * keep
     if (tw) rowgemm_export_next(ws.dt[0]);
-    if ((rc = launch_rowgemm(e.M, e.nhid, e.D, ws.df, e.D, v.pl[5][0], v.pl[5][1], ws.du, e.nhid, nullptr, 0, v.h, e.nhid,
-                             p_drop > 0.f ? keep : 0.f, nullptr, 0, 0.f, 0, 0, st))) return rc;
+    if (lnf) {
+      if ((rc = launch_rowgemm_lnb(e.M, e.nhid, e.D, dy, v.s2, v.st2, w->norm2_w, ws.ds2, ws.lnpart, p_drop, seed, SITE_FFN_OUT + L,
+                                   v.pl[5][0], ws.du, e.nhid, v.h, e.nhid, p_drop > 0.f ? keep : 0.f, st))) return rc;
+    } else if ((rc = launch_rowgemm(e.M, e.nhid, e.D, ws.df, e.D, v.pl[5][0], v.pl[5][1], ws.du, e.nhid, nullptr, 0, v.h, e.nhid,
+                                    p_drop > 0.f ? keep : 0.f, nullptr, 0, 0.f, 0, 0, st))) return rc;
   } else if ((rc = linear_bwd_x(e.M, e.D, e.nhid, ws.df, w->lin2_w, ws.du, v.h, p_drop > 0.f ? keep : 0.f, nullptr, st)))
     return rc;
   if (ax.ok && (rc = chain(st, sw, ax.ev[1]))) return rc;
@@ -1799,8 +1812,8 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
                              ws.ds2, e.D, 0.f, 0, 0, st))) return rc;
   } else if ((rc = linear_bwd_x(e.M, e.nhid, e.D, ws.du, w->lin1_w, ws.dx1, nullptr, 0.f, ws.ds2, st))) return rc;
   // ---- LayerNorm 1 -------------------------------------------------------------------------------
-  if ((rc = launch_ln_bwd(ws.dx1, v.s1, v.st1, w->norm1_w, ws.ds1, ws.dout, tw ? ws.lnpart1 : ws.lnpart, (int)e.M, e.D, p_drop,
-                          seed, SITE_ATTN_OUT + L, st))) return rc;
+  if (!lnf && (rc = launch_ln_bwd(ws.dx1, v.s1, v.st1, w->norm1_w, ws.ds1, ws.dout, tw ? ws.lnpart1 : ws.lnpart, (int)e.M, e.D,
+                                  p_drop, seed, SITE_ATTN_OUT + L, st))) return rc;
   if (!tw && (rc = launch_colsum2(ws.lnpart, lnb, 2 * e.D, 2 * e.D, g->norm1_w, e.D, g->norm1_b, ws.lnred, st))) return rc;
   // ---- attention output projection ---------------------------------------------------------------
   if (ax.ok && (rc = chain(st, sw, ax.ev[2]))) return rc;
@@ -1808,8 +1821,11 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
     return rc;
   if (rg) {
     if (tw) rowgemm_export_next(ws.dt[2]);
-    if ((rc = launch_rowgemm(e.M, e.D, e.D, ws.dout, e.D, v.pl[4][0], v.pl[4][1], ws.da, e.D, nullptr, 0, nullptr, 0, 0.f,
-                             nullptr, 0, 0.f, 0, 0, st))) return rc;
+    if (lnf) {
+      if ((rc = launch_rowgemm_lnb(e.M, e.D, e.D, ws.dx1, v.s1, v.st1, w->norm1_w, ws.ds1, ws.lnpart1, p_drop, seed,
+                                   SITE_ATTN_OUT + L, v.pl[4][0], ws.da, e.D, nullptr, 0, 0.f, st))) return rc;
+    } else if ((rc = launch_rowgemm(e.M, e.D, e.D, ws.dout, e.D, v.pl[4][0], v.pl[4][1], ws.da, e.D, nullptr, 0, nullptr, 0, 0.f,
+                                    nullptr, 0, 0.f, 0, 0, st))) return rc;
   } else if ((rc = linear_bwd_x(e.M, e.D, e.D, ws.dout, w->out_proj_w, ws.da, nullptr, 0.f, nullptr, st))) return rc;
   // ---- attention core ----------------------------------------------------------------------------
   AttnArgs a{};
@@ -1841,8 +1857,8 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
         {ws.dt[1], v.xt[2], ws.twpart[1], g->lin1_w, g->lin1_b, e.nhid, e.D},             // du^T x1
         {ws.dt[0], v.xt[3], ws.twpart[0], g->lin2_w, g->lin2_b, e.D, e.nhid},             // df^T h
         {ws.dt[2], v.xt[1], ws.twpart[2], g->out_proj_w, g->out_proj_b, e.D, e.D}};       // dout^T attn
-    const TileColsumJob cs[2] = {{ws.lnpart, lnb, 2 * e.D, e.D, g->norm2_w, g->norm2_b},
-                                 {ws.lnpart1, lnb, 2 * e.D, e.D, g->norm1_w, g->norm1_b}};
+    const TileColsumJob cs[2] = {{ws.lnpart, lnrows, 2 * e.D, e.D, g->norm2_w, g->norm2_b},
+                                 {ws.lnpart1, lnrows, 2 * e.D, e.D, g->norm1_w, g->norm1_b}};
     return launch_tile_wgrad(e.M, 4, jobs, v.ones, 2, cs, st);
   }
   if (ax.ok && (rc = chain(sw, st, ax.ev[4]))) return rc;                        // join: the caller's stream owns every result

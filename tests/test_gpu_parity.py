@@ -262,7 +262,8 @@ def test_encoder_tile_weight_gradients_match_split_k(T, B, precision_mode, monke
     """The streamed weight gradients (rd_tile_wgrad.hip: operands exported as split-bf16 row tiles by the row-block
     products, one launch for the layer's four dW/db) against the tiled split-K products they replace, in the SAME
     split-bf16 arithmetic and with the same dropout masks: only the summation order differs, so every entry must agree
-    within 2e-5 of the tensor's max-norm.  dx and the LayerNorm gradients do not depend on the path: bit-equal.
+    within 2e-5 of the tensor's max-norm (the LayerNorm gradients too: their partial sums are grouped by 64 rows on the
+    tile path, where the LayerNorm backward is a prologue of the input-gradient products, and by 16 on the other).
     T*B = 2220 / 165 rows end in a partial 32-row chunk."""
     if precision_mode != "bf16x3":
         pytest.skip("the tile stream exists in split-bf16 mode only")
@@ -288,9 +289,9 @@ def test_encoder_tile_weight_gradients_match_split_k(T, B, precision_mode, monke
     monkeypatch.delenv("RD_TILE_WGRAD")
     assert np.array_equal(out["1"][0], out["0"][0])
     for name, a, r in zip(["x"] + list(ops.ENC_PARAM_NAMES), out["1"][1], out["0"][1]):
-        if name == "x" or "norm" in name:
-            assert np.array_equal(a, r), name
-        else:
+        if name == "x":
+            assert np.abs(a - r).max() <= 1e-6 * np.abs(r).max(), name      # LayerNorm backward fused into the products: same
+        else:                                                            # arithmetic, contraction may differ by an ulp
             assert np.abs(a - r).max() <= 2e-5 * np.abs(r).max(), (name, float(np.abs(a - r).max() / np.abs(r).max()))
 
 
