@@ -435,6 +435,15 @@ int launch_wsplit(int njobs, const float* const* W, const int* N, const int* K, 
   return check_launch("k_wsplit");
 }
 
+// 32-row workgroups (480 instead of 240 at P19: two or more per CU, so one's loads overlap another's MFMAs instead of every
+// workgroup of the launch moving through load -> multiply -> store in lockstep).  Bits: 1 plain K<=160, 2 plain K<=288,
+// 4 LayerNorm epilogue, 8 LayerNorm-backward prologue.  MEASURED in-step (same box, ms/step): none 1.077, bits 1|2 1.047,
+// 1|2|4 0.992, all four 0.966 -- the default.
+static int rows32_mask() {
+  static const int m = [] { const char* e = getenv("RD_RG_ROWS32"); return e ? atoi(e) : 15; }();
+  return m;
+}
+
 // The next launch_rowgemm / launch_rowgemm_ln call also exports its A operand as row tiles (nct = ceil(K / 16) column
 // tiles per 32-row chunk) to `tiles`; one-shot.
 static thread_local void* g_export = nullptr;
@@ -456,6 +465,10 @@ int launch_rowgemm_ln(long M, int N, int K, const float* A, const void* Wh, cons
   a.one_product = precision() == RD_PREC_BF16;
   a.ln_g = ln_g; a.ln_b = ln_b; a.ln_s = s_out; a.ln_stats = stats;
   take_export(a);
+  if (rows32_mask() & 4) {
+    if (a.KP == 160) return launch_rowgemm_kc<5, 32, 2, true>(a, st);
+    return launch_rowgemm_kc<9, 32, 2, true>(a, st);
+  }
   if (a.KP == 160) return launch_rowgemm_kc<5, 64, 2, true>(a, st);
   return launch_rowgemm_kc<9, 64, 2, true>(a, st);
 }
@@ -463,7 +476,7 @@ int launch_rowgemm_ln(long M, int N, int K, const float* A, const void* Wh, cons
 // C = epi(A Wp^T) with A = LayerNorm-backward of (dy, s, stats, gamma) computed in the prologue (K = LayerNorm width <= 160);
 // ds_out [M,K]: gradient of the pre-norm sum; part [ceil(M/64)][2K]: dgamma | dbeta partials.  Epilogue: posmask/cscale only.
 bool rowgemm_lnb_ok(int N, int K) { return rowgemm_ok(N, K, K, N) && (K + 31) / 32 == 5; }
-int rowgemm_lnb_part_rows(long M) { return (int)((M + 63) / 64); }
+int rowgemm_lnb_part_rows(long M) { return (rows32_mask() & 8) ? (int)((M + 31) / 32) : (int)((M + 63) / 64); }
 int launch_rowgemm_lnb(long M, int N, int K, const float* dy, const float* s, const float* stats, const float* g, float* ds_out,
                        float* part, float p_drop, uint64_t seed, uint32_t site, const void* Wh, float* C, long ldc,
                        const float* posmask, long pm_ld, float cscale, hipStream_t st) {
@@ -477,6 +490,7 @@ int launch_rowgemm_lnb(long M, int N, int K, const float* dy, const float* s, co
   a.lnb_dy = dy; a.lnb_s = s; a.lnb_stats = stats; a.lnb_g = g; a.lnb_ds = ds_out; a.lnb_part = part;
   a.lnb_p = p_drop; a.lnb_site = site; a.lnb_seed = seed;
   take_export(a);
+  if (rows32_mask() & 8) return launch_rowgemm_kc<5, 32, 2, false, true>(a, st);
   return launch_rowgemm_kc<5, 64, 2, false, true>(a, st);
 }
 
@@ -494,6 +508,9 @@ int launch_rowgemm(long M, int N, int K, const float* A, long lda, const void* W
   a.one_product = precision() == RD_PREC_BF16;
   take_export(a);
   const int kc = a.KP / 32;
+  const int rows32 = rows32_mask();
+  if (kc == 5 && (rows32 & 1)) return launch_rowgemm_kc<5, 32, 2>(a, st);
+  if (kc == 9 && (rows32 & 2)) return launch_rowgemm_kc<9, 32, 2>(a, st);
   if (kc == 5) return launch_rowgemm_kc<5, 64, 2>(a, st);
   if (kc == 9) return launch_rowgemm_kc<9, 64, 2>(a, st);
   // K = 3D (QKV dgrad): 32 rows keep planes + stage inside 160 KB; one column tile per wave keeps the 15-step panel in 120 VGPRs
