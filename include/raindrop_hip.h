@@ -226,6 +226,12 @@ int rd_linear_bwd_input_gated(int32_t M, int32_t N, int32_t K, const float* dy, 
  * loss[0] = mean_b(logsumexp(logits[b]) - logits[b, y[b]]); dlogits = (softmax - onehot) / B. */
 int rd_softmax_xent(int32_t B, int32_t C, const float* logits, const int64_t* y, float* loss,
                     float* dlogits, void* stream);
+/* Tuning knob of the encoder's row-block products (process-global, read when a product is enqueued): bit mask of the kernel
+ * variants that run on 32-row instead of 64-row workgroups (1: K <= 160, 2: K <= 288, 4: LayerNorm epilogue, 8: LayerNorm-
+ * backward prologue); -1 restores the default (environment RD_RG_ROWS32, else 15).  Results do not depend on it beyond
+ * the grouping of the LayerNorm parameter-gradient partial sums.  raindrop_amd.step.TrainStep times both settings when
+ * it captures its graph and keeps the faster one. */
+int rd_set_rowgemm_rows32(int32_t mask);
 /* Classifier head + loss, forward and backward, in two launches (training step; rd_head.hip).
  *   agg = masked mean over time of r [T,B,D] (code/models_rd.py:366-367,379); feat = [agg | static W_emb^T + b_emb]
  *   (:381-384; Fe = 0: no static branch); logits = W2 relu(W0 feat + b0) + b2 (mlp_static, :263-267,385);

@@ -438,10 +438,18 @@ int launch_wsplit(int njobs, const float* const* W, const int* N, const int* K, 
 // 32-row workgroups (480 instead of 240 at P19: two or more per CU, so one's loads overlap another's MFMAs instead of every
 // workgroup of the launch moving through load -> multiply -> store in lockstep).  Bits: 1 plain K<=160, 2 plain K<=288,
 // 4 LayerNorm epilogue, 8 LayerNorm-backward prologue.  MEASURED in-step (same box, ms/step): none 1.077, bits 1|2 1.047,
-// 1|2|4 0.992, all four 0.966 -- the default.
+// 1|2|4 0.992,
+// all four 0.966 -- but on a "fast" box of the same pool 0.7205 without vs 0.7268 with all four: which is better depends on the
+// device's state, so raindrop_amd.step.TrainStep measures both when it captures its graph (rd_set_rowgemm_rows32).
+static int g_rows32 = -1;                            // < 0: environment / default
 static int rows32_mask() {
+  if (g_rows32 >= 0) return g_rows32;
   static const int m = [] { const char* e = getenv("RD_RG_ROWS32"); return e ? atoi(e) : 15; }();
   return m;
+}
+extern "C" int rd_set_rowgemm_rows32(int32_t mask) {   // tuning knob, see include/raindrop_hip.h
+  g_rows32 = mask < 0 ? -1 : (mask & 15);
+  return RD_OK;
 }
 
 // The next launch_rowgemm / launch_rowgemm_ln call also exports its A operand as row tiles (nct = ceil(K / 16) column

@@ -20,6 +20,8 @@ and this step call the SAME kernels in the same order; `tests/test_gpu_parity.py
 gradients agree bit for bit.
 """
 import ctypes
+import os
+import time
 
 import torch
 
@@ -31,11 +33,12 @@ def _p(t):
 
 
 class TrainStep:
-    def __init__(self, model, flat, batch, p_drop=None, use_graph=True, seed=1234):
+    def __init__(self, model, flat, batch, p_drop=None, use_graph=True, seed=1234, autotune=True):
         """model: raindrop_amd.models_rd.Raindrop_v2 on a ROCm device; flat: FlatGradAllReduce over the
         live parameters (its buffer receives the gradients); batch: dict(src, static, times, lengths, y)
         of device tensors that are REUSED every step (copy new data into them)."""
         self.model, self.flat, self.batch = model, flat, batch
+        self.autotune, self.tuned_rows32 = bool(autotune), None
         self.dev = batch["src"].device
         self.lib = _lib.load()
         cfgp = float(model.dropout.p) if p_drop is None else float(p_drop)
@@ -217,6 +220,30 @@ class TrainStep:
             _lib.call("rd_set_seed_cell", None)
 
     def _capture(self):
+        """Capture the step as one hipGraph.  With `autotune`, the graph is captured once per setting of the library's
+        tuning knob (32-row vs 64-row workgroups of the encoder's row-block products, rd_set_rowgemm_rows32: which is
+        faster depends on the device, 8 % either way was measured on two boxes of one pool) and the faster graph is kept.
+        Results are the same function of the inputs either way."""
+        if not self.autotune or os.environ.get("RD_RG_ROWS32") is not None:
+            return self._capture_one()
+        best = None
+        for mask in (15, 0):
+            _lib.call("rd_set_rowgemm_rows32", mask)
+            self._capture_one()
+            for _ in range(3):
+                self.graph.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(12):
+                self.graph.replay()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, mask, self.graph)
+        self.graph, self.tuned_rows32 = best[2], best[1]
+        _lib.call("rd_set_rowgemm_rows32", best[1])                  # eager calls of this process follow the same choice
+
+    def _capture_one(self):
         def cap():
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
