@@ -120,6 +120,68 @@ def k1_roofline(model, cfg, batch, reps=20):
     return _roofline_dict(B, F, K, fwd, bwd, "hipGraph replays timed with HIP events")
 
 
+def encoder_roofline(model, cfg, B, iters=50):
+    """Second roofline object: ONE TransformerEncoderLayer forward + backward (rd_encoder_layer_fwd + rd_encoder_layer_bwd
+    of layer 0, 13 launches at P19: the other ~85 % of the step) as hipGraph replays timed with HIP events.
+    Algorithmic bytes = what the layer must move under its saved-tensor contract, every tensor once per use: forward reads
+    x and writes qkv (3D), attention output, the two pre-norm sums, x1, the FFN hidden (nhid) and y; backward reads dy and
+    every saved tensor once and writes dx: (18 D + 2 nhid) * 4 bytes per token (weights, statistics and masks are noise)."""
+    import ctypes
+    from raindrop_amd import _lib, ops
+    dev = next(model.parameters()).device
+    lib = _lib.load()
+    T, F, d = cfg["max_len"], cfg["d_inp"], cfg["d_ob"]
+    D, nhid = F * d + 16, cfg["nhid"]
+    shp = _lib.shape(B, T, F, d, nhead=cfg["nhead"], nhid=nhid)
+    sp = ctypes.byref(shp)
+    layer = model.transformer_encoder.layers[0]
+    named = dict(layer.named_parameters())
+    w = [named[n].detach().contiguous() for n in ops.ENC_PARAM_NAMES]
+    g = [torch.empty_like(t) for t in w]
+    wp = _lib.RdEncoderPtrs(*[t.data_ptr() for t in w]); gp = _lib.RdEncoderPtrs(*[t.data_ptr() for t in g])
+    x = torch.randn(T, B, D, device=dev); y = torch.empty_like(x); dy = torch.randn_like(x); dx = torch.empty_like(x)
+    mask = torch.zeros(B, T, dtype=torch.bool, device=dev)
+    saved = torch.empty(lib.rd_encoder_layer_saved_bytes(sp), dtype=torch.uint8, device=dev)
+    ws = torch.empty(lib.rd_encoder_layer_workspace_bytes(sp), dtype=torch.uint8, device=dev)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+
+    def fn():
+        st = ops._stream()
+        _lib.call("rd_encoder_layer_fwd", sp, 0, P(x), P(mask), ctypes.byref(wp), 0.2, 1234, P(y), P(saved), saved.numel(),
+                  P(ws), ws.numel(), st)
+        _lib.call("rd_encoder_layer_bwd", sp, 0, P(x), P(mask), ctypes.byref(wp), 0.2, 1234, P(saved), saved.numel(), P(dy),
+                  P(dx), ctypes.byref(gp), P(ws), ws.numel(), st)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fn()
+    for _ in range(5):
+        graph.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    M = T * B
+    alg = M * (18 * D + 2 * nhid) * 4
+    flops = 3 * 2.0 * M * (3 * D * D + D * D + 2 * D * nhid) + 3 * 4.0 * B * T * T * D     # dense fwd + 2x bwd; attention
+    achieved = alg / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "one TransformerEncoderLayer fwd+bwd (rd_encoder_layer_fwd + rd_encoder_layer_bwd, layer 0 of 2; "
+                                       "hipGraph replays timed with HIP events)",
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": None, "algorithmic_bytes": alg, "us": round(ms * 1e3, 2),
+            "mfma": {"algorithmic_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
+                     "frac_issued": round(3 * flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 5)}}
+
+
 def roofline_isolated(args):
     """Run the hipGraph-based K1 measurement in a child process so that a capture failure can never
     take the main JSON line down; returns the roofline dict or None."""
@@ -128,9 +190,13 @@ def roofline_isolated(args):
     try:
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=240,
                              env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+        out = None
         for ln in res.stdout.splitlines():
             if ln.startswith("K1ROOFLINE "):
-                return json.loads(ln[len("K1ROOFLINE "):])
+                out = json.loads(ln[len("K1ROOFLINE "):])
+            if ln.startswith("ENCROOFLINE ") and out is not None:
+                out["encoder_layer"] = json.loads(ln[len("ENCROOFLINE "):])
+        return out
     except Exception:
         pass
     return None
@@ -464,6 +530,10 @@ def main():
             step()
         torch.cuda.synchronize()
         print("K1ROOFLINE " + json.dumps(k1_roofline(model, cfg, batch)), flush=True)
+        try:
+            print("ENCROOFLINE " + json.dumps(encoder_roofline(model, cfg, args.batch)), flush=True)
+        except Exception as e:                                   # the K1 object must survive a failure here
+            print("ENCROOFLINE_FAILED %r" % (e,), file=sys.stderr, flush=True)
         return
 
     for _ in range(args.warmup):
@@ -511,6 +581,8 @@ def main():
         if not args.no_roofline:
             try:
                 line["roofline"] = roofline_isolated(args) or k1_roofline_events(model, cfg, batch)
+                if isinstance(line["roofline"], dict) and "encoder_layer" in line["roofline"]:
+                    line["roofline_encoder_layer"] = line["roofline"].pop("encoder_layer")   # second object: the other ~85 % of the step
             except Exception as e:                                       # pragma: no cover
                 line["roofline"] = {"error": repr(e)[:200]}
             if world == 1:
