@@ -938,6 +938,239 @@ __global__ __launch_bounds__(256) void k_attn_bwd_one_b16(AttnArgs a, int one) {
   ASTAMP(7);
 }
 
+// Eight-wave form of k_attn_fwd_one_b16: wave = (query row tile wq, half wh).  S: two of the four key tiles per wave, the row
+// maximum and the row sum are combined across the two halves through 1 KB of LDS; O = P V: the head-dim tiles split
+// between the halves.  Loads: waves 0-3 fetch Q and K, waves 4-7 V.
+template <int NTH>
+__global__ __launch_bounds__(512) void k_attn_fwd_one_b16w(AttnArgs a, int one) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8, NA = (NTH + 1) / 2;
+  __bf16* Qh = reinterpret_cast<__bf16*>(bsm);
+  __bf16* Ql = Qh + TS * LDB;
+  __bf16* Kh = Ql + TS * LDB;
+  __bf16* Kl = Kh + TS * LDB;
+  __bf16* Vh = Kl + TS * LDB;
+  __bf16* Vl = Vh + TS * LDB;
+  constexpr bool OVL = LDB >= LDT;
+  __bf16* Ph = OVL ? Qh : Vl + TS * LDB;
+  __bf16* Pl = Ph + TS * LDT;
+  float* mxs = reinterpret_cast<float*>((OVL ? Vl + TS * LDB : Pl + TS * LDT));    // [2][64] partial row maxima
+  float* sms = mxs + 2 * TS;                                                       // [2][64] partial row sums
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wq = wave & 3, wh = wave >> 2, lt = tid & 255;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const long rs = (long)a.B * 3 * a.D;
+  const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
+  const bool vec = head_vec_ok(a.hd, rs, a.D, qb, nullptr, nullptr);
+  uint64_t seedv = a.seed;
+  uint8_t mb[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) mb[j] = a.mask[(long)b * a.T + min(16 * (2 * wh + j) + (lane & 15), a.T - 1)];
+  if (a.p_drop > 0.f && a.seed_cell) seedv += load_uniform_u64(a.seed_cell);
+  if (wh == 0) {
+    HeadRegs<NTH> qv, kv;
+    if (vec) {
+      head_load_t<NTH, true>(qv, qb, rs, 0, a.T, a.hd, lt);
+      head_load_t<NTH, true>(kv, qb + a.D, rs, 0, a.T, a.hd, lt);
+    } else {
+      head_load_t<NTH, false>(qv, qb, rs, 0, a.T, a.hd, lt);
+      head_load_t<NTH, false>(kv, qb + a.D, rs, 0, a.T, a.hd, lt);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    head_store_b16<NTH>(qv, Qh, Ql, LDB, HDP, lt);
+    head_store_b16<NTH>(kv, Kh, Kl, LDB, HDP, lt);
+  } else {
+    HeadRegs<NTH> vv;
+    if (vec) head_load_t<NTH, true>(vv, qb + 2 * a.D, rs, 0, a.T, a.hd, lt);
+    else head_load_t<NTH, false>(vv, qb + 2 * a.D, rs, 0, a.T, a.hd, lt);
+    __builtin_amdgcn_sched_barrier(0);
+    head_store_b16<NTH>(vv, Vh, Vl, LDB, HDP, lt);
+  }
+  __syncthreads();
+  const float inv_keep = 1.0f / (1.0f - a.p_drop);
+  f32x4 s[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  mma_b16<2, false, false>(s, Qh, Ql, LDB, wq * 16, Kh + 32 * wh * LDB, Kl + 32 * wh * LDB, LDB, HDP, lane, one);    // S = Q K^T
+  float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int key = 16 * (2 * wh + j) + (lane & 15);
+    const bool dead = key >= a.T || mb[j];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s[j][r] = dead ? -INFINITY : s[j][r] * a.scale;
+      mx[r] = fmaxf(mx[r], s[j][r]);
+    }
+  }
+  const int row0 = wq * 16 + 4 * (lane >> 4);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    mx[r] = group16_max(mx[r]);
+    if ((lane & 15) == 0) mxs[wh * TS + row0 + r] = mx[r];
+  }
+  __syncthreads();                                  // partial maxima visible; every wave is done with Q before P^T overwrites it
+  float m_i[4], rsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) m_i[r] = fmaxf(mxs[row0 + r], mxs[TS + row0 + r]);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int key = 16 * (2 * wh + j) + (lane & 15);
+    float k4[4] = {1.f, 1.f, 1.f, 1.f};
+    if (a.p_drop > 0.f)
+      attn_keep4(k4, seedv, a.site, bh, a.T, row0, min(key, a.T - 1), a.p_drop, inv_keep);
+    float pv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float p = (s[j][r] == -INFINITY) ? 0.f : __expf(s[j][r] - m_i[r]);
+      rsum[r] += p;
+      pv[r] = p * k4[r];
+    }
+    store_t4(Ph, Pl, key, row0, pv);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    rsum[r] = group16_sum(rsum[r]);
+    if ((lane & 15) == 0) sms[wh * TS + row0 + r] = rsum[r];
+  }
+  __syncthreads();
+  float l_i[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) l_i[r] = sms[row0 + r] + sms[TS + row0 + r];
+  const int t0 = wh * NA;
+  f32x4 o[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) o[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  mma_b16<NA, true, true>(o, Ph, Pl, LDT, wq * 16, Vh + 16 * t0, Vl + 16 * t0, LDB, TS, lane, one);      // O = P V
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int q = row0 + r;
+    if (q >= a.T) continue;
+    const float inv = 1.0f / l_i[r];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int c = 16 * (t0 + j) + (lane & 15);
+      if (t0 + j < NTH && c < a.hd) a.out[((long)q * a.B + b) * a.D + h * a.hd + c] = o[j][r] * inv;
+    }
+    if (wh == 0 && (lane & 15) == 0) a.lse[(long)bh * a.T + q] = m_i[r] + logf(l_i[r]);
+  }
+}
+
+// Eight-wave form of the kernel above: wave = (row tile wq, half wh).  S / dP: each wave takes two of the four key
+// tiles of its query rows; dQ / dK / dV: the head-dim tiles are split between the two waves of a row tile.  Loads: waves
+// 0-3 fetch Q, K, V, waves 4-7 dO, O (+ delta, LSE).  Same LDS planes, two waves per SIMD instead of one: the phases of a
+// workgroup overlap a little instead of not at all (nothing needs a cross-wave reduction: the backward uses the saved LSE).
+template <int NTH>
+__global__ __launch_bounds__(512) void k_attn_bwd_one_b16w(AttnArgs a, int one) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8, NA = (NTH + 1) / 2;
+  __bf16* Qh = reinterpret_cast<__bf16*>(bsm);
+  __bf16* Ql = Qh + TS * LDB;
+  __bf16* Kh = Ql + TS * LDB;
+  __bf16* Kl = Kh + TS * LDB;
+  __bf16* Vh = Kl + TS * LDB;
+  __bf16* Vl = Vh + TS * LDB;
+  __bf16* Oh = Vl + TS * LDB;
+  __bf16* Ol = Oh + TS * LDB;
+  __bf16* Ph = Ol + TS * LDB;
+  __bf16* Pl = Ph + TS * LDT;
+  __bf16* Sh = Pl + TS * LDT;
+  __bf16* Sl = Sh + TS * LDT;
+  float* lse_s = reinterpret_cast<float*>(Sl + TS * LDT);
+  float* dl_s = lse_s + TS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wq = wave & 3, wh = wave >> 2, lt = tid & 255;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const long rs = (long)a.B * 3 * a.D, ro = (long)a.B * a.D;
+  const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
+  const float* dob = a.dout + (long)b * a.D + h * a.hd;
+  const float* ob = a.out + (long)b * a.D + h * a.hd;
+  const bool vec = head_vec_ok(a.hd, rs, ro, qb, dob, ob);
+  uint64_t seedv = a.seed;
+  uint8_t mb[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) mb[j] = a.mask[(long)b * a.T + min(16 * (2 * wh + j) + (lane & 15), a.T - 1)];
+  if (a.p_drop > 0.f && a.seed_cell) seedv += load_uniform_u64(a.seed_cell);
+  if (wh == 0) {                                      // wave-uniform
+    HeadRegs<NTH> qv, kv, vv;
+    if (vec) {
+      head_load_t<NTH, true>(qv, qb, rs, 0, a.T, a.hd, lt);
+      head_load_t<NTH, true>(kv, qb + a.D, rs, 0, a.T, a.hd, lt);
+      head_load_t<NTH, true>(vv, qb + 2 * a.D, rs, 0, a.T, a.hd, lt);
+    } else {
+      head_load_t<NTH, false>(qv, qb, rs, 0, a.T, a.hd, lt);
+      head_load_t<NTH, false>(kv, qb + a.D, rs, 0, a.T, a.hd, lt);
+      head_load_t<NTH, false>(vv, qb + 2 * a.D, rs, 0, a.T, a.hd, lt);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    head_store_b16<NTH>(qv, Qh, Ql, LDB, HDP, lt);
+    head_store_b16<NTH>(kv, Kh, Kl, LDB, HDP, lt);
+    head_store_b16<NTH>(vv, Vh, Vl, LDB, HDP, lt);
+  } else {
+    HeadRegs<NTH> dov, ov;
+    if (vec) {
+      head_load_t<NTH, true>(dov, dob, ro, 0, a.T, a.hd, lt);
+      head_load_t<NTH, true>(ov, ob, ro, 0, a.T, a.hd, lt);
+    } else {
+      head_load_t<NTH, false>(dov, dob, ro, 0, a.T, a.hd, lt);
+      head_load_t<NTH, false>(ov, ob, ro, 0, a.T, a.hd, lt);
+    }
+    const int r = lt >> 2;
+    const float l = r < a.T ? a.lse[(long)bh * a.T + r] : 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+    head_mask<NTH>(ov);
+    head_mask<NTH>(dov);
+    const float d = head_rowdot<NTH>(dov, ov);
+    head_store_b16<NTH>(dov, Oh, Ol, LDB, HDP, lt);
+    if ((lt & 3) == 0) { dl_s[r] = d; lse_s[r] = l; }
+  }
+  __syncthreads();
+  const float inv_keep = 1.0f / (1.0f - a.p_drop);
+  f32x4 s[2], dp[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { s[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[j] = s[j]; }
+  mma_b16<2, false, false>(s, Qh, Ql, LDB, wq * 16, Kh + 32 * wh * LDB, Kl + 32 * wh * LDB, LDB, HDP, lane, one);    // S
+  mma_b16<2, false, false>(dp, Oh, Ol, LDB, wq * 16, Vh + 32 * wh * LDB, Vl + 32 * wh * LDB, LDB, HDP, lane, one);   // dP
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int key = 16 * (2 * wh + j) + (lane & 15);
+    const bool dead = key >= a.T || mb[j];
+    float k4[4] = {1.f, 1.f, 1.f, 1.f};
+    if (a.p_drop > 0.f)
+      attn_keep4(k4, seedv, a.site, bh, a.T, wq * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
+    float pm[4], ds[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wq * 16 + 4 * (lane >> 4) + r;
+      pm[r] = 0.f; ds[r] = 0.f;
+      if (!dead && row < a.T) {
+        const float p = __expf(s[j][r] * a.scale - lse_s[row]);
+        pm[r] = p * k4[r];
+        ds[r] = p * (dp[j][r] * k4[r] - dl_s[row]) * a.scale;
+      }
+    }
+    store_t4(Ph, Pl, key, wq * 16 + 4 * (lane >> 4), pm);
+    store_t4(Sh, Sl, key, wq * 16 + 4 * (lane >> 4), ds);
+  }
+  __syncthreads();
+  const int t0 = wh * NA;                             // first head-dim tile of this wave
+  f32x4 dq[NA], dk[NA], dv[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) { dq[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[j] = dq[j]; dv[j] = dq[j]; }
+  mma_b16<NA, true, true>(dq, Sh, Sl, LDT, wq * 16, Kh + 16 * t0, Kl + 16 * t0, LDB, TS, lane, one);     // dQ = dS K
+  mma_b16<NA, false, true>(dk, Sh, Sl, LDT, wq * 16, Qh + 16 * t0, Ql + 16 * t0, LDB, TS, lane, one);    // dK = dS^T Q
+  mma_b16<NA, false, true>(dv, Ph, Pl, LDT, wq * 16, Oh + 16 * t0, Ol + 16 * t0, LDB, TS, lane, one);    // dV = (P o M)^T dO
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int t = wq * 16 + 4 * (lane >> 4) + r;
+    if (t >= a.T) continue;
+    float* row = a.dqkv + ((long)t * a.B + b) * 3 * a.D + h * a.hd;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int c = 16 * (t0 + j) + (lane & 15);
+      if (t0 + j < NTH && c < a.hd) { row[c] = dq[j][r]; row[a.D + c] = dk[j][r]; row[2 * a.D + c] = dv[j][r]; }
+    }
+  }
+}
+
 static bool attn_b16_ok(const AttnArgs& a) {
   const char* e = getenv("RD_ATTN_B16");              // read per call (tests compare both paths in one process)
   return !(e && atoi(e) == 0) && precision() != RD_PREC_FP32 && a.T <= TS && a.hd <= 96;
@@ -950,11 +1183,24 @@ int launch_attn_b16(const AttnArgs& a_in, int which, hipStream_t st) {
   a.stamps = g_attn_stamps;
   if (which == 0) {
     const size_t lds = (size_t)(6 * TS * LDB + (LDB >= LDT ? 0 : 2 * TS * LDT)) * sizeof(__bf16);
+    static const bool widef = [] { const char* e = getenv("RD_ATTN_FWD_W8"); return !(e && atoi(e) == 0); }();
+    if (widef) {
+      const size_t ldsw = lds + 4 * TS * sizeof(float);
+      RD_LDS_ATTR((k_attn_fwd_one_b16w<NTH>), ldsw);
+      hipLaunchKernelGGL(k_attn_fwd_one_b16w<NTH>, dim3(a.B * a.H), dim3(512), ldsw, st, a, one);
+      return check_launch("k_attn_fwd_one_b16w");
+    }
     RD_LDS_ATTR((k_attn_fwd_one_b16<NTH>), lds);
     hipLaunchKernelGGL(k_attn_fwd_one_b16<NTH>, dim3(a.B * a.H), dim3(256), lds, st, a, one);
     return check_launch("k_attn_fwd_one_b16");
   }
   const size_t lds = (size_t)(8 * TS * LDB + 4 * TS * LDT) * sizeof(__bf16) + 2 * TS * sizeof(float);
+  static const bool wide = [] { const char* e = getenv("RD_ATTN_BWD_W8"); return !(e && atoi(e) == 0); }();
+  if (wide) {
+    RD_LDS_ATTR((k_attn_bwd_one_b16w<NTH>), lds);
+    hipLaunchKernelGGL(k_attn_bwd_one_b16w<NTH>, dim3(a.B * a.H), dim3(512), lds, st, a, one);
+    return check_launch("k_attn_bwd_one_b16w");
+  }
   RD_LDS_ATTR((k_attn_bwd_one_b16<NTH>), lds);
   hipLaunchKernelGGL(k_attn_bwd_one_b16<NTH>, dim3(a.B * a.H), dim3(256), lds, st, a, one);
   return check_launch("k_attn_bwd_one_b16");
