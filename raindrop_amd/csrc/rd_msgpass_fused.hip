@@ -43,8 +43,10 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int LDX = KP + 8;      // bf16 elements per LDS plane row (528 B)
 constexpr int LDS_F = 244;       // fp32 staging row stride (conflict-free for both access orders)
+// MEASURED in-step, library variants A/B'd in one call: 1024 threads is neutral on the pool's fast boxes (0.714 vs 0.714 ms/step)
+// and 3 % faster on its slow ones (0.911 -> 0.884), where these instruction-issue-bound kernels stretch the most.
 #ifndef RD_K1_NTHR
-#define RD_K1_NTHR 512
+#define RD_K1_NTHR 1024
 #endif
 constexpr int NTHR = RD_K1_NTHR; // 512: 8 wavefronts, wave w owns output column tiles {w, w+8}; 1024: 16 wavefronts, one tile each
 constexpr int NWAVE = NTHR / 64, NJ = 16 / NWAVE;
