@@ -61,6 +61,24 @@ __device__ __forceinline__ uint64_t load_uniform_u64(const uint64_t* p) {
   return v;
 }
 
+// Sum over the 64 lanes of a wavefront on the DPP path, result uniform (every lane gets it).  row_shr 1/2/4/8 leave each
+// 16-lane row's total in its last lane, row_bcast15 / row_bcast31 carry the totals up to lane 63, v_readlane makes it
+// uniform: six VALU instructions with DPP modifiers instead of six LDS-crossbar round trips (`__shfl_xor` compiles to
+// ds_bpermute_b32; a dependent chain of those is ~6 x 100 cycles, twice that on the pool's slow boxes).  Fixed order.
+__device__ __forceinline__ float wave_sum64_dpp(float v) {
+  const int zero = 0;
+#define RD_DPP_ADD(ctrl, rmask)                                                                              \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(zero, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+  RD_DPP_ADD(0x111, 0xf);   // row_shr:1
+  RD_DPP_ADD(0x112, 0xf);   // row_shr:2
+  RD_DPP_ADD(0x114, 0xf);   // row_shr:4
+  RD_DPP_ADD(0x118, 0xf);   // row_shr:8
+  RD_DPP_ADD(0x142, 0xa);   // row_bcast:15 -> rows 1, 3
+  RD_DPP_ADD(0x143, 0xc);   // row_bcast:31 -> rows 2, 3
+#undef RD_DPP_ADD
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // ------------------------------------------------------------------------------------------
 // Generic fp32 GEMM on the f32-input MFMA (v_mfma_f32_16x16x4_f32: exact fp32, == fmaf chain).
 //   C(m,n) = epilogue( sum_k A(m,k) * B(n,k) )

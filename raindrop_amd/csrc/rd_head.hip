@@ -36,11 +36,7 @@ struct HeadArgs {
   int T, B, D, ds, Fe, dh, C;
 };
 
-__device__ __forceinline__ float wsum64(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+__device__ __forceinline__ float wsum64(float v) { return wave_sum64_dpp(v); }
 
 template <int RB>
 __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {

@@ -95,11 +95,7 @@ __global__ __launch_bounds__(256) void k_wsplit(SplitJobs jobs) {
   }
 }
 
-__device__ __forceinline__ float wave_sum64(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+__device__ __forceinline__ float wave_sum64(float v) { return wave_sum64_dpp(v); }
 
 template <int KC, int RG_NJ>
 struct RPanel { bf16x8 h[RG_NJ][KC], l[RG_NJ][KC]; };

@@ -69,11 +69,7 @@ __device__ __forceinline__ void mma_f32(f32x4 (&acc)[NT], const float* a, int a_
   }
 }
 
-__device__ __forceinline__ float wave_sum64(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+__device__ __forceinline__ float wave_sum64(float v) { return wave_sum64_dpp(v); }   // rd_common.h: same order as the row-block kernels
 __device__ __forceinline__ float wave_max64(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
