@@ -75,14 +75,15 @@ __device__ __forceinline__ float wave_max64(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;
 }
+// max / sum over each 16-lane row of the wavefront, every lane of the row gets the result: four rotate-within-row DPP steps
+// (row_ror:8, 4, 2, 1) instead of four ds_bpermute round trips
+#define RD_ROW_ROR(v, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (n), 0xf, 0xf, false))
 __device__ __forceinline__ float group16_max(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  v = fmaxf(v, RD_ROW_ROR(v, 8)); v = fmaxf(v, RD_ROW_ROR(v, 4)); v = fmaxf(v, RD_ROW_ROR(v, 2)); v = fmaxf(v, RD_ROW_ROR(v, 1));
   return v;
 }
 __device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  v += RD_ROW_ROR(v, 8); v += RD_ROW_ROR(v, 4); v += RD_ROW_ROR(v, 2); v += RD_ROW_ROR(v, 1);
   return v;
 }
 
