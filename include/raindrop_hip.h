@@ -188,6 +188,15 @@ int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const float* x, const
                          const rd_encoder_weights* w, float p_drop, uint64_t seed, float* y,
                          void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes,
                          void* stream);
+/* Optional: the weight-dependent part of the forward (splitting the layer's matrices into matrix-core operand tiles inside
+ * `saved`) as its own call, so that a caller can enqueue it EARLY on another stream -- it depends on the weights only --
+ * and keep it off the critical path; then pass `layer | RD_LAYER_WEIGHTS_PREPARED` to rd_encoder_layer_fwd, which skips
+ * that launch (the caller orders the two calls: event / stream wait).  raindrop_amd.step.TrainStep can do this
+ * (RD_SIDE_PREPARE=1); in its hipGraph step the parallel branch measured 3 % SLOWER than the two serial launches, so
+ * it is off by default there -- the entry point is for callers whose weights change less often than they run forward. */
+#define RD_LAYER_WEIGHTS_PREPARED 0x10000
+int rd_encoder_layer_prepare(const rd_shape* s, const rd_encoder_weights* w, void* saved, size_t saved_bytes,
+                             void* stream);
 /* Backward: dy -> dx and all 12 parameter gradients (overwritten). */
 int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const float* x, const uint8_t* mask,
                          const rd_encoder_weights* w, float p_drop, uint64_t seed, const void* saved,

@@ -57,6 +57,7 @@ SIGNATURES = {
                        + [_P, c_size_t, _P]),
     "rd_encoder_layer_saved_bytes": (c_size_t, [_SHP]),
     "rd_encoder_layer_workspace_bytes": (c_size_t, [_SHP]),
+    "rd_encoder_layer_prepare": (c_int32, [_SHP, _ENC, _P, c_size_t, _P]),
     "rd_encoder_layer_fwd": (c_int32, [_SHP, c_int32, _P, _P, _ENC, c_float, ctypes.c_uint64, _P, _P, c_size_t,
                                         _P, c_size_t, _P]),
     "rd_encoder_layer_bwd": (c_int32, [_SHP, c_int32, _P, _P, _ENC, c_float, ctypes.c_uint64, _P, c_size_t, _P, _P,

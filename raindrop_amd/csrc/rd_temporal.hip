@@ -1927,6 +1927,33 @@ extern "C" size_t rd_encoder_layer_workspace_bytes(const rd_shape* s) {
 
 extern "C" void rd_debug_set_attn_stamps(void* p) { g_attn_stamps = (unsigned long long*)p; }   // not part of the ABI
 
+// weights of a layer -> native bf16 hi/lo operand tiles (both orientations) + the constant tiles of the weight-gradient stream
+static int enc_prepare(const EncDims& e, const rd_encoder_weights* w, const EncSaved& v, bool tw, hipStream_t st) {
+  const float* Ws[8] = {w->in_proj_w, w->out_proj_w, w->lin1_w, w->lin2_w, w->out_proj_w, w->lin2_w, w->lin1_w, w->in_proj_w};
+  const int Ns[8] = {3 * e.D, e.D, e.nhid, e.D, e.D, e.D, e.nhid, 3 * e.D};
+  const int Ks[8] = {e.D, e.D, e.D, e.nhid, e.D, e.nhid, e.D, e.D};
+  const int Tr[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+  __bf16* his[8]; __bf16* los[8];
+  for (int i = 0; i < 8; ++i) { his[i] = v.pl[i][0]; los[i] = v.pl[i][1]; }
+  const int njobs = rowgemm_ok(e.D, 3 * e.D, 3 * e.D, e.D) ? 8 : 7;
+  return launch_wsplit(njobs, Ws, Ns, Ks, Tr, his, los, tw ? v.ones : nullptr, st);
+}
+
+extern "C" int rd_encoder_layer_prepare(const rd_shape* s, const rd_encoder_weights* w, void* saved, size_t saved_bytes,
+                                        void* stream) {
+  int rc = check_enc(s);
+  if (rc) return rc;
+  if (s->B == 0) return RD_OK;
+  RD_REQUIRE(w && saved, "NULL tensor");
+  const EncDims e = enc_dims(s);
+  EncSaved v = carve_saved(e, saved);
+  RD_REQUIRE(saved_bytes >= v.bytes, "saved buffer too small");
+  const bool rg = rowgemm_ok(3 * e.D, e.D, e.D, 3 * e.D) && rowgemm_ok(e.D, e.D, e.D, e.D) &&
+                  rowgemm_ok(e.nhid, e.D, e.D, e.nhid) && rowgemm_ok(e.D, e.nhid, e.nhid, e.D);
+  if (!rg) return RD_OK;                             // the tiled path reads the fp32 weights directly
+  return enc_prepare(e, w, v, tile_path(e) && !aux().ok, (hipStream_t)stream);
+}
+
 extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const float* x, const uint8_t* mask,
                                     const rd_encoder_weights* w, float p_drop, uint64_t seed, float* y,
                                     void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes,
@@ -1942,20 +1969,15 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
   RD_REQUIRE(saved_bytes >= v.bytes && workspace_bytes >= ws.bytes, "saved/workspace buffer too small");
   if (e.B == 0) return RD_OK;
   hipStream_t st = (hipStream_t)stream;
+  const bool prepared = (layer & RD_LAYER_WEIGHTS_PREPARED) != 0;      // rd_encoder_layer_prepare already ran for these weights
+  layer &= 0xffff;
   const uint32_t L = (uint32_t)layer;
   // weights -> bf16 hi/lo planes (both orientations needed by this layer's forward and backward), one launch
   const bool rg = rowgemm_ok(3 * e.D, e.D, e.D, 3 * e.D) && rowgemm_ok(e.D, e.D, e.D, e.D) &&
                   rowgemm_ok(e.nhid, e.D, e.D, e.nhid) && rowgemm_ok(e.D, e.nhid, e.nhid, e.D);
   const bool tw = rg && tile_path(e) && !aux().ok;
   if (rg) {
-    const float* Ws[8] = {w->in_proj_w, w->out_proj_w, w->lin1_w, w->lin2_w, w->out_proj_w, w->lin2_w, w->lin1_w, w->in_proj_w};
-    const int Ns[8] = {3 * e.D, e.D, e.nhid, e.D, e.D, e.D, e.nhid, 3 * e.D};
-    const int Ks[8] = {e.D, e.D, e.D, e.nhid, e.D, e.nhid, e.D, e.D};
-    const int Tr[8] = {0, 0, 0, 0, 1, 1, 1, 1};
-    __bf16* his[8]; __bf16* los[8];
-    for (int i = 0; i < 8; ++i) { his[i] = v.pl[i][0]; los[i] = v.pl[i][1]; }
-    const int njobs = rowgemm_ok(e.D, 3 * e.D, 3 * e.D, e.D) ? 8 : 7;
-    if ((rc = launch_wsplit(njobs, Ws, Ns, Ks, Tr, his, los, tw ? v.ones : nullptr, st))) return rc;
+    if (!prepared && (rc = enc_prepare(e, w, v, tw, st))) return rc;
     if (tw) rowgemm_export_next(v.xt[0]);
     if ((rc = launch_rowgemm(e.M, 3 * e.D, e.D, x, e.D, v.pl[0][0], v.pl[0][1], v.qkv, 3 * e.D, w->in_proj_b, 0, nullptr, 0,
                              0.f, nullptr, 0, 0.f, 0, 0, st))) return rc;
