@@ -241,6 +241,9 @@ int rd_softmax_xent(int32_t B, int32_t C, const float* logits, const int64_t* y,
  * the grouping of the LayerNorm parameter-gradient partial sums.  raindrop_amd.step.TrainStep times both settings when
  * it captures its graph and keeps the faster one. */
 int rd_set_rowgemm_rows32(int32_t mask);
+/* Same bit assignment: kernel variants that run on 16-wave (1024-thread) workgroups, one column tile per wave and round, instead
+ * of 8-wave ones; -1 restores the default (environment RD_RG_WAVES16, else 12). */
+int rd_set_rowgemm_waves16(int32_t mask);
 /* Classifier head + loss, forward and backward, in two launches (training step; rd_head.hip).
  *   agg = masked mean over time of r [T,B,D] (code/models_rd.py:366-367,379); feat = [agg | static W_emb^T + b_emb]
  *   (:381-384; Fe = 0: no static branch); logits = W2 relu(W0 feat + b0) + b2 (mlp_static, :263-267,385);

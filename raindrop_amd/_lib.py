@@ -71,6 +71,7 @@ SIGNATURES = {
     "rd_linear_bwd_input_gated": (c_int32, [c_int32, c_int32, c_int32, _P, c_int32, _P, _P, c_int32, _P, c_int32, _P]),
     "rd_softmax_xent": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _P]),
     "rd_set_rowgemm_rows32": (c_int32, [c_int32]),
+    "rd_set_rowgemm_waves16": (c_int32, [c_int32]),
     "rd_head_train_supported": (c_int32, [c_int32, c_int32, c_int32]),
     "rd_head_train_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "rd_head_train": (c_int32, [_SHP, c_int32, c_int32, c_int32, c_int32] + [_P] * 20 + [_P, c_size_t, _P]),

@@ -20,7 +20,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int RG_THR = 512, RG_WAVES = 8;   // rows per workgroup: template parameter (64; 32 for the long reduction K = 3D)
+// workgroup: WV wavefronts (template parameter, 8 or 16) x RG_ROWS rows (64; 32 for the long reduction K = 3D)
 // per kernel instance: NJ column tiles per wave and round, RG_CPR = 8 * NJ * 16 output columns per round, stage row stride RG_CPR + 4
 
 static unsigned long long* g_rg_stamps = nullptr;   // debug only (tools/rowgemm_timing.py); passed as a kernel argument
@@ -100,7 +100,7 @@ __device__ __forceinline__ float wave_sum64(float v) { return wave_sum64_dpp(v);
 template <int KC, int RG_NJ>
 struct RPanel { bf16x8 h[RG_NJ][KC], l[RG_NJ][KC]; };
 
-template <int KC, int RG_NJ>
+template <int KC, int RG_NJ, int RG_WAVES>
 __device__ __forceinline__ void rg_load_panel(RPanel<KC, RG_NJ>& p, const __bf16* __restrict__ Wt, int tile0, int ntiles, int wave,
                                               int lane) {
 #pragma unroll
@@ -115,8 +115,9 @@ __device__ __forceinline__ void rg_load_panel(RPanel<KC, RG_NJ>& p, const __bf16
   }
 }
 
-template <int KC, int RG_ROWS, int RG_NJ, bool LN, bool LNB>
-__global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
+template <int KC, int RG_ROWS, int RG_NJ, bool LN, bool LNB, int WV>
+__global__ __launch_bounds__(64 * WV) void k_rowgemm(RowGemmArgs a) {
+  constexpr int RG_WAVES = WV, RG_THR = 64 * WV;
   constexpr int RT = RG_ROWS / 16, RG_CPR = RG_WAVES * RG_NJ * 16, RG_LDS_STAGE = RG_CPR + 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
   constexpr int KPc = KC * 32, LDA = KPc + 8;       // bf16 elements per A-plane row
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
         dvr[it] = *reinterpret_cast<const float4*>(a.lnb_dy + row * a.K + c);
       }
     }
-    rg_load_panel<KC, RG_NJ>(pw, a.Wh, 0, ntiles, wave, lane);
+    rg_load_panel<KC, RG_NJ, RG_WAVES>(pw, a.Wh, 0, ntiles, wave, lane);
     __builtin_amdgcn_sched_barrier(0);
     uint64_t lseed = a.lnb_seed;
     if (a.seed_cell) { const uint64_t cv = load_uniform_u64(a.seed_cell); lseed += cv; seed += cv; }
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
       v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (r < RG_ROWS && m0 + r < a.M && k < a.K) v[it] = *reinterpret_cast<const float4*>(a.A + (long)(m0 + r) * a.lda + k);
     }
-    rg_load_panel<KC, RG_NJ>(pw, a.Wh, 0, ntiles, wave, lane);
+    rg_load_panel<KC, RG_NJ, RG_WAVES>(pw, a.Wh, 0, ntiles, wave, lane);
     __builtin_amdgcn_sched_barrier(0);       // keep every request above the first use (the scheduler otherwise
                                              // waits for the rows before it has requested the panel)
     if (a.seed_cell) seed += load_uniform_u64(a.seed_cell);   // scalar path: not queued behind the panel
@@ -238,8 +239,12 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
   if constexpr (LNB) {                 // this workgroup's dgamma | dbeta partial: the 8 waves in fixed order
     const int K2 = 2 * a.K;
     for (int i = tid; i < K2; i += RG_THR)
-      a.lnb_part[(long)blockIdx.x * K2 + i] = ((lnred[i] + lnred[K2 + i]) + (lnred[2 * K2 + i] + lnred[3 * K2 + i])) +
-                                              ((lnred[4 * K2 + i] + lnred[5 * K2 + i]) + (lnred[6 * K2 + i] + lnred[7 * K2 + i]));
+    {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < RG_WAVES; ++w) v += lnred[w * K2 + i];
+      a.lnb_part[(long)blockIdx.x * K2 + i] = v;
+    }
   }
   if (a.xt) {
     // ds_read_b64_tr_b16 (tools/probe_tr16.hip): in a 16-lane group lane i passes the address of 4 consecutive shorts --
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
     }
     if (rd == 0) RGSTAMP(3);
     // next round's weights stream while this round's epilogue runs
-    if (rd + 1 < nrounds) rg_load_panel<KC, RG_NJ>(pw, a.Wh, tile0 + RG_WAVES * RG_NJ, ntiles, wave, lane);
+    if (rd + 1 < nrounds) rg_load_panel<KC, RG_NJ, RG_WAVES>(pw, a.Wh, tile0 + RG_WAVES * RG_NJ, ntiles, wave, lane);
     // ---- accumulators -> stage tile (column = position inside this round's 256-column window) ----
 #pragma unroll
     for (int jj = 0; jj < RG_NJ; ++jj)
@@ -392,12 +397,12 @@ __global__ __launch_bounds__(RG_THR) void k_rowgemm(RowGemmArgs a) {
   RGSTAMP(7);
 }
 
-template <int KC, int ROWS, int NJ, bool LN = false, bool LNB = false>
+template <int KC, int ROWS, int NJ, bool LN = false, bool LNB = false, int WV = 8>
 int launch_rowgemm_kc(const RowGemmArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)2 * ROWS * (KC * 32 + 8) * sizeof(__bf16) + (size_t)ROWS * (RG_WAVES * NJ * 16 + 4) * sizeof(float) +
-                     (LNB ? (size_t)RG_WAVES * 2 * KC * 32 * sizeof(float) : 0);
-  RD_LDS_ATTR((k_rowgemm<KC, ROWS, NJ, LN, LNB>), lds);
-  hipLaunchKernelGGL((k_rowgemm<KC, ROWS, NJ, LN, LNB>), dim3(cdiv(a.M, ROWS)), dim3(RG_THR), lds, st, a);
+  const size_t lds = (size_t)2 * ROWS * (KC * 32 + 8) * sizeof(__bf16) + (size_t)ROWS * (WV * NJ * 16 + 4) * sizeof(float) +
+                     (LNB ? (size_t)WV * 2 * KC * 32 * sizeof(float) : 0);
+  RD_LDS_ATTR((k_rowgemm<KC, ROWS, NJ, LN, LNB, WV>), lds);
+  hipLaunchKernelGGL((k_rowgemm<KC, ROWS, NJ, LN, LNB, WV>), dim3(cdiv(a.M, ROWS)), dim3(64 * WV), lds, st, a);
   return check_launch("k_rowgemm");
 }
 
@@ -443,6 +448,19 @@ static int rows32_mask() {
   static const int m = [] { const char* e = getenv("RD_RG_ROWS32"); return e ? atoi(e) : 15; }();
   return m;
 }
+// 16-wave workgroups (one column tile per wave and round instead of two): same bit assignment as rows32
+static int g_waves16 = -1;
+static int waves16_mask() {
+  if (g_waves16 >= 0) return g_waves16;
+  // MEASURED in-step (ms/step, workgroup height autotuned in each run): fast box 0 -> 0.687, 3 -> 0.682, 12 -> 0.666, 15 -> 0.663-0.678;
+  // slow box 12 -> 0.828, 15 -> 0.836 (8 waves everywhere: 0.867).  Default: the LayerNorm-fused variants on 16 waves.
+  static const int m = [] { const char* e = getenv("RD_RG_WAVES16"); return e ? atoi(e) : 12; }();
+  return m;
+}
+extern "C" int rd_set_rowgemm_waves16(int32_t mask) {
+  g_waves16 = mask < 0 ? -1 : (mask & 15);
+  return RD_OK;
+}
 extern "C" int rd_set_rowgemm_rows32(int32_t mask) {   // tuning knob, see include/raindrop_hip.h
   g_rows32 = mask < 0 ? -1 : (mask & 15);
   return RD_OK;
@@ -469,12 +487,13 @@ int launch_rowgemm_ln(long M, int N, int K, const float* A, const void* Wh, cons
   a.one_product = precision() == RD_PREC_BF16;
   a.ln_g = ln_g; a.ln_b = ln_b; a.ln_s = s_out; a.ln_stats = stats;
   take_export(a);
-  if (rows32_mask() & 4) {
-    if (a.KP == 160) return launch_rowgemm_kc<5, 32, 2, true>(a, st);
-    return launch_rowgemm_kc<9, 32, 2, true>(a, st);
+  const bool r32 = rows32_mask() & 4, w16 = waves16_mask() & 4;
+  if (a.KP == 160) {
+    if (w16) return r32 ? launch_rowgemm_kc<5, 32, 1, true, false, 16>(a, st) : launch_rowgemm_kc<5, 64, 1, true, false, 16>(a, st);
+    return r32 ? launch_rowgemm_kc<5, 32, 2, true>(a, st) : launch_rowgemm_kc<5, 64, 2, true>(a, st);
   }
-  if (a.KP == 160) return launch_rowgemm_kc<5, 64, 2, true>(a, st);
-  return launch_rowgemm_kc<9, 64, 2, true>(a, st);
+  if (w16) return r32 ? launch_rowgemm_kc<9, 32, 1, true, false, 16>(a, st) : launch_rowgemm_kc<9, 64, 1, true, false, 16>(a, st);
+  return r32 ? launch_rowgemm_kc<9, 32, 2, true>(a, st) : launch_rowgemm_kc<9, 64, 2, true>(a, st);
 }
 
 // C = epi(A Wp^T) with A = LayerNorm-backward of (dy, s, stats, gamma) computed in the prologue (K = LayerNorm width <= 160);
@@ -494,8 +513,10 @@ int launch_rowgemm_lnb(long M, int N, int K, const float* dy, const float* s, co
   a.lnb_dy = dy; a.lnb_s = s; a.lnb_stats = stats; a.lnb_g = g; a.lnb_ds = ds_out; a.lnb_part = part;
   a.lnb_p = p_drop; a.lnb_site = site; a.lnb_seed = seed;
   take_export(a);
-  if (rows32_mask() & 8) return launch_rowgemm_kc<5, 32, 2, false, true>(a, st);
-  return launch_rowgemm_kc<5, 64, 2, false, true>(a, st);
+  const bool r32 = rows32_mask() & 8;
+  if (waves16_mask() & 8)
+    return r32 ? launch_rowgemm_kc<5, 32, 1, false, true, 16>(a, st) : launch_rowgemm_kc<5, 64, 1, false, true, 16>(a, st);
+  return r32 ? launch_rowgemm_kc<5, 32, 2, false, true>(a, st) : launch_rowgemm_kc<5, 64, 2, false, true>(a, st);
 }
 
 // C[M,N] = epi(A[M,K] Wp^T): Wp planes [ceil16(N)][ceil32(K)]
@@ -513,6 +534,11 @@ int launch_rowgemm(long M, int N, int K, const float* A, long lda, const void* W
   take_export(a);
   const int kc = a.KP / 32;
   const int rows32 = rows32_mask();
+  const int w16 = waves16_mask();
+  if (kc == 5 && (w16 & 1))
+    return (rows32 & 1) ? launch_rowgemm_kc<5, 32, 1, false, false, 16>(a, st) : launch_rowgemm_kc<5, 64, 1, false, false, 16>(a, st);
+  if (kc == 9 && (w16 & 2))
+    return (rows32 & 2) ? launch_rowgemm_kc<9, 32, 1, false, false, 16>(a, st) : launch_rowgemm_kc<9, 64, 1, false, false, 16>(a, st);
   if (kc == 5 && (rows32 & 1)) return launch_rowgemm_kc<5, 32, 2>(a, st);
   if (kc == 9 && (rows32 & 2)) return launch_rowgemm_kc<9, 32, 2>(a, st);
   if (kc == 5) return launch_rowgemm_kc<5, 64, 2>(a, st);

@@ -252,7 +252,7 @@ class TrainStep:
                 self.graph.replay()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(12):
+            for _ in range(30):
                 self.graph.replay()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
