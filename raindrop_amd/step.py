@@ -38,7 +38,7 @@ class TrainStep:
         live parameters (its buffer receives the gradients); batch: dict(src, static, times, lengths, y)
         of device tensors that are REUSED every step (copy new data into them)."""
         self.model, self.flat, self.batch = model, flat, batch
-        self.autotune, self.tuned_rows32 = bool(autotune), None
+        self.autotune, self.tuned_rows32, self.tuned_waves16 = bool(autotune), None, None
         # MEASURED (same box, hipGraph step): 0.683 ms/step without, 0.702 with the side branch -- the two small launches cost less
         # on the critical path than the cross-stream edges and the contention with the sensor stage; off unless RD_SIDE_PREPARE=1
         self.side_prepare = os.environ.get("RD_SIDE_PREPARE", "0") == "1"
@@ -242,11 +242,12 @@ class TrainStep:
         tuning knob (32-row vs 64-row workgroups of the encoder's row-block products, rd_set_rowgemm_rows32: which is
         faster depends on the device, 8 % either way was measured on two boxes of one pool) and the faster graph is kept.
         Results are the same function of the inputs either way."""
-        if not self.autotune or os.environ.get("RD_RG_ROWS32") is not None:
+        if not self.autotune or os.environ.get("RD_RG_ROWS32") is not None or os.environ.get("RD_RG_WAVES16") is not None:
             return self._capture_one()
-        best = None
-        for mask in (15, 0, 3, 12):                                  # all / none / plain products only / LayerNorm-fused ones only
-            _lib.call("rd_set_rowgemm_rows32", mask)
+
+        def timed(r32, w16):
+            _lib.call("rd_set_rowgemm_rows32", r32)
+            _lib.call("rd_set_rowgemm_waves16", w16)
             self._capture_one()
             for _ in range(3):
                 self.graph.replay()
@@ -255,11 +256,16 @@ class TrainStep:
             for _ in range(30):
                 self.graph.replay()
             torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            if best is None or dt < best[0]:
-                best = (dt, mask, self.graph)
-        self.graph, self.tuned_rows32 = best[2], best[1]
+            return (time.perf_counter() - t0, r32, w16, self.graph)
+        # workgroup height first (all / none / plain products only / LayerNorm-fused ones only) at the default wave counts,
+        # then the wave count of the plain products at the best height
+        best = min((timed(r32, 12) for r32 in (15, 0, 3, 12)), key=lambda t: t[0])
+        alt = timed(best[1], 15)
+        if alt[0] < best[0]:
+            best = alt
+        self.graph, self.tuned_rows32, self.tuned_waves16 = best[3], best[1], best[2]
         _lib.call("rd_set_rowgemm_rows32", best[1])                  # eager calls of this process follow the same choice
+        _lib.call("rd_set_rowgemm_waves16", best[2])
 
     def _capture_one(self):
         def cap():
