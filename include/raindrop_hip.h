@@ -86,6 +86,25 @@ int rd_get_precision(void);
 int rd_set_seed_cell(const uint64_t* device_cell);
 int rd_seed_cell_advance(uint64_t* device_cell, uint64_t delta, void* stream);
 
+/* ---- token plan: the padding mask as a layout --------------------------------------------------------------------------
+ * code/models_rd.py:298-299 builds mask[b,t] = (t >= lengths[b]) and uses it twice: as src_key_padding_mask of the encoder
+ * (:358) and in the masked mean (:366-367,379).  Between them the two uses remove every padded step from the logits AND from
+ * every gradient (its rows of the encoder's activation gradients are exactly zero).  rd_token_plan turns `lengths` into a
+ * layout: samples ordered by descending length (ties by index), sample b's live steps t < min(lengths[b], T) at rows
+ * off[rank[b]] + t of every [tokens, *] tensor.  While a plan is registered (rd_set_token_plan: per host thread, consumed when a
+ * call is ENQUEUED, like the seed cell), rd_sensor_stage_fwd, rd_encoder_layer_fwd/bwd, rd_head_train and rd_msgpass_bwd read and
+ * write ONLY those rows -- buffers keep their padded sizes, the first plan[0] rows are used -- and skip the arithmetic whose
+ * operand is an exactly-zero padded step.  Logits, loss and all parameter gradients are the same function of the inputs as
+ * without a plan (up to the order of the fp32 sums over tokens); z / x / dx at padded steps, which nothing reads, are not
+ * produced.  Supported where the step runs on its fast paths (fused message passing, row-block encoder with single-tile
+ * attention, fused head: the P19 shape); other shapes return RD_EUNSUPPORTED while a plan is registered.
+ * plan_out: rd_token_plan_bytes(s) bytes of int32 (layout: raindrop_amd/csrc/rd_plan.h; [0] = live rows).  If seed_cell is not
+ * NULL the launch also adds `delta` to it (rd_seed_cell_advance folded in: one launch fewer per step). */
+size_t rd_token_plan_bytes(const rd_shape* s);
+int rd_token_plan(const rd_shape* s, const int64_t* lengths, int32_t* plan_out, uint64_t* seed_cell, uint64_t delta,
+                  void* stream);
+int rd_set_token_plan(const int32_t* device_plan);
+
 /* ---- a5/a6: integer work (bit-exact contracts) -------------------------------------------- */
 
 /* code/models_rd.py:307-311: adj = global_structure; adj[diag] = 1; edge_index =

@@ -19,6 +19,7 @@
 //   k_head_wgrad  the three weight/bias gradients as 16 x 16 output tiles over the B rows (operands staged in LDS), and
 //                 the mean of the per-sample losses -- all fixed-order sums, no atomics.
 #include "rd_common.h"
+#include "rd_plan.h"
 
 namespace rd {
 namespace {
@@ -34,7 +35,19 @@ struct HeadArgs {
   float *logits, *dr;
   float *feat, *hid, *dhid, *demb, *dlog, *lossr;   // workspace: [B,dh] x3, [B,Fe], [B,C], [B]
   int T, B, D, ds, Fe, dh, C;
+  const int32_t* plan;             // token plan (rd_plan.h) or null: r / dr hold the live rows only, sample b at rows off[rank[b]] + t
 };
+
+// first row and row step of sample b's time steps in r / dr, and how many of them are live
+struct HeadRows { long row0, rstep; int Tv; };
+__device__ __forceinline__ HeadRows head_rows(const HeadArgs& a, int b) {
+  HeadRows h;
+  if (a.plan) {
+    const int rk = a.plan[plan::rank_base(a.B) + b];
+    h.row0 = a.plan[plan::off_base() + rk]; h.rstep = 1; h.Tv = a.plan[plan::len_base(a.B) + rk];
+  } else { h.row0 = b; h.rstep = a.B; h.Tv = a.T; }
+  return h;
+}
 
 __device__ __forceinline__ float wsum64(float v) { return wave_sum64_dpp(v); }
 
@@ -66,12 +79,14 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
     const int pair = tid % P, tg = tid / P;
     const int r = pair / D4, c4 = pair - r * D4, b = b0 + r;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tg < ntg && b < B)
-      for (int t = tg; t < T; t += ntg)
-        if (!a.mask[(long)b * T + t]) {
-          const float4 v = *reinterpret_cast<const float4*>(a.r + ((long)t * B + b) * D + 4 * c4);
+    if (tg < ntg && b < B) {
+      const HeadRows hr = head_rows(a, b);
+      for (int t = tg; t < hr.Tv; t += ntg)
+        if (a.plan || !a.mask[(long)b * T + t]) {
+          const float4 v = *reinterpret_cast<const float4*>(a.r + (hr.row0 + (long)t * hr.rstep) * D + 4 * c4);
           s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
+    }
     if (tg < ntg) *reinterpret_cast<float4*>(red + ((size_t)tg * P + pair) * 4) = s;
     if (tid < RB) invl[tid] = (b0 + tid < B) ? 1.0f / (float)(a.lengths[b0 + tid] + 1) : 0.f;
   }
@@ -199,9 +214,11 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
     const int c4 = e % D4, rt = e / D4;
     const int t = rt % T, r = rt / T, b = b0 + r;
     if (b >= B) continue;
-    const float il = a.mask[(long)b * T + t] ? 0.f : invl[r];
+    const HeadRows hr = head_rows(a, b);
+    if (t >= hr.Tv) continue;                                           // token plan: padded steps have no row
+    const float il = (!a.plan && a.mask[(long)b * T + t]) ? 0.f : invl[r];
     const float4 v = *reinterpret_cast<const float4*>(&dfeat[r][4 * c4]);
-    *reinterpret_cast<float4*>(a.dr + ((long)t * B + b) * D + 4 * c4) = make_float4(v.x * il, v.y * il, v.z * il, v.w * il);
+    *reinterpret_cast<float4*>(a.dr + (hr.row0 + (long)t * hr.rstep) * D + 4 * c4) = make_float4(v.x * il, v.y * il, v.z * il, v.w * il);
   }
 }
 
@@ -287,6 +304,7 @@ extern "C" int rd_head_train(const rd_shape* s, int32_t D, int32_t d_static, int
   a.feat = ws; a.hid = a.feat + (size_t)B * dh; a.dhid = a.hid + (size_t)B * dh; a.demb = a.dhid + (size_t)B * dh;
   a.dlog = a.demb + (size_t)B * dh; a.lossr = a.dlog + (size_t)B * C;
   a.T = s->T; a.B = B; a.D = D; a.ds = d_static; a.Fe = Fe; a.dh = dh; a.C = C;
+  a.plan = token_plan();
   // one sample per workgroup (B workgroups: every CU busy at B = 256); MEASURED in-step: 1.077 -> 1.056 ms/step against RB = 2
   static const int rb1 = [] { const char* e = getenv("RD_HEAD_RB1"); return e ? atoi(e) : 1; }();
   if (rb1) hipLaunchKernelGGL(k_head_rows<1>, dim3(B), dim3(HR_THR), 0, st, a);

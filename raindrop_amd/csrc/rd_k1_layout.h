@@ -42,6 +42,9 @@ struct Layout {
   size_t wt_bytes, tp_bytes, gate_bytes, mx_bytes;
 };
 
+// the per-sample "1 + last observed step" array rides behind the embedding's gate bytes
+inline size_t lin_offset(int B, int T, int F) { return ((size_t)B * F * T + 255) / 256 * 256; }
+
 inline Layout make_layout(int B, int T, int F) {
   Layout L;
   L.B = B; L.T = T; L.F = F; L.K = T * 4; L.nct = L.K / 16; L.RT = (F + 15) / 16;
@@ -50,7 +53,7 @@ inline Layout make_layout(int B, int T, int F) {
   L.wt_bytes = (size_t)4 * L.nct * NKC * 2 * TILE * 2;
   L.tp_bytes = (size_t)L.S * L.nct * 2 * TILE * 2;
   L.gate_bytes = (size_t)B * F * 16 * sizeof(uint16_t);
-  L.mx_bytes = (size_t)B * F * T;
+  L.mx_bytes = lin_offset(B, T, F) + (size_t)B * sizeof(int);      // gate bytes, then lin[B] (int per sample slot)
   return L;
 }
 

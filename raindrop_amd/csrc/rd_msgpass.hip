@@ -16,6 +16,7 @@
 // epilogue.  The LDS-resident fused kernel for small K lives in rd_msgpass_fused.hip.
 #include "rd_common.h"
 #include "rd_k1_layout.h"
+#include "rd_plan.h"
 #include "rd_rng.h"
 
 namespace rd {
@@ -225,6 +226,7 @@ extern "C" int rd_msgpass_fwd(const rd_shape* s, const float* src, const float* 
     return fused_msgpass_fwd(L, src, R_u, b1, b2, ssum, fv.wt, p_drop, seed, fv.tpX, fv.tpY1, fv.m1, fv.m2, fv.mx, z, ldz,
                              st, nullptr, nullptr, nullptr, nullptr, 0);
   }
+  if (token_plan()) return fail(RD_EUNSUPPORTED, "token plan: only the fused message-passing path (F <= 64, K <= 240, bf16x3) reads it");
   {
     const long per = (long)F * K;
     int gy = (int)((per + 255) / 256); if (gy > 64) gy = 64;
@@ -267,6 +269,7 @@ extern "C" int rd_sensor_stage_fwd(const rd_shape* s, const float* src, const fl
     return fused_msgpass_fwd(L, src, R_u, b1, b2, ssum, fv.wt, p_drop, seed, fv.tpX, fv.tpY1, fv.m1, fv.m2, fv.mx, z, ldz,
                              st, times, lengths, timescales, mask, s->d_pe);
   }
+  if (token_plan()) return fail(RD_EUNSUPPORTED, "token plan: only the fused message-passing path (F <= 64, K <= 240, bf16x3) reads it");
   if ((rc = rd_pe_mask(s, times, lengths, timescales, z, mask, stream))) return rc;
   return rd_msgpass_fwd(s, src, R_u, W1, b1, W2, b2, ssum, p_drop, seed, z, ldz, saved, saved_bytes, stream);
 }
@@ -313,6 +316,7 @@ extern "C" int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* 
       return rc;
     return fused_dw(L, P, fv.tpX, fv.tpY1, fw.tpD1, fw.tpD2, fw.ones, fw.part, fw.rupart, dW1, db1, dW2, db2, dR_u, st);
   }
+  if (token_plan()) return fail(RD_EUNSUPPORTED, "token plan: only the fused message-passing path (F <= 64, K <= 240, bf16x3) reads it");
   MsgWs w = carve(s, workspace);
   RD_REQUIRE(workspace && workspace_bytes >= w.bytes, "workspace too small: %zu < %zu",
              workspace_bytes, w.bytes);

@@ -19,6 +19,7 @@
 // folds the per-sample dR_u partials of the backward kernel.
 #include "rd_common.h"
 #include "rd_k1_layout.h"
+#include "rd_plan.h"
 
 namespace rd {
 namespace {
@@ -34,6 +35,7 @@ struct DwArgs {
   const __bf16 *tpX, *tpY1, *tpD1, *tpD2, *ones;
   float* part;                    // [nslice][2][K][ldp]
   int S, K, nct, nbn, nbk, nslice, ldp;
+  const int32_t* plan; int B, q, rem, per;     // token plan (or null) and the row-tile grouping of rd_k1_layout.h
 };
 
 struct Frag { bf16x8 ah[4], al[4], bh[4], bl[4]; };
@@ -52,7 +54,19 @@ __global__ __launch_bounds__(DW_THR) void k_dw(DwArgs a) {
   // slice sl = reduction tiles sl, sl + nslice, sl + 2 nslice, ...: with nslice == 8 these are the samples b = sl (mod 8),
   // i.e. the row tiles the backward kernel's workgroups on XCD sl wrote a moment ago -- and this group runs on XCD sl
   const int nsl = a.nslice;
-  const int ntile = a.S > sl ? (a.S - sl + nsl - 1) / nsl : 0;        // tiles of this slice
+  // Reduction tiles this block needs.  Layer 2 with a token plan: dZ2's columns at a sample's padded steps are exactly zero
+  // (and not exported), so the 64-column block bn (steps 16 bn ..) sums only over the samples longer than 16 bn -- the row
+  // tiles are stored by RANK (descending length), i.e. over a prefix: nr samples -> nr*q main tiles + ceil(nr / per) leftover
+  // tiles (a leftover tile holds `per` consecutive ranks; its shorter members wrote zeros up to the longest one's block).
+  int nmain = a.B * a.q, ntot = a.S;
+  if (a.plan && layer == 1) {
+    const int t0 = min(16 * bn, __builtin_amdgcn_readfirstlane(a.plan[plan::I_T]));
+    const int nr = __builtin_amdgcn_readfirstlane(a.plan[plan::cnt_base(a.B) + t0]);
+    nmain = nr * a.q;
+    ntot = nmain + (a.rem ? (nr + a.per - 1) / a.per : 0);
+  }
+  const int lbase = a.B * a.q - nmain;                                // reduction index i >= nmain -> tile i + lbase
+  const int ntile = ntot > sl ? (ntot - sl + nsl - 1) / nsl : 0;      // tiles of this slice
   const int s0 = 0, s1 = ntile;                                       // wave tiling below runs over slice-local indices
   const __bf16* tA = layer ? a.tpD2 : a.tpD1;
   const __bf16* tB = layer ? a.tpY1 : a.tpX;
@@ -76,7 +90,8 @@ __global__ __launch_bounds__(DW_THR) void k_dw(DwArgs a) {
   const __bf16* zt = a.ones + TILE + lane * 8;                          // [ones hi][zeros][zeros]
   auto load = [&](Frag& f, int i) {
     const bool ghost = i >= nst;
-    const size_t s = (size_t)(ghost ? sl : sl + nsl * (wave + 4 * i));
+    const int ri = sl + nsl * (wave + 4 * i);                         // reduction index -> tile (ghosts: tile 0)
+    const size_t s = ghost ? 0 : (size_t)(ri < nmain ? ri : ri + lbase);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const __bf16* qa = ghost ? zt : pa[t] + s * step;
@@ -237,6 +252,7 @@ int fused_dw(const k1::Layout& L, const k1::DwPlan& P, const void* tpX, const vo
   a.tpX = (const __bf16*)tpX; a.tpY1 = (const __bf16*)tpY1; a.tpD1 = (const __bf16*)tpD1; a.tpD2 = (const __bf16*)tpD2;
   a.ones = (const __bf16*)ones;
   a.part = part; a.S = L.S; a.K = L.K; a.nct = L.nct; a.nbn = P.nbn; a.nbk = P.nbk; a.nslice = P.nslice; a.ldp = P.ldp;
+  a.plan = token_plan(); a.B = L.B; a.q = L.q; a.rem = L.rem; a.per = L.per;
   const int nmem = P.nbn * P.nbk, ngroups = 2 * P.nslice;
   const int grid = 8 * nmem * cdiv(ngroups, 8);
   RD_LDS_ATTR(k_dw, DW_LDS);

@@ -29,6 +29,7 @@
 
 #include "rd_common.h"
 #include "rd_k1_layout.h"
+#include "rd_plan.h"
 #include "rd_rng.h"
 
 namespace rd {
@@ -65,7 +66,29 @@ struct FusedArgs {
   int B, T, F, K, ldz, nct, q, rem, per;
   float p_drop; uint64_t seed; const uint64_t* seed_cell;
   unsigned long long* stamps;    // debug: per-phase clock64() of every wave of the first 4 workgroups
+  const int32_t* plan;           // token plan (rd_plan.h) or null: which steps of a sample are live, and where its z rows are
+  int* lin;                      // [B] per slot: 1 + last step with a non-zero observation (fwd writes, bwd reads)
 };
+
+// Which sample a workgroup owns and where its rows live.  Padded layout (no plan): workgroup i = sample i, every step is
+// live, z row of step t = t*B + b.  With a plan: workgroup i owns the sample of RANK i (longest first); `b` indexes the
+// caller's tensors (src, times, lengths, mask), `sb` = the rank indexes everything these kernels hand to each other (row
+// tiles, gate bits, per-sample partials); steps t >= L are padding and neither written nor read; z row of step t = row0 + t.
+struct Tok { int b, sb, L, row0, rstride; };
+__device__ __forceinline__ Tok tok_of(const FusedArgs& a) {
+  Tok k;
+  if (a.plan) {
+    const int r = blockIdx.x;
+    k.sb = r;
+    k.b = __builtin_amdgcn_readfirstlane(a.plan[plan::order_base(a.B) + r]);
+    k.L = __builtin_amdgcn_readfirstlane(a.plan[plan::len_base(a.B) + r]);
+    k.row0 = __builtin_amdgcn_readfirstlane(a.plan[plan::off_base() + r]);
+    k.rstride = 1;
+  } else {
+    k.b = k.sb = blockIdx.x; k.L = a.T; k.row0 = blockIdx.x; k.rstride = a.B;
+  }
+  return k;
+}
 
 #define RD_STAMP(i)                                                                              \
   do {                                                                                           \
@@ -191,12 +214,15 @@ __device__ __forceinline__ void zero_plane_pads(__bf16* P, int rows, int prow, i
 // The three split products are issued as three sweeps over independent accumulators.  A product runs as two
 // halves of the reduction (KC = 0..3, 4..7): the registers of the first half are free while the second half
 // multiplies, so the NEXT layer's first half-panel streams in underneath it.
+// kclim (wave-uniform): reduction steps kc >= kclim are skipped -- the caller knows the A operand is exactly zero there
+// (padded / unobserved time steps), so the skipped products are x0: bit-safe.
 template <int RT, int KC0, int KC1>
 __device__ __forceinline__ void mma_steps(f32x4 (&acc)[NJ][RT], const __bf16* Ah, const __bf16* Al,
-                                          const Panel& p, int lane) {
+                                          const Panel& p, int lane, int kclim = NKC) {
   const int aoff = (lane & 15) * LDX + 8 * (lane >> 4);
 #pragma unroll
   for (int kc = KC0; kc < KC1; ++kc) {
+    if (kc >= kclim) break;
     bf16x8 ah[RT], al[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -222,8 +248,8 @@ __device__ __forceinline__ void mma_steps(f32x4 (&acc)[NJ][RT], const __bf16* Ah
 }
 template <int RT>
 __device__ __forceinline__ void mma_panel(f32x4 (&acc)[NJ][RT], const __bf16* Ah, const __bf16* Al,
-                                          const Panel& p, int lane) {
-  mma_steps<RT, 0, NKC>(acc, Ah, Al, p, lane);
+                                          const Panel& p, int lane, int kclim = NKC) {
+  mma_steps<RT, 0, NKC>(acc, Ah, Al, p, lane, kclim);
 }
 
 // srow[rt][r] = ssum[16 rt + 4 g + r] (0 beyond F): one 16-byte load per row tile when F % 4 == 0 puts the quad inside
@@ -278,12 +304,14 @@ __device__ __forceinline__ __bf16* tp_tile(__bf16* tp, int nct, int s, int j) {
 // Staging-sourced: S = fp32 [F][LDS_F] tile of sample b in LDS -> row tiles.  A slot = 8 consecutive graph rows of
 // one column: read down the column (conflict-free across the 16 columns of a lane group), split, one 16-byte
 // store per part; consecutive lanes write consecutive 16-byte slots of a tile.
-__device__ __forceinline__ void tstore_stage(const float* S, __bf16* tp, const FusedArgs& a, int b, int tid) {
-  const int nct = a.nct, K = a.K;
-  const int nslot = a.q * nct * 64;
+// jlim / jlimL: only column tiles j < jlim of the main tiles and j < jlimL of the leftover rows are written (the consumer
+// reads no further: rd_msgpass_dw.hip skips the column blocks that are all padding for a sample).
+__device__ __forceinline__ void tstore_stage(const float* S, __bf16* tp, const FusedArgs& a, int b, int tid, int jlim, int jlimL) {
+  const int nct = a.nct;
+  const int nslot = a.q * jlim * 64;
   for (int idx = tid; idx < nslot; idx += NTHR) {
     const int L = idx & 63, t2 = idx >> 6;
-    const int m = t2 / nct, j = t2 - m * nct;
+    const int m = t2 / jlim, j = t2 - m * jlim;
     const float* p = S + (32 * m + 8 * (L >> 4)) * LDS_F + 16 * j + (L & 15);
     float v[8];
 #pragma unroll
@@ -296,8 +324,9 @@ __device__ __forceinline__ void tstore_stage(const float* S, __bf16* tp, const F
   }
   if (a.rem) {
     const int s = a.B * a.q + b / a.per, slot = b % a.per;
-    for (int idx = tid; idx < a.rem * K; idx += NTHR) {
-      const int li = idx / K, n = idx - li * K;
+    const int KL = 16 * jlimL;
+    for (int idx = tid; idx < a.rem * KL; idx += NTHR) {
+      const int li = idx / KL, n = idx - li * KL;
       const float x = S[(32 * a.q + li) * LDS_F + n];
       const int r = slot * a.rem + li;
       const __bf16 h = (__bf16)x, l = (__bf16)(x - (float)h);
@@ -376,12 +405,17 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   float* Xs = ALIAS ? reinterpret_cast<float*>(Yh) : reinterpret_cast<float*>(smem_raw + PLANES);   // fp32 copy of X
   uint16_t* M1 = reinterpret_cast<uint16_t*>(smem_raw + PLANES + XS_BYTES);                          // [ROWS][16]
   uint16_t* M2 = M1 + ROWS * 16;
+  int* LinW = reinterpret_cast<int*>(M2 + ROWS * 16);     // [NWAVE] per-wave "1 + last observed step" (the slot the backward uses for ssum)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool grpB = __builtin_amdgcn_readfirstlane(wave) >= NWAVE / 2;   // scalar: the group branches are real branches
-  const int b = blockIdx.x;
+  const Tok tk = tok_of(a);
+  const int b = tk.b, sb = tk.sb, L = tk.L;
   const int T = a.T, F = a.F, K = a.K, B = a.B;
   const int nct = a.nct;
   const float inv_keep = 1.0f / (1.0f - a.p_drop);
+  // column tile j of a layer's output = time steps 4j .. 4j+3.  Layer 2's output at padded steps (t >= L) is never read
+  // (rd_plan.h): a wave whose column tiles are all padding skips its layer-2 weight stream, product and epilogue.
+  const bool live2 = 4 * __builtin_amdgcn_readfirstlane(wave) < L;
 
   RD_STAMP(0);
   Panel pw;
@@ -403,6 +437,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   const int total = F * T;
   uint64_t seed_eff = a.seed;
   float v[UNR]; int fi[UNR], ti[UNR]; float4 ru[UNR]; unsigned km[UNR];     // km: keep bits of the 4 channels
+  int lin_w = 0;                                          // wave-uniform: 1 + last step at which this wave saw a non-zero observation
   auto embed_issue = [&](int base) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -417,6 +452,10 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
     for (int u = 0; u < UNR; ++u) {
       const int f = fi[u], t = ti[u];
       pin(v[u]); pin(ru[u]);
+      {   // cells are ordered by time step (f fastest): the highest lane holding a non-zero value has the wave's latest step
+        const unsigned long long nz = __ballot(v[u] != 0.f);
+        if (nz) lin_w = max(lin_w, 1 + __builtin_amdgcn_readlane(t, 63 - __builtin_clzll(nz)));
+      }
       float x[4] = {fmaxf(v[u] * ru[u].x, 0.f), fmaxf(v[u] * ru[u].y, 0.f), fmaxf(v[u] * ru[u].z, 0.f), fmaxf(v[u] * ru[u].w, 0.f)};
       if (a.p_drop > 0.f) {                                   // wave-uniform
         x[0] = (km[u] & 1) ? x[0] * inv_keep : 0.f; x[1] = (km[u] & 2) ? x[1] * inv_keep : 0.f;
@@ -424,7 +463,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
       }
       split_store4(Xh + f * LDX + 4 * t, Xl + f * LDX + 4 * t, x);
       *reinterpret_cast<float4*>(Xs + f * LDS_F + 4 * t) = make_float4(x[0], x[1], x[2], x[3]);
-      a.mx[(size_t)b * total + t * F + f] =                   // [b][t][f]: consecutive lanes, consecutive bytes
+      a.mx[(size_t)sb * total + t * F + f] =                  // [slot][t][f]: consecutive lanes, consecutive bytes
           (uint8_t)((x[0] > 0.f ? 1 : 0) | (x[1] > 0.f ? 2 : 0) | (x[2] > 0.f ? 4 : 0) | (x[3] > 0.f ? 8 : 0));
     }
   };
@@ -454,31 +493,43 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   RD_STAMP(11);
   if (!grpB) { embed_masks(); embed_consume(); }
   for (int base = tid + NTHR * UNR; base < total; base += NTHR * UNR) { embed_issue(base); embed_masks(); embed_consume(); }
+  if (lane == 0) LinW[wave] = lin_w;
   RD_STAMP(1);
   lds_barrier();
   RD_STAMP(2);
+  // X[:, 4t..4t+3] is exactly zero for every step t >= lin (no sensor observed: relu(0 * R_u) = 0, dropout or not), so
+  // layer 1's reduction stops after the last 32-column chunk that holds an observed step
+  int lin = 0;
+#pragma unroll
+  for (int w = 0; w < NWAVE; ++w) lin = max(lin, LinW[w]);
+  lin = __builtin_amdgcn_readfirstlane(lin);
+  const int kclim1 = (4 * lin + 31) >> 5;
+  if (tid == 0) {
+    a.lin[sb] = lin;
+    if (a.plan && lin > L) atomicMax(const_cast<int*>(a.plan) + plan::I_SLACK, lin - L);
+  }
 
   // ---- layer 1: Y1 = relu(X W1^T + b1) * ssum;  X leaves as row tiles for dW1 (reads the fp32 copy) --------
   f32x4 acc[NJ][RT];
   zero_acc<RT>(acc);
   if (grpB) {                                                // group B transposes while group A multiplies ...
-    tstore_stage(Xs, a.tpX, a, b, tid);
-    tzero_uncovered(a.tpX, a, b, tid);
-    tzero_uncovered(a.tpY1, a, b, tid);
+    tstore_stage(Xs, a.tpX, a, sb, tid, nct, nct);
+    tzero_uncovered(a.tpX, a, sb, tid);
+    tzero_uncovered(a.tpY1, a, sb, tid);
   }
   RD_STAMP(13);
-  mma_steps<RT, 0, NKC / 2>(acc, Xh, Xl, pw, lane);
+  mma_steps<RT, 0, NKC / 2>(acc, Xh, Xl, pw, lane, kclim1);
   __builtin_amdgcn_sched_barrier(0);                                   // the scheduler otherwise sinks these loads below the second half
-  load_panel_kc<0, NKC / 2>(pw, wtiles(a, 1, 0), nct, wave, lane);     // layer-2 weights, first half of the reduction
+  if (live2) load_panel_kc<0, NKC / 2>(pw, wtiles(a, 1, 0), nct, wave, lane);     // layer-2 weights, first half of the reduction
   __builtin_amdgcn_sched_barrier(0);
-  mma_steps<RT, NKC / 2, NKC>(acc, Xh, Xl, pw, lane);
+  mma_steps<RT, NKC / 2, NKC>(acc, Xh, Xl, pw, lane, kclim1);
   RD_STAMP(3);
-  load_panel_kc<NKC / 2, NKC>(pw, wtiles(a, 1, 0), nct, wave, lane);   // second half
+  if (live2) load_panel_kc<NKC / 2, NKC>(pw, wtiles(a, 1, 0), nct, wave, lane);   // second half
   RD_STAMP(12);
   if (!grpB) {                                               // ... and the other way round
-    tstore_stage(Xs, a.tpX, a, b, tid);
-    tzero_uncovered(a.tpX, a, b, tid);
-    tzero_uncovered(a.tpY1, a, b, tid);
+    tstore_stage(Xs, a.tpX, a, sb, tid, nct, nct);
+    tzero_uncovered(a.tpX, a, sb, tid);
+    tzero_uncovered(a.tpY1, a, sb, tid);
   }
   if (ALIAS) {                                               // the fp32 copy of X lives in the Y planes: everybody must be done with it
     lds_barrier();
@@ -504,7 +555,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
           const unsigned long long bal = __ballot(y > 0.f);
           if ((lane & 15) == 0) M1[row * 16 + j] = (uint16_t)(bal >> (16 * (lane >> 4)));
         }
-        tstore_acc(a.tpY1, a, b, j, rt, lane, hh, ll);
+        tstore_acc(a.tpY1, a, sb, j, rt, lane, hh, ll);
       }
     }
   }
@@ -513,17 +564,17 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   RD_STAMP(5);
   // gate bits of layer 1 -> global (rows < F: 32 bytes each); leftover rows of Y1 -> row tiles
   for (int i = tid; i < 2 * F; i += NTHR)
-    reinterpret_cast<uint4*>(a.m1 + (size_t)b * F * 16)[i] = reinterpret_cast<const uint4*>(M1)[i];
-  tstore_leftover_planes(Yh, Yl, a.tpY1, a, b, tid);
+    reinterpret_cast<uint4*>(a.m1 + (size_t)sb * F * 16)[i] = reinterpret_cast<const uint4*>(M1)[i];
+  tstore_leftover_planes(Yh, Yl, a.tpY1, a, sb, tid);
 
-  // ---- layer 2: Y2 = relu(Y1 W2^T + b2) * ssum -> fp32 staging -----------------------------------
+  // ---- layer 2: Y2 = relu(Y1 W2^T + b2) * ssum -> fp32 staging (live column tiles only) ------------
   zero_acc<RT>(acc);
-  mma_panel<RT>(acc, Yh, Yl, pw, lane);
+  if (live2) mma_panel<RT>(acc, Yh, Yl, pw, lane);
   RD_STAMP(6);
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
     const int j = wave + NWAVE * jj;
-    if (j < nct) {                                              // wave-uniform
+    if (j < nct && 4 * j < L) {                                 // wave-uniform
       const int n = 16 * j + (lane & 15);
       const float bias = bias2[jj];
 #pragma unroll
@@ -542,28 +593,29 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   lds_barrier();
   RD_STAMP(8);
   for (int i = tid; i < 2 * F; i += NTHR)
-    reinterpret_cast<uint4*>(a.m2 + (size_t)b * F * 16)[i] = reinterpret_cast<const uint4*>(M2)[i];
-  // ---- [F, T*d] -> z[t, b, f*d + c]: thread -> (t, f) with f fastest moves the 4 channels of a cell as one 16-byte
-  // LDS read (conflict-free at stride 244) and one 16-byte store; consecutive lanes write consecutive addresses
+    reinterpret_cast<uint4*>(a.m2 + (size_t)sb * F * 16)[i] = reinterpret_cast<const uint4*>(M2)[i];
+  // ---- [F, T*d] -> z[row(t), f*d + c]: thread -> (t, f) with f fastest moves the 4 channels of a cell as one 16-byte
+  // LDS read (conflict-free at stride 244) and one 16-byte store; consecutive lanes write consecutive addresses.
+  // Live steps only (t < L; L == T on the padded layout).
   if ((a.ldz & 3) == 0) {
-    for (int i = tid; i < total; i += NTHR) {
+    for (int i = tid; i < L * F; i += NTHR) {
       const int t = i / F, f = i - t * F;
-      st16f(a.z + ((size_t)t * B + b) * a.ldz + 4 * f, *reinterpret_cast<const float4*>(Ys + f * LDS_F + 4 * t));
+      st16f(a.z + ((size_t)tk.row0 + (size_t)t * tk.rstride) * a.ldz + 4 * f, *reinterpret_cast<const float4*>(Ys + f * LDS_F + 4 * t));
     }
   } else {
     const int Fd = F * 4;
-    for (int i = tid; i < T * Fd; i += NTHR) {
+    for (int i = tid; i < L * Fd; i += NTHR) {
       const int t = i / Fd, q = i - t * Fd;
-      a.z[((size_t)t * B + b) * a.ldz + q] = Ys[(q >> 2) * LDS_F + t * 4 + (q & 3)];
+      a.z[((size_t)tk.row0 + (size_t)t * tk.rstride) * a.ldz + q] = Ys[(q >> 2) * LDS_F + t * 4 + (q & 3)];
     }
   }
   // ---- positional encoding + padding mask of this sample (code/models_rd.py:28-38,298-299) ----
   if (a.times != nullptr) {
     const int H = a.d_pe >> 1;
-    for (int i = tid; i < T * H; i += NTHR) {
+    for (int i = tid; i < L * H; i += NTHR) {
       const int t = i / H, k = i - t * H;
       const float ang = a.times[(size_t)t * B + b] / a.tscale[k];
-      float* row = a.z + ((size_t)t * B + b) * a.ldz + F * 4;
+      float* row = a.z + ((size_t)tk.row0 + (size_t)t * tk.rstride) * a.ldz + F * 4;
       row[k] = sinf(ang);
       row[H + k] = cosf(ang);
     }
@@ -597,14 +649,29 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   float* Rp = reinterpret_cast<float*>(Eh);              // dR_u partial sums [groups][F*4], aliases the E planes (dead by then)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool grpB = __builtin_amdgcn_readfirstlane(wave) >= NWAVE / 2;   // scalar: the group branches are real branches
-  const int b = blockIdx.x;
+  const Tok tk = tok_of(a);
+  const int b = tk.b, sb = tk.sb, L = tk.L;
   const int T = a.T, F = a.F, K = a.K, B = a.B;
   const int nct = a.nct;
   const int Fd = F * 4;
   const int kq = K / 4;
+  // dz is exactly zero at the padded steps t >= L (rd_plan.h) -- on the padded layout L == T.  So dZ2's columns >= 4L are zero:
+  // the product dZ2 W2 stops after the last 32-column chunk with a live step, and rd_msgpass_dw.hip reads dZ2's column blocks
+  // (64 columns = 16 steps) only for samples that are live there -- only those blocks are exported.
+  // dX feeds dR_u alone, through the gate X > 0, which is closed at every step >= lin (no observation): the wave whose
+  // column tile is past lin skips the dZ1 W1 product.
+  const int kclim2 = (4 * L + 31) >> 5;
+  const int lin = __builtin_amdgcn_readfirstlane(a.lin[sb]);
+  const bool liveX = 4 * __builtin_amdgcn_readfirstlane(wave) < lin;
+  int jlim = nct, jlimL = nct;
+  if (a.plan) {
+    jlim = min(nct, 4 * ((L + 15) >> 4));
+    const int Lg = __builtin_amdgcn_readfirstlane(a.plan[plan::len_base(B) + (sb / a.per) * a.per]);   // longest sample of this leftover tile
+    jlimL = min(nct, 4 * ((Lg + 15) >> 4));
+  }
 
   RD_STAMP(0);
-  if (b == 0 && tid < 192) {                                 // constant operand tiles [ones][zeros][zeros]: column 0 of the 16 is one
+  if (blockIdx.x == 0 && tid < 192) {                                 // constant operand tiles [ones][zeros][zeros]: column 0 of the 16 is one
     bf16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (tid < 64 && (tid & 15) == 0) ? (__bf16)1.f : (__bf16)0.f;
@@ -626,7 +693,8 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
     for (int u = 0; u < GU; ++u) {
       const int i = min(base + u * NTHR, total - 1);            // clamped duplicates rewrite the same cell
       cell_tf(i, F, gt[u], gfi[u]);
-      const float* p = a.dz + ((size_t)gt[u] * B + b) * a.ldz + 4 * gfi[u];
+      const int tl = min(gt[u], max(L - 1, 0));                 // padded steps: a legal address, zeroed at the consumer
+      const float* p = a.dz + ((size_t)tk.row0 + (size_t)tl * tk.rstride) * a.ldz + 4 * gfi[u];
       if (vec4) dd[u] = *reinterpret_cast<const float4*>(p);
       else dd[u] = make_float4(p[0], p[1], p[2], p[3]);
     }
@@ -637,7 +705,8 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
       pin(dd[u]);
       const int f = gfi[u], k = 4 * gt[u];
       const float sf = Ss[f];
-      const unsigned bits = (unsigned)M2[f * 16 + (k >> 4)] >> (k & 15);     // 4 consecutive gate bits (k % 4 == 0)
+      unsigned bits = (unsigned)M2[f * 16 + (k >> 4)] >> (k & 15);           // 4 consecutive gate bits (k % 4 == 0)
+      if (gt[u] >= L) bits = 0;
       *reinterpret_cast<float4*>(St + f * LDS_F + k) =
           make_float4((bits & 1) ? dd[u].x * sf : 0.f, (bits & 2) ? dd[u].y * sf : 0.f, (bits & 4) ? dd[u].z * sf : 0.f,
                       (bits & 8) ? dd[u].w * sf : 0.f);
@@ -645,8 +714,8 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   };
   uint4 mw = make_uint4(0, 0, 0, 0);
   if (tid < 4 * F)                                           // threads [0,2F): M1 rows, [2F,4F): M2 rows
-    mw = tid < 2 * F ? reinterpret_cast<const uint4*>(a.m1 + (size_t)b * F * 16)[tid]
-                     : reinterpret_cast<const uint4*>(a.m2 + (size_t)b * F * 16)[tid - 2 * F];
+    mw = tid < 2 * F ? reinterpret_cast<const uint4*>(a.m1 + (size_t)sb * F * 16)[tid]
+                     : reinterpret_cast<const uint4*>(a.m2 + (size_t)sb * F * 16)[tid - 2 * F];
   float sfv = 0.f;
   if (tid >= NTHR - 64 && tid - (NTHR - 64) < F) sfv = a.ssum[tid - (NTHR - 64)];      // last wave: ssum -> LDS
   gather_issue(tid);
@@ -691,30 +760,30 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
 #pragma unroll
     for (int u = 0; u < XU; ++u) {
       const int t = min(tb + u * TG, T - 1);
-      xb[u] = a.mx[((size_t)b * T + t) * F + rf];
+      xb[u] = a.mx[((size_t)sb * T + t) * F + rf];
       svv[u] = a.src[((size_t)t * B + b) * (2 * F) + rf];
     }
   };
   f32x4 acc[NJ][RT];
   zero_acc<RT>(acc);
   if (grpB) {
-    tstore_stage(St, a.tpD2, a, b, tid);
-    tzero_uncovered(a.tpD2, a, b, tid);
-    tzero_uncovered(a.tpD1, a, b, tid);
+    tstore_stage(St, a.tpD2, a, sb, tid, jlim, jlimL);
+    tzero_uncovered(a.tpD2, a, sb, tid);
+    tzero_uncovered(a.tpD1, a, sb, tid);
   }
-  mma_steps<RT, 0, NKC / 2>(acc, Dh, Dl, pw, lane);
+  mma_steps<RT, 0, NKC / 2>(acc, Dh, Dl, pw, lane, kclim2);
   __builtin_amdgcn_sched_barrier(0);
-  load_panel_kc<0, NKC / 2>(pw, wtiles(a, 0, 1), nct, wave, lane);     // W1^T, first half of the reduction
+  if (liveX) load_panel_kc<0, NKC / 2>(pw, wtiles(a, 0, 1), nct, wave, lane);     // W1^T, first half of the reduction
   __builtin_amdgcn_sched_barrier(0);
-  mma_steps<RT, NKC / 2, NKC>(acc, Dh, Dl, pw, lane);
+  mma_steps<RT, NKC / 2, NKC>(acc, Dh, Dl, pw, lane, kclim2);
   RD_STAMP(4);
-  load_panel_kc<NKC / 2, NKC>(pw, wtiles(a, 0, 1), nct, wave, lane);
+  if (liveX) load_panel_kc<NKC / 2, NKC>(pw, wtiles(a, 0, 1), nct, wave, lane);
   if (ract) ru_issue(rtg);
   RD_STAMP(14);
   if (!grpB) {
-    tstore_stage(St, a.tpD2, a, b, tid);
-    tzero_uncovered(a.tpD2, a, b, tid);
-    tzero_uncovered(a.tpD1, a, b, tid);
+    tstore_stage(St, a.tpD2, a, sb, tid, jlim, jlimL);
+    tzero_uncovered(a.tpD2, a, sb, tid);
+    tzero_uncovered(a.tpD1, a, sb, tid);
   }
   if (ALIAS) lds_barrier();                                    // staging tile lives in the E planes: everybody must be done with it
   if (ALIAS) { zero_plane_pads(Eh, ROWS, ROWS, ROWS, K, tid); zero_plane_pads(El, ROWS, ROWS, ROWS, K, tid); }
@@ -734,23 +803,23 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
           hh[r] = (__bf16)g; ll[r] = (__bf16)(g - (float)hh[r]);
           store_split_pair(Eh, El, row, n, lane, hh[r], ll[r]);
         }
-        tstore_acc(a.tpD1, a, b, j, rt, lane, hh, ll);
+        tstore_acc(a.tpD1, a, sb, j, rt, lane, hh, ll);
       }
     }
   }
   RD_STAMP(5);
   lds_barrier();
   RD_STAMP(15);
-  tstore_leftover_planes(Eh, El, a.tpD1, a, b, tid);
+  tstore_leftover_planes(Eh, El, a.tpD1, a, sb, tid);
 
-  // ---- dX = dZ1 W1 -> fp32 staging (the D planes are dead) -------------------------------------
+  // ---- dX = dZ1 W1 -> fp32 staging (the D planes are dead); observed column tiles only -----------
   zero_acc<RT>(acc);
-  mma_panel<RT>(acc, Eh, El, pw, lane);
+  if (liveX) mma_panel<RT>(acc, Eh, El, pw, lane);
   RD_STAMP(6);
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
     const int j = wave + NWAVE * jj;
-    if (j < nct) {
+    if (j < nct && 4 * j < lin) {
       const int n = 16 * j + (lane & 15);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -771,7 +840,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
       for (int u = 0; u < XU; ++u) {
         const int t = tb + u * TG;
         pin(xb[u]); pin(svv[u]);
-        if (t < T) {
+        if (t < lin) {                                          // lin <= T; beyond it the gate is closed and the staging tile unwritten
           const float sv = svv[u] * keep;
           const float4 dx = *reinterpret_cast<const float4*>(Sx + rf * LDS_F + 4 * t);
           s.x += (xb[u] & 1) ? dx.x * sv : 0.f; s.y += (xb[u] & 2) ? dx.y * sv : 0.f;
@@ -787,7 +856,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   for (int i = tid; i < Fd; i += NTHR) {
     float v = 0.f;
     for (int g = 0; g < TG; ++g) v += Rp[g * Fd + i];
-    a.rupart[(size_t)b * Fd + i] = v;
+    a.rupart[(size_t)sb * Fd + i] = v;
   }
   RD_STAMP(9);
 }
@@ -841,6 +910,7 @@ int fused_msgpass_fwd(const k1::Layout& L, const float* src, const float* R_u, c
   a.tpX = (__bf16*)tpX; a.tpY1 = (__bf16*)tpY1; a.m1 = (uint16_t*)m1; a.m2 = (uint16_t*)m2; a.mx = (uint8_t*)mx;
   a.z = z; a.ldz = ldz;
   a.p_drop = p_drop; a.seed = seed; a.seed_cell = seed_cell(); a.stamps = g_stamps;
+  a.plan = token_plan(); a.lin = reinterpret_cast<int*>(reinterpret_cast<char*>(mx) + k1::lin_offset(L.B, L.T, L.F));
   switch (L.RT) {
     case 1: return launch_fused<1>(a, false, st);
     case 2: return launch_fused<2>(a, false, st);
@@ -858,6 +928,8 @@ int fused_msgpass_bwd(const k1::Layout& L, const float* src, const float* ssum, 
   a.m1 = (uint16_t*)const_cast<void*>(m1); a.m2 = (uint16_t*)const_cast<void*>(m2); a.mx = (uint8_t*)const_cast<void*>(mx);
   a.dz = dz; a.ldz = ldz; a.tpD1 = (__bf16*)tpD1; a.tpD2 = (__bf16*)tpD2; a.ones = (__bf16*)ones; a.rupart = rupart;
   a.p_drop = p_drop; a.stamps = g_stamps;
+  a.plan = token_plan();
+  a.lin = reinterpret_cast<int*>(reinterpret_cast<char*>(const_cast<void*>(mx)) + k1::lin_offset(L.B, L.T, L.F));
   switch (L.RT) {
     case 1: return launch_fused<1>(a, true, st);
     case 2: return launch_fused<2>(a, true, st);

@@ -53,6 +53,9 @@ struct RowGemmArgs {
   // [workgroup][2K].  Same arithmetic and lane <-> column assignment as k_ln_bwd_v (rd_temporal.hip), which it replaces
   // together with the write + re-read of its second output.
   const float *lnb_dy, *lnb_s, *lnb_stats, *lnb_g; float *lnb_ds, *lnb_part; float lnb_p; uint32_t lnb_site; uint64_t lnb_seed;
+  // Live row count on the device (token plan, rd_plan.h: plan[0]) or null.  The grid is sized for the padded M; a workgroup
+  // whose rows are all beyond *mlive exits (after zeroing its LayerNorm partial), the one that straddles it treats the rest as the tail.
+  const int32_t* mlive;
 };
 
 // one weight matrix -> hi/lo planes; transpose != 0 writes split(W^T): rows k, cols n
@@ -129,6 +132,14 @@ __global__ __launch_bounds__(64 * WV) void k_rowgemm(RowGemmArgs a) {
   const int m0 = blockIdx.x * RG_ROWS;
   const int ntiles = (a.N + 15) >> 4;
   const int nrounds = (ntiles + RG_WAVES * RG_NJ - 1) / (RG_WAVES * RG_NJ);
+  if (a.mlive) {                                     // uniform: scalar load
+    a.M = min(a.M, __builtin_amdgcn_readfirstlane(*a.mlive));
+    if (m0 >= a.M) {
+      if constexpr (LNB)
+        for (int i = tid; i < 2 * a.K; i += RG_THR) a.lnb_part[(long)blockIdx.x * 2 * a.K + i] = 0.f;
+      return;
+    }
+  }
 
   RGSTAMP(0);
   uint64_t seed = a.drop_seed;
@@ -470,7 +481,10 @@ extern "C" int rd_set_rowgemm_rows32(int32_t mask) {   // tuning knob, see inclu
 // tiles per 32-row chunk) to `tiles`; one-shot.
 static thread_local void* g_export = nullptr;
 void rowgemm_export_next(void* tiles) { g_export = tiles; }
-static void take_export(RowGemmArgs& a) { a.xt = (__bf16*)g_export; a.xt_nct = (a.K + 15) / 16; g_export = nullptr; }
+// device pointer to the live row count of the following launches (sticky until reset to null by the caller)
+static thread_local const int32_t* g_mlive = nullptr;
+void rowgemm_set_mlive(const int32_t* p) { g_mlive = p; }
+static void take_export(RowGemmArgs& a) { a.xt = (__bf16*)g_export; a.xt_nct = (a.K + 15) / 16; g_export = nullptr; a.mlive = g_mlive; }
 
 // s = residual + dropout(A Wp^T + bias) -> s_out;  y = LayerNorm(s) g + b;  stats[m] = (mean, rstd).  N <= 256, N % 4 == 0,
 // all row strides N.  Same values as launch_rowgemm(.. -> o) followed by the add+LayerNorm kernel.

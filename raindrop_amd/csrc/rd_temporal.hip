@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "rd_common.h"
+#include "rd_plan.h"
 #include "rd_rng.h"
 
 namespace rd {
@@ -33,8 +34,9 @@ size_t tile_wgrad_part_floats(int N, int K);
 bool tile_wgrad_ok(int N, int K);
 struct TileColsumJob { const float* x; int M, N, n1; float *out1, *out2; };
 int launch_tile_wgrad(long M, int njobs, const TileWgradJob* jobs, const void* ones, int ncs, const TileColsumJob* cs,
-                      hipStream_t st);
+                      hipStream_t st, const int32_t* s32);
 void rowgemm_export_next(void* tiles);
+void rowgemm_set_mlive(const int32_t* p);
 bool rowgemm_lnb_ok(int N, int K);
 int rowgemm_lnb_part_rows(long M);
 int launch_rowgemm_lnb(long M, int N, int K, const float* dy, const float* s, const float* stats, const float* g, float* ds_out,
@@ -98,8 +100,22 @@ struct AttnArgs {
   int T, B, D, H, hd;
   float scale, p_drop; uint64_t seed; uint32_t site; const uint64_t* seed_cell;
   unsigned long long* stamps;   // debug only (tools/attn_timing.py)
+  const int32_t* plan;          // token plan (rd_plan.h) or null; honoured by the single-tile split-bf16 kernels (k_attn_*_one_b16w)
 };
 static unsigned long long* g_attn_stamps = nullptr;
+
+// Where the rows of one sample live.  Padded layout: [T,B,*] tensors, row of step t = t*B + b, key validity from the mask.
+// Token plan: workgroup index b is a RANK, its rows are the contiguous block off[b] .. off[b] + len[b]; steps >= len do
+// not exist (as keys they are what the mask would have removed; as queries nothing reads them).
+struct AttnRows { long row0, rstep; int Tv; };
+__device__ __forceinline__ AttnRows attn_rows(const AttnArgs& a, int b) {
+  AttnRows r;
+  if (a.plan) {
+    r.row0 = __builtin_amdgcn_readfirstlane(a.plan[plan::off_base() + b]); r.rstep = 1;
+    r.Tv = __builtin_amdgcn_readfirstlane(a.plan[plan::len_base(a.B) + b]);
+  } else { r.row0 = b; r.rstep = a.B; r.Tv = a.T; }
+  return r;
+}
 #define ASTAMP(i)                                                                                         \
   do {                                                                                                    \
     if (a.stamps && blockIdx.x < 8 && threadIdx.x == 0) a.stamps[blockIdx.x * 16 + (i)] = clock64();      \
@@ -955,30 +971,35 @@ __global__ __launch_bounds__(512) void k_attn_fwd_one_b16w(AttnArgs a, int one) 
   float* sms = mxs + 2 * TS;                                                       // [2][64] partial row sums
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wq = wave & 3, wh = wave >> 2, lt = tid & 255;
   const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
-  const long rs = (long)a.B * 3 * a.D;
-  const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
+  const AttnRows ar = attn_rows(a, b);
+  const int Tv = ar.Tv;
+  const long rs = ar.rstep * 3 * a.D, ro = ar.rstep * a.D;
+  const float* qb = a.qkv + ar.row0 * 3 * a.D + h * a.hd;
   const bool vec = head_vec_ok(a.hd, rs, a.D, qb, nullptr, nullptr);
   uint64_t seedv = a.seed;
   uint8_t mb[2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) mb[j] = a.mask[(long)b * a.T + min(16 * (2 * wh + j) + (lane & 15), a.T - 1)];
+  for (int j = 0; j < 2; ++j) {
+    const int key = min(16 * (2 * wh + j) + (lane & 15), a.T - 1);
+    mb[j] = a.plan ? (uint8_t)(key >= Tv) : a.mask[(long)b * a.T + key];
+  }
   if (a.p_drop > 0.f && a.seed_cell) seedv += load_uniform_u64(a.seed_cell);
   if (wh == 0) {
     HeadRegs<NTH> qv, kv;
     if (vec) {
-      head_load_t<NTH, true>(qv, qb, rs, 0, a.T, a.hd, lt);
-      head_load_t<NTH, true>(kv, qb + a.D, rs, 0, a.T, a.hd, lt);
+      head_load_t<NTH, true>(qv, qb, rs, 0, Tv, a.hd, lt);
+      head_load_t<NTH, true>(kv, qb + a.D, rs, 0, Tv, a.hd, lt);
     } else {
-      head_load_t<NTH, false>(qv, qb, rs, 0, a.T, a.hd, lt);
-      head_load_t<NTH, false>(kv, qb + a.D, rs, 0, a.T, a.hd, lt);
+      head_load_t<NTH, false>(qv, qb, rs, 0, Tv, a.hd, lt);
+      head_load_t<NTH, false>(kv, qb + a.D, rs, 0, Tv, a.hd, lt);
     }
     __builtin_amdgcn_sched_barrier(0);
     head_store_b16<NTH>(qv, Qh, Ql, LDB, HDP, lt);
     head_store_b16<NTH>(kv, Kh, Kl, LDB, HDP, lt);
   } else {
     HeadRegs<NTH> vv;
-    if (vec) head_load_t<NTH, true>(vv, qb + 2 * a.D, rs, 0, a.T, a.hd, lt);
-    else head_load_t<NTH, false>(vv, qb + 2 * a.D, rs, 0, a.T, a.hd, lt);
+    if (vec) head_load_t<NTH, true>(vv, qb + 2 * a.D, rs, 0, Tv, a.hd, lt);
+    else head_load_t<NTH, false>(vv, qb + 2 * a.D, rs, 0, Tv, a.hd, lt);
     __builtin_amdgcn_sched_barrier(0);
     head_store_b16<NTH>(vv, Vh, Vl, LDB, HDP, lt);
   }
@@ -1041,12 +1062,12 @@ __global__ __launch_bounds__(512) void k_attn_fwd_one_b16w(AttnArgs a, int one) 
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int q = row0 + r;
-    if (q >= a.T) continue;
+    if (q >= Tv) continue;
     const float inv = 1.0f / l_i[r];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const int c = 16 * (t0 + j) + (lane & 15);
-      if (t0 + j < NTH && c < a.hd) a.out[((long)q * a.B + b) * a.D + h * a.hd + c] = o[j][r] * inv;
+      if (t0 + j < NTH && c < a.hd) a.out[ar.row0 * a.D + (long)q * ro + h * a.hd + c] = o[j][r] * inv;
     }
     if (wh == 0 && (lane & 15) == 0) a.lse[(long)bh * a.T + q] = m_i[r] + logf(l_i[r]);
   }
@@ -1076,26 +1097,31 @@ __global__ __launch_bounds__(512) void k_attn_bwd_one_b16w(AttnArgs a, int one) 
   float* dl_s = lse_s + TS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wq = wave & 3, wh = wave >> 2, lt = tid & 255;
   const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
-  const long rs = (long)a.B * 3 * a.D, ro = (long)a.B * a.D;
-  const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
-  const float* dob = a.dout + (long)b * a.D + h * a.hd;
-  const float* ob = a.out + (long)b * a.D + h * a.hd;
+  const AttnRows ar = attn_rows(a, b);
+  const int Tv = ar.Tv;
+  const long rs = ar.rstep * 3 * a.D, ro = ar.rstep * a.D;
+  const float* qb = a.qkv + ar.row0 * 3 * a.D + h * a.hd;
+  const float* dob = a.dout + ar.row0 * a.D + h * a.hd;
+  const float* ob = a.out + ar.row0 * a.D + h * a.hd;
   const bool vec = head_vec_ok(a.hd, rs, ro, qb, dob, ob);
   uint64_t seedv = a.seed;
   uint8_t mb[2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) mb[j] = a.mask[(long)b * a.T + min(16 * (2 * wh + j) + (lane & 15), a.T - 1)];
+  for (int j = 0; j < 2; ++j) {
+    const int key = min(16 * (2 * wh + j) + (lane & 15), a.T - 1);
+    mb[j] = a.plan ? (uint8_t)(key >= Tv) : a.mask[(long)b * a.T + key];
+  }
   if (a.p_drop > 0.f && a.seed_cell) seedv += load_uniform_u64(a.seed_cell);
   if (wh == 0) {                                      // wave-uniform
     HeadRegs<NTH> qv, kv, vv;
     if (vec) {
-      head_load_t<NTH, true>(qv, qb, rs, 0, a.T, a.hd, lt);
-      head_load_t<NTH, true>(kv, qb + a.D, rs, 0, a.T, a.hd, lt);
-      head_load_t<NTH, true>(vv, qb + 2 * a.D, rs, 0, a.T, a.hd, lt);
+      head_load_t<NTH, true>(qv, qb, rs, 0, Tv, a.hd, lt);
+      head_load_t<NTH, true>(kv, qb + a.D, rs, 0, Tv, a.hd, lt);
+      head_load_t<NTH, true>(vv, qb + 2 * a.D, rs, 0, Tv, a.hd, lt);
     } else {
-      head_load_t<NTH, false>(qv, qb, rs, 0, a.T, a.hd, lt);
-      head_load_t<NTH, false>(kv, qb + a.D, rs, 0, a.T, a.hd, lt);
-      head_load_t<NTH, false>(vv, qb + 2 * a.D, rs, 0, a.T, a.hd, lt);
+      head_load_t<NTH, false>(qv, qb, rs, 0, Tv, a.hd, lt);
+      head_load_t<NTH, false>(kv, qb + a.D, rs, 0, Tv, a.hd, lt);
+      head_load_t<NTH, false>(vv, qb + 2 * a.D, rs, 0, Tv, a.hd, lt);
     }
     __builtin_amdgcn_sched_barrier(0);
     head_store_b16<NTH>(qv, Qh, Ql, LDB, HDP, lt);
@@ -1104,14 +1130,14 @@ __global__ __launch_bounds__(512) void k_attn_bwd_one_b16w(AttnArgs a, int one) 
   } else {
     HeadRegs<NTH> dov, ov;
     if (vec) {
-      head_load_t<NTH, true>(dov, dob, ro, 0, a.T, a.hd, lt);
-      head_load_t<NTH, true>(ov, ob, ro, 0, a.T, a.hd, lt);
+      head_load_t<NTH, true>(dov, dob, ro, 0, Tv, a.hd, lt);
+      head_load_t<NTH, true>(ov, ob, ro, 0, Tv, a.hd, lt);
     } else {
-      head_load_t<NTH, false>(dov, dob, ro, 0, a.T, a.hd, lt);
-      head_load_t<NTH, false>(ov, ob, ro, 0, a.T, a.hd, lt);
+      head_load_t<NTH, false>(dov, dob, ro, 0, Tv, a.hd, lt);
+      head_load_t<NTH, false>(ov, ob, ro, 0, Tv, a.hd, lt);
     }
     const int r = lt >> 2;
-    const float l = r < a.T ? a.lse[(long)bh * a.T + r] : 0.f;
+    const float l = r < Tv ? a.lse[(long)bh * a.T + r] : 0.f;
     __builtin_amdgcn_sched_barrier(0);
     head_mask<NTH>(ov);
     head_mask<NTH>(dov);
@@ -1138,7 +1164,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_one_b16w(AttnArgs a, int one) 
     for (int r = 0; r < 4; ++r) {
       const int row = wq * 16 + 4 * (lane >> 4) + r;
       pm[r] = 0.f; ds[r] = 0.f;
-      if (!dead && row < a.T) {
+      if (!dead && row < Tv) {
         const float p = __expf(s[j][r] * a.scale - lse_s[row]);
         pm[r] = p * k4[r];
         ds[r] = p * (dp[j][r] * k4[r] - dl_s[row]) * a.scale;
@@ -1158,8 +1184,8 @@ __global__ __launch_bounds__(512) void k_attn_bwd_one_b16w(AttnArgs a, int one) 
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int t = wq * 16 + 4 * (lane >> 4) + r;
-    if (t >= a.T) continue;
-    float* row = a.dqkv + ((long)t * a.B + b) * 3 * a.D + h * a.hd;
+    if (t >= Tv) continue;
+    float* row = a.dqkv + ar.row0 * 3 * a.D + (long)t * rs + h * a.hd;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const int c = 16 * (t0 + j) + (lane & 15);
@@ -1181,7 +1207,7 @@ int launch_attn_b16(const AttnArgs& a_in, int which, hipStream_t st) {
   if (which == 0) {
     const size_t lds = (size_t)(6 * TS * LDB + (LDB >= LDT ? 0 : 2 * TS * LDT)) * sizeof(__bf16);
     static const bool widef = [] { const char* e = getenv("RD_ATTN_FWD_W8"); return !(e && atoi(e) == 0); }();
-    if (widef) {
+    if (widef || a.plan) {
       const size_t ldsw = lds + 4 * TS * sizeof(float);
       RD_LDS_ATTR((k_attn_fwd_one_b16w<NTH>), ldsw);
       hipLaunchKernelGGL(k_attn_fwd_one_b16w<NTH>, dim3(a.B * a.H), dim3(512), ldsw, st, a, one);
@@ -1193,7 +1219,7 @@ int launch_attn_b16(const AttnArgs& a_in, int which, hipStream_t st) {
   }
   const size_t lds = (size_t)(8 * TS * LDB + 4 * TS * LDT) * sizeof(__bf16) + 2 * TS * sizeof(float);
   static const bool wide = [] { const char* e = getenv("RD_ATTN_BWD_W8"); return !(e && atoi(e) == 0); }();
-  if (wide) {
+  if (wide || a.plan) {
     RD_LDS_ATTR((k_attn_bwd_one_b16w<NTH>), lds);
     hipLaunchKernelGGL(k_attn_bwd_one_b16w<NTH>, dim3(a.B * a.H), dim3(512), lds, st, a, one);
     return check_launch("k_attn_bwd_one_b16w");
@@ -1341,6 +1367,8 @@ int attn_big_bwd(const AttnArgs& a, const float* P, const float* PD, float* dS, 
 }
 
 int dispatch_attn(const AttnArgs& a, int which, hipStream_t st) {
+  if (a.plan && !((which == 0 || which == 3) && attn_b16_ok(a)))
+    return fail(RD_EUNSUPPORTED, "token plan: only the single-tile split-bf16 attention (T <= 64, head_dim <= 96, bf16 modes) reads it");
   if ((which == 0 || which == 3) && attn_b16_ok(a)) {
     switch (cdiv(a.hd, 16)) {
       case 1: return launch_attn_b16<1>(a, which, st);
@@ -1976,6 +2004,10 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
   const bool rg = rowgemm_ok(3 * e.D, e.D, e.D, 3 * e.D) && rowgemm_ok(e.D, e.D, e.D, e.D) &&
                   rowgemm_ok(e.nhid, e.D, e.D, e.nhid) && rowgemm_ok(e.D, e.nhid, e.nhid, e.D);
   const bool tw = rg && tile_path(e) && !aux().ok;
+  // token plan (rd_plan.h): x, y and every saved / scratch tensor hold the live rows only, in plan order
+  const int32_t* tp = token_plan();
+  RD_REQUIRE(!tp || (tw && !attn_big(e)), "token plan: this shape / mode does not run on the row-block + tile-stream path");
+  struct MliveScope { MliveScope(const int32_t* p) { rowgemm_set_mlive(p); } ~MliveScope() { rowgemm_set_mlive(nullptr); } } mscope(tp);
   if (rg) {
     if (!prepared && (rc = enc_prepare(e, w, v, tw, st))) return rc;
     if (tw) rowgemm_export_next(v.xt[0]);
@@ -1986,11 +2018,13 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
   a.qkv = v.qkv; a.mask = mask; a.out = v.attn; a.lse = v.lse;
   a.T = e.T; a.B = e.B; a.D = e.D; a.H = e.H; a.hd = e.Hd;
   a.scale = 1.0f / sqrtf((float)e.Hd); a.p_drop = p_drop; a.seed = seed; a.site = SITE_ATTN_PROB + L; a.seed_cell = seed_cell();
+  a.plan = tp;
   if (attn_big(e)) { if ((rc = attn_big_fwd(a, v.pbig, v.pdbig, st))) return rc; }
   else if ((rc = dispatch_attn(a, 0, st))) return rc;
   // out-projection / second FFN layer with the residual add + LayerNorm in their epilogue (a workgroup owns complete rows)
   static const bool ln_fuse_env = [] { const char* e = getenv("RD_LN_FUSE"); return !(e && atoi(e) == 0); }();
   const bool lnf1 = rg && ln_fuse_env && rowgemm_ln_ok(e.D, e.D), lnf2 = rg && ln_fuse_env && rowgemm_ln_ok(e.D, e.nhid);
+  RD_REQUIRE(!tp || (lnf1 && lnf2), "token plan: needs the LayerNorm-epilogue path (RD_LN_FUSE)");
   if (tw) rowgemm_export_next(v.xt[1]);
   if (lnf1) {
     if ((rc = launch_rowgemm_ln(e.M, e.D, e.D, v.attn, v.pl[1][0], w->out_proj_b, x, w->norm1_w, w->norm1_b, v.s1, v.x1, v.st1,
@@ -2047,10 +2081,14 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   // gradients run as one streaming launch at the end of the layer (rd_tile_wgrad.hip), instead of four split-K GEMMs;
   // its reduce launch also column-sums the two LayerNorm partial matrices
   const bool tw = rg && tile_path(e) && !ax.ok;
+  const int32_t* tp = token_plan();
+  RD_REQUIRE(!tp || (tw && !attn_big(e)), "token plan: this shape / mode does not run on the row-block + tile-stream path");
+  struct MliveScope { MliveScope(const int32_t* p) { rowgemm_set_mlive(p); } ~MliveScope() { rowgemm_set_mlive(nullptr); } } mscope(tp);
   // lnf: the LayerNorm backward runs as the PROLOGUE of the input-gradient product that consumes its output (its second
   // output, the dropout-masked gradient, is only ever that product's A operand and -- as row tiles -- the weight gradient's)
   static const bool lnb_env = [] { const char* v = getenv("RD_LNB_FUSE"); return !(v && atoi(v) == 0); }();
   const bool lnf = tw && lnb_env && rowgemm_lnb_ok(e.nhid, e.D) && rowgemm_lnb_ok(e.D, e.D);
+  RD_REQUIRE(!tp || lnf, "token plan: needs the LayerNorm-backward prologue path (RD_LNB_FUSE)");
   const int lnrows = lnf ? rowgemm_lnb_part_rows(e.M) : lnb;
   // ---- LayerNorm 2:  ds2 (residual path), df = ds2 o mask(ffn out) -------------------------------
   if (!lnf && (rc = launch_ln_bwd(dy, v.s2, v.st2, w->norm2_w, ws.ds2, ws.df, ws.lnpart, (int)e.M, e.D, p_drop, seed,
@@ -2097,6 +2135,7 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   a.qkv = v.qkv; a.mask = mask; a.out = v.attn; a.lse = v.lse; a.dout = ws.da; a.dqkv = ws.dqkv; a.delta = ws.delta;
   a.T = e.T; a.B = e.B; a.D = e.D; a.H = e.H; a.hd = e.Hd;
   a.scale = 1.0f / sqrtf((float)e.Hd); a.p_drop = p_drop; a.seed = seed; a.site = SITE_ATTN_PROB + L; a.seed_cell = seed_cell();
+  a.plan = tp;
   if (attn_big(e)) {
     if ((rc = attn_big_bwd(a, v.pbig, v.pdbig, ws.dsbig, st))) return rc;
   } else if (e.T <= TS) {
@@ -2124,7 +2163,7 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
         {ws.dt[2], v.xt[1], ws.twpart[2], g->out_proj_w, g->out_proj_b, e.D, e.D}};       // dout^T attn
     const TileColsumJob cs[2] = {{ws.lnpart, lnrows, 2 * e.D, e.D, g->norm2_w, g->norm2_b},
                                  {ws.lnpart1, lnrows, 2 * e.D, e.D, g->norm1_w, g->norm1_b}};
-    return launch_tile_wgrad(e.M, 4, jobs, v.ones, 2, cs, st);
+    return launch_tile_wgrad(e.M, 4, jobs, v.ones, 2, cs, st, tp ? tp + plan::I_S32 : nullptr);
   }
   if (ax.ok && (rc = chain(sw, st, ax.ev[4]))) return rc;                        // join: the caller's stream owns every result
   return rc;

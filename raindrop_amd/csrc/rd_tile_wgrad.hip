@@ -39,7 +39,8 @@ struct TwProb {
 };
 // column sums riding on the reduce launch: the LayerNorm dgamma | dbeta partials of the layer ([M rows][N], out1 = first n1 sums)
 struct TwColsum { const float* x; int M, N, n1; float *out1, *out2; };
-struct TwArgs { TwProb p[4]; int n, S; const __bf16* ones; TwColsum cs[2]; int ncs, nblk_w; };
+struct TwArgs { TwProb p[4]; int n, S; const __bf16* ones; TwColsum cs[2]; int ncs, nblk_w;
+                const int32_t* s32; };             // device count of live 32-row chunks (token plan, rd_plan.h: plan[1]) or null
 
 struct Frag { bf16x8 ah[TW_NA], al[TW_NA], bh[TW_NB], bl[TW_NB]; };
 
@@ -54,7 +55,8 @@ __global__ __launch_bounds__(TW_THR) void k_twg(TwArgs a) {
   if (mi >= P.nmem) return;
   const int bn = mi / P.nbk, bk = mi - bn * P.nbk;
   const int nctA = P.nctA, nctB = P.nctB;
-  const int ntile = a.S > sl ? (a.S - sl + TW_SLICES - 1) / TW_SLICES : 0;    // chunks of this slice: sl, sl + 8, ...
+  const int S = a.s32 ? min(a.S, __builtin_amdgcn_readfirstlane(*a.s32)) : a.S;   // chunks beyond the live rows hold nothing (never exported)
+  const int ntile = S > sl ? (S - sl + TW_SLICES - 1) / TW_SLICES : 0;        // chunks of this slice: sl, sl + 8, ...
 
   // operand tile pointers of chunk 0 (+ lane offset) and their per-chunk strides.  The B column tile with index nctB is
   // the constant "ones" tile (stride 0).  Tiles beyond an operand's range map to a valid tile; their products are
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(TW_THR) void k_twg(TwArgs a) {
   const __bf16* zt = a.ones + TILE + lane * 8;                        // [ones hi][zeros][zeros]
   auto load = [&](Frag& f, int i) {
     const bool ghost = i >= nst;
-    const size_t s = (size_t)(ghost ? sl : sl + TW_SLICES * (wave + 4 * i));
+    const size_t s = (size_t)(ghost ? 0 : sl + TW_SLICES * (wave + 4 * i));
 #pragma unroll
     for (int t = 0; t < TW_NA; ++t) {
       const __bf16* qa = ghost ? zt : pa[t] + s * stepA;
@@ -228,10 +230,10 @@ struct TileWgradJob { const void *tA, *tB; float* part; float *dW, *db; int N, K
 // (x [M rows][N] contiguous -> out1[0..n1), out2[0..N-n1)) carried by the reduce launch.
 struct TileColsumJob { const float* x; int M, N, n1; float *out1, *out2; };
 int launch_tile_wgrad(long M, int njobs, const TileWgradJob* jobs, const void* ones, int ncs, const TileColsumJob* cs,
-                      hipStream_t st) {
+                      hipStream_t st, const int32_t* s32) {
   if (njobs < 1 || njobs > 4) return fail(RD_EINVAL, "tile_wgrad: 1..4 jobs");
   TwArgs a{};
-  a.n = njobs; a.S = cdiv((int)M, 32); a.ones = (const __bf16*)ones;
+  a.n = njobs; a.S = cdiv((int)M, 32); a.ones = (const __bf16*)ones; a.s32 = s32;
   int wg = 0, q = 0;
   for (int i = 0; i < njobs; ++i) {
     TwProb& P = a.p[i];

@@ -33,11 +33,15 @@ def _p(t):
 
 
 class TrainStep:
-    def __init__(self, model, flat, batch, p_drop=None, use_graph=True, seed=1234, autotune=True):
+    def __init__(self, model, flat, batch, p_drop=None, use_graph=True, seed=1234, autotune=True, token_plan=None):
         """model: raindrop_amd.models_rd.Raindrop_v2 on a ROCm device; flat: FlatGradAllReduce over the
         live parameters (its buffer receives the gradients); batch: dict(src, static, times, lengths, y)
-        of device tensors that are REUSED every step (copy new data into them)."""
+        of device tensors that are REUSED every step (copy new data into them).
+        token_plan: store and process only the live (sample, step) rows (include/raindrop_hip.h "token plan": the padding mask of
+        code/models_rd.py:298-299 applied as a layout; same logits, loss and gradients).  None = environment RD_TOKEN_PLAN
+        (default on) where the shape supports it."""
         self.model, self.flat, self.batch = model, flat, batch
+        self._want_plan = (os.environ.get("RD_TOKEN_PLAN", "1") != "0") if token_plan is None else bool(token_plan)
         self.autotune, self.tuned_rows32, self.tuned_waves16 = bool(autotune), None, None
         # MEASURED (same box, hipGraph step): 0.683 ms/step without, 0.702 with the side branch -- the two small launches cost less
         # on the critical path than the cross-stream edges and the contention with the sensor stage; off unless RD_SIDE_PREPARE=1
@@ -64,6 +68,10 @@ class TrainStep:
         self.G = gview
         self._alloc()
         self.seed_cell = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        # token plan: the step's fast paths only (fused message passing, row-block encoder, fused head)
+        self.plan = None
+        if self._want_plan and self.head_fused and self._plan_supported():
+            self.plan = torch.zeros(max(int(self.lib.rd_token_plan_bytes(self.sp)) // 4, 64), dtype=torch.int32, device=self.dev)
         self._ptrs = self._param_ptrs()                          # the captured graph / cached structs hold these addresses
         self.graph = None
         if use_graph:
@@ -96,21 +104,35 @@ class TrainStep:
     def _param_ptrs(self):
         return tuple(p.data_ptr() for p in self.P.values()) + tuple(g.data_ptr() for g in self.G.values())
 
+    def _plan_supported(self):
+        """Shapes whose whole step runs on the kernels that read a token plan (the P19 envelope, split-bf16 arithmetic)."""
+        m = self.model
+        K = self.T * m.d_ob
+        hd = self.D // m.nhead
+        return (self.lib.rd_get_precision() == 1 and m.d_ob == 4 and m.d_inp <= 64 and K <= 240 and K % 16 == 0
+                and self.T <= 64 and hd <= 96 and (self.D + 31) // 32 == 5 and (m.nhid + 31) // 32 == 9
+                and os.environ.get("RD_K1_FUSED", "1") != "0" and os.environ.get("RD_ROWGEMM", "1") != "0"
+                and os.environ.get("RD_TILE_WGRAD", "1") != "0" and os.environ.get("RD_ATTN_B16", "1") != "0"
+                and os.environ.get("RD_LN_FUSE", "1") != "0" and os.environ.get("RD_LNB_FUSE", "1") != "0"
+                and os.environ.get("RD_ATTN_BIG", "0") == "0" and os.environ.get("RD_AUX_STREAM", "0") == "0")
+
     # ------------------------------------------------------------------------------------------
     def _alloc(self):
         lib, sp, dev, B, T, D = self.lib, self.sp, self.dev, self.B, self.T, self.D
         m = self.model
         f32 = dict(dtype=torch.float32, device=dev)
-        u8 = lambda n: torch.empty(max(int(n), 256), dtype=torch.uint8, device=dev)
-        self.z = torch.empty((T, B, D), **f32)
+        # zero-filled: with a token plan parts of these buffers are never written, and a ghost product (x 0) of an uninitialised
+        # NaN pattern would not be 0
+        u8 = lambda n: torch.zeros(max(int(n), 256), dtype=torch.uint8, device=dev)
+        self.z = torch.zeros((T, B, D), **f32)
         self.mask = torch.empty((B, T), dtype=torch.bool, device=dev)
         self.k1_saved = u8(lib.rd_msgpass_saved_bytes(sp))
         self.k1_ws = u8(lib.rd_msgpass_workspace_bytes(sp))
         self.nl = len(m.transformer_encoder.layers)
-        self.x = [self.z] + [torch.empty((T, B, D), **f32) for _ in range(self.nl)]
+        self.x = [self.z] + [torch.zeros((T, B, D), **f32) for _ in range(self.nl)]
         self.enc_saved = [u8(lib.rd_encoder_layer_saved_bytes(sp)) for _ in range(self.nl)]
         self.enc_ws = u8(lib.rd_encoder_layer_workspace_bytes(sp))
-        self.dx = [torch.empty((T, B, D), **f32) for _ in range(2)]        # ping-pong gradient buffers
+        self.dx = [torch.zeros((T, B, D), **f32) for _ in range(2)]        # ping-pong gradient buffers
         self.Fe = m.d_inp if m.static else 0
         self.feat = torch.empty((B, D + self.Fe), **f32)
         self.dfeat = torch.empty((B, D + self.Fe), **f32)
@@ -144,7 +166,9 @@ class TrainStep:
         B, T, D, Fe = self.B, self.T, self.D, self.Fe
         dh = D + Fe
         c = self._call
-        if self.p_drop > 0.0:
+        if self.plan is not None:                                          # lengths -> token plan (+ the seed bump: one launch)
+            c("rd_token_plan", sp, _p(b["lengths"]), _p(self.plan), _p(self.seed_cell) if self.p_drop > 0.0 else None, 1, st)
+        elif self.p_drop > 0.0:
             c("rd_seed_cell_advance", _p(self.seed_cell), 1, st)           # fresh masks per replay
         W1, b1 = P["ob_propagation.lin_value.weight"], P["ob_propagation.lin_value.bias"]
         W2, b2 = P["ob_propagation_layer2.lin_value.weight"], P["ob_propagation_layer2.lin_value.bias"]
@@ -232,10 +256,12 @@ class TrainStep:
         captured with, and nothing else in the process (an eager model, another TrainStep) ever sees this step's cell --
         dropping a TrainStep can no longer leave a dangling pointer behind."""
         _lib.call("rd_set_seed_cell", _p(self.seed_cell))
+        _lib.call("rd_set_token_plan", _p(self.plan))
         try:
             return fn()
         finally:
             _lib.call("rd_set_seed_cell", None)
+            _lib.call("rd_set_token_plan", None)
 
     def _capture(self):
         """Capture the step as one hipGraph.  With `autotune`, the graph is captured once per setting of the library's
