@@ -1,0 +1,671 @@
+// rd_encfuse.hip -- the row-local half of a post-norm encoder layer as ONE launch per direction.
+//
+// nn.TransformerEncoderLayer (torch/nn/modules/transformer.py:799-983, used at code/models_rd.py:235-237,358) is, apart from
+// the attention core, a chain of per-token operations:
+//   forward   attn -> out_proj -> +x, dropout, LayerNorm1 -> x1 -> linear1, ReLU, dropout -> h -> linear2 -> +x1, dropout,
+//             LayerNorm2 -> y
+//   backward  dy -> LayerNorm2' -> (df, ds2) -> linear2' (gated) -> du -> linear1' + ds2 -> dx1 -> LayerNorm1' -> (dout, ds1)
+//             -> out_proj' -> d attn
+// As separate row-block products (rd_rowgemm.hip) each link was its own launch: three forward, three backward, every one a
+// 15-20 us latency chain (load rows from HBM -> split -> multiply -> stage -> epilogue -> store) over ONE round of workgroups,
+// with the intermediate written to HBM and read back by the next.  Here a workgroup keeps its 32 token rows in LDS through the
+// whole chain: the rows are read once, only what the backward pass (or the attention core) needs is written, and the three
+// weight panels stream from L2 behind one another (the next panel is requested before the current epilogue starts).
+// Same arithmetic, same lane <-> element assignment, same Philox quads and same summation order as the kernels it replaces
+// (k_rowgemm<.., LN> / <.., LNB>): results are bit-identical to the unfused path.
+//
+// Envelope: ceil(D / 32) == 5 and ceil(nhid / 32) == 9 (P19: D = 152, nhid = 272), D % 4 == 0, nhid % 4 == 0, bf16 modes.
+#include "rd_common.h"
+#include "rd_rng.h"
+
+namespace rd {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int EF_ROWS = 32, EF_WV = 16, EF_THR = 64 * EF_WV, EF_RT = EF_ROWS / 16, EF_RPW = EF_ROWS / EF_WV;
+constexpr int KCD = 5, KCH = 9;                     // reduction steps of 32 for D and nhid
+constexpr int KPD = 32 * KCD, KPH = 32 * KCH;       // 160, 288
+constexpr int LDD = KPD + 8, LDH = KPH + 8;         // bf16 plane row strides (conflict-free ds_read_b128)
+constexpr int STG = KPH + 4;                        // fp32 stage row stride: all nhid <= 288 output columns of linear1 + pad
+constexpr int LDF = KPD + 4;                        // fp32 row copy stride (16-byte rows, 4 banks of skew per row)
+
+template <int KC, int NJ>
+struct Panel { bf16x8 h[NJ][KC], l[NJ][KC]; };
+
+// native operand tiles [tile j][kc][hi, lo][64 lanes][8] (k_wsplit, rd_rowgemm.hip): wave w takes tiles w, w + 16, ..
+template <int KC, int NJ>
+__device__ __forceinline__ void load_panel(Panel<KC, NJ>& p, const __bf16* __restrict__ Wt, int ntiles, int wave, int lane, int tile0 = 0) {
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) {
+    const int j = tile0 + wave + EF_WV * jj;
+    const __bf16* t = Wt + (size_t)(j < ntiles ? j : 0) * (KC * 2 * 512) + lane * 8;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      p.h[jj][kc] = *reinterpret_cast<const bf16x8*>(t + (kc * 2 + 0) * 512);
+      p.l[jj][kc] = *reinterpret_cast<const bf16x8*>(t + (kc * 2 + 1) * 512);
+    }
+  }
+}
+
+// reduction steps [KC0, KC1) of the wave's tile only (a long panel is requested in two halves to bound the registers in flight)
+template <int KC, int KC0, int KC1>
+__device__ __forceinline__ void load_panel_kc(Panel<KC, 1>& p, const __bf16* __restrict__ Wt, int ntiles, int wave, int lane) {
+  const __bf16* t = Wt + (size_t)(wave < ntiles ? wave : 0) * (KC * 2 * 512) + lane * 8;
+#pragma unroll
+  for (int kc = KC0; kc < KC1; ++kc) {
+    p.h[0][kc] = *reinterpret_cast<const bf16x8*>(t + (kc * 2 + 0) * 512);
+    p.l[0][kc] = *reinterpret_cast<const bf16x8*>(t + (kc * 2 + 1) * 512);
+  }
+}
+
+// acc[jj][rt] += A[rows 16 rt .., 32 kc ..] * panel^T, split-bf16 (lo*hi + hi*lo + hi*hi), A planes in LDS
+template <int KC, int NJ>
+__device__ __forceinline__ void mma(f32x4 (&acc)[NJ][EF_RT], const __bf16* Ah, const __bf16* Al, int lda, const Panel<KC, NJ>& p,
+                                    int lane, int one) {
+  const int aoff = (lane & 15) * lda + 8 * (lane >> 4);
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+    for (int rt = 0; rt < EF_RT; ++rt) acc[jj][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    bf16x8 ah[EF_RT], al[EF_RT];
+#pragma unroll
+    for (int rt = 0; rt < EF_RT; ++rt) {
+      ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * lda + aoff + kc * 32);
+      al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * lda + aoff + kc * 32);
+    }
+    if (!one) {
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+        for (int rt = 0; rt < EF_RT; ++rt) acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], p.h[jj][kc], acc[jj][rt], 0, 0, 0);
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+        for (int rt = 0; rt < EF_RT; ++rt) acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.l[jj][kc], acc[jj][rt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+      for (int rt = 0; rt < EF_RT; ++rt) acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.h[jj][kc], acc[jj][rt], 0, 0, 0);
+  }
+}
+
+// accumulators -> stage[row][16 tile + column]
+template <int NJ>
+__device__ __forceinline__ void to_stage(float* stage, const f32x4 (&acc)[NJ][EF_RT], int ntiles, int wave, int lane, int tile0 = 0) {
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) {
+    const int j = tile0 + wave + EF_WV * jj;
+    if (j < ntiles) {
+#pragma unroll
+      for (int rt = 0; rt < EF_RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stage[(rt * 16 + 4 * (lane >> 4) + r) * STG + j * 16 + (lane & 15)] = acc[jj][rt][r];
+    }
+  }
+}
+
+__device__ __forceinline__ void split_store4(__bf16* ph, __bf16* pl, const float4& v) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  bf16x4 h, l;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { h[q] = (__bf16)x[q]; l[q] = (__bf16)(x[q] - (float)h[q]); }
+  *reinterpret_cast<bf16x4*>(ph) = h;
+  *reinterpret_cast<bf16x4*>(pl) = l;
+}
+
+// split planes [32][lda] (complete, behind a barrier) -> row tiles [chunk m0/32][column tile j][hi, lo][64][8] of the
+// weight-gradient stream (rd_tile_wgrad.hip), by transposing LDS reads (rd_rowgemm.hip has the lane map)
+__device__ __forceinline__ void export_tiles(const __bf16* Ph, const __bf16* Pl, int lda, __bf16* xt, int nct, int m0, int wave, int lane) {
+  typedef short v4s __attribute__((ext_vector_type(4)));
+  typedef short v8s __attribute__((ext_vector_type(8)));
+  const int i16 = lane & 15, G = lane >> 4;
+  for (int t = wave; t < nct * 2; t += EF_WV) {
+    const int plane = t & 1, j = t >> 1;
+    const __bf16* src = (plane ? Pl : Ph) + (8 * G + (i16 >> 2)) * lda + 16 * j + 4 * (i16 & 3);
+    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(src));
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(src + 4 * lda));
+    const v8s o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    *reinterpret_cast<v8s*>(xt + (((size_t)(m0 / 32) * nct + j) * 2 + plane) * 512 + lane * 8) = o;
+  }
+}
+
+__device__ __forceinline__ float wsum(float v) { return wave_sum64_dpp(v); }
+
+struct PostFwdArgs {
+  const float* attn; const float* x;                // [M, D] each: attention output, layer input (residual of LayerNorm1)
+  const __bf16 *Wo, *W1, *W2;                       // operand tiles of out_proj [D,D], linear1 [H,D], linear2 [D,H]
+  const float *bo, *b1, *b2, *g1, *be1, *g2, *be2;
+  float *s1, *x1, *st1, *h, *s2, *y, *st2;          // saved pre-norm sums, normalised rows, (mean, rstd), FFN hidden, output
+  __bf16 *xt_attn, *xt_x1, *xt_h;                   // row tiles for the weight gradients (null: not wanted)
+  int M, D, H;
+  float p; uint64_t seed; uint32_t site_ao, site_fh, site_fo; const uint64_t* seed_cell;
+  const int32_t* mlive;
+  int one;
+  unsigned long long* stamps;                       // debug (tools/encfuse_timing.py): clock64 per phase, every wave of workgroup 0
+};
+static unsigned long long* g_ef_stamps = nullptr;
+#define EFSTAMP(i)                                                                                       \
+  do {                                                                                                   \
+    if (a.stamps && blockIdx.x == 0 && (threadIdx.x & 63) == 0) a.stamps[(threadIdx.x >> 6) * 16 + (i)] = clock64(); \
+  } while (0)
+
+// LayerNorm epilogue of one row held as 4 values per lane (columns 4 lane ..): sv = residual + dropout(t + bias);
+// writes the pre-norm sum, the normalised row and the statistics; returns the normalised quad.
+__device__ __forceinline__ float4 ln_row(float4 t, const float4& res, const float4& bs, const float4& gg, const float4& bb, bool cok, int N,
+                                         long m, int c, float p, float inv_keep, uint64_t seed, uint32_t site, float* s_out, float* y_out,
+                                         float* stats, int lane) {
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  t.x += bs.x; t.y += bs.y; t.z += bs.z; t.w += bs.w;
+  if (p > 0.f) {
+    const float4 u = uniform4(seed, site, ((uint64_t)m * N + c) >> 2);
+    t.x *= u.x >= p ? inv_keep : 0.f; t.y *= u.y >= p ? inv_keep : 0.f;
+    t.z *= u.z >= p ? inv_keep : 0.f; t.w *= u.w >= p ? inv_keep : 0.f;
+  }
+  const float4 sv = make_float4(res.x + t.x, res.y + t.y, res.z + t.z, res.w + t.w);   // 0 beyond N
+  if (cok) *reinterpret_cast<float4*>(s_out + m * N + c) = sv;
+  const float mean = wsum((sv.x + sv.y) + (sv.z + sv.w)) / N;
+  float4 d = make_float4(sv.x - mean, sv.y - mean, sv.z - mean, sv.w - mean);
+  if (!cok) d = zero4;
+  const float rstd = rsqrtf(wsum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) / N + 1e-5f);
+  float4 o = zero4;
+  if (cok) {
+    o = make_float4(d.x * rstd * gg.x + bb.x, d.y * rstd * gg.y + bb.y, d.z * rstd * gg.z + bb.z, d.w * rstd * gg.w + bb.w);
+    *reinterpret_cast<float4*>(y_out + m * N + c) = o;
+  }
+  if (lane == 0) { stats[2 * m] = mean; stats[2 * m + 1] = rstd; }
+  return o;
+}
+
+__global__ __launch_bounds__(EF_THR) void k_enc_post_fwd(PostFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
+  __bf16* Ah = reinterpret_cast<__bf16*>(esm);                 // [32][LDD]: attn, then x1
+  __bf16* Al = Ah + EF_ROWS * LDD;
+  __bf16* Hh = Al + EF_ROWS * LDD;                             // [32][LDH]: h
+  __bf16* Hl = Hh + EF_ROWS * LDH;
+  float* stage = reinterpret_cast<float*>(Hl + EF_ROWS * LDH); // [32][STG]
+  float* x1f = stage + EF_ROWS * STG;                          // [32][LDF]: x1 in fp32 (residual of LayerNorm2)
+  // per-column vectors [bo | g1 | be1 | b2 | g2 | be2] (KPD each) and b1 (KPH), zero padded: fetched ONCE, first thing, so that no
+  // epilogue has a global load of its own -- those queue behind the weight panel requested just before them (loads return in
+  // order) and made every epilogue wait for the whole next panel
+  float* cst = x1f + EF_ROWS * LDF;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * EF_ROWS;
+  int M = a.M;
+  if (a.mlive) M = min(M, __builtin_amdgcn_readfirstlane(*a.mlive));
+  if (m0 >= M) return;
+  const int D = a.D, H = a.H;
+  const int ntD = (D + 15) >> 4, ntH = (H + 15) >> 4;
+  uint64_t seed = a.seed;
+  const float inv_keep = 1.0f / (1.0f - a.p);
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  EFSTAMP(0);
+  {
+    const int i = tid;                                         // 6 * KPD + KPH = 1248 <= 2 * EF_THR
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int e = i + it * EF_THR;
+      if (e < 6 * KPD + KPH) {
+        const int vsel = e < 6 * KPD ? e / KPD : 6, col = e - vsel * KPD;
+        const float* src = vsel == 0 ? a.bo : vsel == 1 ? a.g1 : vsel == 2 ? a.be1 : vsel == 3 ? a.b2 : vsel == 4 ? a.g2 : vsel == 5 ? a.be2 : a.b1;
+        const int lim = vsel == 6 ? H : D;
+        float val = 0.f;
+        if (col < lim) val = src[col];
+        cst[e] = val;
+      }
+    }
+  }
+
+  // ---- attention rows -> split planes (zero padded to KPD columns, rows beyond M zero) ----
+  constexpr int kq = KPD / 4;
+  constexpr int NIT = (EF_ROWS * kq + EF_THR - 1) / EF_THR;
+  float4 v[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = tid + it * EF_THR;
+    const int r = i / kq, k = 4 * (i - r * kq);
+    v[it] = zero4;
+    if (r < EF_ROWS && m0 + r < M && k < D) v[it] = *reinterpret_cast<const float4*>(a.attn + (long)(m0 + r) * D + k);
+  }
+  // residual rows of LayerNorm1 and the per-column vectors of both LayerNorms: requested now, used much later
+  const int c = 4 * lane;
+  const bool cok = c < D;
+  Panel<KCD, 1> po;
+  load_panel<KCD, 1>(po, a.Wo, ntD, wave, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  if (a.seed_cell) seed += load_uniform_u64(a.seed_cell);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = tid + it * EF_THR;
+    const int r = i / kq, k = 4 * (i - r * kq);
+    if (r < EF_ROWS) split_store4(Ah + r * LDD + k, Al + r * LDD + k, v[it]);
+  }
+  EFSTAMP(1);
+  lds_barrier();
+  EFSTAMP(2);
+  if (a.xt_attn) export_tiles(Ah, Al, LDD, a.xt_attn, ntD, m0, wave, lane);
+
+  // ---- out_proj ----
+  {
+    f32x4 acc[1][EF_RT];
+    mma<KCD, 1>(acc, Ah, Al, LDD, po, lane, a.one);
+    to_stage<1>(stage, acc, ntD, wave, lane);
+  }
+  EFSTAMP(3);
+  float4 xr[EF_RPW];                                           // residual rows of LayerNorm1
+#pragma unroll
+  for (int q = 0; q < EF_RPW; ++q) {
+    const int m = m0 + wave + EF_WV * q;
+    xr[q] = zero4;
+    if (cok && m < M) xr[q] = *reinterpret_cast<const float4*>(a.x + (long)m * D + c);
+  }
+  lds_barrier();                                               // stage complete; every wave is done reading the attn planes
+  EFSTAMP(4);
+  Panel<KCD, 1> p1;                                            // linear1 (column tiles 0..15) streams in under the LayerNorm epilogue
+  load_panel<KCD, 1>(p1, a.W1, ntH, wave, lane);              // (requested BEHIND the barrier: issuing it blocks a wave for a while)
+  EFSTAMP(14);
+  // ---- + bias, dropout, + x, LayerNorm1 -> s1, x1 (global), x1 planes, x1 fp32 copy ----
+  {
+    float4 gg = zero4, bb = zero4, bs = zero4;
+    if (cok) {
+      bs = *reinterpret_cast<const float4*>(cst + c); gg = *reinterpret_cast<const float4*>(cst + KPD + c);
+      bb = *reinterpret_cast<const float4*>(cst + 2 * KPD + c);
+    }
+#pragma unroll
+    for (int q = 0; q < EF_RPW; ++q) {
+      const int rl = wave + EF_WV * q;
+      const long m = m0 + rl;
+      float4 o = zero4;
+      if (m < M) {                                             // wave-uniform
+        float4 t = zero4;
+        if (cok) t = *reinterpret_cast<const float4*>(stage + rl * STG + c);
+        o = ln_row(t, xr[q], bs, gg, bb, cok, D, m, c, a.p, inv_keep, seed, a.site_ao, a.s1, a.x1, a.st1, lane);
+      }
+      if (q == 0) EFSTAMP(15);
+      if (c < KPD) split_store4(Ah + rl * LDD + c, Al + rl * LDD + c, o);       // rows beyond M and pad columns: zeros
+      if (cok) *reinterpret_cast<float4*>(x1f + rl * LDF + c) = o;
+    }
+  }
+  EFSTAMP(5);
+  lds_barrier();
+  EFSTAMP(6);
+  if (a.xt_x1) export_tiles(Ah, Al, LDD, a.xt_x1, ntD, m0, wave, lane);
+
+  // ---- linear1, ReLU, dropout -> h (global fp32 + planes) ----
+  {
+    f32x4 acc[1][EF_RT];
+    mma<KCD, 1>(acc, Ah, Al, LDD, p1, lane, a.one);
+    to_stage<1>(stage, acc, ntH, wave, lane);
+    for (int t0 = EF_WV; t0 < ntH; t0 += EF_WV) {              // nhid > 256: the remaining column tiles (P19: tile 16, wave 0)
+      if (t0 + wave < ntH) {                                   // wave-uniform
+        load_panel<KCD, 1>(p1, a.W1, ntH, wave, lane, t0);
+        mma<KCD, 1>(acc, Ah, Al, LDD, p1, lane, a.one);
+        to_stage<1>(stage, acc, ntH, wave, lane, t0);
+      }
+    }
+  }
+  EFSTAMP(7);
+  lds_barrier();
+  EFSTAMP(8);
+  Panel<KCH, 1> p2;                                            // linear2 streams in under the epilogue
+  load_panel<KCH, 1>(p2, a.W2, ntD, wave, lane);
+  {
+    const int qpr = H >> 2;
+    constexpr int hq = KPH / 4;
+    for (int e = tid; e < EF_ROWS * hq; e += EF_THR) {
+      const int rl = e / hq, q = e - rl * hq;
+      const int m = m0 + rl, n = 4 * q;
+      float4 o = zero4;
+      if (m < M && q < qpr) {
+        const float4 bs = *reinterpret_cast<const float4*>(cst + 6 * KPD + n);
+        const float4 s4 = *reinterpret_cast<const float4*>(stage + rl * STG + n);
+        o = make_float4(fmaxf(s4.x + bs.x, 0.f), fmaxf(s4.y + bs.y, 0.f), fmaxf(s4.z + bs.z, 0.f), fmaxf(s4.w + bs.w, 0.f));
+        if (a.p > 0.f) {
+          const float4 u = uniform4(seed, a.site_fh, ((uint64_t)m * H + n) >> 2);
+          o.x = u.x >= a.p ? o.x * inv_keep : 0.f; o.y = u.y >= a.p ? o.y * inv_keep : 0.f;
+          o.z = u.z >= a.p ? o.z * inv_keep : 0.f; o.w = u.w >= a.p ? o.w * inv_keep : 0.f;
+        }
+        *reinterpret_cast<float4*>(a.h + (long)m * H + n) = o;
+      }
+      split_store4(Hh + rl * LDH + n, Hl + rl * LDH + n, o);
+    }
+  }
+  EFSTAMP(9);
+  lds_barrier();
+  EFSTAMP(10);
+  if (a.xt_h) export_tiles(Hh, Hl, LDH, a.xt_h, ntH, m0, wave, lane);
+
+  // ---- linear2 ----
+  {
+    f32x4 acc[1][EF_RT];
+    mma<KCH, 1>(acc, Hh, Hl, LDH, p2, lane, a.one);
+    to_stage<1>(stage, acc, ntD, wave, lane);
+  }
+  EFSTAMP(11);
+  lds_barrier();
+  EFSTAMP(12);
+  // ---- + bias, dropout, + x1, LayerNorm2 -> s2, y ----
+  {
+    float4 gg = zero4, bb = zero4, bs = zero4;
+    if (cok) {
+      bs = *reinterpret_cast<const float4*>(cst + 3 * KPD + c); gg = *reinterpret_cast<const float4*>(cst + 4 * KPD + c);
+      bb = *reinterpret_cast<const float4*>(cst + 5 * KPD + c);
+    }
+#pragma unroll
+    for (int q = 0; q < EF_RPW; ++q) {
+      const int rl = wave + EF_WV * q;
+      const long m = m0 + rl;
+      if (m >= M) continue;
+      float4 t = zero4, res = zero4;
+      if (cok) { t = *reinterpret_cast<const float4*>(stage + rl * STG + c); res = *reinterpret_cast<const float4*>(x1f + rl * LDF + c); }
+      ln_row(t, res, bs, gg, bb, cok, D, m, c, a.p, inv_keep, seed, a.site_fo, a.s2, a.y, a.st2, lane);
+    }
+  }
+  EFSTAMP(13);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward chain: dy -> LayerNorm2' -> linear2' (gated by h > 0) -> linear1' + ds2 -> LayerNorm1' -> out_proj' -> d attn
+// ------------------------------------------------------------------------------------------------
+struct PreBwdArgs {
+  const float* dy;                                  // [M, D] gradient of the layer output
+  const float *s2, *st2, *g2;                       // LayerNorm2: saved pre-norm sum, (mean, rstd), gamma
+  const float* h;                                   // [M, H] FFN hidden after ReLU and dropout (gate: h > 0)
+  const float *s1, *st1, *g1;                       // LayerNorm1
+  const __bf16 *W2t, *W1t, *Wot;                    // operand tiles of linear2^T [H x D red.], linear1^T [D x H red.], out_proj^T [D x D red.]
+  float *ds1, *da;                                  // [M, D]: gradient of the LayerNorm1 input (residual branch into dx), gradient of attn
+  float *part2, *part1;                             // [M/32][2D] dgamma | dbeta partials of LayerNorm2, LayerNorm1
+  __bf16 *xt_df, *xt_du, *xt_dout;                  // row tiles for the weight gradients
+  int M, D, H;
+  float p; uint64_t seed; uint32_t site_fo, site_ao; const uint64_t* seed_cell;
+  const int32_t* mlive;
+  int one;
+  unsigned long long* stamps;
+};
+
+// LayerNorm backward of this wave's EF_RPW rows (lane: columns 4 lane ..).  dyq / sq: the rows' dy and saved pre-norm quads (zero
+// beyond D or M).  Writes the unmasked gradient quads to ds_lds ([32][LDF], LDS) or ds_glob ([M][K]), the dropout-masked ones (what the next product consumes) as split
+// planes, and accumulates this wave's dgamma | dbeta partial into lnred[wave].  Same arithmetic as k_rowgemm<.., LNB> (rd_rowgemm.hip).
+__device__ __forceinline__ void lnb_rows(const float4 (&dyq)[EF_RPW], const float4 (&sq)[EF_RPW], const float (&mean_r)[EF_RPW],
+                                         const float (&rstd_r)[EF_RPW], const float4& gg, bool cok, int K, int m0, int M, int wave, int lane,
+                                         float p, float inv_keep, uint64_t seed, uint32_t site, float* ds_lds, float* ds_glob, __bf16* Ph,
+                                         __bf16* Pl, float* lnred) {
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int c = 4 * lane;
+  float4 ag = zero4, ab = zero4;
+#pragma unroll
+  for (int it = 0; it < EF_RPW; ++it) {
+    const int rl = wave * EF_RPW + it;
+    const long row = m0 + rl;
+    float4 dr = zero4;
+    if (row < M) {                                     // wave-uniform
+      const float mean = mean_r[it], rstd = rstd_r[it];
+      const float4 dv = dyq[it];
+      float4 xh = make_float4((sq[it].x - mean) * rstd, (sq[it].y - mean) * rstd, (sq[it].z - mean) * rstd, (sq[it].w - mean) * rstd);
+      if (!cok) xh = zero4;
+      const float4 dg = make_float4(dv.x * gg.x, dv.y * gg.y, dv.z * gg.z, dv.w * gg.w);
+      const float c1 = wsum((dg.x + dg.y) + (dg.z + dg.w)) / K;
+      const float c2 = wsum((dg.x * xh.x + dg.y * xh.y) + (dg.z * xh.z + dg.w * xh.w)) / K;
+      if (cok) {
+        const float4 v = make_float4(rstd * (dg.x - c1 - xh.x * c2), rstd * (dg.y - c1 - xh.y * c2),
+                                     rstd * (dg.z - c1 - xh.z * c2), rstd * (dg.w - c1 - xh.w * c2));
+        if (ds_lds) *reinterpret_cast<float4*>(ds_lds + rl * LDF + c) = v;         // uniform pointers: one of the two
+        if (ds_glob) *reinterpret_cast<float4*>(ds_glob + row * K + c) = v;
+        dr = v;
+        if (p > 0.f) {
+          const float4 u = uniform4(seed, site, ((uint64_t)row * K + c) >> 2);
+          dr.x *= u.x >= p ? inv_keep : 0.f; dr.y *= u.y >= p ? inv_keep : 0.f;
+          dr.z *= u.z >= p ? inv_keep : 0.f; dr.w *= u.w >= p ? inv_keep : 0.f;
+        }
+        ag.x += dv.x * xh.x; ag.y += dv.y * xh.y; ag.z += dv.z * xh.z; ag.w += dv.w * xh.w;
+        ab.x += dv.x; ab.y += dv.y; ab.z += dv.z; ab.w += dv.w;
+      }
+    }
+    if (c < KPD) split_store4(Ph + rl * LDD + c, Pl + rl * LDD + c, dr);
+  }
+  if (cok) {
+    *reinterpret_cast<float4*>(lnred + wave * 2 * KPD + c) = ag;
+    *reinterpret_cast<float4*>(lnred + wave * 2 * KPD + KPD + c) = ab;
+  }
+}
+
+__global__ __launch_bounds__(EF_THR) void k_enc_pre_bwd(PreBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
+  __bf16* Ah = reinterpret_cast<__bf16*>(esm);                 // [32][LDD]: df, then dout
+  __bf16* Al = Ah + EF_ROWS * LDD;
+  __bf16* Hh = Al + EF_ROWS * LDD;                             // [32][LDH]: du
+  __bf16* Hl = Hh + EF_ROWS * LDH;
+  float* stage = reinterpret_cast<float*>(Hl + EF_ROWS * LDH); // [32][STG]
+  float* ds2f = stage + EF_ROWS * STG;                         // [32][LDF]: gradient of the LayerNorm2 input (residual branch), fp32
+  float* lnred = ds2f + EF_ROWS * LDF;                         // [16 waves][2 KPD]
+  float* cst = lnred + EF_WV * 2 * KPD;                        // [g2 | g1] (KPD each, zero padded)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * EF_ROWS;
+  const int D = a.D, H = a.H;
+  int M = a.M;
+  if (a.mlive) M = min(M, __builtin_amdgcn_readfirstlane(*a.mlive));
+  if (m0 >= M) {                                               // no live row: the partial sums of this block are zero
+    for (int i = tid; i < 2 * D; i += EF_THR) { a.part2[(long)blockIdx.x * 2 * D + i] = 0.f; a.part1[(long)blockIdx.x * 2 * D + i] = 0.f; }
+    return;
+  }
+  const int ntD = (D + 15) >> 4, ntH = (H + 15) >> 4;
+  uint64_t seed = a.seed;
+  const float inv_keep = 1.0f / (1.0f - a.p);
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int c = 4 * lane;
+  const bool cok = c < D;
+  EFSTAMP(0);
+  if (tid < 2 * KPD) {
+    const int vsel = tid / KPD, col = tid - vsel * KPD;
+    float val = 0.f;
+    if (col < D) val = (vsel ? a.g1 : a.g2)[col];
+    cst[tid] = val;
+  }
+  // ---- rows of dy, s2 and their statistics (wave w: rows 2w, 2w+1; lane: 4 columns) ----
+  float4 dyq[EF_RPW], sq[EF_RPW]; float mean_r[EF_RPW], rstd_r[EF_RPW];
+#pragma unroll
+  for (int it = 0; it < EF_RPW; ++it) {
+    const long row = m0 + wave * EF_RPW + it;
+    const bool rok = row < M;
+    mean_r[it] = rok ? a.st2[2 * row] : 0.f; rstd_r[it] = rok ? a.st2[2 * row + 1] : 0.f;
+    dyq[it] = zero4; sq[it] = zero4;
+    if (rok && cok) {
+      sq[it] = *reinterpret_cast<const float4*>(a.s2 + row * D + c);
+      dyq[it] = *reinterpret_cast<const float4*>(a.dy + row * D + c);
+    }
+  }
+  Panel<KCD, 1> pw;
+  load_panel<KCD, 1>(pw, a.W2t, ntH, wave, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  if (a.seed_cell) seed += load_uniform_u64(a.seed_cell);
+  lds_barrier();                                               // cst visible
+  EFSTAMP(1);
+  {
+    float4 gg = zero4;
+    if (cok) gg = *reinterpret_cast<const float4*>(cst + c);
+    lnb_rows(dyq, sq, mean_r, rstd_r, gg, cok, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_fo, ds2f, nullptr, Ah, Al, lnred);
+  }
+  // the FFN hidden (gate: h > 0): thread -> quads e, e + 1024, e + 2048 of the [32][KPH / 4] grid; requested here, consumed behind
+  // the next product
+  constexpr int hq = KPH / 4;
+  constexpr int HIT = (EF_ROWS * hq + EF_THR - 1) / EF_THR;
+  float4 hv[HIT];
+#pragma unroll
+  for (int it = 0; it < HIT; ++it) {
+    const int e = tid + it * EF_THR;
+    const int rl = e / hq, q = e - rl * hq;
+    hv[it] = zero4;
+    if (rl < EF_ROWS && m0 + rl < M && 4 * q < H) hv[it] = *reinterpret_cast<const float4*>(a.h + (long)(m0 + rl) * H + 4 * q);
+  }
+  EFSTAMP(2);
+  lds_barrier();
+  EFSTAMP(3);
+  for (int i = tid; i < 2 * D; i += EF_THR) {                  // this block's dgamma | dbeta partial: the 16 waves in fixed order
+    const int col = i < D ? i : KPD + (i - D);
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < EF_WV; ++w) v += lnred[w * 2 * KPD + col];
+    a.part2[(long)blockIdx.x * 2 * D + i] = v;
+  }
+  if (a.xt_df) export_tiles(Ah, Al, LDD, a.xt_df, ntD, m0, wave, lane);
+  // ---- du = (df W2) gated by h > 0, * keep ----
+  {
+    f32x4 acc[1][EF_RT];
+    mma<KCD, 1>(acc, Ah, Al, LDD, pw, lane, a.one);
+    to_stage<1>(stage, acc, ntH, wave, lane);
+    for (int t0 = EF_WV; t0 < ntH; t0 += EF_WV) {
+      if (t0 + wave < ntH) {
+        load_panel<KCD, 1>(pw, a.W2t, ntH, wave, lane, t0);
+        mma<KCD, 1>(acc, Ah, Al, LDD, pw, lane, a.one);
+        to_stage<1>(stage, acc, ntH, wave, lane, t0);
+      }
+    }
+  }
+  EFSTAMP(4);
+  lds_barrier();                                               // (also: everybody is done with lnred)
+  EFSTAMP(5);
+  Panel<KCH, 1> p1;
+  load_panel_kc<KCH, 0, 5>(p1, a.W1t, ntD, wave, lane);       // first half of linear1^T's reduction; the rest behind the gate epilogue
+  {
+    const float ks = a.p > 0.f ? inv_keep : 1.0f;
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+      const int e = tid + it * EF_THR;
+      const int rl = e / hq, q = e - rl * hq;
+      if (rl < EF_ROWS) {
+        float4 o = zero4;
+        if (4 * q < H) {
+          const float4 s4 = *reinterpret_cast<const float4*>(stage + rl * STG + 4 * q);
+          o = make_float4(hv[it].x > 0.f ? s4.x * ks : 0.f, hv[it].y > 0.f ? s4.y * ks : 0.f, hv[it].z > 0.f ? s4.z * ks : 0.f,
+                          hv[it].w > 0.f ? s4.w * ks : 0.f);
+        }
+        split_store4(Hh + rl * LDH + 4 * q, Hl + rl * LDH + 4 * q, o);
+      }
+    }
+  }
+  // LayerNorm1's saved rows: requested here, consumed after the next product
+#pragma unroll
+  for (int it = 0; it < EF_RPW; ++it) {
+    const long row = m0 + wave * EF_RPW + it;
+    const bool rok = row < M;
+    mean_r[it] = rok ? a.st1[2 * row] : 0.f; rstd_r[it] = rok ? a.st1[2 * row + 1] : 0.f;
+    sq[it] = zero4;
+    if (rok && cok) sq[it] = *reinterpret_cast<const float4*>(a.s1 + row * D + c);
+  }
+  load_panel_kc<KCH, 5, KCH>(p1, a.W1t, ntD, wave, lane);
+  EFSTAMP(6);
+  lds_barrier();
+  EFSTAMP(7);
+  if (a.xt_du) export_tiles(Hh, Hl, LDH, a.xt_du, ntH, m0, wave, lane);
+  // ---- dx1 = du W1 + ds2 ----
+  {
+    f32x4 acc[1][EF_RT];
+    mma<KCH, 1>(acc, Hh, Hl, LDH, p1, lane, a.one);
+    to_stage<1>(stage, acc, ntD, wave, lane);
+  }
+  EFSTAMP(8);
+  lds_barrier();
+  EFSTAMP(9);
+  Panel<KCD, 1> po;
+  load_panel<KCD, 1>(po, a.Wot, ntD, wave, lane);
+  {
+#pragma unroll
+    for (int it = 0; it < EF_RPW; ++it) {
+      const int rl = wave * EF_RPW + it;
+      dyq[it] = zero4;
+      if (cok && m0 + rl < M) {
+        const float4 t = *reinterpret_cast<const float4*>(stage + rl * STG + c);
+        const float4 r = *reinterpret_cast<const float4*>(ds2f + rl * LDF + c);
+        dyq[it] = make_float4(t.x + r.x, t.y + r.y, t.z + r.z, t.w + r.w);
+      }
+    }
+    float4 gg = zero4;
+    if (cok) gg = *reinterpret_cast<const float4*>(cst + KPD + c);
+    lnb_rows(dyq, sq, mean_r, rstd_r, gg, cok, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_ao, nullptr, a.ds1, Ah, Al, lnred);
+  }
+  EFSTAMP(10);
+  lds_barrier();
+  EFSTAMP(11);
+  for (int i = tid; i < 2 * D; i += EF_THR) {
+    const int col = i < D ? i : KPD + (i - D);
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < EF_WV; ++w) v += lnred[w * 2 * KPD + col];
+    a.part1[(long)blockIdx.x * 2 * D + i] = v;
+  }
+  if (a.xt_dout) export_tiles(Ah, Al, LDD, a.xt_dout, ntD, m0, wave, lane);
+  // ---- d attn = dout Wo ----
+  {
+    f32x4 acc[1][EF_RT];
+    mma<KCD, 1>(acc, Ah, Al, LDD, po, lane, a.one);
+    to_stage<1>(stage, acc, ntD, wave, lane);
+  }
+  EFSTAMP(12);
+  lds_barrier();
+  EFSTAMP(13);
+  {
+    const int qpr = D >> 2;
+    for (int e = tid; e < EF_ROWS * qpr; e += EF_THR) {
+      const int rl = e / qpr, q = e - rl * qpr;
+      if (m0 + rl < M)
+        *reinterpret_cast<float4*>(a.da + (long)(m0 + rl) * D + 4 * q) = *reinterpret_cast<const float4*>(stage + rl * STG + 4 * q);
+    }
+  }
+  EFSTAMP(14);
+}
+
+constexpr size_t PRE_BWD_LDS = (size_t)2 * EF_ROWS * LDD * 2 + (size_t)2 * EF_ROWS * LDH * 2 + (size_t)EF_ROWS * STG * 4 + (size_t)EF_ROWS * LDF * 4 +
+                               (size_t)EF_WV * 2 * KPD * 4 + (size_t)2 * KPD * 4;
+
+constexpr size_t POST_FWD_LDS = (size_t)2 * EF_ROWS * LDD * 2 + (size_t)2 * EF_ROWS * LDH * 2 + (size_t)EF_ROWS * STG * 4 + (size_t)EF_ROWS * LDF * 4 +
+                                (size_t)(6 * KPD + KPH) * 4;
+
+}  // namespace
+
+extern "C" void rd_debug_set_encfuse_stamps(void* p) { g_ef_stamps = (unsigned long long*)p; }   // not part of the ABI
+
+bool encfuse_ok(int D, int H) {
+  static const bool enabled = [] { const char* e = getenv("RD_ENC_FUSE"); return !(e && atoi(e) == 0); }();
+  return enabled && precision() != RD_PREC_FP32 && (D + 31) / 32 == KCD && (H + 31) / 32 == KCH && (D % 4) == 0 && (H % 4) == 0;
+}
+
+int launch_enc_post_fwd(long M, int D, int H, const float* attn, const float* x, const void* Wo, const void* W1, const void* W2,
+                        const float* bo, const float* b1, const float* b2, const float* g1, const float* be1, const float* g2,
+                        const float* be2, float* s1, float* x1, float* st1, float* h, float* s2, float* y, float* st2,
+                        void* xt_attn, void* xt_x1, void* xt_h, float p, uint64_t seed, uint32_t site_ao, uint32_t site_fh,
+                        uint32_t site_fo, const int32_t* mlive, hipStream_t st) {
+  PostFwdArgs a{};
+  a.attn = attn; a.x = x; a.Wo = (const __bf16*)Wo; a.W1 = (const __bf16*)W1; a.W2 = (const __bf16*)W2;
+  a.bo = bo; a.b1 = b1; a.b2 = b2; a.g1 = g1; a.be1 = be1; a.g2 = g2; a.be2 = be2;
+  a.s1 = s1; a.x1 = x1; a.st1 = st1; a.h = h; a.s2 = s2; a.y = y; a.st2 = st2;
+  a.xt_attn = (__bf16*)xt_attn; a.xt_x1 = (__bf16*)xt_x1; a.xt_h = (__bf16*)xt_h;
+  a.M = (int)M; a.D = D; a.H = H; a.p = p; a.seed = seed; a.site_ao = site_ao; a.site_fh = site_fh; a.site_fo = site_fo;
+  a.seed_cell = seed_cell(); a.mlive = mlive; a.one = precision() == RD_PREC_BF16; a.stamps = g_ef_stamps;
+  RD_LDS_ATTR(k_enc_post_fwd, POST_FWD_LDS);
+  hipLaunchKernelGGL(k_enc_post_fwd, dim3(cdiv((int)M, EF_ROWS)), dim3(EF_THR), POST_FWD_LDS, st, a);
+  return check_launch("k_enc_post_fwd");
+}
+
+int encfuse_part_rows(long M) { return (int)((M + EF_ROWS - 1) / EF_ROWS); }
+
+int launch_enc_pre_bwd(long M, int D, int H, const float* dy, const float* s2, const float* st2, const float* g2, const float* h,
+                       const float* s1, const float* st1, const float* g1, const void* W2t, const void* W1t, const void* Wot,
+                       float* ds1, float* da, float* part2, float* part1, void* xt_df, void* xt_du, void* xt_dout, float p,
+                       uint64_t seed, uint32_t site_fo, uint32_t site_ao, const int32_t* mlive, hipStream_t st) {
+  PreBwdArgs a{};
+  a.dy = dy; a.s2 = s2; a.st2 = st2; a.g2 = g2; a.h = h; a.s1 = s1; a.st1 = st1; a.g1 = g1;
+  a.W2t = (const __bf16*)W2t; a.W1t = (const __bf16*)W1t; a.Wot = (const __bf16*)Wot;
+  a.ds1 = ds1; a.da = da; a.part2 = part2; a.part1 = part1;
+  a.xt_df = (__bf16*)xt_df; a.xt_du = (__bf16*)xt_du; a.xt_dout = (__bf16*)xt_dout;
+  a.M = (int)M; a.D = D; a.H = H; a.p = p; a.seed = seed; a.site_fo = site_fo; a.site_ao = site_ao;
+  a.seed_cell = seed_cell(); a.mlive = mlive; a.one = precision() == RD_PREC_BF16; a.stamps = g_ef_stamps;
+  RD_LDS_ATTR(k_enc_pre_bwd, PRE_BWD_LDS);
+  hipLaunchKernelGGL(k_enc_pre_bwd, dim3(cdiv((int)M, EF_ROWS)), dim3(EF_THR), PRE_BWD_LDS, st, a);
+  return check_launch("k_enc_pre_bwd");
+}
+
+}  // namespace rd

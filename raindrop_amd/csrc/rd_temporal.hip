@@ -37,6 +37,18 @@ int launch_tile_wgrad(long M, int njobs, const TileWgradJob* jobs, const void* o
                       hipStream_t st, const int32_t* s32);
 void rowgemm_export_next(void* tiles);
 void rowgemm_set_mlive(const int32_t* p);
+// row-local chains of the layer as one launch per direction (rd_encfuse.hip)
+bool encfuse_ok(int D, int H);
+int launch_enc_post_fwd(long M, int D, int H, const float* attn, const float* x, const void* Wo, const void* W1, const void* W2,
+                        const float* bo, const float* b1, const float* b2, const float* g1, const float* be1, const float* g2,
+                        const float* be2, float* s1, float* x1, float* st1, float* h, float* s2, float* y, float* st2,
+                        void* xt_attn, void* xt_x1, void* xt_h, float p, uint64_t seed, uint32_t site_ao, uint32_t site_fh,
+                        uint32_t site_fo, const int32_t* mlive, hipStream_t st);
+int encfuse_part_rows(long M);
+int launch_enc_pre_bwd(long M, int D, int H, const float* dy, const float* s2, const float* st2, const float* g2, const float* h,
+                       const float* s1, const float* st1, const float* g1, const void* W2t, const void* W1t, const void* Wot,
+                       float* ds1, float* da, float* part2, float* part1, void* xt_df, void* xt_du, void* xt_dout, float p,
+                       uint64_t seed, uint32_t site_fo, uint32_t site_ao, const int32_t* mlive, hipStream_t st);
 bool rowgemm_lnb_ok(int N, int K);
 int rowgemm_lnb_part_rows(long M);
 int launch_rowgemm_lnb(long M, int N, int K, const float* dy, const float* s, const float* stats, const float* g, float* ds_out,
@@ -2025,6 +2037,13 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
   static const bool ln_fuse_env = [] { const char* e = getenv("RD_LN_FUSE"); return !(e && atoi(e) == 0); }();
   const bool lnf1 = rg && ln_fuse_env && rowgemm_ln_ok(e.D, e.D), lnf2 = rg && ln_fuse_env && rowgemm_ln_ok(e.D, e.nhid);
   RD_REQUIRE(!tp || (lnf1 && lnf2), "token plan: needs the LayerNorm-epilogue path (RD_LN_FUSE)");
+  // out_proj + LayerNorm1 + linear1 + linear2 + LayerNorm2 as ONE launch (rd_encfuse.hip): same arithmetic as the three
+  // row-block launches below, the rows stay in LDS in between
+  if (lnf1 && lnf2 && encfuse_ok(e.D, e.nhid))
+    return launch_enc_post_fwd(e.M, e.D, e.nhid, v.attn, x, v.pl[1][0], v.pl[2][0], v.pl[3][0], w->out_proj_b, w->lin1_b, w->lin2_b,
+                               w->norm1_w, w->norm1_b, w->norm2_w, w->norm2_b, v.s1, v.x1, v.st1, v.h, v.s2, y, v.st2,
+                               tw ? v.xt[1] : nullptr, tw ? v.xt[2] : nullptr, tw ? v.xt[3] : nullptr, p_drop, seed,
+                               SITE_ATTN_OUT + L, SITE_FFN_HID + L, SITE_FFN_OUT + L, tp ? tp + plan::I_MLIVE : nullptr, st);
   if (tw) rowgemm_export_next(v.xt[1]);
   if (lnf1) {
     if ((rc = launch_rowgemm_ln(e.M, e.D, e.D, v.attn, v.pl[1][0], w->out_proj_b, x, w->norm1_w, w->norm1_b, v.s1, v.x1, v.st1,
@@ -2089,7 +2108,12 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   static const bool lnb_env = [] { const char* v = getenv("RD_LNB_FUSE"); return !(v && atoi(v) == 0); }();
   const bool lnf = tw && lnb_env && rowgemm_lnb_ok(e.nhid, e.D) && rowgemm_lnb_ok(e.D, e.D);
   RD_REQUIRE(!tp || lnf, "token plan: needs the LayerNorm-backward prologue path (RD_LNB_FUSE)");
-  const int lnrows = lnf ? rowgemm_lnb_part_rows(e.M) : lnb;
+  // the whole row-local chain (LayerNorm2' .. out_proj') as ONE launch (rd_encfuse.hip); same arithmetic as the three launches below
+  const bool fuse = lnf && encfuse_ok(e.D, e.nhid);
+  const int lnrows = fuse ? encfuse_part_rows(e.M) : (lnf ? rowgemm_lnb_part_rows(e.M) : lnb);
+  if (fuse && (rc = launch_enc_pre_bwd(e.M, e.D, e.nhid, dy, v.s2, v.st2, w->norm2_w, v.h, v.s1, v.st1, w->norm1_w, v.pl[5][0], v.pl[6][0],
+                                       v.pl[4][0], ws.ds1, ws.da, ws.lnpart, ws.lnpart1, ws.dt[0], ws.dt[1], ws.dt[2], p_drop, seed,
+                                       SITE_FFN_OUT + L, SITE_ATTN_OUT + L, tp ? tp + plan::I_MLIVE : nullptr, st))) return rc;
   // ---- LayerNorm 2:  ds2 (residual path), df = ds2 o mask(ffn out) -------------------------------
   if (!lnf && (rc = launch_ln_bwd(dy, v.s2, v.st2, w->norm2_w, ws.ds2, ws.df, ws.lnpart, (int)e.M, e.D, p_drop, seed,
                                   SITE_FFN_OUT + L, st))) return rc;
@@ -2098,7 +2122,8 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   // ---- FFN ---------------------------------------------------------------------------------------
   if (ax.ok && (rc = chain(st, sw, ax.ev[0]))) return rc;
   if (!tw && (rc = linear_bwd_w(e.M, e.D, e.nhid, ws.df, v.h, g->lin2_w, g->lin2_b, ws.splitk, ws.colsum, sw))) return rc;
-  if (rg) {                                                        // du = (df W2) gated by h>0, * keep
+  if (fuse) {
+  } else if (rg) {                                                 // du = (df W2) gated by h>0, * keep
     if (tw) rowgemm_export_next(ws.dt[0]);
     if (lnf) {
       if ((rc = launch_rowgemm_lnb(e.M, e.nhid, e.D, dy, v.s2, v.st2, w->norm2_w, ws.ds2, ws.lnpart, p_drop, seed, SITE_FFN_OUT + L,
@@ -2109,7 +2134,8 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
     return rc;
   if (ax.ok && (rc = chain(st, sw, ax.ev[1]))) return rc;
   if (!tw && (rc = linear_bwd_w(e.M, e.nhid, e.D, ws.du, v.x1, g->lin1_w, g->lin1_b, ws.splitk, ws.colsum, sw))) return rc;
-  if (rg) {
+  if (fuse) {
+  } else if (rg) {
     if (tw) rowgemm_export_next(ws.dt[1]);
     if ((rc = launch_rowgemm(e.M, e.D, e.nhid, ws.du, e.nhid, v.pl[6][0], v.pl[6][1], ws.dx1, e.D, nullptr, 0, nullptr, 0, 0.f,
                              ws.ds2, e.D, 0.f, 0, 0, st))) return rc;
@@ -2122,7 +2148,8 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   if (ax.ok && (rc = chain(st, sw, ax.ev[2]))) return rc;
   if (!tw && (rc = linear_bwd_w(e.M, e.D, e.D, ws.dout, v.attn, g->out_proj_w, g->out_proj_b, ws.splitk, ws.colsum, sw)))
     return rc;
-  if (rg) {
+  if (fuse) {
+  } else if (rg) {
     if (tw) rowgemm_export_next(ws.dt[2]);
     if (lnf) {
       if ((rc = launch_rowgemm_lnb(e.M, e.D, e.D, ws.dx1, v.s1, v.st1, w->norm1_w, ws.ds1, ws.lnpart1, p_drop, seed,
