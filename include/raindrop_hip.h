@@ -208,11 +208,9 @@ int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const float* x, const
                          void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes,
                          void* stream);
 /* Optional: the weight-dependent part of the forward (splitting the layer's matrices into matrix-core operand tiles inside
- * `saved`) as its own call, so that a caller can enqueue it EARLY on another stream -- it depends on the weights only --
- * and keep it off the critical path; then pass `layer | RD_LAYER_WEIGHTS_PREPARED` to rd_encoder_layer_fwd, which skips
- * that launch (the caller orders the two calls: event / stream wait).  raindrop_amd.step.TrainStep can do this
- * (RD_SIDE_PREPARE=1); in its hipGraph step the parallel branch measured 3 % SLOWER than the two serial launches, so
- * it is off by default there -- the entry point is for callers whose weights change less often than they run forward. */
+ * `saved`) as its own call, for callers whose weights change less often than they run forward (inference: prepare once per
+ * checkpoint); then pass `layer | RD_LAYER_WEIGHTS_PREPARED` to rd_encoder_layer_fwd, which skips that launch.  The caller
+ * orders the two calls (same stream, or an event). */
 #define RD_LAYER_WEIGHTS_PREPARED 0x10000
 int rd_encoder_layer_prepare(const rd_shape* s, const rd_encoder_weights* w, void* saved, size_t saved_bytes,
                              void* stream);
@@ -221,6 +219,16 @@ int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const float* x, const
                          const rd_encoder_weights* w, float p_drop, uint64_t seed, const void* saved,
                          size_t saved_bytes, const float* dy, float* dx, const rd_encoder_grads* g,
                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* The attention core of that layer alone (between in_proj and out_proj; torch F.multi_head_attention_forward as used at
+ * code/models_rd.py:235-237,358): qkv [T,B,3D] (q | k | v, heads side by side) -> out [T,B,D] and lse [B,H,T] (log-sum-exp of the
+ * scaled masked scores, consumed by the backward); backward dout [T,B,D] -> dqkv [T,B,3D] (delta_ws: B*H*T floats of scratch).
+ * Same kernels as inside rd_encoder_layer_fwd/bwd (head_dim <= 96).  Dropout on the probabilities with Philox site
+ * (attention, layer). */
+int rd_attention_fwd(const rd_shape* s, int32_t layer, const float* qkv, const uint8_t* mask, float p_drop, uint64_t seed,
+                     float* out, float* lse, void* stream);
+int rd_attention_bwd(const rd_shape* s, int32_t layer, const float* qkv, const uint8_t* mask, float p_drop, uint64_t seed,
+                     const float* out, const float* lse, const float* dout, float* dqkv, float* delta_ws, void* stream);
 
 /* code/models_rd.py:366-367,379: out[b, :D] = sum_t r[t,b,:] * (1 - mask[b,t]) / (lengths[b] + 1);
  * out has row stride ldo (so it can be the left block of the [agg | emb] head input). */

@@ -87,6 +87,10 @@ class Observation_progation(nn.Module):
         PRE-softmax weights [E,1] (:193)."""
         if isinstance(x, (tuple, list)):
             x = x[1]
+        if self.dropout > 0.0 and self.training:
+            # code/Ob_propagation.py:196 drops edge coefficients AFTER the softmax; the model never sets it (dropout=0., models_rd.py:243-247)
+            raise _lib.RaindropHipError("RD_EUNSUPPORTED: Observation_progation(dropout > 0) in training mode is not built "
+                                        "(the shipped model constructs the operator with dropout = 0)")
         if use_beta:
             return self._forward_beta(x, p_t, edge_index, edge_weights, return_attention_weights)
         if edge_weights is None:

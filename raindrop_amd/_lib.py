@@ -65,6 +65,8 @@ SIGNATURES = {
                                         _P, c_size_t, _P]),
     "rd_encoder_layer_bwd": (c_int32, [_SHP, c_int32, _P, _P, _ENC, c_float, ctypes.c_uint64, _P, c_size_t, _P, _P,
                                         _ENC, _P, c_size_t, _P]),
+    "rd_attention_fwd": (c_int32, [_SHP, c_int32, _P, _P, c_float, ctypes.c_uint64, _P, _P, _P]),
+    "rd_attention_bwd": (c_int32, [_SHP, c_int32, _P, _P, c_float, ctypes.c_uint64, _P, _P, _P, _P, _P, _P]),
     "rd_masked_mean_fwd": (c_int32, [_SHP, c_int32, _P, _P, _P, _P, c_int32, _P]),
     "rd_masked_mean_bwd": (c_int32, [_SHP, c_int32, _P, c_int32, _P, _P, _P, _P]),
     "rd_adam_step": (c_int32, [ctypes.c_int64, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float,

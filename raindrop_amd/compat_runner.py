@@ -61,7 +61,9 @@ def write_dataset(root, dataset, n_samples, seed=0):
         records = np.array([vals[i].astype(np.float64) for i in range(n_samples)], dtype=object)
         if records.ndim != 1:                                       # equal shapes collapse to 3-D: keep that form
             records = vals.astype(np.float64)
-        y = rng.integers(0, cfg["n_classes"], size=(n_samples, 1)).astype(np.float64)
+        # balanced labels: the script scores `roc_auc_score(one_hot(yval), ...)` (code/Raindrop.py:358), which needs every class
+        # present in every validation split
+        y = (rng.permutation(n_samples) % cfg["n_classes"]).reshape(n_samples, 1).astype(np.float64)
     else:
         records = np.empty(n_samples, dtype=object)
         for i in range(n_samples):

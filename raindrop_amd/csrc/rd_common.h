@@ -127,11 +127,6 @@ int launch_wgrad(long M, int N, int K, const float* dy, long lddy, const float* 
 // two weight gradients of identical shape in one launch pair (ws: 2 * wgrad_ws_floats floats)
 int launch_wgrad2(long M, int N, int K, const float* dyA, const float* xA, float* dWA, float* dbA,
                   const float* dyB, const float* xB, float* dWB, float* dbB, float* ws, hipStream_t st);
-// slab form (rd_wgrad.hip): operands read once, whole output per workgroup; used by launch_wgrad{,2} when it applies
-bool wgrad_slab_ok(long M, int N, int K);
-long wgrad_slab_ws_floats(long M, int N, int K);
-int launch_wgrad_slab(long M, int N, int K, const float* dy, long lddy, const float* x, long ldx, float* dW, float* db,
-                      const float* dy2, const float* x2, float* dW2, float* db2, float* ws, hipStream_t st);
 // sum `nsplit` partials [nsplit][rows*cols] in fixed order into out
 int launch_splitk_reduce(const float* part, int nsplit, long elems, float* out, hipStream_t st);
 // same with partials `stride` floats apart; elements [0,e1) go to out1, [e1, e1+e2) to out2

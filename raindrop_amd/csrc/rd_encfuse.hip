@@ -7,14 +7,22 @@
 //   backward  dy -> LayerNorm2' -> (df, ds2) -> linear2' (gated) -> du -> linear1' + ds2 -> dx1 -> LayerNorm1' -> (dout, ds1)
 //             -> out_proj' -> d attn
 // As separate row-block products (rd_rowgemm.hip) each link was its own launch: three forward, three backward, every one a
-// 15-20 us latency chain (load rows from HBM -> split -> multiply -> stage -> epilogue -> store) over ONE round of workgroups,
-// with the intermediate written to HBM and read back by the next.  Here a workgroup keeps its 32 token rows in LDS through the
-// whole chain: the rows are read once, only what the backward pass (or the attention core) needs is written, and the three
-// weight panels stream from L2 behind one another (the next panel is requested before the current epilogue starts).
-// Same arithmetic, same lane <-> element assignment, same Philox quads and same summation order as the kernels it replaces
-// (k_rowgemm<.., LN> / <.., LNB>): results are bit-identical to the unfused path.
+// 15-20 us chain (load rows -> split -> multiply -> stage -> epilogue -> store) over ONE round of workgroups, with the
+// intermediate written to HBM and read back by the next.  Here a workgroup keeps its token rows in LDS through the whole chain:
+// the rows are read once, only what the backward pass (or the attention core) needs is written, and the three weight panels
+// stream from L2 behind one another.  Same arithmetic, same lane <-> element assignment, same Philox quads and same summation
+// order as the kernels it replaces (k_rowgemm<.., LN> / <.., LNB>): results are bit-identical to the unfused path.
+//
+// Rows per workgroup.  A workgroup needs ~100-150 KB of LDS, so ONE fits a CU and a launch is a whole number of rounds over the
+// `ncu` CUs; these chains are latency-bound (a round costs ~20 us whether it carries 32 or 48 rows per workgroup), so the
+// kernels pick their block height ON THE DEVICE from the live row count: 32 rows while that gives at most one workgroup per CU,
+// 48 rows (three row tiles) when 32 would spill a few blocks into a second round (P19, B = 256: 8000-8500 live rows against
+// 32 x 256 = 8192 -- half of all batches).  The grid is sized for 32-row blocks of the padded row count; blocks beyond the live
+// rows exit at once.
 //
 // Envelope: ceil(D / 32) == 5 and ceil(nhid / 32) == 9 (P19: D = 152, nhid = 272), D % 4 == 0, nhid % 4 == 0, bf16 modes.
+#include <stdlib.h>
+
 #include "rd_common.h"
 #include "rd_rng.h"
 
@@ -24,89 +32,60 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int EF_ROWS = 32, EF_WV = 16, EF_THR = 64 * EF_WV, EF_RT = EF_ROWS / 16, EF_RPW = EF_ROWS / EF_WV;
-constexpr int KCD = 5, KCH = 9;                     // reduction steps of 32 for D and nhid
-constexpr int KPD = 32 * KCD, KPH = 32 * KCH;       // 160, 288
-constexpr int LDD = KPD + 8, LDH = KPH + 8;         // bf16 plane row strides (conflict-free ds_read_b128)
-constexpr int STG = KPH + 4;                        // fp32 stage row stride: all nhid <= 288 output columns of linear1 + pad
-constexpr int LDF = KPD + 4;                        // fp32 row copy stride (16-byte rows, 4 banks of skew per row)
+constexpr int EF_WV = 16, EF_THR = 64 * EF_WV;
+constexpr int EF_RTMAX = 3;                          // row tiles of the tall variant
+constexpr int KCD = 5, KCH = 9;                      // reduction steps of 32 for D and nhid
+constexpr int KPD = 32 * KCD, KPH = 32 * KCH;        // 160, 288
+constexpr int LDD = KPD + 8, LDH = KPH + 8;          // bf16 plane row strides (conflict-free ds_read_b128)
+constexpr int STG = KPH + 4;                         // fp32 stage row stride: all nhid <= 288 output columns of linear1 + pad
 
-template <int KC, int NJ>
-struct Panel { bf16x8 h[NJ][KC], l[NJ][KC]; };
+template <int KC>
+struct Panel { bf16x8 h[KC], l[KC]; };
 
-// native operand tiles [tile j][kc][hi, lo][64 lanes][8] (k_wsplit, rd_rowgemm.hip): wave w takes tiles w, w + 16, ..
-template <int KC, int NJ>
-__device__ __forceinline__ void load_panel(Panel<KC, NJ>& p, const __bf16* __restrict__ Wt, int ntiles, int wave, int lane, int tile0 = 0) {
-#pragma unroll
-  for (int jj = 0; jj < NJ; ++jj) {
-    const int j = tile0 + wave + EF_WV * jj;
-    const __bf16* t = Wt + (size_t)(j < ntiles ? j : 0) * (KC * 2 * 512) + lane * 8;
-#pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-      p.h[jj][kc] = *reinterpret_cast<const bf16x8*>(t + (kc * 2 + 0) * 512);
-      p.l[jj][kc] = *reinterpret_cast<const bf16x8*>(t + (kc * 2 + 1) * 512);
-    }
-  }
-}
-
-// reduction steps [KC0, KC1) of the wave's tile only (a long panel is requested in two halves to bound the registers in flight)
-template <int KC, int KC0, int KC1>
-__device__ __forceinline__ void load_panel_kc(Panel<KC, 1>& p, const __bf16* __restrict__ Wt, int ntiles, int wave, int lane) {
-  const __bf16* t = Wt + (size_t)(wave < ntiles ? wave : 0) * (KC * 2 * 512) + lane * 8;
+// native operand tiles [tile j][kc][hi, lo][64 lanes][8] (k_wsplit, rd_rowgemm.hip); reduction steps [KC0, KC1) of tile j
+// (a long panel is requested in two halves to bound the registers in flight)
+template <int KC, int KC0 = 0, int KC1 = KC>
+__device__ __forceinline__ void load_panel(Panel<KC>& p, const __bf16* __restrict__ Wt, int ntiles, int j, int lane) {
+  const __bf16* t = Wt + (size_t)(j < ntiles ? j : 0) * (KC * 2 * 512) + lane * 8;
 #pragma unroll
   for (int kc = KC0; kc < KC1; ++kc) {
-    p.h[0][kc] = *reinterpret_cast<const bf16x8*>(t + (kc * 2 + 0) * 512);
-    p.l[0][kc] = *reinterpret_cast<const bf16x8*>(t + (kc * 2 + 1) * 512);
+    p.h[kc] = *reinterpret_cast<const bf16x8*>(t + (kc * 2 + 0) * 512);
+    p.l[kc] = *reinterpret_cast<const bf16x8*>(t + (kc * 2 + 1) * 512);
   }
 }
 
-// acc[jj][rt] += A[rows 16 rt .., 32 kc ..] * panel^T, split-bf16 (lo*hi + hi*lo + hi*hi), A planes in LDS
-template <int KC, int NJ>
-__device__ __forceinline__ void mma(f32x4 (&acc)[NJ][EF_RT], const __bf16* Ah, const __bf16* Al, int lda, const Panel<KC, NJ>& p,
-                                    int lane, int one) {
+// acc[rt] = A[rows 16 rt .., :] * panel^T, split-bf16 (lo*hi + hi*lo + hi*hi), A planes in LDS
+template <int KC, int RT>
+__device__ __forceinline__ void mma(f32x4 (&acc)[RT], const __bf16* Ah, const __bf16* Al, int lda, const Panel<KC>& p, int lane, int one) {
   const int aoff = (lane & 15) * lda + 8 * (lane >> 4);
 #pragma unroll
-  for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-    for (int rt = 0; rt < EF_RT; ++rt) acc[jj][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc) {
-    bf16x8 ah[EF_RT], al[EF_RT];
+    bf16x8 ah[RT], al[RT];
 #pragma unroll
-    for (int rt = 0; rt < EF_RT; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * lda + aoff + kc * 32);
       al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * lda + aoff + kc * 32);
     }
     if (!one) {
 #pragma unroll
-      for (int jj = 0; jj < NJ; ++jj)
+      for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], p.h[kc], acc[rt], 0, 0, 0);
 #pragma unroll
-        for (int rt = 0; rt < EF_RT; ++rt) acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], p.h[jj][kc], acc[jj][rt], 0, 0, 0);
-#pragma unroll
-      for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-        for (int rt = 0; rt < EF_RT; ++rt) acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.l[jj][kc], acc[jj][rt], 0, 0, 0);
+      for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.l[kc], acc[rt], 0, 0, 0);
     }
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-      for (int rt = 0; rt < EF_RT; ++rt) acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.h[jj][kc], acc[jj][rt], 0, 0, 0);
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.h[kc], acc[rt], 0, 0, 0);
   }
 }
 
-// accumulators -> stage[row][16 tile + column]
-template <int NJ>
-__device__ __forceinline__ void to_stage(float* stage, const f32x4 (&acc)[NJ][EF_RT], int ntiles, int wave, int lane, int tile0 = 0) {
+// accumulators of column tile j -> stage[row][16 j + column]
+template <int RT>
+__device__ __forceinline__ void to_stage(float* stage, const f32x4 (&acc)[RT], int j, int lane) {
 #pragma unroll
-  for (int jj = 0; jj < NJ; ++jj) {
-    const int j = tile0 + wave + EF_WV * jj;
-    if (j < ntiles) {
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int rt = 0; rt < EF_RT; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) stage[(rt * 16 + 4 * (lane >> 4) + r) * STG + j * 16 + (lane & 15)] = acc[jj][rt][r];
-    }
-  }
+    for (int r = 0; r < 4; ++r) stage[(rt * 16 + 4 * (lane >> 4) + r) * STG + j * 16 + (lane & 15)] = acc[rt][r];
 }
 
 __device__ __forceinline__ void split_store4(__bf16* ph, __bf16* pl, const float4& v) {
@@ -118,41 +97,74 @@ __device__ __forceinline__ void split_store4(__bf16* ph, __bf16* pl, const float
   *reinterpret_cast<bf16x4*>(pl) = l;
 }
 
-// split planes [32][lda] (complete, behind a barrier) -> row tiles [chunk m0/32][column tile j][hi, lo][64][8] of the
-// weight-gradient stream (rd_tile_wgrad.hip), by transposing LDS reads (rd_rowgemm.hip has the lane map)
-__device__ __forceinline__ void export_tiles(const __bf16* Ph, const __bf16* Pl, int lda, __bf16* xt, int nct, int m0, int wave, int lane) {
+// split planes [16 RT][lda] (complete, behind a barrier) -> row tiles [chunk of 32 rows][column tile j][hi, lo][64][8] of the
+// weight-gradient stream (rd_tile_wgrad.hip).  A block may start in the middle of a chunk (48-row blocks), so the unit is a
+// 16-row group = lanes 32 half .. 32 half + 31 of a tile part.  ds_read_b64_tr_b16 (rd_rowgemm.hip has the lane map): in a
+// 16-lane group lane i passes the address of row i >> 2, columns 4 (i & 3) .. of a 4 x 16 block and receives column i; two reads
+// give lane (column i, group g) the rows 8 g .. 8 g + 7 of its column.  Lanes 0-31 work on the hi plane, 32-63 on the lo plane.
+template <int RT>
+__device__ __forceinline__ void export_tiles(const __bf16* Ph, const __bf16* Pl, int lda, __bf16* xt, int nct, int m0, int M, int wave,
+                                             int lane) {
   typedef short v4s __attribute__((ext_vector_type(4)));
   typedef short v8s __attribute__((ext_vector_type(8)));
-  const int i16 = lane & 15, G = lane >> 4;
-  for (int t = wave; t < nct * 2; t += EF_WV) {
-    const int plane = t & 1, j = t >> 1;
-    const __bf16* src = (plane ? Pl : Ph) + (8 * G + (i16 >> 2)) * lda + 16 * j + 4 * (i16 & 3);
+  const int i16 = lane & 15, g = (lane >> 4) & 1, plane = lane >> 5;
+  const int nchunk = (M + 31) >> 5;                    // chunks beyond the live rows are never read (and may not exist)
+  for (int t = wave; t < nct * RT; t += EF_WV) {
+    const int rt = t / nct, j = t - rt * nct;
+    const int grp = (m0 >> 4) + rt;                    // global 16-row group
+    if ((grp >> 1) >= nchunk) continue;
+    const __bf16* src = (plane ? Pl : Ph) + (16 * rt + 8 * g + (i16 >> 2)) * lda + 16 * j + 4 * (i16 & 3);
     const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(src));
     const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(src + 4 * lda));
     const v8s o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    *reinterpret_cast<v8s*>(xt + (((size_t)(m0 / 32) * nct + j) * 2 + plane) * 512 + lane * 8) = o;
+    const int slot = 32 * (grp & 1) + 16 * g + i16;    // lane slot inside the tile part
+    *reinterpret_cast<v8s*>(xt + (((size_t)(grp >> 1) * nct + j) * 2 + plane) * 512 + slot * 8) = o;
+  }
+}
+
+// A block without a live row still owns the 16-row groups it would have exported; where such a group falls into the last live
+// 32-row chunk (48-row blocks can end in the middle of one) the weight-gradient stream reads it: zeros, not last step's rows.
+template <int RT>
+__device__ __forceinline__ void zero_dead_groups(__bf16* xt, int nct, int m0, int M, int tid) {
+  if (!xt) return;
+  const int nchunk = (M + 31) >> 5;
+  for (int rt = 0; rt < RT; ++rt) {
+    const int grp = (m0 >> 4) + rt;
+    if ((grp >> 1) >= nchunk) continue;
+    // 32 lanes x 16 bytes per (column tile, plane): thread -> (j, plane, slot)
+    for (int i = tid; i < nct * 2 * 32; i += EF_THR) {
+      const int slot = i & 31, jp = i >> 5;
+      *reinterpret_cast<float4*>(xt + ((size_t)(grp >> 1) * nct * 2 + jp) * 512 + (32 * (grp & 1) + slot) * 8) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
 }
 
 __device__ __forceinline__ float wsum(float v) { return wave_sum64_dpp(v); }
 
+static unsigned long long* g_ef_stamps = nullptr;    // debug (tools/encfuse_timing.py): clock64 per phase, every wave of workgroup 0
+#define EFSTAMP(i)                                                                                       \
+  do {                                                                                                   \
+    if (a.stamps && blockIdx.x == 0 && (threadIdx.x & 63) == 0) a.stamps[(threadIdx.x >> 6) * 16 + (i)] = clock64(); \
+  } while (0)
+
+// block height for `M` live rows on `ncu` CUs: 2 row tiles unless that needs a second round and 3 do not
+__device__ __forceinline__ int pick_rt(int M, int ncu) { return (M > 32 * ncu && M <= 48 * ncu) ? 3 : 2; }
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
 struct PostFwdArgs {
   const float* attn; const float* x;                // [M, D] each: attention output, layer input (residual of LayerNorm1)
   const __bf16 *Wo, *W1, *W2;                       // operand tiles of out_proj [D,D], linear1 [H,D], linear2 [D,H]
   const float *bo, *b1, *b2, *g1, *be1, *g2, *be2;
   float *s1, *x1, *st1, *h, *s2, *y, *st2;          // saved pre-norm sums, normalised rows, (mean, rstd), FFN hidden, output
   __bf16 *xt_attn, *xt_x1, *xt_h;                   // row tiles for the weight gradients (null: not wanted)
-  int M, D, H;
+  int M, D, H, ncu;
   float p; uint64_t seed; uint32_t site_ao, site_fh, site_fo; const uint64_t* seed_cell;
   const int32_t* mlive;
   int one;
-  unsigned long long* stamps;                       // debug (tools/encfuse_timing.py): clock64 per phase, every wave of workgroup 0
+  unsigned long long* stamps;
 };
-static unsigned long long* g_ef_stamps = nullptr;
-#define EFSTAMP(i)                                                                                       \
-  do {                                                                                                   \
-    if (a.stamps && blockIdx.x == 0 && (threadIdx.x & 63) == 0) a.stamps[(threadIdx.x >> 6) * 16 + (i)] = clock64(); \
-  } while (0)
 
 // LayerNorm epilogue of one row held as 4 values per lane (columns 4 lane ..): sv = residual + dropout(t + bias);
 // writes the pre-norm sum, the normalised row and the statistics; returns the normalised quad.
@@ -181,94 +193,89 @@ __device__ __forceinline__ float4 ln_row(float4 t, const float4& res, const floa
   return o;
 }
 
-__global__ __launch_bounds__(EF_THR) void k_enc_post_fwd(PostFwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
-  __bf16* Ah = reinterpret_cast<__bf16*>(esm);                 // [32][LDD]: attn, then x1
-  __bf16* Al = Ah + EF_ROWS * LDD;
-  __bf16* Hh = Al + EF_ROWS * LDD;                             // [32][LDH]: h
-  __bf16* Hl = Hh + EF_ROWS * LDH;
-  float* stage = reinterpret_cast<float*>(Hl + EF_ROWS * LDH); // [32][STG]
-  float* x1f = stage + EF_ROWS * STG;                          // [32][LDF]: x1 in fp32 (residual of LayerNorm2)
+template <int RT>
+__device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned char* esm, int M) {
+  constexpr int ROWS = 16 * RT;
+  __bf16* Ah = reinterpret_cast<__bf16*>(esm);                 // [ROWS][LDD]: attn, then x1
+  __bf16* Al = Ah + ROWS * LDD;
+  __bf16* Hh = Al + ROWS * LDD;                                // [ROWS][LDH]: h
+  __bf16* Hl = Hh + ROWS * LDH;
+  float* stage = reinterpret_cast<float*>(Hl + ROWS * LDH);    // [ROWS][STG]
   // per-column vectors [bo | g1 | be1 | b2 | g2 | be2] (KPD each) and b1 (KPH), zero padded: fetched ONCE, first thing, so that no
-  // epilogue has a global load of its own -- those queue behind the weight panel requested just before them (loads return in
-  // order) and made every epilogue wait for the whole next panel
-  float* cst = x1f + EF_ROWS * LDF;
+  // epilogue has a global load of its own -- those queue behind the weight panel requested just before them (loads return in order)
+  float* cst = stage + ROWS * STG;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * EF_ROWS;
-  int M = a.M;
-  if (a.mlive) M = min(M, __builtin_amdgcn_readfirstlane(*a.mlive));
-  if (m0 >= M) return;
+  const int m0 = blockIdx.x * ROWS;
   const int D = a.D, H = a.H;
   const int ntD = (D + 15) >> 4, ntH = (H + 15) >> 4;
+  if (m0 >= M) {
+    zero_dead_groups<RT>(a.xt_attn, ntD, m0, M, tid); zero_dead_groups<RT>(a.xt_x1, ntD, m0, M, tid); zero_dead_groups<RT>(a.xt_h, ntH, m0, M, tid);
+    return;
+  }
   uint64_t seed = a.seed;
   const float inv_keep = 1.0f / (1.0f - a.p);
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   EFSTAMP(0);
-  {
-    const int i = tid;                                         // 6 * KPD + KPH = 1248 <= 2 * EF_THR
+  if (a.stamps && tid == 0) { a.stamps[256 + 2 * blockIdx.x] = wall_clock64(); a.stamps[256 + 2 * blockIdx.x + 1] = clock64(); }
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int e = i + it * EF_THR;
-      if (e < 6 * KPD + KPH) {
-        const int vsel = e < 6 * KPD ? e / KPD : 6, col = e - vsel * KPD;
-        const float* src = vsel == 0 ? a.bo : vsel == 1 ? a.g1 : vsel == 2 ? a.be1 : vsel == 3 ? a.b2 : vsel == 4 ? a.g2 : vsel == 5 ? a.be2 : a.b1;
-        const int lim = vsel == 6 ? H : D;
-        float val = 0.f;
-        if (col < lim) val = src[col];
-        cst[e] = val;
-      }
+  for (int it = 0; it < 2; ++it) {                             // 6 * KPD + KPH = 1248 <= 2 * EF_THR
+    const int e = tid + it * EF_THR;
+    if (e < 6 * KPD + KPH) {
+      const int vsel = e < 6 * KPD ? e / KPD : 6, col = e - vsel * KPD;
+      const float* src = vsel == 0 ? a.bo : vsel == 1 ? a.g1 : vsel == 2 ? a.be1 : vsel == 3 ? a.b2 : vsel == 4 ? a.g2 : vsel == 5 ? a.be2 : a.b1;
+      const int lim = vsel == 6 ? H : D;
+      float val = 0.f;
+      if (col < lim) val = src[col];
+      cst[e] = val;
     }
   }
-
   // ---- attention rows -> split planes (zero padded to KPD columns, rows beyond M zero) ----
   constexpr int kq = KPD / 4;
-  constexpr int NIT = (EF_ROWS * kq + EF_THR - 1) / EF_THR;
+  constexpr int NIT = (ROWS * kq + EF_THR - 1) / EF_THR;
   float4 v[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int i = tid + it * EF_THR;
     const int r = i / kq, k = 4 * (i - r * kq);
     v[it] = zero4;
-    if (r < EF_ROWS && m0 + r < M && k < D) v[it] = *reinterpret_cast<const float4*>(a.attn + (long)(m0 + r) * D + k);
+    if (r < ROWS && m0 + r < M && k < D) v[it] = *reinterpret_cast<const float4*>(a.attn + (long)(m0 + r) * D + k);
   }
-  // residual rows of LayerNorm1 and the per-column vectors of both LayerNorms: requested now, used much later
   const int c = 4 * lane;
   const bool cok = c < D;
-  Panel<KCD, 1> po;
-  load_panel<KCD, 1>(po, a.Wo, ntD, wave, lane);
+  Panel<KCD> po;
+  load_panel<KCD>(po, a.Wo, ntD, wave, lane);
   __builtin_amdgcn_sched_barrier(0);
   if (a.seed_cell) seed += load_uniform_u64(a.seed_cell);
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int i = tid + it * EF_THR;
     const int r = i / kq, k = 4 * (i - r * kq);
-    if (r < EF_ROWS) split_store4(Ah + r * LDD + k, Al + r * LDD + k, v[it]);
+    if (r < ROWS) split_store4(Ah + r * LDD + k, Al + r * LDD + k, v[it]);
   }
   EFSTAMP(1);
   lds_barrier();
   EFSTAMP(2);
-  if (a.xt_attn) export_tiles(Ah, Al, LDD, a.xt_attn, ntD, m0, wave, lane);
+  if (a.xt_attn) export_tiles<RT>(Ah, Al, LDD, a.xt_attn, ntD, m0, M, wave, lane);
 
   // ---- out_proj ----
-  {
-    f32x4 acc[1][EF_RT];
-    mma<KCD, 1>(acc, Ah, Al, LDD, po, lane, a.one);
-    to_stage<1>(stage, acc, ntD, wave, lane);
+  if (wave < ntD) {
+    f32x4 acc[RT];
+    mma<KCD, RT>(acc, Ah, Al, LDD, po, lane, a.one);
+    to_stage<RT>(stage, acc, wave, lane);
   }
   EFSTAMP(3);
-  float4 xr[EF_RPW];                                           // residual rows of LayerNorm1
+  float4 xr[RT];                                               // residual rows of LayerNorm1 (wave w: rows w, w + 16, ..)
 #pragma unroll
-  for (int q = 0; q < EF_RPW; ++q) {
+  for (int q = 0; q < RT; ++q) {
     const int m = m0 + wave + EF_WV * q;
     xr[q] = zero4;
     if (cok && m < M) xr[q] = *reinterpret_cast<const float4*>(a.x + (long)m * D + c);
   }
   lds_barrier();                                               // stage complete; every wave is done reading the attn planes
   EFSTAMP(4);
-  Panel<KCD, 1> p1;                                            // linear1 (column tiles 0..15) streams in under the LayerNorm epilogue
-  load_panel<KCD, 1>(p1, a.W1, ntH, wave, lane);              // (requested BEHIND the barrier: issuing it blocks a wave for a while)
-  EFSTAMP(14);
-  // ---- + bias, dropout, + x, LayerNorm1 -> s1, x1 (global), x1 planes, x1 fp32 copy ----
+  Panel<KCD> p1;                                               // linear1 (column tiles 0..15) streams in under the LayerNorm epilogue
+  load_panel<KCD>(p1, a.W1, ntH, wave, lane);                  // (requested BEHIND the barrier: issuing it blocks a wave for a while)
+  // ---- + bias, dropout, + x, LayerNorm1 -> s1, x1 (global), x1 planes ----
   {
     float4 gg = zero4, bb = zero4, bs = zero4;
     if (cok) {
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(EF_THR) void k_enc_post_fwd(PostFwdArgs a) {
       bb = *reinterpret_cast<const float4*>(cst + 2 * KPD + c);
     }
 #pragma unroll
-    for (int q = 0; q < EF_RPW; ++q) {
+    for (int q = 0; q < RT; ++q) {
       const int rl = wave + EF_WV * q;
       const long m = m0 + rl;
       float4 o = zero4;
@@ -285,38 +292,36 @@ __global__ __launch_bounds__(EF_THR) void k_enc_post_fwd(PostFwdArgs a) {
         if (cok) t = *reinterpret_cast<const float4*>(stage + rl * STG + c);
         o = ln_row(t, xr[q], bs, gg, bb, cok, D, m, c, a.p, inv_keep, seed, a.site_ao, a.s1, a.x1, a.st1, lane);
       }
-      if (q == 0) EFSTAMP(15);
       if (c < KPD) split_store4(Ah + rl * LDD + c, Al + rl * LDD + c, o);       // rows beyond M and pad columns: zeros
-      if (cok) *reinterpret_cast<float4*>(x1f + rl * LDF + c) = o;
     }
   }
   EFSTAMP(5);
   lds_barrier();
   EFSTAMP(6);
-  if (a.xt_x1) export_tiles(Ah, Al, LDD, a.xt_x1, ntD, m0, wave, lane);
+  if (a.xt_x1) export_tiles<RT>(Ah, Al, LDD, a.xt_x1, ntD, m0, M, wave, lane);
 
   // ---- linear1, ReLU, dropout -> h (global fp32 + planes) ----
   {
-    f32x4 acc[1][EF_RT];
-    mma<KCD, 1>(acc, Ah, Al, LDD, p1, lane, a.one);
-    to_stage<1>(stage, acc, ntH, wave, lane);
+    f32x4 acc[RT];
+    mma<KCD, RT>(acc, Ah, Al, LDD, p1, lane, a.one);
+    if (wave < ntH) to_stage<RT>(stage, acc, wave, lane);
     for (int t0 = EF_WV; t0 < ntH; t0 += EF_WV) {              // nhid > 256: the remaining column tiles (P19: tile 16, wave 0)
       if (t0 + wave < ntH) {                                   // wave-uniform
-        load_panel<KCD, 1>(p1, a.W1, ntH, wave, lane, t0);
-        mma<KCD, 1>(acc, Ah, Al, LDD, p1, lane, a.one);
-        to_stage<1>(stage, acc, ntH, wave, lane, t0);
+        load_panel<KCD>(p1, a.W1, ntH, t0 + wave, lane);
+        mma<KCD, RT>(acc, Ah, Al, LDD, p1, lane, a.one);
+        to_stage<RT>(stage, acc, t0 + wave, lane);
       }
     }
   }
   EFSTAMP(7);
   lds_barrier();
   EFSTAMP(8);
-  Panel<KCH, 1> p2;                                            // linear2 streams in under the epilogue
-  load_panel<KCH, 1>(p2, a.W2, ntD, wave, lane);
+  Panel<KCH> p2;                                               // linear2 streams in under the epilogue
+  load_panel<KCH>(p2, a.W2, ntD, wave, lane);
   {
     const int qpr = H >> 2;
     constexpr int hq = KPH / 4;
-    for (int e = tid; e < EF_ROWS * hq; e += EF_THR) {
+    for (int e = tid; e < ROWS * hq; e += EF_THR) {
       const int rl = e / hq, q = e - rl * hq;
       const int m = m0 + rl, n = 4 * q;
       float4 o = zero4;
@@ -334,16 +339,23 @@ __global__ __launch_bounds__(EF_THR) void k_enc_post_fwd(PostFwdArgs a) {
       split_store4(Hh + rl * LDH + n, Hl + rl * LDH + n, o);
     }
   }
+  // LayerNorm2's residual x1: read back by the very thread that stored it (rows w, w + 16, .. / columns 4 lane ..)
+#pragma unroll
+  for (int q = 0; q < RT; ++q) {
+    const int m = m0 + wave + EF_WV * q;
+    xr[q] = zero4;
+    if (cok && m < M) xr[q] = *reinterpret_cast<const float4*>(a.x1 + (long)m * D + c);
+  }
   EFSTAMP(9);
   lds_barrier();
   EFSTAMP(10);
-  if (a.xt_h) export_tiles(Hh, Hl, LDH, a.xt_h, ntH, m0, wave, lane);
+  if (a.xt_h) export_tiles<RT>(Hh, Hl, LDH, a.xt_h, ntH, m0, M, wave, lane);
 
   // ---- linear2 ----
-  {
-    f32x4 acc[1][EF_RT];
-    mma<KCH, 1>(acc, Hh, Hl, LDH, p2, lane, a.one);
-    to_stage<1>(stage, acc, ntD, wave, lane);
+  if (wave < ntD) {
+    f32x4 acc[RT];
+    mma<KCH, RT>(acc, Hh, Hl, LDH, p2, lane, a.one);
+    to_stage<RT>(stage, acc, wave, lane);
   }
   EFSTAMP(11);
   lds_barrier();
@@ -356,16 +368,29 @@ __global__ __launch_bounds__(EF_THR) void k_enc_post_fwd(PostFwdArgs a) {
       bb = *reinterpret_cast<const float4*>(cst + 5 * KPD + c);
     }
 #pragma unroll
-    for (int q = 0; q < EF_RPW; ++q) {
+    for (int q = 0; q < RT; ++q) {
       const int rl = wave + EF_WV * q;
       const long m = m0 + rl;
       if (m >= M) continue;
-      float4 t = zero4, res = zero4;
-      if (cok) { t = *reinterpret_cast<const float4*>(stage + rl * STG + c); res = *reinterpret_cast<const float4*>(x1f + rl * LDF + c); }
-      ln_row(t, res, bs, gg, bb, cok, D, m, c, a.p, inv_keep, seed, a.site_fo, a.s2, a.y, a.st2, lane);
+      float4 t = zero4;
+      if (cok) t = *reinterpret_cast<const float4*>(stage + rl * STG + c);
+      ln_row(t, xr[q], bs, gg, bb, cok, D, m, c, a.p, inv_keep, seed, a.site_fo, a.s2, a.y, a.st2, lane);
     }
   }
   EFSTAMP(13);
+  if (a.stamps && tid == 0) { a.stamps[256 + 1024 + 2 * blockIdx.x] = wall_clock64(); a.stamps[256 + 1024 + 2 * blockIdx.x + 1] = clock64(); }
+}
+
+__global__ __launch_bounds__(EF_THR) void k_enc_post_fwd(PostFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
+  int M = a.M;
+  if (a.mlive) M = min(M, __builtin_amdgcn_readfirstlane(*a.mlive));
+  if (pick_rt(M, a.ncu) == 3) post_fwd_body<3>(a, esm, M);
+  else post_fwd_body<2>(a, esm, M);
+}
+
+constexpr size_t post_fwd_lds(int rt) {
+  return (size_t)2 * 16 * rt * LDD * 2 + (size_t)2 * 16 * rt * LDH * 2 + (size_t)16 * rt * STG * 4 + (size_t)(6 * KPD + KPH) * 4;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -376,30 +401,31 @@ struct PreBwdArgs {
   const float *s2, *st2, *g2;                       // LayerNorm2: saved pre-norm sum, (mean, rstd), gamma
   const float* h;                                   // [M, H] FFN hidden after ReLU and dropout (gate: h > 0)
   const float *s1, *st1, *g1;                       // LayerNorm1
-  const __bf16 *W2t, *W1t, *Wot;                    // operand tiles of linear2^T [H x D red.], linear1^T [D x H red.], out_proj^T [D x D red.]
-  float *ds1, *da;                                  // [M, D]: gradient of the LayerNorm1 input (residual branch into dx), gradient of attn
-  float *part2, *part1;                             // [M/32][2D] dgamma | dbeta partials of LayerNorm2, LayerNorm1
+  const __bf16 *W2t, *W1t, *Wot;                    // operand tiles of linear2^T, linear1^T, out_proj^T
+  float *ds2, *ds1, *da;                            // [M, D]: gradients of the LayerNorm2 / LayerNorm1 inputs (residual branches), of attn
+  float *part2, *part1;                             // [grid][2D] dgamma | dbeta partials of LayerNorm2, LayerNorm1
   __bf16 *xt_df, *xt_du, *xt_dout;                  // row tiles for the weight gradients
-  int M, D, H;
+  int M, D, H, ncu;
   float p; uint64_t seed; uint32_t site_fo, site_ao; const uint64_t* seed_cell;
   const int32_t* mlive;
   int one;
   unsigned long long* stamps;
 };
 
-// LayerNorm backward of this wave's EF_RPW rows (lane: columns 4 lane ..).  dyq / sq: the rows' dy and saved pre-norm quads (zero
-// beyond D or M).  Writes the unmasked gradient quads to ds_lds ([32][LDF], LDS) or ds_glob ([M][K]), the dropout-masked ones (what the next product consumes) as split
-// planes, and accumulates this wave's dgamma | dbeta partial into lnred[wave].  Same arithmetic as k_rowgemm<.., LNB> (rd_rowgemm.hip).
-__device__ __forceinline__ void lnb_rows(const float4 (&dyq)[EF_RPW], const float4 (&sq)[EF_RPW], const float (&mean_r)[EF_RPW],
-                                         const float (&rstd_r)[EF_RPW], const float4& gg, bool cok, int K, int m0, int M, int wave, int lane,
-                                         float p, float inv_keep, uint64_t seed, uint32_t site, float* ds_lds, float* ds_glob, __bf16* Ph,
-                                         __bf16* Pl, float* lnred) {
+// LayerNorm backward of this wave's RT rows (rows RT wave .. RT wave + RT - 1; lane: columns 4 lane ..).  dyq / sq: the rows' dy and
+// saved pre-norm quads (zero beyond D or M).  Writes the unmasked gradient quads to ds_glob ([M][K]), the dropout-masked ones (what
+// the next product consumes) as split planes, and accumulates this wave's dgamma | dbeta partial into lnred[wave].  Same arithmetic
+// as k_rowgemm<.., LNB> (rd_rowgemm.hip).
+template <int RT>
+__device__ __forceinline__ void lnb_rows(const float4 (&dyq)[RT], const float4 (&sq)[RT], const float (&mean_r)[RT], const float (&rstd_r)[RT],
+                                         const float4& gg, bool cok, int K, int m0, int M, int wave, int lane, float p, float inv_keep,
+                                         uint64_t seed, uint32_t site, float* ds_glob, __bf16* Ph, __bf16* Pl, float* lnred) {
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const int c = 4 * lane;
   float4 ag = zero4, ab = zero4;
 #pragma unroll
-  for (int it = 0; it < EF_RPW; ++it) {
-    const int rl = wave * EF_RPW + it;
+  for (int it = 0; it < RT; ++it) {
+    const int rl = wave * RT + it;
     const long row = m0 + rl;
     float4 dr = zero4;
     if (row < M) {                                     // wave-uniform
@@ -413,8 +439,7 @@ __device__ __forceinline__ void lnb_rows(const float4 (&dyq)[EF_RPW], const floa
       if (cok) {
         const float4 v = make_float4(rstd * (dg.x - c1 - xh.x * c2), rstd * (dg.y - c1 - xh.y * c2),
                                      rstd * (dg.z - c1 - xh.z * c2), rstd * (dg.w - c1 - xh.w * c2));
-        if (ds_lds) *reinterpret_cast<float4*>(ds_lds + rl * LDF + c) = v;         // uniform pointers: one of the two
-        if (ds_glob) *reinterpret_cast<float4*>(ds_glob + row * K + c) = v;
+        *reinterpret_cast<float4*>(ds_glob + row * K + c) = v;
         dr = v;
         if (p > 0.f) {
           const float4 u = uniform4(seed, site, ((uint64_t)row * K + c) >> 2);
@@ -433,26 +458,28 @@ __device__ __forceinline__ void lnb_rows(const float4 (&dyq)[EF_RPW], const floa
   }
 }
 
-__global__ __launch_bounds__(EF_THR) void k_enc_pre_bwd(PreBwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
-  __bf16* Ah = reinterpret_cast<__bf16*>(esm);                 // [32][LDD]: df, then dout
-  __bf16* Al = Ah + EF_ROWS * LDD;
-  __bf16* Hh = Al + EF_ROWS * LDD;                             // [32][LDH]: du
-  __bf16* Hl = Hh + EF_ROWS * LDH;
-  float* stage = reinterpret_cast<float*>(Hl + EF_ROWS * LDH); // [32][STG]
-  float* ds2f = stage + EF_ROWS * STG;                         // [32][LDF]: gradient of the LayerNorm2 input (residual branch), fp32
-  float* lnred = ds2f + EF_ROWS * LDF;                         // [16 waves][2 KPD]
-  float* cst = lnred + EF_WV * 2 * KPD;                        // [g2 | g1] (KPD each, zero padded)
+template <int RT>
+__device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char* esm, int M) {
+  constexpr int ROWS = 16 * RT;
+  __bf16* Ah = reinterpret_cast<__bf16*>(esm);                 // [ROWS][LDD]: df, then dout
+  __bf16* Al = Ah + ROWS * LDD;
+  __bf16* Hh = Al + ROWS * LDD;                                // [ROWS][LDH]: du
+  __bf16* Hl = Hh + ROWS * LDH;
+  float* stage = reinterpret_cast<float*>(Hl + ROWS * LDH);    // [ROWS][STG]
+  float* cst = stage + ROWS * STG;                             // [g2 | g1] (KPD each, zero padded)
+  // [16 waves][2 KPD] dgamma | dbeta partials of one LayerNorm: aliases the du planes (written only between the two uses, each use is
+  // closed by a barrier before / after the planes are touched)
+  float* lnred = reinterpret_cast<float*>(Hh);
+  static_assert((size_t)EF_WV * 2 * KPD * 4 <= (size_t)2 * 16 * 2 * LDH * 2, "lnred must fit inside the du planes");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * EF_ROWS;
+  const int m0 = blockIdx.x * ROWS;
   const int D = a.D, H = a.H;
-  int M = a.M;
-  if (a.mlive) M = min(M, __builtin_amdgcn_readfirstlane(*a.mlive));
+  const int ntD = (D + 15) >> 4, ntH = (H + 15) >> 4;
   if (m0 >= M) {                                               // no live row: the partial sums of this block are zero
     for (int i = tid; i < 2 * D; i += EF_THR) { a.part2[(long)blockIdx.x * 2 * D + i] = 0.f; a.part1[(long)blockIdx.x * 2 * D + i] = 0.f; }
+    zero_dead_groups<RT>(a.xt_df, ntD, m0, M, tid); zero_dead_groups<RT>(a.xt_du, ntH, m0, M, tid); zero_dead_groups<RT>(a.xt_dout, ntD, m0, M, tid);
     return;
   }
-  const int ntD = (D + 15) >> 4, ntH = (H + 15) >> 4;
   uint64_t seed = a.seed;
   const float inv_keep = 1.0f / (1.0f - a.p);
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -465,11 +492,11 @@ __global__ __launch_bounds__(EF_THR) void k_enc_pre_bwd(PreBwdArgs a) {
     if (col < D) val = (vsel ? a.g1 : a.g2)[col];
     cst[tid] = val;
   }
-  // ---- rows of dy, s2 and their statistics (wave w: rows 2w, 2w+1; lane: 4 columns) ----
-  float4 dyq[EF_RPW], sq[EF_RPW]; float mean_r[EF_RPW], rstd_r[EF_RPW];
+  // ---- rows of dy, s2 and their statistics (wave w: rows RT w ..; lane: 4 columns) ----
+  float4 dyq[RT], sq[RT]; float mean_r[RT], rstd_r[RT];
 #pragma unroll
-  for (int it = 0; it < EF_RPW; ++it) {
-    const long row = m0 + wave * EF_RPW + it;
+  for (int it = 0; it < RT; ++it) {
+    const long row = m0 + wave * RT + it;
     const bool rok = row < M;
     mean_r[it] = rok ? a.st2[2 * row] : 0.f; rstd_r[it] = rok ? a.st2[2 * row + 1] : 0.f;
     dyq[it] = zero4; sq[it] = zero4;
@@ -478,8 +505,8 @@ __global__ __launch_bounds__(EF_THR) void k_enc_pre_bwd(PreBwdArgs a) {
       dyq[it] = *reinterpret_cast<const float4*>(a.dy + row * D + c);
     }
   }
-  Panel<KCD, 1> pw;
-  load_panel<KCD, 1>(pw, a.W2t, ntH, wave, lane);
+  Panel<KCD> pw;
+  load_panel<KCD>(pw, a.W2t, ntH, wave, lane);
   __builtin_amdgcn_sched_barrier(0);
   if (a.seed_cell) seed += load_uniform_u64(a.seed_cell);
   lds_barrier();                                               // cst visible
@@ -487,19 +514,19 @@ __global__ __launch_bounds__(EF_THR) void k_enc_pre_bwd(PreBwdArgs a) {
   {
     float4 gg = zero4;
     if (cok) gg = *reinterpret_cast<const float4*>(cst + c);
-    lnb_rows(dyq, sq, mean_r, rstd_r, gg, cok, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_fo, ds2f, nullptr, Ah, Al, lnred);
+    lnb_rows<RT>(dyq, sq, mean_r, rstd_r, gg, cok, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_fo, a.ds2, Ah, Al, lnred);
   }
-  // the FFN hidden (gate: h > 0): thread -> quads e, e + 1024, e + 2048 of the [32][KPH / 4] grid; requested here, consumed behind
+  // the FFN hidden (gate: h > 0): thread -> quads e, e + 1024, .. of the [ROWS][KPH / 4] grid; requested here, consumed behind
   // the next product
   constexpr int hq = KPH / 4;
-  constexpr int HIT = (EF_ROWS * hq + EF_THR - 1) / EF_THR;
+  constexpr int HIT = (ROWS * hq + EF_THR - 1) / EF_THR;
   float4 hv[HIT];
 #pragma unroll
   for (int it = 0; it < HIT; ++it) {
     const int e = tid + it * EF_THR;
     const int rl = e / hq, q = e - rl * hq;
     hv[it] = zero4;
-    if (rl < EF_ROWS && m0 + rl < M && 4 * q < H) hv[it] = *reinterpret_cast<const float4*>(a.h + (long)(m0 + rl) * H + 4 * q);
+    if (rl < ROWS && m0 + rl < M && 4 * q < H) hv[it] = *reinterpret_cast<const float4*>(a.h + (long)(m0 + rl) * H + 4 * q);
   }
   EFSTAMP(2);
   lds_barrier();
@@ -511,32 +538,32 @@ __global__ __launch_bounds__(EF_THR) void k_enc_pre_bwd(PreBwdArgs a) {
     for (int w = 0; w < EF_WV; ++w) v += lnred[w * 2 * KPD + col];
     a.part2[(long)blockIdx.x * 2 * D + i] = v;
   }
-  if (a.xt_df) export_tiles(Ah, Al, LDD, a.xt_df, ntD, m0, wave, lane);
+  if (a.xt_df) export_tiles<RT>(Ah, Al, LDD, a.xt_df, ntD, m0, M, wave, lane);
   // ---- du = (df W2) gated by h > 0, * keep ----
   {
-    f32x4 acc[1][EF_RT];
-    mma<KCD, 1>(acc, Ah, Al, LDD, pw, lane, a.one);
-    to_stage<1>(stage, acc, ntH, wave, lane);
+    f32x4 acc[RT];
+    mma<KCD, RT>(acc, Ah, Al, LDD, pw, lane, a.one);
+    if (wave < ntH) to_stage<RT>(stage, acc, wave, lane);
     for (int t0 = EF_WV; t0 < ntH; t0 += EF_WV) {
       if (t0 + wave < ntH) {
-        load_panel<KCD, 1>(pw, a.W2t, ntH, wave, lane, t0);
-        mma<KCD, 1>(acc, Ah, Al, LDD, pw, lane, a.one);
-        to_stage<1>(stage, acc, ntH, wave, lane, t0);
+        load_panel<KCD>(pw, a.W2t, ntH, t0 + wave, lane);
+        mma<KCD, RT>(acc, Ah, Al, LDD, pw, lane, a.one);
+        to_stage<RT>(stage, acc, t0 + wave, lane);
       }
     }
   }
   EFSTAMP(4);
-  lds_barrier();                                               // (also: everybody is done with lnred)
+  lds_barrier();                                               // stage complete; everybody is done with lnred (it lives in the du planes)
   EFSTAMP(5);
-  Panel<KCH, 1> p1;
-  load_panel_kc<KCH, 0, 5>(p1, a.W1t, ntD, wave, lane);       // first half of linear1^T's reduction; the rest behind the gate epilogue
+  Panel<KCH> p1;
+  load_panel<KCH, 0, 5>(p1, a.W1t, ntD, wave, lane);           // first half of linear1^T's reduction; the rest behind the gate epilogue
   {
     const float ks = a.p > 0.f ? inv_keep : 1.0f;
 #pragma unroll
     for (int it = 0; it < HIT; ++it) {
       const int e = tid + it * EF_THR;
       const int rl = e / hq, q = e - rl * hq;
-      if (rl < EF_ROWS) {
+      if (rl < ROWS) {
         float4 o = zero4;
         if (4 * q < H) {
           const float4 s4 = *reinterpret_cast<const float4*>(stage + rl * STG + 4 * q);
@@ -547,45 +574,49 @@ __global__ __launch_bounds__(EF_THR) void k_enc_pre_bwd(PreBwdArgs a) {
       }
     }
   }
-  // LayerNorm1's saved rows: requested here, consumed after the next product
+  // LayerNorm1's saved rows and the residual-branch gradient ds2 (read back by the thread that stored it): requested here,
+  // consumed after the next product
+  float4 rq[RT];
 #pragma unroll
-  for (int it = 0; it < EF_RPW; ++it) {
-    const long row = m0 + wave * EF_RPW + it;
+  for (int it = 0; it < RT; ++it) {
+    const long row = m0 + wave * RT + it;
     const bool rok = row < M;
     mean_r[it] = rok ? a.st1[2 * row] : 0.f; rstd_r[it] = rok ? a.st1[2 * row + 1] : 0.f;
-    sq[it] = zero4;
-    if (rok && cok) sq[it] = *reinterpret_cast<const float4*>(a.s1 + row * D + c);
+    sq[it] = zero4; rq[it] = zero4;
+    if (rok && cok) {
+      sq[it] = *reinterpret_cast<const float4*>(a.s1 + row * D + c);
+      rq[it] = *reinterpret_cast<const float4*>(a.ds2 + row * D + c);
+    }
   }
-  load_panel_kc<KCH, 5, KCH>(p1, a.W1t, ntD, wave, lane);
+  load_panel<KCH, 5, KCH>(p1, a.W1t, ntD, wave, lane);
   EFSTAMP(6);
   lds_barrier();
   EFSTAMP(7);
-  if (a.xt_du) export_tiles(Hh, Hl, LDH, a.xt_du, ntH, m0, wave, lane);
+  if (a.xt_du) export_tiles<RT>(Hh, Hl, LDH, a.xt_du, ntH, m0, M, wave, lane);
   // ---- dx1 = du W1 + ds2 ----
-  {
-    f32x4 acc[1][EF_RT];
-    mma<KCH, 1>(acc, Hh, Hl, LDH, p1, lane, a.one);
-    to_stage<1>(stage, acc, ntD, wave, lane);
+  if (wave < ntD) {
+    f32x4 acc[RT];
+    mma<KCH, RT>(acc, Hh, Hl, LDH, p1, lane, a.one);
+    to_stage<RT>(stage, acc, wave, lane);
   }
   EFSTAMP(8);
-  lds_barrier();
+  lds_barrier();                                               // stage complete; the du planes are dead (lnred may be rewritten)
   EFSTAMP(9);
-  Panel<KCD, 1> po;
-  load_panel<KCD, 1>(po, a.Wot, ntD, wave, lane);
+  Panel<KCD> po;
+  load_panel<KCD>(po, a.Wot, ntD, wave, lane);
   {
 #pragma unroll
-    for (int it = 0; it < EF_RPW; ++it) {
-      const int rl = wave * EF_RPW + it;
+    for (int it = 0; it < RT; ++it) {
+      const int rl = wave * RT + it;
       dyq[it] = zero4;
       if (cok && m0 + rl < M) {
         const float4 t = *reinterpret_cast<const float4*>(stage + rl * STG + c);
-        const float4 r = *reinterpret_cast<const float4*>(ds2f + rl * LDF + c);
-        dyq[it] = make_float4(t.x + r.x, t.y + r.y, t.z + r.z, t.w + r.w);
+        dyq[it] = make_float4(t.x + rq[it].x, t.y + rq[it].y, t.z + rq[it].z, t.w + rq[it].w);
       }
     }
     float4 gg = zero4;
     if (cok) gg = *reinterpret_cast<const float4*>(cst + KPD + c);
-    lnb_rows(dyq, sq, mean_r, rstd_r, gg, cok, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_ao, nullptr, a.ds1, Ah, Al, lnred);
+    lnb_rows<RT>(dyq, sq, mean_r, rstd_r, gg, cok, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_ao, a.ds1, Ah, Al, lnred);
   }
   EFSTAMP(10);
   lds_barrier();
@@ -597,19 +628,19 @@ __global__ __launch_bounds__(EF_THR) void k_enc_pre_bwd(PreBwdArgs a) {
     for (int w = 0; w < EF_WV; ++w) v += lnred[w * 2 * KPD + col];
     a.part1[(long)blockIdx.x * 2 * D + i] = v;
   }
-  if (a.xt_dout) export_tiles(Ah, Al, LDD, a.xt_dout, ntD, m0, wave, lane);
+  if (a.xt_dout) export_tiles<RT>(Ah, Al, LDD, a.xt_dout, ntD, m0, M, wave, lane);
   // ---- d attn = dout Wo ----
-  {
-    f32x4 acc[1][EF_RT];
-    mma<KCD, 1>(acc, Ah, Al, LDD, po, lane, a.one);
-    to_stage<1>(stage, acc, ntD, wave, lane);
+  if (wave < ntD) {
+    f32x4 acc[RT];
+    mma<KCD, RT>(acc, Ah, Al, LDD, po, lane, a.one);
+    to_stage<RT>(stage, acc, wave, lane);
   }
   EFSTAMP(12);
   lds_barrier();
   EFSTAMP(13);
   {
     const int qpr = D >> 2;
-    for (int e = tid; e < EF_ROWS * qpr; e += EF_THR) {
+    for (int e = tid; e < ROWS * qpr; e += EF_THR) {
       const int rl = e / qpr, q = e - rl * qpr;
       if (m0 + rl < M)
         *reinterpret_cast<float4*>(a.da + (long)(m0 + rl) * D + 4 * q) = *reinterpret_cast<const float4*>(stage + rl * STG + 4 * q);
@@ -618,19 +649,42 @@ __global__ __launch_bounds__(EF_THR) void k_enc_pre_bwd(PreBwdArgs a) {
   EFSTAMP(14);
 }
 
-constexpr size_t PRE_BWD_LDS = (size_t)2 * EF_ROWS * LDD * 2 + (size_t)2 * EF_ROWS * LDH * 2 + (size_t)EF_ROWS * STG * 4 + (size_t)EF_ROWS * LDF * 4 +
-                               (size_t)EF_WV * 2 * KPD * 4 + (size_t)2 * KPD * 4;
+__global__ __launch_bounds__(EF_THR) void k_enc_pre_bwd(PreBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
+  int M = a.M;
+  if (a.mlive) M = min(M, __builtin_amdgcn_readfirstlane(*a.mlive));
+  if (pick_rt(M, a.ncu) == 3) pre_bwd_body<3>(a, esm, M);
+  else pre_bwd_body<2>(a, esm, M);
+}
 
-constexpr size_t POST_FWD_LDS = (size_t)2 * EF_ROWS * LDD * 2 + (size_t)2 * EF_ROWS * LDH * 2 + (size_t)EF_ROWS * STG * 4 + (size_t)EF_ROWS * LDF * 4 +
-                                (size_t)(6 * KPD + KPH) * 4;
+constexpr size_t pre_bwd_lds(int rt) {
+  return (size_t)2 * 16 * rt * LDD * 2 + (size_t)2 * 16 * rt * LDH * 2 + (size_t)16 * rt * STG * 4 + (size_t)2 * KPD * 4;
+}
+
+int device_cus() {
+  static const int n = [] {
+    int dev = 0, v = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256;
+    return v;
+  }();
+  return n;
+}
 
 }  // namespace
 
 extern "C" void rd_debug_set_encfuse_stamps(void* p) { g_ef_stamps = (unsigned long long*)p; }   // not part of the ABI
 
 bool encfuse_ok(int D, int H) {
-  static const bool enabled = [] { const char* e = getenv("RD_ENC_FUSE"); return !(e && atoi(e) == 0); }();
+  const char* e = getenv("RD_ENC_FUSE");               // read per call (tests compare the fused and the unfused path in one process)
+  const bool enabled = !(e && atoi(e) == 0);
   return enabled && precision() != RD_PREC_FP32 && (D + 31) / 32 == KCD && (H + 31) / 32 == KCH && (D % 4) == 0 && (H % 4) == 0;
+}
+
+// RD_ENC_FUSE_TALL=0 pins the block height to 32 rows (A/B of the device-side choice)
+static int ef_ncu() {
+  const char* e = getenv("RD_ENC_FUSE_TALL");           // read per call
+  const bool tall = !(e && atoi(e) == 0);
+  return tall ? device_cus() : (1 << 20);
 }
 
 int launch_enc_post_fwd(long M, int D, int H, const float* attn, const float* x, const void* Wo, const void* W1, const void* W2,
@@ -643,28 +697,30 @@ int launch_enc_post_fwd(long M, int D, int H, const float* attn, const float* x,
   a.bo = bo; a.b1 = b1; a.b2 = b2; a.g1 = g1; a.be1 = be1; a.g2 = g2; a.be2 = be2;
   a.s1 = s1; a.x1 = x1; a.st1 = st1; a.h = h; a.s2 = s2; a.y = y; a.st2 = st2;
   a.xt_attn = (__bf16*)xt_attn; a.xt_x1 = (__bf16*)xt_x1; a.xt_h = (__bf16*)xt_h;
-  a.M = (int)M; a.D = D; a.H = H; a.p = p; a.seed = seed; a.site_ao = site_ao; a.site_fh = site_fh; a.site_fo = site_fo;
+  a.M = (int)M; a.D = D; a.H = H; a.ncu = ef_ncu(); a.p = p; a.seed = seed; a.site_ao = site_ao; a.site_fh = site_fh; a.site_fo = site_fo;
   a.seed_cell = seed_cell(); a.mlive = mlive; a.one = precision() == RD_PREC_BF16; a.stamps = g_ef_stamps;
-  RD_LDS_ATTR(k_enc_post_fwd, POST_FWD_LDS);
-  hipLaunchKernelGGL(k_enc_post_fwd, dim3(cdiv((int)M, EF_ROWS)), dim3(EF_THR), POST_FWD_LDS, st, a);
+  constexpr size_t lds = post_fwd_lds(EF_RTMAX);
+  RD_LDS_ATTR(k_enc_post_fwd, lds);
+  hipLaunchKernelGGL(k_enc_post_fwd, dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a);
   return check_launch("k_enc_post_fwd");
 }
 
-int encfuse_part_rows(long M) { return (int)((M + EF_ROWS - 1) / EF_ROWS); }
+int encfuse_part_rows(long M) { return (int)((M + 31) / 32); }
 
 int launch_enc_pre_bwd(long M, int D, int H, const float* dy, const float* s2, const float* st2, const float* g2, const float* h,
                        const float* s1, const float* st1, const float* g1, const void* W2t, const void* W1t, const void* Wot,
-                       float* ds1, float* da, float* part2, float* part1, void* xt_df, void* xt_du, void* xt_dout, float p,
+                       float* ds2, float* ds1, float* da, float* part2, float* part1, void* xt_df, void* xt_du, void* xt_dout, float p,
                        uint64_t seed, uint32_t site_fo, uint32_t site_ao, const int32_t* mlive, hipStream_t st) {
   PreBwdArgs a{};
   a.dy = dy; a.s2 = s2; a.st2 = st2; a.g2 = g2; a.h = h; a.s1 = s1; a.st1 = st1; a.g1 = g1;
   a.W2t = (const __bf16*)W2t; a.W1t = (const __bf16*)W1t; a.Wot = (const __bf16*)Wot;
-  a.ds1 = ds1; a.da = da; a.part2 = part2; a.part1 = part1;
+  a.ds2 = ds2; a.ds1 = ds1; a.da = da; a.part2 = part2; a.part1 = part1;
   a.xt_df = (__bf16*)xt_df; a.xt_du = (__bf16*)xt_du; a.xt_dout = (__bf16*)xt_dout;
-  a.M = (int)M; a.D = D; a.H = H; a.p = p; a.seed = seed; a.site_fo = site_fo; a.site_ao = site_ao;
+  a.M = (int)M; a.D = D; a.H = H; a.ncu = ef_ncu(); a.p = p; a.seed = seed; a.site_fo = site_fo; a.site_ao = site_ao;
   a.seed_cell = seed_cell(); a.mlive = mlive; a.one = precision() == RD_PREC_BF16; a.stamps = g_ef_stamps;
-  RD_LDS_ATTR(k_enc_pre_bwd, PRE_BWD_LDS);
-  hipLaunchKernelGGL(k_enc_pre_bwd, dim3(cdiv((int)M, EF_ROWS)), dim3(EF_THR), PRE_BWD_LDS, st, a);
+  constexpr size_t lds = pre_bwd_lds(EF_RTMAX);
+  RD_LDS_ATTR(k_enc_pre_bwd, lds);
+  hipLaunchKernelGGL(k_enc_pre_bwd, dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a);
   return check_launch("k_enc_pre_bwd");
 }
 

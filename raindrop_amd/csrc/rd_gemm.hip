@@ -768,14 +768,11 @@ int splitk_plan(long red, int rows, int cols, int* k_per_split) {
 // dW[N,K] = dy[M,N]^T x[M,K] and db[N] = sum_m dy[m,:] with ONE pass over dy: the split-K product
 // accumulates the row sums of its A operand (= dy^T) on the side.  ws: nsplit*(N*K + N) floats.
 long wgrad_ws_floats(long M, int N, int K) {
-  if (wgrad_slab_ok(M, N, K)) return wgrad_slab_ws_floats(M, N, K);
   int kps; const int ns = splitk_plan(M, N, K, &kps);
   return (long)ns * ((long)N * K + N);
 }
 int launch_wgrad(long M, int N, int K, const float* dy, long lddy, const float* x, long ldx, float* dW,
                  float* db, float* ws, hipStream_t st) {
-  if (wgrad_slab_ok(M, N, K))
-    return launch_wgrad_slab(M, N, K, dy, lddy, x, ldx, dW, db, nullptr, nullptr, nullptr, nullptr, ws, st);
   int kps; const int ns = splitk_plan(M, N, K, &kps);
   GemmArgs t{};
   t.M = N; t.N = K; t.K = (int)M;
@@ -797,7 +794,6 @@ int launch_wgrad(long M, int N, int K, const float* dy, long lddy, const float* 
 
 int launch_wgrad2(long M, int N, int K, const float* dyA, const float* xA, float* dWA, float* dbA,
                   const float* dyB, const float* xB, float* dWB, float* dbB, float* ws, hipStream_t st) {
-  if (wgrad_slab_ok(M, N, K)) return launch_wgrad_slab(M, N, K, dyA, N, xA, K, dWA, dbA, dyB, xB, dWB, dbB, ws, st);
   int kps; const int ns = splitk_plan(M, N, K, &kps);
   const long stride = (long)N * K + N;
   if (ns <= 1 || precision() == RD_PREC_FP32) {        // the batched form exists for the bf16 MFMA kernel only
@@ -863,6 +859,64 @@ int launch_colsum(const float* x, int M, int N, long ldx, float* out, float* ws,
   int rc = check_launch("k_colsum_part");
   if (rc) return rc;
   return launch_splitk_reduce(ws, nby, N, out, st);
+}
+
+namespace {
+// ---- wide fixed-order reduce: 64 element quads x 16 split groups per workgroup ---------------------
+struct RedJob { const float* part; float* out1; float* out2; };
+struct RedArgs { RedJob j[2]; int nsplit; long stride, e1, e2; };
+
+__global__ __launch_bounds__(1024) void k_reduce_wide(RedArgs a) {
+  __shared__ float4 red[16][64];
+  const RedJob job = a.j[blockIdx.y];
+  const int ql = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const long q = (long)blockIdx.x * 64 + ql, nq = (a.e1 + a.e2) >> 2;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (q < nq) {
+#pragma unroll 4
+    for (int z = sg; z < a.nsplit; z += 16) {
+      const float4 t = *reinterpret_cast<const float4*>(job.part + (long)z * a.stride + 4 * q);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+  }
+  red[sg][ql] = s;
+  __syncthreads();
+  if (sg == 0 && q < nq) {
+    float4 t = red[0][ql];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) { const float4 u = red[g][ql]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    const long i = 4 * q;
+    if (i < a.e1) *reinterpret_cast<float4*>(job.out1 + i) = t;
+    else *reinterpret_cast<float4*>(job.out2 + (i - a.e1)) = t;
+  }
+}
+
+}  // namespace
+
+// fixed-order sum of `nsplit` partials ([e1 | e2] floats each, `stride` apart) for one or two problems:
+// the wide kernel (16 split groups x float4) when the layout allows 16-byte accesses, else the scalar one
+int launch_splitk_reduce_pair(const float* partA, float* out1A, float* out2A, const float* partB, float* out1B,
+                              float* out2B, int nsplit, long stride, long e1, long e2, hipStream_t st) {
+  const bool two = partB != nullptr;
+  const bool same_e2 = !two || ((out2A != nullptr) == (out2B != nullptr));
+  const long e2a = out2A ? e2 : 0;
+  static const bool wide_on = [] { const char* e = getenv("RD_REDUCE_WIDE"); return !(e && atoi(e) == 0); }();
+  const bool vec = wide_on && same_e2 && ((stride | e1 | e2a) & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(partA) | reinterpret_cast<uintptr_t>(out1A) | reinterpret_cast<uintptr_t>(out2A) |
+                     reinterpret_cast<uintptr_t>(partB) | reinterpret_cast<uintptr_t>(out1B) | reinterpret_cast<uintptr_t>(out2B)) & 15) == 0;
+  if (!vec) {
+    int rc = launch_splitk_reduce2(partA, nsplit, stride, e1, out1A, out2A ? e2 : 0, out2A, st);
+    if (rc || !two) return rc;
+    return launch_splitk_reduce2(partB, nsplit, stride, e1, out1B, out2B ? e2 : 0, out2B, st);
+  }
+  RedArgs r{};
+  r.j[0] = RedJob{partA, out1A, out2A};
+  r.j[1] = RedJob{partB, out1B, out2B};
+  r.nsplit = nsplit; r.stride = stride; r.e1 = e1; r.e2 = e2a;
+  const long nq = (r.e1 + r.e2) >> 2;
+  if (nq <= 0) return RD_OK;
+  hipLaunchKernelGGL(k_reduce_wide, dim3((unsigned)((nq + 63) / 64), two ? 2 : 1), dim3(1024), 0, st, r);
+  return check_launch("k_reduce_wide");
 }
 
 }  // namespace rd

@@ -35,6 +35,10 @@ struct BetaArgs {
   int B, N, K, T, d, E, Kk;
 };
 
+// edge endpoint -> node index that is always legal (raindrop_amd.ops.graph_beta validates the range and raises like the
+// reference's index_select; the kernels must not read out of range whatever they are handed)
+__device__ __forceinline__ int node_of(int64_t v, int N) { return v < 0 ? 0 : (v >= N ? N - 1 : (int)v); }
+
 __device__ __forceinline__ unsigned sortable_desc(float x) {          // larger float -> smaller key
   unsigned u = __float_as_uint(x);
   u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);                     // ascending order-preserving map
@@ -49,24 +53,40 @@ struct Lds {
   int* soff; int* slist;    // per-source lists of kept positions: soff [N+1], slist [Kk]
   int* toff; int* tlist;    // per-target lists
   float* mx; float* inv;    // [N][T] softmax max / 1/(Z + 1e-16) per source and time step
-  float* S; float* db;      // backward: [N][T] sum_e weight * dweight per source; dbeta / 32 per target
+  float* S; float* db;      // backward: [N][Tc] sum_e weight * dweight per source; dbeta / 32 per target
+  float* dmacc; float* dwacc;   // backward: sums over the time chunks: d map_weights [N][16], d edge weight [Kk]
 };
 
-__device__ Lds carve(unsigned char* base, int N, int T, int P2, int Kk) {
+// Forward (bwd == false): beta, mx, inv for ALL T steps (the pruning sort needs every step's score) + the sort keys.
+// Backward: no sort; the five [N][Tc] arrays hold one CHUNK of Tc time steps at a time (everything but the two sums over time --
+// d map_weights and d edge weight, accumulated in dmacc / dwacc -- is independent per step), so T is not bounded by LDS.
+__device__ Lds carve(unsigned char* base, int N, int T, int P2, int Kk, bool bwd) {
   Lds l; size_t off = 0;
   auto take = [&](size_t bytes) { void* p = base + off; off += (bytes + 15) & ~(size_t)15; return p; };
   l.beta = (float*)take((size_t)N * T * 4);
-  l.keys = (unsigned long long*)take((size_t)P2 * 8);
+  l.keys = bwd ? nullptr : (unsigned long long*)take((size_t)P2 * 8);
   l.ksrc = (int*)take((size_t)Kk * 4); l.ktgt = (int*)take((size_t)Kk * 4); l.kw = (float*)take((size_t)Kk * 4);
   l.soff = (int*)take((size_t)(N + 1) * 4); l.slist = (int*)take((size_t)Kk * 4);
   l.toff = (int*)take((size_t)(N + 1) * 4); l.tlist = (int*)take((size_t)Kk * 4);
   l.mx = (float*)take((size_t)N * T * 4); l.inv = (float*)take((size_t)N * T * 4);
-  l.S = (float*)take((size_t)N * T * 4); l.db = (float*)take((size_t)N * T * 4);
+  if (bwd) {
+    l.S = (float*)take((size_t)N * T * 4); l.db = (float*)take((size_t)N * T * 4);
+    l.dmacc = (float*)take((size_t)N * 16 * 4); l.dwacc = (float*)take((size_t)Kk * 4);
+  } else { l.S = nullptr; l.db = nullptr; l.dmacc = nullptr; l.dwacc = nullptr; }
   return l;
 }
-size_t lds_bytes(int N, int T, int P2, int Kk) {
+// T here is the number of time steps RESIDENT in LDS (all of them forward, one chunk backward)
+size_t lds_bytes(int N, int T, int P2, int Kk, bool bwd) {
   auto r = [](size_t b) { return (b + 15) & ~(size_t)15; };
-  return r((size_t)N * T * 4) * 5 + r((size_t)P2 * 8) + r((size_t)Kk * 4) * 5 + r((size_t)(N + 1) * 4) * 2;
+  const size_t lists = r((size_t)Kk * 4) * 5 + r((size_t)(N + 1) * 4) * 2;
+  if (!bwd) return r((size_t)N * T * 4) * 3 + r((size_t)P2 * 8) + lists;
+  return r((size_t)N * T * 4) * 5 + lists + r((size_t)N * 16 * 4) + r((size_t)Kk * 4);
+}
+// largest chunk of time steps the backward kernel can keep resident (>= 1 whenever the lists fit)
+int bwd_chunk(int N, int T, int Kk) {
+  int tc = T;
+  while (tc > 1 && lds_bytes(N, tc, 0, Kk, true) > 160 * 1024) tc = (tc + 1) / 2;
+  return tc;
 }
 
 // per-node lists (by source or by target) of kept positions, in pruning order: thread n scans the kept edges
@@ -88,14 +108,15 @@ __device__ void build_lists(const int* key, int Kk, int N, int* off, int* list, 
 }
 
 // softmax statistics per (source n, time step t) over n's kept edges: mx, inv = 1 / (sum exp(g - mx) + 1e-16)
-__device__ void softmax_stats(const Lds& l, int N, int T, int tid) {
-  for (int i = tid; i < N * T; i += GB_THR) {
-    const int n = i / T, t = i - n * T;
+// (tc resident steps, rows LT apart)
+__device__ void softmax_stats(const Lds& l, int N, int tc, int LT, int tid) {
+  for (int i = tid; i < N * tc; i += GB_THR) {
+    const int n = i / tc, t = i - n * tc;
     float m = -INFINITY;
-    for (int q = l.soff[n]; q < l.soff[n + 1]; ++q) { const int e = l.slist[q]; m = fmaxf(m, l.beta[l.ktgt[e] * T + t] * l.kw[e]); }
+    for (int q = l.soff[n]; q < l.soff[n + 1]; ++q) { const int e = l.slist[q]; m = fmaxf(m, l.beta[l.ktgt[e] * LT + t] * l.kw[e]); }
     float z = 0.f;
-    for (int q = l.soff[n]; q < l.soff[n + 1]; ++q) { const int e = l.slist[q]; z += expf(l.beta[l.ktgt[e] * T + t] * l.kw[e] - m); }
-    l.mx[i] = m; l.inv[i] = 1.0f / (z + 1e-16f);
+    for (int q = l.soff[n]; q < l.soff[n + 1]; ++q) { const int e = l.slist[q]; z += expf(l.beta[l.ktgt[e] * LT + t] * l.kw[e] - m); }
+    l.mx[n * LT + t] = m; l.inv[n * LT + t] = 1.0f / (z + 1e-16f);
   }
   __syncthreads();
 }
@@ -104,7 +125,7 @@ __global__ __launch_bounds__(GB_THR) void k_graph_beta_fwd(BetaArgs a, int P2) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   const int tid = threadIdx.x, b = blockIdx.x;
   const int N = a.N, T = a.T, K = a.K, d = a.d, E = a.E, Kk = a.Kk;
-  Lds l = carve(gsm, N, T, P2, Kk);
+  Lds l = carve(gsm, N, T, P2, Kk, false);
   const float* H = a.H + (size_t)b * N * T * 32;
   const float* V = a.V + (size_t)b * N * K;
   const float* pt = a.p_t + (size_t)b * a.pt_bstride;
@@ -127,7 +148,7 @@ __global__ __launch_bounds__(GB_THR) void k_graph_beta_fwd(BetaArgs a, int P2) {
   for (int e = tid; e < P2; e += GB_THR) {
     unsigned long long key = ~0ull;                                   // padding sorts last
     if (e < E) {
-      const int tg = (int)a.ei[a.ei_stride + e];
+      const int tg = node_of(a.ei[a.ei_stride + e], N);
       float s = 0.f;
       for (int t = 0; t < T; ++t) s += l.beta[tg * T + t] * w[e];
       s = s / (float)T;                                               // == mean over the K = T*d repeated channels
@@ -151,7 +172,7 @@ __global__ __launch_bounds__(GB_THR) void k_graph_beta_fwd(BetaArgs a, int P2) {
   // ---- kept edges in pruning order ----
   for (int q = tid; q < Kk; q += GB_THR) {
     const int e = (int)(l.keys[q] & 0xFFFFFFFFu);
-    const int sr = (int)a.ei[e], tg = (int)a.ei[a.ei_stride + e];
+    const int sr = node_of(a.ei[e], N), tg = node_of(a.ei[a.ei_stride + e], N);
     l.ksrc[q] = sr; l.ktgt[q] = tg; l.kw[q] = w[e];
     a.kept[(size_t)b * Kk + q] = e;
     a.ei_out[(size_t)b * 2 * Kk + q] = sr; a.ei_out[(size_t)b * 2 * Kk + Kk + q] = tg;
@@ -161,7 +182,7 @@ __global__ __launch_bounds__(GB_THR) void k_graph_beta_fwd(BetaArgs a, int P2) {
   }
   __syncthreads();
   build_lists(l.ksrc, Kk, N, l.soff, l.slist, tid);
-  softmax_stats(l, N, T, tid);
+  softmax_stats(l, N, T, T, tid);
   // ---- out[n][k] = sum over n's kept out-edges of softmax weight[e][t(k)] * V[tgt(e)][k] ----
   float* out = a.out + (size_t)b * N * K;
   for (int i = tid; i < N * K; i += GB_THR) {
@@ -176,88 +197,103 @@ __global__ __launch_bounds__(GB_THR) void k_graph_beta_fwd(BetaArgs a, int P2) {
   }
 }
 
-__global__ __launch_bounds__(GB_THR) void k_graph_beta_bwd(BetaArgs a, int P2) {
+__global__ __launch_bounds__(GB_THR) void k_graph_beta_bwd(BetaArgs a, int Tc) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   const int tid = threadIdx.x, b = blockIdx.x;
   const int N = a.N, T = a.T, K = a.K, d = a.d, Kk = a.Kk;
-  Lds l = carve(gsm, N, T, P2, Kk);
+  Lds l = carve(gsm, N, Tc, 0, Kk, true);
   float* S = l.S;
   const float* H = a.H + (size_t)b * N * T * 32;
   const float* V = a.V + (size_t)b * N * K;
   const float* dout = a.dout + (size_t)b * N * K;
   const float* pt = a.p_t + (size_t)b * a.pt_bstride;
   const float* w = a.w + (size_t)b * a.w_bstride;
-  for (int i = tid; i < N * T; i += GB_THR) l.beta[i] = a.beta_save[(size_t)b * N * T + i];
   for (int q = tid; q < Kk; q += GB_THR) {
     const int e = a.kept[(size_t)b * Kk + q];
-    l.ksrc[q] = (int)a.ei[e]; l.ktgt[q] = (int)a.ei[a.ei_stride + e]; l.kw[q] = w[e];
+    l.ksrc[q] = node_of(a.ei[e], N); l.ktgt[q] = node_of(a.ei[a.ei_stride + e], N); l.kw[q] = w[e];
+    l.dwacc[q] = 0.f;
   }
+  for (int i = tid; i < N * 16; i += GB_THR) l.dmacc[i] = 0.f;
   __syncthreads();
   build_lists(l.ksrc, Kk, N, l.soff, l.slist, tid);
   build_lists(l.ktgt, Kk, N, l.toff, l.tlist, tid);
-  softmax_stats(l, N, T, tid);
-  auto weight = [&](int e, int t) {
-    const int n = l.ksrc[e];
-    return expf(l.beta[l.ktgt[e] * T + t] * l.kw[e] - l.mx[n * T + t]) * l.inv[n * T + t];
-  };
-  auto dwgt = [&](int e, int t) {                                    // d loss / d weight[e][t] = sum_c dout[src][td+c] * V[tgt][td+c]
-    const float* po = dout + (size_t)l.ksrc[e] * K + t * d;
-    const float* pv = V + (size_t)l.ktgt[e] * K + t * d;
-    float s = 0.f;
-    for (int c = 0; c < d; ++c) s += po[c] * pv[c];
-    return s;
-  };
-  // S[n][t] = sum over n's out-edges of weight * dweight
-  for (int i = tid; i < N * T; i += GB_THR) {
-    const int n = i / T, t = i - n * T;
-    float s = 0.f;
-    for (int q = l.soff[n]; q < l.soff[n + 1]; ++q) { const int e = l.slist[q]; s += weight(e, t) * dwgt(e, t); }
-    S[i] = s;
-  }
-  __syncthreads();
-  // dV[i][k] = sum over kept edges INTO i of weight[e][t(k)] * dout[src(e)][k]
   float* dV = a.dV + (size_t)b * N * K;
-  for (int i = tid; i < N * K; i += GB_THR) {
-    const int n = i / K, k = i - n * K, t = k / d;
-    float acc = 0.f;
-    for (int q = l.toff[n]; q < l.toff[n + 1]; ++q) { const int e = l.tlist[q]; acc += weight(e, t) * dout[(size_t)l.ksrc[e] * K + k]; }
-    dV[i] = acc;
-  }
-  // dbeta[i][t] = sum over kept edges into i of w[e] * dg[e][t],  dg = weight * (dweight - S[src])
-  // dH[i][t][c] = dbeta * aa[c] / 32;  dmap[i][c<16] = sum_t dbeta * H[i][t][c] / 32
   float* dH = a.dH + (size_t)b * N * T * 32;
-  for (int i = tid; i < N * T; i += GB_THR) {
-    const int n = i / T, t = i - n * T;
-    float s = 0.f;
-    for (int q = l.toff[n]; q < l.toff[n + 1]; ++q) {
-      const int e = l.tlist[q];
-      s += l.kw[e] * (weight(e, t) * (dwgt(e, t) - S[l.ksrc[e] * T + t]));
+  // time steps [t0, t0 + tc) resident per pass; local step tt = t - t0, rows of the [N][Tc] arrays Tc apart
+  for (int t0 = 0; t0 < T; t0 += Tc) {
+    const int tc = min(Tc, T - t0);
+    for (int i = tid; i < N * tc; i += GB_THR) {
+      const int n = i / tc, tt = i - n * tc;
+      l.beta[n * Tc + tt] = a.beta_save[((size_t)b * N + n) * T + t0 + tt];
     }
-    const float db = s * (1.0f / 32.0f);
-    float* ph = dH + ((size_t)n * T + t) * 32;
+    __syncthreads();
+    softmax_stats(l, N, tc, Tc, tid);
+    auto weight = [&](int e, int tt) {
+      const int n = l.ksrc[e];
+      return expf(l.beta[l.ktgt[e] * Tc + tt] * l.kw[e] - l.mx[n * Tc + tt]) * l.inv[n * Tc + tt];
+    };
+    auto dwgt = [&](int e, int tt) {                                 // d loss / d weight[e][t] = sum_c dout[src][td+c] * V[tgt][td+c]
+      const float* po = dout + (size_t)l.ksrc[e] * K + (t0 + tt) * d;
+      const float* pv = V + (size_t)l.ktgt[e] * K + (t0 + tt) * d;
+      float s = 0.f;
+      for (int c = 0; c < d; ++c) s += po[c] * pv[c];
+      return s;
+    };
+    // S[n][t] = sum over n's out-edges of weight * dweight
+    for (int i = tid; i < N * tc; i += GB_THR) {
+      const int n = i / tc, tt = i - n * tc;
+      float s = 0.f;
+      for (int q = l.soff[n]; q < l.soff[n + 1]; ++q) { const int e = l.slist[q]; s += weight(e, tt) * dwgt(e, tt); }
+      S[n * Tc + tt] = s;
+    }
+    __syncthreads();
+    // dV[i][k] = sum over kept edges INTO i of weight[e][t(k)] * dout[src(e)][k]      (columns of this chunk)
+    const int kc = tc * d;
+    for (int i = tid; i < N * kc; i += GB_THR) {
+      const int n = i / kc, kk = i - n * kc, k = t0 * d + kk, tt = kk / d;
+      float acc = 0.f;
+      for (int q = l.toff[n]; q < l.toff[n + 1]; ++q) { const int e = l.tlist[q]; acc += weight(e, tt) * dout[(size_t)l.ksrc[e] * K + k]; }
+      dV[(size_t)n * K + k] = acc;
+    }
+    // dbeta[i][t] = sum over kept edges into i of w[e] * dg[e][t],  dg = weight * (dweight - S[src])
+    // dH[i][t][c] = dbeta * aa[c] / 32;  dmap[i][c<16] = sum_t dbeta * H[i][t][c] / 32
+    for (int i = tid; i < N * tc; i += GB_THR) {
+      const int n = i / tc, tt = i - n * tc, t = t0 + tt;
+      float s = 0.f;
+      for (int q = l.toff[n]; q < l.toff[n + 1]; ++q) {
+        const int e = l.tlist[q];
+        s += l.kw[e] * (weight(e, tt) * (dwgt(e, tt) - S[l.ksrc[e] * Tc + tt]));
+      }
+      const float db = s * (1.0f / 32.0f);
+      float* ph = dH + ((size_t)n * T + t) * 32;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) ph[c] = db * a.map_w[n * 16 + c];
+      for (int c = 0; c < 16; ++c) ph[c] = db * a.map_w[n * 16 + c];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) ph[16 + c] = db * pt[t * 16 + c];
-    l.db[i] = db;
+      for (int c = 0; c < 16; ++c) ph[16 + c] = db * pt[t * 16 + c];
+      l.db[n * Tc + tt] = db;
+    }
+    __syncthreads();
+    for (int i = tid; i < N * 16; i += GB_THR) {                     // same thread for a given (n, c) in every pass: ordered sum over t
+      const int n = i >> 4, c = i & 15;
+      float s = l.dmacc[i];
+      for (int tt = 0; tt < tc; ++tt) s += l.db[n * Tc + tt] * H[((size_t)n * T + t0 + tt) * 32 + c];
+      l.dmacc[i] = s;
+    }
+    // d loss / d w[e] = sum_t dg[e][t] * beta[tgt][t] for kept edges
+    if (a.dw)
+      for (int q = tid; q < Kk; q += GB_THR) {
+        float s = l.dwacc[q];
+        for (int tt = 0; tt < tc; ++tt) s += weight(q, tt) * (dwgt(q, tt) - S[l.ksrc[q] * Tc + tt]) * l.beta[l.ktgt[q] * Tc + tt];
+        l.dwacc[q] = s;
+      }
+    __syncthreads();
   }
-  __syncthreads();
-  for (int i = tid; i < N * 16; i += GB_THR) {
-    const int n = i >> 4, c = i & 15;
-    float s = 0.f;
-    for (int t = 0; t < T; ++t) s += l.db[n * T + t] * H[((size_t)n * T + t) * 32 + c];
-    a.dmap_part[(size_t)b * N * 16 + i] = s;
-  }
-  // d loss / d w[e] = sum_t dg[e][t] * beta[tgt][t] for kept edges, 0 for pruned ones
-  if (a.dw) {
+  for (int i = tid; i < N * 16; i += GB_THR) a.dmap_part[(size_t)b * N * 16 + i] = l.dmacc[i];
+  if (a.dw) {                                                        // 0 for pruned edges
     float* dw = a.dw + (size_t)b * a.E;
     for (int e = tid; e < a.E; e += GB_THR) dw[e] = 0.f;
     __syncthreads();
-    for (int q = tid; q < Kk; q += GB_THR) {
-      float s = 0.f;
-      for (int t = 0; t < T; ++t) s += weight(q, t) * (dwgt(q, t) - S[l.ksrc[q] * T + t]) * l.beta[l.ktgt[q] * T + t];
-      dw[a.kept[(size_t)b * Kk + q]] = s;
-    }
+    for (int q = tid; q < Kk; q += GB_THR) dw[a.kept[(size_t)b * Kk + q]] = l.dwacc[q];
   }
 }
 
@@ -320,8 +356,10 @@ extern "C" int rd_graph_beta_fwd(int32_t B, int32_t N, int32_t K, int32_t T, int
   a.beta_save = beta_save; a.kept = kept;
   a.B = B; a.N = N; a.K = K; a.T = T; a.d = d_ob; a.E = E; a.Kk = rd_graph_beta_kept(E);
   const int P2 = next_pow2(E > 1 ? E : 2);
-  const size_t lds = lds_bytes(N, T, P2, a.Kk > 0 ? a.Kk : 1);
-  RD_REQUIRE(lds <= 160 * 1024, "graph does not fit LDS (%zu bytes)", lds);
+  const size_t lds = lds_bytes(N, T, P2, a.Kk > 0 ? a.Kk : 1, false);
+  if (lds > 160 * 1024)
+    return fail(RD_EUNSUPPORTED, "rd_graph_beta_fwd: the per-step scores of one graph (3 x N*T floats + the sort keys = %zu bytes) exceed "
+                "the 160 KB of LDS (N=%d, T=%d, E=%d)", lds, N, T, E);
   RD_LDS_ATTR(k_graph_beta_fwd, 160 * 1024);
   hipLaunchKernelGGL(k_graph_beta_fwd, dim3(B), dim3(GB_THR), lds, (hipStream_t)stream, a, P2);
   return check_launch("k_graph_beta_fwd");
@@ -342,11 +380,12 @@ extern "C" int rd_graph_beta_bwd(int32_t B, int32_t N, int32_t K, int32_t T, int
   a.w = edge_weights; a.w_bstride = w_bstride; a.beta_save = const_cast<float*>(beta_save); a.kept = const_cast<int32_t*>(kept);
   a.dout = dout; a.dV = dV; a.dH = dH; a.dmap_part = dmap_part; a.dw = dw;
   a.B = B; a.N = N; a.K = K; a.T = T; a.d = d_ob; a.E = E; a.Kk = rd_graph_beta_kept(E);
-  const int P2 = next_pow2(E > 1 ? E : 2);
-  const size_t lds = lds_bytes(N, T, P2, a.Kk > 0 ? a.Kk : 1);
-  RD_REQUIRE(lds <= 160 * 1024, "graph does not fit LDS (%zu bytes)", lds);
+  const int Kc = a.Kk > 0 ? a.Kk : 1;
+  const int Tc = bwd_chunk(N, T, Kc);
+  const size_t lds = lds_bytes(N, Tc, 0, Kc, true);
+  if (lds > 160 * 1024) return fail(RD_EUNSUPPORTED, "rd_graph_beta_bwd: edge lists do not fit LDS (N=%d, E=%d)", N, E);
   RD_LDS_ATTR(k_graph_beta_bwd, 160 * 1024);
-  hipLaunchKernelGGL(k_graph_beta_bwd, dim3(B), dim3(GB_THR), lds, (hipStream_t)stream, a, P2);
+  hipLaunchKernelGGL(k_graph_beta_bwd, dim3(B), dim3(GB_THR), lds, (hipStream_t)stream, a, Tc);
   return check_launch("k_graph_beta_bwd");
 }
 

@@ -146,8 +146,11 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
     float se = 0.f;
     for (int c = 0; c < C; ++c) se += expf(lg[r][c] - m);
     const float lse = m + logf(se);
-    const int t = (int)a.y[b];
-    a.lossr[b] = lse - lg[r][t];
+    // a label outside [0, C) has no logit to index (torch raises): the sample's loss becomes NaN -- loud, and no out-of-bounds read
+    const long yb = a.y[b];
+    const bool yok = yb >= 0 && yb < C;
+    const int t = yok ? (int)yb : 0;
+    a.lossr[b] = yok ? lse - lg[r][t] : __builtin_nanf("");
     const float invB = 1.0f / (float)B;
     for (int c = 0; c < C; ++c) {
       const float d = (expf(lg[r][c] - lse) - (c == t ? 1.f : 0.f)) * invB;

@@ -47,7 +47,7 @@ int launch_enc_post_fwd(long M, int D, int H, const float* attn, const float* x,
 int encfuse_part_rows(long M);
 int launch_enc_pre_bwd(long M, int D, int H, const float* dy, const float* s2, const float* st2, const float* g2, const float* h,
                        const float* s1, const float* st1, const float* g1, const void* W2t, const void* W1t, const void* Wot,
-                       float* ds1, float* da, float* part2, float* part1, void* xt_df, void* xt_du, void* xt_dout, float p,
+                       float* ds2, float* ds1, float* da, float* part2, float* part1, void* xt_df, void* xt_du, void* xt_dout, float p,
                        uint64_t seed, uint32_t site_fo, uint32_t site_ao, const int32_t* mlive, hipStream_t st);
 bool rowgemm_lnb_ok(int N, int K);
 int rowgemm_lnb_part_rows(long M);
@@ -1913,33 +1913,6 @@ int linear_bwd_w(long M, int N, int K, const float* dy, const float* x, float* d
   return launch_wgrad(M, N, K, dy, N, x, K, dW, db, splitk, st);
 }
 
-// Side stream for the weight-gradient products of the encoder backward.  They are off the critical
-// path (nothing downstream of the layer needs dW), each is a latency-bound split-K product that
-// leaves most CUs idle, so they run concurrently with the dgrad chain: fork after the producer of
-// their `dy`, join before the entry point returns (so callers still see plain stream semantics).
-// MEASURED on MI355X (P19, B=256): 1.77-1.82 ms/step with the side stream vs 1.63-1.70 ms without --
-// the GEMMs are bound by operand re-reads at the L2 level, not by idle CUs, so overlapping them
-// only adds contention.  Off by default; RD_AUX_STREAM=1 enables it.
-struct Aux {
-  hipStream_t s = nullptr;
-  hipEvent_t ev[6];
-  bool ok = false;
-  Aux() {
-    const char* e = getenv("RD_AUX_STREAM");
-    if (!e || atoi(e) == 0) return;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return;
-    for (auto& x : ev) if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) return;
-    ok = true;
-  }
-};
-Aux& aux() { static Aux a; return a; }
-// make `to` wait for everything enqueued on `from` so far
-int chain(hipStream_t from, hipStream_t to, hipEvent_t ev) {
-  RD_HIP(hipEventRecord(ev, from));
-  RD_HIP(hipStreamWaitEvent(to, ev, 0));
-  return RD_OK;
-}
-
 int check_enc(const rd_shape* s) {
   RD_REQUIRE(s != nullptr, "rd_shape is NULL");
   RD_REQUIRE(s->B >= 0 && s->T > 0 && s->F > 0 && s->d_ob > 0 && s->d_pe >= 0 && s->nhead > 0 && s->nhid > 0,
@@ -1991,7 +1964,7 @@ extern "C" int rd_encoder_layer_prepare(const rd_shape* s, const rd_encoder_weig
   const bool rg = rowgemm_ok(3 * e.D, e.D, e.D, 3 * e.D) && rowgemm_ok(e.D, e.D, e.D, e.D) &&
                   rowgemm_ok(e.nhid, e.D, e.D, e.nhid) && rowgemm_ok(e.D, e.nhid, e.nhid, e.D);
   if (!rg) return RD_OK;                             // the tiled path reads the fp32 weights directly
-  return enc_prepare(e, w, v, tile_path(e) && !aux().ok, (hipStream_t)stream);
+  return enc_prepare(e, w, v, tile_path(e), (hipStream_t)stream);
 }
 
 extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const float* x, const uint8_t* mask,
@@ -2015,7 +1988,7 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
   // weights -> bf16 hi/lo planes (both orientations needed by this layer's forward and backward), one launch
   const bool rg = rowgemm_ok(3 * e.D, e.D, e.D, 3 * e.D) && rowgemm_ok(e.D, e.D, e.D, e.D) &&
                   rowgemm_ok(e.nhid, e.D, e.D, e.nhid) && rowgemm_ok(e.D, e.nhid, e.nhid, e.D);
-  const bool tw = rg && tile_path(e) && !aux().ok;
+  const bool tw = rg && tile_path(e);
   // token plan (rd_plan.h): x, y and every saved / scratch tensor hold the live rows only, in plan order
   const int32_t* tp = token_plan();
   RD_REQUIRE(!tp || (tw && !attn_big(e)), "token plan: this shape / mode does not run on the row-block + tile-stream path");
@@ -2092,14 +2065,13 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   const uint32_t L = (uint32_t)layer;
   const float keep = 1.0f / (1.0f - p_drop);
   const int lnb = cdiv((int)e.M, LN_RPB);
-  Aux& ax = aux();
-  hipStream_t sw = ax.ok ? ax.s : st;                       // stream of the weight-gradient products
+  hipStream_t sw = st;
   const bool rg = rowgemm_ok(3 * e.D, e.D, e.D, 3 * e.D) && rowgemm_ok(e.D, e.D, e.D, e.D) &&
                   rowgemm_ok(e.nhid, e.D, e.D, e.nhid) && rowgemm_ok(e.D, e.nhid, e.nhid, e.D);
   // tw: the input-gradient products below export their A operand (df, du, dout, dqkv) as row tiles and the four weight
   // gradients run as one streaming launch at the end of the layer (rd_tile_wgrad.hip), instead of four split-K GEMMs;
   // its reduce launch also column-sums the two LayerNorm partial matrices
-  const bool tw = rg && tile_path(e) && !ax.ok;
+  const bool tw = rg && tile_path(e);
   const int32_t* tp = token_plan();
   RD_REQUIRE(!tp || (tw && !attn_big(e)), "token plan: this shape / mode does not run on the row-block + tile-stream path");
   struct MliveScope { MliveScope(const int32_t* p) { rowgemm_set_mlive(p); } ~MliveScope() { rowgemm_set_mlive(nullptr); } } mscope(tp);
@@ -2112,7 +2084,7 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   const bool fuse = lnf && encfuse_ok(e.D, e.nhid);
   const int lnrows = fuse ? encfuse_part_rows(e.M) : (lnf ? rowgemm_lnb_part_rows(e.M) : lnb);
   if (fuse && (rc = launch_enc_pre_bwd(e.M, e.D, e.nhid, dy, v.s2, v.st2, w->norm2_w, v.h, v.s1, v.st1, w->norm1_w, v.pl[5][0], v.pl[6][0],
-                                       v.pl[4][0], ws.ds1, ws.da, ws.lnpart, ws.lnpart1, ws.dt[0], ws.dt[1], ws.dt[2], p_drop, seed,
+                                       v.pl[4][0], ws.ds2, ws.ds1, ws.da, ws.lnpart, ws.lnpart1, ws.dt[0], ws.dt[1], ws.dt[2], p_drop, seed,
                                        SITE_FFN_OUT + L, SITE_ATTN_OUT + L, tp ? tp + plan::I_MLIVE : nullptr, st))) return rc;
   // ---- LayerNorm 2:  ds2 (residual path), df = ds2 o mask(ffn out) -------------------------------
   if (!lnf && (rc = launch_ln_bwd(dy, v.s2, v.st2, w->norm2_w, ws.ds2, ws.df, ws.lnpart, (int)e.M, e.D, p_drop, seed,
@@ -2120,7 +2092,6 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   // lnpart is a [blocks, 2D] matrix (dgamma | dbeta per block): column-sum it in fixed order
   if (!tw && (rc = launch_colsum2(ws.lnpart, lnb, 2 * e.D, 2 * e.D, g->norm2_w, e.D, g->norm2_b, ws.lnred, st))) return rc;
   // ---- FFN ---------------------------------------------------------------------------------------
-  if (ax.ok && (rc = chain(st, sw, ax.ev[0]))) return rc;
   if (!tw && (rc = linear_bwd_w(e.M, e.D, e.nhid, ws.df, v.h, g->lin2_w, g->lin2_b, ws.splitk, ws.colsum, sw))) return rc;
   if (fuse) {
   } else if (rg) {                                                 // du = (df W2) gated by h>0, * keep
@@ -2132,7 +2103,6 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
                                     p_drop > 0.f ? keep : 0.f, nullptr, 0, 0.f, 0, 0, st))) return rc;
   } else if ((rc = linear_bwd_x(e.M, e.D, e.nhid, ws.df, w->lin2_w, ws.du, v.h, p_drop > 0.f ? keep : 0.f, nullptr, st)))
     return rc;
-  if (ax.ok && (rc = chain(st, sw, ax.ev[1]))) return rc;
   if (!tw && (rc = linear_bwd_w(e.M, e.nhid, e.D, ws.du, v.x1, g->lin1_w, g->lin1_b, ws.splitk, ws.colsum, sw))) return rc;
   if (fuse) {
   } else if (rg) {
@@ -2145,7 +2115,6 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
                                   p_drop, seed, SITE_ATTN_OUT + L, st))) return rc;
   if (!tw && (rc = launch_colsum2(ws.lnpart, lnb, 2 * e.D, 2 * e.D, g->norm1_w, e.D, g->norm1_b, ws.lnred, st))) return rc;
   // ---- attention output projection ---------------------------------------------------------------
-  if (ax.ok && (rc = chain(st, sw, ax.ev[2]))) return rc;
   if (!tw && (rc = linear_bwd_w(e.M, e.D, e.D, ws.dout, v.attn, g->out_proj_w, g->out_proj_b, ws.splitk, ws.colsum, sw)))
     return rc;
   if (fuse) {
@@ -2172,7 +2141,6 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
     if ((rc = dispatch_attn(a, 2, st))) return rc;
   }
   // ---- input projection --------------------------------------------------------------------------
-  if (ax.ok && (rc = chain(st, sw, ax.ev[3]))) return rc;
   if (!tw && (rc = linear_bwd_w(e.M, 3 * e.D, e.D, ws.dqkv, x, g->in_proj_w, g->in_proj_b, ws.splitk, ws.colsum, sw)))
     return rc;
   if (tw) rowgemm_export_next(ws.dt[3]);
@@ -2192,8 +2160,48 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
                                  {ws.lnpart1, lnrows, 2 * e.D, e.D, g->norm1_w, g->norm1_b}};
     return launch_tile_wgrad(e.M, 4, jobs, v.ones, 2, cs, st, tp ? tp + plan::I_S32 : nullptr);
   }
-  if (ax.ok && (rc = chain(sw, st, ax.ev[4]))) return rc;                        // join: the caller's stream owns every result
   return rc;
+}
+
+// The attention core alone (torch F.multi_head_attention_forward between in_proj and out_proj, as used by the encoder layer of
+// code/models_rd.py:235-237,358): qkv [T,B,3D] -> out [T,B,D], lse [B,H,T]; backward: dout -> dqkv.  Same kernels and dispatch as
+// inside rd_encoder_layer_fwd/bwd; exposed so that this sub-graph (no ReLU gate in it) can be held to a tight bound against the
+// oracle by itself (tests/test_gpu_parity.py::test_attention_core_vs_float64).
+extern "C" int rd_attention_fwd(const rd_shape* s, int32_t layer, const float* qkv, const uint8_t* mask, float p_drop, uint64_t seed,
+                                float* out, float* lse, void* stream) {
+  int rc = check_enc(s);
+  if (rc) return rc;
+  if (s->B == 0) return RD_OK;
+  RD_REQUIRE(qkv && mask && out && lse, "NULL tensor");
+  RD_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "p_drop must be in [0,1)");
+  const EncDims e = enc_dims(s);
+  RD_REQUIRE(!attn_big(e), "rd_attention_fwd: head_dim %d > 96 runs as materialised products inside the layer only", e.Hd);
+  AttnArgs a{};
+  a.qkv = qkv; a.mask = mask; a.out = out; a.lse = lse;
+  a.T = e.T; a.B = e.B; a.D = e.D; a.H = e.H; a.hd = e.Hd;
+  a.scale = 1.0f / sqrtf((float)e.Hd); a.p_drop = p_drop; a.seed = seed; a.site = SITE_ATTN_PROB + (uint32_t)layer; a.seed_cell = seed_cell();
+  a.plan = token_plan();
+  return dispatch_attn(a, 0, (hipStream_t)stream);
+}
+// delta_ws: [B,H,T] floats of scratch
+extern "C" int rd_attention_bwd(const rd_shape* s, int32_t layer, const float* qkv, const uint8_t* mask, float p_drop, uint64_t seed,
+                                const float* out, const float* lse, const float* dout, float* dqkv, float* delta_ws, void* stream) {
+  int rc = check_enc(s);
+  if (rc) return rc;
+  if (s->B == 0) return RD_OK;
+  RD_REQUIRE(qkv && mask && out && lse && dout && dqkv && delta_ws, "NULL tensor");
+  RD_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "p_drop must be in [0,1)");
+  const EncDims e = enc_dims(s);
+  RD_REQUIRE(!attn_big(e), "rd_attention_bwd: head_dim %d > 96 runs as materialised products inside the layer only", e.Hd);
+  AttnArgs a{};
+  a.qkv = qkv; a.mask = mask; a.out = const_cast<float*>(out); a.lse = const_cast<float*>(lse); a.dout = dout; a.dqkv = dqkv; a.delta = delta_ws;
+  a.T = e.T; a.B = e.B; a.D = e.D; a.H = e.H; a.hd = e.Hd;
+  a.scale = 1.0f / sqrtf((float)e.Hd); a.p_drop = p_drop; a.seed = seed; a.site = SITE_ATTN_PROB + (uint32_t)layer; a.seed_cell = seed_cell();
+  a.plan = token_plan();
+  hipStream_t st = (hipStream_t)stream;
+  if (e.T <= TS) return dispatch_attn(a, 3, st);
+  if ((rc = dispatch_attn(a, 1, st))) return rc;
+  return dispatch_attn(a, 2, st);
 }
 
 extern "C" int rd_masked_mean_fwd(const rd_shape* s, int32_t D, const float* r, const uint8_t* mask,

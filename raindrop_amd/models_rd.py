@@ -126,6 +126,11 @@ class Raindrop_v2(nn.Module):
         them keeps this model's R_u instead of failing `strict=True`."""
         key = prefix + "R_u"
         if key not in state_dict:
+            import warnings
+            warnings.warn("Raindrop_v2.load_state_dict: the checkpoint has no `R_u` (a reference GPU checkpoint: upstream R_u is a non-leaf "
+                          "tensor that is never saved, code/models_rd.py:241).  The model that wrote it used ITS OWN glorot draw of R_u, which "
+                          "the file does not contain; this model keeps its current R_u, so its logits will differ from the writer's unless "
+                          "R_u is restored separately (same torch seed at construction, or assign model.R_u.data).", stacklevel=3)
             state_dict = dict(state_dict)
             state_dict[key] = self.R_u.detach()
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)

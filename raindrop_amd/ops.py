@@ -307,6 +307,28 @@ def _colsum_rows(x):
 
 
 def graph_beta(V, H, map_w, p_t, edge_index, edge_weights, d_ob=4):
+    """use_beta branch of Observation_progation.message, batched (include/raindrop_hip.h: rd_graph_beta_fwd).  V [B,N,K],
+    H [B,N,T*32], map_w [N,16], p_t [B or 1, T, 16], edge_index int64 [2,E], edge_weights [B or 1, E].  Shapes and edge
+    endpoints are validated here (one device read for the endpoint range: the reference's index_select syncs and raises
+    IndexError at the same point)."""
+    if V.dim() != 3 or H.dim() != 3 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise ValueError("graph_beta: V [B,N,K], H [B,N,T*32], edge_index [2,E] expected")
+    B, N, K = V.shape
+    if K % d_ob:
+        raise ValueError("graph_beta: K (%d) is not a multiple of d_ob (%d)" % (K, d_ob))
+    T, E = K // d_ob, edge_index.shape[1]
+    if tuple(H.shape) != (B, N, T * 32):
+        raise ValueError("graph_beta: H must be [B,N,T*32] = %s, got %s" % ((B, N, T * 32), tuple(H.shape)))
+    if tuple(map_w.shape) != (N, 16):
+        raise ValueError("graph_beta: map_weights must be [N,16] = %s, got %s" % ((N, 16), tuple(map_w.shape)))
+    if p_t.dim() != 3 or p_t.shape[0] not in (1, B) or tuple(p_t.shape[1:]) != (T, 16):
+        raise ValueError("graph_beta: p_t must be [1 or B, T, 16], got %s" % (tuple(p_t.shape),))
+    if edge_weights.dim() != 2 or edge_weights.shape[0] not in (1, B) or edge_weights.shape[1] != E:
+        raise ValueError("graph_beta: edge_weights must be [1 or B, E], got %s" % (tuple(edge_weights.shape),))
+    if E > 0:
+        lo, hi = int(edge_index.min()), int(edge_index.max())
+        if lo < 0 or hi >= N:
+            raise IndexError("graph_beta: edge endpoint out of range [0, %d): min %d, max %d" % (N, lo, hi))
     return _GraphBeta.apply(V.contiguous(), H.contiguous(), map_w.contiguous(), p_t.contiguous(), edge_index.contiguous(),
                             edge_weights.contiguous(), int(d_ob))
 

@@ -43,10 +43,6 @@ class TrainStep:
         self.model, self.flat, self.batch = model, flat, batch
         self._want_plan = (os.environ.get("RD_TOKEN_PLAN", "1") != "0") if token_plan is None else bool(token_plan)
         self.autotune, self.tuned_rows32, self.tuned_waves16 = bool(autotune), None, None
-        # MEASURED (same box, hipGraph step): 0.683 ms/step without, 0.702 with the side branch -- the two small launches cost less
-        # on the critical path than the cross-stream edges and the contention with the sensor stage; off unless RD_SIDE_PREPARE=1
-        self.side_prepare = os.environ.get("RD_SIDE_PREPARE", "0") == "1"
-        self._side = torch.cuda.Stream(device=batch["src"].device) if self.side_prepare else None
         self.dev = batch["src"].device
         self.lib = _lib.load()
         cfgp = float(model.dropout.p) if p_drop is None else float(p_drop)
@@ -114,7 +110,7 @@ class TrainStep:
                 and os.environ.get("RD_K1_FUSED", "1") != "0" and os.environ.get("RD_ROWGEMM", "1") != "0"
                 and os.environ.get("RD_TILE_WGRAD", "1") != "0" and os.environ.get("RD_ATTN_B16", "1") != "0"
                 and os.environ.get("RD_LN_FUSE", "1") != "0" and os.environ.get("RD_LNB_FUSE", "1") != "0"
-                and os.environ.get("RD_ATTN_BIG", "0") == "0" and os.environ.get("RD_AUX_STREAM", "0") == "0")
+                and os.environ.get("RD_ATTN_BIG", "0") == "0")
 
     # ------------------------------------------------------------------------------------------
     def _alloc(self):
@@ -174,25 +170,11 @@ class TrainStep:
         W2, b2 = P["ob_propagation_layer2.lin_value.weight"], P["ob_propagation_layer2.lin_value.bias"]
         ssum = self.graph_info["ssum"]
         # ---------------- forward ----------------
-        # the encoder layers' weight tiles depend on the weights only: split them on a side stream while the sensor stage
-        # runs (two launches off the critical path; inside a capture this becomes a parallel branch of the graph)
-        prepared = 0
-        if self.side_prepare:
-            main = torch.cuda.current_stream()
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                sst = ops._stream()
-                for i in range(self.nl):
-                    c("rd_encoder_layer_prepare", sp, ctypes.byref(self.enc_w[i]), _p(self.enc_saved[i]),
-                      self.enc_saved[i].numel(), sst)
-            prepared = 0x10000                                             # RD_LAYER_WEIGHTS_PREPARED
         c("rd_sensor_stage_fwd", sp, _p(b["src"]), _p(b["times"]), _p(b["lengths"]), _p(self.ts), _p(P["R_u"]), _p(W1),
           _p(b1), _p(W2), _p(b2), _p(ssum), self.p_drop, self.seed, _p(self.z), _p(self.mask), _p(self.k1_saved),
           self.k1_saved.numel(), st)
-        if self.side_prepare:
-            torch.cuda.current_stream().wait_stream(self._side)
         for i in range(self.nl):
-            c("rd_encoder_layer_fwd", sp, i | prepared, _p(self.x[i]), _p(self.mask), ctypes.byref(self.enc_w[i]), self.p_drop,
+            c("rd_encoder_layer_fwd", sp, i, _p(self.x[i]), _p(self.mask), ctypes.byref(self.enc_w[i]), self.p_drop,
               self.seed, _p(self.x[i + 1]), _p(self.enc_saved[i]), self.enc_saved[i].numel(), _p(self.enc_ws),
               self.enc_ws.numel(), st)
         cur = self.dx[0]
@@ -268,7 +250,10 @@ class TrainStep:
         tuning knob (32-row vs 64-row workgroups of the encoder's row-block products, rd_set_rowgemm_rows32: which is
         faster depends on the device, 8 % either way was measured on two boxes of one pool) and the faster graph is kept.
         Results are the same function of the inputs either way."""
-        if not self.autotune or os.environ.get("RD_RG_ROWS32") is not None or os.environ.get("RD_RG_WAVES16") is not None:
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # data-parallel ranks must run the SAME kernel variants (the tuner decides by wall clock: ranks could disagree): no tuning there
+        if not self.autotune or multi or os.environ.get("RD_RG_ROWS32") is not None or os.environ.get("RD_RG_WAVES16") is not None:
             return self._capture_one()
 
         def timed(r32, w16):

@@ -33,6 +33,19 @@ def test_every_declared_symbol_is_exported(lib):
         assert hasattr(lib, name), name
 
 
+def test_no_undeclared_exports(lib):
+    """Everything the shared library exports under the rd_ prefix is declared: the ABI in include/raindrop_hip.h, the profiling
+    hooks (no binding, tools only) in include/raindrop_hip_debug.h."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("rd_")})
+    text = open(os.path.join(ROOT, "include", "raindrop_hip_debug.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    debug = sorted(set(re.findall(r"\b(rd_debug_[a-z0-9_]+)\s*\(", text)))
+    assert all(n.startswith("rd_debug_") for n in debug)
+    assert exported == sorted(_declared() + debug)
+
+
 def test_identity(lib):
     assert lib.rd_version() == 1
     assert lib.rd_arch() == b"gfx950"

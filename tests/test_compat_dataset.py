@@ -48,6 +48,32 @@ def test_reference_loader_accepts_synthetic_dataset(tmp_path, dataset):
     assert np.array_equal(P[:, :, F:].numpy() > 0, raw != 0)
 
 
+def test_reference_loader_accepts_synthetic_pam_dataset(tmp_path):
+    """PAM (BASELINE.json configs[0]): bare [T,F] records, no static features, 8 classes; the script's PAM branch
+    (code/Raindrop.py:196-204) normalises with `tensorize_normalize_other` (code/utils_rd.py:243-257), which also invents the time
+    axis linspace(0, T, T) / 60 -- first stamp 0, so `lengths` (Raindrop.py:317) is T - 1 for every sample."""
+    u = _utils_rd()
+    cfg = synth.make_config("PAM")
+    n = 24
+    base = compat_runner.write_dataset(str(tmp_path), "PAM", n, seed=2)
+    split = "/splits/" + compat_runner.DATASETS["PAM"][3] % 1
+    Ptrain, Pval, Ptest, ytrain, yval, ytest = u.get_data_split(base, split, split_type="random", reverse=False,
+                                                                baseline=False, dataset="PAM")
+    assert len(Ptrain) + len(Pval) + len(Ptest) == n
+    T, F = Ptrain[0].shape
+    assert (T, F) == (cfg["max_len"], cfg["d_inp"])
+    raw = np.array(Ptrain, dtype=np.float64).transpose(1, 0, 2).copy()   # (mask_normalize works in place on the PAM records)
+    mf, stdf = compat_runner.get_stats_numpy2(np.asarray(Ptrain, dtype=np.float64))
+    P, Pstatic, Ptime, y = u.tensorize_normalize_other(Ptrain, ytrain, mf, stdf)
+    assert Pstatic is None
+    P = P.permute(1, 0, 2); Ptime = Ptime.squeeze(2).permute(1, 0)
+    assert tuple(P.shape) == (T, len(Ptrain), 2 * F) and tuple(Ptime.shape) == (T, len(Ptrain))
+    lengths = (Ptime > 0).sum(0)
+    assert int(lengths.min()) == T - 1 and int(lengths.max()) == T - 1
+    assert int(y.min()) >= 0 and int(y.max()) < cfg["n_classes"]
+    assert np.array_equal(P[:, :, F:].numpy() > 0, raw != 0)
+
+
 def test_workspace_layout(tmp_path):
     code = compat_runner.make_workspace(str(tmp_path), "P19", 40, ref_loader.reference_root())
     assert os.path.islink(os.path.join(code, "Raindrop.py")) and os.path.islink(os.path.join(code, "utils_rd.py"))

@@ -86,6 +86,68 @@ def test_two_rank_step_equals_full_batch_step():
     assert dp_.max() <= 2.1 * 1e-3 * STEPS
 
 
+RANK_SEED_STRIDE = 0x9E3779B97F4A7C15          # raindrop_amd.ops.rank_seed_offset
+
+
+def _graph_dropout_step(batch, seed):
+    """ONE hipGraph step with dropout 0.2 (the configuration bench.py --gpus N runs): returns (loss, flat gradient after
+    flat.allreduce())."""
+    from raindrop_amd import dp, synth
+    from raindrop_amd.models_rd import Raindrop_v2
+    from raindrop_amd.step import TrainStep
+    dev = torch.device("cuda", 0)
+    cfg = synth.make_config("P19")
+    gs = synth.make_structure(cfg, "sparse")
+    m = Raindrop_v2(cfg["d_inp"], cfg["d_model"], cfg["nhead"], cfg["nhid"], cfg["nlayers"], cfg["dropout"],
+                    cfg["max_len"], cfg["d_static"], cfg["MAX"], 0.5, cfg["aggreg"], cfg["n_classes"], gs,
+                    sensor_wise_mask=False)
+    synth.fill_params_(m, seed=21)
+    m = m.to(dev).train()
+    named = dict(m.named_parameters())
+    flat = dp.FlatGradAllReduce([(n, named[n]) for n in synth.live_parameter_names(cfg)], n_buckets=2)
+    b = {k: (None if v is None else v.to(dev)) for k, v in batch.items()}
+    ts = TrainStep(m, flat, b, p_drop=0.2, use_graph=True, seed=seed, autotune=False)
+    ts.seed_cell.zero_()                                          # the capture's warm-up runs bumped it: one defined replay
+    loss = float(ts.run())
+    flat.allreduce()
+    torch.cuda.synchronize()
+    g = flat.flat.detach().cpu().numpy().copy()
+    ts.close()
+    return loss, g
+
+
+def _graph_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from raindrop_amd import dp, synth
+    full = synth.make_batch(synth.make_config("P19"), B_GLOBAL, seed=33)
+    ret[rank] = _graph_dropout_step(dp.shard_batch(full, rank, world), seed=1234)
+    dist.destroy_process_group()
+
+
+def test_two_rank_graph_step_with_dropout():
+    """The step bench.py --gpus N actually runs -- hipGraph replay, dropout 0.2, per-rank seed offsets, device seed cell -- on two
+    ranks: the all-reduced gradient is bit-identical on both ranks, the ranks drew DIFFERENT masks (different local losses), and
+    the result equals a single process replaying the two shards with the two ranks' seeds and averaging."""
+    from raindrop_amd import dp, synth
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_graph_worker, args=(world, port, ret), nprocs=world, join=True)
+    (l0, g0), (l1, g1) = ret[0], ret[1]
+    assert np.array_equal(g0, g1)
+    assert l0 != l1
+    full = synth.make_batch(synth.make_config("P19"), B_GLOBAL, seed=33)
+    rep = []
+    for r in range(world):                                        # no process group here: rank_seed_offset() == 0, so pass the rank's seed
+        seed = (1234 + r * RANK_SEED_STRIDE) & 0x7FFFFFFFFFFFFFFF
+        rep.append(_graph_dropout_step(dp.shard_batch(full, r, world), seed=seed))
+    assert rep[0][0] == l0 and rep[1][0] == l1                    # same masks as the ranks drew
+    avg = (rep[0][1] + rep[1][1]) / np.float32(world)
+    assert np.array_equal(avg, g0)
+
+
 def _eval_worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)

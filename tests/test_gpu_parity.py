@@ -257,6 +257,78 @@ def test_encoder_layer_vs_oracle(T, B, F, nhead):
         _grad_close(a.cpu().numpy(), r.numpy(), 2e-4, name)
 
 
+@pytest.mark.parametrize("T,B,F,nhead", [(60, 9, 34, 2), (33, 4, 34, 2), (64, 3, 12, 4), (215, 2, 36, 2), (16, 5, 17, 2)])
+def test_attention_core_vs_float64(T, B, F, nhead):
+    """The attention core by itself (rd_attention_fwd / rd_attention_bwd: the kernels the encoder layer runs between in_proj and
+    out_proj) against float64 torch: softmax(q k^T / sqrt(hd) with padded keys at -inf) v per head, and its gradient.  No ReLU
+    gate lives in this sub-graph, so -- unlike the whole-model gradient checks, which a flipped gate can move by a percent -- the
+    single-tile split-bf16 kernels (T <= 64) are held to 2e-4 of each tensor's max-norm directly against the oracle arithmetic;
+    the exact-fp32 mode and the multi-tile fp32 kernels to 2e-5."""
+    from raindrop_amd import _lib
+    D = F * 4 + 16
+    hd = D // nhead
+    rng = np.random.default_rng(T * 13 + B)
+    qkv = torch.from_numpy(rng.standard_normal((T, B, 3 * D)).astype(np.float32))
+    lengths = torch.from_numpy(rng.integers(1, T + 1, size=B)).long()
+    lengths[0] = T
+    mask = torch.from_numpy(O2.padding_mask(lengths.numpy(), T))
+    dout = torch.from_numpy(rng.standard_normal((T, B, D)).astype(np.float32))
+    # ---- float64 reference (torch semantics: F.multi_head_attention_forward, key_padding_mask -> -inf) ----
+    q64 = qkv.double().requires_grad_(True)
+    q, k, v = q64[..., :D], q64[..., D:2 * D], q64[..., 2 * D:]
+    sh = lambda t: t.reshape(T, B, nhead, hd).permute(1, 2, 0, 3)                       # [B,H,T,hd]
+    S = (sh(q) / np.sqrt(hd)) @ sh(k).transpose(-1, -2)
+    S = S.masked_fill(mask[:, None, None, :], float("-inf"))
+    out64 = (torch.softmax(S, -1) @ sh(v)).permute(2, 0, 1, 3).reshape(T, B, D)
+    (g64,) = torch.autograd.grad(out64, q64, dout.double())
+    # ---- device ----
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    qd, md, dd = qkv.to(DEV), mask.to(DEV), dout.to(DEV)
+    out = torch.zeros(T, B, D, device=DEV); lse = torch.zeros(B, nhead, T, device=DEV)
+    dqkv = torch.zeros(T, B, 3 * D, device=DEV); ws = torch.zeros(B, nhead, T, device=DEV)
+    shp = _lib.shape(B, T, F, 4, nhead=nhead, nhid=2 * F * 4)
+    _lib.call("rd_attention_fwd", ctypes.byref(shp), 0, P(qd), P(md), 0.0, 0, P(out), P(lse), None)
+    _lib.call("rd_attention_bwd", ctypes.byref(shp), 0, P(qd), P(md), 0.0, 0, P(out), P(lse), P(dd), P(dqkv), P(ws), None)
+    torch.cuda.synchronize()
+    tol = 2e-4 if (TOL["x"] != 1.0 and T <= 64) else 2e-5
+    # padded QUERY rows are computed too (torch does): compare everything
+    assert _rel(out.cpu().numpy(), out64.detach().numpy()) < tol, _rel(out.cpu().numpy(), out64.detach().numpy())
+    assert _rel(dqkv.cpu().numpy(), g64.numpy()) < tol, _rel(dqkv.cpu().numpy(), g64.numpy())
+
+
+@pytest.mark.parametrize("T,B,p_drop", [(60, 6, 0.0), (60, 150, 0.2), (60, 256, 0.2), (33, 7, 0.2), (60, 137, 0.0)])
+def test_fused_row_local_chains_match_row_block_products(T, B, p_drop, precision_mode, monkeypatch):
+    """rd_encfuse.hip (out_proj + LayerNorm1 + FFN + LayerNorm2 in one launch, and its backward chain) against the three
+    row-block launches per direction it replaces, IN THE SAME ARITHMETIC with the same Philox quads (dropout ON): the two paths
+    must agree bit for bit in the forward output and to summation order (per-block LayerNorm partials: 32- vs 48-row blocks)
+    in the gradients.  B = 150 / 137 (9000 / 8220 rows) make the kernels pick their 48-row blocks on a 256-CU device, B = 256
+    (15360 rows) two rounds of 32-row blocks."""
+    if precision_mode == "fp32":
+        pytest.skip("the fused chains are bf16-mode kernels")
+    from raindrop_amd import _lib, ops
+    F, nhead = 34, 2
+    D, nhid = F * 4 + 16, 2 * F * 4
+    rng = np.random.default_rng(T * 7 + B)
+    x = torch.from_numpy(rng.standard_normal((T, B, D)).astype(np.float32)).to(DEV)
+    lengths = torch.from_numpy(rng.integers(1, T + 1, size=B)).long()
+    lengths[0] = T
+    mask = torch.from_numpy(O2.padding_mask(lengths.numpy(), T)).to(DEV)
+    dy = torch.from_numpy(rng.standard_normal((T, B, D)).astype(np.float32)).to(DEV)
+    p = _enc_params(D, nhid, seed=T)
+    shp = _lib.shape(B, T, F, 4, nhead=nhead, nhid=nhid)
+    res = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("RD_ENC_FUSE", fuse)
+        xd = x.clone().requires_grad_(True)
+        pd = [p[n].to(DEV).requires_grad_(True) for n in ops.ENC_PARAM_NAMES]
+        y = ops.encoder_layer(xd, mask, shp, 1, p_drop, 77, pd)
+        g = torch.autograd.grad(y, [xd] + pd, dy)
+        res[fuse] = (y.detach().cpu().numpy(), [t.cpu().numpy() for t in g])
+    assert np.array_equal(res["0"][0], res["1"][0])
+    for name, a, b in zip(["x"] + list(ops.ENC_PARAM_NAMES), res["1"][1], res["0"][1]):
+        assert _rel(a, b) < 2e-5, (name, _rel(a, b))
+
+
 @pytest.mark.parametrize("T,B", [(60, 37), (60, 256), (33, 5)])
 def test_encoder_tile_weight_gradients_match_split_k(T, B, precision_mode, monkeypatch):
     """The streamed weight gradients (rd_tile_wgrad.hip: operands exported as split-bf16 row tiles by the row-block
@@ -613,51 +685,21 @@ def test_static_train_step_matches_autograd(use_graph, fused_head, precision_mod
         step.close()
 
 
-def test_slab_weight_gradients_match_tiled_split_k():
-    """The slab weight-gradient product (operands read once, whole output per workgroup; also the
-    batched pair of the two message-passing layers) against the tiled split-K form on the same
-    inputs: only the summation order differs."""
-    import ctypes
-    from raindrop_amd import _lib
-    lib = _lib.load()
-    lib.rd_debug_set_wgrad_slabs.argtypes = [ctypes.c_int]
-    cfg = synth.make_config("P19")
-    gs = synth.make_structure(cfg, "sparse")
-    batch = synth.make_batch(cfg, 48, seed=43)                  # B*F = 1632 node rows, T*B = 2880 tokens
-    dv = {k: (None if v is None else v.to(DEV)) for k, v in batch.items()}
-    m = build_ours(cfg, gs, DEV, 9).train()
-    live = synth.live_parameter_names(cfg)
-    named = dict(m.named_parameters())
-    grads = {}
-    try:
-        for slabs in (0, 1, 3):
-            lib.rd_debug_set_wgrad_slabs(slabs)
-            logits, _, _ = m(dv["src"], dv["static"], dv["times"], dv["lengths"])
-            loss = torch.nn.functional.cross_entropy(logits, dv["y"])
-            grads[slabs] = [g.cpu().numpy() for g in torch.autograd.grad(loss, [named[n] for n in live])]
-    finally:
-        lib.rd_debug_set_wgrad_slabs(0)
-    for slabs in (1, 3):
-        for n, a, b in zip(live, grads[slabs], grads[0]):
-            assert _rel(a, b) < 2e-5, (slabs, n, _rel(a, b))
-    # every tile configuration of the kernel, ragged row counts, against fp64
+def test_split_k_weight_gradients_vs_float64():
+    """rd_linear_bwd_weight (split over the M rows, fixed-order reduce; bias gradient riding on the same product) on the
+    layer shapes of the path and ragged row counts, against float64."""
     from raindrop_amd import ops
     rng = np.random.default_rng(5)
-    try:
-        lib.rd_debug_set_wgrad_slabs(2)
-        for (M, N, K) in [(15360, 152, 272), (5000, 272, 152), (4099, 152, 152), (3001, 456, 152), (8704, 240, 240),
-                          (1025, 64, 48)]:
-            x = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(DEV).requires_grad_(True)
-            W = torch.from_numpy(rng.standard_normal((N, K)).astype(np.float32)).to(DEV).requires_grad_(True)
-            bb = torch.zeros(N, device=DEV, requires_grad=True)
-            dy = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).to(DEV)
-            _, hW, hb = torch.autograd.grad(ops.linear(x, W, bb, 0), [x, W, bb], dy)
-            refW = (dy.double().t() @ x.detach().double()).cpu().numpy()
-            refb = dy.double().sum(0).cpu().numpy()
-            assert _rel(hW.cpu().numpy(), refW) < 2e-5 * TOL["x"], (M, N, K)
-            assert _rel(hb.cpu().numpy(), refb) < 2e-5, (M, N, K)
-    finally:
-        lib.rd_debug_set_wgrad_slabs(0)
+    for (M, N, K) in [(15360, 152, 272), (5000, 272, 152), (4099, 152, 152), (3001, 456, 152), (8704, 240, 240), (1025, 64, 48)]:
+        x = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(DEV).requires_grad_(True)
+        W = torch.from_numpy(rng.standard_normal((N, K)).astype(np.float32)).to(DEV).requires_grad_(True)
+        bb = torch.zeros(N, device=DEV, requires_grad=True)
+        dy = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).to(DEV)
+        _, hW, hb = torch.autograd.grad(ops.linear(x, W, bb, 0), [x, W, bb], dy)
+        refW = (dy.double().t() @ x.detach().double()).cpu().numpy()
+        refb = dy.double().sum(0).cpu().numpy()
+        assert _rel(hW.cpu().numpy(), refW) < 2e-5 * TOL["x"], (M, N, K)
+        assert _rel(hb.cpu().numpy(), refb) < 2e-5, (M, N, K)
 
 
 def test_static_train_step_dropout_varies_per_replay():
