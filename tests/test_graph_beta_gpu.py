@@ -91,3 +91,56 @@ def test_pruning_ties_keep_edge_order(monkeypatch):
                       return_attention_weights=True)
     assert np.array_equal(ei2.cpu().numpy(), ei_ref.numpy())
     assert np.abs(y.detach().cpu().numpy() - y_ref.numpy()).max() < 1e-5
+
+
+@pytest.mark.parametrize("n,T", [(36, 215), (17, 600), (34, 60)])
+def test_beta_operator_at_dataset_shapes(n, T, monkeypatch):
+    """The use_beta operator at the reference's three dataset shapes (P12: 36 sensors x 215 steps, PAM: 17 x 600, P19: 34 x 60) on a
+    sparse random structure (distinct edge scores: no pruning ties), forward and backward, against the restatement (O2, CPU
+    autograd).  P12 and PAM need the per-direction LDS layout / the backward's time chunks (the five [N,T] arrays of the first
+    version were 184 / 211 KB)."""
+    d = 4
+    K = T * d
+    op = Observation_progation(K, K, n_nodes=n, ob_dim=d, heads=1)
+    synth.fill_params_(op, seed=5)
+    rng = np.random.default_rng(n * 1000 + T)
+    adj = (rng.random((n, n)) < 0.3).astype(np.float32) * rng.uniform(0.5, 1.5, (n, n)).astype(np.float32)
+    ei, ew = O2.build_graph(adj)
+    x = torch.from_numpy((rng.standard_normal((n, K)) * 0.5).astype(np.float32))
+    p_t = torch.from_numpy(rng.standard_normal((T, 16)).astype(np.float32))
+    R = torch.from_numpy(rng.standard_normal((n, K)).astype(np.float32))
+    real_argsort = torch.argsort
+    monkeypatch.setattr(torch, "argsort", lambda t, *a, **k: real_argsort(t, *a, **dict(k, stable=True)))
+    params = [op.lin_value.weight, op.lin_value.bias, op.increase_dim.weight, op.increase_dim.bias, op.map_weights]
+    xr = x.clone().requires_grad_(True)
+    pr = [p.detach().clone().requires_grad_(True) for p in params]
+    y_ref, (ei_ref, a_ref) = O2.observation_propagation_beta(xr, p_t, torch.from_numpy(ei), torch.from_numpy(ew), *pr, d)
+    g_ref = torch.autograd.grad((y_ref * R).sum(), [xr] + pr)
+    monkeypatch.undo()
+    opd = op.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    y, (ei2, alpha) = opd(xd, p_t=p_t.to(DEV), edge_index=_t(ei), edge_weights=_t(ew), use_beta=True, return_attention_weights=True)
+    assert np.array_equal(ei2.cpu().numpy(), ei_ref.numpy())
+    assert np.abs(alpha.cpu().numpy().ravel() - a_ref.detach().numpy().ravel()).max() < 1e-6
+    assert np.abs(y.detach().cpu().numpy() - y_ref.detach().numpy()).max() < 2e-5
+    g = torch.autograd.grad((y * R.to(DEV)).sum(), [xd, opd.lin_value.weight, opd.lin_value.bias, opd.increase_dim.weight,
+                                                    opd.increase_dim.bias, opd.map_weights])
+    for name, got, ref in zip(["x", "Wv", "bv", "Wi", "bi", "map"], g, g_ref):
+        r = ref.numpy()
+        assert np.abs(got.cpu().numpy() - r).max() <= 5e-5 * np.abs(r).max() + 1e-9, (name, float(np.abs(got.cpu().numpy() - r).max() / np.abs(r).max()))
+
+
+def test_graph_beta_rejects_malformed_input():
+    n, T, d = 5, 4, 4
+    K = T * d
+    V = torch.zeros(2, n, K, device=DEV); H = torch.zeros(2, n, T * 32, device=DEV)
+    mw = torch.zeros(n, 16, device=DEV); pt = torch.zeros(1, T, 16, device=DEV)
+    ei = torch.tensor([[0, 1, 2], [1, 2, 7]], device=DEV)                      # endpoint 7 >= n
+    ew = torch.ones(1, 3, device=DEV)
+    with pytest.raises(IndexError):
+        ops.graph_beta(V, H, mw, pt, ei, ew, d)
+    ei_ok = torch.tensor([[0, 1, 2], [1, 2, 3]], device=DEV)
+    with pytest.raises(ValueError):
+        ops.graph_beta(V, H, torch.zeros(n, 8, device=DEV), pt, ei_ok, ew, d)  # map_weights not [N,16]
+    with pytest.raises(ValueError):
+        ops.graph_beta(V, H, mw, torch.zeros(3, T, 16, device=DEV), ei_ok, ew, d)   # p_t batch neither 1 nor B
