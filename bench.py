@@ -66,6 +66,45 @@ def parse():
     return ap.parse_args()
 
 
+def _use_token_plan(cfg):
+    """The step runs on the token plan (include/raindrop_hip.h) wherever raindrop_amd.step.TrainStep supports it: the isolated
+    roofline loops then measure the kernels on the same layout."""
+    K = cfg["max_len"] * cfg["d_ob"]
+    D = cfg["d_inp"] * cfg["d_ob"] + 16
+    return (os.environ.get("RD_TOKEN_PLAN", "1") != "0" and os.environ.get("RD_PRECISION", "bf16x3") == "bf16x3" and cfg["d_ob"] == 4
+            and cfg["d_inp"] <= 64 and K <= 240 and K % 16 == 0 and cfg["max_len"] <= 64 and (D + 31) // 32 == 5
+            and (cfg["nhid"] + 31) // 32 == 9)
+
+
+def _make_plan(shp, lengths):
+    """lengths -> token plan (one launch, outside the timed graphs: it is a function of `lengths` only and shared by every
+    kernel of the step)."""
+    import ctypes
+    from raindrop_amd import _lib
+    lib = _lib.load()
+    plan = torch.zeros(max(int(lib.rd_token_plan_bytes(ctypes.byref(shp))) // 4, 64), dtype=torch.int32, device=lengths.device)
+    _lib.call("rd_token_plan", ctypes.byref(shp), ctypes.c_void_p(lengths.data_ptr()), ctypes.c_void_p(plan.data_ptr()), None, 0,
+              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    return plan
+
+
+class _plan_scope:
+    """Registers a token plan for the calls enqueued inside (rd_set_token_plan is consumed at enqueue / capture time)."""
+    def __init__(self, plan):
+        self.plan = plan
+
+    def __enter__(self):
+        import ctypes
+        from raindrop_amd import _lib
+        if self.plan is not None:
+            _lib.call("rd_set_token_plan", ctypes.c_void_p(self.plan.data_ptr()))
+
+    def __exit__(self, *a):
+        from raindrop_amd import _lib
+        _lib.call("rd_set_token_plan", None)
+
+
 def k1_roofline(model, cfg, batch, reps=20):
     """Time K1 forward and backward in isolation (same tensors the training step uses) with HIP
     events recorded on the stream the kernels are launched on (torch's current stream)."""
@@ -82,14 +121,17 @@ def k1_roofline(model, cfg, batch, reps=20):
             0.2, 1234)
     dz = torch.randn(T, B, F * d + 16, device=dev)
     det = [t.detach() for t in args[:10]]
+    plan = _make_plan(shp, batch["lengths"]) if _use_token_plan(cfg) else None
     # the raw (autograd-free) entry points the autograd Function itself calls: nothing but the
     # library's launches lands in the captured graph
     def fwd_only():
-        return ops.sensor_stage_fwd_raw(*det, shp, 0.2, 1234)
+        with _plan_scope(plan):
+            return ops.sensor_stage_fwd_raw(*det, shp, 0.2, 1234)
 
     def fwd_bwd():
-        z, _, saved = ops.sensor_stage_fwd_raw(*det, shp, 0.2, 1234)
-        ops.sensor_stage_bwd_raw(det[0], det[5], det[6], det[8], det[4], saved, z, dz, shp, 0.2)
+        with _plan_scope(plan):
+            z, _, saved = ops.sensor_stage_fwd_raw(*det, shp, 0.2, 1234)
+            ops.sensor_stage_bwd_raw(det[0], det[5], det[6], det[8], det[4], saved, z, dz, shp, 0.2)
 
     def time_graph(fn, iters=50):
         """Capture `fn` into a hipGraph and time back-to-back replays with HIP events on the replay
@@ -117,10 +159,11 @@ def k1_roofline(model, cfg, batch, reps=20):
     fwd = time_graph(fwd_only)
     both = time_graph(fwd_bwd)
     bwd = both - fwd
-    return _roofline_dict(B, F, K, fwd, bwd, "hipGraph replays timed with HIP events")
+    return _roofline_dict(B, F, K, fwd, bwd, "hipGraph replays timed with HIP events" +
+                          ("; on the step's token plan (live rows only: %d of %d)" % (int(plan[0]), T * B) if plan is not None else ""))
 
 
-def encoder_roofline(model, cfg, B, iters=50):
+def encoder_roofline(model, cfg, B, iters=50, lengths=None):
     """Second roofline object: ONE TransformerEncoderLayer forward + backward (rd_encoder_layer_fwd + rd_encoder_layer_bwd
     of layer 0, 13 launches at P19: the other ~85 % of the step) as hipGraph replays timed with HIP events.
     Algorithmic bytes = what the layer must move under its saved-tensor contract, every tensor once per use: forward reads
@@ -140,17 +183,21 @@ def encoder_roofline(model, cfg, B, iters=50):
     g = [torch.empty_like(t) for t in w]
     wp = _lib.RdEncoderPtrs(*[t.data_ptr() for t in w]); gp = _lib.RdEncoderPtrs(*[t.data_ptr() for t in g])
     x = torch.randn(T, B, D, device=dev); y = torch.empty_like(x); dy = torch.randn_like(x); dx = torch.empty_like(x)
-    mask = torch.zeros(B, T, dtype=torch.bool, device=dev)
-    saved = torch.empty(lib.rd_encoder_layer_saved_bytes(sp), dtype=torch.uint8, device=dev)
-    ws = torch.empty(lib.rd_encoder_layer_workspace_bytes(sp), dtype=torch.uint8, device=dev)
+    if lengths is None:
+        lengths = torch.full((B,), T, dtype=torch.int64, device=dev)
+    mask = (torch.arange(T, device=dev)[None, :] >= lengths[:, None]).contiguous()
+    saved = torch.zeros(lib.rd_encoder_layer_saved_bytes(sp), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(lib.rd_encoder_layer_workspace_bytes(sp), dtype=torch.uint8, device=dev)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
+    plan = _make_plan(shp, lengths) if _use_token_plan(cfg) else None
 
     def fn():
         st = ops._stream()
-        _lib.call("rd_encoder_layer_fwd", sp, 0, P(x), P(mask), ctypes.byref(wp), 0.2, 1234, P(y), P(saved), saved.numel(),
-                  P(ws), ws.numel(), st)
-        _lib.call("rd_encoder_layer_bwd", sp, 0, P(x), P(mask), ctypes.byref(wp), 0.2, 1234, P(saved), saved.numel(), P(dy),
-                  P(dx), ctypes.byref(gp), P(ws), ws.numel(), st)
+        with _plan_scope(plan):
+            _lib.call("rd_encoder_layer_fwd", sp, 0, P(x), P(mask), ctypes.byref(wp), 0.2, 1234, P(y), P(saved), saved.numel(),
+                      P(ws), ws.numel(), st)
+            _lib.call("rd_encoder_layer_bwd", sp, 0, P(x), P(mask), ctypes.byref(wp), 0.2, 1234, P(saved), saved.numel(), P(dy),
+                      P(dx), ctypes.byref(gp), P(ws), ws.numel(), st)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -174,10 +221,15 @@ def encoder_roofline(model, cfg, B, iters=50):
     alg = M * (18 * D + 2 * nhid) * 4
     flops = 3 * 2.0 * M * (3 * D * D + D * D + 2 * D * nhid) + 3 * 4.0 * B * T * T * D     # dense fwd + 2x bwd; attention
     achieved = alg / (ms * 1e-3) / 1e9
+    traffic, traffic_src = _enc_pmc_traffic(B, cfg)
+    live = int(plan[0]) if plan is not None else M
     return {"bound": "hbm", "kernel": "one TransformerEncoderLayer fwd+bwd (rd_encoder_layer_fwd + rd_encoder_layer_bwd, layer 0 of 2; "
-                                       "hipGraph replays timed with HIP events)",
+                                       "hipGraph replays timed with HIP events)" +
+                                       ("; on the step's token plan: %d live rows of %d" % (live, M) if plan is not None else ""),
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": None, "algorithmic_bytes": alg, "us": round(ms * 1e3, 2),
+            "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": alg,
+            "algorithmic_bytes_live_rows": live * (18 * D + 2 * nhid) * 4,
+            "frac_live_rows": round(live * (18 * D + 2 * nhid) * 4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "us": round(ms * 1e3, 2),
             "mfma": {"algorithmic_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
                      "frac_issued": round(3 * flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 5)}}
 
@@ -261,6 +313,34 @@ def _pmc_traffic(B, F, K):
         return None, "unavailable: %r" % (e,)
 
 
+def _enc_pmc_traffic(B, cfg):
+    """HBM bytes of one encoder layer fwd+bwd from committed PMC passes over the graph step (raindrop_amd/enc_pmc_traffic.json, made
+    by tools/enc_traffic_json.py from separate FETCH_SIZE / WRITE_SIZE runs); valid for the P19 B=256 shape and the kernel sources
+    it was collected on."""
+    try:
+        with open(os.path.join(ROOT, "raindrop_amd", "enc_pmc_traffic.json")) as fh:
+            d = json.load(fh)
+        if (B, cfg["name"]) != (256, "P19"):
+            return None, "PMC passes exist for the P19 B=256 shape only"
+        if d.get("source_sha1") != enc_source_hash():
+            return None, "stale: the encoder kernel sources changed since the PMC passes (tools/step_pmc.sh + tools/enc_traffic_json.py)"
+        return int(d["bytes_per_layer"]), d["source"]
+    except Exception as e:
+        return None, "unavailable: %r" % (e,)
+
+
+ENC_SOURCES = ("rd_temporal.hip", "rd_rowgemm.hip", "rd_encfuse.hip", "rd_tile_wgrad.hip", "rd_plan.hip")
+
+
+def enc_source_hash():
+    import hashlib
+    h = hashlib.sha1()
+    for f in ENC_SOURCES:
+        with open(os.path.join(ROOT, "raindrop_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
 
 
@@ -295,6 +375,24 @@ def fp32_mode_ms(args):
            args.config, "--no-cpu-baseline", "--no-roofline"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env["RD_PRECISION"] = "fp32"
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+        for ln in res.stdout.splitlines():
+            if ln.startswith("{"):
+                return json.loads(ln)["ms_per_step"]
+    except Exception:
+        pass
+    return None
+
+
+def padded_layout_ms(args):
+    """ms per step of the same training step on the PADDED layout (RD_TOKEN_PLAN=0: every sample carried at max_len rows, the
+    padded rows computed and masked as in the reference), measured in a child process; None if the child fails."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "20", "--warmup", "5", "--batch", str(args.batch), "--config",
+           args.config, "--no-cpu-baseline", "--no-roofline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["RD_TOKEN_PLAN"] = "0"
     try:
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
         for ln in res.stdout.splitlines():
@@ -510,6 +608,7 @@ def main():
         return (time.perf_counter() - t0) / n
 
     step = eager_step
+    t_eager = t_graph = None
     if tstep is not None:
         # keep the graph only if it is actually faster here (e.g. two processes sharing one GPU in the
         # RD_BENCH_ONE_GPU test replay graphs pathologically slowly; one GPU per rank does not)
@@ -524,6 +623,8 @@ def main():
             step = graph_step
         else:
             tstep.close(); tstep = None
+    else:
+        t_eager = time_mode(eager_step)
 
     if args.k1_child:      # isolated process: K1 roofline only (hipGraph replays), one JSON object on stdout
         for _ in range(3):
@@ -531,7 +632,7 @@ def main():
         torch.cuda.synchronize()
         print("K1ROOFLINE " + json.dumps(k1_roofline(model, cfg, batch)), flush=True)
         try:
-            print("ENCROOFLINE " + json.dumps(encoder_roofline(model, cfg, args.batch)), flush=True)
+            print("ENCROOFLINE " + json.dumps(encoder_roofline(model, cfg, args.batch, lengths=batch["lengths"])), flush=True)
         except Exception as e:                                   # the K1 object must survive a failure here
             print("ENCROOFLINE_FAILED %r" % (e,), file=sys.stderr, flush=True)
         return
@@ -557,8 +658,11 @@ def main():
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
+        metric = ("samples/sec fwd+bwd, P19 34-sensor batch=256; % HBM roofline on msg-pass kernel" if (cfg["name"], B) == ("P19", 256)
+                  else "samples/sec fwd+bwd, %s %d-sensor batch=%d; %% HBM roofline on msg-pass kernel" % (cfg["name"], cfg["d_inp"], B))
+        token_plan_on = tstep is not None and getattr(tstep, "plan", None) is not None
         line = {
-            "metric": "samples/sec fwd+bwd, P19 34-sensor batch=256; % HBM roofline on msg-pass kernel",
+            "metric": metric,
             "value": round(world * B * args.steps / elapsed, 1), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if prec == "bf16" else "f32",
@@ -573,6 +677,13 @@ def main():
                        "batch_source": ("rd_batch_gather from a device-resident dataset (N=8192) every step" if feed_next
                                         else "one resident batch re-used (inputs in HBM before the timed region)"),
                        "arithmetic": ARITH[prec],
+                       # the drop-in path of code/Raindrop.py:319-323 (model.forward -> criterion -> loss.backward() through autograd, one
+                       # C-ABI call per operator, + flat.finish() + Adam), same batch, same kernels: what the unmodified script gets
+                       "eager_ms_per_step": None if t_eager is None else round(t_eager * 1e3, 4),
+                       "token_plan": ("on: the padding mask (code/models_rd.py:298-299) applied as a layout -- only the %d live (sample, step) rows "
+                                      "of %d are stored and processed; logits, loss and every gradient are the same function of the inputs "
+                                      "(tests/test_token_plan_gpu.py); config.padded_layout_ms_per_step is the same step with every padded row "
+                                      "computed and masked" % (int(tstep.plan[0]), B * cfg["max_len"])) if token_plan_on else "off (padded layout)",
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "grad_allreduce_bytes": flat.nbytes()},
         }
@@ -587,6 +698,8 @@ def main():
                 line["roofline"] = {"error": repr(e)[:200]}
             if world == 1:
                 line["config"]["fp32_mode_ms_per_step"] = fp32_mode_ms(args)
+                if token_plan_on:
+                    line["config"]["padded_layout_ms_per_step"] = padded_layout_ms(args)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, gs, B, args.cpu_reps)
             line["cpu_baseline"]["reference_o1"] = recorded_o1(cfg["name"], B)

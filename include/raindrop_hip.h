@@ -174,6 +174,13 @@ int rd_sensor_stage_fwd(const rd_shape* s, const float* src, const float* times,
                         const float* W2, const float* b2, const float* ssum, float p_drop, uint64_t seed,
                         float* z, uint8_t* mask, void* saved, size_t saved_bytes, void* stream);
 
+/* rd_sensor_stage_fwd after rd_step_prepare has written this step's operand tiles of W1, W2 into `saved`: same arguments, same
+ * results, no weight-split launch of its own. */
+int rd_sensor_stage_fwd_prepared(const rd_shape* s, const float* src, const float* times, const int64_t* lengths,
+                                 const float* timescales, const float* R_u, const float* W1, const float* b1,
+                                 const float* W2, const float* b2, const float* ssum, float p_drop, uint64_t seed,
+                                 float* z, uint8_t* mask, void* saved, size_t saved_bytes, void* stream);
+
 /* Backward of rd_msgpass_fwd.  dz is the gradient w.r.t. z (row stride ldz; only the first
  * F*d columns are read).  Writes dW1,db1,dW2,db2 and dR_u [F*d] (overwrite, not accumulate). */
 int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* R_u, const float* W1,
@@ -214,6 +221,16 @@ int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const float* x, const
 #define RD_LAYER_WEIGHTS_PREPARED 0x10000
 int rd_encoder_layer_prepare(const rd_shape* s, const rd_encoder_weights* w, void* saved, size_t saved_bytes,
                              void* stream);
+/* Every weight matrix of a training step -> operand tiles in ONE launch (the weights change once per step, in the optimizer):
+ * the `nlayers` (<= 2) encoder layers' into their `saved` buffers (what rd_encoder_layer_prepare does per layer) and the two
+ * lin_value matrices of the message-passing stage into its `saved` buffer (what rd_sensor_stage_fwd does first; pass NULL to
+ * skip).  Then call rd_encoder_layer_fwd(layer | RD_LAYER_WEIGHTS_PREPARED) and rd_sensor_stage_fwd_prepared.
+ * rd_step_prepare_covers reports (1 / 0) whether the encoder layers / the sensor stage of this shape take prepared tiles in the
+ * current arithmetic mode; where it says 0 the plain entry points must be used. */
+int rd_step_prepare(const rd_shape* s, int32_t nlayers, const rd_encoder_weights* const* w, void* const* enc_saved,
+                    const size_t* enc_saved_bytes, const float* W1, const float* W2, void* k1_saved, size_t k1_saved_bytes,
+                    void* stream);
+int rd_step_prepare_covers(const rd_shape* s, int32_t* encoder, int32_t* sensor_stage);
 /* Backward: dy -> dx and all 12 parameter gradients (overwritten). */
 int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const float* x, const uint8_t* mask,
                          const rd_encoder_weights* w, float p_drop, uint64_t seed, const void* saved,

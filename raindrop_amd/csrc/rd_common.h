@@ -43,6 +43,11 @@ const uint64_t* seed_cell();
 int precision();
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// one weight matrix W [N,K] (row-major fp32) -> native matrix-core operand tiles [ceil16(rows)/16][ceil32(cols)/32][hi, lo][64][8]
+// (rows = N, cols = K; transpose: rows = K, cols = N, i.e. the tiles of W^T); rd_rowgemm.hip: launch_wsplit_specs
+struct WsplitSpec { const float* W; int N, K, transpose; void* tiles; };
+int launch_wsplit_specs(int njobs, const WsplitSpec* specs, int nones, void* const* ones, hipStream_t st);
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

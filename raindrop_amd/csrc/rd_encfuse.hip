@@ -556,7 +556,9 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   lds_barrier();                                               // stage complete; everybody is done with lnred (it lives in the du planes)
   EFSTAMP(5);
   Panel<KCH> p1;
-  load_panel<KCH, 0, 5>(p1, a.W1t, ntD, wave, lane);           // first half of linear1^T's reduction; the rest behind the gate epilogue
+  // first half of linear1^T's reduction now, the rest behind the gate epilogue (the tall variant has no registers to carry a
+  // half panel through that epilogue: it requests the whole panel afterwards)
+  if constexpr (RT == 2) load_panel<KCH, 0, 5>(p1, a.W1t, ntD, wave, lane);
   {
     const float ks = a.p > 0.f ? inv_keep : 1.0f;
 #pragma unroll
@@ -588,7 +590,8 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
       rq[it] = *reinterpret_cast<const float4*>(a.ds2 + row * D + c);
     }
   }
-  load_panel<KCH, 5, KCH>(p1, a.W1t, ntD, wave, lane);
+  if constexpr (RT == 2) load_panel<KCH, 5, KCH>(p1, a.W1t, ntD, wave, lane);
+  else load_panel<KCH>(p1, a.W1t, ntD, wave, lane);
   EFSTAMP(6);
   lds_barrier();
   EFSTAMP(7);

@@ -248,10 +248,10 @@ extern "C" int rd_msgpass_fwd(const rd_shape* s, const float* src, const float* 
 
 // PE + padding mask + message passing in one call: on the fused path ONE launch (plus the weight
 // split) produces the whole [T,B,D] input of the temporal encoder and the mask.
-extern "C" int rd_sensor_stage_fwd(const rd_shape* s, const float* src, const float* times, const int64_t* lengths,
-                                   const float* timescales, const float* R_u, const float* W1, const float* b1,
-                                   const float* W2, const float* b2, const float* ssum, float p_drop, uint64_t seed,
-                                   float* z, uint8_t* mask, void* saved, size_t saved_bytes, void* stream) {
+static int sensor_stage_fwd_impl(const rd_shape* s, const float* src, const float* times, const int64_t* lengths,
+                                 const float* timescales, const float* R_u, const float* W1, const float* b1,
+                                 const float* W2, const float* b2, const float* ssum, float p_drop, uint64_t seed,
+                                 float* z, uint8_t* mask, void* saved, size_t saved_bytes, void* stream, bool prepared) {
   int rc = check_shape(s);
   if (rc) return rc;
   if (s->B == 0) return RD_OK;
@@ -265,7 +265,7 @@ extern "C" int rd_sensor_stage_fwd(const rd_shape* s, const float* src, const fl
     FusedSaved fv = carve_fused_saved(L, saved);
     RD_REQUIRE(saved_bytes >= fv.bytes, "saved buffer too small: %zu < %zu", saved_bytes, fv.bytes);
     hipStream_t st = (hipStream_t)stream;
-    if ((rc = fused_wprep(L, W1, W2, fv.wt, st))) return rc;
+    if (!prepared && (rc = fused_wprep(L, W1, W2, fv.wt, st))) return rc;
     return fused_msgpass_fwd(L, src, R_u, b1, b2, ssum, fv.wt, p_drop, seed, fv.tpX, fv.tpY1, fv.m1, fv.m2, fv.mx, z, ldz,
                              st, times, lengths, timescales, mask, s->d_pe);
   }
@@ -273,6 +273,39 @@ extern "C" int rd_sensor_stage_fwd(const rd_shape* s, const float* src, const fl
   if ((rc = rd_pe_mask(s, times, lengths, timescales, z, mask, stream))) return rc;
   return rd_msgpass_fwd(s, src, R_u, W1, b1, W2, b2, ssum, p_drop, seed, z, ldz, saved, saved_bytes, stream);
 }
+
+extern "C" int rd_sensor_stage_fwd(const rd_shape* s, const float* src, const float* times, const int64_t* lengths,
+                                   const float* timescales, const float* R_u, const float* W1, const float* b1,
+                                   const float* W2, const float* b2, const float* ssum, float p_drop, uint64_t seed,
+                                   float* z, uint8_t* mask, void* saved, size_t saved_bytes, void* stream) {
+  return sensor_stage_fwd_impl(s, src, times, lengths, timescales, R_u, W1, b1, W2, b2, ssum, p_drop, seed, z, mask, saved, saved_bytes,
+                               stream, false);
+}
+// the same after rd_step_prepare has written the operand tiles of W1, W2 into `saved` (this step's weights): no split launch here
+extern "C" int rd_sensor_stage_fwd_prepared(const rd_shape* s, const float* src, const float* times, const int64_t* lengths,
+                                            const float* timescales, const float* R_u, const float* W1, const float* b1,
+                                            const float* W2, const float* b2, const float* ssum, float p_drop, uint64_t seed,
+                                            float* z, uint8_t* mask, void* saved, size_t saved_bytes, void* stream) {
+  return sensor_stage_fwd_impl(s, src, times, lengths, timescales, R_u, W1, b1, W2, b2, ssum, p_drop, seed, z, mask, saved, saved_bytes,
+                               stream, true);
+}
+
+namespace rd {
+// the operand-tile jobs of the fused message-passing stage (W1, W2: forward and transposed orientation) for rd_step_prepare;
+// 0 when this shape / mode does not run the fused path (its weights are then read as fp32)
+int k1_weight_split_specs(const rd_shape* s, const float* W1, const float* W2, void* saved, size_t saved_bytes, WsplitSpec* out) {
+  if (!s || !fused_msgpass_ok(s) || !saved) return 0;
+  const k1::Layout L = k1::make_layout(s->B, s->T, s->F);
+  FusedSaved fv = carve_fused_saved(L, saved);
+  if (saved_bytes < fv.bytes) return 0;
+  const size_t per = (size_t)L.nct * k1::NKC * 2 * k1::TILE;           // bf16 elements of one (layer, orientation) tile set
+  __bf16* wt = (__bf16*)fv.wt;
+  const int K = L.K;
+  out[0] = WsplitSpec{W1, K, K, 0, wt}; out[1] = WsplitSpec{W1, K, K, 1, wt + per};
+  out[2] = WsplitSpec{W2, K, K, 0, wt + 2 * per}; out[3] = WsplitSpec{W2, K, K, 1, wt + 3 * per};
+  return 4;
+}
+}  // namespace rd
 
 extern "C" int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* R_u, const float* W1,
                               const float* W2, const float* ssum, float p_drop, const void* saved,

@@ -60,7 +60,8 @@ struct RowGemmArgs {
 
 // one weight matrix -> hi/lo planes; transpose != 0 writes split(W^T): rows k, cols n
 struct SplitJob { const float* W; int N, K, transpose; __bf16* hi; __bf16* lo; int rows, cols_p; };
-struct SplitJobs { SplitJob j[8]; int n; __bf16* ones; };   // ones: constant tiles of the weight-gradient stream (or null)
+constexpr int WS_MAXJOBS = 24, WS_MAXONES = 4;
+struct SplitJobs { SplitJob j[WS_MAXJOBS]; int n; __bf16* ones[WS_MAXONES]; };   // ones: constant tiles of the weight-gradient streams (or null)
 
 // Output: NATIVE MFMA operand tiles [ntile = rows/16][kc = cols_p/32][hi, lo][64 lanes][8] (one contiguous kilobyte per
 // wave-load; rd_k1_layout.h has the measurement: 61 B/clk/CU against 16 B/clk for a row-major plane).  `hi` is the
@@ -71,14 +72,15 @@ __global__ __launch_bounds__(256) void k_wsplit(SplitJobs jobs) {
   const int ntile = jb.rows >> 4, nkc = jb.cols_p >> 5;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, G = lane >> 4;
   const int src_rows = jb.transpose ? jb.K : jb.N, src_cols = jb.transpose ? jb.N : jb.K;
-  if (jobs.ones && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && wave < WS_MAXONES && jobs.ones[wave]) {
     // [ones hi: column 0 = 1][zeros][zeros] (rd_tile_wgrad.hip: the B operand whose output column is the bias gradient)
     bf16x8 o, z;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { o[e] = (__bf16)(c == 0 ? 1.f : 0.f); z[e] = (__bf16)0.f; }
-    *reinterpret_cast<bf16x8*>(jobs.ones + lane * 8) = o;
-    *reinterpret_cast<bf16x8*>(jobs.ones + 512 + lane * 8) = z;
-    *reinterpret_cast<bf16x8*>(jobs.ones + 1024 + lane * 8) = z;
+    __bf16* on = jobs.ones[wave];
+    *reinterpret_cast<bf16x8*>(on + lane * 8) = o;
+    *reinterpret_cast<bf16x8*>(on + 512 + lane * 8) = z;
+    *reinterpret_cast<bf16x8*>(on + 1024 + lane * 8) = z;
   }
   for (int t = blockIdx.x * 4 + wave; t < ntile * nkc; t += gridDim.x * 4) {
     const int j = t / nkc, kc = t - j * nkc;
@@ -433,18 +435,30 @@ bool rowgemm_ok(int N, int K, long lda, long ldc) {
 size_t rowgemm_plane_elems(int rows, int cols) { return (size_t)((rows + 15) / 16 * 16) * ((cols + 31) / 32 * 32); }
 
 // split up to 8 weight matrices with one launch; job i: W [N_i, K_i] -> planes at hi_i / lo_i
-int launch_wsplit(int njobs, const float* const* W, const int* N, const int* K, const int* transpose, __bf16* const* hi,
-                  __bf16* const* lo, void* ones, hipStream_t st) {
+// up to WS_MAXJOBS matrices and WS_MAXONES constant-tile buffers in ONE launch (a whole training step's weights: rd_step_prepare)
+int launch_wsplit_specs(int njobs, const WsplitSpec* specs, int nones, void* const* ones, hipStream_t st) {
+  if (njobs < 1 || njobs > WS_MAXJOBS || nones < 0 || nones > WS_MAXONES) return fail(RD_EINVAL, "wsplit: %d jobs, %d constant tiles", njobs, nones);
   SplitJobs jobs{};
-  jobs.n = njobs; jobs.ones = (__bf16*)ones;
+  jobs.n = njobs;
+  for (int i = 0; i < nones; ++i) jobs.ones[i] = (__bf16*)ones[i];
   for (int i = 0; i < njobs; ++i) {
     SplitJob& j = jobs.j[i];
-    j.W = W[i]; j.N = N[i]; j.K = K[i]; j.transpose = transpose[i]; j.hi = hi[i]; j.lo = lo[i];
-    const int rows = transpose[i] ? K[i] : N[i], cols = transpose[i] ? N[i] : K[i];
+    j.W = specs[i].W; j.N = specs[i].N; j.K = specs[i].K; j.transpose = specs[i].transpose; j.hi = (__bf16*)specs[i].tiles; j.lo = nullptr;
+    const int rows = j.transpose ? j.K : j.N, cols = j.transpose ? j.N : j.K;
     j.rows = (rows + 15) / 16 * 16; j.cols_p = (cols + 31) / 32 * 32;
   }
   hipLaunchKernelGGL(k_wsplit, dim3(64, njobs), dim3(256), 0, st, jobs);
   return check_launch("k_wsplit");
+}
+
+int launch_wsplit(int njobs, const float* const* W, const int* N, const int* K, const int* transpose, __bf16* const* hi,
+                  __bf16* const* lo, void* ones, hipStream_t st) {
+  (void)lo;
+  WsplitSpec specs[WS_MAXJOBS];
+  if (njobs > WS_MAXJOBS) return fail(RD_EINVAL, "wsplit: too many jobs");
+  for (int i = 0; i < njobs; ++i) specs[i] = WsplitSpec{W[i], N[i], K[i], transpose[i], hi[i]};
+  void* on[1] = {ones};
+  return launch_wsplit_specs(njobs, specs, ones ? 1 : 0, on, st);
 }
 
 // 32-row workgroups (480 instead of 240 at P19: two or more per CU, so one's loads overlap another's MFMAs instead of every

@@ -1941,15 +1941,20 @@ extern "C" size_t rd_encoder_layer_workspace_bytes(const rd_shape* s) {
 extern "C" void rd_debug_set_attn_stamps(void* p) { g_attn_stamps = (unsigned long long*)p; }   // not part of the ABI
 
 // weights of a layer -> native bf16 hi/lo operand tiles (both orientations) + the constant tiles of the weight-gradient stream
-static int enc_prepare(const EncDims& e, const rd_encoder_weights* w, const EncSaved& v, bool tw, hipStream_t st) {
+static int enc_split_specs(const EncDims& e, const rd_encoder_weights* w, const EncSaved& v, WsplitSpec* out) {
   const float* Ws[8] = {w->in_proj_w, w->out_proj_w, w->lin1_w, w->lin2_w, w->out_proj_w, w->lin2_w, w->lin1_w, w->in_proj_w};
   const int Ns[8] = {3 * e.D, e.D, e.nhid, e.D, e.D, e.D, e.nhid, 3 * e.D};
   const int Ks[8] = {e.D, e.D, e.D, e.nhid, e.D, e.nhid, e.D, e.D};
   const int Tr[8] = {0, 0, 0, 0, 1, 1, 1, 1};
-  __bf16* his[8]; __bf16* los[8];
-  for (int i = 0; i < 8; ++i) { his[i] = v.pl[i][0]; los[i] = v.pl[i][1]; }
   const int njobs = rowgemm_ok(e.D, 3 * e.D, 3 * e.D, e.D) ? 8 : 7;
-  return launch_wsplit(njobs, Ws, Ns, Ks, Tr, his, los, tw ? v.ones : nullptr, st);
+  for (int i = 0; i < njobs; ++i) out[i] = WsplitSpec{Ws[i], Ns[i], Ks[i], Tr[i], v.pl[i][0]};
+  return njobs;
+}
+static int enc_prepare(const EncDims& e, const rd_encoder_weights* w, const EncSaved& v, bool tw, hipStream_t st) {
+  WsplitSpec specs[8];
+  const int n = enc_split_specs(e, w, v, specs);
+  void* on[1] = {v.ones};
+  return launch_wsplit_specs(n, specs, tw ? 1 : 0, on, st);
 }
 
 extern "C" int rd_encoder_layer_prepare(const rd_shape* s, const rd_encoder_weights* w, void* saved, size_t saved_bytes,
@@ -1965,6 +1970,49 @@ extern "C" int rd_encoder_layer_prepare(const rd_shape* s, const rd_encoder_weig
                   rowgemm_ok(e.nhid, e.D, e.D, e.nhid) && rowgemm_ok(e.D, e.nhid, e.nhid, e.D);
   if (!rg) return RD_OK;                             // the tiled path reads the fp32 weights directly
   return enc_prepare(e, w, v, tile_path(e), (hipStream_t)stream);
+}
+
+namespace rd {
+int k1_weight_split_specs(const rd_shape* s, const float* W1, const float* W2, void* saved, size_t saved_bytes, WsplitSpec* out);
+bool fused_msgpass_ok(const rd_shape* s);
+}
+
+// Every weight matrix of a training step -> matrix-core operand tiles in ONE launch: the encoder layers' (what
+// rd_encoder_layer_prepare does per layer) and the message-passing stage's (what rd_sensor_stage_fwd does first).
+extern "C" int rd_step_prepare(const rd_shape* s, int32_t nlayers, const rd_encoder_weights* const* w, void* const* enc_saved,
+                               const size_t* enc_saved_bytes, const float* W1, const float* W2, void* k1_saved, size_t k1_saved_bytes,
+                               void* stream) {
+  int rc = check_enc(s);
+  if (rc) return rc;
+  if (s->B == 0) return RD_OK;
+  RD_REQUIRE(nlayers >= 0 && nlayers <= 2 && (nlayers == 0 || (w && enc_saved && enc_saved_bytes)), "rd_step_prepare: 0..2 encoder layers");
+  const EncDims e = enc_dims(s);
+  const bool rg = rowgemm_ok(3 * e.D, e.D, e.D, 3 * e.D) && rowgemm_ok(e.D, e.D, e.D, e.D) &&
+                  rowgemm_ok(e.nhid, e.D, e.D, e.nhid) && rowgemm_ok(e.D, e.nhid, e.nhid, e.D);
+  const bool tw = rg && tile_path(e);
+  WsplitSpec specs[24]; void* ones[4]; int n = 0, no = 0;
+  if (rg)
+    for (int l = 0; l < nlayers; ++l) {
+      RD_REQUIRE(w[l] && enc_saved[l], "NULL tensor");
+      EncSaved v = carve_saved(e, enc_saved[l]);
+      RD_REQUIRE(enc_saved_bytes[l] >= v.bytes, "saved buffer too small");
+      n += enc_split_specs(e, w[l], v, specs + n);
+      if (tw) ones[no++] = v.ones;
+    }
+  if (W1 && W2 && k1_saved) n += k1_weight_split_specs(s, W1, W2, k1_saved, k1_saved_bytes, specs + n);
+  if (n == 0) return RD_OK;
+  return launch_wsplit_specs(n, specs, no, ones, (hipStream_t)stream);
+}
+// 1 if rd_step_prepare covers the encoder layers / the message-passing stage of this shape in the current arithmetic mode (then
+// pass RD_LAYER_WEIGHTS_PREPARED / call rd_sensor_stage_fwd_prepared), else the per-call splits must run
+extern "C" int rd_step_prepare_covers(const rd_shape* s, int32_t* encoder, int32_t* sensor_stage) {
+  if (check_enc(s)) return RD_EINVAL;
+  const EncDims e = enc_dims(s);
+  const bool rg = rowgemm_ok(3 * e.D, e.D, e.D, 3 * e.D) && rowgemm_ok(e.D, e.D, e.D, e.D) &&
+                  rowgemm_ok(e.nhid, e.D, e.D, e.nhid) && rowgemm_ok(e.D, e.nhid, e.nhid, e.D);
+  if (encoder) *encoder = rg ? 1 : 0;
+  if (sensor_stage) *sensor_stage = fused_msgpass_ok(s) ? 1 : 0;
+  return RD_OK;
 }
 
 extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const float* x, const uint8_t* mask,

@@ -68,6 +68,14 @@ class TrainStep:
         self.plan = None
         if self._want_plan and self.head_fused and self._plan_supported():
             self.plan = torch.zeros(max(int(self.lib.rd_token_plan_bytes(self.sp)) // 4, 64), dtype=torch.int32, device=self.dev)
+        # all weight splits of the step in one launch (rd_step_prepare) where the shape takes prepared tiles
+        enc_ok, k1_ok = ctypes.c_int32(0), ctypes.c_int32(0)
+        _lib.call("rd_step_prepare_covers", self.sp, ctypes.byref(enc_ok), ctypes.byref(k1_ok))
+        one = os.environ.get("RD_STEP_PREPARE", "1") != "0"
+        self.prep_enc, self.prep_k1 = bool(enc_ok.value) and one, bool(k1_ok.value) and one
+        self._prep_w = (ctypes.POINTER(_lib.RdEncoderPtrs) * self.nl)(*[ctypes.pointer(w) for w in self.enc_w])
+        self._prep_saved = (ctypes.c_void_p * self.nl)(*[t.data_ptr() for t in self.enc_saved])
+        self._prep_bytes = (ctypes.c_size_t * self.nl)(*[t.numel() for t in self.enc_saved])
         self._ptrs = self._param_ptrs()                          # the captured graph / cached structs hold these addresses
         self.graph = None
         if use_graph:
@@ -170,11 +178,14 @@ class TrainStep:
         W2, b2 = P["ob_propagation_layer2.lin_value.weight"], P["ob_propagation_layer2.lin_value.bias"]
         ssum = self.graph_info["ssum"]
         # ---------------- forward ----------------
-        c("rd_sensor_stage_fwd", sp, _p(b["src"]), _p(b["times"]), _p(b["lengths"]), _p(self.ts), _p(P["R_u"]), _p(W1),
+        if self.prep_enc or self.prep_k1:
+            c("rd_step_prepare", sp, self.nl if self.prep_enc else 0, self._prep_w, self._prep_saved, self._prep_bytes,
+              _p(W1) if self.prep_k1 else None, _p(W2) if self.prep_k1 else None, _p(self.k1_saved), self.k1_saved.numel(), st)
+        c("rd_sensor_stage_fwd_prepared" if self.prep_k1 else "rd_sensor_stage_fwd", sp, _p(b["src"]), _p(b["times"]), _p(b["lengths"]), _p(self.ts), _p(P["R_u"]), _p(W1),
           _p(b1), _p(W2), _p(b2), _p(ssum), self.p_drop, self.seed, _p(self.z), _p(self.mask), _p(self.k1_saved),
           self.k1_saved.numel(), st)
         for i in range(self.nl):
-            c("rd_encoder_layer_fwd", sp, i, _p(self.x[i]), _p(self.mask), ctypes.byref(self.enc_w[i]), self.p_drop,
+            c("rd_encoder_layer_fwd", sp, i | (0x10000 if self.prep_enc else 0), _p(self.x[i]), _p(self.mask), ctypes.byref(self.enc_w[i]), self.p_drop,
               self.seed, _p(self.x[i + 1]), _p(self.enc_saved[i]), self.enc_saved[i].numel(), _p(self.enc_ws),
               self.enc_ws.numel(), st)
         cur = self.dx[0]

@@ -7,8 +7,8 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$1; mkdir -p $out
 ref=$GRAFT_REPO_ROOT/_ab/reference_stage
 sha256sum $ref/code/Raindrop.py $ref/code/utils_rd.py > $out/reference_files.sha256
 cd $GRAFT_REPO_ROOT
-( time python -m raindrop_amd.compat_runner --dataset P19 --samples ${2:-2400} --root /tmp/ws_p19 --reference $ref ) > $out/P19_script.log 2>&1
+[ "${2:-2400}" != "0" ] && ( time python -m raindrop_amd.compat_runner --dataset P19 --samples ${2:-2400} --root /tmp/ws_p19 --reference $ref ) > $out/P19_script.log 2>&1
 echo "P19 rc=$?" >> $out/P19_script.log
-( time python -m raindrop_amd.compat_runner --dataset PAM --samples ${3:-320} --root /tmp/ws_pam --reference $ref ) > $out/PAM_script.log 2>&1
+( time python -m raindrop_amd.compat_runner --dataset PAM --samples ${3:-640} --root /tmp/ws_pam --reference $ref ) > $out/PAM_script.log 2>&1
 echo "PAM rc=$?" >> $out/PAM_script.log
 tail -5 $out/P19_script.log; tail -5 $out/PAM_script.log
