@@ -36,14 +36,14 @@ def _stamp(src):
     return h.hexdigest()
 
 
-def _compile(src, force):
-    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+def _compile(src, force, objdir=None, extra=()):
+    obj = os.path.join(objdir or OBJ, os.path.basename(src)[:-4] + ".o")
     stamp_file = obj + ".stamp"
-    stamp = _stamp(src)
+    stamp = _stamp(src) + " ".join(extra)
     if not force and os.path.exists(obj) and os.path.exists(stamp_file) \
             and open(stamp_file).read() == stamp:
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+    cmd = [HIPCC] + FLAGS + list(extra) + ["-c", src, "-o", obj]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, res.stdout, res.stderr))
@@ -72,5 +72,25 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_variant(name, extra):
+    """A/B build of the WHOLE library with extra hipcc flags -> raindrop_amd/_ab/lib_<name>.so (git-ignored, travels with gpurun);
+    use as RD_LIB_PATH=raindrop_amd/_ab/lib_<name>.so.  `tools/ab_build.sh` is the one-file form."""
+    objdir = os.path.join(PKG, "_ab", name)
+    os.makedirs(objdir, exist_ok=True)
+    srcs = sources()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = [o for o, _ in ex.map(lambda s: _compile(s, False, objdir, tuple(extra)), srcs)]
+    lib = os.path.join(PKG, "_ab", "lib_%s.so" % name)
+    res = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("link failed:\n%s\n%s" % (res.stdout, res.stderr))
+    print(lib)
+    return lib
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--variant" in sys.argv:                     # python -m raindrop_amd.build --variant philox -DRD_RNG_PHILOX
+        i = sys.argv.index("--variant")
+        build_variant(sys.argv[i + 1], sys.argv[i + 2:])
+    else:
+        build(force="--force" in sys.argv)

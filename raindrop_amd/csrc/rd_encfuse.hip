@@ -193,7 +193,9 @@ __device__ __forceinline__ float4 ln_row(float4 t, const float4& res, const floa
   return o;
 }
 
-template <int RT>
+// DC / HC: model width and FFN width as compile-time constants (0: read from the arguments).  These chains are instruction-issue
+// bound; with the widths known the row / quad index arithmetic (64-bit multiplies at quarter rate, divisions) folds away.
+template <int RT, int DC, int HC>
 __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned char* esm, int M) {
   constexpr int ROWS = 16 * RT;
   __bf16* Ah = reinterpret_cast<__bf16*>(esm);                 // [ROWS][LDD]: attn, then x1
@@ -206,7 +208,7 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
   float* cst = stage + ROWS * STG;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * ROWS;
-  const int D = a.D, H = a.H;
+  const int D = DC ? DC : a.D, H = HC ? HC : a.H;
   const int ntD = (D + 15) >> 4, ntH = (H + 15) >> 4;
   if (m0 >= M) {
     zero_dead_groups<RT>(a.xt_attn, ntD, m0, M, tid); zero_dead_groups<RT>(a.xt_x1, ntD, m0, M, tid); zero_dead_groups<RT>(a.xt_h, ntH, m0, M, tid);
@@ -381,12 +383,13 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
   if (a.stamps && tid == 0) { a.stamps[256 + 1024 + 2 * blockIdx.x] = wall_clock64(); a.stamps[256 + 1024 + 2 * blockIdx.x + 1] = clock64(); }
 }
 
+template <int DC, int HC>
 __global__ __launch_bounds__(EF_THR) void k_enc_post_fwd(PostFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
   int M = a.M;
   if (a.mlive) M = min(M, __builtin_amdgcn_readfirstlane(*a.mlive));
-  if (pick_rt(M, a.ncu) == 3) post_fwd_body<3>(a, esm, M);
-  else post_fwd_body<2>(a, esm, M);
+  if (pick_rt(M, a.ncu) == 3) post_fwd_body<3, DC, HC>(a, esm, M);
+  else post_fwd_body<2, DC, HC>(a, esm, M);
 }
 
 constexpr size_t post_fwd_lds(int rt) {
@@ -458,7 +461,7 @@ __device__ __forceinline__ void lnb_rows(const float4 (&dyq)[RT], const float4 (
   }
 }
 
-template <int RT>
+template <int RT, int DC, int HC>
 __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char* esm, int M) {
   constexpr int ROWS = 16 * RT;
   __bf16* Ah = reinterpret_cast<__bf16*>(esm);                 // [ROWS][LDD]: df, then dout
@@ -473,7 +476,7 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   static_assert((size_t)EF_WV * 2 * KPD * 4 <= (size_t)2 * 16 * 2 * LDH * 2, "lnred must fit inside the du planes");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * ROWS;
-  const int D = a.D, H = a.H;
+  const int D = DC ? DC : a.D, H = HC ? HC : a.H;
   const int ntD = (D + 15) >> 4, ntH = (H + 15) >> 4;
   if (m0 >= M) {                                               // no live row: the partial sums of this block are zero
     for (int i = tid; i < 2 * D; i += EF_THR) { a.part2[(long)blockIdx.x * 2 * D + i] = 0.f; a.part1[(long)blockIdx.x * 2 * D + i] = 0.f; }
@@ -652,12 +655,19 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   EFSTAMP(14);
 }
 
+template <int DC, int HC>
 __global__ __launch_bounds__(EF_THR) void k_enc_pre_bwd(PreBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
   int M = a.M;
   if (a.mlive) M = min(M, __builtin_amdgcn_readfirstlane(*a.mlive));
-  if (pick_rt(M, a.ncu) == 3) pre_bwd_body<3>(a, esm, M);
-  else pre_bwd_body<2>(a, esm, M);
+  if (pick_rt(M, a.ncu) == 3) pre_bwd_body<3, DC, HC>(a, esm, M);
+  else pre_bwd_body<2, DC, HC>(a, esm, M);
+}
+
+// RD_ENC_SPECIALIZE=0: the P19 widths on the runtime-width instantiation (A/B and the parity test of the two)
+static bool ef_specialize(int D, int H) {
+  const char* e = getenv("RD_ENC_SPECIALIZE");
+  return D == 152 && H == 272 && !(e && atoi(e) == 0);
 }
 
 constexpr size_t pre_bwd_lds(int rt) {
@@ -703,8 +713,13 @@ int launch_enc_post_fwd(long M, int D, int H, const float* attn, const float* x,
   a.M = (int)M; a.D = D; a.H = H; a.ncu = ef_ncu(); a.p = p; a.seed = seed; a.site_ao = site_ao; a.site_fh = site_fh; a.site_fo = site_fo;
   a.seed_cell = seed_cell(); a.mlive = mlive; a.one = precision() == RD_PREC_BF16; a.stamps = g_ef_stamps;
   constexpr size_t lds = post_fwd_lds(EF_RTMAX);
-  RD_LDS_ATTR(k_enc_post_fwd, lds);
-  hipLaunchKernelGGL(k_enc_post_fwd, dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a);
+  if (ef_specialize(D, H)) {
+    RD_LDS_ATTR((k_enc_post_fwd<152, 272>), lds);
+    hipLaunchKernelGGL((k_enc_post_fwd<152, 272>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a);
+  } else {
+    RD_LDS_ATTR((k_enc_post_fwd<0, 0>), lds);
+    hipLaunchKernelGGL((k_enc_post_fwd<0, 0>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a);
+  }
   return check_launch("k_enc_post_fwd");
 }
 
@@ -722,8 +737,13 @@ int launch_enc_pre_bwd(long M, int D, int H, const float* dy, const float* s2, c
   a.M = (int)M; a.D = D; a.H = H; a.ncu = ef_ncu(); a.p = p; a.seed = seed; a.site_fo = site_fo; a.site_ao = site_ao;
   a.seed_cell = seed_cell(); a.mlive = mlive; a.one = precision() == RD_PREC_BF16; a.stamps = g_ef_stamps;
   constexpr size_t lds = pre_bwd_lds(EF_RTMAX);
-  RD_LDS_ATTR(k_enc_pre_bwd, lds);
-  hipLaunchKernelGGL(k_enc_pre_bwd, dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a);
+  if (ef_specialize(D, H)) {
+    RD_LDS_ATTR((k_enc_pre_bwd<152, 272>), lds);
+    hipLaunchKernelGGL((k_enc_pre_bwd<152, 272>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a);
+  } else {
+    RD_LDS_ATTR((k_enc_pre_bwd<0, 0>), lds);
+    hipLaunchKernelGGL((k_enc_pre_bwd<0, 0>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a);
+  }
   return check_launch("k_enc_pre_bwd");
 }
 

@@ -104,8 +104,10 @@ __global__ __launch_bounds__(256) void k_pe_mask(const float* __restrict__ times
   float* row = z + i * D + Dm;
   for (int k = 0; k < H; ++k) {
     const float a = tm / ts[k];
-    row[k] = sinf(a);
-    row[H + k] = cosf(a);
+    float sn, cs;
+    sincosf(a, &sn, &cs);            // same call as the fused stage (rd_msgpass_fused.hip): the two paths stay bit-equal
+    row[k] = sn;
+    row[H + k] = cs;
   }
   mask[(long)b * T + t] = (uint8_t)((int64_t)t >= lengths[b]);
 }

@@ -32,6 +32,12 @@
 #include "rd_plan.h"
 #include "rd_rng.h"
 
+// RD_ABL: bit mask of phases compiled OUT (timing ablations, tools/k1_ablate.sh; results are garbage):
+//   1 weight panel loads   2 MFMAs   4 row-tile exports   8 z scatter + PE / dR_u tail   16 embedding / dz gather arithmetic
+#ifndef RD_ABL
+#define RD_ABL 0
+#endif
+
 namespace rd {
 namespace {
 
@@ -90,14 +96,32 @@ __device__ __forceinline__ Tok tok_of(const FusedArgs& a) {
   return k;
 }
 
+// Shape numbers of a launch.  The kernels are instantiated with the sensor and step counts as COMPILE-TIME constants for the shapes
+// that matter (P19: F = 34, T = 60) and with FC = TC = 0 (read from the arguments) for every other shape of the envelope: these
+// kernels are instruction-issue bound, and a quarter of the generic instantiation's instructions was index arithmetic on runtime
+// shape numbers (integer divisions, 32-bit multiplies at quarter rate) that folds to shifts and adds here.
+// A specialised instantiation also fixes ldz = 4 F + 16 and d_pe = 16 (the model's layout, code/models_rd.py:216,354); the
+// host picks it only then, and only while every element index of the launch fits 31 bits (the index arithmetic is 32-bit there).
+struct Dim { int B, T, F, K, nct, q, rem, per, ldz, H; };
+template <int FC, int TC>
+__device__ __forceinline__ Dim dims_of(const FusedArgs& a) {
+  Dim d;
+  d.B = a.B; d.T = TC ? TC : a.T; d.F = FC ? FC : a.F;
+  d.K = 4 * d.T; d.nct = d.K / 16; d.q = d.F / 32; d.rem = d.F % 32; d.per = d.rem ? 32 / d.rem : 1;
+  d.ldz = FC ? 4 * FC + 16 : a.ldz; d.H = FC ? 8 : (a.d_pe >> 1);
+  return d;
+}
+// 24-bit multiply (full rate; v_mul_lo_u32 issues at quarter rate): both factors < 2^24, product < 2^32
+__device__ __forceinline__ unsigned m24(unsigned x, unsigned y) { return __umul24(x, y); }
+
 #define RD_STAMP(i)                                                                              \
   do {                                                                                           \
     if (a.stamps && blockIdx.x < 4 && (threadIdx.x & 63) == 0)                                   \
       a.stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = clock64();                    \
   } while (0)
 
-__device__ __forceinline__ const __bf16* wtiles(const FusedArgs& a, int layer, int orient) {
-  return a.wt + (size_t)((layer * 2 + orient) * a.nct) * (NKC * 2 * TILE);
+__device__ __forceinline__ const __bf16* wtiles(const FusedArgs& a, const Dim& d, int layer, int orient) {
+  return a.wt + (size_t)((layer * 2 + orient) * d.nct) * (NKC * 2 * TILE);
 }
 
 // bulk-output stores (row tiles, z).  A write-through (sc1, inline asm) variant was measured: no gain at the kernel
@@ -158,6 +182,7 @@ struct Panel {
 // reduction steps [KC0, KC1) of both column tiles
 template <int KC0, int KC1>
 __device__ __forceinline__ void load_panel_kc(Panel& p, const __bf16* __restrict__ wl, int nct, int wave, int lane) {
+  if (RD_ABL & 1) return;
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
     const int j = wave + NWAVE * jj;
@@ -220,6 +245,7 @@ template <int RT, int KC0, int KC1>
 __device__ __forceinline__ void mma_steps(f32x4 (&acc)[NJ][RT], const __bf16* Ah, const __bf16* Al,
                                           const Panel& p, int lane, int kclim = NKC) {
   const int aoff = (lane & 15) * LDX + 8 * (lane >> 4);
+  if (RD_ABL & 2) return;
 #pragma unroll
   for (int kc = KC0; kc < KC1; ++kc) {
     if (kc >= kclim) break;
@@ -306,12 +332,13 @@ __device__ __forceinline__ __bf16* tp_tile(__bf16* tp, int nct, int s, int j) {
 // store per part; consecutive lanes write consecutive 16-byte slots of a tile.
 // jlim / jlimL: only column tiles j < jlim of the main tiles and j < jlimL of the leftover rows are written (the consumer
 // reads no further: rd_msgpass_dw.hip skips the column blocks that are all padding for a sample).
-__device__ __forceinline__ void tstore_stage(const float* S, __bf16* tp, const FusedArgs& a, int b, int tid, int jlim, int jlimL) {
+__device__ __forceinline__ void tstore_stage(const float* S, __bf16* tp, const Dim& a, int b, int tid, int jlim, int jlimL) {
+  if (RD_ABL & 4) return;
   const int nct = a.nct;
   const int nslot = a.q * jlim * 64;
   for (int idx = tid; idx < nslot; idx += NTHR) {
     const int L = idx & 63, t2 = idx >> 6;
-    const int m = t2 / jlim, j = t2 - m * jlim;
+    const int m = a.q == 1 ? 0 : t2 / jlim, j = t2 - m * jlim;
     const float* p = S + (32 * m + 8 * (L >> 4)) * LDS_F + 16 * j + (L & 15);
     float v[8];
 #pragma unroll
@@ -325,30 +352,34 @@ __device__ __forceinline__ void tstore_stage(const float* S, __bf16* tp, const F
   if (a.rem) {
     const int s = a.B * a.q + b / a.per, slot = b % a.per;
     const int KL = 16 * jlimL;
-    for (int idx = tid; idx < a.rem * KL; idx += NTHR) {
-      const int li = idx / KL, n = idx - li * KL;
-      const float x = S[(32 * a.q + li) * LDS_F + n];
-      const int r = slot * a.rem + li;
-      const __bf16 h = (__bf16)x, l = (__bf16)(x - (float)h);
-      __bf16* dst = tp_tile(tp, nct, s, n >> 4) + ((n & 15) + 16 * (r >> 3)) * 8 + (r & 7);
-      st2(dst, h); st2(dst + TILE, l);
+    // thread -> (leftover row li = tid / 256 + 4 pass, column n = tid % 256): K <= 256, no division
+    for (int li = tid >> 8; li < a.rem; li += NTHR >> 8) {
+      const int n = tid & 255;
+      if (n < KL) {
+        const float x = S[(32 * a.q + li) * LDS_F + n];
+        const int r = slot * a.rem + li;
+        const __bf16 h = (__bf16)x, l = (__bf16)(x - (float)h);
+        __bf16* dst = tp_tile(tp, nct, s, n >> 4) + ((n & 15) + 16 * (r >> 3)) * 8 + (r & 7);
+        st2(dst, h); st2(dst + TILE, l);
+      }
     }
   }
 }
 
 // positions of a leftover tile that no sample covers: zeros, written by the workgroup whose sample sits at position 0
-__device__ __forceinline__ void tzero_uncovered(__bf16* tp, const FusedArgs& a, int b, int tid) {
+__device__ __forceinline__ void tzero_uncovered(__bf16* tp, const Dim& a, int b, int tid) {
   if (a.rem == 0 || (b % a.per) != 0) return;
   const int first = b / a.per * a.per;
   const int nvalid = min(a.per, a.B - first);
   const int r0 = nvalid * a.rem;
   const int s = a.B * a.q + b / a.per;
   const __bf16 zero = (__bf16)0.f;
-  for (int idx = tid; idx < (32 - r0) * a.K; idx += NTHR) {
-    const int rr = idx / a.K, n = idx - rr * a.K;
-    const int r = r0 + rr;
-    __bf16* dst = tp_tile(tp, a.nct, s, n >> 4) + ((n & 15) + 16 * (r >> 3)) * 8 + (r & 7);
-    st2(dst, zero); st2(dst + TILE, zero);
+  for (int rr = tid >> 8; rr < 32 - r0; rr += NTHR >> 8) {
+    const int n = tid & 255, r = r0 + rr;
+    if (n < a.K) {
+      __bf16* dst = tp_tile(tp, a.nct, s, n >> 4) + ((n & 15) + 16 * (r >> 3)) * 8 + (r & 7);
+      st2(dst, zero); st2(dst + TILE, zero);
+    }
   }
 }
 
@@ -356,8 +387,9 @@ __device__ __forceinline__ void tzero_uncovered(__bf16* tp, const FusedArgs& a, 
 // h/l[i] = split value at (row 16 rt + 4 g + i, column 16 j + c).  Row tiles rt >= 2 q hold leftover rows: those are
 // stored from the LDS planes after the epilogue's barrier (tstore_leftover_planes), two store instructions per wave
 // instead of sixteen mostly-masked ones.
-__device__ __forceinline__ void tstore_acc(__bf16* tp, const FusedArgs& a, int b, int j, int rt, int lane,
+__device__ __forceinline__ void tstore_acc(__bf16* tp, const Dim& a, int b, int j, int rt, int lane,
                                            const __bf16 (&h)[4], const __bf16 (&l)[4]) {
+  if (RD_ABL & 4) return;
   const int c = lane & 15, g = lane >> 4;
   if (rt < 2 * a.q) {                                    // uniform: this row tile is half of a main tile
     bf16x4 hv, lv;
@@ -369,16 +401,17 @@ __device__ __forceinline__ void tstore_acc(__bf16* tp, const FusedArgs& a, int b
   }
 }
 // leftover rows (32 q + li, li < rem) of a tensor whose split planes [row][LDX] are complete in LDS
-__device__ __forceinline__ void tstore_leftover_planes(const __bf16* Ph, const __bf16* Pl, __bf16* tp, const FusedArgs& a,
+__device__ __forceinline__ void tstore_leftover_planes(const __bf16* Ph, const __bf16* Pl, __bf16* tp, const Dim& a,
                                                        int b, int tid) {
-  if (a.rem == 0) return;
+  if (a.rem == 0 || (RD_ABL & 4)) return;
   const int s = a.B * a.q + b / a.per, slot = b % a.per;
-  for (int idx = tid; idx < a.rem * a.K; idx += NTHR) {
-    const int li = idx / a.K, n = idx - li * a.K;
-    const int r = slot * a.rem + li;
-    __bf16* dst = tp_tile(tp, a.nct, s, n >> 4) + ((n & 15) + 16 * (r >> 3)) * 8 + (r & 7);
-    st2(dst, Ph[(32 * a.q + li) * LDX + n]);
-    st2(dst + TILE, Pl[(32 * a.q + li) * LDX + n]);
+  for (int li = tid >> 8; li < a.rem; li += NTHR >> 8) {
+    const int n = tid & 255, r = slot * a.rem + li;
+    if (n < a.K) {
+      __bf16* dst = tp_tile(tp, a.nct, s, n >> 4) + ((n & 15) + 16 * (r >> 3)) * 8 + (r & 7);
+      st2(dst, Ph[(32 * a.q + li) * LDX + n]);
+      st2(dst + TILE, Pl[(32 * a.q + li) * LDX + n]);
+    }
   }
 }
 
@@ -390,7 +423,7 @@ __device__ __forceinline__ void tstore_leftover_planes(const __bf16* Ph, const _
 // SIMD's matrix pipe works for one wave while its partner wave splits, stores or issues loads (measured: a
 // GEMM of the two waves of a SIMD is pipe-bound, 2 x 144 MFMA x 16 cycles; a wave blocks while it issues a
 // 32-load weight panel, ~2 k cycles for half the workgroup).
-template <int RT>
+template <int RT, int FC, int TC>
 __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int ROWS = RT * 16;
@@ -410,8 +443,9 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   const bool grpB = __builtin_amdgcn_readfirstlane(wave) >= NWAVE / 2;   // scalar: the group branches are real branches
   const Tok tk = tok_of(a);
   const int b = tk.b, sb = tk.sb, L = tk.L;
-  const int T = a.T, F = a.F, K = a.K, B = a.B;
-  const int nct = a.nct;
+  const Dim dm = dims_of<FC, TC>(a);
+  const int T = dm.T, F = dm.F, K = dm.K, B = dm.B;
+  const int nct = dm.nct;
   const float inv_keep = 1.0f / (1.0f - a.p_drop);
   // column tile j of a layer's output = time steps 4j .. 4j+3.  Layer 2's output at padded steps (t >= L) is never read
   // (rd_plan.h): a wave whose column tiles are all padding skips its layer-2 weight stream, product and epilogue.
@@ -443,7 +477,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
     for (int u = 0; u < UNR; ++u) {
       const int i = min(base + u * NTHR, total - 1);          // clamped duplicates rewrite the same cell
       cell_tf(i, F, ti[u], fi[u]);
-      v[u] = a.src[((size_t)ti[u] * B + b) * (2 * F) + fi[u]];
+      v[u] = a.src[(size_t)(m24(m24(ti[u], B) + b, 2 * F) + fi[u])];
       ru[u] = *reinterpret_cast<const float4*>(a.R_u + fi[u] * 4);
     }
   };
@@ -461,9 +495,9 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
         x[0] = (km[u] & 1) ? x[0] * inv_keep : 0.f; x[1] = (km[u] & 2) ? x[1] * inv_keep : 0.f;
         x[2] = (km[u] & 4) ? x[2] * inv_keep : 0.f; x[3] = (km[u] & 8) ? x[3] * inv_keep : 0.f;
       }
-      split_store4(Xh + f * LDX + 4 * t, Xl + f * LDX + 4 * t, x);
-      *reinterpret_cast<float4*>(Xs + f * LDS_F + 4 * t) = make_float4(x[0], x[1], x[2], x[3]);
-      a.mx[(size_t)sb * total + t * F + f] =                  // [slot][t][f]: consecutive lanes, consecutive bytes
+      split_store4(Xh + m24(f, LDX) + 4 * t, Xl + m24(f, LDX) + 4 * t, x);
+      *reinterpret_cast<float4*>(Xs + m24(f, LDS_F) + 4 * t) = make_float4(x[0], x[1], x[2], x[3]);
+      a.mx[(size_t)(m24(sb, total) + m24(t, F) + f)] =        // [slot][t][f]: consecutive lanes, consecutive bytes
           (uint8_t)((x[0] > 0.f ? 1 : 0) | (x[1] > 0.f ? 2 : 0) | (x[2] > 0.f ? 4 : 0) | (x[3] > 0.f ? 8 : 0));
     }
   };
@@ -473,13 +507,13 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
     if (a.p_drop > 0.f) {
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
-        const float4 q4 = uniform4(seed_eff, SITE_OBS_EMBED, ((uint64_t)ti[u] * B + b) * F + fi[u]);
+        const float4 q4 = uniform4(seed_eff, SITE_OBS_EMBED, (uint64_t)(m24(m24(ti[u], B) + b, F) + fi[u]));
         km[u] = (q4.x >= a.p_drop ? 1u : 0u) | (q4.y >= a.p_drop ? 2u : 0u) | (q4.z >= a.p_drop ? 4u : 0u) | (q4.w >= a.p_drop ? 8u : 0u);
         pin(km[u]);
       }
     }
   };
-  embed_issue(tid);
+  if (!(RD_ABL & 16)) embed_issue(tid);
   // device seed cell (rd_set_seed_cell) on the scalar path: a vector load would queue behind the panel
   if (a.seed_cell) seed_eff += load_uniform_u64(a.seed_cell);
   // pads only: X rows >= F and columns >= K (the embedding writes the rest)
@@ -487,12 +521,13 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   if (!ALIAS) { zero_plane_pads(Yh, ROWS, ROWS, ROWS, K, tid); zero_plane_pads(Yl, ROWS, ROWS, ROWS, K, tid); }
   // group B does its arithmetic BEFORE requesting its weight panel, group A after: one-sided uniform branches around
   // a single panel load (an if/else with the panel in both arms makes the allocator spill the panel)
-  if (grpB) { embed_masks(); embed_consume(); }
+  if (grpB && !(RD_ABL & 16)) { embed_masks(); embed_consume(); }
   RD_STAMP(10);
-  load_panel(pw, wtiles(a, 0, 0), nct, wave, lane);
+  load_panel(pw, wtiles(a, dm, 0, 0), nct, wave, lane);
   RD_STAMP(11);
-  if (!grpB) { embed_masks(); embed_consume(); }
-  for (int base = tid + NTHR * UNR; base < total; base += NTHR * UNR) { embed_issue(base); embed_masks(); embed_consume(); }
+  if (!grpB && !(RD_ABL & 16)) { embed_masks(); embed_consume(); }
+  if (!(RD_ABL & 16))
+    for (int base = tid + NTHR * UNR; base < total; base += NTHR * UNR) { embed_issue(base); embed_masks(); embed_consume(); }
   if (lane == 0) LinW[wave] = lin_w;
   RD_STAMP(1);
   lds_barrier();
@@ -513,23 +548,23 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   f32x4 acc[NJ][RT];
   zero_acc<RT>(acc);
   if (grpB) {                                                // group B transposes while group A multiplies ...
-    tstore_stage(Xs, a.tpX, a, sb, tid, nct, nct);
-    tzero_uncovered(a.tpX, a, sb, tid);
-    tzero_uncovered(a.tpY1, a, sb, tid);
+    tstore_stage(Xs, a.tpX, dm, sb, tid, nct, nct);
+    tzero_uncovered(a.tpX, dm, sb, tid);
+    tzero_uncovered(a.tpY1, dm, sb, tid);
   }
   RD_STAMP(13);
   mma_steps<RT, 0, NKC / 2>(acc, Xh, Xl, pw, lane, kclim1);
   __builtin_amdgcn_sched_barrier(0);                                   // the scheduler otherwise sinks these loads below the second half
-  if (live2) load_panel_kc<0, NKC / 2>(pw, wtiles(a, 1, 0), nct, wave, lane);     // layer-2 weights, first half of the reduction
+  if (live2) load_panel_kc<0, NKC / 2>(pw, wtiles(a, dm, 1, 0), nct, wave, lane);     // layer-2 weights, first half of the reduction
   __builtin_amdgcn_sched_barrier(0);
   mma_steps<RT, NKC / 2, NKC>(acc, Xh, Xl, pw, lane, kclim1);
   RD_STAMP(3);
-  if (live2) load_panel_kc<NKC / 2, NKC>(pw, wtiles(a, 1, 0), nct, wave, lane);   // second half
+  if (live2) load_panel_kc<NKC / 2, NKC>(pw, wtiles(a, dm, 1, 0), nct, wave, lane);   // second half
   RD_STAMP(12);
   if (!grpB) {                                               // ... and the other way round
-    tstore_stage(Xs, a.tpX, a, sb, tid, nct, nct);
-    tzero_uncovered(a.tpX, a, sb, tid);
-    tzero_uncovered(a.tpY1, a, sb, tid);
+    tstore_stage(Xs, a.tpX, dm, sb, tid, nct, nct);
+    tzero_uncovered(a.tpX, dm, sb, tid);
+    tzero_uncovered(a.tpY1, dm, sb, tid);
   }
   if (ALIAS) {                                               // the fp32 copy of X lives in the Y planes: everybody must be done with it
     lds_barrier();
@@ -555,7 +590,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
           const unsigned long long bal = __ballot(y > 0.f);
           if ((lane & 15) == 0) M1[row * 16 + j] = (uint16_t)(bal >> (16 * (lane >> 4)));
         }
-        tstore_acc(a.tpY1, a, sb, j, rt, lane, hh, ll);
+        tstore_acc(a.tpY1, dm, sb, j, rt, lane, hh, ll);
       }
     }
   }
@@ -564,8 +599,8 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   RD_STAMP(5);
   // gate bits of layer 1 -> global (rows < F: 32 bytes each); leftover rows of Y1 -> row tiles
   for (int i = tid; i < 2 * F; i += NTHR)
-    reinterpret_cast<uint4*>(a.m1 + (size_t)sb * F * 16)[i] = reinterpret_cast<const uint4*>(M1)[i];
-  tstore_leftover_planes(Yh, Yl, a.tpY1, a, sb, tid);
+    reinterpret_cast<uint4*>(a.m1 + (size_t)m24(sb, F * 16))[i] = reinterpret_cast<const uint4*>(M1)[i];
+  tstore_leftover_planes(Yh, Yl, a.tpY1, dm, sb, tid);
 
   // ---- layer 2: Y2 = relu(Y1 W2^T + b2) * ssum -> fp32 staging (live column tiles only) ------------
   zero_acc<RT>(acc);
@@ -593,34 +628,39 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   lds_barrier();
   RD_STAMP(8);
   for (int i = tid; i < 2 * F; i += NTHR)
-    reinterpret_cast<uint4*>(a.m2 + (size_t)sb * F * 16)[i] = reinterpret_cast<const uint4*>(M2)[i];
+    reinterpret_cast<uint4*>(a.m2 + (size_t)m24(sb, F * 16))[i] = reinterpret_cast<const uint4*>(M2)[i];
   // ---- [F, T*d] -> z[row(t), f*d + c]: thread -> (t, f) with f fastest moves the 4 channels of a cell as one 16-byte
   // LDS read (conflict-free at stride 244) and one 16-byte store; consecutive lanes write consecutive addresses.
   // Live steps only (t < L; L == T on the padded layout).
-  if ((a.ldz & 3) == 0) {
+  const int ldz = dm.ldz;
+  if (RD_ABL & 8) return;
+  if ((ldz & 3) == 0) {
     for (int i = tid; i < L * F; i += NTHR) {
-      const int t = i / F, f = i - t * F;
-      st16f(a.z + ((size_t)tk.row0 + (size_t)t * tk.rstride) * a.ldz + 4 * f, *reinterpret_cast<const float4*>(Ys + f * LDS_F + 4 * t));
+      int t, f;
+      cell_tf(i, F, t, f);
+      st16f(a.z + (size_t)(m24(tk.row0 + m24(t, tk.rstride), ldz) + 4 * f), *reinterpret_cast<const float4*>(Ys + m24(f, LDS_F) + 4 * t));
     }
   } else {
     const int Fd = F * 4;
     for (int i = tid; i < L * Fd; i += NTHR) {
       const int t = i / Fd, q = i - t * Fd;
-      a.z[((size_t)tk.row0 + (size_t)t * tk.rstride) * a.ldz + q] = Ys[(q >> 2) * LDS_F + t * 4 + (q & 3)];
+      a.z[(size_t)(m24(tk.row0 + m24(t, tk.rstride), ldz) + q)] = Ys[(q >> 2) * LDS_F + t * 4 + (q & 3)];
     }
   }
   // ---- positional encoding + padding mask of this sample (code/models_rd.py:28-38,298-299) ----
   if (a.times != nullptr) {
-    const int H = a.d_pe >> 1;
+    const int H = dm.H;
     for (int i = tid; i < L * H; i += NTHR) {
       const int t = i / H, k = i - t * H;
-      const float ang = a.times[(size_t)t * B + b] / a.tscale[k];
-      float* row = a.z + ((size_t)tk.row0 + (size_t)t * tk.rstride) * a.ldz + F * 4;
-      row[k] = sinf(ang);
-      row[H + k] = cosf(ang);
+      const float ang = a.times[(size_t)(m24(t, B) + b)] / a.tscale[k];
+      float* row = a.z + (size_t)(m24(tk.row0 + m24(t, tk.rstride), ldz) + F * 4);
+      float sn, cs;
+      sincosf(ang, &sn, &cs);                                  // one argument reduction for the pair
+      row[k] = sn;
+      row[H + k] = cs;
     }
     const int64_t len = a.lengths[b];
-    for (int t = tid; t < T; t += NTHR) a.mask[(size_t)b * T + t] = (uint8_t)((int64_t)t >= len);
+    for (int t = tid; t < T; t += NTHR) a.mask[(size_t)(m24(b, T) + t)] = (uint8_t)((int64_t)t >= len);
   }
   RD_STAMP(9);
 }
@@ -630,7 +670,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
 // The weight gradients dW_l = dZ_l^T In_l reduce over all B*F rows: rd_msgpass_dw.hip.
 // Same two-group schedule as the forward kernel.
 // ------------------------------------------------------------------------------------------------
-template <int RT>
+template <int RT, int FC, int TC>
 __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int ROWS = RT * 16;
@@ -651,8 +691,9 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   const bool grpB = __builtin_amdgcn_readfirstlane(wave) >= NWAVE / 2;   // scalar: the group branches are real branches
   const Tok tk = tok_of(a);
   const int b = tk.b, sb = tk.sb, L = tk.L;
-  const int T = a.T, F = a.F, K = a.K, B = a.B;
-  const int nct = a.nct;
+  const Dim dm = dims_of<FC, TC>(a);
+  const int T = dm.T, F = dm.F, K = dm.K, B = dm.B;
+  const int nct = dm.nct;
   const int Fd = F * 4;
   const int kq = K / 4;
   // dz is exactly zero at the padded steps t >= L (rd_plan.h) -- on the padded layout L == T.  So dZ2's columns >= 4L are zero:
@@ -666,7 +707,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   int jlim = nct, jlimL = nct;
   if (a.plan) {
     jlim = min(nct, 4 * ((L + 15) >> 4));
-    const int Lg = __builtin_amdgcn_readfirstlane(a.plan[plan::len_base(B) + (sb / a.per) * a.per]);   // longest sample of this leftover tile
+    const int Lg = __builtin_amdgcn_readfirstlane(a.plan[plan::len_base(B) + (sb / dm.per) * dm.per]);   // longest sample of this leftover tile
     jlimL = min(nct, 4 * ((Lg + 15) >> 4));
   }
 
@@ -686,7 +727,8 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   // thread -> cell (t, f), f fastest: one 16-byte load per cell (the 4 channels), one 16-byte LDS store
   constexpr int GU = CPT;
   const int total = F * T;
-  const bool vec4 = (a.ldz & 3) == 0;
+  const int ldz = dm.ldz;
+  const bool vec4 = (ldz & 3) == 0;
   float4 dd[GU]; int gt[GU], gfi[GU];
   auto gather_issue = [&](int base) {
 #pragma unroll
@@ -694,7 +736,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
       const int i = min(base + u * NTHR, total - 1);            // clamped duplicates rewrite the same cell
       cell_tf(i, F, gt[u], gfi[u]);
       const int tl = min(gt[u], max(L - 1, 0));                 // padded steps: a legal address, zeroed at the consumer
-      const float* p = a.dz + ((size_t)tk.row0 + (size_t)tl * tk.rstride) * a.ldz + 4 * gfi[u];
+      const float* p = a.dz + (size_t)(m24(tk.row0 + m24(tl, tk.rstride), ldz) + 4 * gfi[u]);
       if (vec4) dd[u] = *reinterpret_cast<const float4*>(p);
       else dd[u] = make_float4(p[0], p[1], p[2], p[3]);
     }
@@ -707,19 +749,19 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
       const float sf = Ss[f];
       unsigned bits = (unsigned)M2[f * 16 + (k >> 4)] >> (k & 15);           // 4 consecutive gate bits (k % 4 == 0)
       if (gt[u] >= L) bits = 0;
-      *reinterpret_cast<float4*>(St + f * LDS_F + k) =
+      *reinterpret_cast<float4*>(St + m24(f, LDS_F) + k) =
           make_float4((bits & 1) ? dd[u].x * sf : 0.f, (bits & 2) ? dd[u].y * sf : 0.f, (bits & 4) ? dd[u].z * sf : 0.f,
                       (bits & 8) ? dd[u].w * sf : 0.f);
     }
   };
   uint4 mw = make_uint4(0, 0, 0, 0);
   if (tid < 4 * F)                                           // threads [0,2F): M1 rows, [2F,4F): M2 rows
-    mw = tid < 2 * F ? reinterpret_cast<const uint4*>(a.m1 + (size_t)sb * F * 16)[tid]
-                     : reinterpret_cast<const uint4*>(a.m2 + (size_t)sb * F * 16)[tid - 2 * F];
+    mw = tid < 2 * F ? reinterpret_cast<const uint4*>(a.m1 + (size_t)m24(sb, F * 16))[tid]
+                     : reinterpret_cast<const uint4*>(a.m2 + (size_t)m24(sb, F * 16))[tid - 2 * F];
   float sfv = 0.f;
   if (tid >= NTHR - 64 && tid - (NTHR - 64) < F) sfv = a.ssum[tid - (NTHR - 64)];      // last wave: ssum -> LDS
-  gather_issue(tid);
-  load_panel(pw, wtiles(a, 1, 1), nct, wave, lane);          // W2^T panel queues behind the gather
+  if (!(RD_ABL & 16)) gather_issue(tid);
+  load_panel(pw, wtiles(a, dm, 1, 1), nct, wave, lane);          // W2^T panel queues behind the gather
   RD_STAMP(10);
   // D planes: zero the pads (rows >= F, columns >= K); the staging tile is fully written for rows < F, columns < K
   zero_plane_pads(Dh, ROWS, F, F, K, tid); zero_plane_pads(Dl, ROWS, F, F, K, tid);
@@ -733,17 +775,21 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   RD_STAMP(11);
   lds_barrier();
   RD_STAMP(12);
-  gather_consume();
-  for (int base = tid + GU * NTHR; base < total; base += GU * NTHR) { gather_issue(base); gather_consume(); }
+  if (!(RD_ABL & 16)) {
+    gather_consume();
+    for (int base = tid + GU * NTHR; base < total; base += GU * NTHR) { gather_issue(base); gather_consume(); }
+  }
   RD_STAMP(13);
   lds_barrier();
   RD_STAMP(1);
   // staging -> D planes (row-major, the A operand of the next product)
   for (int i = tid; i < F * kq; i += NTHR) {
-    const int f = i / kq, k = 4 * (i - f * kq);
-    const float4 v = *reinterpret_cast<const float4*>(St + f * LDS_F + k);
+    int f, kk;
+    cell_tf(i, kq, f, kk);                                     // i < 2^15, kq <= 64
+    const int k = 4 * kk;
+    const float4 v = *reinterpret_cast<const float4*>(St + m24(f, LDS_F) + k);
     const float x[4] = {v.x, v.y, v.z, v.w};
-    split_store4(Dh + f * LDX + k, Dl + f * LDX + k, x);
+    split_store4(Dh + m24(f, LDX) + k, Dl + m24(f, LDX) + k, x);
   }
   RD_STAMP(2);
   lds_barrier();
@@ -760,30 +806,30 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
 #pragma unroll
     for (int u = 0; u < XU; ++u) {
       const int t = min(tb + u * TG, T - 1);
-      xb[u] = a.mx[((size_t)sb * T + t) * F + rf];
-      svv[u] = a.src[((size_t)t * B + b) * (2 * F) + rf];
+      xb[u] = a.mx[(size_t)(m24(m24(sb, T) + t, F) + rf)];
+      svv[u] = a.src[(size_t)(m24(m24(t, B) + b, 2 * F) + rf)];
     }
   };
   f32x4 acc[NJ][RT];
   zero_acc<RT>(acc);
   if (grpB) {
-    tstore_stage(St, a.tpD2, a, sb, tid, jlim, jlimL);
-    tzero_uncovered(a.tpD2, a, sb, tid);
-    tzero_uncovered(a.tpD1, a, sb, tid);
+    tstore_stage(St, a.tpD2, dm, sb, tid, jlim, jlimL);
+    tzero_uncovered(a.tpD2, dm, sb, tid);
+    tzero_uncovered(a.tpD1, dm, sb, tid);
   }
   mma_steps<RT, 0, NKC / 2>(acc, Dh, Dl, pw, lane, kclim2);
   __builtin_amdgcn_sched_barrier(0);
-  if (liveX) load_panel_kc<0, NKC / 2>(pw, wtiles(a, 0, 1), nct, wave, lane);     // W1^T, first half of the reduction
+  if (liveX) load_panel_kc<0, NKC / 2>(pw, wtiles(a, dm, 0, 1), nct, wave, lane);     // W1^T, first half of the reduction
   __builtin_amdgcn_sched_barrier(0);
   mma_steps<RT, NKC / 2, NKC>(acc, Dh, Dl, pw, lane, kclim2);
   RD_STAMP(4);
-  if (liveX) load_panel_kc<NKC / 2, NKC>(pw, wtiles(a, 0, 1), nct, wave, lane);
+  if (liveX) load_panel_kc<NKC / 2, NKC>(pw, wtiles(a, dm, 0, 1), nct, wave, lane);
   if (ract) ru_issue(rtg);
   RD_STAMP(14);
   if (!grpB) {
-    tstore_stage(St, a.tpD2, a, sb, tid, jlim, jlimL);
-    tzero_uncovered(a.tpD2, a, sb, tid);
-    tzero_uncovered(a.tpD1, a, sb, tid);
+    tstore_stage(St, a.tpD2, dm, sb, tid, jlim, jlimL);
+    tzero_uncovered(a.tpD2, dm, sb, tid);
+    tzero_uncovered(a.tpD1, dm, sb, tid);
   }
   if (ALIAS) lds_barrier();                                    // staging tile lives in the E planes: everybody must be done with it
   if (ALIAS) { zero_plane_pads(Eh, ROWS, ROWS, ROWS, K, tid); zero_plane_pads(El, ROWS, ROWS, ROWS, K, tid); }
@@ -803,14 +849,14 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
           hh[r] = (__bf16)g; ll[r] = (__bf16)(g - (float)hh[r]);
           store_split_pair(Eh, El, row, n, lane, hh[r], ll[r]);
         }
-        tstore_acc(a.tpD1, a, sb, j, rt, lane, hh, ll);
+        tstore_acc(a.tpD1, dm, sb, j, rt, lane, hh, ll);
       }
     }
   }
   RD_STAMP(5);
   lds_barrier();
   RD_STAMP(15);
-  tstore_leftover_planes(Eh, El, a.tpD1, a, sb, tid);
+  tstore_leftover_planes(Eh, El, a.tpD1, dm, sb, tid);
 
   // ---- dX = dZ1 W1 -> fp32 staging (the D planes are dead); observed column tiles only -----------
   zero_acc<RT>(acc);
@@ -832,6 +878,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   // ---- dR_u[f*4+c] = sum_t dX[f, 4t+c] * (X > 0) * src[t,b,f] * keep -----------------------------
   // pass 1: thread (tg, f) sums its time steps (fixed order) into Rp[tg][f*4 + c]
   const float keep = 1.0f / (1.0f - a.p_drop);
+  if (RD_ABL & 8) return;
   if (ract) {
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int tb = rtg; tb < T; tb += XU * TG) {
@@ -842,7 +889,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
         pin(xb[u]); pin(svv[u]);
         if (t < lin) {                                          // lin <= T; beyond it the gate is closed and the staging tile unwritten
           const float sv = svv[u] * keep;
-          const float4 dx = *reinterpret_cast<const float4*>(Sx + rf * LDS_F + 4 * t);
+          const float4 dx = *reinterpret_cast<const float4*>(Sx + m24(rf, LDS_F) + 4 * t);
           s.x += (xb[u] & 1) ? dx.x * sv : 0.f; s.y += (xb[u] & 2) ? dx.y * sv : 0.f;
           s.z += (xb[u] & 4) ? dx.z * sv : 0.f; s.w += (xb[u] & 8) ? dx.w * sv : 0.f;
         }
@@ -856,23 +903,37 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   for (int i = tid; i < Fd; i += NTHR) {
     float v = 0.f;
     for (int g = 0; g < TG; ++g) v += Rp[g * Fd + i];
-    a.rupart[(size_t)sb * Fd + i] = v;
+    a.rupart[(size_t)(m24(sb, Fd) + i)] = v;
   }
   RD_STAMP(9);
 }
 
-template <int RT>
+template <int RT, int FC, int TC>
 int launch_fused(const FusedArgs& a, bool bwd, hipStream_t st) {
   const size_t lds = (size_t)4 * RT * 16 * LDX * sizeof(__bf16) + (RT > 3 ? 0 : (size_t)RT * 16 * LDS_F * sizeof(float)) +
                      (size_t)2 * RT * 16 * 16 * sizeof(uint16_t) + (size_t)RT * 16 * sizeof(float);
   if (!bwd) {
-    RD_LDS_ATTR((k_msg_fwd_fused<RT>), lds);
-    hipLaunchKernelGGL(k_msg_fwd_fused<RT>, dim3(a.B), dim3(NTHR), lds, st, a);
+    RD_LDS_ATTR((k_msg_fwd_fused<RT, FC, TC>), lds);
+    hipLaunchKernelGGL((k_msg_fwd_fused<RT, FC, TC>), dim3(a.B), dim3(NTHR), lds, st, a);
     return check_launch("k_msg_fwd_fused");
   }
-  RD_LDS_ATTR((k_msg_bwd_fused<RT>), lds);
-  hipLaunchKernelGGL(k_msg_bwd_fused<RT>, dim3(a.B), dim3(NTHR), lds, st, a);
+  RD_LDS_ATTR((k_msg_bwd_fused<RT, FC, TC>), lds);
+  hipLaunchKernelGGL((k_msg_bwd_fused<RT, FC, TC>), dim3(a.B), dim3(NTHR), lds, st, a);
   return check_launch("k_msg_bwd_fused");
+}
+
+// RD_K1_SPECIALIZE=0 runs the P19 shape on the generic instantiation (A/B, and the parity test of the two)
+int launch_fused_shape(const FusedArgs& a, const k1::Layout& L, bool bwd, hipStream_t st) {
+  if (a.ldz >= 1024) return fail(RD_EUNSUPPORTED, "fused message passing: ldz (%d) must be < 1024", a.ldz);
+  const char* e = getenv("RD_K1_SPECIALIZE");
+  const bool model_layout = a.ldz == 4 * L.F + 16 && (bwd || a.times == nullptr || a.d_pe == 16);
+  if (L.F == 34 && L.T == 60 && model_layout && !(e && atoi(e) == 0)) return launch_fused<3, 34, 60>(a, bwd, st);
+  switch (L.RT) {
+    case 1: return launch_fused<1, 0, 0>(a, bwd, st);
+    case 2: return launch_fused<2, 0, 0>(a, bwd, st);
+    case 3: return launch_fused<3, 0, 0>(a, bwd, st);
+    default: return launch_fused<4, 0, 0>(a, bwd, st);
+  }
 }
 
 void fill_layout(FusedArgs& a, const k1::Layout& L) {
@@ -891,7 +952,9 @@ bool fused_msgpass_ok(const rd_shape* s) {
   const bool enabled = !(e && atoi(e) == 0);
   const int K = s->T * s->d_ob;
   // staging tile [F][244] fp32 must fit inside two bf16 planes [RT*16][264]; d_ob == 4 only
-  return enabled && precision() == RD_PREC_BF16X3 && s->d_ob == 4 && s->F <= 64 && K <= 240 && (K % 16) == 0 && K >= 16;
+  // index arithmetic of the kernels is 32-bit with 24-bit multiplies: B*T rows < 2^22 (with ldz < 1024, checked at the call)
+  return enabled && precision() == RD_PREC_BF16X3 && s->d_ob == 4 && s->F <= 64 && K <= 240 && (K % 16) == 0 && K >= 16 &&
+         (long)s->B * s->T < (1L << 22);
 }
 
 int fused_wprep(const k1::Layout& L, const float* W1, const float* W2, void* wt, hipStream_t st) {
@@ -911,12 +974,7 @@ int fused_msgpass_fwd(const k1::Layout& L, const float* src, const float* R_u, c
   a.z = z; a.ldz = ldz;
   a.p_drop = p_drop; a.seed = seed; a.seed_cell = seed_cell(); a.stamps = g_stamps;
   a.plan = token_plan(); a.lin = reinterpret_cast<int*>(reinterpret_cast<char*>(mx) + k1::lin_offset(L.B, L.T, L.F));
-  switch (L.RT) {
-    case 1: return launch_fused<1>(a, false, st);
-    case 2: return launch_fused<2>(a, false, st);
-    case 3: return launch_fused<3>(a, false, st);
-    default: return launch_fused<4>(a, false, st);
-  }
+  return launch_fused_shape(a, L, false, st);
 }
 
 int fused_msgpass_bwd(const k1::Layout& L, const float* src, const float* ssum, const void* wt, float p_drop,
@@ -930,12 +988,7 @@ int fused_msgpass_bwd(const k1::Layout& L, const float* src, const float* ssum, 
   a.p_drop = p_drop; a.stamps = g_stamps;
   a.plan = token_plan();
   a.lin = reinterpret_cast<int*>(reinterpret_cast<char*>(const_cast<void*>(mx)) + k1::lin_offset(L.B, L.T, L.F));
-  switch (L.RT) {
-    case 1: return launch_fused<1>(a, true, st);
-    case 2: return launch_fused<2>(a, true, st);
-    case 3: return launch_fused<3>(a, true, st);
-    default: return launch_fused<4>(a, true, st);
-  }
+  return launch_fused_shape(a, L, true, st);
 }
 
 }  // namespace rd

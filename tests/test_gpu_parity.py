@@ -773,6 +773,39 @@ def test_k1_fused_vs_generic_same_arithmetic(F, T, B, kind, precision_mode, monk
         assert _rel2(a, r) < 1e-3, (n, _rel2(a, r))
 
 
+@pytest.mark.parametrize("B,p_drop", [(7, 0.0), (256, 0.2)])
+def test_k1_shape_specialised_kernels_equal_generic_instantiation(B, p_drop, precision_mode, monkeypatch):
+    """The P19 shape runs instantiations of the fused kernels with F = 34, T = 60 as compile-time constants (index arithmetic
+    folded; rd_msgpass_fused.hip `Dim`).  Same source, same arithmetic, same order: output, mask and all five gradients must be
+    BIT-equal to the runtime-shape instantiation (RD_K1_SPECIALIZE=0)."""
+    if precision_mode != "bf16x3":
+        pytest.skip("the fused path exists in split-bf16 mode only")
+    from raindrop_amd import _lib, ops
+    F, T, d = 34, 60, 4
+    K = T * d
+    rng = np.random.default_rng(B)
+    b = synth.make_batch(dict(d_inp=F, max_len=T, static=True, d_static=3, n_classes=2), B, seed=B)
+    names = ["R_u", "W1", "b1", "W2", "b2"]
+    shapes = [(1, F * d), (K, K), (K,), (K, K), (K,)]
+    p = {n: synth.param_values("k1s." + n, s, seed=5).to(DEV) for n, s in zip(names, shapes)}
+    adj, _, _ = ops.graph_build(torch.ones(F, F, device=DEV))
+    _, ssum = ops.edge_softmax_dense(adj)
+    shp = _lib.shape(B, T, F, d)
+    dz = torch.from_numpy(rng.standard_normal((T, B, F * d + 16)).astype(np.float32)).to(DEV)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RD_K1_SPECIALIZE", mode)
+        q = {n: t.clone().requires_grad_(True) for n, t in p.items()}
+        z, mask = ops.sensor_stage(b["src"].to(DEV), b["times"].to(DEV), b["lengths"].to(DEV), ops.timescales(T).to(DEV), ssum,
+                                   q["R_u"], q["W1"], q["b1"], q["W2"], q["b2"], shp, p_drop, 11)
+        g = torch.autograd.grad(z, [q[n] for n in names], dz)
+        torch.cuda.synchronize()
+        res[mode] = [z.detach().cpu().numpy(), mask.cpu().numpy()] + [x.cpu().numpy() for x in g]
+    monkeypatch.delenv("RD_K1_SPECIALIZE")
+    for n, a, r in zip(["z", "mask"] + names, res["1"], res["0"]):
+        assert np.array_equal(a, r), n
+
+
 def test_k1_fused_dropout_backward_uses_forward_mask(precision_mode, monkeypatch):
     """Dropout on the observation embedding, fused path: the forward pass hands its keep mask to the backward pass as
     gate bits (no regeneration).  Same seed -> identical output, another seed -> another mask; the generic path draws

@@ -7,7 +7,7 @@ from raindrop_amd import _lib, ops, synth
 lib = _lib.load()
 lib.rd_debug_set_encfuse_stamps.argtypes = [ctypes.c_void_p]
 dev = torch.device("cuda")
-T, B, F = 60, 128, 34
+T, B, F = 60, int(sys.argv[1]) if len(sys.argv) > 1 else 128, 34
 D, nhid = F * 4 + 16, 2 * F * 4
 x = torch.randn(T, B, D, device=dev, requires_grad=True)
 mask = torch.zeros(B, T, dtype=torch.bool, device=dev)
