@@ -147,6 +147,23 @@ int rd_aggregate_fwd(int32_t N, int32_t C, const float* gamma, const float* V, c
 int rd_aggregate_bwd(int32_t N, int32_t C, const float* gamma, const float* dout, float* dV,
                      void* stream);
 
+/* Batched forms (replace the per-sample Python loop + torch index_put_ the round-2 TransformerConv surface used):
+ *  - rd_edge_softmax_list_batched: B edge lists in one launch, edge_index [B][2,E] int64 `batch_stride` elements apart (0 = one
+ *    shared list), rows `row_stride` apart; weights [B,E] `w_bstride` floats apart (0 = shared); gamma_e [B,E], ssum [B,N].
+ *    Layer 2 of the use_beta model reads each sample's OWN pruned edge list through it (code/models_rd.py:331-335).
+ *  - rd_edge_gamma_dense: dense coefficient matrix gamma[j*N + i] = sum of gamma_e over the edges j -> i, duplicate edges added in
+ *    edge order (the scatter-add of PyG's aggregate, code/transformer_conv.py:139-160, deterministic: no float atomics).
+ *  - rd_aggregate_batched_fwd/bwd: out[b,i,c] = sum_j gamma[j,i] V[b,j,c] (+ skip[b,i,c]) for B feature matrices that share the
+ *    graph, as ONE batched product (the legacy `Raindrop` model loops the operator over the batch, code/models_rd.py:155-165). */
+int rd_edge_softmax_list_batched(int32_t B, int32_t N, int32_t E, const int64_t* edge_index, int64_t batch_stride,
+                                 int64_t row_stride, int32_t norm_row, const float* edge_weights, int64_t w_bstride,
+                                 float* gamma_e, float* ssum, void* stream);
+int rd_edge_gamma_dense(int32_t N, int32_t E, const int64_t* edge_index, int64_t row_stride, const float* gamma_e,
+                        float* gamma_dense, void* stream);
+int rd_aggregate_batched_fwd(int32_t B, int32_t N, int32_t C, const float* gamma, const float* V, const float* skip,
+                             float* out, void* stream);
+int rd_aggregate_batched_bwd(int32_t B, int32_t N, int32_t C, const float* gamma, const float* dout, float* dV, void* stream);
+
 size_t rd_msgpass_workspace_bytes(const rd_shape* s);   /* scratch of rd_msgpass_bwd            */
 size_t rd_msgpass_saved_bytes(const rd_shape* s);       /* forward -> backward hand-over buffer */
 
@@ -350,6 +367,22 @@ int rd_graph_beta_bwd(int32_t B, int32_t N, int32_t K, int32_t T, int32_t d_ob, 
 /* code/models_rd.py:345-346: distance = mean(cdist(alpha_all.T, alpha_all.T, p=2)) for alpha_all [E,B] (one column of edge
  * scores per sample); workspace B floats.  Identically 0 on the shipped path (equal columns); evaluated here in general. */
 int rd_structure_distance(int32_t E, int32_t B, const float* alpha_all, float* workspace, float* distance, void* stream);
+
+/* ---- building blocks of the paper-faithful sensor stage: Raindrop_v2(use_beta=True), i.e. code/models_rd.py:313-343 with the
+ * literal at :317 flipped.  Layer 1 prunes a different edge set per sample, so the stage is composed instead of fused:
+ *   rd_obs_embed_fwd -> rd_linear_fwd (lin_value + ReLU, increase_dim) -> rd_graph_beta_fwd -> rd_edge_softmax_list_batched ->
+ *   rd_linear_fwd (layer 2's lin_value + ReLU) -> rd_rows_to_tokens_fwd; rd_pe_mask writes the PE columns and the mask.
+ *  - rd_obs_embed_fwd: X[b,f,t*d+c] = dropout(relu(src[t,b,f] * R_u[f*d+c]))  ([B,F,T*d]; code/models_rd.py:290-296,326-327; same
+ *    dropout site and element numbering as the fused stage).  rd_obs_embed_bwd: dR_u from dX (gate X > 0 = ReLU open AND kept).
+ *  - rd_rows_to_tokens_fwd: z[t,b,f*d+c] = Y[b,f,t*d+c] * rowscale[b,f] (rowscale NULL = 1): the aggregate coefficient of layer 2
+ *    (sum of the per-target softmax over a sample's surviving edges) and the layout change of code/models_rd.py:338-342;
+ *    _bwd: dY = dz * rowscale in Y's layout. */
+int rd_obs_embed_fwd(const rd_shape* s, const float* src, const float* R_u, float p_drop, uint64_t seed, float* X, void* stream);
+size_t rd_obs_embed_bwd_workspace_bytes(const rd_shape* s);
+int rd_obs_embed_bwd(const rd_shape* s, const float* src, const float* X, const float* dX, float p_drop, float* dR_u,
+                     void* workspace, size_t workspace_bytes, void* stream);
+int rd_rows_to_tokens_fwd(const rd_shape* s, const float* Y, const float* rowscale, float* z, int32_t ldz, void* stream);
+int rd_rows_to_tokens_bwd(const rd_shape* s, const float* dz, int32_t ldz, const float* rowscale, float* dY, void* stream);
 
 /* ---- host preprocessing on the device: code/utils_rd.py:149-257, code/Raindrop.py:215-231 ------------
  * Inputs are float64 (the reference's numpy arrays), outputs float32 (its torch.Tensor casts).  Every result is

@@ -102,7 +102,32 @@ def load():
     return _cached
 
 
-def build_raindrop_v2(cfg, global_structure, sensor_wise_mask=False):
+def load_models_rd_with_beta():
+    """The reference's `code/models_rd.py` with ONE literal flipped in memory: `use_beta = False` -> `use_beta = True`
+    (`code/models_rd.py:317`, the switch the reference hard-wires off).  Everything else is the file as it lies under the
+    reference tree; nothing is written anywhere.  Used only to generate / re-check the `*_beta` golden fixtures."""
+    import types
+    load()                                           # Ob_propagation / transformer_conv imported under the shim
+    path = os.path.join(reference_root(), "code", "models_rd.py")
+    with open(path) as fh:
+        text = fh.read()
+    assert text.count("use_beta = False") == 1, "the reference's use_beta literal moved"
+    text = text.replace("use_beta = False", "use_beta = True")
+    mod = types.ModuleType("models_rd_use_beta")
+    mod.__file__ = path
+    code = os.path.join(reference_root(), "code")
+    sys.path.insert(0, code)
+    sys.path.insert(0, _SHIM)
+    try:
+        with _patched():
+            exec(compile(text, path, "exec"), mod.__dict__)
+    finally:
+        sys.path.remove(code)
+        sys.path.remove(_SHIM)
+    return mod
+
+
+def build_raindrop_v2(cfg, global_structure, sensor_wise_mask=False, use_beta=False):
     """Construct the reference `Raindrop_v2` exactly as `code/Raindrop.py:245-251` does."""
     ref = load()
     args = (cfg["d_inp"], cfg["d_model"], cfg["nhead"], cfg["nhid"], cfg["nlayers"], cfg["dropout"],
@@ -111,7 +136,8 @@ def build_raindrop_v2(cfg, global_structure, sensor_wise_mask=False):
     kw = dict(sensor_wise_mask=sensor_wise_mask)
     if not cfg["static"]:
         kw["static"] = False
-    return ref.run(ref.models_rd.Raindrop_v2, *args, **kw)
+    cls = load_models_rd_with_beta().Raindrop_v2 if use_beta else ref.models_rd.Raindrop_v2
+    return ref.run(cls, *args, **kw)
 
 
 def forward(model, src, static, times, lengths):

@@ -52,6 +52,16 @@ SIGNATURES = {
     "rd_edge_softmax_list": (c_int32, [c_int32, c_int32, _P, ctypes.c_int64, c_int32, _P, _P, _P, _P]),
     "rd_aggregate_fwd": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _P]),
     "rd_aggregate_bwd": (c_int32, [c_int32, c_int32, _P, _P, _P, _P]),
+    "rd_edge_softmax_list_batched": (c_int32, [c_int32, c_int32, c_int32, _P, ctypes.c_int64, ctypes.c_int64, c_int32, _P,
+                                               ctypes.c_int64, _P, _P, _P]),
+    "rd_edge_gamma_dense": (c_int32, [c_int32, c_int32, _P, ctypes.c_int64, _P, _P, _P]),
+    "rd_aggregate_batched_fwd": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P]),
+    "rd_aggregate_batched_bwd": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P]),
+    "rd_obs_embed_fwd": (c_int32, [_SHP, _P, _P, c_float, ctypes.c_uint64, _P, _P]),
+    "rd_obs_embed_bwd_workspace_bytes": (c_size_t, [_SHP]),
+    "rd_obs_embed_bwd": (c_int32, [_SHP, _P, _P, _P, c_float, _P, _P, c_size_t, _P]),
+    "rd_rows_to_tokens_fwd": (c_int32, [_SHP, _P, _P, _P, c_int32, _P]),
+    "rd_rows_to_tokens_bwd": (c_int32, [_SHP, _P, c_int32, _P, _P, _P]),
     "rd_msgpass_workspace_bytes": (c_size_t, [_SHP]),
     "rd_msgpass_saved_bytes": (c_size_t, [_SHP]),
     "rd_msgpass_fwd": (c_int32, [_SHP] + [_P] * 7 + [c_float, ctypes.c_uint64, _P, c_int32, _P, c_size_t, _P]),

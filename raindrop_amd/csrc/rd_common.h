@@ -120,6 +120,7 @@ struct GemmArgs {
   // batched form (nbatch > 1, nsplit <= 1): problem z = (o, i) = (z / batch_inner, z % batch_inner) reads A + o*a_bo + i*a_bi,
   // B + o*b_bo + i*b_bi and writes C + o*c_bo + i*c_bi (two-level strides: sample and head of the [T,B,3D] attention tensors)
   int nbatch, batch_inner; long a_bo, a_bi, b_bo, b_bi, c_bo, c_bi;
+  int res_batched;                // batched form: the residual is laid out like C (offset by the problem's C offset)
 };
 int launch_gemm(const GemmArgs& a, hipStream_t st);
 // split of the reduction length `red` of a [rows x cols] weight-gradient product into nsplit chunks

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
   if (g.nbatch > 1) {                                 // batched: z selects the problem, no split
     const int o = z / g.batch_inner, i = z - o * g.batch_inner;
     g.A += o * g.a_bo + i * g.a_bi; g.B += o * g.b_bo + i * g.b_bi; g.C += o * g.c_bo + i * g.c_bi;
+    if (g.residual && g.res_batched) g.residual += o * g.c_bo + i * g.c_bi;
     z = 0;
   }
   const int kbeg = z * g.k_per_split;
@@ -441,6 +442,7 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
   if (g.nbatch > 1) {                                 // batched: z selects the problem, no split
     const int o = z / g.batch_inner, i = z - o * g.batch_inner;
     g.A += o * g.a_bo + i * g.a_bi; g.B += o * g.b_bo + i * g.b_bi; g.C += o * g.c_bo + i * g.c_bi;
+    if (g.residual && g.res_batched) g.residual += o * g.c_bo + i * g.c_bi;
     z = 0;
   }
   if (g.A2 != nullptr && z >= g.nsplit) {             // second problem of a batched pair (uniform per block)

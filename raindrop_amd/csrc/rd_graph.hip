@@ -116,13 +116,16 @@ __global__ __launch_bounds__(256) void k_pe_mask(const float* __restrict__ times
 // row `norm_row` of edge_index (1 = target: Observation_progation default / TransformerConv,
 // code/Ob_propagation.py:195, code/transformer_conv.py:201; 0 = source: the use_beta branch,
 // code/Ob_propagation.py:184).  One wavefront per node scans the list three times.
+// blockIdx.y = graph of a batch (strides 0: shared)
 __global__ __launch_bounds__(256) void k_edge_softmax_list(const int64_t* __restrict__ idx, int E,
                                                            const float* __restrict__ w, int N,
                                                            float* __restrict__ gamma_e,
-                                                           float* __restrict__ ssum) {
+                                                           float* __restrict__ ssum, long idx_bstride, long w_bstride) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
+  idx += (long)blockIdx.y * idx_bstride; w += (long)blockIdx.y * w_bstride;
+  gamma_e += (long)blockIdx.y * E; ssum += (long)blockIdx.y * N;
   float m = -INFINITY;
   for (int e = lane; e < E; e += 64)
     if (idx[e] == n) m = fmaxf(m, w[e]);
@@ -140,6 +143,26 @@ __global__ __launch_bounds__(256) void k_edge_softmax_list(const int64_t* __rest
     }
   tot = wave_sum(tot);
   if (lane == 0) ssum[n] = tot;
+}
+
+// dense coefficient matrix of an edge list: G[j*N + i] = sum of gamma_e over the edges (j -> i), duplicates added in EDGE ORDER
+// (the scatter-add of code/transformer_conv.py:205 via PyG aggregate, made deterministic).  One wavefront per target i; the edge
+// list is walked by the whole wave (uniform loads), the lane that owns source j = src % 64 adds into its LDS row slot.
+__global__ __launch_bounds__(256) void k_edge_gamma_dense(const int64_t* __restrict__ src, const int64_t* __restrict__ tgt, int E,
+                                                          const float* __restrict__ gamma_e, int N, float* __restrict__ G) {
+  extern __shared__ float grow[];                       // [4 waves][N]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wv;
+  float* row = grow + (size_t)wv * N;
+  if (i < N) {
+    for (int j = lane; j < N; j += 64) row[j] = 0.f;
+    for (int e = 0; e < E; ++e) {
+      if ((int)tgt[e] != i) continue;                   // wave-uniform
+      const int j = (int)src[e];
+      if (lane == (j & 63) && j >= 0 && j < N) row[j] += gamma_e[e];   // one lane per source: edge order, no atomics
+    }
+    for (int j = lane; j < N; j += 64) G[(long)j * N + i] = row[j];
+  }
 }
 
 }  // namespace
@@ -185,8 +208,33 @@ extern "C" int rd_edge_softmax_list(int32_t N, int32_t E, const int64_t* edge_in
   RD_REQUIRE(norm_row == 0 || norm_row == 1, "norm_row must be 0 (source) or 1 (target)");
   RD_REQUIRE(edge_index && edge_weights && gamma_e && ssum, "NULL tensor");
   hipLaunchKernelGGL(k_edge_softmax_list, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream,
-                     edge_index + (long)norm_row * row_stride, E, edge_weights, N, gamma_e, ssum);
+                     edge_index + (long)norm_row * row_stride, E, edge_weights, N, gamma_e, ssum, 0L, 0L);
   return check_launch("k_edge_softmax_list");
+}
+
+// B graphs in one launch: edge lists `batch_stride` int64 apart (0: one shared list), weights `w_bstride` floats apart (0: shared);
+// gamma_e [B,E], ssum [B,N].  The per-sample pruned edge lists of the use_beta branch feed layer 2 through this
+// (code/models_rd.py:331-335: edge_index_layer2 / edge_weights_layer2 differ per sample).
+extern "C" int rd_edge_softmax_list_batched(int32_t B, int32_t N, int32_t E, const int64_t* edge_index, int64_t batch_stride,
+                                            int64_t row_stride, int32_t norm_row, const float* edge_weights, int64_t w_bstride,
+                                            float* gamma_e, float* ssum, void* stream) {
+  RD_REQUIRE(B >= 0 && N > 0 && E >= 0, "bad B=%d N=%d E=%d", B, N, E);
+  RD_REQUIRE(norm_row == 0 || norm_row == 1, "norm_row must be 0 (source) or 1 (target)");
+  if (B == 0) return RD_OK;
+  RD_REQUIRE(B <= 65535, "B=%d exceeds the grid's y extent", B);
+  RD_REQUIRE(edge_index && edge_weights && gamma_e && ssum, "NULL tensor");
+  hipLaunchKernelGGL(k_edge_softmax_list, dim3(cdiv(N, 4), B), dim3(256), 0, (hipStream_t)stream,
+                     edge_index + (long)norm_row * row_stride, E, edge_weights, N, gamma_e, ssum, (long)batch_stride, (long)w_bstride);
+  return check_launch("k_edge_softmax_list");
+}
+
+extern "C" int rd_edge_gamma_dense(int32_t N, int32_t E, const int64_t* edge_index, int64_t row_stride, const float* gamma_e,
+                                   float* gamma_dense, void* stream) {
+  RD_REQUIRE(N > 0 && N <= 4096 && E >= 0, "bad N=%d E=%d", N, E);
+  RD_REQUIRE(edge_index && gamma_e && gamma_dense, "NULL tensor");
+  hipLaunchKernelGGL(k_edge_gamma_dense, dim3(cdiv(N, 4)), dim3(256), (size_t)4 * N * sizeof(float), (hipStream_t)stream, edge_index,
+                     edge_index + row_stride, E, gamma_e, N, gamma_dense);
+  return check_launch("k_edge_gamma_dense");
 }
 
 // out[i,c] = sum_j gamma[j,i] * V[j,c] (+ skip[i,c])  -- the source-valued aggregate of
@@ -201,6 +249,38 @@ extern "C" int rd_aggregate_fwd(int32_t N, int32_t C, const float* gamma, const 
   g.B = V; g.sb_n = 1; g.sb_k = C;         // B(c,j) = V[j*C + c]
   g.C = out; g.sc_m = C;
   g.residual = skip; g.res_m = C;
+  return launch_gemm(g, (hipStream_t)stream);
+}
+
+// The same for B feature matrices V [B,N,C] that share one coefficient matrix (one batched product; the legacy `Raindrop` model,
+// code/models_rd.py:155-165, calls the operator once per sample of a batch with the same graph).
+extern "C" int rd_aggregate_batched_fwd(int32_t B, int32_t N, int32_t C, const float* gamma, const float* V, const float* skip,
+                                        float* out, void* stream) {
+  RD_REQUIRE(B >= 0 && N > 0 && C > 0, "bad B=%d N=%d C=%d", B, N, C);
+  if (B == 0) return RD_OK;
+  RD_REQUIRE(gamma && V && out, "NULL tensor");
+  if (B == 1) return rd_aggregate_fwd(N, C, gamma, V, skip, out, stream);
+  GemmArgs g{};
+  g.M = N; g.N = C; g.K = N; g.nsplit = 1;
+  g.A = gamma; g.sa_m = 1; g.sa_k = N;
+  g.B = V; g.sb_n = 1; g.sb_k = C;
+  g.C = out; g.sc_m = C;
+  g.nbatch = B; g.batch_inner = 1; g.a_bo = 0; g.b_bo = (long)N * C; g.c_bo = (long)N * C;
+  g.residual = skip; g.res_m = C; g.res_batched = 1;
+  return launch_gemm(g, (hipStream_t)stream);
+}
+extern "C" int rd_aggregate_batched_bwd(int32_t B, int32_t N, int32_t C, const float* gamma, const float* dout, float* dV,
+                                        void* stream) {
+  RD_REQUIRE(B >= 0 && N > 0 && C > 0, "bad B=%d N=%d C=%d", B, N, C);
+  if (B == 0) return RD_OK;
+  RD_REQUIRE(gamma && dout && dV, "NULL tensor");
+  if (B == 1) return rd_aggregate_bwd(N, C, gamma, dout, dV, stream);
+  GemmArgs g{};
+  g.M = N; g.N = C; g.K = N; g.nsplit = 1;
+  g.A = gamma; g.sa_m = N; g.sa_k = 1;
+  g.B = dout; g.sb_n = 1; g.sb_k = C;
+  g.C = dV; g.sc_m = C;
+  g.nbatch = B; g.batch_inner = 1; g.a_bo = 0; g.b_bo = (long)N * C; g.c_bo = (long)N * C;
   return launch_gemm(g, (hipStream_t)stream);
 }
 

@@ -103,6 +103,26 @@ __global__ __launch_bounds__(256) void k_obs_embed_bwd(const float* __restrict__
   }
 }
 
+// z[t,b,f*d+c] = Y[b,f,t*d+c] * rs[b,f]  -- the [F,T*d] -> [T,F*d] layout change of code/models_rd.py:338-342 with the
+// aggregate coefficient of a per-sample graph folded in (rs == null: 1).  Iterates in the DESTINATION order (coalesced stores).
+__global__ __launch_bounds__(256) void k_rows_to_tokens(const float* __restrict__ Y, const float* __restrict__ rs,
+                                                        float* __restrict__ z, int B, int T, int F, int d, long ldz, int bwd) {
+  const int b = blockIdx.x;
+  const int Fd = F * d;
+  const long total = (long)T * Fd;
+  float* Yw = const_cast<float*>(Y);
+  for (long i = blockIdx.y * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.y * blockDim.x) {
+    const int t = (int)(i / Fd);
+    const int fc = (int)(i - (long)t * Fd);
+    const int f = fc / d, c = fc - f * d;
+    const long zi = ((long)t * B + b) * ldz + fc;
+    const long yi = ((long)b * F + f) * ((long)T * d) + t * d + c;
+    const float r = rs ? rs[(long)b * F + f] : 1.f;
+    if (bwd) Yw[yi] = z[zi] * r;                       // dY = dz * rs (z holds dz)
+    else z[zi] = Y[yi] * r;
+  }
+}
+
 struct MsgWs {
   float *dz2, *dz1, *dx, *splitk, *colsum, *rupart;
   size_t bytes;
@@ -383,4 +403,66 @@ extern "C" int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* 
   // weight gradients dW_l = dz_l^T in_l (+ bias gradients as row sums of dz_l^T), split over the B*F rows
   if ((rc = launch_wgrad2(M, K, K, w.dz2, y1save, dW2, db2, w.dz1, xsave, dW1, db1, w.splitk, st))) return rc;
   return RD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Building blocks of the paper-faithful sensor stage (Raindrop_v2(use_beta=True): code/models_rd.py:317-343 with the literal
+// at :317 flipped).  There the two graph layers cannot be folded into one fused launch (layer 1 prunes a different edge set per
+// sample), so the model composes: observation embedding -> lin_value / increase_dim (rd_linear_fwd) -> rd_graph_beta_fwd ->
+// rd_edge_softmax_list_batched -> lin_value of layer 2 (rd_linear_fwd) -> rd_rows_to_tokens_fwd.
+// ------------------------------------------------------------------------------------------------
+extern "C" int rd_obs_embed_fwd(const rd_shape* s, const float* src, const float* R_u, float p_drop, uint64_t seed, float* X,
+                                void* stream) {
+  int rc = check_shape(s);
+  if (rc) return rc;
+  if (s->B == 0) return RD_OK;
+  RD_REQUIRE(src && R_u && X, "NULL tensor");
+  RD_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "p_drop must be in [0,1)");
+  const long per = (long)s->F * s->T * s->d_ob;
+  int gy = (int)((per + 255) / 256); if (gy > 64) gy = 64;
+  hipLaunchKernelGGL(k_obs_embed, dim3(s->B, gy), dim3(256), 0, (hipStream_t)stream, src, R_u, X, s->B, s->T, s->F, s->d_ob, p_drop,
+                     seed, seed_cell());
+  return check_launch("k_obs_embed");
+}
+
+extern "C" size_t rd_obs_embed_bwd_workspace_bytes(const rd_shape* s) {
+  if (!s || s->B <= 0) return 256;
+  return ((size_t)s->B * s->F * s->d_ob + (size_t)colsum_ws_floats(s->B, s->F * s->d_ob)) * sizeof(float) + 512;
+}
+
+extern "C" int rd_obs_embed_bwd(const rd_shape* s, const float* src, const float* X, const float* dX, float p_drop, float* dR_u,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_shape(s);
+  if (rc) return rc;
+  RD_REQUIRE(dR_u, "NULL gradient output");
+  hipStream_t st = (hipStream_t)stream;
+  const int B = s->B, T = s->T, F = s->F, d = s->d_ob;
+  if (B == 0) { RD_HIP(hipMemsetAsync(dR_u, 0, sizeof(float) * F * d, st)); return RD_OK; }
+  RD_REQUIRE(src && X && dX && workspace, "NULL tensor");
+  RD_REQUIRE(workspace_bytes >= rd_obs_embed_bwd_workspace_bytes(s), "workspace too small");
+  RD_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "p_drop must be in [0,1)");
+  float* rupart = (float*)workspace;
+  float* cws = rupart + align_up((size_t)B * F * d * sizeof(float), 256) / sizeof(float);
+  hipLaunchKernelGGL(k_obs_embed_bwd, dim3(B), dim3(256), 0, st, dX, X, src, rupart, B, T, F, d, 1.0f / (1.0f - p_drop));
+  if ((rc = check_launch("k_obs_embed_bwd"))) return rc;
+  return launch_colsum(rupart, B, F * d, F * d, dR_u, cws, st);
+}
+
+static int rows_tokens(const rd_shape* s, const float* Y, const float* rowscale, float* z, int32_t ldz, void* stream, int bwd) {
+  int rc = check_shape(s);
+  if (rc) return rc;
+  if (s->B == 0) return RD_OK;
+  RD_REQUIRE(Y && z, "NULL tensor");
+  RD_REQUIRE(ldz >= s->F * s->d_ob, "ldz (%d) < F*d_ob", ldz);
+  const long per = (long)s->F * s->T * s->d_ob;
+  int gy = (int)((per + 255) / 256); if (gy > 64) gy = 64;
+  hipLaunchKernelGGL(k_rows_to_tokens, dim3(s->B, gy), dim3(256), 0, (hipStream_t)stream, Y, rowscale, z, s->B, s->T, s->F, s->d_ob,
+                     (long)ldz, bwd);
+  return check_launch("k_rows_to_tokens");
+}
+extern "C" int rd_rows_to_tokens_fwd(const rd_shape* s, const float* Y, const float* rowscale, float* z, int32_t ldz, void* stream) {
+  return rows_tokens(s, Y, rowscale, z, ldz, stream, 0);
+}
+extern "C" int rd_rows_to_tokens_bwd(const rd_shape* s, const float* dz, int32_t ldz, const float* rowscale, float* dY, void* stream) {
+  return rows_tokens(s, dY, rowscale, const_cast<float*>(dz), ldz, stream, 1);
 }

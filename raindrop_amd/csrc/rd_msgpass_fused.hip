@@ -235,47 +235,74 @@ __device__ __forceinline__ void zero_plane_pads(__bf16* P, int rows, int prow, i
   }
 }
 
-// acc[jj][rt] (16x16 tiles) += A[rows rt*16.., 32 KC0 .. 32 KC1) * panel^T ; A planes (hi/lo) in LDS.
-// The three split products are issued as three sweeps over independent accumulators.  A product runs as two
-// halves of the reduction (KC = 0..3, 4..7): the registers of the first half are free while the second half
-// multiplies, so the NEXT layer's first half-panel streams in underneath it.
+// acc[jj][rt] (16x16 tiles) += A[rows rt*16.., 0 .. 32 NKC) * panel^T ; A planes (hi/lo) in LDS.
+// The A fragments are ROLLED: as soon as the three split products of (step kc, row tile rt) are issued, the fragments of
+// (kc + 1, rt) are requested into the same registers, so the LDS reads of the next reduction step travel under the MFMAs of the
+// other row tiles instead of in front of the step (measured round 3: the products ran at ~50 % of the matrix pipe with
+// read-then-multiply steps -- all waves of a SIMD read, then all multiply).  RD_K1_ROLL=0 builds the old order (A/B).
+// `mid()` runs after step NKC/2 - 1: the registers of the first half of the panel are free there, so the NEXT layer's first
+// half-panel streams in underneath the second half of this product.
 // kclim (wave-uniform): reduction steps kc >= kclim are skipped -- the caller knows the A operand is exactly zero there
 // (padded / unobserved time steps), so the skipped products are x0: bit-safe.
-template <int RT, int KC0, int KC1>
-__device__ __forceinline__ void mma_steps(f32x4 (&acc)[NJ][RT], const __bf16* Ah, const __bf16* Al,
-                                          const Panel& p, int lane, int kclim = NKC) {
+#ifndef RD_K1_ROLL
+#define RD_K1_ROLL 1
+#endif
+template <int RT, typename Mid>
+__device__ __forceinline__ void mma_mid(f32x4 (&acc)[NJ][RT], const __bf16* Ah, const __bf16* Al, Panel& p, int lane, int kclim, Mid&& mid) {
   const int aoff = (lane & 15) * LDX + 8 * (lane >> 4);
-  if (RD_ABL & 2) return;
-#pragma unroll
-  for (int kc = KC0; kc < KC1; ++kc) {
-    if (kc >= kclim) break;
-    bf16x8 ah[RT], al[RT];
+  if (RD_ABL & 2) { mid(); return; }
+  bf16x8 ah[RT], al[RT];
+  if (RD_K1_ROLL) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * LDX + aoff + kc * 32);
-      al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * LDX + aoff + kc * 32);
+      ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * LDX + aoff);
+      al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * LDX + aoff);
     }
+  }
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj)
+  for (int kc = 0; kc < NKC; ++kc) {
+    if (kc < kclim) {                                              // wave-uniform
+      if (!RD_K1_ROLL) {
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-        acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], p.h[jj][kc], acc[jj][rt], 0, 0, 0);
+        for (int rt = 0; rt < RT; ++rt) {
+          ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * LDX + aoff + kc * 32);
+          al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * LDX + aoff + kc * 32);
+        }
+      }
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj)
+      for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-        acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.l[jj][kc], acc[jj][rt], 0, 0, 0);
+        for (int jj = 0; jj < NJ; ++jj) {
+          acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], p.h[jj][kc], acc[jj][rt], 0, 0, 0);
+          acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.l[jj][kc], acc[jj][rt], 0, 0, 0);
+          acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.h[jj][kc], acc[jj][rt], 0, 0, 0);
+        }
+        if (RD_K1_ROLL && kc + 1 < NKC) {                          // in-bounds whatever kclim is: the planes hold NKC steps
+          ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * LDX + aoff + (kc + 1) * 32);
+          al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * LDX + aoff + (kc + 1) * 32);
+        }
+      }
+      if (RD_K1_ROLL && kc + 1 < NKC) {
+        // pin the issue order of this step: three MFMAs, the two fragment reads they free, ... (the scheduler otherwise
+        // collects all six reads behind the ninth MFMA and waits for them at once)
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-        acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.h[jj][kc], acc[jj][rt], 0, 0, 0);
+        for (int rt = 0; rt < RT; ++rt) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 3 * NJ, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+      }
+    }
+    if (kc == NKC / 2 - 1) {
+      __builtin_amdgcn_sched_barrier(0);                            // the scheduler otherwise sinks these loads below the second half
+      mid();
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 }
 template <int RT>
 __device__ __forceinline__ void mma_panel(f32x4 (&acc)[NJ][RT], const __bf16* Ah, const __bf16* Al,
-                                          const Panel& p, int lane, int kclim = NKC) {
-  mma_steps<RT, 0, NKC>(acc, Ah, Al, p, lane, kclim);
+                                          Panel& p, int lane, int kclim = NKC) {
+  mma_mid<RT>(acc, Ah, Al, p, lane, kclim, [] {});
 }
 
 // srow[rt][r] = ssum[16 rt + 4 g + r] (0 beyond F): one 16-byte load per row tile when F % 4 == 0 puts the quad inside
@@ -553,11 +580,9 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
     tzero_uncovered(a.tpY1, dm, sb, tid);
   }
   RD_STAMP(13);
-  mma_steps<RT, 0, NKC / 2>(acc, Xh, Xl, pw, lane, kclim1);
-  __builtin_amdgcn_sched_barrier(0);                                   // the scheduler otherwise sinks these loads below the second half
-  if (live2) load_panel_kc<0, NKC / 2>(pw, wtiles(a, dm, 1, 0), nct, wave, lane);     // layer-2 weights, first half of the reduction
-  __builtin_amdgcn_sched_barrier(0);
-  mma_steps<RT, NKC / 2, NKC>(acc, Xh, Xl, pw, lane, kclim1);
+  mma_mid<RT>(acc, Xh, Xl, pw, lane, kclim1, [&] {
+    if (live2) load_panel_kc<0, NKC / 2>(pw, wtiles(a, dm, 1, 0), nct, wave, lane);   // layer-2 weights, first half of the reduction
+  });
   RD_STAMP(3);
   if (live2) load_panel_kc<NKC / 2, NKC>(pw, wtiles(a, dm, 1, 0), nct, wave, lane);   // second half
   RD_STAMP(12);
@@ -817,11 +842,9 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
     tzero_uncovered(a.tpD2, dm, sb, tid);
     tzero_uncovered(a.tpD1, dm, sb, tid);
   }
-  mma_steps<RT, 0, NKC / 2>(acc, Dh, Dl, pw, lane, kclim2);
-  __builtin_amdgcn_sched_barrier(0);
-  if (liveX) load_panel_kc<0, NKC / 2>(pw, wtiles(a, dm, 0, 1), nct, wave, lane);     // W1^T, first half of the reduction
-  __builtin_amdgcn_sched_barrier(0);
-  mma_steps<RT, NKC / 2, NKC>(acc, Dh, Dl, pw, lane, kclim2);
+  mma_mid<RT>(acc, Dh, Dl, pw, lane, kclim2, [&] {
+    if (liveX) load_panel_kc<0, NKC / 2>(pw, wtiles(a, dm, 0, 1), nct, wave, lane);   // W1^T, first half of the reduction
+  });
   RD_STAMP(4);
   if (liveX) load_panel_kc<NKC / 2, NKC>(pw, wtiles(a, dm, 0, 1), nct, wave, lane);
   if (ract) ru_issue(rtg);

@@ -69,16 +69,25 @@ class Raindrop_v2(nn.Module):
 
     def __init__(self, d_inp=36, d_model=64, nhead=4, nhid=128, nlayers=2, dropout=0.3, max_len=215,
                  d_static=9, MAX=100, perc=0.5, aggreg='mean', n_classes=2, global_structure=None,
-                 sensor_wise_mask=False, static=True, freeze_R_u=False):
+                 sensor_wise_mask=False, static=True, freeze_R_u=False, use_beta=False, compute_distance=False):
         """Positional signature of code/models_rd.py:208-209.  `freeze_R_u` (keyword, not in the reference): the
         upstream GPU run builds `R_u = Parameter(...).cuda()`, a NON-leaf tensor -- it never reaches the optimizer or
         the state_dict and keeps its initial value.  Here R_u is a registered, trained Parameter
-        (the evident intent); `freeze_R_u=True` restores the upstream dynamics (requires_grad=False, still saved)."""
+        (the evident intent); `freeze_R_u=True` restores the upstream dynamics (requires_grad=False, still saved).
+
+        `use_beta` / `compute_distance` (keywords, defaults = the reference's literals): the reference hard-wires
+        `use_beta = False` inside forward (code/models_rd.py:317) and always evaluates `distance`, which is exactly 0 on
+        that path.  `use_beta=True` runs the paper's branch -- layer 1 through
+        `Observation_progation.message`'s use_beta arm (time-dependent edge scores from the positional encoding, half of
+        the edges pruned PER SAMPLE), layer 2 on each sample's surviving edges -- and `compute_distance=True` evaluates
+        code/models_rd.py:345-346 on the returned edge scores instead of returning the constant."""
         super().__init__()
         from torch.nn import TransformerEncoder, TransformerEncoderLayer
         self.model_type = 'Transformer'
         self.global_structure = global_structure
         self.sensor_wise_mask = sensor_wise_mask
+        self.use_beta = bool(use_beta)
+        self.compute_distance = bool(compute_distance)
         if sensor_wise_mask:
             raise _lib.RaindropHipError(
                 "RD_EUNSUPPORTED: sensor_wise_mask=True is broken in the reference itself (shape "
@@ -153,6 +162,37 @@ class Raindrop_v2(nn.Module):
             self._graph_cache = (key, dict(adj=adj, edge_index=ei, edge_weights=ew, gamma=gamma, ssum=ssum))
         return self._graph_cache[1]
 
+    def _sensor_stage_beta(self, src, times, lengths, shp, p_drop, seed, g):
+        """code/models_rd.py:313-346 with `use_beta = True`, batched over the samples (the reference loops):
+        X = dropout(relu(src * R_u)) as [B,F,K]; layer 1 = the use_beta operator with p_t = the sample's positional
+        encoding (:324,:329) -> per-sample pruned edge lists and scores; layer 2 = the default branch on THOSE lists
+        (:331-336): relu(lin_value(y1_i)) * sum of the per-target softmax over the surviving edges into i (1 where a
+        target keeps an edge, 0 where pruning removed them all); then the [F,T*d] -> [T,F*d] layout and the PE columns.
+        `distance` = mean pairwise distance of the samples' returned scores (:345-346) when `compute_distance`."""
+        dev = src.device
+        B, T, F_, d = shp.B, shp.T, shp.F, shp.d_ob
+        K, D = T * d, F_ * d + self.d_pe
+        z = torch.empty((T, B, D), dtype=torch.float32, device=dev)
+        mask = torch.empty((B, T), dtype=torch.bool, device=dev)
+        times = times.contiguous()
+        ts = self.pos_encoder.timescales(dev)
+        _lib.call("rd_pe_mask", ctypes.byref(shp), ops._ptr(times), ops._ptr(lengths), ops._ptr(ts), ops._ptr(z), ops._ptr(mask),
+                  ops._stream())
+        l1, l2 = self.ob_propagation, self.ob_propagation_layer2
+        X = ops.obs_embed(src, self.R_u, shp, p_drop, seed).view(B * F_, K)
+        V = ops.linear(X, l1.lin_value.weight, l1.lin_value.bias, act=1).view(B, F_, K)
+        H = ops.linear(X, l1.increase_dim.weight, l1.increase_dim.bias).view(B, F_, T * 32)
+        p_t = z[:, :, F_ * d:].permute(1, 0, 2).contiguous()                       # [B,T,16]: layout only
+        y1, ei2, alpha1 = ops.graph_beta(V, H, l1.map_weights, p_t, g["edge_index"], g["edge_weights"].view(1, -1), d)
+        _, ssum2 = ops.edge_softmax_list_batched(ei2, alpha1, F_, norm_row=1)
+        y2 = ops.linear(y1.reshape(B * F_, K), l2.lin_value.weight, l2.lin_value.bias, act=1).view(B, F_, K)
+        z = ops.rows_to_tokens(y2, ssum2, z, shp)
+        if self.compute_distance:
+            distance = ops.structure_distance(alpha1.t().contiguous())
+        else:
+            distance = torch.zeros((), dtype=torch.float32, device=dev)
+        return z, mask, distance
+
     def forward(self, src, static, times, lengths):
         """src [T,B,2F] (values | observation mask), static [B,d_static] or None, times [T,B],
         lengths [B] -> (logits [B,C], distance 0-d, None)   -- code/models_rd.py:278-387."""
@@ -171,12 +211,16 @@ class Raindrop_v2(nn.Module):
         self._drop_calls += 1
         seed = (torch.initial_seed() * 1000003 + self._drop_calls + ops.rank_seed_offset()) & 0x7FFFFFFFFFFFFFFF
         lengths = lengths.to(device=dev, dtype=torch.int64)
-        z, mask = ops.sensor_stage(
-            src.float(), times.float(), lengths, self.pos_encoder.timescales(dev), g["ssum"], self.R_u,
-            self.ob_propagation.lin_value.weight, self.ob_propagation.lin_value.bias,
-            self.ob_propagation_layer2.lin_value.weight, self.ob_propagation_layer2.lin_value.bias, shp,
-            p_drop, seed)
-        distance = torch.zeros((), dtype=torch.float32, device=dev)
+        if self.use_beta:
+            z, mask, distance = self._sensor_stage_beta(src.float(), times.float(), lengths, shp, p_drop, seed, g)
+        else:
+            z, mask = ops.sensor_stage(
+                src.float(), times.float(), lengths, self.pos_encoder.timescales(dev), g["ssum"], self.R_u,
+                self.ob_propagation.lin_value.weight, self.ob_propagation.lin_value.bias,
+                self.ob_propagation_layer2.lin_value.weight, self.ob_propagation_layer2.lin_value.bias, shp,
+                p_drop, seed)
+            # every sample returns the same edge scores on this branch: cdist of equal columns, exactly 0
+            distance = torch.zeros((), dtype=torch.float32, device=dev)
         # ---- temporal stage: nn.TransformerEncoder semantics on the HIP kernels (K2/K3) ----------
         r_out = z
         for i, layer in enumerate(self.transformer_encoder.layers):

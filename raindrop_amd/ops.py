@@ -247,6 +247,114 @@ def aggregate(gamma, V, skip=None):
     return _Aggregate.apply(gamma.contiguous(), V.contiguous(), None if skip is None else skip.contiguous())
 
 
+def edge_softmax_list_batched(edge_index, edge_weights, n_nodes, norm_row=1):
+    """B edge lists in one launch: edge_index int64 [B,2,E] (or [2,E] shared), edge_weights [B,E] -> (gamma_e [B,E], ssum [B,N])."""
+    ei = edge_index.contiguous()
+    w = edge_weights.contiguous()
+    _check(ei, dtype=torch.int64)
+    _check(w)
+    B, E = w.shape
+    shared = ei.dim() == 2
+    if not shared and (ei.shape[0] != B or ei.shape[1] != 2 or ei.shape[2] != E):
+        raise ValueError("edge_softmax_list_batched: edge_index must be [B,2,E] or [2,E], got %s" % (tuple(ei.shape),))
+    gamma = torch.empty((B, E), dtype=torch.float32, device=w.device)
+    ssum = torch.empty((B, n_nodes), dtype=torch.float32, device=w.device)
+    _lib.call("rd_edge_softmax_list_batched", B, int(n_nodes), E, _ptr(ei), 0 if shared else 2 * E, E, int(norm_row), _ptr(w), E,
+              _ptr(gamma), _ptr(ssum), _stream())
+    return gamma, ssum
+
+
+def edge_gamma_dense(edge_index, gamma_e, n_nodes):
+    """Dense coefficient matrix gamma[j, i] of an edge list (duplicates added in edge order, on device, deterministic)."""
+    ei = edge_index.contiguous()
+    g = gamma_e.contiguous()
+    _check(ei, dtype=torch.int64)
+    _check(g)
+    out = torch.empty((n_nodes, n_nodes), dtype=torch.float32, device=g.device)
+    _lib.call("rd_edge_gamma_dense", int(n_nodes), ei.shape[1], _ptr(ei), ei.stride(0), _ptr(g), _ptr(out), _stream())
+    return out
+
+
+class _AggregateBatched(torch.autograd.Function):
+    """out[b] = gamma^T V[b] (+ skip[b]) for V [B,N,C]: one batched product (rd_aggregate_batched_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, gamma, V, skip):
+        _check(gamma, V, skip)
+        B, N, C = V.shape
+        out = torch.empty_like(V)
+        _lib.call("rd_aggregate_batched_fwd", B, N, C, _ptr(gamma), _ptr(V), _ptr(skip), _ptr(out), _stream())
+        ctx.save_for_backward(gamma)
+        ctx.has_skip = skip is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (gamma,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        B, N, C = dout.shape
+        dV = torch.empty_like(dout)
+        _lib.call("rd_aggregate_batched_bwd", B, N, C, _ptr(gamma), _ptr(dout), _ptr(dV), _stream())
+        return None, dV, (dout if ctx.has_skip else None)
+
+
+def aggregate_batched(gamma, V, skip=None):
+    return _AggregateBatched.apply(gamma.contiguous(), V.contiguous(), None if skip is None else skip.contiguous())
+
+
+class _ObsEmbed(torch.autograd.Function):
+    """X[b,f,t*d+c] = dropout(relu(src[t,b,f] * R_u[f*d+c])): rd_obs_embed_fwd / _bwd (gradient w.r.t. R_u only)."""
+
+    @staticmethod
+    def forward(ctx, src, R_u, shp, p_drop, seed):
+        _check(src, R_u)
+        B, T, F, d = shp.B, shp.T, shp.F, shp.d_ob
+        X = torch.empty((B, F, T * d), dtype=torch.float32, device=src.device)
+        _lib.call("rd_obs_embed_fwd", ctypes.byref(shp), _ptr(src), _ptr(R_u), float(p_drop), int(seed), _ptr(X), _stream())
+        ctx.save_for_backward(src, X)
+        ctx.shp, ctx.p_drop, ctx.ru_shape = shp, float(p_drop), tuple(R_u.shape)
+        return X
+
+    @staticmethod
+    def backward(ctx, dX):
+        src, X = ctx.saved_tensors
+        dX = dX.contiguous()
+        dRu = torch.empty(ctx.ru_shape, dtype=torch.float32, device=dX.device)
+        ws = _workspace(_lib.load().rd_obs_embed_bwd_workspace_bytes(ctypes.byref(ctx.shp)), dX.device)
+        _lib.call("rd_obs_embed_bwd", ctypes.byref(ctx.shp), _ptr(src), _ptr(X), _ptr(dX), ctx.p_drop, _ptr(dRu), _ptr(ws), ws.numel(),
+                  _stream())
+        return None, dRu, None, None, None
+
+
+def obs_embed(src, R_u, shp, p_drop=0.0, seed=0):
+    return _ObsEmbed.apply(src.contiguous(), R_u.contiguous(), shp, p_drop, seed)
+
+
+class _RowsToTokens(torch.autograd.Function):
+    """z[:, :, :F*d] of a [T,B,ldz] buffer <- Y [B,F,T*d] * rowscale [B,F] (in place into `z`, which already holds the PE columns)."""
+
+    @staticmethod
+    def forward(ctx, Y, rowscale, z, shp):
+        _check(Y, rowscale, z)
+        _lib.call("rd_rows_to_tokens_fwd", ctypes.byref(shp), _ptr(Y), _ptr(rowscale), _ptr(z), z.shape[2], _stream())
+        ctx.save_for_backward(rowscale)
+        ctx.shp, ctx.yshape = shp, tuple(Y.shape)
+        ctx.mark_dirty(z)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        (rowscale,) = ctx.saved_tensors
+        dz = dz.contiguous()
+        dY = torch.empty(ctx.yshape, dtype=torch.float32, device=dz.device)
+        _lib.call("rd_rows_to_tokens_bwd", ctypes.byref(ctx.shp), _ptr(dz), dz.shape[2], _ptr(rowscale), _ptr(dY), _stream())
+        return dY, None, None, None
+
+
+def rows_to_tokens(Y, rowscale, z, shp):
+    return _RowsToTokens.apply(Y.contiguous(), None if rowscale is None else rowscale.contiguous(), z, shp)
+
+
 class _GraphBeta(torch.autograd.Function):
     """The use_beta graph operator (rd_graph_beta_fwd / _bwd), batched: V [B,N,K], H [B,N,T*32], map_w [N,16],
     p_t [B or 1, T, 16], edge_index int64 [2,E], edge_weights [B or 1, E] -> out [B,N,K], edge_index' [B,2,Kk], alpha [B,Kk]."""

@@ -61,14 +61,20 @@ class TransformerConv(nn.Module):
             raise _lib.RaindropHipError(
                 "RD_EUNSUPPORTED: TransformerConv is built for the reference's only use: heads=1, "
                 "edge_weights given (they replace q.k scores), no edge_attr/beta/dropout")
-        n = x.shape[0]
+        # x [N, C] (the reference's call) or [B, N, C]: B feature matrices on the same graph in one batched product
+        batched = x.dim() == 3
+        n = x.shape[-2]
         gamma_e, _ = ops.edge_softmax_list(edge_index, edge_weights, n, norm_row=1)
-        # dense coefficient matrix gamma[j, i]; duplicate edges accumulate (== scatter-add of messages)
-        gamma = torch.zeros((n, n), dtype=torch.float32, device=x.device)
-        gamma.index_put_((edge_index[0], edge_index[1]), gamma_e, accumulate=True)
-        v = ops.linear(x, self.lin_value.weight, self.lin_value.bias, act=0)
-        skip = ops.linear(x, self.lin_skip.weight, self.lin_skip.bias, act=0) if self.root_weight else None
-        out = ops.aggregate(gamma, v, skip)
+        # dense coefficient matrix gamma[j, i]; duplicate edges accumulate in edge order (== scatter-add of messages), on device
+        gamma = ops.edge_gamma_dense(edge_index, gamma_e, n)
+        x2 = x.reshape(-1, x.shape[-1])
+        v = ops.linear(x2, self.lin_value.weight, self.lin_value.bias, act=0)
+        skip = ops.linear(x2, self.lin_skip.weight, self.lin_skip.bias, act=0) if self.root_weight else None
+        if batched:
+            B = x.shape[0]
+            out = ops.aggregate_batched(gamma, v.view(B, n, -1), None if skip is None else skip.view(B, n, -1))
+        else:
+            out = ops.aggregate(gamma, v, skip)
         if isinstance(return_attention_weights, bool):
             return out, (edge_index, gamma_e.unsqueeze(-1))
         return out

@@ -44,7 +44,15 @@ MODEL_CASES = [
     # heads of 520): two samples are what the CPU reference finishes in minutes
     ("syn256_b2", "SYN256", 2, "sparse", 8, 10),
 ]
-FULL_LIMIT = {"p19_b256": 4096, "p12_b32": 4096, "syn256_b2": 4096}
+FULL_LIMIT = {"p19_b256": 4096, "p12_b32": 4096, "syn256_b2": 4096, "p19_beta_sparse": 4096, "p19_beta_ones": 4096,
+              "p12_beta_sparse": 4096}
+# the paper's branch: the reference with its `use_beta = False` literal (code/models_rd.py:317) flipped IN MEMORY by
+# oracle/ref_loader.load_models_rd_with_beta(); Raindrop_v2(use_beta=True, compute_distance=True) here
+BETA_CASES = [
+    ("p19_beta_sparse", "P19", 8, "sparse", 11, 12),
+    ("p19_beta_ones", "P19", 8, "ones", 13, 14),
+    ("p12_beta_sparse", "P12", 3, "sparse", 15, 16),
+]
 
 
 def strided(t, n=SAMPLE, full_limit=70_000):
@@ -64,10 +72,10 @@ def zero_dropout(model):
             mod.dropout = 0.0
 
 
-def model_case(name, cfg_name, B, kind, pseed, bseed):
+def model_case(name, cfg_name, B, kind, pseed, bseed, use_beta=False):
     cfg = synth.make_config(cfg_name)
     gs = synth.make_structure(cfg, kind)
-    model = ref_loader.build_raindrop_v2(cfg, gs.clone())
+    model = ref_loader.build_raindrop_v2(cfg, gs.clone(), use_beta=use_beta)
     synth.fill_params_(model, seed=pseed)
     zero_dropout(model)
     b = synth.make_batch(cfg, B, seed=bseed)
@@ -82,18 +90,23 @@ def model_case(name, cfg_name, B, kind, pseed, bseed):
 
     params = dict(model.named_parameters())
     live = [n for n, t in params.items() if t.grad is not None]
-    assert sorted(live) == sorted(synth.live_parameter_names(cfg)), (live, synth.live_parameter_names(cfg))
+    want_live = synth.live_parameter_names(cfg) + (["ob_propagation.map_weights", "ob_propagation.increase_dim.weight",
+                                                   "ob_propagation.increase_dim.bias"] if use_beta else [])
+    assert sorted(live) == sorted(want_live), (live, want_live)
 
     # cross-check with the independent restatement before trusting either
     p = {n: t.detach().clone().requires_grad_(n in live) for n, t in params.items()}
-    lg2, loss2, g2 = O2.step_fwd_bwd(p, cfg, b, gs, faithful=False)
-    _, _, inter = O2.raindrop_v2_forward({n: t.detach() for n, t in params.items()}, cfg, b["src"],
-                                         b["static"], b["times"], b["lengths"], gs,
-                                         return_intermediates=True)
+    lg2, loss2, g2 = O2.step_fwd_bwd(p, cfg, b, gs, faithful=use_beta, use_beta=use_beta)
+    _, d2, inter = O2.raindrop_v2_forward({n: t.detach() for n, t in params.items()}, cfg, b["src"],
+                                          b["static"], b["times"], b["lengths"], gs, faithful=use_beta,
+                                          return_intermediates=True, use_beta=use_beta)
+    assert abs(float(d2) - float(distance)) <= 1e-6 * max(1.0, abs(float(distance))), (float(d2), float(distance))
     e_logit = float((lg2 - logits.detach()).abs().max())
     e_grad = max(float((g2[n] - params[n].grad).abs().max() / (params[n].grad.abs().max() + 1e-30))
                  for n in live)
-    assert e_logit < 2e-6 and e_grad < 2e-5, (name, e_logit, e_grad)
+    # use_beta: the pruned edges of a sample are summed in pruning order, and the reference's argsort (unstable) orders tied
+    # scores (all-ones structure: 34 equal edges per target) differently from the restatement's -- rounding-level, bounded looser
+    assert e_logit < 2e-6 and e_grad < (1e-4 if use_beta else 2e-5), (name, e_logit, e_grad)
 
     ei, ew = O2.build_graph(gs.numpy())
     out = dict(
@@ -259,3 +272,6 @@ if __name__ == "__main__":
     for case in MODEL_CASES:
         if not only or case[0] in only:
             model_case(*case)
+    for case in BETA_CASES:
+        if not only or case[0] in only:
+            model_case(*case, use_beta=True)

@@ -9,6 +9,8 @@ from raindrop_amd import synth
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 MODEL_CASES = ["tiny_sparse", "p19_ones", "p19_sparse", "p12_ones", "pam_ones", "p19_b256", "p12_b32", "syn256_b2"]
+# the paper's branch (reference with its use_beta literal flipped in memory, tests/golden/make_goldens.py BETA_CASES)
+BETA_CASES = ["p19_beta_sparse", "p19_beta_ones", "p12_beta_sparse"]
 
 
 def load_golden(name):
@@ -38,9 +40,10 @@ def golden_grad(g, name, full):
     return g["grad/" + name], full.detach().reshape(-1)[::stride].cpu().numpy()
 
 
-def build_ours(cfg, gs, device, param_seed):
+def build_ours(cfg, gs, device, param_seed, **extra):
     from raindrop_amd.models_rd import Raindrop_v2
     kw = {} if cfg["static"] else {"static": False}
+    kw.update(extra)
     m = Raindrop_v2(cfg["d_inp"], cfg["d_model"], cfg["nhead"], cfg["nhid"], cfg["nlayers"],
                     cfg["dropout"], cfg["max_len"], cfg["d_static"], cfg["MAX"], 0.5, cfg["aggreg"],
                     cfg["n_classes"], gs, sensor_wise_mask=False, **kw)

@@ -9,7 +9,7 @@ import torch
 
 from oracle import restatement as O2
 from raindrop_amd import synth
-from tests.helpers import MODEL_CASES, build_ours, case_inputs, golden_grad, load_golden
+from tests.helpers import BETA_CASES, MODEL_CASES, build_ours, case_inputs, golden_grad, load_golden
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -192,6 +192,81 @@ def test_model_vs_golden(name):
     gr = m._graph(torch.device(DEV))
     assert np.array_equal(gr["edge_index"].cpu().numpy(), g["edge_index"])
     assert np.array_equal(gr["edge_weights"].cpu().numpy(), g["edge_weights"])
+
+
+@pytest.mark.parametrize("name", BETA_CASES)
+def test_model_use_beta_vs_golden(name, precision_mode):
+    """Raindrop_v2(use_beta=True, compute_distance=True): the paper's branch of the model (layer 1 = use_beta operator with the
+    sample's positional encoding as p_t, per-sample pruning, layer 2 on the surviving edges) against fixtures produced by the
+    reference's own forward with its `use_beta = False` literal (code/models_rd.py:317) flipped.  Logits 1e-4, loss 1e-5, the
+    structure distance (non-zero on this branch) 1e-5 relative, every gradient -- incl. map_weights / increase_dim, which only
+    this branch trains."""
+    g, meta = load_golden(name)
+    cfg, gs, batch = case_inputs(meta)
+    m = build_ours(cfg, gs, DEV, meta["param_seed"], use_beta=True, compute_distance=True)
+    m.train()
+    dv = {k: (None if v is None else v.to(DEV)) for k, v in batch.items()}
+    logits, distance, third = m(dv["src"], dv["static"], dv["times"], dv["lengths"])
+    assert third is None
+    loss = torch.nn.functional.cross_entropy(logits, dv["y"])
+    loss.backward()
+    assert np.abs(logits.detach().cpu().numpy() - g["logits"]).max() < 1e-4
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    assert abs(float(distance) - float(g["distance"])) <= 1e-5 * float(g["distance"]) + 1e-7, (float(distance), float(g["distance"]))
+    params = dict(m.named_parameters())
+    live = [str(x) for x in g["live"]]
+    assert sorted(n for n, p in params.items() if p.grad is not None) == sorted(live)
+    for n in live:
+        exp, got = golden_grad(g, n, params[n].grad)
+        _grad_close(got, exp, 1e-3, n)
+        gn = float(g["gradnorm/" + n])
+        assert abs(params[n].grad.double().norm().item() - gn) <= 1e-3 * gn + 1e-12, n
+    # default keywords reproduce the reference's literals: use_beta off, distance the exact constant 0
+    m2 = build_ours(cfg, gs, DEV, meta["param_seed"])
+    assert not m2.use_beta and not m2.compute_distance
+    with torch.no_grad():
+        _, d0, _ = m2(dv["src"], dv["static"], dv["times"], dv["lengths"])
+    assert float(d0) == 0.0
+
+
+def test_batched_edge_ops_match_single_graph_calls():
+    """rd_edge_softmax_list_batched == B calls of rd_edge_softmax_list (bit for bit); rd_edge_gamma_dense == the scatter of the
+    per-edge coefficients (duplicate edges added in edge order); rd_aggregate_batched == B calls of rd_aggregate, fwd + bwd."""
+    from raindrop_amd import ops
+    rng = np.random.default_rng(5)
+    B, N, E, C = 5, 23, 140, 37
+    ei = torch.from_numpy(rng.integers(0, N, size=(B, 2, E))).to(DEV)
+    ei[:, :, 7] = ei[:, :, 3]                                        # a duplicate edge per graph
+    w = torch.from_numpy(rng.standard_normal((B, E)).astype(np.float32)).to(DEV)
+    gb, sb = ops.edge_softmax_list_batched(ei, w, N, norm_row=1)
+    for b in range(B):
+        g1, s1 = ops.edge_softmax_list(ei[b], w[b], N, norm_row=1)
+        assert torch.equal(gb[b], g1) and torch.equal(sb[b], s1)
+    gs_, ss_ = ops.edge_softmax_list_batched(ei[0], w, N, norm_row=0)  # one shared list, per-graph weights, source-normalised
+    for b in range(B):
+        g1, s1 = ops.edge_softmax_list(ei[0], w[b], N, norm_row=0)
+        assert torch.equal(gs_[b], g1) and torch.equal(ss_[b], s1)
+    dense = ops.edge_gamma_dense(ei[0], gb[0], N).cpu().numpy()
+    ref = np.zeros((N, N), np.float32)
+    e0, g0 = ei[0].cpu().numpy(), gb[0].cpu().numpy()
+    for e in range(E):
+        ref[e0[0, e], e0[1, e]] = np.float32(ref[e0[0, e], e0[1, e]] + g0[e])
+    assert np.array_equal(dense, ref)
+    gam = torch.from_numpy(dense).to(DEV)
+    V = torch.from_numpy(rng.standard_normal((B, N, C)).astype(np.float32)).to(DEV).requires_grad_(True)
+    S = torch.from_numpy(rng.standard_normal((B, N, C)).astype(np.float32)).to(DEV).requires_grad_(True)
+    R = torch.from_numpy(rng.standard_normal((B, N, C)).astype(np.float32)).to(DEV)
+    out = ops.aggregate_batched(gam, V, S)
+    gV, gS = torch.autograd.grad((out * R).sum(), [V, S])
+    for b in range(B):
+        v1 = V[b].detach().clone().requires_grad_(True)
+        s1 = S[b].detach().clone().requires_grad_(True)
+        o1 = ops.aggregate(gam, v1, s1)
+        g1 = torch.autograd.grad((o1 * R[b]).sum(), [v1, s1])
+        assert torch.allclose(out[b], o1, rtol=0, atol=1e-6) and torch.allclose(gV[b], g1[0], rtol=0, atol=1e-6)
+        assert torch.equal(gS[b], g1[1])
+    ref_out = np.einsum("ji,bjc->bic", dense.astype(np.float64), V.detach().cpu().numpy().astype(np.float64)) + S.detach().cpu().numpy()
+    assert np.abs(out.detach().cpu().numpy() - ref_out).max() < 1e-4
 
 
 def test_operator_goldens_on_device():

@@ -6,7 +6,7 @@ import torch
 
 from oracle import restatement as O2
 from raindrop_amd import synth
-from tests.helpers import MODEL_CASES, case_inputs, load_golden
+from tests.helpers import BETA_CASES, MODEL_CASES, case_inputs, load_golden
 
 FAST = [c for c in MODEL_CASES if c != "pam_ones"]   # PAM (150 M parameters) runs in the slow set
 
@@ -38,6 +38,31 @@ def test_restatement_matches_golden(name):
         got = grads[n].reshape(-1)[:: int(g["gradstride/" + n])].numpy()
         scale = np.abs(exp).max() + 1e-30
         assert np.abs(got - exp).max() / scale < 5e-5, n
+        assert abs(grads[n].double().norm().item() - float(g["gradnorm/" + n])) <= 1e-4 * float(g["gradnorm/" + n]) + 1e-12
+
+
+@pytest.mark.parametrize("name", BETA_CASES)
+def test_restatement_matches_use_beta_golden(name):
+    """The paper's branch: the reference's forward with `use_beta = True` (code/models_rd.py:317 flipped in memory when the
+    fixture was made) against the restatement's use_beta order -- logits, loss, the structure distance (non-zero here: the
+    samples prune different edges) and every gradient, including the three tensors only this branch trains."""
+    g, meta = load_golden(name)
+    cfg, gs, batch = case_inputs(meta)
+    live = set(str(x) for x in g["live"])
+    assert {"ob_propagation.map_weights", "ob_propagation.increase_dim.weight", "ob_propagation.increase_dim.bias"} <= live
+    p = _params(cfg, gs, meta, live)
+    logits, loss, grads = O2.step_fwd_bwd(p, cfg, batch, gs, faithful=True, use_beta=True)
+    with torch.no_grad():
+        _, dist = O2.raindrop_v2_forward(p, cfg, batch["src"], batch["static"], batch["times"], batch["lengths"], gs,
+                                         faithful=True, use_beta=True)
+    assert np.abs(logits.numpy() - g["logits"]).max() < 2e-6
+    assert abs(float(loss) - float(g["loss"])) < 2e-6
+    assert float(g["distance"]) > 0.0 and abs(float(dist) - float(g["distance"])) < 1e-6
+    for n in live:
+        exp = g["grad/" + n]
+        got = grads[n].reshape(-1)[:: int(g["gradstride/" + n])].numpy()
+        scale = np.abs(exp).max() + 1e-30
+        assert np.abs(got - exp).max() / scale < 2e-4, n            # tied scores: summation order of the kept edges differs
         assert abs(grads[n].double().norm().item() - float(g["gradnorm/" + n])) <= 1e-4 * float(g["gradnorm/" + n]) + 1e-12
 
 
