@@ -377,6 +377,11 @@ int rd_structure_distance(int32_t E, int32_t B, const float* alpha_all, float* w
  *  - rd_rows_to_tokens_fwd: z[t,b,f*d+c] = Y[b,f,t*d+c] * rowscale[b,f] (rowscale NULL = 1): the aggregate coefficient of layer 2
  *    (sum of the per-target softmax over a sample's surviving edges) and the layout change of code/models_rd.py:338-342;
  *    _bwd: dY = dz * rowscale in Y's layout. */
+/* Scalar scale + nn.Dropout as a pure function of (seed + seed cell, site, element index): out = x * scale * keep / (1 - p)
+ * (p = 0: the plain scale).  The backward is the same call on the gradient.  Sites < 16 are free for callers (the library's own sites start at 16; the observation embedding is 1).
+ * The legacy `Raindrop` model's `encoder(src) * sqrt(d_model)` and input dropout (code/models_rd.py:131-134) run through it. */
+int rd_scale_dropout(int64_t n, const float* x, float scale, float p_drop, uint64_t seed, uint32_t site, float* out, void* stream);
+
 int rd_obs_embed_fwd(const rd_shape* s, const float* src, const float* R_u, float p_drop, uint64_t seed, float* X, void* stream);
 size_t rd_obs_embed_bwd_workspace_bytes(const rd_shape* s);
 int rd_obs_embed_bwd(const rd_shape* s, const float* src, const float* X, const float* dX, float p_drop, float* dR_u,

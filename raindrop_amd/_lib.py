@@ -57,6 +57,7 @@ SIGNATURES = {
     "rd_edge_gamma_dense": (c_int32, [c_int32, c_int32, _P, ctypes.c_int64, _P, _P, _P]),
     "rd_aggregate_batched_fwd": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P, _P]),
     "rd_aggregate_batched_bwd": (c_int32, [c_int32, c_int32, c_int32, _P, _P, _P, _P]),
+    "rd_scale_dropout": (c_int32, [ctypes.c_int64, _P, c_float, c_float, ctypes.c_uint64, ctypes.c_uint32, _P, _P]),
     "rd_obs_embed_fwd": (c_int32, [_SHP, _P, _P, c_float, ctypes.c_uint64, _P, _P]),
     "rd_obs_embed_bwd_workspace_bytes": (c_size_t, [_SHP]),
     "rd_obs_embed_bwd": (c_int32, [_SHP, _P, _P, _P, c_float, _P, _P, c_size_t, _P]),

@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include "rd_common.h"
+#include "rd_rng.h"
 
 namespace rd {
 
@@ -53,6 +54,31 @@ extern "C" int rd_seed_cell_advance(uint64_t* device_cell, uint64_t delta, void*
   RD_REQUIRE(device_cell != nullptr, "NULL cell");
   hipLaunchKernelGGL(k_seed_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, device_cell, delta);
   return check_launch("k_seed_advance");
+}
+
+namespace {
+// out[i] = x[i] * scale * (keep ? 1/(1-p) : 0): nn.Dropout (after a scalar scale) as a pure function of (seed, site, element), four
+// elements per thread; p == 0 is the plain scale
+__global__ __launch_bounds__(256) void k_dropout(const float* __restrict__ x, float* __restrict__ out, long n, float scale, float p,
+                                                 uint64_t seed, uint32_t site, const uint64_t* cell) {
+  seed = eff_seed(seed, cell);
+  const float inv_keep = scale / (1.0f - p);
+  for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; 4 * q < n; q += (long)gridDim.x * blockDim.x) {
+    float uu[4] = {1.f, 1.f, 1.f, 1.f};
+    if (p > 0.f) { const float4 u = uniform4(seed, site, (uint64_t)q); uu[0] = u.x; uu[1] = u.y; uu[2] = u.z; uu[3] = u.w; }
+    for (int c = 0; c < 4 && 4 * q + c < n; ++c) out[4 * q + c] = uu[c] >= p ? x[4 * q + c] * inv_keep : 0.f;
+  }
+}
+}  // namespace
+// The backward of dropout is the same call on the gradient (same seed, same site): the mask is regenerated, not stored.
+extern "C" int rd_scale_dropout(int64_t n, const float* x, float scale, float p_drop, uint64_t seed, uint32_t site, float* out,
+                                void* stream) {
+  RD_REQUIRE(n >= 0 && p_drop >= 0.f && p_drop < 1.f, "bad n=%ld / p_drop", (long)n);
+  if (n == 0) return RD_OK;
+  RD_REQUIRE(x && out, "NULL tensor");
+  long blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_dropout, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, out, (long)n, scale, p_drop, seed, site, seed_cell());
+  return check_launch("k_dropout");
 }
 
 extern "C" int rd_version(void) { return RD_ABI_VERSION; }

@@ -25,7 +25,7 @@ from . import _lib, ops
 from .Ob_propagation import Observation_progation, glorot
 from .transformer_conv import TransformerConv
 
-__all__ = ["PositionalEncodingTF", "Raindrop_v2", "Observation_progation", "TransformerConv"]
+__all__ = ["PositionalEncodingTF", "Raindrop", "Raindrop_v2", "Observation_progation", "TransformerConv"]
 
 
 class PositionalEncodingTF(nn.Module):
@@ -61,6 +61,110 @@ class PositionalEncodingTF(nn.Module):
 
     def forward(self, P_time):
         return self.getPE(P_time)
+
+
+class Raindrop(nn.Module):
+    """code/models_rd.py:46-191 -- the legacy model `from models_rd import *` also exports (never constructed by
+    code/Raindrop.py).  A `Linear(d_inp, 36)` input encoder scaled by sqrt(d_model), a `TransformerConv` applied per sample to the
+    [T, 36] step matrix (its NODES are the time steps, the sensor graph's edges connect the first 36 of them -- as upstream), a
+    36-wide positional encoding, the temporal encoder, the masked mean and the static head.  Same constructor signature,
+    registration order and state_dict surface; the per-sample Python loop of :155-165 is one batched operator call.
+    Upstream hard-codes 36 sensors and 215 steps inside forward (:150,:155); the sizes are read from the inputs here, and the
+    width relations upstream relies on (d_model a multiple of d_inp = 36) are checked at construction."""
+
+    def __init__(self, d_inp=36, d_model=64, nhead=4, nhid=128, nlayers=2, dropout=0.3, max_len=215, d_static=9,
+                 MAX=100, perc=0.5, aggreg='mean', n_classes=2, global_structure=None):
+        super().__init__()
+        from torch.nn import TransformerEncoder, TransformerEncoderLayer
+        self.model_type = 'Transformer'
+        self.global_structure = global_structure
+        d_pe = 36
+        d_enc = 36
+        self.d_pe = d_pe
+        self.pos_encoder = PositionalEncodingTF(d_pe, max_len, MAX)
+        encoder_layers = TransformerEncoderLayer(d_model + 36, nhead, nhid, dropout)
+        self.transformer_encoder = TransformerEncoder(encoder_layers, nlayers, enable_nested_tensor=False)
+        self.gcs = nn.ModuleList()
+        self.dim = int(d_model / d_inp)
+        self.transconv = TransformerConv(in_channels=36, out_channels=36 * self.dim, heads=1)
+        d_final = 36 * (self.dim + 1) + d_model
+        self.mlp_static = nn.Sequential(nn.Linear(d_final, d_final), nn.ReLU(), nn.Linear(d_final, n_classes))
+        self.d_inp = d_inp
+        self.d_model = d_model
+        self.encoder = nn.Linear(d_inp, d_enc)
+        self.emb = nn.Linear(d_static, d_model)
+        self.MLP_replace_transformer = nn.Linear(72, 36)                                   # dead (:98)
+        self.mlp = nn.Sequential(nn.Linear(d_model, d_model), nn.ReLU(), nn.Linear(d_model, n_classes))   # dead (:100-104)
+        self.aggreg = aggreg
+        self.relu = nn.ReLU()
+        self.dropout = nn.Dropout(dropout)
+        self.nhead, self.nhid, self.nlayers, self.max_len = nhead, nhid, nlayers, max_len
+        self.n_classes, self.d_static = n_classes, d_static
+        self._graph_cache = None
+        self._drop_calls = 0
+        if 36 * self.dim + 36 != d_model + 36:
+            raise _lib.RaindropHipError("Raindrop (legacy): d_model (%d) must be a multiple of 36 -- upstream concatenates a "
+                                        "[.., 36*int(d_model/d_inp)] graph output with a 36-wide encoding for an encoder of "
+                                        "width d_model + 36 (code/models_rd.py:75,84,168)" % d_model)
+        self.init_weights()
+
+    def init_weights(self):
+        """code/models_rd.py:110-113."""
+        initrange = 1e-10
+        self.encoder.weight.data.uniform_(-initrange, initrange)
+        self.emb.weight.data.uniform_(-initrange, initrange)
+
+    def _graph(self, device):
+        gs = self.global_structure
+        key = (str(device), gs.data_ptr(), gs._version)
+        if self._graph_cache is None or self._graph_cache[0] != key:
+            adj, ei, ew = ops.graph_build(gs.to(device=device, dtype=torch.float32))        # :147-151 (diagonal set, nonzero order)
+            self._graph_cache = (key, dict(adj=adj, edge_index=ei, edge_weights=ew))
+        return self._graph_cache[1]
+
+    def forward(self, src, static, times, lengths):
+        """src [T,B,2*d_inp], static [B,d_static], times [T,B], lengths [B] -> (logits, distance, None) -- code/models_rd.py:115-191."""
+        if not src.is_cuda:
+            raise _lib.RaindropHipError("Raindrop runs on a ROCm device only; move inputs with .cuda()")
+        import math
+        dev = src.device
+        T, B = src.shape[0], src.shape[1]
+        p_drop = float(self.dropout.p) if self.training else 0.0
+        self._drop_calls += 1
+        seed = (torch.initial_seed() * 1000003 + self._drop_calls + ops.rank_seed_offset()) & 0x7FFFFFFFFFFFFFFF
+        lengths = lengths.to(device=dev, dtype=torch.int64)
+        vals = src[:, :, :self.d_inp].float().contiguous().view(T * B, self.d_inp)          # :126 (layout only)
+        x = ops.linear(vals, self.encoder.weight, self.encoder.bias)                         # :129
+        x = ops.scale_dropout(x, math.sqrt(self.d_model), p_drop, seed, site=2)              # :129,:134
+        n_feat = self.encoder.out_features
+        x = x.view(T, B, n_feat).permute(1, 0, 2).contiguous()                               # [B, T nodes, 36]: layout only
+        g = self._graph(dev)
+        C = 36 * self.dim
+        shp = _lib.shape(B, T, 36, self.dim, d_pe=self.d_pe, nhead=self.nhead, nhid=self.nhid, d_static=self.d_static,
+                         n_classes=self.n_classes, max_len=self.max_len)
+        # PE columns + padding mask straight into the encoder's input buffer (:131,:143-144,:168)
+        z = torch.empty((T, B, C + self.d_pe), dtype=torch.float32, device=dev)
+        mask = torch.empty((B, T), dtype=torch.bool, device=dev)
+        tt = times.float().contiguous()
+        ts = self.pos_encoder.timescales(dev)
+        _lib.call("rd_pe_mask", ctypes.byref(shp), ops._ptr(tt), ops._ptr(lengths), ops._ptr(ts), ops._ptr(z), ops._ptr(mask),
+                  ops._stream())
+        out = self.transconv(x, g["edge_index"], edge_weights=g["edge_weights"], edge_attr=None, return_attention_weights=True)[0]
+        # [B,T,C] -> columns [0, C) of z[T,B,:]: the per-sample assignment of :162 as one layout kernel (F = 1 "sensor" of C channels
+        # per step would transpose nothing: rows_to_tokens with T steps of one C-wide cell)
+        shp_l = _lib.shape(B, T, 1, C, d_pe=self.d_pe)
+        z = ops.rows_to_tokens(out.reshape(B, 1, T * C), None, z, shp_l)
+        distance = torch.zeros((), dtype=torch.float32, device=dev)    # every sample returns the same coefficients: cdist == 0 (:166-167)
+        r_out = z
+        for i, layer in enumerate(self.transformer_encoder.layers):
+            named = dict(layer.named_parameters())
+            r_out = ops.encoder_layer(r_out, mask, shp, i, p_drop, seed, [named[n] for n in ops.ENC_PARAM_NAMES])
+        emb = ops.linear(static.float(), self.emb.weight, self.emb.bias)                     # :135
+        agg = ops.masked_mean(r_out, mask, lengths, shp)                                     # :178-183
+        output = torch.cat([agg, emb], dim=1)                                                # :187
+        hid = ops.linear(output, self.mlp_static[0].weight, self.mlp_static[0].bias, act=1)
+        output = ops.linear(hid, self.mlp_static[2].weight, self.mlp_static[2].bias)
+        return output, distance, None
 
 
 class Raindrop_v2(nn.Module):

@@ -302,6 +302,32 @@ def aggregate_batched(gamma, V, skip=None):
     return _AggregateBatched.apply(gamma.contiguous(), V.contiguous(), None if skip is None else skip.contiguous())
 
 
+class _ScaleDropout(torch.autograd.Function):
+    """x * scale followed by nn.Dropout on the device RNG (rd_scale_dropout): forward and backward regenerate the same mask."""
+
+    @staticmethod
+    def forward(ctx, x, scale, p, seed, site):
+        _check(x)
+        out = torch.empty_like(x)
+        _lib.call("rd_scale_dropout", x.numel(), _ptr(x), float(scale), float(p), int(seed), int(site), _ptr(out), _stream())
+        ctx.args = (float(scale), float(p), int(seed), int(site))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        dx = torch.empty_like(dout)
+        scale, p, seed, site = ctx.args
+        _lib.call("rd_scale_dropout", dout.numel(), _ptr(dout), scale, p, seed, site, _ptr(dx), _stream())
+        return dx, None, None, None, None
+
+
+def scale_dropout(x, scale=1.0, p=0.0, seed=0, site=2):
+    if p <= 0.0 and scale == 1.0:
+        return x
+    return _ScaleDropout.apply(x.contiguous(), scale, p, seed, site)
+
+
 class _ObsEmbed(torch.autograd.Function):
     """X[b,f,t*d+c] = dropout(relu(src[t,b,f] * R_u[f*d+c])): rd_obs_embed_fwd / _bwd (gradient w.r.t. R_u only)."""
 

@@ -243,6 +243,44 @@ def beta_batched_case():
     print("beta_batched -> %s (%.1f KB), distance %.6f" % (os.path.basename(path), os.path.getsize(path) / 1024, dist.item()))
 
 
+def legacy_v1_case():
+    """The legacy `Raindrop` class (code/models_rd.py:46-191; exported by `from models_rd import *`, never built by the script),
+    run by the reference itself at the only shape its forward admits (215 steps, 36 sensors hard-coded at :150,:155):
+    logits (train mode, dropout forced to 0, and eval), loss, distance, every live gradient, and the state_dict surface."""
+    ref = ref_loader.load()
+    d_inp, d_model, nhead, nhid, nlayers, T, d_static, B = 36, 72, 4, 96, 2, 215, 9, 3
+    gs = synth.make_structure(dict(d_inp=d_inp), "sparse", seed=3)
+    model = ref.run(ref.models_rd.Raindrop, d_inp, d_model, nhead, nhid, nlayers, 0.3, T, d_static, 100, 0.5, "mean", 2, gs.clone())
+    synth.fill_params_(model, seed=31)
+    zero_dropout(model)
+    cfg = dict(max_len=T, d_inp=d_inp, static=True, d_static=d_static, n_classes=2)
+    b = synth.make_batch(cfg, B, seed=32, density=0.4)
+    model.train()
+    logits, distance, _ = ref_loader.forward(model, b["src"], b["static"], b["times"], b["lengths"])
+    loss = F.cross_entropy(logits, b["y"])
+    loss.backward()
+    model.eval()
+    with torch.no_grad():
+        logits_eval, _, _ = ref_loader.forward(model, b["src"], b["static"], b["times"], b["lengths"])
+    params = dict(model.named_parameters())
+    live = [n for n, t in params.items() if t.grad is not None]
+    out = dict(meta=json.dumps(dict(d_inp=d_inp, d_model=d_model, nhead=nhead, nhid=nhid, nlayers=nlayers, max_len=T, d_static=d_static,
+                                    batch=B, param_seed=31, batch_seed=32, density=0.4, structure_seed=3, torch=torch.__version__)),
+               logits=logits.detach().numpy(), logits_eval=logits_eval.numpy(), loss=np.float32(loss.item()),
+               distance=np.float32(float(distance)), live=np.array(live),
+               surface=json.dumps({k: list(v.shape) for k, v in model.state_dict().items()}))
+    for n in live:
+        g = params[n].grad
+        sm, st = strided(g, full_limit=4096)
+        out["grad/" + n] = sm
+        out["gradstride/" + n] = np.int64(st)
+        out["gradnorm/" + n] = np.float64(g.double().norm().item())
+    path = os.path.join(HERE, "legacy_v1.npz")
+    np.savez_compressed(path, **out)
+    print("legacy_v1    logits %s loss %.6f distance %.3g, %d live tensors -> %s (%.1f KB)" % (
+        tuple(logits.shape), loss.item(), float(distance), len(live), os.path.basename(path), os.path.getsize(path) / 1024))
+
+
 def state_dict_surface():
     """Names and shapes of the reference's state_dict per dataset config (checkpoint surface,
     code/Raindrop.py:374,381).  Under the CPU shim `R_u` is a registered parameter."""
@@ -269,6 +307,8 @@ if __name__ == "__main__":
         state_dict_surface()
     if not only or "beta_batched" in only:
         beta_batched_case()
+    if not only or "legacy_v1" in only:
+        legacy_v1_case()
     for case in MODEL_CASES:
         if not only or case[0] in only:
             model_case(*case)

@@ -176,3 +176,28 @@ def test_sharded_evaluate_standard_all_gathers_the_same_logits():
     mp.spawn(_eval_worker, args=(world, port, ret), nprocs=world, join=True)
     assert ret[0].shape == (101, 2)
     assert np.array_equal(ret[0], ref) and np.array_equal(ret[1], ref)
+
+
+def test_bench_two_ranks_launch_line_on_one_gpu():
+    """`bench.py --gpus 2` launched EXACTLY as the driver launches it (`python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 2 --master-addr 127.0.0.1 ...`), with RD_BENCH_ONE_GPU=1 so that both ranks share cuda:0 and talk gloo:
+    the whole N > 1 control flow of the benchmark -- process-group setup, the collective step-mode decision, per-rank batches,
+    broadcast of the parameters, barriers around the timed region, MAX over ranks, rank 0's single JSON line -- runs on every
+    1-GPU box.  (The collective itself is RCCL on a real node; no scaling curve has been measured by this repo.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RD_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--batch", "32", "--no-roofline", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd=root)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert res.returncode == 0 and len(lines) == 1, (res.returncode, res.stdout[-2000:], res.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "samples/s"
+    assert d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and abs(d["value"] - 2 * 32 * 3 / (d["ms_per_step"] * 3e-3)) <= 0.02 * d["value"]
+    assert "all-reduce" in d["config"]["workload"]

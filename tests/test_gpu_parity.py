@@ -229,6 +229,50 @@ def test_model_use_beta_vs_golden(name, precision_mode):
     assert float(d0) == 0.0
 
 
+def test_legacy_raindrop_vs_golden(precision_mode):
+    """The legacy `Raindrop` model (code/models_rd.py:46-191) on the HIP operators -- input encoder + scale + dropout, batched
+    TransformerConv over the [T, 36] step matrices, 36-wide PE, temporal encoder (D = 108, four heads of 27), masked mean, head --
+    against the reference's own forward / backward at the shape its forward hard-codes (215 steps, 36 sensors)."""
+    import json, os
+    from raindrop_amd.models_rd import Raindrop
+    from tests.helpers import GOLDEN, zero_dropout
+    g = np.load(os.path.join(GOLDEN, "legacy_v1.npz"), allow_pickle=False)
+    meta = json.loads(str(g["meta"]))
+    gs = synth.make_structure(dict(d_inp=meta["d_inp"]), "sparse", seed=meta["structure_seed"])
+    m = Raindrop(meta["d_inp"], meta["d_model"], meta["nhead"], meta["nhid"], meta["nlayers"], 0.3, meta["max_len"], meta["d_static"],
+                 100, 0.5, "mean", 2, gs)
+    synth.fill_params_(m, seed=meta["param_seed"])
+    zero_dropout(m)
+    m = m.to(DEV).train()
+    cfg = dict(max_len=meta["max_len"], d_inp=meta["d_inp"], static=True, d_static=meta["d_static"], n_classes=2)
+    b = synth.make_batch(cfg, meta["batch"], seed=meta["batch_seed"], density=meta["density"])
+    dv = {k: (None if v is None else v.to(DEV)) for k, v in b.items()}
+    logits, distance, third = m(dv["src"], dv["static"], dv["times"], dv["lengths"])
+    assert third is None and float(distance) == float(g["distance"]) == 0.0
+    loss = torch.nn.functional.cross_entropy(logits, dv["y"])
+    loss.backward()
+    assert np.abs(logits.detach().cpu().numpy() - g["logits"]).max() < 1e-4
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    params = dict(m.named_parameters())
+    live = [str(x) for x in g["live"]]
+    assert sorted(n for n, p in params.items() if p.grad is not None) == sorted(live)
+    for n in live:
+        exp, got = golden_grad(g, n, params[n].grad)
+        _grad_close(got, exp, 1e-3, n)
+    m.eval()
+    with torch.no_grad():
+        le, _, _ = m(dv["src"], dv["static"], dv["times"], dv["lengths"])
+    assert np.abs(le.cpu().numpy() - g["logits_eval"]).max() < 1e-4
+    # input dropout (code/models_rd.py:134) on the device RNG: deterministic per call counter, and it changes the output
+    m.train()
+    m.dropout.p = 0.3
+    torch.manual_seed(5); m._drop_calls = 0
+    a1 = m(dv["src"], dv["static"], dv["times"], dv["lengths"])[0]
+    torch.manual_seed(5); m._drop_calls = 0
+    a2 = m(dv["src"], dv["static"], dv["times"], dv["lengths"])[0]
+    assert torch.equal(a1, a2) and not torch.equal(a1, logits)
+
+
 def test_batched_edge_ops_match_single_graph_calls():
     """rd_edge_softmax_list_batched == B calls of rd_edge_softmax_list (bit for bit); rd_edge_gamma_dense == the scatter of the
     per-edge coefficients (duplicate edges added in edge order); rd_aggregate_batched == B calls of rd_aggregate, fwd + bwd."""

@@ -56,3 +56,21 @@ def test_synthetic_batch_contract():
     assert torch.all(b["src"][:, :, :34][b["src"][:, :, 34:] == 0] == 0)
     b2 = synth.make_batch(cfg, 16, seed=1)
     assert torch.equal(b["src"], b2["src"])                  # reproducible from the seed
+
+
+def test_legacy_raindrop_surface_matches_reference():
+    """The legacy `Raindrop` class (code/models_rd.py:46-191, exported by `from models_rd import *`): same positional constructor,
+    same state_dict keys / shapes / order as the reference's (captured in tests/golden/legacy_v1.npz), same init_weights."""
+    import numpy as np
+    from raindrop_amd import models_rd
+    from raindrop_amd.models_rd import Raindrop
+    assert "Raindrop" in models_rd.__all__
+    g = np.load(os.path.join(GOLDEN, "legacy_v1.npz"), allow_pickle=False)
+    meta, surf = json.loads(str(g["meta"])), json.loads(str(g["surface"]))
+    m = Raindrop(meta["d_inp"], meta["d_model"], meta["nhead"], meta["nhid"], meta["nlayers"], 0.3, meta["max_len"], meta["d_static"],
+                 100, 0.5, "mean", 2, torch.ones(36, 36))
+    ours = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert list(ours.items()) == list(surf.items())                 # names, shapes AND registration order
+    assert float(m.encoder.weight.abs().max()) <= 1e-10 and float(m.emb.weight.abs().max()) <= 1e-10   # code/models_rd.py:110-113
+    with pytest.raises(_lib.RaindropHipError):
+        Raindrop(36, 64, 4, 128, 2, 0.3, 215, 9, 100, 0.5, "mean", 2, torch.ones(36, 36))   # upstream's own defaults do not compose
