@@ -54,28 +54,50 @@ __device__ __forceinline__ void load_panel(Panel<KC>& p, const __bf16* __restric
   }
 }
 
-// acc[rt] = A[rows 16 rt .., :] * panel^T, split-bf16 (lo*hi + hi*lo + hi*hi), A planes in LDS
+// acc[rt] = A[rows 16 rt .., :] * panel^T, split-bf16 (lo*hi + hi*lo + hi*hi), A planes in LDS.
+// One (hi, lo) fragment pair is live per row tile and step: the three products of (kc, rt) are issued, then the pair of (kc + 1, rt)
+// is requested into the same registers (the rolled order of rd_msgpass_fused.hip's mma_mid) -- the LDS reads travel under the other
+// row tiles' MFMAs, and the tall variant keeps 8 fragment registers fewer alive beside its 72-register panels.
 template <int KC, int RT>
 __device__ __forceinline__ void mma(f32x4 (&acc)[RT], const __bf16* Ah, const __bf16* Al, int lda, const Panel<KC>& p, int lane, int one) {
   const int aoff = (lane & 15) * lda + 8 * (lane >> 4);
+  bf16x8 ah[RT], al[RT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (one) {                                         // RD_PREC_BF16 (hi * hi only): read-then-multiply steps
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * lda + aoff + kc * 32);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.h[kc], acc[rt], 0, 0, 0);
+    }
+    return;
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * lda + aoff);
+    al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * lda + aoff);
+  }
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc) {
-    bf16x8 ah[RT], al[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * lda + aoff + kc * 32);
-      al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * lda + aoff + kc * 32);
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], p.h[kc], acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.l[kc], acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.h[kc], acc[rt], 0, 0, 0);
+      if (kc + 1 < KC) {
+        ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * lda + aoff + (kc + 1) * 32);
+        al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * lda + aoff + (kc + 1) * 32);
+      }
     }
-    if (!one) {
+    if (kc + 1 < KC) {                               // pin the issue order: three MFMAs, the two reads they free, ...
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], p.h[kc], acc[rt], 0, 0, 0);
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.l[kc], acc[rt], 0, 0, 0);
+      for (int rt = 0; rt < RT; ++rt) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
     }
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.h[kc], acc[rt], 0, 0, 0);
   }
 }
 
@@ -219,17 +241,14 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   EFSTAMP(0);
   if (a.stamps && tid == 0) { a.stamps[256 + 2 * blockIdx.x] = wall_clock64(); a.stamps[256 + 2 * blockIdx.x + 1] = clock64(); }
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {                             // 6 * KPD + KPH = 1248 <= 2 * EF_THR
-    const int e = tid + it * EF_THR;
-    if (e < 6 * KPD + KPH) {
-      const int vsel = e < 6 * KPD ? e / KPD : 6, col = e - vsel * KPD;
-      const float* src = vsel == 0 ? a.bo : vsel == 1 ? a.g1 : vsel == 2 ? a.be1 : vsel == 3 ? a.b2 : vsel == 4 ? a.g2 : vsel == 5 ? a.be2 : a.b1;
-      const int lim = vsel == 6 ? H : D;
-      float val = 0.f;
-      if (col < lim) val = src[col];
-      cst[e] = val;
-    }
+  {   // one masked load per vector and thread, each from ITS kernel argument: a per-lane select among the seven pointers made the
+      // compiler keep a pointer table in scratch (7 stores per lane at kernel entry = 10 MB of scratch writes per launch)
+    auto fetch = [&](const float* src, int lim, int base, int n) {
+      if (tid < n) { float val = 0.f; if (tid < lim) val = src[tid]; cst[base + tid] = val; }
+    };
+    fetch(a.bo, D, 0, KPD); fetch(a.g1, D, KPD, KPD); fetch(a.be1, D, 2 * KPD, KPD);
+    fetch(a.b2, D, 3 * KPD, KPD); fetch(a.g2, D, 4 * KPD, KPD); fetch(a.be2, D, 5 * KPD, KPD);
+    fetch(a.b1, H, 6 * KPD, KPH);
   }
   // ---- attention rows -> split planes (zero padded to KPD columns, rows beyond M zero) ----
   constexpr int kq = KPD / 4;
@@ -341,13 +360,18 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
       split_store4(Hh + rl * LDH + n, Hl + rl * LDH + n, o);
     }
   }
-  // LayerNorm2's residual x1: read back by the very thread that stored it (rows w, w + 16, .. / columns 4 lane ..)
+  // LayerNorm2's residual x1: read back by the very thread that stored it (rows w, w + 16, .. / columns 4 lane ..).  The tall
+  // variant has no registers to carry the three quads through linear2's product beside its 72-register panel (they spilled:
+  // 23 MB of scratch writes per launch): it requests them behind the product instead.
+  auto load_res2 = [&]() {
 #pragma unroll
-  for (int q = 0; q < RT; ++q) {
-    const int m = m0 + wave + EF_WV * q;
-    xr[q] = zero4;
-    if (cok && m < M) xr[q] = *reinterpret_cast<const float4*>(a.x1 + (long)m * D + c);
-  }
+    for (int q = 0; q < RT; ++q) {
+      const int m = m0 + wave + EF_WV * q;
+      xr[q] = zero4;
+      if (cok && m < M) xr[q] = *reinterpret_cast<const float4*>(a.x1 + (long)m * D + c);
+    }
+  };
+  if constexpr (RT < 3) load_res2();
   EFSTAMP(9);
   lds_barrier();
   EFSTAMP(10);
@@ -359,6 +383,7 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
     mma<KCH, RT>(acc, Hh, Hl, LDH, p2, lane, a.one);
     to_stage<RT>(stage, acc, wave, lane);
   }
+  if constexpr (RT >= 3) load_res2();
   EFSTAMP(11);
   lds_barrier();
   EFSTAMP(12);
@@ -489,11 +514,10 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   const int c = 4 * lane;
   const bool cok = c < D;
   EFSTAMP(0);
-  if (tid < 2 * KPD) {
-    const int vsel = tid / KPD, col = tid - vsel * KPD;
-    float val = 0.f;
-    if (col < D) val = (vsel ? a.g1 : a.g2)[col];
-    cst[tid] = val;
+  if (tid < KPD) {                                             // each vector from its own kernel argument (no pointer select)
+    float v2 = 0.f, v1 = 0.f;
+    if (tid < D) { v2 = a.g2[tid]; v1 = a.g1[tid]; }
+    cst[tid] = v2; cst[KPD + tid] = v1;
   }
   // ---- rows of dy, s2 and their statistics (wave w: rows RT w ..; lane: 4 columns) ----
   float4 dyq[RT], sq[RT]; float mean_r[RT], rstd_r[RT];
@@ -582,17 +606,22 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   // LayerNorm1's saved rows and the residual-branch gradient ds2 (read back by the thread that stored it): requested here,
   // consumed after the next product
   float4 rq[RT];
+  auto load_ln1 = [&]() {
 #pragma unroll
-  for (int it = 0; it < RT; ++it) {
-    const long row = m0 + wave * RT + it;
-    const bool rok = row < M;
-    mean_r[it] = rok ? a.st1[2 * row] : 0.f; rstd_r[it] = rok ? a.st1[2 * row + 1] : 0.f;
-    sq[it] = zero4; rq[it] = zero4;
-    if (rok && cok) {
-      sq[it] = *reinterpret_cast<const float4*>(a.s1 + row * D + c);
-      rq[it] = *reinterpret_cast<const float4*>(a.ds2 + row * D + c);
+    for (int it = 0; it < RT; ++it) {
+      const long row = m0 + wave * RT + it;
+      const bool rok = row < M;
+      mean_r[it] = rok ? a.st1[2 * row] : 0.f; rstd_r[it] = rok ? a.st1[2 * row + 1] : 0.f;
+      sq[it] = zero4; rq[it] = zero4;
+      if (rok && cok) {
+        sq[it] = *reinterpret_cast<const float4*>(a.s1 + row * D + c);
+        rq[it] = *reinterpret_cast<const float4*>(a.ds2 + row * D + c);
+      }
     }
-  }
+  };
+  // (the tall variant cannot carry these 30 registers through the next product beside the 72-register panel: they spilled,
+  // 41 MB of scratch traffic per launch; it requests them behind the product)
+  if constexpr (RT < 3) load_ln1();
   if constexpr (RT == 2) load_panel<KCH, 5, KCH>(p1, a.W1t, ntD, wave, lane);
   else load_panel<KCH>(p1, a.W1t, ntD, wave, lane);
   EFSTAMP(6);
@@ -605,6 +634,7 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
     mma<KCH, RT>(acc, Hh, Hl, LDH, p1, lane, a.one);
     to_stage<RT>(stage, acc, wave, lane);
   }
+  if constexpr (RT >= 3) load_ln1();
   EFSTAMP(8);
   lds_barrier();                                               // stage complete; the du planes are dead (lnred may be rewritten)
   EFSTAMP(9);

@@ -1,8 +1,9 @@
-"""Run only the K1 path (sensor stage forward + backward, P19 B=256) a few times: target for rocprofv3
-kernel-trace / PMC passes (HBM FETCH_SIZE / WRITE_SIZE per launch)."""
+"""Run only the K1 path (sensor stage forward + backward, P19 B=256, on the step's token plan exactly as bench.py's roofline loop
+runs it) a few times: target for rocprofv3 kernel-trace / PMC passes (HBM FETCH_SIZE / WRITE_SIZE per launch)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import bench
 from raindrop_amd import _lib, ops, synth
 from raindrop_amd.models_rd import Raindrop_v2
 dev = torch.device("cuda")
@@ -15,7 +16,9 @@ det = [t.detach() for t in (b["src"], b["times"], b["lengths"], m.pos_encoder.ti
                             m.ob_propagation.lin_value.weight, m.ob_propagation.lin_value.bias,
                             m.ob_propagation_layer2.lin_value.weight, m.ob_propagation_layer2.lin_value.bias)]
 dz = torch.randn(60, B, 152, device=dev)
+plan = bench._make_plan(shp, b["lengths"]) if bench._use_token_plan(cfg) else None
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 10):
-    z, _, saved = ops.sensor_stage_fwd_raw(*det, shp, 0.2, 1234)
-    ops.sensor_stage_bwd_raw(det[0], det[5], det[6], det[8], det[4], saved, z, dz, shp, 0.2)
+    with bench._plan_scope(plan):
+        z, _, saved = ops.sensor_stage_fwd_raw(*det, shp, 0.2, 1234)
+        ops.sensor_stage_bwd_raw(det[0], det[5], det[6], det[8], det[4], saved, z, dz, shp, 0.2)
 torch.cuda.synchronize()
