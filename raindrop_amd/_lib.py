@@ -69,6 +69,7 @@ SIGNATURES = {
     "rd_sensor_stage_fwd": (c_int32, [_SHP] + [_P] * 10 + [c_float, ctypes.c_uint64, _P, _P, _P, c_size_t, _P]),
     "rd_sensor_stage_fwd_prepared": (c_int32, [_SHP] + [_P] * 10 + [c_float, ctypes.c_uint64, _P, _P, _P, c_size_t, _P]),
     "rd_step_prepare": (c_int32, [_SHP, c_int32, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "rd_step_begin": (c_int32, [_SHP, _P, _P, _P, ctypes.c_uint64, c_int32, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "rd_step_prepare_covers": (c_int32, [_SHP, _P, _P]),
     "rd_msgpass_bwd": (c_int32, [_SHP] + [_P] * 5 + [c_float, _P, c_size_t, _P, _P, c_int32] + [_P] * 5
                        + [_P, c_size_t, _P]),

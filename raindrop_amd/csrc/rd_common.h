@@ -48,6 +48,8 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // (rows = N, cols = K; transpose: rows = K, cols = N, i.e. the tiles of W^T); rd_rowgemm.hip: launch_wsplit_specs
 struct WsplitSpec { const float* W; int N, K, transpose; void* tiles; };
 int launch_wsplit_specs(int njobs, const WsplitSpec* specs, int nones, void* const* ones, hipStream_t st);
+int launch_wsplit_plan(int njobs, const WsplitSpec* specs, int nones, void* const* ones, const int64_t* lengths, int32_t* plan_out,
+                       int B, int T, uint64_t* seed_cell_dev, uint64_t delta, hipStream_t st);
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

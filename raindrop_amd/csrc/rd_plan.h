@@ -19,6 +19,7 @@
 //   [.. + B]          len[r]                clamp(lengths[order[r]], 0, T)
 //   [.. + B]          cnt[t], t = 0..T      number of samples with len > t
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -34,6 +35,85 @@ __host__ __device__ inline int order_base(int B) { return HDR + 2 * B + 1; }
 __host__ __device__ inline int len_base(int B) { return HDR + 3 * B + 1; }
 __host__ __device__ inline int cnt_base(int B) { return HDR + 4 * B + 1; }
 __host__ __device__ inline size_t ints(int B, int T) { return (size_t)HDR + 4 * (size_t)B + 1 + T + 1; }
+
+
+#if defined(__HIPCC__)
+// LDS ints the plan needs: len [B], cnt [T + 2], within [B], cc [ceil(B / 64)][T + 1]
+__host__ __device__ inline size_t lds_bytes(int B, int T) { return ((size_t)2 * B + T + 2 + (size_t)((B + 63) / 64) * (T + 1)) * sizeof(int); }
+
+// The whole plan by ONE workgroup of any size (a multiple of 64 threads).  rank of b = (samples strictly longer) + (equally long
+// samples with a smaller index): a stable counting sort made of ballots and prefix sums only, so nothing depends on an execution
+// order.  Wave w takes the 64-sample chunks w, w + nw, ..: for every length value v one ballot gives the chunk's count of v and,
+// by the lower-lane bits, every member's position among the chunk's v's; the chunk counts are prefix-summed over the chunks per v
+// (thread per v).  Also bumps the dropout seed cell (one launch fewer per step).
+__device__ inline void token_plan_body(const int64_t* __restrict__ lengths, int32_t* __restrict__ p, int B, int T, uint64_t* seed_cell,
+                                       uint64_t delta, int* psm) {
+  const int nthr = blockDim.x, nw = nthr >> 6;
+  const int nchunk = (B + 63) >> 6, T1 = T + 1;
+  int* len = psm;                 // [B]
+  int* cnt = psm + B;             // [T + 2]: histogram, then cnt[t] = #(len > t)
+  int* within = cnt + T + 2;      // [B]: equally long samples with a smaller index inside the same chunk
+  int* cc = within + B;           // [nchunk][T + 1]: count of v in chunk, then in the chunks before it
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int b = tid; b < B; b += nthr) {
+    const int64_t l = lengths[b];
+    len[b] = (int)(l < 0 ? 0 : (l > T ? T : l));
+  }
+  __syncthreads();
+  for (int ch = wave; ch < nchunk; ch += nw) {
+    const int b = ch * 64 + lane;
+    const int l = b < B ? len[b] : -1;
+    int sl = 0;
+    for (int v = 0; v <= T; ++v) {
+      const unsigned long long m = __ballot(l == v);
+      if (l == v) sl = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) cc[ch * T1 + v] = __popcll(m);
+    }
+    if (b < B) within[b] = sl;
+  }
+  __syncthreads();
+  for (int v = tid; v <= T; v += nthr) {
+    int run = 0;
+    for (int ch = 0; ch < nchunk; ++ch) { const int t = cc[ch * T1 + v]; cc[ch * T1 + v] = run; run += t; }
+    cnt[v] = run;
+  }
+  __syncthreads();
+  // cnt[t] = number of samples with len > t  (T + 1 entries, cnt[T] = 0): exclusive suffix sum of the histogram
+  if (wave == 0) {
+    if (T1 <= 64) {
+      const int h = lane <= T ? cnt[lane] : 0;
+      int sfx = h;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_down(sfx, o); if (lane + o < 64) sfx += v; }
+      if (lane <= T) cnt[lane] = sfx - h;
+    } else if (lane == 0) {
+      int above = 0;
+      for (int t = T; t >= 0; --t) { const int h = cnt[t]; cnt[t] = above; above += h; }
+    }
+    if (lane == 0 && seed_cell) *seed_cell += delta;
+  }
+  __syncthreads();
+  int* off = p + plan::off_base();
+  int* rank = p + plan::rank_base(B);
+  int* order = p + plan::order_base(B);
+  int* lenr = p + plan::len_base(B);
+  int* cntg = p + plan::cnt_base(B);
+  for (int b = tid; b < B; b += nthr) {
+    const int l = len[b];
+    const int r = cnt[l] + cc[(b >> 6) * T1 + l] + within[b];
+    rank[b] = r; order[r] = b; lenr[r] = l;
+  }
+  // off[r] = sum of the r longest lengths = sum_t min(r, cnt[t])   (the samples with len > t are the first cnt[t] ranks)
+  for (int r = tid; r <= B; r += nthr) {
+    int s = 0;
+    for (int t = 0; t < T; ++t) s += min(r, cnt[t]);
+    off[r] = s;
+    if (r == B) { p[plan::I_MLIVE] = s; p[plan::I_S32] = (s + 31) >> 5; }
+  }
+  for (int t = tid; t <= T; t += nthr) cntg[t] = cnt[t];
+  if (tid == 0) { p[plan::I_B] = B; p[plan::I_T] = T; p[plan::I_SLACK] = 0; p[5] = 0; p[6] = 0; p[7] = 0; }
+}
+#endif
 
 }  // namespace plan
 

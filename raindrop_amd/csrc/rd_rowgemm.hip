@@ -12,6 +12,7 @@
 // dgrad    (dy W):   Wp = split(W^T)    [K rows, N cols]
 // Split-bf16 arithmetic (hi*hi + hi*lo + lo*hi, fp32 accumulate) as everywhere else.
 #include "rd_common.h"
+#include "rd_plan.h"
 #include "rd_rng.h"
 
 namespace rd {
@@ -61,13 +62,20 @@ struct RowGemmArgs {
 // one weight matrix -> hi/lo planes; transpose != 0 writes split(W^T): rows k, cols n
 struct SplitJob { const float* W; int N, K, transpose; __bf16* hi; __bf16* lo; int rows, cols_p; };
 constexpr int WS_MAXJOBS = 24, WS_MAXONES = 4;
-struct SplitJobs { SplitJob j[WS_MAXJOBS]; int n; __bf16* ones[WS_MAXONES]; };   // ones: constant tiles of the weight-gradient streams (or null)
+struct SplitJobs { SplitJob j[WS_MAXJOBS]; int n; __bf16* ones[WS_MAXONES];   // ones: constant tiles of the weight-gradient streams (or null)
+                   // optional: the step's token plan (rd_plan.h) by the workgroup (0, n) of the same launch (rd_step_begin)
+                   const int64_t* plan_lengths; int32_t* plan_out; int plan_B, plan_T; uint64_t* seed_cell; uint64_t seed_delta; };
 
 // Output: NATIVE MFMA operand tiles [ntile = rows/16][kc = cols_p/32][hi, lo][64 lanes][8] (one contiguous kilobyte per
 // wave-load; rd_k1_layout.h has the measurement: 61 B/clk/CU against 16 B/clk for a row-major plane).  `hi` is the
 // base of the tile array, `lo` is unused (kept for the job layout).  One workgroup row per job; a wave converts one
 // (ntile, kc) tile per iteration.
 __global__ __launch_bounds__(256) void k_wsplit(SplitJobs jobs) {
+  if ((int)blockIdx.y == jobs.n) {                  // the extra block row of rd_step_begin: lengths -> token plan (+ seed bump)
+    extern __shared__ int wsm_plan[];
+    if (blockIdx.x == 0) plan::token_plan_body(jobs.plan_lengths, jobs.plan_out, jobs.plan_B, jobs.plan_T, jobs.seed_cell, jobs.seed_delta, wsm_plan);
+    return;
+  }
   const SplitJob jb = jobs.j[blockIdx.y];
   const int ntile = jb.rows >> 4, nkc = jb.cols_p >> 5;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, G = lane >> 4;
@@ -437,9 +445,15 @@ size_t rowgemm_plane_elems(int rows, int cols) { return (size_t)((rows + 15) / 1
 // split up to 8 weight matrices with one launch; job i: W [N_i, K_i] -> planes at hi_i / lo_i
 // up to WS_MAXJOBS matrices and WS_MAXONES constant-tile buffers in ONE launch (a whole training step's weights: rd_step_prepare)
 int launch_wsplit_specs(int njobs, const WsplitSpec* specs, int nones, void* const* ones, hipStream_t st) {
+  return launch_wsplit_plan(njobs, specs, nones, ones, nullptr, nullptr, 0, 0, nullptr, 0, st);
+}
+// the same launch with one extra workgroup that builds the token plan of the step (plan_out == null: none)
+int launch_wsplit_plan(int njobs, const WsplitSpec* specs, int nones, void* const* ones, const int64_t* lengths, int32_t* plan_out,
+                       int B, int T, uint64_t* seed_cell_dev, uint64_t delta, hipStream_t st) {
   if (njobs < 1 || njobs > WS_MAXJOBS || nones < 0 || nones > WS_MAXONES) return fail(RD_EINVAL, "wsplit: %d jobs, %d constant tiles", njobs, nones);
   SplitJobs jobs{};
   jobs.n = njobs;
+  jobs.plan_lengths = lengths; jobs.plan_out = plan_out; jobs.plan_B = B; jobs.plan_T = T; jobs.seed_cell = seed_cell_dev; jobs.seed_delta = delta;
   for (int i = 0; i < nones; ++i) jobs.ones[i] = (__bf16*)ones[i];
   for (int i = 0; i < njobs; ++i) {
     SplitJob& j = jobs.j[i];
@@ -447,7 +461,9 @@ int launch_wsplit_specs(int njobs, const WsplitSpec* specs, int nones, void* con
     const int rows = j.transpose ? j.K : j.N, cols = j.transpose ? j.N : j.K;
     j.rows = (rows + 15) / 16 * 16; j.cols_p = (cols + 31) / 32 * 32;
   }
-  hipLaunchKernelGGL(k_wsplit, dim3(64, njobs), dim3(256), 0, st, jobs);
+  const size_t lds = plan_out ? plan::lds_bytes(B, T) : 0;
+  if (lds > 64 * 1024) return fail(RD_EINVAL, "rd_step_begin: B x T too large for the one-workgroup token plan (%d, %d)", B, T);
+  hipLaunchKernelGGL(k_wsplit, dim3(64, njobs + (plan_out ? 1 : 0)), dim3(256), lds, st, jobs);
   return check_launch("k_wsplit");
 }
 

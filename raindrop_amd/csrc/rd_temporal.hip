@@ -1979,9 +1979,9 @@ bool fused_msgpass_ok(const rd_shape* s);
 
 // Every weight matrix of a training step -> matrix-core operand tiles in ONE launch: the encoder layers' (what
 // rd_encoder_layer_prepare does per layer) and the message-passing stage's (what rd_sensor_stage_fwd does first).
-extern "C" int rd_step_prepare(const rd_shape* s, int32_t nlayers, const rd_encoder_weights* const* w, void* const* enc_saved,
-                               const size_t* enc_saved_bytes, const float* W1, const float* W2, void* k1_saved, size_t k1_saved_bytes,
-                               void* stream) {
+static int step_prepare_impl(const rd_shape* s, int32_t nlayers, const rd_encoder_weights* const* w, void* const* enc_saved,
+                             const size_t* enc_saved_bytes, const float* W1, const float* W2, void* k1_saved, size_t k1_saved_bytes,
+                             const int64_t* lengths, int32_t* plan_out, uint64_t* seed_cell_dev, uint64_t delta, void* stream) {
   int rc = check_enc(s);
   if (rc) return rc;
   if (s->B == 0) return RD_OK;
@@ -2000,8 +2000,22 @@ extern "C" int rd_step_prepare(const rd_shape* s, int32_t nlayers, const rd_enco
       if (tw) ones[no++] = v.ones;
     }
   if (W1 && W2 && k1_saved) n += k1_weight_split_specs(s, W1, W2, k1_saved, k1_saved_bytes, specs + n);
-  if (n == 0) return RD_OK;
-  return launch_wsplit_specs(n, specs, no, ones, (hipStream_t)stream);
+  if (n == 0) return plan_out ? rd_token_plan(s, lengths, plan_out, seed_cell_dev, delta, stream) : RD_OK;
+  return launch_wsplit_plan(n, specs, no, ones, lengths, plan_out, s->B, s->T, seed_cell_dev, delta, (hipStream_t)stream);
+}
+extern "C" int rd_step_prepare(const rd_shape* s, int32_t nlayers, const rd_encoder_weights* const* w, void* const* enc_saved,
+                               const size_t* enc_saved_bytes, const float* W1, const float* W2, void* k1_saved, size_t k1_saved_bytes,
+                               void* stream) {
+  return step_prepare_impl(s, nlayers, w, enc_saved, enc_saved_bytes, W1, W2, k1_saved, k1_saved_bytes, nullptr, nullptr, nullptr, 0, stream);
+}
+// rd_token_plan + rd_step_prepare as ONE launch: everything a training step needs before its first compute kernel (the plan is one
+// workgroup of integer work, the splits ~1500 small tiles: two launches of 6-8 us each were mostly launch latency)
+extern "C" int rd_step_begin(const rd_shape* s, const int64_t* lengths, int32_t* plan_out, uint64_t* seed_cell_dev, uint64_t delta,
+                             int32_t nlayers, const rd_encoder_weights* const* w, void* const* enc_saved, const size_t* enc_saved_bytes,
+                             const float* W1, const float* W2, void* k1_saved, size_t k1_saved_bytes, void* stream) {
+  RD_REQUIRE(lengths && plan_out, "NULL tensor");
+  return step_prepare_impl(s, nlayers, w, enc_saved, enc_saved_bytes, W1, W2, k1_saved, k1_saved_bytes, lengths, plan_out, seed_cell_dev,
+                           delta, stream);
 }
 // 1 if rd_step_prepare covers the encoder layers / the message-passing stage of this shape in the current arithmetic mode (then
 // pass RD_LAYER_WEIGHTS_PREPARED / call rd_sensor_stage_fwd_prepared), else the per-call splits must run

@@ -72,6 +72,7 @@ class TrainStep:
         enc_ok, k1_ok = ctypes.c_int32(0), ctypes.c_int32(0)
         _lib.call("rd_step_prepare_covers", self.sp, ctypes.byref(enc_ok), ctypes.byref(k1_ok))
         one = os.environ.get("RD_STEP_PREPARE", "1") != "0"
+        self.one_begin = os.environ.get("RD_STEP_BEGIN", "1") != "0"      # A/B: token plan and weight splits as one launch
         self.prep_enc, self.prep_k1 = bool(enc_ok.value) and one, bool(k1_ok.value) and one
         self._prep_w = (ctypes.POINTER(_lib.RdEncoderPtrs) * self.nl)(*[ctypes.pointer(w) for w in self.enc_w])
         self._prep_saved = (ctypes.c_void_p * self.nl)(*[t.data_ptr() for t in self.enc_saved])
@@ -170,17 +171,23 @@ class TrainStep:
         B, T, D, Fe = self.B, self.T, self.D, self.Fe
         dh = D + Fe
         c = self._call
-        if self.plan is not None:                                          # lengths -> token plan (+ the seed bump: one launch)
-            c("rd_token_plan", sp, _p(b["lengths"]), _p(self.plan), _p(self.seed_cell) if self.p_drop > 0.0 else None, 1, st)
-        elif self.p_drop > 0.0:
-            c("rd_seed_cell_advance", _p(self.seed_cell), 1, st)           # fresh masks per replay
         W1, b1 = P["ob_propagation.lin_value.weight"], P["ob_propagation.lin_value.bias"]
         W2, b2 = P["ob_propagation_layer2.lin_value.weight"], P["ob_propagation_layer2.lin_value.bias"]
         ssum = self.graph_info["ssum"]
+        prep = self.prep_enc or self.prep_k1
+        prep_args = (self.nl if self.prep_enc else 0, self._prep_w, self._prep_saved, self._prep_bytes,
+                     _p(W1) if self.prep_k1 else None, _p(W2) if self.prep_k1 else None, _p(self.k1_saved), self.k1_saved.numel(), st)
+        cell = _p(self.seed_cell) if self.p_drop > 0.0 else None
+        if self.plan is not None and prep and self.one_begin:             # plan + seed bump + every weight split: ONE launch
+            c("rd_step_begin", sp, _p(b["lengths"]), _p(self.plan), cell, 1, *prep_args)
+        else:
+            if self.plan is not None:                                      # lengths -> token plan (+ the seed bump: one launch)
+                c("rd_token_plan", sp, _p(b["lengths"]), _p(self.plan), cell, 1, st)
+            elif self.p_drop > 0.0:
+                c("rd_seed_cell_advance", _p(self.seed_cell), 1, st)       # fresh masks per replay
+            if prep:
+                c("rd_step_prepare", sp, *prep_args)
         # ---------------- forward ----------------
-        if self.prep_enc or self.prep_k1:
-            c("rd_step_prepare", sp, self.nl if self.prep_enc else 0, self._prep_w, self._prep_saved, self._prep_bytes,
-              _p(W1) if self.prep_k1 else None, _p(W2) if self.prep_k1 else None, _p(self.k1_saved), self.k1_saved.numel(), st)
         c("rd_sensor_stage_fwd_prepared" if self.prep_k1 else "rd_sensor_stage_fwd", sp, _p(b["src"]), _p(b["times"]), _p(b["lengths"]), _p(self.ts), _p(P["R_u"]), _p(W1),
           _p(b1), _p(W2), _p(b2), _p(ssum), self.p_drop, self.seed, _p(self.z), _p(self.mask), _p(self.k1_saved),
           self.k1_saved.numel(), st)
