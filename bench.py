@@ -593,8 +593,7 @@ def main():
     def graph_step():
         if feed_next is not None:
             feed_next()
-        loss = tstep.run()
-        flat.allreduce()
+        loss = tstep.run_allreduce()           # N > 1: the last layer's + head's gradients are all-reduced beside the rest of the backward
         if not args.no_optimizer:
             opt.step()
         return loss
@@ -673,7 +672,9 @@ def main():
                                        cfg["name"], cfg["d_inp"], cfg["max_len"], cfg["max_len"] * 4, B,
                                        "+RCCL flat-grad all-reduce" if world > 1 else "",
                                        "" if args.no_optimizer else "+Adam", cfg["dropout"]),
-                       "step_mode": "hipGraph(fwd+CE+bwd) + eager all-reduce/Adam" if tstep is not None else "eager autograd",
+                       "step_mode": ("eager autograd" if tstep is None else
+                                     "two hipGraphs (fwd+CE+bwd of head and last layer | rest of bwd), first all-reduce bucket between them, + Adam"
+                                     if tstep.split else "hipGraph(fwd+CE+bwd) + eager all-reduce/Adam"),
                        "batch_source": ("rd_batch_gather from a device-resident dataset (N=8192) every step" if feed_next
                                         else "one resident batch re-used (inputs in HBM before the timed region)"),
                        "arithmetic": ARITH[prec],

@@ -119,6 +119,29 @@ class FlatGradAllReduce:
             if self.average and not use_avg:
                 self.flat.div_(self.world)
 
+    # -- overlapped form: the tail of the buffer (parameters from `first_name` on, in forward order) is complete once the
+    #    backward pass has left the last encoder layer; its collective runs beside the rest of the backward pass ---------------
+    def tail_start(self, first_name):
+        """Offset of parameter `first_name` in the flat buffer (slices start on 256-byte boundaries)."""
+        return self.slices[self.names.index(first_name)][0]
+
+    def allreduce_range_async(self, lo, hi):
+        """Start the all-reduce of flat[lo:hi] on the collective's own stream (it waits for what the current stream has enqueued so
+        far, and nothing later); returns a handle for allreduce_wait().  No-op (None) for a single process."""
+        if self.world <= 1 or hi <= lo:
+            return None
+        use_avg = self.average and dist.get_backend(self.group) == "nccl"
+        op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM
+        return (dist.all_reduce(self.flat[lo:hi], op=op, group=self.group, async_op=True), lo, hi, use_avg)
+
+    def allreduce_wait(self, handle):
+        if handle is None:
+            return
+        h, lo, hi, use_avg = handle
+        h.wait()
+        if self.average and not use_avg:
+            self.flat[lo:hi].div_(self.world)
+
     def nbytes(self):
         return self.flat.numel() * 4
 

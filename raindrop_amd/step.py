@@ -33,7 +33,7 @@ def _p(t):
 
 
 class TrainStep:
-    def __init__(self, model, flat, batch, p_drop=None, use_graph=True, seed=1234, autotune=True, token_plan=None):
+    def __init__(self, model, flat, batch, p_drop=None, use_graph=True, seed=1234, autotune=True, token_plan=None, split=None):
         """model: raindrop_amd.models_rd.Raindrop_v2 on a ROCm device; flat: FlatGradAllReduce over the
         live parameters (its buffer receives the gradients); batch: dict(src, static, times, lengths, y)
         of device tensors that are REUSED every step (copy new data into them).
@@ -41,6 +41,14 @@ class TrainStep:
         code/models_rd.py:298-299 applied as a layout; same logits, loss and gradients).  None = environment RD_TOKEN_PLAN
         (default on) where the shape supports it."""
         self.model, self.flat, self.batch = model, flat, batch
+        # split: capture the step as TWO graphs -- (A) forward + loss + the backward of the head and the last encoder layer, (B) the
+        # rest of the backward pass -- so that a data-parallel caller can start the all-reduce of the gradients A has finished
+        # (run(between=...)) beside B.  None = on when torch.distributed runs more than one rank (RD_DP_OVERLAP=0 turns it off).
+        if split is None:
+            import torch.distributed as dist
+            split = (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+                     and os.environ.get("RD_DP_OVERLAP", "1") != "0")
+        self.split = bool(split) and len(model.transformer_encoder.layers) >= 2
         self._want_plan = (os.environ.get("RD_TOKEN_PLAN", "1") != "0") if token_plan is None else bool(token_plan)
         self.autotune, self.tuned_rows32, self.tuned_waves16 = bool(autotune), None, None
         self.dev = batch["src"].device
@@ -79,6 +87,7 @@ class TrainStep:
         self._prep_bytes = (ctypes.c_size_t * self.nl)(*[t.numel() for t in self.enc_saved])
         self._ptrs = self._param_ptrs()                          # the captured graph / cached structs hold these addresses
         self.graph = None
+        self.graph_b = None
         if use_graph:
             self._capture()
 
@@ -164,8 +173,11 @@ class TrainStep:
     def _call(self, name, *a):
         _lib.call(name, *a)
 
-    def _body(self):
-        """Enqueue one forward + loss + backward on the current stream (no host sync)."""
+    def _body(self, part=None):
+        """Enqueue one forward + loss + backward on the current stream (no host sync).  part 'a' / 'b': the two halves of the split
+        form (see __init__); None: everything."""
+        if part == "b":
+            return self._body_tail(self.nl - 2)
         m, b, P, G, sp = self.model, self.batch, self.P, self.G, self.sp
         st = ops._stream()
         B, T, D, Fe = self.B, self.T, self.D, self.Fe
@@ -206,16 +218,33 @@ class TrainStep:
               _p(G["mlp_static.2.weight"]), _p(G["mlp_static.2.bias"]), _p(cur), _p(self.head_ws), self.head_ws.numel(), st)
         else:
             self._head_by_operator(cur, st)
-        for i in reversed(range(self.nl)):
+        if part == "a":                                   # the last layer's backward closes part A
+            self._enc_bwd(self.nl - 1, cur, self.dx[1], st)
+            return
+        self._body_tail(self.nl - 1, cur)
+
+    def _enc_bwd(self, i, cur, nxt, st):
+        self._call("rd_encoder_layer_bwd", self.sp, i, _p(self.x[i]), _p(self.mask), ctypes.byref(self.enc_w[i]), self.p_drop,
+                   self.seed, _p(self.enc_saved[i]), self.enc_saved[i].numel(), _p(cur), _p(nxt), ctypes.byref(self.enc_g[i]),
+                   _p(self.enc_ws), self.enc_ws.numel(), st)
+
+    def _body_tail(self, top, cur=None):
+        """Backward of encoder layers top .. 0 and of the sensor stage; the entry gradient is dx[0] for the top layer of the stack
+        (written by the head) and alternates between the two buffers from there."""
+        b, P, G, sp = self.batch, self.P, self.G, self.sp
+        st = ops._stream()
+        D = self.D
+        if cur is None:                                   # layer `top` reads what layer top + 1 wrote
+            cur = self.dx[(self.nl - 1 - top) % 2]
+        for i in range(top, -1, -1):
             nxt = self.dx[1] if cur is self.dx[0] else self.dx[0]
-            c("rd_encoder_layer_bwd", sp, i, _p(self.x[i]), _p(self.mask), ctypes.byref(self.enc_w[i]), self.p_drop,
-              self.seed, _p(self.enc_saved[i]), self.enc_saved[i].numel(), _p(cur), _p(nxt), ctypes.byref(self.enc_g[i]),
-              _p(self.enc_ws), self.enc_ws.numel(), st)
+            self._enc_bwd(i, cur, nxt, st)
             cur = nxt
-        c("rd_msgpass_bwd", sp, _p(b["src"]), _p(P["R_u"]), _p(W1), _p(W2), _p(ssum), self.p_drop, _p(self.k1_saved),
-          self.k1_saved.numel(), _p(self.z), _p(cur), D, _p(G["ob_propagation.lin_value.weight"]),
-          _p(G["ob_propagation.lin_value.bias"]), _p(G["ob_propagation_layer2.lin_value.weight"]),
-          _p(G["ob_propagation_layer2.lin_value.bias"]), _p(G["R_u"]), _p(self.k1_ws), self.k1_ws.numel(), st)
+        W1, W2 = P["ob_propagation.lin_value.weight"], P["ob_propagation_layer2.lin_value.weight"]
+        self._call("rd_msgpass_bwd", sp, _p(b["src"]), _p(P["R_u"]), _p(W1), _p(W2), _p(self.graph_info["ssum"]), self.p_drop,
+                   _p(self.k1_saved), self.k1_saved.numel(), _p(self.z), _p(cur), D, _p(G["ob_propagation.lin_value.weight"]),
+                   _p(G["ob_propagation.lin_value.bias"]), _p(G["ob_propagation_layer2.lin_value.weight"]),
+                   _p(G["ob_propagation_layer2.lin_value.bias"]), _p(G["R_u"]), _p(self.k1_ws), self.k1_ws.numel(), st)
 
     def _head_by_operator(self, cur, st):
         """masked mean -> [agg | emb] -> mlp_static -> cross entropy and their backward, one C-ABI call per operator."""
@@ -271,7 +300,7 @@ class TrainStep:
         import torch.distributed as dist
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         # data-parallel ranks must run the SAME kernel variants (the tuner decides by wall clock: ranks could disagree): no tuning there
-        if not self.autotune or multi or os.environ.get("RD_RG_ROWS32") is not None or os.environ.get("RD_RG_WAVES16") is not None:
+        if not self.autotune or multi or self.split or os.environ.get("RD_RG_ROWS32") is not None or os.environ.get("RD_RG_WAVES16") is not None:
             return self._capture_one()
 
         def timed(r32, w16):
@@ -306,27 +335,70 @@ class TrainStep:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
+            self.graph_b = None
+            if not self.split:
+                with torch.no_grad(), torch.cuda.graph(self.graph):
+                    self._body()
+                return
             with torch.no_grad(), torch.cuda.graph(self.graph):
-                self._body()
+                self._body("a")
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(self.graph_b, pool=self.graph.pool()):
+                self._body("b")
         self._with_cell(cap)
 
     # ------------------------------------------------------------------------------------------
-    def run(self):
-        """One forward + loss + backward; gradients land in flat.flat (p.grad views point there)."""
+    def early_grad_offset(self):
+        """Offset in the flat gradient buffer from which every gradient is final when `between` runs (split form): the last encoder
+        layer's parameters and, behind them in forward order, the classifier head's."""
+        return self.flat.tail_start("transformer_encoder.layers.%d.self_attn.in_proj_weight" % (self.nl - 1))
+
+    def run(self, between=None):
+        """One forward + loss + backward; gradients land in flat.flat (p.grad views point there).  `between` (split form only) is
+        called after the first graph has been enqueued and before the second: gradients at flat offsets >= early_grad_offset() are
+        complete in stream order at that point."""
         if self._param_ptrs() != self._ptrs:
             raise _lib.RaindropHipError("TrainStep: a parameter or gradient buffer moved since construction (model.to(), "
                                         "flatten_parameters() or a re-assignment): build a new TrainStep")
         if self.graph is not None:
             self.graph.replay()
+            if self.graph_b is not None:
+                if between is not None:
+                    between()
+                self.graph_b.replay()
         else:
             def eager():
                 with torch.no_grad():
-                    self._body()
+                    if self.split:
+                        self._body("a")
+                        if between is not None:
+                            between()
+                        self._body("b")
+                    else:
+                        self._body()
             self._with_cell(eager)
         for p, v in zip(self.flat.params, self.flat.views):
             p.grad = v
         return self.loss
 
+    def run_allreduce(self):
+        """run() + the gradient all-reduce of `flat` (no-op for one process).  Split form: the collective of the gradients the first
+        graph completes (last encoder layer + head: ~0.8 of 2.0 MB at P19) is started between the two graphs and runs beside the
+        rest of the backward pass; the remainder follows the second graph.  Returns the loss tensor."""
+        flat = self.flat
+        if not self.split:
+            loss = self.run()
+            flat.allreduce()
+            return loss
+        off, hold = self.early_grad_offset(), []
+        loss = self.run(between=lambda: hold.append(flat.allreduce_range_async(off, flat.flat.numel())))
+        rest = flat.allreduce_range_async(0, off)
+        for h in hold:
+            flat.allreduce_wait(h)
+        flat.allreduce_wait(rest)
+        return loss
+
     def close(self):
         """Kept for callers of the round-1 API: the seed cell is no longer registered outside run() / capture."""
         self.graph = None
+        self.graph_b = None

@@ -89,7 +89,7 @@ def test_two_rank_step_equals_full_batch_step():
 RANK_SEED_STRIDE = 0x9E3779B97F4A7C15          # raindrop_amd.ops.rank_seed_offset
 
 
-def _graph_dropout_step(batch, seed):
+def _graph_dropout_step(batch, seed, overlapped=False):
     """ONE hipGraph step with dropout 0.2 (the configuration bench.py --gpus N runs): returns (loss, flat gradient after
     flat.allreduce())."""
     from raindrop_amd import dp, synth
@@ -108,33 +108,40 @@ def _graph_dropout_step(batch, seed):
     b = {k: (None if v is None else v.to(dev)) for k, v in batch.items()}
     ts = TrainStep(m, flat, b, p_drop=0.2, use_graph=True, seed=seed, autotune=False)
     ts.seed_cell.zero_()                                          # the capture's warm-up runs bumped it: one defined replay
-    loss = float(ts.run())
-    flat.allreduce()
+    if overlapped:                                                # two graphs, the tail bucket's collective started between them
+        assert ts.split and ts.graph_b is not None and 0 < ts.early_grad_offset() < flat.flat.numel()
+        loss = float(ts.run_allreduce())
+    else:
+        loss = float(ts.run())
+        flat.allreduce()
     torch.cuda.synchronize()
     g = flat.flat.detach().cpu().numpy().copy()
     ts.close()
     return loss, g
 
 
-def _graph_worker(rank, world, port, ret):
+def _graph_worker(rank, world, port, ret, overlapped=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from raindrop_amd import dp, synth
     full = synth.make_batch(synth.make_config("P19"), B_GLOBAL, seed=33)
-    ret[rank] = _graph_dropout_step(dp.shard_batch(full, rank, world), seed=1234)
+    ret[rank] = _graph_dropout_step(dp.shard_batch(full, rank, world), seed=1234, overlapped=overlapped)
     dist.destroy_process_group()
 
 
-def test_two_rank_graph_step_with_dropout():
+@pytest.mark.parametrize("overlapped", [False, True])
+def test_two_rank_graph_step_with_dropout(overlapped):
     """The step bench.py --gpus N actually runs -- hipGraph replay, dropout 0.2, per-rank seed offsets, device seed cell -- on two
     ranks: the all-reduced gradient is bit-identical on both ranks, the ranks drew DIFFERENT masks (different local losses), and
-    the result equals a single process replaying the two shards with the two ranks' seeds and averaging."""
+    the result equals a single process replaying the two shards with the two ranks' seeds and averaging.  `overlapped`: the
+    split form bench.py uses at N > 1 (TrainStep.run_allreduce: two graphs, the collective of the last layer's + head's
+    gradients started between them) against the same single-process one-graph replay: bit-equal."""
     from raindrop_amd import dp, synth
     world, port = 2, _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_graph_worker, args=(world, port, ret), nprocs=world, join=True)
+    mp.spawn(_graph_worker, args=(world, port, ret, overlapped), nprocs=world, join=True)
     (l0, g0), (l1, g1) = ret[0], ret[1]
     assert np.array_equal(g0, g1)
     assert l0 != l1

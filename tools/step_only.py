@@ -18,12 +18,12 @@ b = {k: (None if v is None else v.to(dev)) for k, v in synth.make_batch(cfg, B, 
 named = dict(m.named_parameters())
 flat = dp.FlatGradAllReduce([(n, named[n]) for n in synth.live_parameter_names(cfg)], n_buckets=2)
 opt = FlatAdam(flat.flatten_parameters(), lr=1e-4)
-ts = TrainStep(m, flat, b)
+ts = TrainStep(m, flat, b, split=True if os.environ.get('RD_SPLIT') == '1' else None)   # RD_SPLIT=1: the two-graph form of N > 1 (cost of the split)
 import time
 for _ in range(3):
-    ts.run(); flat.allreduce(); opt.step()
+    ts.run_allreduce(); opt.step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(steps):
-    ts.run(); flat.allreduce(); opt.step()
+    ts.run_allreduce(); opt.step()
 torch.cuda.synchronize(); t1 = time.perf_counter()
 print("loss", float(ts.loss), "ms/step %.4f" % ((t1 - t0) * 1e3 / steps))
