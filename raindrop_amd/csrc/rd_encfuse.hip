@@ -188,31 +188,100 @@ struct PostFwdArgs {
   unsigned long long* stamps;
 };
 
-// LayerNorm epilogue of one row held as 4 values per lane (columns 4 lane ..): sv = residual + dropout(t + bias);
-// writes the pre-norm sum, the normalised row and the statistics; returns the normalised quad.
-__device__ __forceinline__ float4 ln_row(float4 t, const float4& res, const float4& bs, const float4& gg, const float4& bb, bool cok, int N,
-                                         long m, int c, float p, float inv_keep, uint64_t seed, uint32_t site, float* s_out, float* y_out,
-                                         float* stats, int lane) {
+// ---- LayerNorm passes: FOUR rows per wave pass, one per 16-lane DPP row -------------------------------------------------------
+// Lane (g = lane >> 4, i = lane & 15) works on row 4 pass + g and on the column quads i, i + 16, i + 32 of it (D <= 188; at
+// D = 152 the third quad exists for i < 6).  With one row per pass (64 lanes, 38 of them on the 38 quads of a row) a LayerNorm
+// phase was ~180 instructions per row, three rows per wave, four waves per SIMD: 10-11 k cycles of pure issue per phase.  Here the
+// row sums are 4-step rotate-add butterflies inside a DPP row (every lane of the row ends with the same bits), a pass costs about
+// twice a row's instructions for four rows, and 4 RT of the 16 waves run one pass each.
+constexpr int LNQ = 3;                                // column quads per lane
+
+__device__ __forceinline__ float row16_allsum(float v) {
+#define RD_ROR_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+  RD_ROR_ADD(0x128);   // row_ror:8
+  RD_ROR_ADD(0x124);   // row_ror:4
+  RD_ROR_ADD(0x122);   // row_ror:2
+  RD_ROR_ADD(0x121);   // row_ror:1
+#undef RD_ROR_ADD
+  return v;
+}
+// EVEN 16-lane rows: x + (the same lane of the next row), i.e. rows 0 + 1 and 2 + 3; the odd rows' results are not used.
+// v_permlane16_swap_b32 (gfx950) exchanges the odd rows of its first operand with the even rows of its second: the even rows of
+// a + b are right whichever of the two directions the hardware completes (tools/probe_permlane_swap.hip: measured).
+__device__ __forceinline__ float rowpair_sum(float x) {
+  float a = x, b = x;
+  asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+
+// residual / saved rows of a pass: quad k of row m0 + 4 wave + g from a [M, D] tensor (zero beyond D or M)
+__device__ __forceinline__ void ln_load3(float4 (&r)[LNQ], const float* src, int D, int m0, int M, int wave, int lane) {
+  const long m = m0 + 4 * wave + (lane >> 4);
+#pragma unroll
+  for (int k = 0; k < LNQ; ++k) {
+    const int c = 4 * ((lane & 15) + 16 * k);
+    r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < D && m < M) r[k] = *reinterpret_cast<const float4*>(src + m * D + c);
+  }
+}
+
+// One pass of the LayerNorm epilogue: sv = residual + dropout(stage + bias); writes the pre-norm sum, the normalised row and the
+// statistics; normalised rows also go to the split planes (Ph != null; zeros beyond D / M: the next product reads them).
+// bs / gg / bb: the bias, gamma, beta vectors in LDS (zero padded to KPD).
+__device__ __forceinline__ void ln_rows4(const float* stage, const float4 (&res)[LNQ], const float* bs, const float* gg, const float* bb, int D,
+                                         int m0, int M, int wave, int lane, float p, float inv_keep, uint64_t seed, uint32_t site,
+                                         float* s_out, float* y_out, float* stats, __bf16* Ph, __bf16* Pl) {
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  t.x += bs.x; t.y += bs.y; t.z += bs.z; t.w += bs.w;
-  if (p > 0.f) {
-    const float4 u = uniform4(seed, site, ((uint64_t)m * N + c) >> 2);
-    t.x *= u.x >= p ? inv_keep : 0.f; t.y *= u.y >= p ? inv_keep : 0.f;
-    t.z *= u.z >= p ? inv_keep : 0.f; t.w *= u.w >= p ? inv_keep : 0.f;
+  const int g = lane >> 4, i16 = lane & 15, rl = 4 * wave + g;
+  const long m = m0 + rl;
+  const bool rok = m < M;
+  float4 sv[LNQ];
+  float part = 0.f;
+#pragma unroll
+  for (int k = 0; k < LNQ; ++k) {
+    const int c = 4 * (i16 + 16 * k);
+    const bool ok = rok && c < D;
+    float4 t = zero4;
+    if (c < D) {
+      t = *reinterpret_cast<const float4*>(stage + rl * STG + c);
+      const float4 b4 = *reinterpret_cast<const float4*>(bs + c);
+      t.x += b4.x; t.y += b4.y; t.z += b4.z; t.w += b4.w;
+    }
+    if (p > 0.f) {
+      const float4 u = uniform4(seed, site, ((uint64_t)m * D + c) >> 2);
+      t.x *= u.x >= p ? inv_keep : 0.f; t.y *= u.y >= p ? inv_keep : 0.f;
+      t.z *= u.z >= p ? inv_keep : 0.f; t.w *= u.w >= p ? inv_keep : 0.f;
+    }
+    sv[k] = zero4;
+    if (ok) {
+      sv[k] = make_float4(res[k].x + t.x, res[k].y + t.y, res[k].z + t.z, res[k].w + t.w);
+      *reinterpret_cast<float4*>(s_out + m * D + c) = sv[k];
+    }
+    part += (sv[k].x + sv[k].y) + (sv[k].z + sv[k].w);
   }
-  const float4 sv = make_float4(res.x + t.x, res.y + t.y, res.z + t.z, res.w + t.w);   // 0 beyond N
-  if (cok) *reinterpret_cast<float4*>(s_out + m * N + c) = sv;
-  const float mean = wsum((sv.x + sv.y) + (sv.z + sv.w)) / N;
-  float4 d = make_float4(sv.x - mean, sv.y - mean, sv.z - mean, sv.w - mean);
-  if (!cok) d = zero4;
-  const float rstd = rsqrtf(wsum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) / N + 1e-5f);
-  float4 o = zero4;
-  if (cok) {
-    o = make_float4(d.x * rstd * gg.x + bb.x, d.y * rstd * gg.y + bb.y, d.z * rstd * gg.z + bb.z, d.w * rstd * gg.w + bb.w);
-    *reinterpret_cast<float4*>(y_out + m * N + c) = o;
+  const float mean = row16_allsum(part) / D;
+  float4 d[LNQ];
+  float vpart = 0.f;
+#pragma unroll
+  for (int k = 0; k < LNQ; ++k) {
+    const int c = 4 * (i16 + 16 * k);
+    d[k] = zero4;
+    if (rok && c < D) d[k] = make_float4(sv[k].x - mean, sv[k].y - mean, sv[k].z - mean, sv[k].w - mean);
+    vpart += (d[k].x * d[k].x + d[k].y * d[k].y) + (d[k].z * d[k].z + d[k].w * d[k].w);
   }
-  if (lane == 0) { stats[2 * m] = mean; stats[2 * m + 1] = rstd; }
-  return o;
+  const float rstd = rsqrtf(row16_allsum(vpart) / D + 1e-5f);
+#pragma unroll
+  for (int k = 0; k < LNQ; ++k) {
+    const int c = 4 * (i16 + 16 * k);
+    float4 o = zero4;
+    if (rok && c < D) {
+      const float4 g4 = *reinterpret_cast<const float4*>(gg + c), b4 = *reinterpret_cast<const float4*>(bb + c);
+      o = make_float4(d[k].x * rstd * g4.x + b4.x, d[k].y * rstd * g4.y + b4.y, d[k].z * rstd * g4.z + b4.z, d[k].w * rstd * g4.w + b4.w);
+      *reinterpret_cast<float4*>(y_out + m * D + c) = o;
+    }
+    if (Ph && c < KPD) split_store4(Ph + rl * LDD + c, Pl + rl * LDD + c, o);
+  }
+  if (i16 == 0 && rok) { stats[2 * m] = mean; stats[2 * m + 1] = rstd; }
 }
 
 // DC / HC: model width and FFN width as compile-time constants (0: read from the arguments).  These chains are instruction-issue
@@ -261,8 +330,6 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
     v[it] = zero4;
     if (r < ROWS && m0 + r < M && k < D) v[it] = *reinterpret_cast<const float4*>(a.attn + (long)(m0 + r) * D + k);
   }
-  const int c = 4 * lane;
-  const bool cok = c < D;
   Panel<KCD> po;
   load_panel<KCD>(po, a.Wo, ntD, wave, lane);
   __builtin_amdgcn_sched_barrier(0);
@@ -285,37 +352,16 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
     to_stage<RT>(stage, acc, wave, lane);
   }
   EFSTAMP(3);
-  float4 xr[RT];                                               // residual rows of LayerNorm1 (wave w: rows w, w + 16, ..)
-#pragma unroll
-  for (int q = 0; q < RT; ++q) {
-    const int m = m0 + wave + EF_WV * q;
-    xr[q] = zero4;
-    if (cok && m < M) xr[q] = *reinterpret_cast<const float4*>(a.x + (long)m * D + c);
-  }
+  constexpr int NPASS = 4 * RT;                                // LayerNorm passes of 4 rows: waves 0 .. NPASS - 1 run one each
+  const bool lnw = wave < NPASS;
+  float4 xr[LNQ];                                              // residual rows of LayerNorm1, in the pass layout (ln_rows4)
+  if (lnw) ln_load3(xr, a.x, D, m0, M, wave, lane);
   lds_barrier();                                               // stage complete; every wave is done reading the attn planes
   EFSTAMP(4);
   Panel<KCD> p1;                                               // linear1 (column tiles 0..15) streams in under the LayerNorm epilogue
   load_panel<KCD>(p1, a.W1, ntH, wave, lane);                  // (requested BEHIND the barrier: issuing it blocks a wave for a while)
   // ---- + bias, dropout, + x, LayerNorm1 -> s1, x1 (global), x1 planes ----
-  {
-    float4 gg = zero4, bb = zero4, bs = zero4;
-    if (cok) {
-      bs = *reinterpret_cast<const float4*>(cst + c); gg = *reinterpret_cast<const float4*>(cst + KPD + c);
-      bb = *reinterpret_cast<const float4*>(cst + 2 * KPD + c);
-    }
-#pragma unroll
-    for (int q = 0; q < RT; ++q) {
-      const int rl = wave + EF_WV * q;
-      const long m = m0 + rl;
-      float4 o = zero4;
-      if (m < M) {                                             // wave-uniform
-        float4 t = zero4;
-        if (cok) t = *reinterpret_cast<const float4*>(stage + rl * STG + c);
-        o = ln_row(t, xr[q], bs, gg, bb, cok, D, m, c, a.p, inv_keep, seed, a.site_ao, a.s1, a.x1, a.st1, lane);
-      }
-      if (c < KPD) split_store4(Ah + rl * LDD + c, Al + rl * LDD + c, o);       // rows beyond M and pad columns: zeros
-    }
-  }
+  if (lnw) ln_rows4(stage, xr, cst, cst + KPD, cst + 2 * KPD, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_ao, a.s1, a.x1, a.st1, Ah, Al);
   EFSTAMP(5);
   lds_barrier();
   EFSTAMP(6);
@@ -360,17 +406,10 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
       split_store4(Hh + rl * LDH + n, Hl + rl * LDH + n, o);
     }
   }
-  // LayerNorm2's residual x1: read back by the very thread that stored it (rows w, w + 16, .. / columns 4 lane ..).  The tall
-  // variant has no registers to carry the three quads through linear2's product beside its 72-register panel (they spilled:
-  // 23 MB of scratch writes per launch): it requests them behind the product instead.
-  auto load_res2 = [&]() {
-#pragma unroll
-    for (int q = 0; q < RT; ++q) {
-      const int m = m0 + wave + EF_WV * q;
-      xr[q] = zero4;
-      if (cok && m < M) xr[q] = *reinterpret_cast<const float4*>(a.x1 + (long)m * D + c);
-    }
-  };
+  // LayerNorm2's residual x1: read back by the very lane that stored it (pass layout).  The tall variant has no registers to carry
+  // the three quads through linear2's product beside its 72-register panel (they spilled: 23 MB of scratch writes per launch): it
+  // requests them behind the product instead.
+  auto load_res2 = [&]() { if (lnw) ln_load3(xr, a.x1, D, m0, M, wave, lane); };
   if constexpr (RT < 3) load_res2();
   EFSTAMP(9);
   lds_barrier();
@@ -388,22 +427,8 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
   lds_barrier();
   EFSTAMP(12);
   // ---- + bias, dropout, + x1, LayerNorm2 -> s2, y ----
-  {
-    float4 gg = zero4, bb = zero4, bs = zero4;
-    if (cok) {
-      bs = *reinterpret_cast<const float4*>(cst + 3 * KPD + c); gg = *reinterpret_cast<const float4*>(cst + 4 * KPD + c);
-      bb = *reinterpret_cast<const float4*>(cst + 5 * KPD + c);
-    }
-#pragma unroll
-    for (int q = 0; q < RT; ++q) {
-      const int rl = wave + EF_WV * q;
-      const long m = m0 + rl;
-      if (m >= M) continue;
-      float4 t = zero4;
-      if (cok) t = *reinterpret_cast<const float4*>(stage + rl * STG + c);
-      ln_row(t, xr[q], bs, gg, bb, cok, D, m, c, a.p, inv_keep, seed, a.site_fo, a.s2, a.y, a.st2, lane);
-    }
-  }
+  if (lnw) ln_rows4(stage, xr, cst + 3 * KPD, cst + 4 * KPD, cst + 5 * KPD, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_fo, a.s2, a.y, a.st2,
+                    nullptr, nullptr);
   EFSTAMP(13);
   if (a.stamps && tid == 0) { a.stamps[256 + 1024 + 2 * blockIdx.x] = wall_clock64(); a.stamps[256 + 1024 + 2 * blockIdx.x + 1] = clock64(); }
 }
@@ -440,49 +465,57 @@ struct PreBwdArgs {
   unsigned long long* stamps;
 };
 
-// LayerNorm backward of this wave's RT rows (rows RT wave .. RT wave + RT - 1; lane: columns 4 lane ..).  dyq / sq: the rows' dy and
-// saved pre-norm quads (zero beyond D or M).  Writes the unmasked gradient quads to ds_glob ([M][K]), the dropout-masked ones (what
-// the next product consumes) as split planes, and accumulates this wave's dgamma | dbeta partial into lnred[wave].  Same arithmetic
-// as k_rowgemm<.., LNB> (rd_rowgemm.hip).
-template <int RT>
-__device__ __forceinline__ void lnb_rows(const float4 (&dyq)[RT], const float4 (&sq)[RT], const float (&mean_r)[RT], const float (&rstd_r)[RT],
-                                         const float4& gg, bool cok, int K, int m0, int M, int wave, int lane, float p, float inv_keep,
-                                         uint64_t seed, uint32_t site, float* ds_glob, __bf16* Ph, __bf16* Pl, float* lnred) {
+// LayerNorm backward, one pass of four rows (the layout of ln_rows4).  dyq / sq: the rows' dy and saved pre-norm quads (zero beyond
+// D or M); mean / rstd: the lane's row statistics.  Writes the unmasked gradient quads to ds_glob ([M][K]), the dropout-masked ones
+// (what the next product consumes) as split planes, and this pass's dgamma | dbeta partials, summed over row pairs in registers
+// (rowpair_sum), into lnred[2 wave + (g >> 1)].  Same arithmetic as k_rowgemm<.., LNB> (rd_rowgemm.hip) up to the order of the sums.
+__device__ __forceinline__ void lnb_rows4(const float4 (&dyq)[LNQ], const float4 (&sq)[LNQ], float mean, float rstd, const float* gg, int K,
+                                          int m0, int M, int wave, int lane, float p, float inv_keep, uint64_t seed, uint32_t site,
+                                          float* ds_glob, __bf16* Ph, __bf16* Pl, float* lnred) {
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int c = 4 * lane;
-  float4 ag = zero4, ab = zero4;
+  const int g = lane >> 4, i16 = lane & 15, rl = 4 * wave + g;
+  const long row = m0 + rl;
+  const bool rok = row < M;
+  float4 dg[LNQ], xh[LNQ];
+  float p1 = 0.f, p2 = 0.f;
 #pragma unroll
-  for (int it = 0; it < RT; ++it) {
-    const int rl = wave * RT + it;
-    const long row = m0 + rl;
+  for (int k = 0; k < LNQ; ++k) {
+    const int c = 4 * (i16 + 16 * k);
+    dg[k] = zero4; xh[k] = zero4;
+    if (rok && c < K) {
+      const float4 g4 = *reinterpret_cast<const float4*>(gg + c);
+      xh[k] = make_float4((sq[k].x - mean) * rstd, (sq[k].y - mean) * rstd, (sq[k].z - mean) * rstd, (sq[k].w - mean) * rstd);
+      dg[k] = make_float4(dyq[k].x * g4.x, dyq[k].y * g4.y, dyq[k].z * g4.z, dyq[k].w * g4.w);
+    }
+    p1 += (dg[k].x + dg[k].y) + (dg[k].z + dg[k].w);
+    p2 += (dg[k].x * xh[k].x + dg[k].y * xh[k].y) + (dg[k].z * xh[k].z + dg[k].w * xh[k].w);
+  }
+  const float c1 = row16_allsum(p1) / K, c2 = row16_allsum(p2) / K;
+  float* slot = lnred + (size_t)(2 * wave + (g >> 1)) * 2 * KPD;
+#pragma unroll
+  for (int k = 0; k < LNQ; ++k) {
+    const int c = 4 * (i16 + 16 * k);
     float4 dr = zero4;
-    if (row < M) {                                     // wave-uniform
-      const float mean = mean_r[it], rstd = rstd_r[it];
-      const float4 dv = dyq[it];
-      float4 xh = make_float4((sq[it].x - mean) * rstd, (sq[it].y - mean) * rstd, (sq[it].z - mean) * rstd, (sq[it].w - mean) * rstd);
-      if (!cok) xh = zero4;
-      const float4 dg = make_float4(dv.x * gg.x, dv.y * gg.y, dv.z * gg.z, dv.w * gg.w);
-      const float c1 = wsum((dg.x + dg.y) + (dg.z + dg.w)) / K;
-      const float c2 = wsum((dg.x * xh.x + dg.y * xh.y) + (dg.z * xh.z + dg.w * xh.w)) / K;
-      if (cok) {
-        const float4 v = make_float4(rstd * (dg.x - c1 - xh.x * c2), rstd * (dg.y - c1 - xh.y * c2),
-                                     rstd * (dg.z - c1 - xh.z * c2), rstd * (dg.w - c1 - xh.w * c2));
-        *reinterpret_cast<float4*>(ds_glob + row * K + c) = v;
-        dr = v;
-        if (p > 0.f) {
-          const float4 u = uniform4(seed, site, ((uint64_t)row * K + c) >> 2);
-          dr.x *= u.x >= p ? inv_keep : 0.f; dr.y *= u.y >= p ? inv_keep : 0.f;
-          dr.z *= u.z >= p ? inv_keep : 0.f; dr.w *= u.w >= p ? inv_keep : 0.f;
-        }
-        ag.x += dv.x * xh.x; ag.y += dv.y * xh.y; ag.z += dv.z * xh.z; ag.w += dv.w * xh.w;
-        ab.x += dv.x; ab.y += dv.y; ab.z += dv.z; ab.w += dv.w;
+    if (rok && c < K) {
+      const float4 v = make_float4(rstd * (dg[k].x - c1 - xh[k].x * c2), rstd * (dg[k].y - c1 - xh[k].y * c2),
+                                   rstd * (dg[k].z - c1 - xh[k].z * c2), rstd * (dg[k].w - c1 - xh[k].w * c2));
+      *reinterpret_cast<float4*>(ds_glob + row * K + c) = v;
+      dr = v;
+      if (p > 0.f) {
+        const float4 u = uniform4(seed, site, ((uint64_t)row * K + c) >> 2);
+        dr.x *= u.x >= p ? inv_keep : 0.f; dr.y *= u.y >= p ? inv_keep : 0.f;
+        dr.z *= u.z >= p ? inv_keep : 0.f; dr.w *= u.w >= p ? inv_keep : 0.f;
       }
     }
     if (c < KPD) split_store4(Ph + rl * LDD + c, Pl + rl * LDD + c, dr);
-  }
-  if (cok) {
-    *reinterpret_cast<float4*>(lnred + wave * 2 * KPD + c) = ag;
-    *reinterpret_cast<float4*>(lnred + wave * 2 * KPD + KPD + c) = ab;
+    // dgamma | dbeta of this row (dyq is zero beyond D / M), added to the neighbouring row's in registers: all 64 lanes take part
+    const float4 ag = make_float4(rowpair_sum(dyq[k].x * xh[k].x), rowpair_sum(dyq[k].y * xh[k].y), rowpair_sum(dyq[k].z * xh[k].z),
+                                  rowpair_sum(dyq[k].w * xh[k].w));
+    const float4 ab = make_float4(rowpair_sum(dyq[k].x), rowpair_sum(dyq[k].y), rowpair_sum(dyq[k].z), rowpair_sum(dyq[k].w));
+    if ((g & 1) == 0 && c < K) {
+      *reinterpret_cast<float4*>(slot + c) = ag;
+      *reinterpret_cast<float4*>(slot + KPD + c) = ab;
+    }
   }
 }
 
@@ -495,10 +528,10 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   __bf16* Hl = Hh + ROWS * LDH;
   float* stage = reinterpret_cast<float*>(Hl + ROWS * LDH);    // [ROWS][STG]
   float* cst = stage + ROWS * STG;                             // [g2 | g1] (KPD each, zero padded)
-  // [16 waves][2 KPD] dgamma | dbeta partials of one LayerNorm: aliases the du planes (written only between the two uses, each use is
-  // closed by a barrier before / after the planes are touched)
+  // [2 NPASS row pairs][2 KPD] dgamma | dbeta partials of one LayerNorm: aliases the du planes (written only between the two uses,
+  // each use is closed by a barrier before / after the planes are touched)
   float* lnred = reinterpret_cast<float*>(Hh);
-  static_assert((size_t)EF_WV * 2 * KPD * 4 <= (size_t)2 * 16 * 2 * LDH * 2, "lnred must fit inside the du planes");
+  static_assert((size_t)2 * 4 * RT * 2 * KPD * 4 <= (size_t)2 * ROWS * LDH * 2, "lnred must fit inside the du planes");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * ROWS;
   const int D = DC ? DC : a.D, H = HC ? HC : a.H;
@@ -511,38 +544,32 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   uint64_t seed = a.seed;
   const float inv_keep = 1.0f / (1.0f - a.p);
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int c = 4 * lane;
-  const bool cok = c < D;
   EFSTAMP(0);
   if (tid < KPD) {                                             // each vector from its own kernel argument (no pointer select)
     float v2 = 0.f, v1 = 0.f;
     if (tid < D) { v2 = a.g2[tid]; v1 = a.g1[tid]; }
     cst[tid] = v2; cst[KPD + tid] = v1;
   }
-  // ---- rows of dy, s2 and their statistics (wave w: rows RT w ..; lane: 4 columns) ----
-  float4 dyq[RT], sq[RT]; float mean_r[RT], rstd_r[RT];
+  // ---- rows of dy, s2 and their statistics, in the LayerNorm pass layout (four rows per wave, waves 0 .. NPASS - 1) ----
+  constexpr int NPASS = 4 * RT;
+  const bool lnw = wave < NPASS;
+  float4 dyq[LNQ], sq[LNQ]; float mean_l = 0.f, rstd_l = 0.f;
+  auto load_stats = [&](const float* st) {
+    const long row = m0 + 4 * wave + (lane >> 4);
+    mean_l = 0.f; rstd_l = 0.f;
+    if (lnw && row < M) { mean_l = st[2 * row]; rstd_l = st[2 * row + 1]; }
+  };
 #pragma unroll
-  for (int it = 0; it < RT; ++it) {
-    const long row = m0 + wave * RT + it;
-    const bool rok = row < M;
-    mean_r[it] = rok ? a.st2[2 * row] : 0.f; rstd_r[it] = rok ? a.st2[2 * row + 1] : 0.f;
-    dyq[it] = zero4; sq[it] = zero4;
-    if (rok && cok) {
-      sq[it] = *reinterpret_cast<const float4*>(a.s2 + row * D + c);
-      dyq[it] = *reinterpret_cast<const float4*>(a.dy + row * D + c);
-    }
-  }
+  for (int k = 0; k < LNQ; ++k) { dyq[k] = zero4; sq[k] = zero4; }
+  if (lnw) { ln_load3(sq, a.s2, D, m0, M, wave, lane); ln_load3(dyq, a.dy, D, m0, M, wave, lane); }
+  load_stats(a.st2);
   Panel<KCD> pw;
   load_panel<KCD>(pw, a.W2t, ntH, wave, lane);
   __builtin_amdgcn_sched_barrier(0);
   if (a.seed_cell) seed += load_uniform_u64(a.seed_cell);
   lds_barrier();                                               // cst visible
   EFSTAMP(1);
-  {
-    float4 gg = zero4;
-    if (cok) gg = *reinterpret_cast<const float4*>(cst + c);
-    lnb_rows<RT>(dyq, sq, mean_r, rstd_r, gg, cok, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_fo, a.ds2, Ah, Al, lnred);
-  }
+  if (lnw) lnb_rows4(dyq, sq, mean_l, rstd_l, cst, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_fo, a.ds2, Ah, Al, lnred);
   // the FFN hidden (gate: h > 0): thread -> quads e, e + 1024, .. of the [ROWS][KPH / 4] grid; requested here, consumed behind
   // the next product
   constexpr int hq = KPH / 4;
@@ -562,7 +589,7 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
     const int col = i < D ? i : KPD + (i - D);
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < EF_WV; ++w) v += lnred[w * 2 * KPD + col];
+    for (int w = 0; w < 2 * NPASS; ++w) v += lnred[w * 2 * KPD + col];
     a.part2[(long)blockIdx.x * 2 * D + i] = v;
   }
   if (a.xt_df) export_tiles<RT>(Ah, Al, LDD, a.xt_df, ntD, m0, M, wave, lane);
@@ -605,19 +632,12 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   }
   // LayerNorm1's saved rows and the residual-branch gradient ds2 (read back by the thread that stored it): requested here,
   // consumed after the next product
-  float4 rq[RT];
+  float4 rq[LNQ];
   auto load_ln1 = [&]() {
+    load_stats(a.st1);
 #pragma unroll
-    for (int it = 0; it < RT; ++it) {
-      const long row = m0 + wave * RT + it;
-      const bool rok = row < M;
-      mean_r[it] = rok ? a.st1[2 * row] : 0.f; rstd_r[it] = rok ? a.st1[2 * row + 1] : 0.f;
-      sq[it] = zero4; rq[it] = zero4;
-      if (rok && cok) {
-        sq[it] = *reinterpret_cast<const float4*>(a.s1 + row * D + c);
-        rq[it] = *reinterpret_cast<const float4*>(a.ds2 + row * D + c);
-      }
-    }
+    for (int k = 0; k < LNQ; ++k) { sq[k] = zero4; rq[k] = zero4; }
+    if (lnw) { ln_load3(sq, a.s1, D, m0, M, wave, lane); ln_load3(rq, a.ds2, D, m0, M, wave, lane); }   // ds2: read back by the lane that stored it
   };
   // (the tall variant cannot carry these 30 registers through the next product beside the 72-register panel: they spilled,
   // 41 MB of scratch traffic per launch; it requests them behind the product)
@@ -640,19 +660,18 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   EFSTAMP(9);
   Panel<KCD> po;
   load_panel<KCD>(po, a.Wot, ntD, wave, lane);
-  {
+  if (lnw) {
+    const int rl = 4 * wave + (lane >> 4);
 #pragma unroll
-    for (int it = 0; it < RT; ++it) {
-      const int rl = wave * RT + it;
-      dyq[it] = zero4;
-      if (cok && m0 + rl < M) {
-        const float4 t = *reinterpret_cast<const float4*>(stage + rl * STG + c);
-        dyq[it] = make_float4(t.x + rq[it].x, t.y + rq[it].y, t.z + rq[it].z, t.w + rq[it].w);
+    for (int k = 0; k < LNQ; ++k) {
+      const int cq = 4 * ((lane & 15) + 16 * k);
+      dyq[k] = zero4;
+      if (cq < D && m0 + rl < M) {
+        const float4 t = *reinterpret_cast<const float4*>(stage + rl * STG + cq);
+        dyq[k] = make_float4(t.x + rq[k].x, t.y + rq[k].y, t.z + rq[k].z, t.w + rq[k].w);
       }
     }
-    float4 gg = zero4;
-    if (cok) gg = *reinterpret_cast<const float4*>(cst + KPD + c);
-    lnb_rows<RT>(dyq, sq, mean_r, rstd_r, gg, cok, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_ao, a.ds1, Ah, Al, lnred);
+    lnb_rows4(dyq, sq, mean_l, rstd_l, cst + KPD, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_ao, a.ds1, Ah, Al, lnred);
   }
   EFSTAMP(10);
   lds_barrier();
@@ -661,7 +680,7 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
     const int col = i < D ? i : KPD + (i - D);
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < EF_WV; ++w) v += lnred[w * 2 * KPD + col];
+    for (int w = 0; w < 2 * NPASS; ++w) v += lnred[w * 2 * KPD + col];
     a.part1[(long)blockIdx.x * 2 * D + i] = v;
   }
   if (a.xt_dout) export_tiles<RT>(Ah, Al, LDD, a.xt_dout, ntD, m0, M, wave, lane);

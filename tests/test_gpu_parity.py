@@ -418,9 +418,9 @@ def test_attention_core_vs_float64(T, B, F, nhead):
 @pytest.mark.parametrize("T,B,p_drop", [(60, 6, 0.0), (60, 150, 0.2), (60, 256, 0.2), (33, 7, 0.2), (60, 137, 0.0)])
 def test_fused_row_local_chains_match_row_block_products(T, B, p_drop, precision_mode, monkeypatch):
     """rd_encfuse.hip (out_proj + LayerNorm1 + FFN + LayerNorm2 in one launch, and its backward chain) against the three
-    row-block launches per direction it replaces, IN THE SAME ARITHMETIC with the same Philox quads (dropout ON): the two paths
-    must agree bit for bit in the forward output and to summation order (per-block LayerNorm partials: 32- vs 48-row blocks)
-    in the gradients.  B = 150 / 137 (9000 / 8220 rows) make the kernels pick their 48-row blocks on a 256-CU device, B = 256
+    row-block launches per direction it replaces, IN THE SAME ARITHMETIC with the same dropout quads (dropout ON): the two paths
+    must agree to summation order (LayerNorm row sums; per-block LayerNorm partials: 32- vs 48-row blocks) in the output and
+    the gradients.  B = 150 / 137 (9000 / 8220 rows) make the kernels pick their 48-row blocks on a 256-CU device, B = 256
     (15360 rows) two rounds of 32-row blocks."""
     if precision_mode == "fp32":
         pytest.skip("the fused chains are bf16-mode kernels")
@@ -443,7 +443,9 @@ def test_fused_row_local_chains_match_row_block_products(T, B, p_drop, precision
         y = ops.encoder_layer(xd, mask, shp, 1, p_drop, 77, pd)
         g = torch.autograd.grad(y, [xd] + pd, dy)
         res[fuse] = (y.detach().cpu().numpy(), [t.cpu().numpy() for t in g])
-    assert np.array_equal(res["0"][0], res["1"][0])
+    # same products, same dropout quads; the LayerNorm row sums are grouped differently (16-lane butterflies over three quads per
+    # lane in the fused chains, one 64-lane tree in the row-block kernels): rounding-level differences only
+    assert _rel(res["1"][0], res["0"][0]) < 2e-6, _rel(res["1"][0], res["0"][0])
     for name, a, b in zip(["x"] + list(ops.ENC_PARAM_NAMES), res["1"][1], res["0"][1]):
         assert _rel(a, b) < 2e-5, (name, _rel(a, b))
 
@@ -481,8 +483,8 @@ def test_encoder_tile_weight_gradients_match_split_k(T, B, precision_mode, monke
     assert np.array_equal(out["1"][0], out["0"][0])
     for name, a, r in zip(["x"] + list(ops.ENC_PARAM_NAMES), out["1"][1], out["0"][1]):
         if name == "x":
-            assert np.abs(a - r).max() <= 1e-6 * np.abs(r).max(), name      # LayerNorm backward fused into the products: same
-        else:                                                            # arithmetic, contraction may differ by an ulp
+            assert np.abs(a - r).max() <= 1e-5 * np.abs(r).max(), name      # LayerNorm backward inside the fused chain: same arithmetic,
+        else:                                                            # row sums grouped differently (16-lane butterflies vs one 64-lane tree)
             assert np.abs(a - r).max() <= 2e-5 * np.abs(r).max(), (name, float(np.abs(a - r).max() / np.abs(r).max()))
 
 
