@@ -46,7 +46,10 @@ struct Panel { bf16x8 h[KC], l[KC]; };
 // (a long panel is requested in two halves to bound the registers in flight)
 template <int KC, int KC0 = 0, int KC1 = KC>
 __device__ __forceinline__ void load_panel(Panel<KC>& p, const __bf16* __restrict__ Wt, int ntiles, int j, int lane) {
-  const __bf16* t = Wt + (size_t)(j < ntiles ? j : 0) * (KC * 2 * 512) + lane * 8;
+  // a wave without a column tile requests nothing (wave-uniform): 6 of the 16 waves have none in the D-wide products, and their
+  // 10-18 KB of loads each only lengthened the address unit's queue in front of everybody's stores
+  if (__builtin_amdgcn_readfirstlane(j) >= ntiles) return;
+  const __bf16* t = Wt + (size_t)j * (KC * 2 * 512) + lane * 8;
 #pragma unroll
   for (int kc = KC0; kc < KC1; ++kc) {
     p.h[kc] = *reinterpret_cast<const bf16x8*>(t + (kc * 2 + 0) * 512);

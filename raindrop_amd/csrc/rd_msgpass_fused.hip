@@ -185,8 +185,9 @@ __device__ __forceinline__ void load_panel_kc(Panel& p, const __bf16* __restrict
   if (RD_ABL & 1) return;
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
-    const int j = wave + NWAVE * jj;
-    const __bf16* t = wl + (size_t)(j < nct ? j : 0) * (NKC * 2 * TILE) + lane * 8;
+    const int j = __builtin_amdgcn_readfirstlane(wave) + NWAVE * jj;
+    if (j >= nct) continue;                            // a wave without this column tile requests nothing (wave-uniform)
+    const __bf16* t = wl + (size_t)j * (NKC * 2 * TILE) + lane * 8;
 #pragma unroll
     for (int kc = KC0; kc < KC1; ++kc) {
       p.h[jj][kc] = *reinterpret_cast<const bf16x8*>(t + (kc * 2 + 0) * TILE);
