@@ -133,9 +133,12 @@ def k1_roofline(model, cfg, batch, reps=20):
             z, _, saved = ops.sensor_stage_fwd_raw(*det, shp, 0.2, 1234)
             ops.sensor_stage_bwd_raw(det[0], det[5], det[6], det[8], det[4], saved, z, dz, shp, 0.2)
 
-    def time_graph(fn, iters=50):
-        """Capture `fn` into a hipGraph and time back-to-back replays with HIP events on the replay
-        stream: pure device time of the launches `fn` makes, without host launch gaps."""
+    INNER = 8
+
+    def time_graph(fn, iters=25):
+        """Capture INNER back-to-back calls of `fn` into ONE hipGraph and time replays with HIP events on the replay stream: device
+        time of the launches `fn` makes, without host launch gaps -- and with the fixed cost of starting a graph (a few us per replay,
+        which the training step pays once for ~30 launches) spread over INNER repetitions instead of charged to 2-5 launches."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -145,8 +148,9 @@ def k1_roofline(model, cfg, batch, reps=20):
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            fn()
-        for _ in range(5):
+            for _ in range(INNER):
+                fn()
+        for _ in range(3):
             graph.replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -154,12 +158,12 @@ def k1_roofline(model, cfg, batch, reps=20):
             graph.replay()
         e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / iters           # ms per replay
+        return e0.elapsed_time(e1) / (iters * INNER)   # ms per call of fn
 
     fwd = time_graph(fwd_only)
     both = time_graph(fwd_bwd)
     bwd = both - fwd
-    return _roofline_dict(B, F, K, fwd, bwd, "hipGraph replays timed with HIP events" +
+    return _roofline_dict(B, F, K, fwd, bwd, "hipGraph replays (8 calls per graph) timed with HIP events" +
                           ("; on the step's token plan (live rows only: %d of %d)" % (int(plan[0]), T * B) if plan is not None else ""))
 
 
