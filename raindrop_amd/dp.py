@@ -27,11 +27,17 @@ class FlatGradAllReduce:
     buffer with ONE batched copy, all-reduces the buffer over RCCL in a few large buckets, and
     re-points every `p.grad` at its slice of the flat buffer, which is what the optimizer reads."""
 
-    def __init__(self, params, process_group=None, n_buckets=2, average=True):
-        """params: list of (name, Parameter) that will receive gradients, in forward order."""
+    def __init__(self, params, process_group=None, n_buckets=2, average=True, force_collective=False):
+        """params: list of (name, Parameter) that will receive gradients, in forward order.
+        force_collective (testing): issue the collectives even in a one-rank group -- a single MI355X can then exercise the RCCL
+        calls themselves (backend load, AVG, async handles next to hipGraph replays), which a world of one otherwise skips."""
         self.group = process_group
         self.average = average
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if force_collective and dist.is_initialized():
+            self._force = True                                            # (the true world size still sets the average)
+        else:
+            self._force = False
         self.params = [p for _, p in params]
         self.names = [n for n, _ in params]
         # every slice starts on a 256-byte boundary: the kernels use 16-byte loads on weights and
@@ -109,7 +115,7 @@ class FlatGradAllReduce:
     def allreduce(self):
         """All-reduce the flat buffer in place (gradients were written into it directly, e.g. by
         raindrop_amd.step.TrainStep); no-op for a single process."""
-        if self.world > 1:
+        if self.world > 1 or self._force:
             use_avg = self.average and dist.get_backend(self.group) == "nccl"
             op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM
             handles = [dist.all_reduce(self.flat[self.bounds[b]:self.bounds[b + 1]], op=op, group=self.group,
@@ -128,7 +134,7 @@ class FlatGradAllReduce:
     def allreduce_range_async(self, lo, hi):
         """Start the all-reduce of flat[lo:hi] on the collective's own stream (it waits for what the current stream has enqueued so
         far, and nothing later); returns a handle for allreduce_wait().  No-op (None) for a single process."""
-        if self.world <= 1 or hi <= lo:
+        if (self.world <= 1 and not self._force) or hi <= lo:
             return None
         use_avg = self.average and dist.get_backend(self.group) == "nccl"
         op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM

@@ -208,3 +208,46 @@ def test_bench_two_ranks_launch_line_on_one_gpu():
     assert d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and abs(d["value"] - 2 * 32 * 3 / (d["ms_per_step"] * 3e-3)) <= 0.02 * d["value"]
     assert "all-reduce" in d["config"]["workload"]
+
+
+def _rccl_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from raindrop_amd import dp, synth
+    from raindrop_amd.models_rd import Raindrop_v2
+    from raindrop_amd.step import TrainStep
+    dev = torch.device("cuda", 0)
+    cfg = synth.make_config("P19")
+    out = []
+    for split in (False, True):
+        m = Raindrop_v2(cfg["d_inp"], cfg["d_model"], cfg["nhead"], cfg["nhid"], cfg["nlayers"], cfg["dropout"], cfg["max_len"],
+                        cfg["d_static"], cfg["MAX"], 0.5, cfg["aggreg"], cfg["n_classes"], synth.make_structure(cfg, "sparse"),
+                        sensor_wise_mask=False)
+        synth.fill_params_(m, seed=21)
+        m = m.to(dev).train()
+        named = dict(m.named_parameters())
+        flat = dp.FlatGradAllReduce([(n, named[n]) for n in synth.live_parameter_names(cfg)], n_buckets=2, force_collective=split)
+        b = {k: (None if v is None else v.to(dev)) for k, v in synth.make_batch(cfg, 16, seed=33).items()}
+        ts = TrainStep(m, flat, b, p_drop=0.2, use_graph=True, seed=77, autotune=False, split=split)
+        ts.seed_cell.zero_()
+        for _ in range(3):                                          # three replays: the collectives interleave with graph replays
+            loss = float(ts.run_allreduce())
+        torch.cuda.synchronize()
+        out.append((loss, flat.flat.detach().cpu().numpy().copy()))
+        ts.close()
+    ret[0] = out
+    dist.destroy_process_group()
+
+
+def test_rccl_one_rank_collectives_between_graph_replays():
+    """RCCL itself on the one GPU this box has: a one-rank `nccl` process group, the two-graph step with its two asynchronous AVG
+    all-reduces issued for real (force_collective), three replays -- loss and gradients bit-equal to the one-graph step without any
+    collective.  (What N > 1 adds to this is other ranks' data; backend load, reduce op, stream ordering against hipGraph replays and
+    the handle protocol are all exercised here.)"""
+    world, port = 1, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rccl_worker, args=(world, port, ret), nprocs=1, join=True)
+    (l0, g0), (l1, g1) = ret[0]
+    assert l0 == l1 and np.array_equal(g0, g1)
