@@ -83,23 +83,26 @@ __global__ __launch_bounds__(256) void k_msg_dz2(const float* __restrict__ dz,
   }
 }
 
-// per-sample partial of dR_u: part[b][f*d+c] = sum_t dx[b,f,t*d+c] * (x>0) * src[t,b,f]
+// per-sample partial of dR_u: part[b][f*d+c] = sum_t dx[b,f,t*d+c] * (x>0) * src[t,b,f].  One wavefront per (b, f) row of
+// T*d contiguous floats, lanes along t (coalesced up to the stride d), fixed-order DPP sum over the 64 lanes.
 __global__ __launch_bounds__(256) void k_obs_embed_bwd(const float* __restrict__ dx,
                                                        const float* __restrict__ X,
                                                        const float* __restrict__ src,
                                                        float* __restrict__ part, int B, int T, int F,
                                                        int d, float keep_scale) {
-  const int b = blockIdx.x;
-  const int K = T * d;
-  for (int fc = threadIdx.x; fc < F * d; fc += blockDim.x) {
-    const int f = fc / d, c = fc - f * d;
-    const long base = ((long)b * F + f) * K + c;
+  const int lane = threadIdx.x & 63;
+  const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+  if (row >= (long)B * F) return;
+  const int b = (int)(row / F), f = (int)(row - (long)b * F);
+  const long base = row * ((long)T * d);
+  for (int c = 0; c < d; ++c) {
     float s = 0.f;
-    for (int t = 0; t < T; ++t) {
-      const long o = base + (long)t * d;
+    for (int t = lane; t < T; t += 64) {
+      const long o = base + (long)t * d + c;
       if (X[o] > 0.f) s += dx[o] * src[((long)t * B + b) * (2 * F) + f];   // X>0 <=> relu open AND kept
     }
-    part[(long)b * F * d + fc] = s * keep_scale;
+    s = wave_sum64_dpp(s);
+    if (lane == 0) part[row * d + c] = s * keep_scale;
   }
 }
 
@@ -395,7 +398,7 @@ extern "C" int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* 
   h.B = W1; h.sb_n = 1; h.sb_k = K;
   h.C = w.dx; h.sc_m = K;
   if ((rc = launch_gemm(h, st))) return rc;
-  hipLaunchKernelGGL(k_obs_embed_bwd, dim3(B), dim3(256), 0, st, w.dx, xsave, src, w.rupart, B, T, F, d,
+  hipLaunchKernelGGL(k_obs_embed_bwd, dim3((unsigned)(((long)B * F + 3) / 4)), dim3(256), 0, st, w.dx, xsave, src, w.rupart, B, T, F, d,
                      1.0f / (1.0f - p_drop));
   if ((rc = check_launch("k_obs_embed_bwd"))) return rc;
   if ((rc = launch_colsum(w.rupart, B, F * d, F * d, dR_u, w.colsum, st))) return rc;
@@ -443,7 +446,7 @@ extern "C" int rd_obs_embed_bwd(const rd_shape* s, const float* src, const float
   RD_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "p_drop must be in [0,1)");
   float* rupart = (float*)workspace;
   float* cws = rupart + align_up((size_t)B * F * d * sizeof(float), 256) / sizeof(float);
-  hipLaunchKernelGGL(k_obs_embed_bwd, dim3(B), dim3(256), 0, st, dX, X, src, rupart, B, T, F, d, 1.0f / (1.0f - p_drop));
+  hipLaunchKernelGGL(k_obs_embed_bwd, dim3((unsigned)(((long)B * F + 3) / 4)), dim3(256), 0, st, dX, X, src, rupart, B, T, F, d, 1.0f / (1.0f - p_drop));
   if ((rc = check_launch("k_obs_embed_bwd"))) return rc;
   return launch_colsum(rupart, B, F * d, F * d, dR_u, cws, st);
 }

@@ -162,7 +162,7 @@ template <int NTH>
 struct HeadRegs { float4 v[NTH]; unsigned ok; };     // ok: bit 4*i+j = component j of chunk i is inside the tile
 
 // VEC: 16-byte loads (head_dim % 4 == 0, row strides % 4 == 0, 16-byte aligned bases -- decided once per kernel
-// by head_vec_ok, a wave-uniform branch); otherwise four 4-byte loads per chunk.  Every load is UNCONDITIONAL
+// by the host, attn_vec_ok, and compiled in as the kernels' VEC flag); otherwise four 4-byte loads per chunk.  Every load is UNCONDITIONAL
 // from a clamped (always legal) address and the zero padding is applied later by head_mask: a conditional
 // load is a phi of {0, loaded value}, which makes the compiler shuffle registers -- and therefore wait --
 // right behind the request.
@@ -192,10 +192,6 @@ __device__ __forceinline__ void head_load_t(HeadRegs<NTH>& h, const float* base,
     }
   }
   h.ok = ok;
-}
-__device__ __forceinline__ bool head_vec_ok(int hd, long rs, long ro, const void* p0, const void* p1, const void* p2) {
-  return ((hd & 3) == 0) && ((rs & 3) == 0) && ((ro & 3) == 0) &&
-         (((reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15) == 0);
 }
 // zero padding (rows >= T, columns >= head_dim); call below the point where the loads may complete
 template <int NTH>
@@ -230,7 +226,7 @@ __device__ __forceinline__ float head_rowdot(const HeadRegs<NTH>& a, const HeadR
 // ------------------------------------------------------------------------------------------------
 // forward: grid (q tiles, B*H).  Wave w owns query rows 16w..16w+15 of the tile.
 // ------------------------------------------------------------------------------------------------
-template <int NTH>
+template <int NTH, bool VEC>
 __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int HDP = 16 * NTH, LDH = HDP + 4;
@@ -248,7 +244,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
   const int q0 = blockIdx.x * TS;
   const long rs = (long)a.B * 3 * a.D;
   const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
-  const bool vec = head_vec_ok(a.hd, rs, a.D, qb, nullptr, nullptr);
+  constexpr bool vec = VEC;
   HeadRegs<NTH> qv;
   if (vec) {
     head_load_t<NTH, true>(qv, qb, rs, q0, a.T, a.hd, tid);
@@ -349,7 +345,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
 // ------------------------------------------------------------------------------------------------
 // backward, dQ: grid (q tiles, B*H); also writes delta = rowsum(dout * out).
 // ------------------------------------------------------------------------------------------------
-template <int NTH>
+template <int NTH, bool VEC>
 __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int HDP = 16 * NTH, LDH = HDP + 4;
@@ -367,7 +363,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
   const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
   const float* dob = a.dout + (long)b * a.D + h * a.hd;
   const float* ob = a.out + (long)b * a.D + h * a.hd;
-  const bool vec = head_vec_ok(a.hd, rs, ro, qb, dob, ob);
+  constexpr bool vec = VEC;
   {
     HeadRegs<NTH> qv, dov, ov;
     if (vec) {
@@ -452,7 +448,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
 // backward, dK / dV: grid (key tiles, B*H).  Wave w owns key rows 16w..16w+15; scores are formed
 // directly transposed (S^T = K Q^T) so that both products below reduce over the query axis.
 // ------------------------------------------------------------------------------------------------
-template <int NTH>
+template <int NTH, bool VEC>
 __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int HDP = 16 * NTH, LDH = HDP + 4;
@@ -470,7 +466,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
   const long rs = (long)a.B * 3 * a.D, ro = (long)a.B * a.D;
   const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
   const float* dob = a.dout + (long)b * a.D + h * a.hd;
-  const bool vec = head_vec_ok(a.hd, rs, ro, qb, dob, nullptr);
+  constexpr bool vec = VEC;
   {
     HeadRegs<NTH> kv, vv;
     if (vec) {
@@ -563,7 +559,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
 // scores in each kernel and is kept for longer sequences).  Wave w owns query rows 16w..16w+15 for
 // S / dP / dQ and key rows 16w..16w+15 for dK / dV; dS and P o M are exchanged through LDS.
 // ------------------------------------------------------------------------------------------------
-template <int NTH>
+template <int NTH, bool VEC>
 __global__ __launch_bounds__(256) void k_attn_bwd_one(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int HDP = 16 * NTH, LDH = HDP + 4;
@@ -582,7 +578,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_one(AttnArgs a) {
   const float* dob = a.dout + (long)b * a.D + h * a.hd;
   const float* ob = a.out + (long)b * a.D + h * a.hd;
   // all five tiles (Q, K, V, dO, O), the LSE row and the key mask are requested in one burst
-  const bool vec = head_vec_ok(a.hd, rs, ro, qb, dob, ob);
+  constexpr bool vec = VEC;
   uint64_t seedv = a.seed;
   uint8_t mb[4];
   {
@@ -745,7 +741,7 @@ __device__ __forceinline__ void store_t4(__bf16* Ph, __bf16* Pl, int key, int q4
   *reinterpret_cast<abf4*>(Pl + key * LDT + q4) = lo;
 }
 
-template <int NTH>
+template <int NTH, bool VEC>
 __global__ __launch_bounds__(256) void k_attn_fwd_one_b16(AttnArgs a, int one) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
   constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8;
@@ -762,7 +758,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd_one_b16(AttnArgs a, int one) {
   const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
   const long rs = (long)a.B * 3 * a.D;
   const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
-  const bool vec = head_vec_ok(a.hd, rs, a.D, qb, nullptr, nullptr);
+  constexpr bool vec = VEC;
   ASTAMP(0);
   uint64_t seedv = a.seed;
   uint8_t mb[4];
@@ -850,7 +846,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd_one_b16(AttnArgs a, int one) {
   ASTAMP(7);
 }
 
-template <int NTH>
+template <int NTH, bool VEC>
 __global__ __launch_bounds__(256) void k_attn_bwd_one_b16(AttnArgs a, int one) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
   constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8;
@@ -874,7 +870,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_one_b16(AttnArgs a, int one) {
   const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
   const float* dob = a.dout + (long)b * a.D + h * a.hd;
   const float* ob = a.out + (long)b * a.D + h * a.hd;
-  const bool vec = head_vec_ok(a.hd, rs, ro, qb, dob, ob);
+  constexpr bool vec = VEC;
   ASTAMP(0);
   uint64_t seedv = a.seed;
   uint8_t mb[4];
@@ -966,7 +962,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_one_b16(AttnArgs a, int one) {
 // Eight-wave form of k_attn_fwd_one_b16: wave = (query row tile wq, half wh).  S: two of the four key tiles per wave, the row
 // maximum and the row sum are combined across the two halves through 1 KB of LDS; O = P V: the head-dim tiles split
 // between the halves.  Loads: waves 0-3 fetch Q and K, waves 4-7 V.
-template <int NTH>
+template <int NTH, bool VEC>
 __global__ __launch_bounds__(512) void k_attn_fwd_one_b16w(AttnArgs a, int one) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
   constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8, NA = (NTH + 1) / 2;
@@ -987,7 +983,7 @@ __global__ __launch_bounds__(512) void k_attn_fwd_one_b16w(AttnArgs a, int one) 
   const int Tv = ar.Tv;
   const long rs = ar.rstep * 3 * a.D, ro = ar.rstep * a.D;
   const float* qb = a.qkv + ar.row0 * 3 * a.D + h * a.hd;
-  const bool vec = head_vec_ok(a.hd, rs, a.D, qb, nullptr, nullptr);
+  constexpr bool vec = VEC;
   uint64_t seedv = a.seed;
   uint8_t mb[2];
 #pragma unroll
@@ -1089,7 +1085,7 @@ __global__ __launch_bounds__(512) void k_attn_fwd_one_b16w(AttnArgs a, int one) 
 // tiles of its query rows; dQ / dK / dV: the head-dim tiles are split between the two waves of a row tile.  Loads: waves
 // 0-3 fetch Q, K, V, waves 4-7 dO, O (+ delta, LSE).  Same LDS planes, two waves per SIMD instead of one: the phases of a
 // workgroup overlap a little instead of not at all (nothing needs a cross-wave reduction: the backward uses the saved LSE).
-template <int NTH>
+template <int NTH, bool VEC>
 __global__ __launch_bounds__(512) void k_attn_bwd_one_b16w(AttnArgs a, int one) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
   constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8, NA = (NTH + 1) / 2;
@@ -1115,7 +1111,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_one_b16w(AttnArgs a, int one) 
   const float* qb = a.qkv + ar.row0 * 3 * a.D + h * a.hd;
   const float* dob = a.dout + ar.row0 * a.D + h * a.hd;
   const float* ob = a.out + ar.row0 * a.D + h * a.hd;
-  const bool vec = head_vec_ok(a.hd, rs, ro, qb, dob, ob);
+  constexpr bool vec = VEC;
   uint64_t seedv = a.seed;
   uint8_t mb[2];
 #pragma unroll
@@ -1206,12 +1202,457 @@ __global__ __launch_bounds__(512) void k_attn_bwd_one_b16w(AttnArgs a, int one) 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Multi-tile attention (T > 64: P12's 215 steps) on the split-bf16 matrix path: the flash-style loops of k_attn_fwd /
+// k_attn_bwd_dq / k_attn_bwd_dkv with the planes, fragments and products of the single-tile kernels above (Q / K / V / dO split
+// once per tile while stored; P o M and dS kept transposed, [key][query]).  Two things the fp32 kernels do not do:
+//  * a 64-key tile with no live key (padding: most P12 samples are far shorter than 215) contributes exactly nothing -- p = 0,
+//    alpha = 1 -- and is skipped: one 64-bit "tile has a live key" word per sample, built from the key mask before the loop;
+//  * the NEXT tile's rows are requested while the current tile is computed (register double buffer) and the loop's barriers
+//    order LDS only (lds_barrier: no vmcnt drain).  A head tile is 64 rows of 320 bytes 120 KB apart; measured ~3.7 us from
+//    request to data at the P12 shape -- with one workgroup per CU that latency was 45% of the loop.
+// Padded layout only.
+// ------------------------------------------------------------------------------------------------
+// bit i: key tile i of sample b holds at least one live key (tiles >= 64 are never skipped)
+__device__ __forceinline__ uint64_t live_key_tiles(const uint8_t* __restrict__ mrow, int T, int lane) {
+  const int nt = (T + TS - 1) / TS;
+  uint64_t live = 0ull;
+  for (int i0 = 0; i0 < nt && i0 < 64; i0 += 4) {
+    uint8_t mv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int key = (i0 + u) * TS + lane;
+      const uint8_t m = mrow[min(key, T - 1)];
+      mv[u] = key < T ? m : (uint8_t)1;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (__ballot(mv[u] == 0) != 0ull && i0 + u < 64) live |= 1ull << (i0 + u);
+  }
+  return live;
+}
+// first live tile index >= i, or nt
+__device__ __forceinline__ int next_live_tile(uint64_t live, int i, int nt) {
+  while (i < nt && i < 64 && !((live >> i) & 1ull)) ++i;
+  return i;
+}
+template <int NTH>
+__device__ __forceinline__ void head_load2(HeadRegs<NTH>& x, const float* bx, long sx, HeadRegs<NTH>& y, const float* by, long sy,
+                                           int t0, int T, int hd, int tid, bool vec) {
+  if (vec) {
+    head_load_t<NTH, true>(x, bx, sx, t0, T, hd, tid);
+    head_load_t<NTH, true>(y, by, sy, t0, T, hd, tid);
+  } else {
+    head_load_t<NTH, false>(x, bx, sx, t0, T, hd, tid);
+    head_load_t<NTH, false>(y, by, sy, t0, T, hd, tid);
+  }
+}
+// key-mask bytes of the four 16-key groups of tile k0 a lane scores (1 = dead; keys >= T dead)
+__device__ __forceinline__ void key_mask4(uint8_t (&mb)[4], const uint8_t* __restrict__ mrow, int k0, int T, int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int key = k0 + 16 * j + (lane & 15);
+    const uint8_t m = mrow[min(key, T - 1)];
+    mb[j] = key < T ? m : (uint8_t)1;
+  }
+}
+
+#define MT_ACC(i)                                                                      \
+  do {                                                                                 \
+    if (a.stamps) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = clock64(); tacc[i] += t_ - tprev; tprev = t_; } \
+  } while (0)
+template <int NTH, bool VEC>
+__global__ __launch_bounds__(256) void k_attn_fwd_b16(AttnArgs a, int one) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8;
+  __bf16* Qh = reinterpret_cast<__bf16*>(bsm);
+  __bf16* Ql = Qh + TS * LDB;
+  __bf16* Kh = Ql + TS * LDB;
+  __bf16* Kl = Kh + TS * LDB;
+  __bf16* Vh = Kl + TS * LDB;
+  __bf16* Vl = Vh + TS * LDB;
+  __bf16* Ph = Vl + TS * LDB;                       // (P o M)^T of the current key tile  [key][query]
+  __bf16* Pl = Ph + TS * LDT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int q0 = blockIdx.x * TS;
+  const long rs = (long)a.B * 3 * a.D;
+  const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
+  constexpr bool vec = VEC;
+  const uint8_t* mrow = a.mask + (long)b * a.T;
+  const int nt = (a.T + TS - 1) / TS;
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = a.stamps ? clock64() : 0;
+  // everything the first tile needs is requested at once; key tile 0 is processed whether live or not (a dead tile is an identity)
+  HeadRegs<NTH> qv, kv, vv;
+  uint8_t mb[4];
+  if (vec) head_load_t<NTH, true>(qv, qb, rs, q0, a.T, a.hd, tid);
+  else head_load_t<NTH, false>(qv, qb, rs, q0, a.T, a.hd, tid);
+  head_load2<NTH>(kv, qb + a.D, rs, vv, qb + 2 * a.D, rs, 0, a.T, a.hd, tid, vec);
+  key_mask4(mb, mrow, 0, a.T, lane);
+  const uint64_t live = live_key_tiles(mrow, a.T, lane) | 1ull;
+  uint64_t seedv = a.seed;
+  if (a.p_drop > 0.f && a.seed_cell) seedv += load_uniform_u64(a.seed_cell);
+  float m_i[4], l_i[4];
+  f32x4 o[NTH];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { m_i[r] = -INFINITY; l_i[r] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < NTH; ++j) o[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float inv_keep = 1.0f / (1.0f - a.p_drop);
+  head_store_b16<NTH>(qv, Qh, Ql, LDB, HDP, tid);
+  MT_ACC(0);
+  int kt = 0;
+  while (kt < nt) {
+    const int k0 = kt * TS;
+    lds_barrier();                                    // the previous tile's P V product has read V and P^T
+    MT_ACC(1);
+    head_store_b16<NTH>(kv, Kh, Kl, LDB, HDP, tid);
+    head_store_b16<NTH>(vv, Vh, Vl, LDB, HDP, tid);
+    const uint8_t mc[4] = {mb[0], mb[1], mb[2], mb[3]};
+    const int kn = next_live_tile(live, kt + 1, nt);
+    if (kn < nt) {                                    // in flight during this tile's products
+      head_load2<NTH>(kv, qb + a.D, rs, vv, qb + 2 * a.D, rs, kn * TS, a.T, a.hd, tid, vec);
+      key_mask4(mb, mrow, kn * TS, a.T, lane);
+    }
+    lds_barrier();
+    MT_ACC(2);
+    f32x4 s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mma_b16<4, false, false>(s, Qh, Ql, LDB, wave * 16, Kh, Kl, LDB, HDP, lane, one);      // S = Q K^T
+    MT_ACC(3);
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[j][r] = mc[j] ? -INFINITY : s[j][r] * a.scale;
+        mx[r] = fmaxf(mx[r], s[j][r]);
+      }
+    }
+    float alpha[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float mn = fmaxf(m_i[r], group16_max(mx[r]));
+      alpha[r] = (m_i[r] == -INFINITY) ? 0.f : expf(m_i[r] - mn);
+      m_i[r] = mn;
+    }
+    float rsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int key = k0 + 16 * j + (lane & 15);
+      float k4[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.p_drop > 0.f)     // F.dropout on the attention probabilities (after the softmax sum)
+        attn_keep4(k4, seedv, a.site, bh, a.T, q0 + wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
+      float pv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = (s[j][r] == -INFINITY) ? 0.f : __expf(s[j][r] - m_i[r]);
+        rsum[r] += p;
+        pv[r] = p * k4[r];
+      }
+      store_t4(Ph, Pl, 16 * j + (lane & 15), wave * 16 + 4 * (lane >> 4), pv);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) l_i[r] = l_i[r] * alpha[r] + group16_sum(rsum[r]);
+#pragma unroll
+    for (int j = 0; j < NTH; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[j][r] *= alpha[r];
+    lds_barrier();
+    MT_ACC(4);
+    mma_b16<NTH, true, true>(o, Ph, Pl, LDT, wave * 16, Vh, Vl, LDB, TS, lane, one);       // O += (P o M) V
+    MT_ACC(5);
+    kt = kn;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int q = q0 + wave * 16 + 4 * (lane >> 4) + r;
+    if (q >= a.T) continue;
+    const float inv = 1.0f / l_i[r];
+#pragma unroll
+    for (int j = 0; j < NTH; ++j) {
+      const int c = 16 * j + (lane & 15);
+      if (c < a.hd) a.out[((long)q * a.B + b) * a.D + h * a.hd + c] = o[j][r] * inv;
+    }
+    if ((lane & 15) == 0) a.lse[(long)bh * a.T + q] = m_i[r] + logf(l_i[r]);
+  }
+  if (a.stamps && blockIdx.x == 0 && blockIdx.y < 8 && tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) a.stamps[blockIdx.y * 16 + i] = tacc[i];
+    a.stamps[blockIdx.y * 16 + 6] = clock64() - tprev;
+    a.stamps[blockIdx.y * 16 + 7] = __popcll(live);
+  }
+}
+
+// dQ (and delta = rowsum(dO * O)): grid (q tiles, B*H); wave w owns query rows 16w .. 16w+15 of the tile
+template <int NTH, bool VEC>
+__global__ __launch_bounds__(256) void k_attn_bwd_dq_b16(AttnArgs a, int one) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8;
+  __bf16* Qh = reinterpret_cast<__bf16*>(bsm);
+  __bf16* Ql = Qh + TS * LDB;
+  __bf16* Oh = Ql + TS * LDB;                       // dO
+  __bf16* Ol = Oh + TS * LDB;
+  __bf16* Kh = Ol + TS * LDB;
+  __bf16* Kl = Kh + TS * LDB;
+  __bf16* Vh = Kl + TS * LDB;
+  __bf16* Vl = Vh + TS * LDB;
+  __bf16* Sh = Vl + TS * LDB;                       // dS^T of the current key tile  [key][query]
+  __bf16* Sl = Sh + TS * LDT;
+  float* lse_s = reinterpret_cast<float*>(Sl + TS * LDT);
+  float* dl_s = lse_s + TS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int q0 = blockIdx.x * TS;
+  const long rs = (long)a.B * 3 * a.D, ro = (long)a.B * a.D;
+  const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
+  const float* dob = a.dout + (long)b * a.D + h * a.hd;
+  const float* ob = a.out + (long)b * a.D + h * a.hd;
+  constexpr bool vec = VEC;
+  const uint8_t* mrow = a.mask + (long)b * a.T;
+  const int nt = (a.T + TS - 1) / TS;
+  HeadRegs<NTH> kv, vv;
+  uint8_t mb[4];
+  uint64_t live;
+  {
+    HeadRegs<NTH> qv, dov, ov;
+    if (vec) head_load_t<NTH, true>(qv, qb, rs, q0, a.T, a.hd, tid);
+    else head_load_t<NTH, false>(qv, qb, rs, q0, a.T, a.hd, tid);
+    head_load2<NTH>(dov, dob, ro, ov, ob, ro, q0, a.T, a.hd, tid, vec);
+    const int r = tid >> 2, q = q0 + r;
+    const float l = a.lse[(long)bh * a.T + min(q, a.T - 1)];
+    head_load2<NTH>(kv, qb + a.D, rs, vv, qb + 2 * a.D, rs, 0, a.T, a.hd, tid, vec);     // key tile 0: always processed
+    key_mask4(mb, mrow, 0, a.T, lane);
+    live = live_key_tiles(mrow, a.T, lane) | 1ull;
+    head_store_b16<NTH>(qv, Qh, Ql, LDB, HDP, tid);
+    head_mask<NTH>(ov);
+    head_mask<NTH>(dov);
+    const float d = head_rowdot<NTH>(dov, ov);          // delta = rowsum(dO * O), in fp32; rows >= T are zero padded
+    head_store_b16<NTH>(dov, Oh, Ol, LDB, HDP, tid);
+    if ((tid & 3) == 0) {
+      dl_s[r] = d; lse_s[r] = q < a.T ? l : 0.f;
+      if (q < a.T) a.delta[(long)bh * a.T + q] = d;
+    }
+  }
+  uint64_t seedv = a.seed;
+  if (a.p_drop > 0.f && a.seed_cell) seedv += load_uniform_u64(a.seed_cell);
+  f32x4 dq[NTH];
+#pragma unroll
+  for (int j = 0; j < NTH; ++j) dq[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float inv_keep = 1.0f / (1.0f - a.p_drop);
+  int kt = 0;
+  while (kt < nt) {
+    const int k0 = kt * TS;
+    lds_barrier();                                    // the previous tile's dS K product has read K and dS^T
+    head_store_b16<NTH>(kv, Kh, Kl, LDB, HDP, tid);
+    head_store_b16<NTH>(vv, Vh, Vl, LDB, HDP, tid);
+    const uint8_t mc[4] = {mb[0], mb[1], mb[2], mb[3]};
+    const int kn = next_live_tile(live, kt + 1, nt);
+    if (kn < nt) {
+      head_load2<NTH>(kv, qb + a.D, rs, vv, qb + 2 * a.D, rs, kn * TS, a.T, a.hd, tid, vec);
+      key_mask4(mb, mrow, kn * TS, a.T, lane);
+    }
+    lds_barrier();
+    f32x4 s[4], dp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[j] = s[j]; }
+    mma_b16<4, false, false>(s, Qh, Ql, LDB, wave * 16, Kh, Kl, LDB, HDP, lane, one);      // S  = Q K^T
+    mma_b16<4, false, false>(dp, Oh, Ol, LDB, wave * 16, Vh, Vl, LDB, HDP, lane, one);     // dP = dO V^T
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int key = k0 + 16 * j + (lane & 15);
+      float k4[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.p_drop > 0.f)
+        attn_keep4(k4, seedv, a.site, bh, a.T, q0 + wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
+      float ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wave * 16 + 4 * (lane >> 4) + r;
+        ds[r] = 0.f;
+        if (!mc[j] && q0 + row < a.T) {
+          const float p = __expf(s[j][r] * a.scale - lse_s[row]);
+          ds[r] = p * (dp[j][r] * k4[r] - dl_s[row]) * a.scale;
+        }
+      }
+      store_t4(Sh, Sl, 16 * j + (lane & 15), wave * 16 + 4 * (lane >> 4), ds);
+    }
+    lds_barrier();
+    mma_b16<NTH, true, true>(dq, Sh, Sl, LDT, wave * 16, Kh, Kl, LDB, TS, lane, one);      // dQ += dS K
+    kt = kn;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int q = q0 + wave * 16 + 4 * (lane >> 4) + r;
+    if (q >= a.T) continue;
+#pragma unroll
+    for (int j = 0; j < NTH; ++j) {
+      const int c = 16 * j + (lane & 15);
+      if (c < a.hd) a.dqkv[((long)q * a.B + b) * 3 * a.D + h * a.hd + c] = dq[j][r];
+    }
+  }
+}
+
+// dK / dV: grid (key tiles, B*H).  Per query tile the scores are formed query-major (wave w: query rows 16w .. 16w+15 of the
+// tile against the workgroup's 64 keys, so the dropout quads are the forward's), stored transposed, and wave w then owns key
+// rows 16w .. 16w+15 of dK = dS^T Q and dV = (P o M)^T dO.  A key tile with no live key writes zeros and leaves.
+template <int NTH, bool VEC>
+__global__ __launch_bounds__(256) void k_attn_bwd_dkv_b16(AttnArgs a, int one) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8;
+  __bf16* Kh = reinterpret_cast<__bf16*>(bsm);
+  __bf16* Kl = Kh + TS * LDB;
+  __bf16* Vh = Kl + TS * LDB;
+  __bf16* Vl = Vh + TS * LDB;
+  __bf16* Qh = Vl + TS * LDB;
+  __bf16* Ql = Qh + TS * LDB;
+  __bf16* Oh = Ql + TS * LDB;                       // dO
+  __bf16* Ol = Oh + TS * LDB;
+  __bf16* Ph = Ol + TS * LDB;                       // (P o M)^T  [key][query]
+  __bf16* Pl = Ph + TS * LDT;
+  __bf16* Sh = Pl + TS * LDT;                       // dS^T       [key][query]
+  __bf16* Sl = Sh + TS * LDT;
+  float* lse_s = reinterpret_cast<float*>(Sl + TS * LDT);
+  float* dl_s = lse_s + TS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int k0 = blockIdx.x * TS;
+  const long rs = (long)a.B * 3 * a.D, ro = (long)a.B * a.D;
+  const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
+  const float* dob = a.dout + (long)b * a.D + h * a.hd;
+  constexpr bool vec = VEC;
+  const uint8_t* mrow = a.mask + (long)b * a.T;
+  uint8_t mb[4];
+  key_mask4(mb, mrow, k0, a.T, lane);
+  f32x4 dk[NTH], dv[NTH];
+#pragma unroll
+  for (int j = 0; j < NTH; ++j) { dk[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[j] = dk[j]; }
+  // the workgroup's K / V tile and the first query tile are requested before the mask is looked at
+  HeadRegs<NTH> qv, dov;
+  float lq, dq_;
+  {
+    HeadRegs<NTH> kv, vv;
+    head_load2<NTH>(kv, qb + a.D, rs, vv, qb + 2 * a.D, rs, k0, a.T, a.hd, tid, vec);
+    head_load2<NTH>(qv, qb, rs, dov, dob, ro, 0, a.T, a.hd, tid, vec);
+    lq = a.lse[(long)bh * a.T + min(tid & (TS - 1), a.T - 1)];
+    dq_ = a.delta[(long)bh * a.T + min(tid & (TS - 1), a.T - 1)];
+    head_store_b16<NTH>(kv, Kh, Kl, LDB, HDP, tid);
+    head_store_b16<NTH>(vv, Vh, Vl, LDB, HDP, tid);
+  }
+  const bool any_live = __ballot((mb[0] & mb[1] & mb[2] & mb[3]) == 0) != 0ull;   // same keys in every wave
+  if (any_live) {
+    uint64_t seedv = a.seed;
+    if (a.p_drop > 0.f && a.seed_cell) seedv += load_uniform_u64(a.seed_cell);
+    const float inv_keep = 1.0f / (1.0f - a.p_drop);
+    for (int q0 = 0; q0 < a.T; q0 += TS) {
+      lds_barrier();                                  // the previous query tile's products have read Q, dO, P^T, dS^T
+      head_store_b16<NTH>(qv, Qh, Ql, LDB, HDP, tid);
+      head_store_b16<NTH>(dov, Oh, Ol, LDB, HDP, tid);
+      if (tid < TS) { lse_s[tid] = q0 + tid < a.T ? lq : 0.f; dl_s[tid] = q0 + tid < a.T ? dq_ : 0.f; }
+      if (q0 + TS < a.T) {                            // next query tile, in flight during this one's products
+        head_load2<NTH>(qv, qb, rs, dov, dob, ro, q0 + TS, a.T, a.hd, tid, vec);
+        lq = a.lse[(long)bh * a.T + min(q0 + TS + (tid & (TS - 1)), a.T - 1)];
+        dq_ = a.delta[(long)bh * a.T + min(q0 + TS + (tid & (TS - 1)), a.T - 1)];
+      }
+      lds_barrier();
+      f32x4 s[4], dp[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[j] = s[j]; }
+      mma_b16<4, false, false>(s, Qh, Ql, LDB, wave * 16, Kh, Kl, LDB, HDP, lane, one);    // S  = Q K^T
+      mma_b16<4, false, false>(dp, Oh, Ol, LDB, wave * 16, Vh, Vl, LDB, HDP, lane, one);   // dP = dO V^T
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = k0 + 16 * j + (lane & 15);
+        float k4[4] = {1.f, 1.f, 1.f, 1.f};
+        if (a.p_drop > 0.f)
+          attn_keep4(k4, seedv, a.site, bh, a.T, q0 + wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
+        float pm[4], ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wave * 16 + 4 * (lane >> 4) + r;
+          pm[r] = 0.f; ds[r] = 0.f;
+          if (!mb[j] && q0 + row < a.T) {
+            const float p = __expf(s[j][r] * a.scale - lse_s[row]);
+            pm[r] = p * k4[r];
+            ds[r] = p * (dp[j][r] * k4[r] - dl_s[row]) * a.scale;
+          }
+        }
+        store_t4(Ph, Pl, 16 * j + (lane & 15), wave * 16 + 4 * (lane >> 4), pm);
+        store_t4(Sh, Sl, 16 * j + (lane & 15), wave * 16 + 4 * (lane >> 4), ds);
+      }
+      lds_barrier();
+      mma_b16<NTH, false, true>(dk, Sh, Sl, LDT, wave * 16, Qh, Ql, LDB, TS, lane, one);   // dK += dS^T Q
+      mma_b16<NTH, false, true>(dv, Ph, Pl, LDT, wave * 16, Oh, Ol, LDB, TS, lane, one);   // dV += (P o M)^T dO
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int key = k0 + wave * 16 + 4 * (lane >> 4) + r;
+    if (key >= a.T) continue;
+#pragma unroll
+    for (int j = 0; j < NTH; ++j) {
+      const int c = 16 * j + (lane & 15);
+      if (c < a.hd) {
+        float* row = a.dqkv + ((long)key * a.B + b) * 3 * a.D + h * a.hd + c;
+        row[a.D] = dk[j][r];
+        row[2 * a.D] = dv[j][r];
+      }
+    }
+  }
+}
+
+// 16-byte head-tile loads are legal: every row of every head starts on a 16-byte boundary.  Decided HERE and compiled into the
+// kernel (template flag): as a runtime flag the compiler merged the two load forms into four 4-byte loads per chunk -- 4x the
+// vector-memory instructions of every attention kernel.
+static bool attn_vec_ok(const AttnArgs& a) {
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return (a.hd & 3) == 0 && (a.D & 3) == 0 && al(a.qkv) && al(a.out) && al(a.dout);
+}
+#define ATTN_LAUNCH(K, grid, block, lds_attr, lds, ...)                                                  \
+  do {                                                                                                   \
+    if (vec) {                                                                                           \
+      RD_LDS_ATTR((K<NTH, true>), lds_attr);                                                             \
+      hipLaunchKernelGGL((K<NTH, true>), grid, block, lds, st, __VA_ARGS__);                             \
+    } else {                                                                                             \
+      RD_LDS_ATTR((K<NTH, false>), lds_attr);                                                            \
+      hipLaunchKernelGGL((K<NTH, false>), grid, block, lds, st, __VA_ARGS__);                            \
+    }                                                                                                    \
+  } while (0)
+
+static bool attn_b16_mt_ok(const AttnArgs& a) {
+  const char* e = getenv("RD_ATTN_B16_MT");           // read per call (tests compare both paths in one process)
+  return !(e && atoi(e) == 0) && precision() != RD_PREC_FP32 && a.T > TS && a.hd <= 96 && !a.plan;
+}
+template <int NTH>
+int launch_attn_b16_mt(const AttnArgs& a_in, int which, hipStream_t st) {
+  const bool vec = attn_vec_ok(a_in);
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8;
+  AttnArgs a = a_in;
+  a.stamps = g_attn_stamps;
+  const int one = precision() == RD_PREC_BF16;
+  const dim3 grid(cdiv(a.T, TS), a.B * a.H);
+  if (which == 0) {
+    const size_t lds = (size_t)(6 * TS * LDB + 2 * TS * LDT) * sizeof(__bf16);
+    ATTN_LAUNCH(k_attn_fwd_b16, grid, dim3(256), lds, lds, a, one);
+    return check_launch("k_attn_fwd_b16");
+  }
+  if (which == 1) {
+    const size_t lds = (size_t)(8 * TS * LDB + 2 * TS * LDT) * sizeof(__bf16) + 2 * TS * sizeof(float);
+    ATTN_LAUNCH(k_attn_bwd_dq_b16, grid, dim3(256), lds, lds, a, one);
+    return check_launch("k_attn_bwd_dq_b16");
+  }
+  const size_t lds = (size_t)(8 * TS * LDB + 4 * TS * LDT) * sizeof(__bf16) + 2 * TS * sizeof(float);
+  ATTN_LAUNCH(k_attn_bwd_dkv_b16, grid, dim3(256), lds, lds, a, one);
+  return check_launch("k_attn_bwd_dkv_b16");
+}
+
 static bool attn_b16_ok(const AttnArgs& a) {
   const char* e = getenv("RD_ATTN_B16");              // read per call (tests compare both paths in one process)
   return !(e && atoi(e) == 0) && precision() != RD_PREC_FP32 && a.T <= TS && a.hd <= 96;
 }
 template <int NTH>
 int launch_attn_b16(const AttnArgs& a_in, int which, hipStream_t st) {
+  const bool vec = attn_vec_ok(a_in);
   constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8;
   const int one = precision() == RD_PREC_BF16;
   AttnArgs a = a_in;
@@ -1221,52 +1662,46 @@ int launch_attn_b16(const AttnArgs& a_in, int which, hipStream_t st) {
     static const bool widef = [] { const char* e = getenv("RD_ATTN_FWD_W8"); return !(e && atoi(e) == 0); }();
     if (widef || a.plan) {
       const size_t ldsw = lds + 4 * TS * sizeof(float);
-      RD_LDS_ATTR((k_attn_fwd_one_b16w<NTH>), ldsw);
-      hipLaunchKernelGGL(k_attn_fwd_one_b16w<NTH>, dim3(a.B * a.H), dim3(512), ldsw, st, a, one);
+      ATTN_LAUNCH(k_attn_fwd_one_b16w, dim3(a.B * a.H), dim3(512), ldsw, ldsw, a, one);
       return check_launch("k_attn_fwd_one_b16w");
     }
-    RD_LDS_ATTR((k_attn_fwd_one_b16<NTH>), lds);
-    hipLaunchKernelGGL(k_attn_fwd_one_b16<NTH>, dim3(a.B * a.H), dim3(256), lds, st, a, one);
+    ATTN_LAUNCH(k_attn_fwd_one_b16, dim3(a.B * a.H), dim3(256), lds, lds, a, one);
     return check_launch("k_attn_fwd_one_b16");
   }
   const size_t lds = (size_t)(8 * TS * LDB + 4 * TS * LDT) * sizeof(__bf16) + 2 * TS * sizeof(float);
   static const bool wide = [] { const char* e = getenv("RD_ATTN_BWD_W8"); return !(e && atoi(e) == 0); }();
   if (wide || a.plan) {
-    RD_LDS_ATTR((k_attn_bwd_one_b16w<NTH>), lds);
-    hipLaunchKernelGGL(k_attn_bwd_one_b16w<NTH>, dim3(a.B * a.H), dim3(512), lds, st, a, one);
+    ATTN_LAUNCH(k_attn_bwd_one_b16w, dim3(a.B * a.H), dim3(512), lds, lds, a, one);
     return check_launch("k_attn_bwd_one_b16w");
   }
-  RD_LDS_ATTR((k_attn_bwd_one_b16<NTH>), lds);
-  hipLaunchKernelGGL(k_attn_bwd_one_b16<NTH>, dim3(a.B * a.H), dim3(256), lds, st, a, one);
+  ATTN_LAUNCH(k_attn_bwd_one_b16, dim3(a.B * a.H), dim3(256), lds, lds, a, one);
   return check_launch("k_attn_bwd_one_b16");
 }
 
 template <int NTH>
 int launch_attn(const AttnArgs& a, int which, hipStream_t st) {
+  const bool vec = attn_vec_ok(a);
   constexpr int LDH = 16 * NTH + 4;
   dim3 grid(cdiv(a.T, TS), a.B * a.H);
   size_t lds;
   if (which == 0) {
     lds = sizeof(float) * (3 * TS * LDH + TS * LDP);
-    RD_LDS_ATTR((k_attn_fwd<NTH>), lds);
+    const size_t lds_attr = lds;
     if (a.T <= TS && LDH >= LDP) lds = sizeof(float) * (3 * TS * LDH);   // P overlays Q
-    hipLaunchKernelGGL(k_attn_fwd<NTH>, grid, dim3(256), lds, st, a);
+    ATTN_LAUNCH(k_attn_fwd, grid, dim3(256), lds_attr, lds, a);
     return check_launch("k_attn_fwd");
   } else if (which == 1) {
     lds = sizeof(float) * (4 * TS * LDH + TS * LDP + 2 * TS);
-    RD_LDS_ATTR((k_attn_bwd_dq<NTH>), lds);
-    hipLaunchKernelGGL(k_attn_bwd_dq<NTH>, grid, dim3(256), lds, st, a);
+    ATTN_LAUNCH(k_attn_bwd_dq, grid, dim3(256), lds, lds, a);
     return check_launch("k_attn_bwd_dq");
   }
   if (which == 3) {
     lds = sizeof(float) * (4 * TS * LDH + 2 * TS * LDP + 2 * TS);
-    RD_LDS_ATTR((k_attn_bwd_one<NTH>), lds);
-    hipLaunchKernelGGL(k_attn_bwd_one<NTH>, dim3(a.B * a.H), dim3(256), lds, st, a);
+    ATTN_LAUNCH(k_attn_bwd_one, dim3(a.B * a.H), dim3(256), lds, lds, a);
     return check_launch("k_attn_bwd_one");
   }
   lds = sizeof(float) * (4 * TS * LDH + 2 * TS * LDP + 2 * TS);
-  RD_LDS_ATTR((k_attn_bwd_dkv<NTH>), lds);
-  hipLaunchKernelGGL(k_attn_bwd_dkv<NTH>, grid, dim3(256), lds, st, a);
+  ATTN_LAUNCH(k_attn_bwd_dkv, grid, dim3(256), lds, lds, a);
   return check_launch("k_attn_bwd_dkv");
 }
 
@@ -1389,6 +1824,16 @@ int dispatch_attn(const AttnArgs& a, int which, hipStream_t st) {
       case 4: return launch_attn_b16<4>(a, which, st);
       case 5: return launch_attn_b16<5>(a, which, st);
       default: return launch_attn_b16<6>(a, which, st);
+    }
+  }
+  if (which <= 2 && attn_b16_mt_ok(a)) {
+    switch (cdiv(a.hd, 16)) {
+      case 1: return launch_attn_b16_mt<1>(a, which, st);
+      case 2: return launch_attn_b16_mt<2>(a, which, st);
+      case 3: return launch_attn_b16_mt<3>(a, which, st);
+      case 4: return launch_attn_b16_mt<4>(a, which, st);
+      case 5: return launch_attn_b16_mt<5>(a, which, st);
+      default: return launch_attn_b16_mt<6>(a, which, st);
     }
   }
   switch (cdiv(a.hd, 16)) {
