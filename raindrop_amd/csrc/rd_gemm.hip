@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "rd_common.h"
+#include <type_traits>
 #include "rd_rng.h"
 
 namespace rd {
@@ -480,7 +481,10 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
   }
   if (tid < TN) bias_s[tid] = (g.bias && n0 + tid < g.N) ? g.bias[n0 + tid] : 0.f;
 
-  auto mma_tile = [&]() {
+  // `three` products (split-bf16) or hi*hi only (RD_PREC_BF16), decided outside the reduction loop: a branch inside it made every
+  // step its own basic block and kept the next step's fragment reads below this step's products
+  auto mma_steps = [&](auto three_tag) {
+    constexpr bool THREE = decltype(three_tag)::value;
 #pragma unroll
     for (int kc = 0; kc < BK2; kc += 32) {
       bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
@@ -488,16 +492,16 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
       for (int i = 0; i < MI; ++i) {
         const int oa = (wy * 16 * MI + i * 16 + (lane & 15)) * LDB + kc + 8 * (lane >> 4);
         ah[i] = *reinterpret_cast<const bf16x8*>(Ah + oa);
-        al[i] = *reinterpret_cast<const bf16x8*>(Al + oa);
+        if (THREE) al[i] = *reinterpret_cast<const bf16x8*>(Al + oa);
       }
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const int ob = (wx * 16 * NI + j * 16 + (lane & 15)) * LDB + kc + 8 * (lane >> 4);
         bh[j] = *reinterpret_cast<const bf16x8*>(Bh + ob);
-        bl[j] = *reinterpret_cast<const bf16x8*>(Bl + ob);
+        if (THREE) bl[j] = *reinterpret_cast<const bf16x8*>(Bl + ob);
       }
       // three passes over independent accumulators: no back-to-back MFMA on the same registers
-      if (!g.one_product) {                             // uniform: RD_PREC_BF16 keeps the hi*hi product only
+      if (THREE) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -515,6 +519,10 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
     }
+  };
+  auto mma_tile = [&]() {
+    if (!g.one_product) mma_steps(std::true_type{});
+    else mma_steps(std::false_type{});
   };
 
   if (NPRE > 0) {

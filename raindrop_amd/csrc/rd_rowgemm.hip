@@ -296,15 +296,17 @@ __global__ __launch_bounds__(64 * WV) void k_rowgemm(RowGemmArgs a) {
     for (int jj = 0; jj < RG_NJ; ++jj)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) acc[jj][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the single-product mode (RD_PREC_BF16) is decided OUTSIDE the reduction loop: a branch inside it cut every step into its own
+    // basic block, and the A-fragment reads of step kc+1 could not be scheduled above the products of step kc
+    if (!a.one_product) {
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-      bf16x8 ah[RT], al[RT];
+      for (int kc = 0; kc < KC; ++kc) {
+        bf16x8 ah[RT], al[RT];
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * LDA + aoff + kc * 32);
-        al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * LDA + aoff + kc * 32);
-      }
-      if (!a.one_product) {                              // uniform: RD_PREC_BF16 keeps the hi*hi product only
+        for (int rt = 0; rt < RT; ++rt) {
+          ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * LDA + aoff + kc * 32);
+          al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * LDA + aoff + kc * 32);
+        }
 #pragma unroll
         for (int jj = 0; jj < RG_NJ; ++jj)
 #pragma unroll
@@ -315,12 +317,23 @@ __global__ __launch_bounds__(64 * WV) void k_rowgemm(RowGemmArgs a) {
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
             acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], pw.l[jj][kc], acc[jj][rt], 0, 0, 0);
+#pragma unroll
+        for (int jj = 0; jj < RG_NJ; ++jj)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], pw.h[jj][kc], acc[jj][rt], 0, 0, 0);
       }
+    } else {
 #pragma unroll
-      for (int jj = 0; jj < RG_NJ; ++jj)
+      for (int kc = 0; kc < KC; ++kc) {
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-          acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], pw.h[jj][kc], acc[jj][rt], 0, 0, 0);
+        for (int rt = 0; rt < RT; ++rt) {
+          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * LDA + aoff + kc * 32);
+#pragma unroll
+          for (int jj = 0; jj < RG_NJ; ++jj)
+            acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, pw.h[jj][kc], acc[jj][rt], 0, 0, 0);
+        }
+      }
     }
     if (rd == 0) RGSTAMP(3);
     // next round's weights stream while this round's epilogue runs

@@ -691,23 +691,36 @@ __device__ __forceinline__ abf8 frag_t(const __bf16* P, int ld, int k0, int col0
 template <int NT, bool AT, bool BT>
 __device__ __forceinline__ void mma_b16(f32x4 (&acc)[NT], const __bf16* Ah, const __bf16* Al, int lda, int a0,
                                         const __bf16* Bh, const __bf16* Bl, int ldb, int KK, int lane, bool one) {
-  for (int k0 = 0; k0 < KK; k0 += 32) {
-    const abf8 ah = AT ? frag_t(Ah, lda, k0, a0, lane) : frag_n(Ah, lda, a0, k0, lane);
-    const abf8 al = AT ? frag_t(Al, lda, k0, a0, lane) : frag_n(Al, lda, a0, k0, lane);
-    abf8 bh[NT], bl[NT];
+  // `one` (RD_PREC_BF16: hi*hi only) is decided outside the reduction loop: inside it every step became its own basic block and
+  // the fragment reads of the next step could not move above this step's products
+  if (!one) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      bh[j] = BT ? frag_t(Bh, ldb, k0, 16 * j, lane) : frag_n(Bh, ldb, 16 * j, k0, lane);
-      bl[j] = BT ? frag_t(Bl, ldb, k0, 16 * j, lane) : frag_n(Bl, ldb, 16 * j, k0, lane);
-    }
-    if (!one) {
+    for (int k0 = 0; k0 < KK; k0 += 32) {
+      const abf8 ah = AT ? frag_t(Ah, lda, k0, a0, lane) : frag_n(Ah, lda, a0, k0, lane);
+      const abf8 al = AT ? frag_t(Al, lda, k0, a0, lane) : frag_n(Al, lda, a0, k0, lane);
+      abf8 bh[NT], bl[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        bh[j] = BT ? frag_t(Bh, ldb, k0, 16 * j, lane) : frag_n(Bh, ldb, 16 * j, k0, lane);
+        bl[j] = BT ? frag_t(Bl, ldb, k0, 16 * j, lane) : frag_n(Bl, ldb, 16 * j, k0, lane);
+      }
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[j], 0, 0, 0);
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[j], 0, 0, 0);
-    }
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[j], 0, 0, 0);
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[j], 0, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int k0 = 0; k0 < KK; k0 += 32) {
+      const abf8 ah = AT ? frag_t(Ah, lda, k0, a0, lane) : frag_n(Ah, lda, a0, k0, lane);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const abf8 bh = BT ? frag_t(Bh, ldb, k0, 16 * j, lane) : frag_n(Bh, ldb, 16 * j, k0, lane);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[j], 0, 0, 0);
+      }
+    }
   }
 }
 // head tile (fp32 registers) -> hi/lo planes [64][ldb], columns [16 NTH, hdp) zeroed
@@ -1203,16 +1216,26 @@ __global__ __launch_bounds__(512) void k_attn_bwd_one_b16w(AttnArgs a, int one) 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Multi-tile attention (T > 64: P12's 215 steps) on the split-bf16 matrix path: the flash-style loops of k_attn_fwd /
-// k_attn_bwd_dq / k_attn_bwd_dkv with the planes, fragments and products of the single-tile kernels above (Q / K / V / dO split
-// once per tile while stored; P o M and dS kept transposed, [key][query]).  Two things the fp32 kernels do not do:
+// Multi-tile attention (T > 64: P12's 215 steps, PAM's 600) on the split-bf16 matrix path, scores chained in REGISTERS.
+// The MFMA accumulator layout (lane l: column l & 15, rows 4 (l >> 4) + r) is, up to a permutation of the reduction index that
+// the other operand can follow, the B-operand layout of the next product.  So the kernels form the scores with the OWNED
+// dimension in the accumulator columns and feed them straight back:
+//   forward / dQ (a wave owns 16 queries):  S^T = K Q^T, dP^T = V dO^T  ->  O^T += V^T (P o M)^T,  dQ^T += K^T dS^T
+//   dK / dV      (a wave owns 16 keys):     S   = Q K^T, dP   = dO V^T  ->  dV^T += dO^T (P o M),  dK^T += Q^T dS
+// The owned rows' own operand (Q, dO / K, V) lives in registers as B fragments read once from global memory; only the streamed
+// 64-row tiles (K, V / Q, dO) go through LDS as hi/lo planes, whose transposed A fragments are two ds_read_b64_tr_b16 of FOUR
+// rows each (frag_t2: rows 4G.. of two 16-row blocks -- the permutation the accumulators impose).  No P / dS planes, no
+// transposing stores, one barrier less per tile, 53 KB of LDS instead of 98 - 143, 8 waves (128 owned rows) per workgroup, and the
+// results leave as 16-byte stores (an accumulator holds 4 consecutive head columns of one row).
 //  * a 64-key tile with no live key (padding: most P12 samples are far shorter than 215) contributes exactly nothing -- p = 0,
 //    alpha = 1 -- and is skipped: one 64-bit "tile has a live key" word per sample, built from the key mask before the loop;
 //  * the NEXT tile's rows are requested while the current tile is computed (register double buffer) and the loop's barriers
-//    order LDS only (lds_barrier: no vmcnt drain).  A head tile is 64 rows of 320 bytes 120 KB apart; measured ~3.7 us from
-//    request to data at the P12 shape -- with one workgroup per CU that latency was 45% of the loop.
-// Padded layout only.
+//    order LDS only (lds_barrier: no vmcnt drain).
+// Same masks, same dropout quads (attn_quad), same saved LSE as the fp32 kernels; padded layout only.
 // ------------------------------------------------------------------------------------------------
+constexpr int QW = 8;                   // waves per workgroup: 16-row blocks of the owned dimension
+constexpr int QROWS = 16 * QW;
+
 // bit i: key tile i of sample b holds at least one live key (tiles >= 64 are never skipped)
 __device__ __forceinline__ uint64_t live_key_tiles(const uint8_t* __restrict__ mrow, int T, int lane) {
   const int nt = (T + TS - 1) / TS;
@@ -1236,367 +1259,429 @@ __device__ __forceinline__ int next_live_tile(uint64_t live, int i, int nt) {
   while (i < nt && i < 64 && !((live >> i) & 1ull)) ++i;
   return i;
 }
-template <int NTH>
-__device__ __forceinline__ void head_load2(HeadRegs<NTH>& x, const float* bx, long sx, HeadRegs<NTH>& y, const float* by, long sy,
-                                           int t0, int T, int hd, int tid, bool vec) {
-  if (vec) {
-    head_load_t<NTH, true>(x, bx, sx, t0, T, hd, tid);
-    head_load_t<NTH, true>(y, by, sy, t0, T, hd, tid);
-  } else {
-    head_load_t<NTH, false>(x, bx, sx, t0, T, hd, tid);
-    head_load_t<NTH, false>(y, by, sy, t0, T, hd, tid);
+
+// The 8 consecutive head columns 32 ks + 8 G .. +7 of ONE row, per reduction step ks: a lane's share of a register-resident
+// B operand (lane l: row l & 15 of the wave's 16, G = l >> 4).  Loads are unconditional from clamped addresses (raw_load);
+// rows >= T and columns >= head_dim become zero in raw_split.
+template <int NKS>
+struct RawFrag { float4 v[NKS][2]; };
+template <int NKS, bool VEC>
+__device__ __forceinline__ void raw_load(RawFrag<NKS>& f, const float* __restrict__ row, int hd, int G) {
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int c = 32 * ks + 8 * G;
+    if (VEC) {
+      f.v[ks][0] = *reinterpret_cast<const float4*>(row + (c < hd ? c : 0));
+      f.v[ks][1] = *reinterpret_cast<const float4*>(row + (c + 4 < hd ? c + 4 : 0));
+    } else {
+      float e[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) e[u] = row[c + u < hd ? c + u : 0];
+      f.v[ks][0] = make_float4(e[0], e[1], e[2], e[3]);
+      f.v[ks][1] = make_float4(e[4], e[5], e[6], e[7]);
+    }
   }
 }
-// key-mask bytes of the four 16-key groups of tile k0 a lane scores (1 = dead; keys >= T dead)
-__device__ __forceinline__ void key_mask4(uint8_t (&mb)[4], const uint8_t* __restrict__ mrow, int k0, int T, int lane) {
+template <int NKS>
+__device__ __forceinline__ void raw_zero(RawFrag<NKS>& f, bool rok, int hd, int G) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int key = k0 + 16 * j + (lane & 15);
-    const uint8_t m = mrow[min(key, T - 1)];
-    mb[j] = key < T ? m : (uint8_t)1;
+  for (int ks = 0; ks < NKS; ++ks) {
+    float* e = reinterpret_cast<float*>(&f.v[ks][0]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (!(rok && 32 * ks + 8 * G + u < hd)) e[u] = 0.f;
+  }
+}
+template <int NKS>
+__device__ __forceinline__ void raw_split(const RawFrag<NKS>& f, abf8 (&fh)[NKS], abf8 (&fl)[NKS]) {
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const float* e = reinterpret_cast<const float*>(&f.v[ks][0]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      fh[ks][u] = (__bf16)e[u];
+      fl[ks][u] = (__bf16)(e[u] - (float)fh[ks][u]);
+    }
+  }
+}
+// two accumulator tiles (16-row blocks 2p and 2p+1 of the 64-row tile) -> the B operand of reduction step p:
+// slots 0..3 = rows 32 p + 4 G + r, slots 4..7 = rows 32 p + 16 + 4 G + r (the order frag_t2 reads the other operand in)
+__device__ __forceinline__ void pack_b(const float (&x0)[4], const float (&x1)[4], abf8& bh, abf8& bl) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    bh[r] = (__bf16)x0[r]; bl[r] = (__bf16)(x0[r] - (float)bh[r]);
+    bh[4 + r] = (__bf16)x1[r]; bl[4 + r] = (__bf16)(x1[r] - (float)bh[4 + r]);
+  }
+}
+// A fragment with the reduction index along the plane's rows, in the accumulator-imposed order: lane -> column col0 + (l & 15),
+// rows ra + 4 G .. +3 then rb + 4 G .. +3
+__device__ __forceinline__ abf8 frag_t2(const __bf16* P, int ld, int ra, int rb, int col0, int lane) {
+  const int i = lane & 15, G = lane >> 4;
+  const int o = (4 * G + (i >> 2)) * ld + col0 + 4 * (i & 3);
+  const as4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((as4 __attribute__((address_space(3)))*)(P + ra * ld + o));
+  const as4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((as4 __attribute__((address_space(3)))*)(P + rb * ld + o));
+  const as8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(abf8, v);
+}
+template <bool ONE>
+__device__ __forceinline__ void mfma3(f32x4& acc, const abf8& ah, const abf8& al, const abf8& bh, const abf8& bl) {
+  if (!ONE) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+  }
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+}
+// acc[j] (rows = rows 16 j .. of the 64-row plane tile, columns = the wave's 16 owned rows) += plane(64 x HDP) . regs^T
+template <int NKS, bool ONE>
+__device__ __forceinline__ void mma_plane_regs(f32x4 (&acc)[4], const __bf16* Ph, const __bf16* Pl, int ld, const abf8 (&bh)[NKS],
+                                               const abf8 (&bl)[NKS], int lane) {
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const abf8 ah = frag_n(Ph, ld, 16 * j, 32 * ks, lane);
+      abf8 al = ah;
+      if (!ONE) al = frag_n(Pl, ld, 16 * j, 32 * ks, lane);
+      mfma3<ONE>(acc[j], ah, al, bh[ks], bl[ks]);
+    }
+}
+// acc[ct] (rows = head columns 16 ct .., columns = the wave's 16 owned rows) += plane^T(HDP x 64) . x, x = the four accumulator
+// tiles xs[j][r] of the 64 streamed rows
+template <int NTH, bool ONE>
+__device__ __forceinline__ void mma_planeT_acc(f32x4 (&acc)[NTH], const __bf16* Ph, const __bf16* Pl, int ld, const float (&xs)[4][4],
+                                               int lane) {
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    abf8 bh, bl;
+    pack_b(xs[2 * p], xs[2 * p + 1], bh, bl);
+#pragma unroll
+    for (int ct = 0; ct < NTH; ++ct) {
+      const abf8 ah = frag_t2(Ph, ld, 32 * p, 32 * p + 16, 16 * ct, lane);
+      abf8 al = ah;
+      if (!ONE) al = frag_t2(Pl, ld, 32 * p, 32 * p + 16, 16 * ct, lane);
+      mfma3<ONE>(acc[ct], ah, al, bh, bl);
+    }
+  }
+}
+// sum / max over the four 16-lane rows of the wavefront (lanes l, l^16, l^32, l^48): every lane gets the result
+__device__ __forceinline__ float rows4_sum(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
+__device__ __forceinline__ float rows4_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); v = fmaxf(v, __shfl_xor(v, 32)); return v; }
+// Dropout keep flags in the TRANSPOSED score layout (a lane: ONE query q, keys kb .. kb+3): the quad of (key, queries 4m .. 4m+3)
+// is evaluated once, by the lane whose (l & 3) names the key, and the four lanes of a quad exchange their 4-bit results through
+// DPP quad_perm -- the same number of generator calls as the query-major kernels.  Returns bit r = keep (q, kb + r).
+__device__ __forceinline__ unsigned keep_bits_t(uint64_t seed, uint32_t site, int bh, int T, int q, int kb, int lane, float p) {
+  const float4 u = uniform4(seed, site, attn_quad(bh, T, q, min(kb + (lane & 3), T - 1)));
+  const int mine = (u.x >= p ? 1 : 0) | (u.y >= p ? 2 : 0) | (u.z >= p ? 4 : 0) | (u.w >= p ? 8 : 0);   // queries 4m .. 4m+3 of MY key
+  const int sh = lane & 3;                                                                           // my query's component
+  unsigned bits = 0;
+  bits |= ((unsigned)__builtin_amdgcn_update_dpp(0, mine, 0x00, 0xf, 0xf, false) >> sh & 1u) << 0;
+  bits |= ((unsigned)__builtin_amdgcn_update_dpp(0, mine, 0x55, 0xf, 0xf, false) >> sh & 1u) << 1;
+  bits |= ((unsigned)__builtin_amdgcn_update_dpp(0, mine, 0xaa, 0xf, 0xf, false) >> sh & 1u) << 2;
+  bits |= ((unsigned)__builtin_amdgcn_update_dpp(0, mine, 0xff, 0xf, 0xf, false) >> sh & 1u) << 3;
+  return bits;
+}
+// a lane's 4 consecutive head columns 16 ct + 4 G .. of row `dst` (16-byte store when VEC)
+template <bool VEC>
+__device__ __forceinline__ void store_cols4(float* __restrict__ dst, int c, int hd, const f32x4& v, float s) {
+  if (VEC) {
+    if (c < hd) *reinterpret_cast<float4*>(dst + c) = make_float4(v[0] * s, v[1] * s, v[2] * s, v[3] * s);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (c + r < hd) dst[c + r] = v[r] * s;
   }
 }
 
-#define MT_ACC(i)                                                                      \
-  do {                                                                                 \
-    if (a.stamps) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = clock64(); tacc[i] += t_ - tprev; tprev = t_; } \
-  } while (0)
-template <int NTH, bool VEC>
-__global__ __launch_bounds__(256) void k_attn_fwd_b16(AttnArgs a, int one) {
+template <int NTH, bool VEC, bool ONE>
+__global__ __launch_bounds__(64 * QW) void k_attn_fwd_b16(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
-  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8;
-  __bf16* Qh = reinterpret_cast<__bf16*>(bsm);
-  __bf16* Ql = Qh + TS * LDB;
-  __bf16* Kh = Ql + TS * LDB;
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8, NKS = HDP / 32;
+  __bf16* Kh = reinterpret_cast<__bf16*>(bsm);
   __bf16* Kl = Kh + TS * LDB;
   __bf16* Vh = Kl + TS * LDB;
   __bf16* Vl = Vh + TS * LDB;
-  __bf16* Ph = Vl + TS * LDB;                       // (P o M)^T of the current key tile  [key][query]
-  __bf16* Pl = Ph + TS * LDT;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t* mk = reinterpret_cast<uint32_t*>(Vl + TS * LDB);   // key-mask bytes of the current tile (1 = dead)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4;
   const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-  const int q0 = blockIdx.x * TS;
+  const int qw0 = blockIdx.x * QROWS + wave * 16;             // the wave's first query
+  const int q = qw0 + (lane & 15);
   const long rs = (long)a.B * 3 * a.D;
   const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
-  constexpr bool vec = VEC;
   const uint8_t* mrow = a.mask + (long)b * a.T;
   const int nt = (a.T + TS - 1) / TS;
-  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = a.stamps ? clock64() : 0;
-  // everything the first tile needs is requested at once; key tile 0 is processed whether live or not (a dead tile is an identity)
-  HeadRegs<NTH> qv, kv, vv;
-  uint8_t mb[4];
-  if (vec) head_load_t<NTH, true>(qv, qb, rs, q0, a.T, a.hd, tid);
-  else head_load_t<NTH, false>(qv, qb, rs, q0, a.T, a.hd, tid);
-  head_load2<NTH>(kv, qb + a.D, rs, vv, qb + 2 * a.D, rs, 0, a.T, a.hd, tid, vec);
-  key_mask4(mb, mrow, 0, a.T, lane);
+  // requests: my query row, key tile 0 (threads 0..255: K, 256..511: V; processed whether live or not -- a dead tile is an identity)
+  RawFrag<NKS> qraw;
+  raw_load<NKS, VEC>(qraw, qb + (long)min(q, a.T - 1) * rs, a.hd, G);
+  const bool isv = tid >= 256;
+  const int lt = tid & 255;
+  const float* kvb = qb + (isv ? 2 : 1) * a.D;
+  HeadRegs<NTH> kvr;
+  head_load_t<NTH, VEC>(kvr, kvb, rs, 0, a.T, a.hd, lt);
+  uint8_t mbyte = mrow[min(tid & 63, a.T - 1)];
   const uint64_t live = live_key_tiles(mrow, a.T, lane) | 1ull;
   uint64_t seedv = a.seed;
   if (a.p_drop > 0.f && a.seed_cell) seedv += load_uniform_u64(a.seed_cell);
-  float m_i[4], l_i[4];
-  f32x4 o[NTH];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) { m_i[r] = -INFINITY; l_i[r] = 0.f; }
-#pragma unroll
-  for (int j = 0; j < NTH; ++j) o[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float inv_keep = 1.0f / (1.0f - a.p_drop);
-  head_store_b16<NTH>(qv, Qh, Ql, LDB, HDP, tid);
-  MT_ACC(0);
+  abf8 qh[NKS], ql[NKS];
+  raw_zero<NKS>(qraw, q < a.T, a.hd, G);
+  raw_split<NKS>(qraw, qh, ql);
+  float m_i = -INFINITY, l_i = 0.f;                            // l_i: this lane's keys only; combined over the 4 lane rows at the end
+  f32x4 o[NTH];                                               // O^T: rows = head columns, column = my query
+#pragma unroll
+  for (int ct = 0; ct < NTH; ++ct) o[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
   int kt = 0;
   while (kt < nt) {
     const int k0 = kt * TS;
-    lds_barrier();                                    // the previous tile's P V product has read V and P^T
-    MT_ACC(1);
-    head_store_b16<NTH>(kv, Kh, Kl, LDB, HDP, tid);
-    head_store_b16<NTH>(vv, Vh, Vl, LDB, HDP, tid);
-    const uint8_t mc[4] = {mb[0], mb[1], mb[2], mb[3]};
+    lds_barrier();                                            // the previous tile's products have read the planes
+    head_store_b16<NTH>(kvr, isv ? Vh : Kh, isv ? Vl : Kl, LDB, HDP, lt);
+    if (tid < TS) reinterpret_cast<uint8_t*>(mk)[tid] = (k0 + tid < a.T) ? mbyte : (uint8_t)1;
     const int kn = next_live_tile(live, kt + 1, nt);
-    if (kn < nt) {                                    // in flight during this tile's products
-      head_load2<NTH>(kv, qb + a.D, rs, vv, qb + 2 * a.D, rs, kn * TS, a.T, a.hd, tid, vec);
-      key_mask4(mb, mrow, kn * TS, a.T, lane);
+    if (kn < nt) {                                            // in flight during this tile's products
+      head_load_t<NTH, VEC>(kvr, kvb, rs, kn * TS, a.T, a.hd, lt);
+      mbyte = mrow[min(kn * TS + (tid & 63), a.T - 1)];
     }
     lds_barrier();
-    MT_ACC(2);
     f32x4 s[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mma_b16<4, false, false>(s, Qh, Ql, LDB, wave * 16, Kh, Kl, LDB, HDP, lane, one);      // S = Q K^T
-    MT_ACC(3);
-    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    mma_plane_regs<NKS, ONE>(s, Kh, Kl, LDB, qh, ql, lane);    // S^T = K Q^T: rows = keys 16 j + 4 G + r, column = my query
+    float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+      const uint32_t dm = mk[4 * j + G];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        s[j][r] = mc[j] ? -INFINITY : s[j][r] * a.scale;
-        mx[r] = fmaxf(mx[r], s[j][r]);
+        s[j][r] = ((dm >> (8 * r)) & 0xffu) ? -INFINITY : s[j][r] * a.scale;
+        mx = fmaxf(mx, s[j][r]);
       }
     }
-    float alpha[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float mn = fmaxf(m_i[r], group16_max(mx[r]));
-      alpha[r] = (m_i[r] == -INFINITY) ? 0.f : expf(m_i[r] - mn);
-      m_i[r] = mn;
-    }
-    float rsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const float mn = fmaxf(m_i, rows4_max(mx));
+    const float alpha = (m_i == -INFINITY) ? 0.f : expf(m_i - mn);
+    m_i = mn;
+    float rsum = 0.f, pm[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int key = k0 + 16 * j + (lane & 15);
-      float k4[4] = {1.f, 1.f, 1.f, 1.f};
-      if (a.p_drop > 0.f)     // F.dropout on the attention probabilities (after the softmax sum)
-        attn_keep4(k4, seedv, a.site, bh, a.T, q0 + wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
-      float pv[4];
+      unsigned kb = 0xfu;
+      if (a.p_drop > 0.f) kb = keep_bits_t(seedv, a.site, bh, a.T, q, k0 + 16 * j + 4 * G, lane, a.p_drop);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = (s[j][r] == -INFINITY) ? 0.f : __expf(s[j][r] - m_i[r]);
-        rsum[r] += p;
-        pv[r] = p * k4[r];
+        const float p = (s[j][r] == -INFINITY) ? 0.f : __expf(s[j][r] - m_i);
+        rsum += p;
+        pm[j][r] = ((kb >> r) & 1u) ? (a.p_drop > 0.f ? p * inv_keep : p) : 0.f;   // F.dropout on the probabilities (after the softmax sum)
       }
-      store_t4(Ph, Pl, 16 * j + (lane & 15), wave * 16 + 4 * (lane >> 4), pv);
     }
+    l_i = l_i * alpha + rsum;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) l_i[r] = l_i[r] * alpha[r] + group16_sum(rsum[r]);
+    for (int ct = 0; ct < NTH; ++ct)
 #pragma unroll
-    for (int j = 0; j < NTH; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[j][r] *= alpha[r];
-    lds_barrier();
-    MT_ACC(4);
-    mma_b16<NTH, true, true>(o, Ph, Pl, LDT, wave * 16, Vh, Vl, LDB, TS, lane, one);       // O += (P o M) V
-    MT_ACC(5);
+      for (int r = 0; r < 4; ++r) o[ct][r] *= alpha;
+    mma_planeT_acc<NTH, ONE>(o, Vh, Vl, LDB, pm, lane);        // O^T += V^T (P o M)^T
     kt = kn;
   }
+  const float l = rows4_sum(l_i);
+  if (q < a.T) {
+    const float inv = 1.0f / l;
+    float* orow = a.out + ((long)q * a.B + b) * a.D + h * a.hd;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int q = q0 + wave * 16 + 4 * (lane >> 4) + r;
-    if (q >= a.T) continue;
-    const float inv = 1.0f / l_i[r];
-#pragma unroll
-    for (int j = 0; j < NTH; ++j) {
-      const int c = 16 * j + (lane & 15);
-      if (c < a.hd) a.out[((long)q * a.B + b) * a.D + h * a.hd + c] = o[j][r] * inv;
-    }
-    if ((lane & 15) == 0) a.lse[(long)bh * a.T + q] = m_i[r] + logf(l_i[r]);
-  }
-  if (a.stamps && blockIdx.x == 0 && blockIdx.y < 8 && tid == 0) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) a.stamps[blockIdx.y * 16 + i] = tacc[i];
-    a.stamps[blockIdx.y * 16 + 6] = clock64() - tprev;
-    a.stamps[blockIdx.y * 16 + 7] = __popcll(live);
+    for (int ct = 0; ct < NTH; ++ct) store_cols4<VEC>(orow, 16 * ct + 4 * G, a.hd, o[ct], inv);
+    if (G == 0) a.lse[(long)bh * a.T + q] = m_i + logf(l);
   }
 }
 
-// dQ (and delta = rowsum(dO * O)): grid (q tiles, B*H); wave w owns query rows 16w .. 16w+15 of the tile
-template <int NTH, bool VEC>
-__global__ __launch_bounds__(256) void k_attn_bwd_dq_b16(AttnArgs a, int one) {
+// dQ (and delta = rowsum(dO * O)): grid (query super-tiles, B*H); a wave owns 16 queries
+template <int NTH, bool VEC, bool ONE>
+__global__ __launch_bounds__(64 * QW) void k_attn_bwd_dq_b16(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
-  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8;
-  __bf16* Qh = reinterpret_cast<__bf16*>(bsm);
-  __bf16* Ql = Qh + TS * LDB;
-  __bf16* Oh = Ql + TS * LDB;                       // dO
-  __bf16* Ol = Oh + TS * LDB;
-  __bf16* Kh = Ol + TS * LDB;
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8, NKS = HDP / 32;
+  __bf16* Kh = reinterpret_cast<__bf16*>(bsm);
   __bf16* Kl = Kh + TS * LDB;
   __bf16* Vh = Kl + TS * LDB;
   __bf16* Vl = Vh + TS * LDB;
-  __bf16* Sh = Vl + TS * LDB;                       // dS^T of the current key tile  [key][query]
-  __bf16* Sl = Sh + TS * LDT;
-  float* lse_s = reinterpret_cast<float*>(Sl + TS * LDT);
-  float* dl_s = lse_s + TS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t* mk = reinterpret_cast<uint32_t*>(Vl + TS * LDB);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4;
   const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-  const int q0 = blockIdx.x * TS;
+  const int qw0 = blockIdx.x * QROWS + wave * 16;
+  const int q = qw0 + (lane & 15);
+  const int qc = min(q, a.T - 1);
   const long rs = (long)a.B * 3 * a.D, ro = (long)a.B * a.D;
   const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
-  const float* dob = a.dout + (long)b * a.D + h * a.hd;
-  const float* ob = a.out + (long)b * a.D + h * a.hd;
-  constexpr bool vec = VEC;
   const uint8_t* mrow = a.mask + (long)b * a.T;
   const int nt = (a.T + TS - 1) / TS;
-  HeadRegs<NTH> kv, vv;
-  uint8_t mb[4];
-  uint64_t live;
-  {
-    HeadRegs<NTH> qv, dov, ov;
-    if (vec) head_load_t<NTH, true>(qv, qb, rs, q0, a.T, a.hd, tid);
-    else head_load_t<NTH, false>(qv, qb, rs, q0, a.T, a.hd, tid);
-    head_load2<NTH>(dov, dob, ro, ov, ob, ro, q0, a.T, a.hd, tid, vec);
-    const int r = tid >> 2, q = q0 + r;
-    const float l = a.lse[(long)bh * a.T + min(q, a.T - 1)];
-    head_load2<NTH>(kv, qb + a.D, rs, vv, qb + 2 * a.D, rs, 0, a.T, a.hd, tid, vec);     // key tile 0: always processed
-    key_mask4(mb, mrow, 0, a.T, lane);
-    live = live_key_tiles(mrow, a.T, lane) | 1ull;
-    head_store_b16<NTH>(qv, Qh, Ql, LDB, HDP, tid);
-    head_mask<NTH>(ov);
-    head_mask<NTH>(dov);
-    const float d = head_rowdot<NTH>(dov, ov);          // delta = rowsum(dO * O), in fp32; rows >= T are zero padded
-    head_store_b16<NTH>(dov, Oh, Ol, LDB, HDP, tid);
-    if ((tid & 3) == 0) {
-      dl_s[r] = d; lse_s[r] = q < a.T ? l : 0.f;
-      if (q < a.T) a.delta[(long)bh * a.T + q] = d;
-    }
-  }
+  RawFrag<NKS> qraw, doraw, oraw;
+  raw_load<NKS, VEC>(qraw, qb + (long)qc * rs, a.hd, G);
+  raw_load<NKS, VEC>(doraw, a.dout + (long)b * a.D + h * a.hd + (long)qc * ro, a.hd, G);
+  raw_load<NKS, VEC>(oraw, a.out + (long)b * a.D + h * a.hd + (long)qc * ro, a.hd, G);
+  const float lse_q = a.lse[(long)bh * a.T + qc];
+  const bool isv = tid >= 256;
+  const int lt = tid & 255;
+  const float* kvb = qb + (isv ? 2 : 1) * a.D;
+  HeadRegs<NTH> kvr;
+  head_load_t<NTH, VEC>(kvr, kvb, rs, 0, a.T, a.hd, lt);
+  uint8_t mbyte = mrow[min(tid & 63, a.T - 1)];
+  const uint64_t live = live_key_tiles(mrow, a.T, lane) | 1ull;
   uint64_t seedv = a.seed;
   if (a.p_drop > 0.f && a.seed_cell) seedv += load_uniform_u64(a.seed_cell);
-  f32x4 dq[NTH];
-#pragma unroll
-  for (int j = 0; j < NTH; ++j) dq[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float inv_keep = 1.0f / (1.0f - a.p_drop);
+  abf8 qh[NKS], ql[NKS], gh[NKS], gl[NKS];                     // Q and dO rows of my query, as B operands
+  const bool qok = q < a.T;
+  raw_zero<NKS>(qraw, qok, a.hd, G);
+  raw_zero<NKS>(doraw, qok, a.hd, G);
+  raw_zero<NKS>(oraw, qok, a.hd, G);
+  float dsum = 0.f;                                           // delta = rowsum(dO * O), in fp32
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const float* x = reinterpret_cast<const float*>(&doraw.v[ks][0]);
+    const float* y = reinterpret_cast<const float*>(&oraw.v[ks][0]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dsum += x[u] * y[u];
+  }
+  const float dl_q = rows4_sum(dsum);
+  if (qok && G == 0) a.delta[(long)bh * a.T + q] = dl_q;
+  raw_split<NKS>(qraw, qh, ql);
+  raw_split<NKS>(doraw, gh, gl);
+  f32x4 dq[NTH];                                              // dQ^T: rows = head columns, column = my query
+#pragma unroll
+  for (int ct = 0; ct < NTH; ++ct) dq[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
   int kt = 0;
   while (kt < nt) {
     const int k0 = kt * TS;
-    lds_barrier();                                    // the previous tile's dS K product has read K and dS^T
-    head_store_b16<NTH>(kv, Kh, Kl, LDB, HDP, tid);
-    head_store_b16<NTH>(vv, Vh, Vl, LDB, HDP, tid);
-    const uint8_t mc[4] = {mb[0], mb[1], mb[2], mb[3]};
+    lds_barrier();
+    head_store_b16<NTH>(kvr, isv ? Vh : Kh, isv ? Vl : Kl, LDB, HDP, lt);
+    if (tid < TS) reinterpret_cast<uint8_t*>(mk)[tid] = (k0 + tid < a.T) ? mbyte : (uint8_t)1;
     const int kn = next_live_tile(live, kt + 1, nt);
     if (kn < nt) {
-      head_load2<NTH>(kv, qb + a.D, rs, vv, qb + 2 * a.D, rs, kn * TS, a.T, a.hd, tid, vec);
-      key_mask4(mb, mrow, kn * TS, a.T, lane);
+      head_load_t<NTH, VEC>(kvr, kvb, rs, kn * TS, a.T, a.hd, lt);
+      mbyte = mrow[min(kn * TS + (tid & 63), a.T - 1)];
     }
     lds_barrier();
     f32x4 s[4], dp[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { s[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[j] = s[j]; }
-    mma_b16<4, false, false>(s, Qh, Ql, LDB, wave * 16, Kh, Kl, LDB, HDP, lane, one);      // S  = Q K^T
-    mma_b16<4, false, false>(dp, Oh, Ol, LDB, wave * 16, Vh, Vl, LDB, HDP, lane, one);     // dP = dO V^T
+    mma_plane_regs<NKS, ONE>(s, Kh, Kl, LDB, qh, ql, lane);    // S^T  = K Q^T
+    mma_plane_regs<NKS, ONE>(dp, Vh, Vl, LDB, gh, gl, lane);   // dP^T = V dO^T
+    float ds[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int key = k0 + 16 * j + (lane & 15);
-      float k4[4] = {1.f, 1.f, 1.f, 1.f};
-      if (a.p_drop > 0.f)
-        attn_keep4(k4, seedv, a.site, bh, a.T, q0 + wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
-      float ds[4];
+      const uint32_t dm = mk[4 * j + G];
+      unsigned kb = 0xfu;
+      if (a.p_drop > 0.f) kb = keep_bits_t(seedv, a.site, bh, a.T, q, k0 + 16 * j + 4 * G, lane, a.p_drop);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = wave * 16 + 4 * (lane >> 4) + r;
-        ds[r] = 0.f;
-        if (!mc[j] && q0 + row < a.T) {
-          const float p = __expf(s[j][r] * a.scale - lse_s[row]);
-          ds[r] = p * (dp[j][r] * k4[r] - dl_s[row]) * a.scale;
+        ds[j][r] = 0.f;
+        if (!((dm >> (8 * r)) & 0xffu) && qok) {
+          const float p = __expf(s[j][r] * a.scale - lse_q);
+          const float k = ((kb >> r) & 1u) ? (a.p_drop > 0.f ? inv_keep : 1.f) : 0.f;
+          ds[j][r] = p * (dp[j][r] * k - dl_q) * a.scale;
         }
       }
-      store_t4(Sh, Sl, 16 * j + (lane & 15), wave * 16 + 4 * (lane >> 4), ds);
     }
-    lds_barrier();
-    mma_b16<NTH, true, true>(dq, Sh, Sl, LDT, wave * 16, Kh, Kl, LDB, TS, lane, one);      // dQ += dS K
+    mma_planeT_acc<NTH, ONE>(dq, Kh, Kl, LDB, ds, lane);       // dQ^T += K^T dS^T
     kt = kn;
   }
+  if (qok) {
+    float* row = a.dqkv + ((long)q * a.B + b) * 3 * a.D + h * a.hd;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int q = q0 + wave * 16 + 4 * (lane >> 4) + r;
-    if (q >= a.T) continue;
-#pragma unroll
-    for (int j = 0; j < NTH; ++j) {
-      const int c = 16 * j + (lane & 15);
-      if (c < a.hd) a.dqkv[((long)q * a.B + b) * 3 * a.D + h * a.hd + c] = dq[j][r];
-    }
+    for (int ct = 0; ct < NTH; ++ct) store_cols4<VEC>(row, 16 * ct + 4 * G, a.hd, dq[ct], 1.f);
   }
 }
 
-// dK / dV: grid (key tiles, B*H).  Per query tile the scores are formed query-major (wave w: query rows 16w .. 16w+15 of the
-// tile against the workgroup's 64 keys, so the dropout quads are the forward's), stored transposed, and wave w then owns key
-// rows 16w .. 16w+15 of dK = dS^T Q and dV = (P o M)^T dO.  A key tile with no live key writes zeros and leaves.
-template <int NTH, bool VEC>
-__global__ __launch_bounds__(256) void k_attn_bwd_dkv_b16(AttnArgs a, int one) {
+// dK / dV: grid (key super-tiles, B*H); a wave owns 16 keys, K and V rows in registers, the Q / dO tiles stream through LDS.
+// A workgroup whose 128 keys are all dead writes zeros and leaves; a wave whose 16 keys are all dead only helps with the tiles.
+template <int NTH, bool VEC, bool ONE>
+__global__ __launch_bounds__(64 * QW) void k_attn_bwd_dkv_b16(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
-  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8;
-  __bf16* Kh = reinterpret_cast<__bf16*>(bsm);
-  __bf16* Kl = Kh + TS * LDB;
-  __bf16* Vh = Kl + TS * LDB;
-  __bf16* Vl = Vh + TS * LDB;
-  __bf16* Qh = Vl + TS * LDB;
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8, NKS = HDP / 32;
+  __bf16* Qh = reinterpret_cast<__bf16*>(bsm);
   __bf16* Ql = Qh + TS * LDB;
   __bf16* Oh = Ql + TS * LDB;                       // dO
   __bf16* Ol = Oh + TS * LDB;
-  __bf16* Ph = Ol + TS * LDB;                       // (P o M)^T  [key][query]
-  __bf16* Pl = Ph + TS * LDT;
-  __bf16* Sh = Pl + TS * LDT;                       // dS^T       [key][query]
-  __bf16* Sl = Sh + TS * LDT;
-  float* lse_s = reinterpret_cast<float*>(Sl + TS * LDT);
+  float* lse_s = reinterpret_cast<float*>(Ol + TS * LDB);
   float* dl_s = lse_s + TS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ int any_live_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4;
   const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-  const int k0 = blockIdx.x * TS;
+  const int key = blockIdx.x * QROWS + wave * 16 + (lane & 15);
+  const int kc = min(key, a.T - 1);
   const long rs = (long)a.B * 3 * a.D, ro = (long)a.B * a.D;
   const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
   const float* dob = a.dout + (long)b * a.D + h * a.hd;
-  constexpr bool vec = VEC;
   const uint8_t* mrow = a.mask + (long)b * a.T;
-  uint8_t mb[4];
-  key_mask4(mb, mrow, k0, a.T, lane);
-  f32x4 dk[NTH], dv[NTH];
+  RawFrag<NKS> kraw, vraw;
+  raw_load<NKS, VEC>(kraw, qb + a.D + (long)kc * rs, a.hd, G);
+  raw_load<NKS, VEC>(vraw, qb + 2 * a.D + (long)kc * rs, a.hd, G);
+  const uint8_t mkey = mrow[kc];
+  // first query tile (threads 0..255: Q, 256..511: dO), lse / delta of its rows (threads 0..63)
+  const bool isg = tid >= 256;
+  const int lt = tid & 255;
+  const float* tb = isg ? dob : qb;
+  const long ts = isg ? ro : rs;
+  HeadRegs<NTH> tr;
+  head_load_t<NTH, VEC>(tr, tb, ts, 0, a.T, a.hd, lt);
+  float lq = a.lse[(long)bh * a.T + min(tid & 63, a.T - 1)], dlq = a.delta[(long)bh * a.T + min(tid & 63, a.T - 1)];
+  const bool dead = key >= a.T || mkey;
+  const bool wave_live = __ballot(!dead) != 0ull;
+  if (tid == 0) any_live_s = 0;
+  __syncthreads();
+  if (wave_live && lane == 0) any_live_s = 1;
+  __syncthreads();
+  const bool any_live = any_live_s != 0;
+  f32x4 dk[NTH], dv[NTH];                                     // dK^T, dV^T: rows = head columns, column = my key
 #pragma unroll
-  for (int j = 0; j < NTH; ++j) { dk[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[j] = dk[j]; }
-  // the workgroup's K / V tile and the first query tile are requested before the mask is looked at
-  HeadRegs<NTH> qv, dov;
-  float lq, dq_;
-  {
-    HeadRegs<NTH> kv, vv;
-    head_load2<NTH>(kv, qb + a.D, rs, vv, qb + 2 * a.D, rs, k0, a.T, a.hd, tid, vec);
-    head_load2<NTH>(qv, qb, rs, dov, dob, ro, 0, a.T, a.hd, tid, vec);
-    lq = a.lse[(long)bh * a.T + min(tid & (TS - 1), a.T - 1)];
-    dq_ = a.delta[(long)bh * a.T + min(tid & (TS - 1), a.T - 1)];
-    head_store_b16<NTH>(kv, Kh, Kl, LDB, HDP, tid);
-    head_store_b16<NTH>(vv, Vh, Vl, LDB, HDP, tid);
-  }
-  const bool any_live = __ballot((mb[0] & mb[1] & mb[2] & mb[3]) == 0) != 0ull;   // same keys in every wave
+  for (int ct = 0; ct < NTH; ++ct) { dk[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[ct] = dk[ct]; }
   if (any_live) {
+    abf8 kh[NKS], kl[NKS], vh[NKS], vl[NKS];
+    raw_zero<NKS>(kraw, key < a.T, a.hd, G);
+    raw_zero<NKS>(vraw, key < a.T, a.hd, G);
+    raw_split<NKS>(kraw, kh, kl);
+    raw_split<NKS>(vraw, vh, vl);
     uint64_t seedv = a.seed;
     if (a.p_drop > 0.f && a.seed_cell) seedv += load_uniform_u64(a.seed_cell);
     const float inv_keep = 1.0f / (1.0f - a.p_drop);
     for (int q0 = 0; q0 < a.T; q0 += TS) {
-      lds_barrier();                                  // the previous query tile's products have read Q, dO, P^T, dS^T
-      head_store_b16<NTH>(qv, Qh, Ql, LDB, HDP, tid);
-      head_store_b16<NTH>(dov, Oh, Ol, LDB, HDP, tid);
-      if (tid < TS) { lse_s[tid] = q0 + tid < a.T ? lq : 0.f; dl_s[tid] = q0 + tid < a.T ? dq_ : 0.f; }
-      if (q0 + TS < a.T) {                            // next query tile, in flight during this one's products
-        head_load2<NTH>(qv, qb, rs, dov, dob, ro, q0 + TS, a.T, a.hd, tid, vec);
-        lq = a.lse[(long)bh * a.T + min(q0 + TS + (tid & (TS - 1)), a.T - 1)];
-        dq_ = a.delta[(long)bh * a.T + min(q0 + TS + (tid & (TS - 1)), a.T - 1)];
+      lds_barrier();                                          // the previous query tile's products have read the planes
+      head_store_b16<NTH>(tr, isg ? Oh : Qh, isg ? Ol : Ql, LDB, HDP, lt);
+      if (tid < TS) { lse_s[tid] = lq; dl_s[tid] = dlq; }
+      if (q0 + TS < a.T) {                                    // next query tile, in flight during this one's products
+        head_load_t<NTH, VEC>(tr, tb, ts, q0 + TS, a.T, a.hd, lt);
+        lq = a.lse[(long)bh * a.T + min(q0 + TS + (tid & 63), a.T - 1)];
+        dlq = a.delta[(long)bh * a.T + min(q0 + TS + (tid & 63), a.T - 1)];
       }
       lds_barrier();
+      if (!wave_live) continue;                               // uniform per wave; the barriers above are still met
       f32x4 s[4], dp[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) { s[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[j] = s[j]; }
-      mma_b16<4, false, false>(s, Qh, Ql, LDB, wave * 16, Kh, Kl, LDB, HDP, lane, one);    // S  = Q K^T
-      mma_b16<4, false, false>(dp, Oh, Ol, LDB, wave * 16, Vh, Vl, LDB, HDP, lane, one);   // dP = dO V^T
+      mma_plane_regs<NKS, ONE>(s, Qh, Ql, LDB, kh, kl, lane);  // S  = Q K^T: rows = queries 16 j + 4 G + r, column = my key
+      mma_plane_regs<NKS, ONE>(dp, Oh, Ol, LDB, vh, vl, lane); // dP = dO V^T
+      float pm[4][4], ds[4][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int key = k0 + 16 * j + (lane & 15);
+        const int qj = q0 + 16 * j + 4 * G;
         float k4[4] = {1.f, 1.f, 1.f, 1.f};
-        if (a.p_drop > 0.f)
-          attn_keep4(k4, seedv, a.site, bh, a.T, q0 + wave * 16 + 4 * (lane >> 4), min(key, a.T - 1), a.p_drop, inv_keep);
-        float pm[4], ds[4];
+        if (a.p_drop > 0.f) attn_keep4(k4, seedv, a.site, bh, a.T, qj, kc, a.p_drop, inv_keep);
+        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 16 * j + 4 * G);
+        const float4 d4 = *reinterpret_cast<const float4*>(dl_s + 16 * j + 4 * G);
+        const float lr[4] = {l4.x, l4.y, l4.z, l4.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = wave * 16 + 4 * (lane >> 4) + r;
-          pm[r] = 0.f; ds[r] = 0.f;
-          if (!mb[j] && q0 + row < a.T) {
-            const float p = __expf(s[j][r] * a.scale - lse_s[row]);
-            pm[r] = p * k4[r];
-            ds[r] = p * (dp[j][r] * k4[r] - dl_s[row]) * a.scale;
+          pm[j][r] = 0.f; ds[j][r] = 0.f;
+          if (!dead && qj + r < a.T) {
+            const float p = __expf(s[j][r] * a.scale - lr[r]);
+            pm[j][r] = p * k4[r];
+            ds[j][r] = p * (dp[j][r] * k4[r] - dr[r]) * a.scale;
           }
         }
-        store_t4(Ph, Pl, 16 * j + (lane & 15), wave * 16 + 4 * (lane >> 4), pm);
-        store_t4(Sh, Sl, 16 * j + (lane & 15), wave * 16 + 4 * (lane >> 4), ds);
       }
-      lds_barrier();
-      mma_b16<NTH, false, true>(dk, Sh, Sl, LDT, wave * 16, Qh, Ql, LDB, TS, lane, one);   // dK += dS^T Q
-      mma_b16<NTH, false, true>(dv, Ph, Pl, LDT, wave * 16, Oh, Ol, LDB, TS, lane, one);   // dV += (P o M)^T dO
+      mma_planeT_acc<NTH, ONE>(dv, Oh, Ol, LDB, pm, lane);     // dV^T += dO^T (P o M)
+      mma_planeT_acc<NTH, ONE>(dk, Qh, Ql, LDB, ds, lane);     // dK^T += Q^T dS
     }
   }
+  if (key < a.T) {
+    float* row = a.dqkv + ((long)key * a.B + b) * 3 * a.D + h * a.hd;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int key = k0 + wave * 16 + 4 * (lane >> 4) + r;
-    if (key >= a.T) continue;
-#pragma unroll
-    for (int j = 0; j < NTH; ++j) {
-      const int c = 16 * j + (lane & 15);
-      if (c < a.hd) {
-        float* row = a.dqkv + ((long)key * a.B + b) * 3 * a.D + h * a.hd + c;
-        row[a.D] = dk[j][r];
-        row[2 * a.D] = dv[j][r];
-      }
+    for (int ct = 0; ct < NTH; ++ct) {
+      store_cols4<VEC>(row + a.D, 16 * ct + 4 * G, a.hd, dk[ct], 1.f);
+      store_cols4<VEC>(row + 2 * a.D, 16 * ct + 4 * G, a.hd, dv[ct], 1.f);
     }
   }
 }
@@ -1623,26 +1708,29 @@ static bool attn_b16_mt_ok(const AttnArgs& a) {
   const char* e = getenv("RD_ATTN_B16_MT");           // read per call (tests compare both paths in one process)
   return !(e && atoi(e) == 0) && precision() != RD_PREC_FP32 && a.T > TS && a.hd <= 96 && !a.plan;
 }
+#define ATTN_LAUNCH_MT(K, grid, lds, arg)                                                                \
+  do {                                                                                                   \
+    if (vec && one) { RD_LDS_ATTR((K<NTH, true, true>), lds); hipLaunchKernelGGL((K<NTH, true, true>), grid, dim3(64 * QW), lds, st, arg); }          \
+    else if (vec) { RD_LDS_ATTR((K<NTH, true, false>), lds); hipLaunchKernelGGL((K<NTH, true, false>), grid, dim3(64 * QW), lds, st, arg); }         \
+    else if (one) { RD_LDS_ATTR((K<NTH, false, true>), lds); hipLaunchKernelGGL((K<NTH, false, true>), grid, dim3(64 * QW), lds, st, arg); }         \
+    else { RD_LDS_ATTR((K<NTH, false, false>), lds); hipLaunchKernelGGL((K<NTH, false, false>), grid, dim3(64 * QW), lds, st, arg); }               \
+  } while (0)
 template <int NTH>
-int launch_attn_b16_mt(const AttnArgs& a_in, int which, hipStream_t st) {
-  const bool vec = attn_vec_ok(a_in);
+int launch_attn_b16_mt(const AttnArgs& a, int which, hipStream_t st) {
+  const bool vec = attn_vec_ok(a);
   constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8;
-  AttnArgs a = a_in;
-  a.stamps = g_attn_stamps;
-  const int one = precision() == RD_PREC_BF16;
-  const dim3 grid(cdiv(a.T, TS), a.B * a.H);
+  const bool one = precision() == RD_PREC_BF16;
+  const dim3 grid(cdiv(a.T, QROWS), a.B * a.H);
+  const size_t planes = (size_t)4 * TS * LDB * sizeof(__bf16);
   if (which == 0) {
-    const size_t lds = (size_t)(6 * TS * LDB + 2 * TS * LDT) * sizeof(__bf16);
-    ATTN_LAUNCH(k_attn_fwd_b16, grid, dim3(256), lds, lds, a, one);
+    ATTN_LAUNCH_MT(k_attn_fwd_b16, grid, planes + TS, a);
     return check_launch("k_attn_fwd_b16");
   }
   if (which == 1) {
-    const size_t lds = (size_t)(8 * TS * LDB + 2 * TS * LDT) * sizeof(__bf16) + 2 * TS * sizeof(float);
-    ATTN_LAUNCH(k_attn_bwd_dq_b16, grid, dim3(256), lds, lds, a, one);
+    ATTN_LAUNCH_MT(k_attn_bwd_dq_b16, grid, planes + TS, a);
     return check_launch("k_attn_bwd_dq_b16");
   }
-  const size_t lds = (size_t)(8 * TS * LDB + 4 * TS * LDT) * sizeof(__bf16) + 2 * TS * sizeof(float);
-  ATTN_LAUNCH(k_attn_bwd_dkv_b16, grid, dim3(256), lds, lds, a, one);
+  ATTN_LAUNCH_MT(k_attn_bwd_dkv_b16, grid, planes + 2 * TS * sizeof(float), a);
   return check_launch("k_attn_bwd_dkv_b16");
 }
 
