@@ -716,10 +716,12 @@ __global__ __launch_bounds__(EF_THR) void k_enc_pre_bwd(PreBwdArgs a) {
   else pre_bwd_body<2, DC, HC>(a, esm, M);
 }
 
-// RD_ENC_SPECIALIZE=0: the P19 widths on the runtime-width instantiation (A/B and the parity test of the two)
-static bool ef_specialize(int D, int H) {
+// Widths compiled in for the two datasets that fit these kernels: 1 = P19 (152, 272), 2 = P12 (160, 288); 0 = runtime widths.
+// RD_ENC_SPECIALIZE=0: always the runtime-width instantiation (A/B and the parity test of the two)
+static int ef_specialize(int D, int H) {
   const char* e = getenv("RD_ENC_SPECIALIZE");
-  return D == 152 && H == 272 && !(e && atoi(e) == 0);
+  if (e && atoi(e) == 0) return 0;
+  return (D == 152 && H == 272) ? 1 : ((D == 160 && H == 288) ? 2 : 0);
 }
 
 constexpr size_t pre_bwd_lds(int rt) {
@@ -765,9 +767,13 @@ int launch_enc_post_fwd(long M, int D, int H, const float* attn, const float* x,
   a.M = (int)M; a.D = D; a.H = H; a.ncu = ef_ncu(); a.p = p; a.seed = seed; a.site_ao = site_ao; a.site_fh = site_fh; a.site_fo = site_fo;
   a.seed_cell = seed_cell(); a.mlive = mlive; a.one = precision() == RD_PREC_BF16; a.stamps = g_ef_stamps;
   constexpr size_t lds = post_fwd_lds(EF_RTMAX);
-  if (ef_specialize(D, H)) {
+  const int spec = ef_specialize(D, H);
+  if (spec == 1) {
     RD_LDS_ATTR((k_enc_post_fwd<152, 272>), lds);
     hipLaunchKernelGGL((k_enc_post_fwd<152, 272>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a);
+  } else if (spec == 2) {
+    RD_LDS_ATTR((k_enc_post_fwd<160, 288>), lds);
+    hipLaunchKernelGGL((k_enc_post_fwd<160, 288>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a);
   } else {
     RD_LDS_ATTR((k_enc_post_fwd<0, 0>), lds);
     hipLaunchKernelGGL((k_enc_post_fwd<0, 0>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a);
@@ -789,9 +795,13 @@ int launch_enc_pre_bwd(long M, int D, int H, const float* dy, const float* s2, c
   a.M = (int)M; a.D = D; a.H = H; a.ncu = ef_ncu(); a.p = p; a.seed = seed; a.site_fo = site_fo; a.site_ao = site_ao;
   a.seed_cell = seed_cell(); a.mlive = mlive; a.one = precision() == RD_PREC_BF16; a.stamps = g_ef_stamps;
   constexpr size_t lds = pre_bwd_lds(EF_RTMAX);
-  if (ef_specialize(D, H)) {
+  const int spec = ef_specialize(D, H);
+  if (spec == 1) {
     RD_LDS_ATTR((k_enc_pre_bwd<152, 272>), lds);
     hipLaunchKernelGGL((k_enc_pre_bwd<152, 272>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a);
+  } else if (spec == 2) {
+    RD_LDS_ATTR((k_enc_pre_bwd<160, 288>), lds);
+    hipLaunchKernelGGL((k_enc_pre_bwd<160, 288>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a);
   } else {
     RD_LDS_ATTR((k_enc_pre_bwd<0, 0>), lds);
     hipLaunchKernelGGL((k_enc_pre_bwd<0, 0>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a);

@@ -457,17 +457,19 @@ def test_multi_tile_attention_split_bf16_matches_fp32_kernels(T, B, F, nhead, p_
         assert _rel(a, b) < tol, (name, _rel(a, b))
 
 
-@pytest.mark.parametrize("T,B,p_drop", [(60, 6, 0.0), (60, 150, 0.2), (60, 256, 0.2), (33, 7, 0.2), (60, 137, 0.0)])
-def test_fused_row_local_chains_match_row_block_products(T, B, p_drop, precision_mode, monkeypatch):
+@pytest.mark.parametrize("T,B,p_drop,F", [(60, 6, 0.0, 34), (60, 150, 0.2, 34), (60, 256, 0.2, 34), (33, 7, 0.2, 34), (60, 137, 0.0, 34),
+                                          (215, 8, 0.2, 36), (40, 45, 0.2, 36), (50, 9, 0.2, 35)])
+def test_fused_row_local_chains_match_row_block_products(T, B, p_drop, F, precision_mode, monkeypatch):
     """rd_encfuse.hip (out_proj + LayerNorm1 + FFN + LayerNorm2 in one launch, and its backward chain) against the three
     row-block launches per direction it replaces, IN THE SAME ARITHMETIC with the same dropout quads (dropout ON): the two paths
     must agree to summation order (LayerNorm row sums; per-block LayerNorm partials: 32- vs 48-row blocks) in the output and
     the gradients.  B = 150 / 137 (9000 / 8220 rows) make the kernels pick their 48-row blocks on a 256-CU device, B = 256
-    (15360 rows) two rounds of 32-row blocks."""
+    (15360 rows) two rounds of 32-row blocks.  F = 34 / 36 are the widths compiled in (P19: 152 x 272, P12: 160 x 288), F = 35
+    runs the runtime-width instantiation."""
     if precision_mode == "fp32":
         pytest.skip("the fused chains are bf16-mode kernels")
     from raindrop_amd import _lib, ops
-    F, nhead = 34, 2
+    nhead = 2
     D, nhid = F * 4 + 16, 2 * F * 4
     rng = np.random.default_rng(T * 7 + B)
     x = torch.from_numpy(rng.standard_normal((T, B, D)).astype(np.float32)).to(DEV)
