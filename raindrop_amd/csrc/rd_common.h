@@ -123,6 +123,9 @@ struct GemmArgs {
   // B + o*b_bo + i*b_bi and writes C + o*c_bo + i*c_bi (two-level strides: sample and head of the [T,B,3D] attention tensors)
   int nbatch, batch_inner; long a_bo, a_bi, b_bo, b_bi, c_bo, c_bi;
   int res_batched;                // batched form: the residual is laid out like C (offset by the problem's C offset)
+  // optional: B (as used: B(n,k), N x K) already split into native operand tiles by launch_wsplit_specs (rows = N, cols = K);
+  // launch_gemm then runs the panel form (k_gemm_panel) when the product qualifies, and ignores B / sb_n / sb_k
+  const void* Btiles; int bt_ntile, bt_nkc;       // tile counts: ceil(N / 16), ceil(K / 32)
 };
 int launch_gemm(const GemmArgs& a, hipStream_t st);
 // split of the reduction length `red` of a [rows x cols] weight-gradient product into nsplit chunks

@@ -290,35 +290,80 @@ struct Stage {
 // planes are dead by now) so that each thread owns 4 consecutive COLUMNS of one row: bias /
 // mask / residual reads and the output stores become 16-byte accesses in 256..640-byte runs, and the
 // Philox dropout mask costs one evaluation per 4 elements.
-template <int MI, int NI>
+template <int MI, int NI, int WY = 2, int WX = 2, int NTHR = 256>   // WY x WX waves hold 16 MI x 16 NI outputs each; NTHR threads store
 __device__ __forceinline__ void epilogue_t(const GemmArgs& g, f32x4 (&acc)[MI][NI], float* stage, const float* bias_s,
-                                           int m0, int n0, int wy, int wx, int z, int tid, int lane) {
-  constexpr int TM = 32 * MI, TN = 32 * NI, LDSG = TN + 4;
+                                           int m0, int n0, int wy, int wx, int z, int tid, int lane, bool writer = true) {
+  constexpr int TM = 16 * MI * WY, TN = 16 * NI * WX, LDSG = TN + 4;
+  if (writer) {
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
+      for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        stage[(wy * 16 * MI + i * 16 + 4 * (lane >> 4) + r) * LDSG + wx * 16 * NI + j * 16 + (lane & 15)] = acc[i][j][r];
+        for (int r = 0; r < 4; ++r)
+          stage[(wy * 16 * MI + i * 16 + 4 * (lane >> 4) + r) * LDSG + wx * 16 * NI + j * 16 + (lane & 15)] = acc[i][j][r];
+  }
   __syncthreads();
   float* Cz = g.C + (long)z * g.sc_split;
   const bool raw = g.nsplit > 1;
   const bool vec = ((g.N & 3) == 0) && ((g.sc_m & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cz) & 15) == 0) &&
                    !g.scatter && (!g.posmask || (((g.pm_m & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.posmask) & 15) == 0))) &&
                    (!g.residual || (((g.res_m & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.residual) & 15) == 0)));
+  const bool svec = g.scatter && g.sd == 4 && ((g.N & 3) == 0) && ((g.ldz & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
   const float inv_keep = 1.0f / (1.0f - g.drop_p);
   constexpr int QPR = TN / 4;                         // column quads per tile row
-  constexpr int ITER = TM * QPR / 256;
+  constexpr int ITER = TM * QPR / NTHR;
+  // Straight path for the common epilogues (bias, ReLU, row scale, gate mask, constant scale; 16-byte rows or the d_ob = 4
+  // scatter): every global read -- row scales included -- is requested in one unbranched pass before the first is used.  The
+  // general loop below interleaves loads, flag tests and stores per iteration; measured 11 k cycles per 64 x 128 tile against
+  // a 25 k-cycle main loop in the panel kernel.
+  if (!raw && (vec || (svec && !g.posmask)) && !g.residual && !(g.drop_p > 0.f)) {
+    float rsc[ITER]; float4 pm[ITER]; int bq[ITER], fq[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int e = tid + it * NTHR;
+      const int rl = e / QPR, q = e - rl * QPR;
+      const int mc = min(m0 + rl, g.M - 1), nc = min(n0 + 4 * q, g.N - 4);        // clamped: always legal addresses
+      rsc[it] = g.rowscale ? g.rowscale[mc % g.rs_period] : 1.f;
+      pm[it] = g.posmask ? *reinterpret_cast<const float4*>(g.posmask + (long)mc * g.pm_m + nc) : make_float4(1.f, 1.f, 1.f, 1.f);
+      bq[it] = 0; fq[it] = 0;
+      if (svec) { bq[it] = mc / g.sF; fq[it] = mc - bq[it] * g.sF; }
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int e = tid + it * NTHR;
+      const int rl = e / QPR, q = e - rl * QPR;
+      const int m = m0 + rl, n = n0 + 4 * q;
+      if (m >= g.M || n >= g.N) continue;
+      const float4 a4 = *reinterpret_cast<const float4*>(stage + rl * LDSG + 4 * q);
+      float v[4] = {a4.x, a4.y, a4.z, a4.w};
+      const float pmv[4] = {pm[it].x, pm[it].y, pm[it].z, pm[it].w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float x = v[c];
+        if (g.bias) x += bias_s[4 * q + c];
+        if (g.relu) x = fmaxf(x, 0.f);
+        x *= rsc[it];
+        if (g.posmask) x = (pmv[c] > 0.f) ? x : 0.f;
+        if (g.cscale != 0.f) x *= g.cscale;
+        v[c] = x;
+      }
+      float* dst = svec ? g.C + ((long)(n >> 2) * g.sB + bq[it]) * g.ldz + fq[it] * 4 : Cz + (long)m * g.sc_m + n;
+      *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    return;
+  }
   // every global read of the epilogue (mask / residual) is issued before any of them is consumed:
   // one memory round trip for the whole tile instead of one per row group
   float4 pm4[ITER], rs4[ITER];
-#pragma unroll
+  float rsc_r[ITER];                                  // row scale of each of this thread's rows (a load per row inside the
+#pragma unroll                                        // store loop below was one dependent round trip per iteration)
   for (int it = 0; it < ITER; ++it) {
-    const int e = tid + it * 256;
+    const int e = tid + it * NTHR;
     const int rl = e / QPR, q = e - rl * QPR;
     const int m = m0 + rl, n = n0 + 4 * q;
     pm4[it] = make_float4(1.f, 1.f, 1.f, 1.f); rs4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    rsc_r[it] = (!raw && g.rowscale && m < g.M) ? g.rowscale[m % g.rs_period] : 1.f;
     if (!raw && m < g.M && n < g.N) {
       if (g.posmask) {
         if (vec) pm4[it] = *reinterpret_cast<const float4*>(g.posmask + (long)m * g.pm_m + n);
@@ -340,7 +385,7 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, f32x4 (&acc)[MI][N
   }
 #pragma unroll
   for (int it = 0; it < ITER; ++it) {
-    const int e = tid + it * 256;
+    const int e = tid + it * NTHR;
     const int rl = e / QPR, q = e - rl * QPR;
     const int m = m0 + rl, n = n0 + 4 * q;
     if (m >= g.M || n >= g.N) continue;
@@ -348,7 +393,7 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, f32x4 (&acc)[MI][N
     float v[4] = {a4.x, a4.y, a4.z, a4.w};
     const int nv = min(4, g.N - n);
     if (!raw) {
-      const float rsc = g.rowscale ? g.rowscale[m % g.rs_period] : 1.f;
+      const float rsc = rsc_r[it];
       float4 du = make_float4(1.f, 1.f, 1.f, 1.f);
       if (g.drop_p > 0.f) {
         if (vec) {
@@ -379,6 +424,10 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, f32x4 (&acc)[MI][N
     }
     if (g.scatter && !raw) {
       const int b = m / g.sF, f = m - b * g.sF;
+      if (svec) {                                     // d_ob = 4: the column quad is one (t, b, f) cell of z
+        *reinterpret_cast<float4*>(g.C + ((long)(n >> 2) * g.sB + b) * g.ldz + f * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        continue;
+      }
       for (int c = 0; c < nv; ++c) {
         const int t = (n + c) / g.sd, cc = (n + c) - t * g.sd;
         g.C[((long)t * g.sB + b) * g.ldz + f * g.sd + cc] = v[c];
@@ -610,6 +659,167 @@ int launch_bf16x3(const GemmArgs& g, hipStream_t st) {
   return launch_bf16x3_n<A_KC, B_KC, MI, NI, 0>(g, st);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Panel product: C = epilogue(A W'), A [M,K] k-contiguous fp32, W' given as NATIVE operand tiles (k_wsplit, rd_rowgemm.hip:
+// [n tile][k tile][hi, lo][64 lanes][8] -- a B fragment is one contiguous KB per wave, straight from L2 into registers, no
+// LDS, no conversion).  Built for the square products of the unfused message passing (K = N = T d_ob: 860 at P12, 2400 at
+// PAM), where k_gemm_bf16x3 converts BOTH operands through LDS every 64 k with two barriers around 24 MFMAs per wave.
+// Here: workgroup = 64 rows x 64 NJ columns; four waves side by side (each: all 64 rows x 16 NJ columns, 12 RT NJ MFMAs per
+// 32 k) -- twice: a second group of four waves takes the odd 64-k chunks (split K inside the workgroup: with ~1 workgroup per CU
+// that is the second wave per SIMD that overlaps one group's loads and conversions with the other's products) and hands its
+// accumulators over through LDS at the end.  Only A is staged (hi/lo planes, double buffered per group: ONE LDS-only barrier per
+// round), the next chunk of A and of the weight fragments is in flight during the products.  Same epilogue as the tiled kernel (bias, ReLU, row scale, masks,
+// dropout, residual, the [T,B,ldz] scatter), same XCD-aware tile order.
+// ------------------------------------------------------------------------------------------------
+template <int NJ>
+__global__ __launch_bounds__(512) void k_gemm_panel(GemmArgs g) {
+  constexpr int RT = 4, TM = 16 * RT, TN = 64 * NJ, PLANE = TM * LDB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+  __bf16* Pb = reinterpret_cast<__bf16*>(gsm);                  // [2 groups][2 buffers][hi, lo][TM][LDB]
+  constexpr size_t PLANES_B = (size_t)8 * PLANE * sizeof(__bf16), STAGE_B = (size_t)TM * (TN + 4) * sizeof(float);
+  constexpr size_t RED_B = (size_t)4 * RT * NJ * 4 * 64 * sizeof(float);
+  static_assert(STAGE_B + RED_B <= PLANES_B, "epilogue stage + group-1 accumulators must fit the dead planes");
+  float* red = reinterpret_cast<float*>(gsm + STAGE_B);         // group 1's accumulators, lane for lane
+  float* bias_s = reinterpret_cast<float*>(gsm + PLANES_B);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2, wv = wave & 3, gt = tid & 255;     // two groups of four waves: even / odd 64-k chunks
+  // XCD-aware AND balanced tile order: workgroup ids round-robin over the 8 XCDs (own L2 each); XCD x takes the contiguous
+  // run [x per, (x+1) per) of the row-major tile list, per = ceil(tiles / 8).  The column blocks of one A row block then share
+  // an L2 (a row block is cut between two XCDs at most once) and no XCD gets more than `per` tiles: with whole row blocks per
+  // XCD (the tiled kernel's order) P12's 36 x 7 tiles came out as 35 / 28 per XCD of 32 CUs -- a second round for 3 tiles.
+  const int ncb = (g.N + TN - 1) / TN, tiles = ncb * ((g.M + TM - 1) / TM), per = (tiles + 7) / 8;
+  const int lin = g.xcd_swizzle ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (lin >= tiles || (g.xcd_swizzle && (int)(blockIdx.x >> 3) >= per)) return;
+  const int rblk = lin / ncb, cblk = lin - rblk * ncb;
+  const int m0 = rblk * TM, n0 = cblk * TN;
+#define PSTAMP(i)                                                                                                   \
+  do {                                                                                                              \
+    if (g.stamps && threadIdx.x == 0 && (blockIdx.x * 8) / gridDim.x != ((blockIdx.x - 1) * 8) / gridDim.x)         \
+      g.stamps[((blockIdx.x * 8) / gridDim.x) * 8 + (i)] = clock64();                                                \
+  } while (0)
+  PSTAMP(0);
+  const int nkc = g.bt_nkc;
+  const __bf16* Bt = reinterpret_cast<const __bf16*>(g.Btiles);
+  size_t toff[NJ];
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) toff[jj] = (size_t)min(n0 / 16 + wv * NJ + jj, g.bt_ntile - 1) * nkc * 1024 + lane * 8;
+  using SA = Stage<true, TM>;
+  float ra[SA::NREG]; unsigned long long oka;
+  const int nch = (g.K + BK2 - 1) / BK2;
+  const int niter = (nch + 1) / 2;                    // both groups run the same number of rounds (the barriers are shared)
+  f32x4 acc[RT][NJ];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  struct BFr { bf16x8 h[NJ][2], l[NJ][2]; };
+  // Every look-ahead load is UNCONDITIONAL (past the end: the last chunk again, with the A rows masked to zero): behind a
+  // branch, the compiler's wait-count bookkeeping has to assume the path that issued nothing, and then waits for the NEWEST
+  // loads -- the ones just requested -- before the products on the current fragments.
+  auto load_b = [&](BFr& b, int c) {
+    const int cc = min(c, nch - 1);
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const __bf16* t = Bt + toff[jj] + (size_t)min(2 * cc + ks, nkc - 1) * 1024;
+        b.h[jj][ks] = *reinterpret_cast<const bf16x8*>(t);
+        b.l[jj][ks] = *reinterpret_cast<const bf16x8*>(t + 512);
+      }
+  };
+  auto load_a = [&](int c) {
+    SA::load(ra, oka, g.A, g.sa_m, 1, m0, g.M, min(c, nch - 1) * BK2, g.K, gt, true);
+    if (c >= nch) oka = 0ull;                         // no such chunk: the planes get zeros
+  };
+  const int aoff = (lane & 15) * LDB + 8 * (lane >> 4);
+  auto products = [&](const __bf16* Ah, const __bf16* Al, const BFr& b, auto three_tag) {
+    constexpr bool THREE = decltype(three_tag)::value;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ah[RT], al[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * LDB + aoff + ks * 32);
+        if (THREE) al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * LDB + aoff + ks * 32);
+      }
+      if (THREE) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) acc[rt][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], b.h[jj][ks], acc[rt][jj], 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) acc[rt][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], b.l[jj][ks], acc[rt][jj], 0, 0, 0);
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) acc[rt][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], b.h[jj][ks], acc[rt][jj], 0, 0, 0);
+    }
+  };
+  __bf16* Pg = Pb + (size_t)grp * 4 * PLANE;          // this group's two buffers
+  // round i: the group's chunk 2 i + grp on buffer i & 1 with fragments `cur`; the chunk of round i+1 arrives meanwhile
+  auto step = [&](int i, const BFr& cur, BFr& nxt) {
+    __bf16* Ah = Pg + (size_t)(i & 1) * 2 * PLANE;
+    load_b(nxt, 2 * (i + 1) + grp);
+    if (!g.one_product) products(Ah, Ah + PLANE, cur, std::true_type{});
+    else products(Ah, Ah + PLANE, cur, std::false_type{});
+    __bf16* Nh = Pg + (size_t)((i + 1) & 1) * 2 * PLANE;
+    SA::store(ra, oka, Nh, Nh + PLANE, gt);           // round i+1's chunk
+    load_a(2 * (i + 2) + grp);
+    lds_barrier();                                    // buffer i & 1 is free for round i+2; buffer (i+1) & 1 is complete
+  };
+  BFr b0, b1;
+  load_a(grp);
+  load_b(b0, grp);
+  if (tid < TN) bias_s[tid] = (g.bias && n0 + tid < g.N) ? g.bias[n0 + tid] : 0.f;
+  SA::store(ra, oka, Pg, Pg + PLANE, gt);
+  load_a(2 + grp);
+  lds_barrier();
+  PSTAMP(1);
+  int i = 0;
+  for (; i + 1 < niter; i += 2) { step(i, b0, b1); step(i + 1, b1, b0); }
+  if (i < niter) step(i, b0, b1);
+  PSTAMP(2);
+  // group 1 hands its accumulators over, lane for lane; group 0 adds them (fixed order) and owns the epilogue's stage writes
+  if (grp == 1) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+        *reinterpret_cast<f32x4*>(red + ((((size_t)wv * RT + rt) * NJ + jj) * 64 + lane) * 4) = acc[rt][jj];
+  }
+  lds_barrier();
+  if (grp == 0) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(red + ((((size_t)wv * RT + rt) * NJ + jj) * 64 + lane) * 4);
+        acc[rt][jj] += o;
+      }
+  }
+  epilogue_t<RT, NJ, 1, 4, 512>(g, acc, reinterpret_cast<float*>(gsm), bias_s, m0, n0, 0, wv, 0, tid, lane, grp == 0);
+  PSTAMP(3);
+#undef PSTAMP
+}
+
+// the panel form applies: pre-split weight tiles given, A k-contiguous with 16-byte rows, one plain pass
+static bool panel_ok(const GemmArgs& g) {
+  static const bool on = [] { const char* e = getenv("RD_GEMM_PANEL"); return !(e && atoi(e) == 0); }();
+  return on && g.Btiles && g.sa_k == 1 && (g.sa_m & 3) == 0 && (reinterpret_cast<uintptr_t>(g.A) & 15) == 0 && g.nsplit <= 1 &&
+         g.nbatch <= 1 && !g.A2 && !g.rowsum && g.K >= 64;
+}
+static int launch_panel(const GemmArgs& g, hipStream_t st) {
+  constexpr int NJ = 2, TM = 64, TN = 64 * NJ;
+  const size_t lds = (size_t)8 * TM * LDB * sizeof(__bf16) + TN * sizeof(float);      // planes (stage and hand-over alias them) + bias
+  const dim3 grid(8 * cdiv(cdiv(g.M, TM) * cdiv(g.N, TN), 8));
+  RD_LDS_ATTR((k_gemm_panel<NJ>), lds);
+  hipLaunchKernelGGL((k_gemm_panel<NJ>), grid, dim3(512), lds, st, g);
+  return check_launch("k_gemm_panel");
+}
+
 // padded work / tile efficiency: bigger tiles re-read less and amortise the barrier, but waste
 // more on ragged edges; pick the cheapest legal (MI, NI).
 template <bool A_KC, bool B_KC>
@@ -739,6 +949,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     static const int sx_env = [] { const char* e = getenv("RD_SPLITK_XCD"); return e ? atoi(e) : 1; }();
     g.slice_xcd = (g.nsplit > 1 && sx_env) ? 1 : 0;
     if (g.nsplit > 1 && (g.k_per_split % BK2) != 0) return fail(RD_EINVAL, "gemm: k_per_split must be a multiple of 64");
+    if (panel_ok(g)) return launch_panel(g, st);
     if (akc && bkc) return dispatch_bf16x3<true, true>(g, st);
     if (akc && !bkc) return dispatch_bf16x3<true, false>(g, st);
     if (!akc && bkc) return dispatch_bf16x3<false, true>(g, st);

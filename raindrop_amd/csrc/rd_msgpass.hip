@@ -152,7 +152,9 @@ MsgWs carve(const rd_shape* s, void* base) {
   return w;
 }
 
-struct MsgSaved { float *xsave, *y1save; size_t bytes; };
+// wt: W1, W2, W2^T, W1^T as native operand tiles (k_wsplit; bf16 modes): the B operands of the two forward products and of the two
+// input-gradient products (launch_gemm's panel form), written once by the forward and kept for the backward
+struct MsgSaved { float *xsave, *y1save; void* wt[4]; int ntile, nkc; size_t bytes; };
 MsgSaved carve_saved(const rd_shape* s, void* base) {
   const size_t M = (size_t)s->B * s->F, K = (size_t)s->T * s->d_ob;
   MsgSaved v; size_t off = 0;
@@ -160,6 +162,9 @@ MsgSaved carve_saved(const rd_shape* s, void* base) {
                                   off += align_up(bytes, 256); return p; };
   v.xsave = (float*)take(M * K * sizeof(float));
   v.y1save = (float*)take(M * K * sizeof(float));
+  const size_t plane = ((K + 15) / 16 * 16) * ((K + 31) / 32 * 32);                    // elements of one plane (rd_rowgemm.hip: k_wsplit)
+  for (int i = 0; i < 4; ++i) v.wt[i] = take(2 * plane * 2);                           // hi + lo, bf16
+  v.ntile = ((int)K + 15) / 16; v.nkc = ((int)K + 31) / 32;
   v.bytes = off;
   return v;
 }
@@ -257,14 +262,21 @@ extern "C" int rd_msgpass_fwd(const rd_shape* s, const float* src, const float* 
                        p_drop, seed, seed_cell());
     if ((rc = check_launch("k_obs_embed"))) return rc;
   }
+  const bool tiles = precision() != RD_PREC_FP32;      // the split weights feed the panel form of launch_gemm (bf16 modes)
+  if (tiles) {
+    const WsplitSpec specs[4] = {{W1, K, K, 0, v.wt[0]}, {W2, K, K, 0, v.wt[1]}, {W2, K, K, 1, v.wt[2]}, {W1, K, K, 1, v.wt[3]}};
+    if ((rc = launch_wsplit_specs(4, specs, 0, nullptr, st))) return rc;
+  }
   GemmArgs g{};
   g.M = M; g.N = K; g.K = K; g.nsplit = 1;
   g.A = xsave; g.sa_m = K; g.sa_k = 1;
   g.B = W1; g.sb_n = K; g.sb_k = 1;
+  if (tiles) { g.Btiles = v.wt[0]; g.bt_ntile = v.ntile; g.bt_nkc = v.nkc; }
   g.C = y1save; g.sc_m = K;
   g.bias = b1; g.relu = 1; g.rowscale = ssum; g.rs_period = F;
   if ((rc = launch_gemm(g, st))) return rc;
   g.A = y1save; g.B = W2; g.bias = b2;
+  if (tiles) g.Btiles = v.wt[1];
   g.C = z; g.scatter = 1; g.sB = B; g.sF = F; g.sd = d; g.ldz = ldz;
   return launch_gemm(g, st);
 }
@@ -388,6 +400,8 @@ extern "C" int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* 
   g.M = M; g.N = K; g.K = K; g.nsplit = 1;
   g.A = w.dz2; g.sa_m = K; g.sa_k = 1;
   g.B = W2; g.sb_n = 1; g.sb_k = K;          // B(n=k_out, k=n_red) = W2[n_red*K + k_out]
+  const bool tiles = precision() != RD_PREC_FP32;     // W2^T / W1^T tiles written by the forward
+  if (tiles) { g.Btiles = sv.wt[2]; g.bt_ntile = sv.ntile; g.bt_nkc = sv.nkc; }
   g.C = w.dz1; g.sc_m = K;
   g.rowscale = ssum; g.rs_period = F; g.posmask = y1save; g.pm_m = K;
   if ((rc = launch_gemm(g, st))) return rc;
@@ -396,6 +410,7 @@ extern "C" int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* 
   h.M = M; h.N = K; h.K = K; h.nsplit = 1;
   h.A = w.dz1; h.sa_m = K; h.sa_k = 1;
   h.B = W1; h.sb_n = 1; h.sb_k = K;
+  if (tiles) { h.Btiles = sv.wt[3]; h.bt_ntile = sv.ntile; h.bt_nkc = sv.nkc; }
   h.C = w.dx; h.sc_m = K;
   if ((rc = launch_gemm(h, st))) return rc;
   hipLaunchKernelGGL(k_obs_embed_bwd, dim3((unsigned)(((long)B * F + 3) / 4)), dim3(256), 0, st, w.dx, xsave, src, w.rupart, B, T, F, d,
