@@ -44,11 +44,14 @@ struct Panel { bf16x8 h[KC], l[KC]; };
 
 // native operand tiles [tile j][kc][hi, lo][64 lanes][8] (k_wsplit, rd_rowgemm.hip); reduction steps [KC0, KC1) of tile j
 // (a long panel is requested in two halves to bound the registers in flight)
-template <int KC, int KC0 = 0, int KC1 = KC>
+// ALL: every wave is known to own a tile (the nhid-wide products: nhid > 256 = 16 tiles, encfuse_ok) -- no test.  The test is
+// a branch around the loads, and behind a branch the compiler's wait-count bookkeeping assumes the path that requested nothing:
+// the LayerNorm epilogue that runs under the streaming panel then waited (vmcnt(0)) for the panel instead of its own, older rows.
+template <int KC, int KC0 = 0, int KC1 = KC, bool ALL = false>
 __device__ __forceinline__ void load_panel(Panel<KC>& p, const __bf16* __restrict__ Wt, int ntiles, int j, int lane) {
   // a wave without a column tile requests nothing (wave-uniform): 6 of the 16 waves have none in the D-wide products, and their
   // 10-18 KB of loads each only lengthened the address unit's queue in front of everybody's stores
-  if (__builtin_amdgcn_readfirstlane(j) >= ntiles) return;
+  if (!ALL && __builtin_amdgcn_readfirstlane(j) >= ntiles) return;
   const __bf16* t = Wt + (size_t)j * (KC * 2 * 512) + lane * 8;
 #pragma unroll
   for (int kc = KC0; kc < KC1; ++kc) {
@@ -362,7 +365,7 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
   lds_barrier();                                               // stage complete; every wave is done reading the attn planes
   EFSTAMP(4);
   Panel<KCD> p1;                                               // linear1 (column tiles 0..15) streams in under the LayerNorm epilogue
-  load_panel<KCD>(p1, a.W1, ntH, wave, lane);                  // (requested BEHIND the barrier: issuing it blocks a wave for a while)
+  load_panel<KCD, 0, KCD, true>(p1, a.W1, ntH, wave, lane);    // (requested BEHIND the barrier: issuing it blocks a wave for a while)
   // ---- + bias, dropout, + x, LayerNorm1 -> s1, x1 (global), x1 planes ----
   if (lnw) ln_rows4(stage, xr, cst, cst + KPD, cst + 2 * KPD, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_ao, a.s1, a.x1, a.st1, Ah, Al);
   EFSTAMP(5);
@@ -374,13 +377,20 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
   {
     f32x4 acc[RT];
     mma<KCD, RT>(acc, Ah, Al, LDD, p1, lane, a.one);
-    if (wave < ntH) to_stage<RT>(stage, acc, wave, lane);
-    for (int t0 = EF_WV; t0 < ntH; t0 += EF_WV) {              // nhid > 256: the remaining column tiles (P19: tile 16, wave 0)
-      if (t0 + wave < ntH) {                                   // wave-uniform
-        load_panel<KCD>(p1, a.W1, ntH, t0 + wave, lane);
-        mma<KCD, RT>(acc, Ah, Al, LDD, p1, lane, a.one);
-        to_stage<RT>(stage, acc, t0 + wave, lane);
-      }
+    // nhid > 256: the remaining column tiles (P19: tile 16, wave 0 -- the other 15 waves wait for it at the barrier).  Its panel
+    // goes into the registers the first product has just released, as ONE batch of requests in front of the stage writes: left
+    // to itself the compiler trickled the ten loads in between the first product's MFMAs, each with its own vmcnt(0) in front
+    // of the second product -- six dependent round trips on the workgroup's critical path.
+    for (int t0 = EF_WV; t0 < ntH + EF_WV; t0 += EF_WV) {
+      const bool more = t0 + wave < ntH;                       // wave-uniform
+      f32x4 prev[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) prev[rt] = acc[rt];
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) load_panel<KCD>(p1, a.W1, ntH, t0 + wave, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t0 - EF_WV + wave < ntH) to_stage<RT>(stage, prev, t0 - EF_WV + wave, lane);
+      if (more) mma<KCD, RT>(acc, Ah, Al, LDD, p1, lane, a.one);
     }
   }
   EFSTAMP(7);
@@ -567,7 +577,7 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   if (lnw) { ln_load3(sq, a.s2, D, m0, M, wave, lane); ln_load3(dyq, a.dy, D, m0, M, wave, lane); }
   load_stats(a.st2);
   Panel<KCD> pw;
-  load_panel<KCD>(pw, a.W2t, ntH, wave, lane);
+  load_panel<KCD, 0, KCD, true>(pw, a.W2t, ntH, wave, lane);
   __builtin_amdgcn_sched_barrier(0);
   if (a.seed_cell) seed += load_uniform_u64(a.seed_cell);
   lds_barrier();                                               // cst visible
@@ -582,8 +592,9 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   for (int it = 0; it < HIT; ++it) {
     const int e = tid + it * EF_THR;
     const int rl = e / hq, q = e - rl * hq;
-    hv[it] = zero4;
-    if (rl < ROWS && m0 + rl < M && 4 * q < H) hv[it] = *reinterpret_cast<const float4*>(a.h + (long)(m0 + rl) * H + 4 * q);
+    // UNCONDITIONAL from a clamped address (rows >= M have a zero gradient in the stage, columns >= H and rows >= ROWS are not
+    // consumed): a conditional load is a phi of {0, value} and the compiler waited for each one right behind its request
+    hv[it] = *reinterpret_cast<const float4*>(a.h + (long)min(m0 + min(rl, ROWS - 1), M - 1) * H + min(4 * q, H - 4));
   }
   EFSTAMP(2);
   lds_barrier();
@@ -600,13 +611,16 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   {
     f32x4 acc[RT];
     mma<KCD, RT>(acc, Ah, Al, LDD, pw, lane, a.one);
-    if (wave < ntH) to_stage<RT>(stage, acc, wave, lane);
-    for (int t0 = EF_WV; t0 < ntH; t0 += EF_WV) {
-      if (t0 + wave < ntH) {
-        load_panel<KCD>(pw, a.W2t, ntH, t0 + wave, lane);
-        mma<KCD, RT>(acc, Ah, Al, LDD, pw, lane, a.one);
-        to_stage<RT>(stage, acc, t0 + wave, lane);
-      }
+    for (int t0 = EF_WV; t0 < ntH + EF_WV; t0 += EF_WV) {       // second-round tiles: one batch of requests, see the forward chain
+      const bool more = t0 + wave < ntH;                       // wave-uniform
+      f32x4 prev[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) prev[rt] = acc[rt];
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) load_panel<KCD>(pw, a.W2t, ntH, t0 + wave, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t0 - EF_WV + wave < ntH) to_stage<RT>(stage, prev, t0 - EF_WV + wave, lane);
+      if (more) mma<KCD, RT>(acc, Ah, Al, LDD, pw, lane, a.one);
     }
   }
   EFSTAMP(4);
