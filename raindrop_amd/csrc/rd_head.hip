@@ -49,29 +49,46 @@ __device__ __forceinline__ HeadRows head_rows(const HeadArgs& a, int b) {
   return h;
 }
 
+// the same for a workgroup-uniform sample, through the scalar cache: the two dependent plan look-ups do not queue behind the
+// 64 W0 loads per lane that were requested just before (vector memory returns in order)
+__device__ __forceinline__ int load_uniform_i32(const int32_t* p) {
+  int v;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ HeadRows head_rows_uniform(const HeadArgs& a, int b) {
+  HeadRows h;
+  if (a.plan) {
+    const int rk = load_uniform_i32(a.plan + plan::rank_base(a.B) + b);
+    h.row0 = load_uniform_i32(a.plan + plan::off_base() + rk); h.rstep = 1; h.Tv = load_uniform_i32(a.plan + plan::len_base(a.B) + rk);
+  } else { h.row0 = b; h.rstep = a.B; h.Tv = a.T; }
+  return h;
+}
+
 __device__ __forceinline__ float wsum64(float v) { return wave_sum64_dpp(v); }
 
 template <int RB>
 __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
   __shared__ __attribute__((aligned(16))) float feat[RB][HR_LD], hid[RB][HR_LD], dhid[RB][HR_LD], dfeat[RB][HR_LD];
   __shared__ __attribute__((aligned(16))) float red[HR_WAVES * RB * HR_LD];     // mean-phase and wave partials
-  __shared__ float lg[RB][16], dl[RB][16], invl[RB];
+  __shared__ float lg[RB][16], dl[RB][16], invl[RB], b0s[HR_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b0 = blockIdx.x * RB;
   const int T = a.T, B = a.B, D = a.D, dh = a.dh, C = a.C, D4 = D >> 2;
 
   // ---- W0 rows of this wave -> registers (requested first: they are needed after the masked mean) ----
+  // UNCONDITIONAL loads from clamped addresses: rows j >= dh are never used (wave-uniform tests below) and columns k >= dh only
+  // reach accumulator slots nobody reads.  As conditional loads (a phi of {0, value} each) the compiler waited for them one
+  // group at a time -- two dozen dependent round trips at the head of a kernel whose 256 workgroups all run at once, so its
+  // duration IS one workgroup's latency chain.
   float w[HR_RJ][HR_KI];
 #pragma unroll
   for (int jj = 0; jj < HR_RJ; ++jj) {
-    const int j = wave + HR_WAVES * jj;
+    const int jc = min(wave + HR_WAVES * jj, dh - 1);
 #pragma unroll
-    for (int i = 0; i < HR_KI; ++i) {
-      const int k = lane + 64 * i;
-      w[jj][i] = 0.f;
-      if (j < dh && k < dh) w[jj][i] = a.w0[(long)j * dh + k];
-    }
+    for (int i = 0; i < HR_KI; ++i) w[jj][i] = a.w0[(long)jc * dh + min(lane + 64 * i, dh - 1)];
   }
+  if (tid < HR_LD) b0s[tid] = a.b0[min(tid, dh - 1)];    // the first layer's bias -> LDS (was a dependent load per output row)
   // ---- masked mean: thread = (sample r, column quad c4, time group tg) ----
   const int P = RB * D4;
   const int ntg = min(HR_THR / P, 16);
@@ -80,12 +97,21 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
     const int r = pair / D4, c4 = pair - r * D4, b = b0 + r;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tg < ntg && b < B) {
-      const HeadRows hr = head_rows(a, b);
-      for (int t = tg; t < hr.Tv; t += ntg)
-        if (a.plan || !a.mask[(long)b * T + t]) {
-          const float4 v = *reinterpret_cast<const float4*>(a.r + (hr.row0 + (long)t * hr.rstep) * D + 4 * c4);
-          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      const HeadRows hr = RB == 1 ? head_rows_uniform(a, __builtin_amdgcn_readfirstlane(b)) : head_rows(a, b);
+      // four steps per pass, requested together (clamped rows, the step's validity applied to the value): one round trip per
+      // pass instead of one per step
+      for (int t0 = tg; t0 < hr.Tv; t0 += 4 * ntg) {
+        float4 v[4]; bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = t0 + u * ntg, tc = min(t, hr.Tv - 1);
+          ok[u] = t < hr.Tv && (a.plan || !a.mask[(long)b * T + tc]);
+          v[u] = *reinterpret_cast<const float4*>(a.r + (hr.row0 + (long)tc * hr.rstep) * D + 4 * c4);
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (ok[u]) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+      }
     }
     if (tg < ntg) *reinterpret_cast<float4*>(red + ((size_t)tg * P + pair) * 4) = s;
     if (tid < RB) invl[tid] = (b0 + tid < B) ? 1.0f / (float)(a.lengths[b0 + tid] + 1) : 0.f;
@@ -124,7 +150,7 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
           if (k < dh) p += feat[r][k] * w[jj][i];
         }
         p = wsum64(p);
-        if (lane == 0) hid[r][j] = fmaxf(p + a.b0[j], 0.f);
+        if (lane == 0) hid[r][j] = fmaxf(p + b0s[j], 0.f);
       }
     }
   }
@@ -213,11 +239,13 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
   }
   __syncthreads();
   // ---- masked mean backward: dr[t,b,:] = valid ? dfeat[b,:D] / (len + 1) : 0   (code/models_rd.py:379, autograd) ----
+  HeadRows hr1{};                                                        // RB == 1: the workgroup's one sample, looked up once
+  if (RB == 1 && b0 < B) hr1 = head_rows_uniform(a, b0);
   for (int e = tid; e < RB * T * D4; e += HR_THR) {
     const int c4 = e % D4, rt = e / D4;
     const int t = rt % T, r = rt / T, b = b0 + r;
     if (b >= B) continue;
-    const HeadRows hr = head_rows(a, b);
+    const HeadRows hr = RB == 1 ? hr1 : head_rows(a, b);
     if (t >= hr.Tv) continue;                                           // token plan: padded steps have no row
     const float il = (!a.plan && a.mask[(long)b * T + t]) ? 0.f : invl[r];
     const float4 v = *reinterpret_cast<const float4*>(&dfeat[r][4 * c4]);
