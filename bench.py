@@ -31,8 +31,8 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ARITH = {
     "bf16x3": "fp32 tensors everywhere; dense contractions as split-bf16 (hi+lo, 3 products) on v_mfma_f32_16x16x32_bf16 with "
               "fp32 accumulation (~2^-16 per product; logits within 1e-4 of the fp32 reference, tests/test_gpu_parity.py); "
-              "the attention contractions too when a sample is one tile (T <= 64: P19) or the head is wide (> 96: SYN256), exact-fp32 "
-              "MFMA for the multi-tile online-softmax kernels (P12, PAM); softmax, LayerNorm, the classifier head and all "
+              "the attention contractions too (one tile, T <= 64: P19; multi-tile with the scores chained in registers: P12, PAM; "
+              "materialised scores for wide heads > 96: SYN256); softmax, LayerNorm, the classifier head and all "
               "reductions in fp32 (RD_PRECISION=fp32 switches every contraction to the exact-fp32 MFMA)",
     "fp32": "fp32 everywhere: dense contractions on v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain)",
     "bf16": "fp32 tensors in HBM; dense contractions with operands rounded to bf16, ONE product per step on "

@@ -68,6 +68,18 @@ __device__ __forceinline__ uint64_t load_uniform_u64(const uint64_t* p) {
   return v;
 }
 
+// uniform 32-bit load through the scalar cache (token-plan look-ups of a workgroup's sample)
+__device__ __forceinline__ int load_uniform_i32(const int32_t* p) {
+  int v;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
+
+// two independent uniform loads, one wait
+__device__ __forceinline__ void load_uniform_2xi32(const int32_t* p, const int32_t* q, int& x, int& y) {
+  asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(x), "=&s"(y) : "s"(p), "s"(q) : "memory");
+}
+
 // Sum over the 64 lanes of a wavefront on the DPP path, result uniform (every lane gets it).  row_shr 1/2/4/8 leave each
 // 16-lane row's total in its last lane, row_bcast15 / row_bcast31 carry the totals up to lane 63, v_readlane makes it
 // uniform: six VALU instructions with DPP modifiers instead of six LDS-crossbar round trips (`__shfl_xor` compiles to

@@ -51,16 +51,13 @@ __device__ __forceinline__ HeadRows head_rows(const HeadArgs& a, int b) {
 
 // the same for a workgroup-uniform sample, through the scalar cache: the two dependent plan look-ups do not queue behind the
 // 64 W0 loads per lane that were requested just before (vector memory returns in order)
-__device__ __forceinline__ int load_uniform_i32(const int32_t* p) {
-  int v;
-  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
-  return v;
-}
 __device__ __forceinline__ HeadRows head_rows_uniform(const HeadArgs& a, int b) {
   HeadRows h;
   if (a.plan) {
     const int rk = load_uniform_i32(a.plan + plan::rank_base(a.B) + b);
-    h.row0 = load_uniform_i32(a.plan + plan::off_base() + rk); h.rstep = 1; h.Tv = load_uniform_i32(a.plan + plan::len_base(a.B) + rk);
+    int row0, tv;
+    load_uniform_2xi32(a.plan + plan::off_base() + rk, a.plan + plan::len_base(a.B) + rk, row0, tv);
+    h.row0 = row0; h.rstep = 1; h.Tv = tv;
   } else { h.row0 = b; h.rstep = a.B; h.Tv = a.T; }
   return h;
 }
