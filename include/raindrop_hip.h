@@ -173,11 +173,13 @@ size_t rd_msgpass_saved_bytes(const rd_shape* s);       /* forward -> backward h
  *   Y1 = relu(X  W1^T + b1) * ssum[f];   Y2 = relu(Y1 W2^T + b2) * ssum[f]
  *   z[t,b,f*d+c]  = Y2[b,f,t*d+c]                            (columns [0, F*d) of z, row stride ldz)
  * src [T,B,2F] (values in the first F columns).  `saved` (rd_msgpass_saved_bytes) receives what
- * the backward pass needs: X and Y1 as [B,F,K] and, on the fused path, the split-bf16 weight planes.
- * p_drop > 0 applies nn.Dropout to the embedding h (code/models_rd.py:296) with a Philox mask
+ * the backward pass needs: X and Y1 as [B,F,K] and the weights as split-bf16 operand tiles (fused path: its
+ * planes; other shapes, bf16 modes: W1, W2, W2^T, W1^T as native tiles, 4 x 4 ceil16(K) ceil32(K) bytes).
+ * p_drop > 0 applies nn.Dropout to the embedding h (code/models_rd.py:296) with a counter-based mask
  * that is a pure function of (seed, element index); p_drop = 0 in eval mode.
  * Shapes with F <= 64, d_ob = 4, K = T*d_ob <= 240, K % 16 == 0 (P19) run as ONE fused
- * LDS-resident kernel per batch (one workgroup per sample); others as tiled GEMMs. */
+ * LDS-resident kernel per batch (one workgroup per sample); others as two panel products (rd_gemm.hip:
+ * k_gemm_panel) behind the observation-embedding kernel. */
 int rd_msgpass_fwd(const rd_shape* s, const float* src, const float* R_u, const float* W1,
                    const float* b1, const float* W2, const float* b2, const float* ssum,
                    float p_drop, uint64_t seed, float* z, int32_t ldz, void* saved, size_t saved_bytes,
