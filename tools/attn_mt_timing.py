@@ -4,9 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from raindrop_amd import _lib, synth
 dev = torch.device("cuda")
-T, B, F, nhead = 215, int(sys.argv[1]) if len(sys.argv) > 1 else 64, 36, 2
+T, B, F, nhead = int(sys.argv[2]) if len(sys.argv) > 2 else 215, int(sys.argv[1]) if len(sys.argv) > 1 else 64, int(sys.argv[3]) if len(sys.argv) > 3 else 36, 2
 D = F * 4 + 16
-cfg = synth.make_config("P12"); L = synth.make_batch(cfg, max(B, 4), seed=100)["lengths"][:B]
+cfg = synth.make_config("P12" if T > 64 else "P19"); L = synth.make_batch(cfg, max(B, 4), seed=100)["lengths"][:B]
 mask = (torch.arange(T)[None, :] >= L[:, None]).to(dev)
 qkv = torch.randn(T, B, 3 * D, device=dev); dout = torch.randn(T, B, D, device=dev)
 out = torch.zeros(T, B, D, device=dev); lse = torch.zeros(B, nhead, T, device=dev)
