@@ -118,10 +118,12 @@ def test_linear_fwd_bwd(M, N, K, act):
 
 
 @pytest.mark.parametrize("cfg_name,B,kind", [("TINY", 1, "sparse"), ("TINY", 5, "ones"), ("P19", 9, "sparse"),
-                                             ("P12", 3, "ones")])
+                                             ("P12", 3, "ones"), ("P12", 5, "sparse"), ("PAM", 2, "sparse")])
 def test_sensor_stage_vs_oracle(cfg_name, B, kind):
     """Observation embedding + both Observation_progation layers + PE concat, forward and backward,
-    against the faithful (per-sample, per-edge) restatement of the reference."""
+    against the faithful (per-sample, per-edge) restatement of the reference.  P12 (K = 860: ragged in rows, columns and
+    reduction chunks) and PAM (K = 2400, 34 rows: less than one row block) run the panel products of rd_gemm.hip with
+    the d_ob = 4 scatter and the gate-mask epilogues; P19 the fused kernels; TINY the tiled GEMM."""
     from raindrop_amd import _lib, ops
     cfg = synth.make_config(cfg_name)
     gs = synth.make_structure(cfg, kind)
