@@ -2432,6 +2432,25 @@ int linear_fwd(long M, int N, int K, const float* x, const float* W, const float
   return launch_gemm(g, st);
 }
 // dx = dy W (+ residual), optionally gated by posmask > 0 and scaled
+// the same products with the weight also given as native operand tiles (k_wsplit): launch_gemm takes the panel form when it applies
+static int linear_fwd_t(long M, int N, int K, const float* x, const float* W, const void* tiles, const float* b, float* y, int relu,
+                        float p, uint64_t seed, uint32_t site, hipStream_t st) {
+  GemmArgs g{};
+  g.M = (int)M; g.N = N; g.K = K; g.nsplit = 1;
+  g.A = x; g.sa_m = K; g.sa_k = 1; g.B = W; g.sb_n = K; g.sb_k = 1; g.C = y; g.sc_m = N;
+  g.Btiles = tiles; g.bt_ntile = cdiv(N, 16); g.bt_nkc = cdiv(K, 32);
+  g.bias = b; g.relu = relu; g.drop_p = p; g.drop_seed = seed; g.drop_site = site;
+  return launch_gemm(g, st);
+}
+static int linear_bwd_x_t(long M, int N, int K, const float* dy, const float* W, const void* tiles_t, float* dx, const float* posmask,
+                          float cscale, const float* residual, hipStream_t st) {
+  GemmArgs g{};
+  g.M = (int)M; g.N = K; g.K = N; g.nsplit = 1;
+  g.A = dy; g.sa_m = N; g.sa_k = 1; g.B = W; g.sb_n = 1; g.sb_k = K; g.C = dx; g.sc_m = K;
+  g.Btiles = tiles_t; g.bt_ntile = cdiv(K, 16); g.bt_nkc = cdiv(N, 32);     // tiles of W^T: rows = K, reduction = N
+  g.posmask = posmask; g.pm_m = K; g.cscale = cscale; g.residual = residual; g.res_m = K;
+  return launch_gemm(g, st);
+}
 int linear_bwd_x(long M, int N, int K, const float* dy, const float* W, float* dx, const float* posmask,
                  float cscale, const float* residual, hipStream_t st) {
   GemmArgs g{};
@@ -2474,12 +2493,12 @@ extern "C" size_t rd_encoder_layer_workspace_bytes(const rd_shape* s) {
 extern "C" void rd_debug_set_attn_stamps(void* p) { g_attn_stamps = (unsigned long long*)p; }   // not part of the ABI
 
 // weights of a layer -> native bf16 hi/lo operand tiles (both orientations) + the constant tiles of the weight-gradient stream
-static int enc_split_specs(const EncDims& e, const rd_encoder_weights* w, const EncSaved& v, WsplitSpec* out) {
+static int enc_split_specs(const EncDims& e, const rd_encoder_weights* w, const EncSaved& v, WsplitSpec* out, bool all8 = false) {
   const float* Ws[8] = {w->in_proj_w, w->out_proj_w, w->lin1_w, w->lin2_w, w->out_proj_w, w->lin2_w, w->lin1_w, w->in_proj_w};
   const int Ns[8] = {3 * e.D, e.D, e.nhid, e.D, e.D, e.D, e.nhid, 3 * e.D};
   const int Ks[8] = {e.D, e.D, e.D, e.nhid, e.D, e.nhid, e.D, e.D};
   const int Tr[8] = {0, 0, 0, 0, 1, 1, 1, 1};
-  const int njobs = rowgemm_ok(e.D, 3 * e.D, 3 * e.D, e.D) ? 8 : 7;
+  const int njobs = (all8 || rowgemm_ok(e.D, 3 * e.D, 3 * e.D, e.D)) ? 8 : 7;
   for (int i = 0; i < njobs; ++i) out[i] = WsplitSpec{Ws[i], Ns[i], Ks[i], Tr[i], v.pl[i][0]};
   return njobs;
 }
@@ -2584,6 +2603,7 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
   const bool rg = rowgemm_ok(3 * e.D, e.D, e.D, 3 * e.D) && rowgemm_ok(e.D, e.D, e.D, e.D) &&
                   rowgemm_ok(e.nhid, e.D, e.D, e.nhid) && rowgemm_ok(e.D, e.nhid, e.nhid, e.D);
   const bool tw = rg && tile_path(e);
+  const bool panel = !rg && precision() != RD_PREC_FP32;
   // token plan (rd_plan.h): x, y and every saved / scratch tensor hold the live rows only, in plan order
   const int32_t* tp = token_plan();
   RD_REQUIRE(!tp || (tw && !attn_big(e)), "token plan: this shape / mode does not run on the row-block + tile-stream path");
@@ -2593,7 +2613,16 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
     if (tw) rowgemm_export_next(v.xt[0]);
     if ((rc = launch_rowgemm(e.M, 3 * e.D, e.D, x, e.D, v.pl[0][0], v.pl[0][1], v.qkv, 3 * e.D, w->in_proj_b, 0, nullptr, 0,
                              0.f, nullptr, 0, 0.f, 0, 0, st))) return rc;
-  } else if ((rc = linear_fwd(e.M, 3 * e.D, e.D, x, w->in_proj_w, w->in_proj_b, v.qkv, 0, 0.f, 0, 0, st))) return rc;
+  } else {
+    // widths beyond the row-block kernels (SYN256: D = 1040): the tiled family -- in the bf16 modes on its panel form, with the
+    // layer's eight weight orientations split here (kept in `saved` for the backward)
+    if (panel) {
+      WsplitSpec specs[8];
+      const int n = enc_split_specs(e, w, v, specs, true);
+      if ((rc = launch_wsplit_specs(n, specs, 0, nullptr, st))) return rc;
+    }
+    if ((rc = linear_fwd_t(e.M, 3 * e.D, e.D, x, w->in_proj_w, panel ? v.pl[0][0] : nullptr, w->in_proj_b, v.qkv, 0, 0.f, 0, 0, st))) return rc;
+  }
   AttnArgs a{};
   a.qkv = v.qkv; a.mask = mask; a.out = v.attn; a.lse = v.lse;
   a.T = e.T; a.B = e.B; a.D = e.D; a.H = e.H; a.hd = e.Hd;
@@ -2620,7 +2649,7 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
     if (rg) {
       if ((rc = launch_rowgemm(e.M, e.D, e.D, v.attn, e.D, v.pl[1][0], v.pl[1][1], ws.o, e.D, w->out_proj_b, 0, nullptr, 0, 0.f,
                                nullptr, 0, 0.f, 0, 0, st))) return rc;
-    } else if ((rc = linear_fwd(e.M, e.D, e.D, v.attn, w->out_proj_w, w->out_proj_b, ws.o, 0, 0.f, 0, 0, st))) return rc;
+    } else if ((rc = linear_fwd_t(e.M, e.D, e.D, v.attn, w->out_proj_w, panel ? v.pl[1][0] : nullptr, w->out_proj_b, ws.o, 0, 0.f, 0, 0, st))) return rc;
     if ((rc = launch_add_ln_fwd(x, ws.o, w->norm1_w, w->norm1_b, v.s1, v.x1, v.st1, (int)e.M, e.D, p_drop, seed,
                                 SITE_ATTN_OUT + L, st))) return rc;
   }
@@ -2635,9 +2664,9 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
     if ((rc = launch_rowgemm(e.M, e.D, e.nhid, v.h, e.nhid, v.pl[3][0], v.pl[3][1], ws.f, e.D, w->lin2_b, 0, nullptr, 0, 0.f,
                              nullptr, 0, 0.f, 0, 0, st))) return rc;
   } else {
-    if ((rc = linear_fwd(e.M, e.nhid, e.D, v.x1, w->lin1_w, w->lin1_b, v.h, 1, p_drop, seed, SITE_FFN_HID + L, st)))
+    if ((rc = linear_fwd_t(e.M, e.nhid, e.D, v.x1, w->lin1_w, panel ? v.pl[2][0] : nullptr, w->lin1_b, v.h, 1, p_drop, seed, SITE_FFN_HID + L, st)))
       return rc;
-    if ((rc = linear_fwd(e.M, e.D, e.nhid, v.h, w->lin2_w, w->lin2_b, ws.f, 0, 0.f, 0, 0, st))) return rc;
+    if ((rc = linear_fwd_t(e.M, e.D, e.nhid, v.h, w->lin2_w, panel ? v.pl[3][0] : nullptr, w->lin2_b, ws.f, 0, 0.f, 0, 0, st))) return rc;
   }
   return launch_add_ln_fwd(v.x1, ws.f, w->norm2_w, w->norm2_b, v.s2, y, v.st2, (int)e.M, e.D, p_drop, seed,
                            SITE_FFN_OUT + L, st);
@@ -2667,6 +2696,7 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   // gradients run as one streaming launch at the end of the layer (rd_tile_wgrad.hip), instead of four split-K GEMMs;
   // its reduce launch also column-sums the two LayerNorm partial matrices
   const bool tw = rg && tile_path(e);
+  const bool panel = !rg && precision() != RD_PREC_FP32;      // the forward split the eight weight orientations into `saved`
   const int32_t* tp = token_plan();
   RD_REQUIRE(!tp || (tw && !attn_big(e)), "token plan: this shape / mode does not run on the row-block + tile-stream path");
   struct MliveScope { MliveScope(const int32_t* p) { rowgemm_set_mlive(p); } ~MliveScope() { rowgemm_set_mlive(nullptr); } } mscope(tp);
@@ -2696,7 +2726,7 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
                                    v.pl[5][0], ws.du, e.nhid, v.h, e.nhid, p_drop > 0.f ? keep : 0.f, st))) return rc;
     } else if ((rc = launch_rowgemm(e.M, e.nhid, e.D, ws.df, e.D, v.pl[5][0], v.pl[5][1], ws.du, e.nhid, nullptr, 0, v.h, e.nhid,
                                     p_drop > 0.f ? keep : 0.f, nullptr, 0, 0.f, 0, 0, st))) return rc;
-  } else if ((rc = linear_bwd_x(e.M, e.D, e.nhid, ws.df, w->lin2_w, ws.du, v.h, p_drop > 0.f ? keep : 0.f, nullptr, st)))
+  } else if ((rc = linear_bwd_x_t(e.M, e.D, e.nhid, ws.df, w->lin2_w, panel ? v.pl[5][0] : nullptr, ws.du, v.h, p_drop > 0.f ? keep : 0.f, nullptr, st)))
     return rc;
   if (!tw && (rc = linear_bwd_w(e.M, e.nhid, e.D, ws.du, v.x1, g->lin1_w, g->lin1_b, ws.splitk, ws.colsum, sw))) return rc;
   if (fuse) {
@@ -2704,7 +2734,7 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
     if (tw) rowgemm_export_next(ws.dt[1]);
     if ((rc = launch_rowgemm(e.M, e.D, e.nhid, ws.du, e.nhid, v.pl[6][0], v.pl[6][1], ws.dx1, e.D, nullptr, 0, nullptr, 0, 0.f,
                              ws.ds2, e.D, 0.f, 0, 0, st))) return rc;
-  } else if ((rc = linear_bwd_x(e.M, e.nhid, e.D, ws.du, w->lin1_w, ws.dx1, nullptr, 0.f, ws.ds2, st))) return rc;
+  } else if ((rc = linear_bwd_x_t(e.M, e.nhid, e.D, ws.du, w->lin1_w, panel ? v.pl[6][0] : nullptr, ws.dx1, nullptr, 0.f, ws.ds2, st))) return rc;
   // ---- LayerNorm 1 -------------------------------------------------------------------------------
   if (!lnf && (rc = launch_ln_bwd(ws.dx1, v.s1, v.st1, w->norm1_w, ws.ds1, ws.dout, tw ? ws.lnpart1 : ws.lnpart, (int)e.M, e.D,
                                   p_drop, seed, SITE_ATTN_OUT + L, st))) return rc;
@@ -2720,7 +2750,7 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
                                    SITE_ATTN_OUT + L, v.pl[4][0], ws.da, e.D, nullptr, 0, 0.f, st))) return rc;
     } else if ((rc = launch_rowgemm(e.M, e.D, e.D, ws.dout, e.D, v.pl[4][0], v.pl[4][1], ws.da, e.D, nullptr, 0, nullptr, 0, 0.f,
                                     nullptr, 0, 0.f, 0, 0, st))) return rc;
-  } else if ((rc = linear_bwd_x(e.M, e.D, e.D, ws.dout, w->out_proj_w, ws.da, nullptr, 0.f, nullptr, st))) return rc;
+  } else if ((rc = linear_bwd_x_t(e.M, e.D, e.D, ws.dout, w->out_proj_w, panel ? v.pl[4][0] : nullptr, ws.da, nullptr, 0.f, nullptr, st))) return rc;
   // ---- attention core ----------------------------------------------------------------------------
   AttnArgs a{};
   a.qkv = v.qkv; a.mask = mask; a.out = v.attn; a.lse = v.lse; a.dout = ws.da; a.dqkv = ws.dqkv; a.delta = ws.delta;
@@ -2743,7 +2773,7 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
     rc = launch_rowgemm(e.M, e.D, 3 * e.D, ws.dqkv, 3 * e.D, v.pl[7][0], v.pl[7][1], dx, e.D, nullptr, 0, nullptr, 0, 0.f, ws.ds1,
                         e.D, 0.f, 0, 0, st);
   else
-    rc = linear_bwd_x(e.M, 3 * e.D, e.D, ws.dqkv, w->in_proj_w, dx, nullptr, 0.f, ws.ds1, st);
+    rc = linear_bwd_x_t(e.M, 3 * e.D, e.D, ws.dqkv, w->in_proj_w, panel ? v.pl[7][0] : nullptr, dx, nullptr, 0.f, ws.ds1, st);
   if (rc) return rc;
   if (tw) {
     const TileWgradJob jobs[4] = {
