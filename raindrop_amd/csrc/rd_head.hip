@@ -27,6 +27,7 @@ namespace {
 constexpr int HR_THR = 1024, HR_WAVES = 16;
 constexpr int HR_RJ = 16, HR_KI = 4;               // W0 rows per wave (dh <= 256), column slots per lane (dh <= 256)
 constexpr int HR_LD = 256;                         // row stride of the per-sample vectors in LDS
+constexpr int HR_EMBW = 1024, HR_DS = 64;         // static embedding held in LDS when Fe * d_static <= 1024 and d_static <= 64 (else read in place; keeps the two-sample variant under 64 KB of static LDS)
 
 struct HeadArgs {
   const float* r; const uint8_t* mask; const int64_t* lengths; const float* stat;
@@ -69,6 +70,11 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
   __shared__ __attribute__((aligned(16))) float feat[RB][HR_LD], hid[RB][HR_LD], dhid[RB][HR_LD], dfeat[RB][HR_LD];
   __shared__ __attribute__((aligned(16))) float red[HR_WAVES * RB * HR_LD];     // mean-phase and wave partials
   __shared__ float lg[RB][16], dl[RB][16], invl[RB], b0s[HR_LD];
+  // every small operand of the later phases, fetched ONCE at the top beside W0: as global loads inside their phases (static
+  // embedding: d_static dependent steps of two loads; logits: three; the label; W2 again in the gradient) they were ~17 dependent
+  // round trips during which the workgroup's other waves sat at the next barrier (SQ counters: 80 % of the wave cycles waiting)
+  __shared__ float w2s[16 * HR_LD], embb[HR_LD], b2s[16], embws[HR_EMBW], stats[RB][HR_DS];
+  __shared__ long long ys[RB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b0 = blockIdx.x * RB;
   const int T = a.T, B = a.B, D = a.D, dh = a.dh, C = a.C, D4 = D >> 2;
@@ -86,6 +92,15 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
     for (int i = 0; i < HR_KI; ++i) w[jj][i] = a.w0[(long)jc * dh + min(lane + 64 * i, dh - 1)];
   }
   if (tid < HR_LD) b0s[tid] = a.b0[min(tid, dh - 1)];    // the first layer's bias -> LDS (was a dependent load per output row)
+  const bool emb_lds = a.Fe > 0 && a.Fe * a.ds <= HR_EMBW && a.ds <= HR_DS;
+  for (int i = tid; i < C * dh; i += HR_THR) w2s[i] = a.w2[i];
+  if (tid < C) b2s[tid] = a.b2[tid];
+  if (tid < RB) ys[tid] = (b0 + tid < B) ? a.y[b0 + tid] : 0;
+  if (emb_lds) {
+    for (int i = tid; i < a.Fe * a.ds; i += HR_THR) embws[i] = a.emb_w[i];
+    if (tid < a.Fe) embb[tid] = a.emb_b[tid];
+    for (int i = tid; i < RB * a.ds; i += HR_THR) { const int r = i / a.ds, q = i - r * a.ds; stats[r][q] = (b0 + r < B) ? a.stat[(long)(b0 + r) * a.ds + q] : 0.f; }
+  }
   // ---- masked mean: thread = (sample r, column quad c4, time group tg) ----
   const int P = RB * D4;
   const int ntg = min(HR_THR / P, 16);
@@ -125,11 +140,18 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
     *reinterpret_cast<float4*>(&feat[r][4 * c4]) = make_float4(s.x * il, s.y * il, s.z * il, s.w * il);
   }
   // ---- static embedding into the right block (code/models_rd.py:381): thread = (r, j) ----
-  for (int e = tid; e < RB * a.Fe; e += HR_THR) {
+  for (int e = tid; e < RB * a.Fe; e += HR_THR) {         // (the prefetched operands were stored before the barrier above)
     const int r = e / a.Fe, j = e - r * a.Fe, b = b0 + r;
-    float s = a.emb_b[j];
-    if (b < B)
-      for (int q = 0; q < a.ds; ++q) s += a.stat[(long)b * a.ds + q] * a.emb_w[(long)j * a.ds + q];
+    float s;
+    if (emb_lds) {
+      s = embb[j];
+      if (b < B)
+        for (int q = 0; q < a.ds; ++q) s += stats[r][q] * embws[j * a.ds + q];
+    } else {
+      s = a.emb_b[j];
+      if (b < B)
+        for (int q = 0; q < a.ds; ++q) s += a.stat[(long)b * a.ds + q] * a.emb_w[(long)j * a.ds + q];
+    }
     feat[r][D + j] = s;
   }
   __syncthreads();
@@ -156,9 +178,9 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
   for (int o = wave; o < RB * C; o += HR_WAVES) {
     const int r = o / C, c = o - r * C;
     float p = 0.f;
-    for (int k = lane; k < dh; k += 64) p += hid[r][k] * a.w2[(long)c * dh + k];
+    for (int k = lane; k < dh; k += 64) p += hid[r][k] * w2s[c * dh + k];
     p = wsum64(p);
-    if (lane == 0) lg[r][c] = p + a.b2[c];
+    if (lane == 0) lg[r][c] = p + b2s[c];
   }
   __syncthreads();
   // ---- softmax cross entropy per sample, dlogits = (softmax - onehot) / B ----
@@ -170,7 +192,7 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
     for (int c = 0; c < C; ++c) se += expf(lg[r][c] - m);
     const float lse = m + logf(se);
     // a label outside [0, C) has no logit to index (torch raises): the sample's loss becomes NaN -- loud, and no out-of-bounds read
-    const long yb = a.y[b];
+    const long yb = (long)ys[r];
     const bool yok = yb >= 0 && yb < C;
     const int t = yok ? (int)yb : 0;
     a.lossr[b] = yok ? lse - lg[r][t] : __builtin_nanf("");
@@ -189,7 +211,7 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
   for (int e = tid; e < RB * dh; e += HR_THR) {
     const int r = e / dh, j = e - r * dh, b = b0 + r;
     float s = 0.f;
-    for (int c = 0; c < C; ++c) s += dl[r][c] * a.w2[(long)c * dh + j];
+    for (int c = 0; c < C; ++c) s += dl[r][c] * w2s[c * dh + j];
     const float h = hid[r][j];
     s = h > 0.f ? s : 0.f;
     dhid[r][j] = s;
