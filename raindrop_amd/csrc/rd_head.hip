@@ -91,15 +91,31 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
 #pragma unroll
     for (int i = 0; i < HR_KI; ++i) w[jj][i] = a.w0[(long)jc * dh + min(lane + 64 * i, dh - 1)];
   }
-  if (tid < HR_LD) b0s[tid] = a.b0[min(tid, dh - 1)];    // the first layer's bias -> LDS (was a dependent load per output row)
+  // small operands -> LDS: ALL requests first (unconditional, clamped indices), then the stores.  Written as `if (tid < n) lds[tid] =
+  // g[tid];` per array each was its own load -> wait -> store block: seven dependent round trips at the top of the kernel.
   const bool emb_lds = a.Fe > 0 && a.Fe * a.ds <= HR_EMBW && a.ds <= HR_DS;
-  for (int i = tid; i < C * dh; i += HR_THR) w2s[i] = a.w2[i];
-  if (tid < C) b2s[tid] = a.b2[tid];
-  if (tid < RB) ys[tid] = (b0 + tid < B) ? a.y[b0 + tid] : 0;
-  if (emb_lds) {
-    for (int i = tid; i < a.Fe * a.ds; i += HR_THR) embws[i] = a.emb_w[i];
-    if (tid < a.Fe) embb[tid] = a.emb_b[tid];
-    for (int i = tid; i < RB * a.ds; i += HR_THR) { const int r = i / a.ds, q = i - r * a.ds; stats[r][q] = (b0 + r < B) ? a.stat[(long)(b0 + r) * a.ds + q] : 0.f; }
+  {
+    const int nw2 = C * dh;
+    const float pb0 = a.b0[min(tid, dh - 1)], pw2 = a.w2[min(tid, nw2 - 1)], pb2 = a.b2[min(tid, C - 1)];
+    const long long py = a.y[min(b0 + min(tid, RB - 1), B - 1)];
+    float pew = 0.f, peb = 0.f, pst = 0.f;
+    if (emb_lds) {                                     // uniform
+      const int ne = a.Fe * a.ds, ns = RB * a.ds, ts = min(tid, ns - 1), rs = ts / a.ds;
+      pew = a.emb_w[min(tid, ne - 1)]; peb = a.emb_b[min(tid, a.Fe - 1)];
+      pst = a.stat[(long)min(b0 + rs, B - 1) * a.ds + (ts - rs * a.ds)];
+    }
+    if (tid < HR_LD) b0s[tid] = pb0;
+    if (tid < nw2) w2s[tid] = pw2;
+    if (tid < C) b2s[tid] = pb2;
+    if (tid < RB) ys[tid] = py;
+    if (emb_lds) {
+      const int ne = a.Fe * a.ds;
+      if (tid < ne) embws[tid] = pew;
+      if (tid < a.Fe) embb[tid] = peb;
+      if (tid < RB * a.ds) stats[tid / a.ds][tid % a.ds] = pst;
+      for (int i = tid + HR_THR; i < ne; i += HR_THR) embws[i] = a.emb_w[i];          // HR_EMBW <= HR_THR: never runs; kept for safety
+    }
+    for (int i = tid + HR_THR; i < nw2; i += HR_THR) w2s[i] = a.w2[i];                // C * dh > 1024 only
   }
   // ---- masked mean: thread = (sample r, column quad c4, time group tg) ----
   const int P = RB * D4;
