@@ -12,6 +12,7 @@
 // dgrad    (dy W):   Wp = split(W^T)    [K rows, N cols]
 // Split-bf16 arithmetic (hi*hi + hi*lo + lo*hi, fp32 accumulate) as everywhere else.
 #include "rd_common.h"
+#include <type_traits>
 #include "rd_plan.h"
 #include "rd_rng.h"
 
@@ -128,8 +129,30 @@ __device__ __forceinline__ void rg_load_panel(RPanel<KC, RG_NJ>& p, const __bf16
   }
 }
 
+// reduction steps [K0, K1) of the wave's tiles into a panel of KP = K1 - K0 (or more) steps: the K = 3D product holds HALF of its
+// 15-step panel at a time (64 instead of 120 registers -> two workgroups per CU, see k_rowgemm)
+template <int KC, int KP, int RG_NJ, int RG_WAVES, int K0, int K1>
+__device__ __forceinline__ void rg_load_panel_part(RPanel<KP, RG_NJ>& p, const __bf16* __restrict__ Wt, int tile0, int ntiles, int wave,
+                                                   int lane) {
+#pragma unroll
+  for (int jj = 0; jj < RG_NJ; ++jj) {
+    const int j = tile0 + wave + RG_WAVES * jj;
+    const __bf16* t = Wt + (size_t)(j < ntiles ? j : 0) * (KC * 2 * 512) + lane * 8;
+#pragma unroll
+    for (int kc = K0; kc < K1; ++kc) {
+      p.h[jj][kc - K0] = *reinterpret_cast<const bf16x8*>(t + (kc * 2 + 0) * 512);
+      p.l[jj][kc - K0] = *reinterpret_cast<const bf16x8*>(t + (kc * 2 + 1) * 512);
+    }
+  }
+}
+
 template <int KC, int RG_ROWS, int RG_NJ, bool LN, bool LNB, int WV>
 __global__ __launch_bounds__(64 * WV) void k_rowgemm(RowGemmArgs a) {
+  // SPLIT (the K = 3D = 456 input gradient of the QKV projection): the 15-step weight panel is 120 VGPRs -- with them the kernel
+  // needs 178, ONE 8-wave workgroup per CU, and the 266 32-row workgroups of 8497 live rows run in two rounds on 256 CUs (the
+  // second for 10 of them).  Holding half a panel at a time keeps the kernel under 128 registers: two workgroups per CU, one round.
+  constexpr bool SPLIT = KC == 15 && !LN && !LNB;
+  constexpr int KH = SPLIT ? 8 : KC;                 // steps of the resident (half) panel
   constexpr int RG_WAVES = WV, RG_THR = 64 * WV;
   constexpr int RT = RG_ROWS / 16, RG_CPR = RG_WAVES * RG_NJ * 16, RG_LDS_STAGE = RG_CPR + 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
@@ -157,7 +180,7 @@ __global__ __launch_bounds__(64 * WV) void k_rowgemm(RowGemmArgs a) {
   // KC quads per thread: all of them are requested first, THEN the weight panel (loads return in issue
   // order: the rows are needed now, the panel only at the first MFMA), then the rows are split into LDS
   // while the panel streams in.
-  RPanel<KC, RG_NJ> pw;
+  RPanel<KH, RG_NJ> pw;
   if constexpr (LNB) {
     // ---- LayerNorm backward per row (wave w: rows 8w .. 8w+7 of the block; lane l: columns 4l .. 4l+3) -> split planes ----
     constexpr int RPW = RG_ROWS / RG_WAVES;
@@ -178,7 +201,7 @@ __global__ __launch_bounds__(64 * WV) void k_rowgemm(RowGemmArgs a) {
         dvr[it] = *reinterpret_cast<const float4*>(a.lnb_dy + row * a.K + c);
       }
     }
-    rg_load_panel<KC, RG_NJ, RG_WAVES>(pw, a.Wh, 0, ntiles, wave, lane);
+    rg_load_panel_part<KC, KH, RG_NJ, RG_WAVES, 0, KH>(pw, a.Wh, 0, ntiles, wave, lane);
     __builtin_amdgcn_sched_barrier(0);
     uint64_t lseed = a.lnb_seed;
     if (a.seed_cell) { const uint64_t cv = load_uniform_u64(a.seed_cell); lseed += cv; seed += cv; }
@@ -236,7 +259,7 @@ __global__ __launch_bounds__(64 * WV) void k_rowgemm(RowGemmArgs a) {
       v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (r < RG_ROWS && m0 + r < a.M && k < a.K) v[it] = *reinterpret_cast<const float4*>(a.A + (long)(m0 + r) * a.lda + k);
     }
-    rg_load_panel<KC, RG_NJ, RG_WAVES>(pw, a.Wh, 0, ntiles, wave, lane);
+    rg_load_panel_part<KC, KH, RG_NJ, RG_WAVES, 0, KH>(pw, a.Wh, 0, ntiles, wave, lane);
     __builtin_amdgcn_sched_barrier(0);       // keep every request above the first use (the scheduler otherwise
                                              // waits for the rows before it has requested the panel)
     if (a.seed_cell) seed += load_uniform_u64(a.seed_cell);   // scalar path: not queued behind the panel
@@ -298,46 +321,48 @@ __global__ __launch_bounds__(64 * WV) void k_rowgemm(RowGemmArgs a) {
       for (int rt = 0; rt < RT; ++rt) acc[jj][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // the single-product mode (RD_PREC_BF16) is decided OUTSIDE the reduction loop: a branch inside it cut every step into its own
     // basic block, and the A-fragment reads of step kc+1 could not be scheduled above the products of step kc
-    if (!a.one_product) {
+    auto steps = [&](auto k0_tag, auto k1_tag, auto three_tag) {
+      constexpr int K0 = decltype(k0_tag)::value, K1 = decltype(k1_tag)::value;
+      constexpr bool THREE = decltype(three_tag)::value;
 #pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
+      for (int kc = K0; kc < K1; ++kc) {
         bf16x8 ah[RT], al[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * LDA + aoff + kc * 32);
-          al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * LDA + aoff + kc * 32);
+          if (THREE) al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * LDA + aoff + kc * 32);
         }
-#pragma unroll
-        for (int jj = 0; jj < RG_NJ; ++jj)
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-            acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], pw.h[jj][kc], acc[jj][rt], 0, 0, 0);
-#pragma unroll
-        for (int jj = 0; jj < RG_NJ; ++jj)
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-            acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], pw.l[jj][kc], acc[jj][rt], 0, 0, 0);
-#pragma unroll
-        for (int jj = 0; jj < RG_NJ; ++jj)
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-            acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], pw.h[jj][kc], acc[jj][rt], 0, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * LDA + aoff + kc * 32);
+        if (THREE) {
 #pragma unroll
           for (int jj = 0; jj < RG_NJ; ++jj)
-            acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, pw.h[jj][kc], acc[jj][rt], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+              acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], pw.h[jj][kc - K0], acc[jj][rt], 0, 0, 0);
+#pragma unroll
+          for (int jj = 0; jj < RG_NJ; ++jj)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+              acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], pw.l[jj][kc - K0], acc[jj][rt], 0, 0, 0);
         }
+#pragma unroll
+        for (int jj = 0; jj < RG_NJ; ++jj)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], pw.h[jj][kc - K0], acc[jj][rt], 0, 0, 0);
       }
+    };
+    using I0 = std::integral_constant<int, 0>; using IH = std::integral_constant<int, KH>; using IK = std::integral_constant<int, KC>;
+    if (!a.one_product) steps(I0{}, IH{}, std::true_type{}); else steps(I0{}, IH{}, std::false_type{});
+    if constexpr (SPLIT) {
+      __builtin_amdgcn_sched_barrier(0);               // the second half goes into the registers the first half has released
+      rg_load_panel_part<KC, KH, RG_NJ, RG_WAVES, KH, KC>(pw, a.Wh, tile0, ntiles, wave, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!a.one_product) steps(IH{}, IK{}, std::true_type{}); else steps(IH{}, IK{}, std::false_type{});
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (rd == 0) RGSTAMP(3);
     // next round's weights stream while this round's epilogue runs
-    if (rd + 1 < nrounds) rg_load_panel<KC, RG_NJ, RG_WAVES>(pw, a.Wh, tile0 + RG_WAVES * RG_NJ, ntiles, wave, lane);
+    if (rd + 1 < nrounds) rg_load_panel_part<KC, KH, RG_NJ, RG_WAVES, 0, KH>(pw, a.Wh, tile0 + RG_WAVES * RG_NJ, ntiles, wave, lane);
     // ---- accumulators -> stage tile (column = position inside this round's 256-column window) ----
 #pragma unroll
     for (int jj = 0; jj < RG_NJ; ++jj)
