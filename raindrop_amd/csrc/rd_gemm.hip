@@ -824,10 +824,12 @@ static int launch_panel(const GemmArgs& g, hipStream_t st) {
 // more on ragged edges; pick the cheapest legal (MI, NI).
 template <bool A_KC, bool B_KC>
 int dispatch_bf16x3(const GemmArgs& g, hipStream_t st) {
-  static const int cand[][2] = {{2, 2}, {4, 2}, {4, 4}, {2, 4}, {4, 5}, {2, 5}};
+  // (a 128 x 160 tile was a candidate until round 3: its two instantiations were the last kernels of the library with register
+  // spills -- 656 bytes of scratch per lane -- and no shape of the path ever selected them)
+  static const int cand[][2] = {{2, 2}, {4, 2}, {4, 4}, {2, 4}, {2, 5}};
   if (g.tile_hint == 1) return launch_bf16x3<A_KC, B_KC, 4, 4>(g, st);
   int best = 0; double bcost = 1e300;
-  for (int c = 0; c < 6; ++c) {
+  for (int c = 0; c < 5; ++c) {
     const int mi = cand[c][0], ni = cand[c][1];
     if (ni == 5 && !B_KC) continue;                  // 160-row staging only exists for k-contiguous operands
     const double tm = 32.0 * mi, tn = 32.0 * ni;
@@ -846,7 +848,6 @@ int dispatch_bf16x3(const GemmArgs& g, hipStream_t st) {
     case 1: return launch_bf16x3<A_KC, B_KC, 4, 2>(g, st);
     case 2: return launch_bf16x3<A_KC, B_KC, 4, 4>(g, st);
     case 3: return launch_bf16x3<A_KC, B_KC, 2, 4>(g, st);
-    case 4: return launch_bf16x3<A_KC, true, 4, 5>(g, st);
     default: return launch_bf16x3<A_KC, true, 2, 5>(g, st);
   }
 }
