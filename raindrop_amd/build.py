@@ -7,7 +7,9 @@ hipcc cross-compiles without a GPU; each translation unit becomes an object unde
 `raindrop_amd/csrc/_build/` and the objects are linked into `raindrop_amd/libraindrop_hip.so`.
 """
 import hashlib
+import json
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -19,6 +21,7 @@ LIB = os.path.join(PKG, "libraindrop_hip.so")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
+         "-Rpass-analysis=kernel-resource-usage",       # per-kernel registers / scratch / LDS -> <object>.usage.json (tests/test_kernel_resources.py)
          "-I", INCLUDE]
 
 
@@ -47,11 +50,54 @@ def _compile(src, force, objdir=None, extra=()):
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, res.stdout, res.stderr))
-    if res.stderr.strip():
-        sys.stderr.write(res.stderr)
+    usage, rest = _parse_resource_remarks(res.stderr)
+    with open(obj + ".usage.json", "w") as fh:
+        json.dump(usage, fh, indent=0, sort_keys=True)
+    if rest.strip():
+        sys.stderr.write(rest)
     with open(stamp_file, "w") as fh:
         fh.write(stamp)
     return obj, True
+
+
+_FN = re.compile(r"remark:\s+Function Name: (\S+)\s+\[-Rpass-analysis=kernel-resource-usage\]")
+_KV = re.compile(r"remark:\s+([A-Za-z][A-Za-z \[\]/]*?): (\S+)\s+\[-Rpass-analysis=kernel-resource-usage\]")
+_CTX = re.compile(r"^\s*\d*\s*\|")                 # the source excerpt / caret lines clang prints under a diagnostic
+_KEYS = {"VGPRs": "vgprs", "AGPRs": "agprs", "TotalSGPRs": "sgprs", "ScratchSize [bytes/lane]": "scratch", "Occupancy [waves/SIMD]": "occupancy",
+         "VGPRs Spill": "vgpr_spill", "SGPRs Spill": "sgpr_spill", "LDS Size [bytes/block]": "lds"}
+
+
+def _parse_resource_remarks(stderr):
+    """hipcc's kernel-resource-usage remarks -> {mangled kernel name: {vgprs, agprs, scratch, occupancy, lds, ..}}; returns that and
+    the rest of stderr (real warnings)."""
+    usage, rest, cur, after_remark = {}, [], None, False
+    for line in stderr.splitlines():
+        if "-Rpass-analysis=kernel-resource-usage" in line:
+            after_remark = True
+            m = _FN.search(line)
+            if m:
+                cur = usage.setdefault(m.group(1), {})
+                continue
+            m = _KV.search(line)
+            if m and cur is not None and m.group(1) in _KEYS:
+                v = m.group(2)
+                cur[_KEYS[m.group(1)]] = int(v) if v.lstrip("-").isdigit() else v
+            continue
+        if after_remark and _CTX.match(line):
+            continue
+        after_remark = False
+        rest.append(line)
+    return usage, "\n".join(rest) + ("\n" if rest else "")
+
+
+def resource_usage():
+    """{mangled kernel name: usage} over every object of the last build (raindrop_amd/csrc/_build/*.usage.json)."""
+    out = {}
+    for f in sorted(os.listdir(OBJ)) if os.path.isdir(OBJ) else []:
+        if f.endswith(".usage.json"):
+            with open(os.path.join(OBJ, f)) as fh:
+                out.update(json.load(fh))
+    return out
 
 
 def build(force=False, verbose=True):

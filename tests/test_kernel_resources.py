@@ -1,0 +1,55 @@
+"""What the compiler made of the hot kernels, checked at build time (no GPU): `raindrop_amd.build` compiles with
+-Rpass-analysis=kernel-resource-usage and keeps the per-kernel numbers next to the objects.
+
+Why these are tests and not notes: each of them was a measured loss once (rules 11 and 21) --
+  * register spills in the two fused encoder chains were 9 % of the training step,
+  * the K = 3D row-block product at 178 registers ran one workgroup per CU and therefore TWO rounds on 256 CUs (8 us per call),
+and both are one careless edit away from coming back without any functional test noticing."""
+import pytest
+
+from raindrop_amd import build
+
+
+@pytest.fixture(scope="module")
+def usage():
+    build.build(verbose=False)
+    u = build.resource_usage()
+    assert len(u) > 100, "no resource-usage records: was the library built by raindrop_amd.build?"
+    return u
+
+
+def _find(usage, *parts):
+    hits = [(k, v) for k, v in usage.items() if all(p in k for p in parts)]
+    assert hits, "no kernel matching %r" % (parts,)
+    return hits
+
+
+# (name fragments, max VGPRs or None): the kernels of the P19 training step and of the P12 / PAM paths
+HOT = [
+    (("k_msg_fwd_fusedILi3ELi34ELi60E",), 128), (("k_msg_bwd_fusedILi3ELi34ELi60E",), 128), (("4k_dwE",), None), (("k_wprep",), None),
+    (("k_enc_post_fwdILi152ELi272E",), 128), (("k_enc_pre_bwdILi152ELi272E",), 128),          # 16 waves per workgroup: 128 is the cap
+    (("k_enc_post_fwdILi160ELi288E",), 128), (("k_enc_pre_bwdILi160ELi288E",), 128),
+    (("k_rowgemmILi5ELi32ELi2ELb0ELb0ELi8E",), 128),                                         # two 8-wave workgroups per CU
+    (("k_rowgemmILi15ELi32ELi1ELb0ELb0ELi8E",), 128),                                        # two per CU: ONE round of 266 workgroups
+    (("5k_twgE",), None), (("k_twg_reduce",), None),
+    (("k_attn_fwd_one_b16wILi5ELb1E",), 128), (("k_attn_bwd_one_b16wILi5ELb1E",), 128),
+    (("k_attn_fwd_b16ILi5ELb1ELb0E",), 256), (("k_attn_bwd_dq_b16ILi5ELb1ELb0E",), 256), (("k_attn_bwd_dkv_b16ILi5ELb1ELb0E",), 256),
+    (("k_head_rowsILi1E",), 128), (("k_head_wgrad",), None), (("k_gemm_panelILi2E",), 256), (("k_adam",), None), (("k_wsplit",), None),
+]
+
+
+@pytest.mark.parametrize("parts,max_vgprs", HOT, ids=[p[0][0] for p in HOT])
+def test_hot_kernel_has_no_scratch_and_fits_its_occupancy(usage, parts, max_vgprs):
+    for name, u in _find(usage, *parts):
+        assert u["scratch"] == 0 and u["vgpr_spill"] == 0, (name, u)          # (SGPR spills go to VGPR lanes, not to memory)
+        if max_vgprs is not None:
+            assert u["vgprs"] + u.get("agprs", 0) <= max_vgprs, (name, u)
+
+
+def test_scratch_users_are_the_known_ones(usage):
+    """Every kernel with a non-zero scratch size is on this list (runtime-shape instantiations for shapes no dataset has, the
+    preprocessing kernels' local arrays, one 12-byte spill at head_dim 81..96 without 16-byte rows): a new entry is a regression."""
+    known = ("k_enc_pre_bwdILi0ELi0E", "k_msg_fwd_fusedILi4ELi0ELi0E", "k_msg_bwd_fusedILi4ELi0ELi0E", "k_pw_leaves", "k_pw_combine",
+             "k_attn_bwd_dkv_b16ILi6ELb0ELb0E")
+    new = [k for k, u in usage.items() if u.get("scratch") and not any(n in k for n in known)]
+    assert not new, new
