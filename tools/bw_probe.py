@@ -1,3 +1,4 @@
+"""Debug: achievable HBM bandwidth of plain torch copies / reads on this box (sanity figure beside the kernels' rooflines)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,3 +1,6 @@
+"""Time the hipGraph training step (TrainStep.run + flat Adam) of any BASELINE config:   python tools/step_cfg.py CONFIG B STEPS
+(P12 / PAM / SYN256 counterpart of tools/step_only.py; target of rocprofv3 --kernel-trace for those shapes).  RD_PRECISION and
+the RD_* switches of README.md apply."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
