@@ -53,3 +53,25 @@ def test_scratch_users_are_the_known_ones(usage):
              "k_attn_bwd_dkv_b16ILi6ELb0ELb0E")
     new = [k for k, u in usage.items() if u.get("scratch") and not any(n in k for n in known)]
     assert not new, new
+
+
+def test_resource_remark_parser_keeps_real_warnings():
+    """The build filters hipcc's kernel-resource-usage remarks (and the source excerpts under them) out of what it echoes, and must
+    not swallow a real diagnostic that follows."""
+    err = "\n".join([
+        "a.hip:11:1: remark: Function Name: _Z1kPf [-Rpass-analysis=kernel-resource-usage]",
+        "   11 |   float b1) {",
+        "      | ^",
+        "a.hip:11:1: remark:     VGPRs: 37 [-Rpass-analysis=kernel-resource-usage]",
+        "a.hip:11:1: remark:     AGPRs: 0 [-Rpass-analysis=kernel-resource-usage]",
+        "a.hip:11:1: remark:     ScratchSize [bytes/lane]: 12 [-Rpass-analysis=kernel-resource-usage]",
+        "a.hip:11:1: remark:     Occupancy [waves/SIMD]: 8 [-Rpass-analysis=kernel-resource-usage]",
+        "a.hip:11:1: remark:     VGPRs Spill: 3 [-Rpass-analysis=kernel-resource-usage]",
+        "a.hip:11:1: remark:     LDS Size [bytes/block]: 4096 [-Rpass-analysis=kernel-resource-usage]",
+        "a.hip:20:7: warning: unused variable 'x' [-Wunused-variable]",
+        "   20 |   int x;",
+        "      |       ^",
+    ])
+    usage, rest = build._parse_resource_remarks(err)
+    assert usage == {"_Z1kPf": {"vgprs": 37, "agprs": 0, "scratch": 12, "occupancy": 8, "vgpr_spill": 3, "lds": 4096}}
+    assert "unused variable" in rest and "int x;" in rest and "remark" not in rest and "float b1" not in rest
