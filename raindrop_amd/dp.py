@@ -28,7 +28,11 @@ class FlatGradAllReduce:
     re-points every `p.grad` at its slice of the flat buffer, which is what the optimizer reads."""
 
     def __init__(self, params, process_group=None, n_buckets=2, average=True, force_collective=False):
-        """params: list of (name, Parameter) that will receive gradients, in forward order.
+        """params: list of (name, Parameter) that will receive gradients, in FORWARD order (raindrop_amd.synth.live_parameter_names:
+        R_u, emb, ob_propagation*, encoder layers 0.., mlp_static).  The order is a contract for the overlapped form below
+        (tail_start / allreduce_range_async, used by TrainStep's two-graph step): the tail of the buffer from the last encoder
+        layer's in_proj_weight on must hold exactly the gradients that are final before the rest of the backward pass runs.
+        TrainStep checks it; model.named_parameters() order violates it (R_u, ob_propagation* come last there).
         force_collective (testing): issue the collectives even in a one-rank group -- a single MI355X can then exercise the RCCL
         calls themselves (backend load, AVG, async handles next to hipGraph replays), which a world of one otherwise skips."""
         self.group = process_group

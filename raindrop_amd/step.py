@@ -85,6 +85,8 @@ class TrainStep:
         self._prep_w = (ctypes.POINTER(_lib.RdEncoderPtrs) * self.nl)(*[ctypes.pointer(w) for w in self.enc_w])
         self._prep_saved = (ctypes.c_void_p * self.nl)(*[t.data_ptr() for t in self.enc_saved])
         self._prep_bytes = (ctypes.c_size_t * self.nl)(*[t.numel() for t in self.enc_saved])
+        if self.split:
+            self._check_split_order()
         self._ptrs = self._param_ptrs()                          # the captured graph / cached structs hold these addresses
         self.graph = None
         self.graph_b = None
@@ -95,6 +97,12 @@ class TrainStep:
     def _validate(model, batch):
         """The step hands raw data_ptr()s to the C-ABI: everything the autograd wrappers check per call is checked here
         once (dtype, contiguity, device, shapes, label range).  Labels are read on the host ONCE, at construction."""
+        # The step enqueues the DEFAULT branch of the sensor stage (rd_sensor_stage_fwd / rd_msgpass_bwd: code/models_rd.py:317's
+        # `use_beta = False`, distance exactly 0).  A model built with the paper's branch switched on would silently train a
+        # different network here (and never see gradients for increase_dim / map_weights): refuse it.
+        if getattr(model, "use_beta", False) or getattr(model, "compute_distance", False):
+            raise _lib.RaindropHipError("TrainStep: Raindrop_v2(use_beta=True / compute_distance=True) runs on the eager model "
+                                        "surface only (model.forward + autograd); the captured step implements the default branch")
         T, B = batch["src"].shape[0], batch["src"].shape[1]
         want = {"src": (torch.float32, (T, B, 2 * model.d_inp)), "times": (torch.float32, (T, B)),
                 "lengths": (torch.int64, (B,)), "y": (torch.int64, (B,))}
@@ -293,37 +301,63 @@ class TrainStep:
             _lib.call("rd_set_token_plan", None)
 
     def _capture(self):
-        """Capture the step as one hipGraph.  With `autotune`, the graph is captured once per setting of the library's
-        tuning knob (32-row vs 64-row workgroups of the encoder's row-block products, rd_set_rowgemm_rows32: which is
-        faster depends on the device, 8 % either way was measured on two boxes of one pool) and the faster graph is kept.
-        Results are the same function of the inputs either way."""
+        """Capture the step as one hipGraph (two in the split form).  With `autotune`, the step is captured once per setting of the
+        library's tuning knobs (32-row vs 64-row workgroups of the encoder's row-block products, rd_set_rowgemm_rows32, then 8 vs
+        16 waves for the plain ones: which is faster depends on the device, 8 % either way was measured on two boxes of one pool)
+        and the fastest kept.  Under torch.distributed every rank times every variant and the per-variant times are SUMMED over
+        the ranks before the choice, so all ranks run the same kernels -- and the same ones a single process would pick on such
+        boxes.  The choice is in `tuned_rows32` / `tuned_waves16` (bench.py: config.tuned).
+        Results: the knobs change which rows share a workgroup, never a row's arithmetic; on the fused row-local chains
+        (rd_encfuse.hip: the P19 / P12 widths) no cross-row sum depends on them, so every variant gives the same gradient bits.
+        On the unfused LayerNorm-epilogue products (other widths) the dgamma / dbeta partial grouping follows the workgroup
+        height: there the bits depend on the choice, which is why it is recorded (pin it with RD_RG_ROWS32 / RD_RG_WAVES16)."""
         import torch.distributed as dist
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        # data-parallel ranks must run the SAME kernel variants (the tuner decides by wall clock: ranks could disagree): no tuning there
-        if not self.autotune or multi or self.split or os.environ.get("RD_RG_ROWS32") is not None or os.environ.get("RD_RG_WAVES16") is not None:
+        if not self.autotune or os.environ.get("RD_RG_ROWS32") is not None or os.environ.get("RD_RG_WAVES16") is not None:
             return self._capture_one()
+
+        def agree(ts):
+            """per-variant times summed over the ranks (identical on every rank afterwards)"""
+            if not multi:
+                return ts
+            dev = self.dev if dist.get_backend() == "nccl" else torch.device("cpu")
+            t = torch.tensor(ts, dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return [float(v) for v in t.cpu()]
 
         def timed(r32, w16):
             _lib.call("rd_set_rowgemm_rows32", r32)
             _lib.call("rd_set_rowgemm_waves16", w16)
             self._capture_one()
+            graphs = (self.graph, self.graph_b)
+
+            def replay():
+                graphs[0].replay()
+                if graphs[1] is not None:
+                    graphs[1].replay()
             for _ in range(3):
-                self.graph.replay()
+                replay()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(30):
-                self.graph.replay()
+                replay()
             torch.cuda.synchronize()
-            return (time.perf_counter() - t0, r32, w16, self.graph)
+            return (time.perf_counter() - t0, graphs)
         # workgroup height first (all / none / plain products only / LayerNorm-fused ones only) at the default wave counts,
         # then the wave count of the plain products at the best height
-        best = min((timed(r32, 12) for r32 in (15, 0, 3, 12)), key=lambda t: t[0])
-        alt = timed(best[1], 15)
-        if alt[0] < best[0]:
-            best = alt
-        self.graph, self.tuned_rows32, self.tuned_waves16 = best[3], best[1], best[2]
-        _lib.call("rd_set_rowgemm_rows32", best[1])                  # eager calls of this process follow the same choice
-        _lib.call("rd_set_rowgemm_waves16", best[2])
+        heights = (15, 0, 3, 12)
+        runs = [timed(r32, 12) for r32 in heights]
+        ts = agree([r[0] for r in runs])
+        bi = min(range(len(heights)), key=lambda i: (ts[i], i))
+        best_r32, best_w16, best_graphs, best_t = heights[bi], 12, runs[bi][1], ts[bi]
+        alt = timed(best_r32, 15)
+        alt_t = agree([alt[0]])[0]
+        if alt_t < best_t:
+            best_w16, best_graphs = 15, alt[1]
+        self.graph, self.graph_b = best_graphs
+        self.tuned_rows32, self.tuned_waves16 = best_r32, best_w16
+        _lib.call("rd_set_rowgemm_rows32", best_r32)                 # eager calls of this process follow the same choice
+        _lib.call("rd_set_rowgemm_waves16", best_w16)
 
     def _capture_one(self):
         def cap():
@@ -348,6 +382,34 @@ class TrainStep:
         self._with_cell(cap)
 
     # ------------------------------------------------------------------------------------------
+    def _early_names(self):
+        """Parameters whose gradients the first all-reduce bucket of the split form carries: the last encoder layer's and the
+        classifier head's (mlp_static).  (The static embedding's gradient is complete by then too, but sits in front of the
+        offset in forward order and travels with the rest: early completion is harmless, late completion is not.)"""
+        pre = "transformer_encoder.layers.%d." % (self.nl - 1)
+        return [n for n in self.flat.names if n.startswith(pre) or n.startswith("mlp_static.")]
+
+    def _check_split_order(self):
+        """Ordering contract of the split (overlapped all-reduce) form: in the flat buffer every gradient the first graph completes
+        must sit at or behind early_grad_offset(), and nothing the SECOND graph writes (R_u, ob_propagation*, earlier encoder
+        layers, emb) may sit there -- the collective started between the graphs would read it while graph B is still writing.
+        raindrop_amd.synth.live_parameter_names (forward order) satisfies it; model.named_parameters() order does NOT
+        (R_u and ob_propagation* are registered behind transformer_encoder, code/models_rd.py:241-247)."""
+        names = list(self.flat.names)
+        first = "transformer_encoder.layers.%d.self_attn.in_proj_weight" % (self.nl - 1)
+        if first not in names:
+            raise _lib.RaindropHipError("TrainStep(split=True): %s is not in the flat gradient buffer" % first)
+        i0 = names.index(first)
+        early = set(self._early_names())
+        bad_tail = [n for n in names[i0:] if n not in early]
+        bad_head = [n for n in names[:i0] if n in early]
+        if bad_tail or bad_head:
+            raise _lib.RaindropHipError(
+                "TrainStep(split=True): the flat gradient buffer must hold the parameters in FORWARD order "
+                "(raindrop_amd.synth.live_parameter_names): behind %s only the last encoder layer and mlp_static may follow; "
+                "found %s behind it and %s in front of it.  Pass split=False (or RD_DP_OVERLAP=0) for another order."
+                % (first, bad_tail[:4], bad_head[:4]))
+
     def early_grad_offset(self):
         """Offset in the flat gradient buffer from which every gradient is final when `between` runs (split form): the last encoder
         layer's parameters and, behind them in forward order, the classifier head's."""

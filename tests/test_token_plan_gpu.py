@@ -173,3 +173,150 @@ def test_dropout_gradient_consistency_on_token_plan():
         an = float((g * d).sum())
         assert abs(fd - an) < 0.05 * abs(an) + 1e-5, (name, fd, an, l0)
     step.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# One capture, many batches: the real use of the step (code/Raindrop.py:310-324 draws a new batch every iteration; INTEGRATION.md
+# "static training step": `DeviceDataset.batch(idx, out=batch); step.run()`).  New `lengths` change the plan INSIDE the captured
+# graph (rd_step_begin): live-row count, rank order, block height and input slack all move, and rows beyond the new M_live still
+# hold the previous batch's values.  Every result must equal a FRESH step built on that batch alone.
+# ------------------------------------------------------------------------------------------------------------------------------
+REPLAY_SEQ = ["random", "full_length", "short", "min_length", "first_time_zero", "one_long", "random"]
+
+
+def _seq_batch(cfg, B, case, seed):
+    if case == "short":                                         # fewer live rows than "random": lengths ~ U[2, T/4]
+        batch = synth.make_batch(cfg, B, seed=seed + 1)
+        T = cfg["max_len"]
+        cut = torch.from_numpy(np.random.default_rng(seed).integers(2, T // 4 + 1, size=B))
+        dead = torch.arange(T)[:, None] >= cut[None, :]
+        batch["times"][dead] = 0
+        batch["src"][dead] = 0
+        batch["lengths"] = torch.sum(batch["times"] > 0, dim=0)
+        return batch
+    return _case_batch(cfg, B, case, seed)
+
+
+def _make_step(cfg, gs, dv, token_plan, use_graph, p_drop, split=False, seed_params=7):
+    from raindrop_amd.step import TrainStep
+    m = build_ours(cfg, gs, DEV, seed_params).train()
+    m.dropout.p = p_drop
+    live = synth.live_parameter_names(cfg)
+    named = dict(m.named_parameters())
+    flat = dp.FlatGradAllReduce([(n, named[n]) for n in live])
+    step = TrainStep(m, flat, dv, use_graph=use_graph, token_plan=token_plan, autotune=False, split=split)
+    return step, named, live
+
+
+def _snapshot(step, named, live):
+    torch.cuda.synchronize()
+    return (float(step.loss), step.logits.cpu().numpy().copy(), {n: named[n].grad.detach().cpu().numpy().copy() for n in live})
+
+
+def _load_into(dv, batch):
+    for k, v in batch.items():
+        if v is not None:
+            dv[k].copy_(v.to(dv[k].dtype))
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_captured_plan_graph_replayed_on_new_batches(split):
+    """Capture ONCE on batch A, then copy batches with more / fewer / minimal live rows, a slack-1 batch and A again into the SAME
+    buffers and replay.  Reference: a fresh padded-layout TrainStep on each batch (dropout off): loss 2e-6, logits 2e-6,
+    every gradient 2e-5 of its max-norm.  `split`: the two-graph data-parallel form (graph A | graph B)."""
+    cfg = synth.make_config("P19")
+    gs = synth.make_structure(cfg, "sparse")
+    B = 256
+    batches = [_seq_batch(cfg, B, c, seed=61 + 3 * i) for i, c in enumerate(REPLAY_SEQ)]
+    batches[-1] = batches[0]                                                # the first batch again at the end
+    dv = {k: (None if v is None else v.to(DEV).clone()) for k, v in batches[0].items()}
+    step, named, live = _make_step(cfg, gs, dv, True, True, 0.0, split=split)
+    assert step.plan is not None and step.graph is not None and (step.graph_b is not None) == split
+    got, mlives = [], []
+    for bt in batches:
+        _load_into(dv, bt)
+        step.run()
+        got.append(_snapshot(step, named, live))
+        mlives.append(int(step.plan[0]))
+    step.close()
+    T = cfg["max_len"]
+    for bt, ml in zip(batches, mlives):
+        assert ml == int(torch.clamp(bt["lengths"], 0, T).sum())
+    assert mlives[1] > mlives[0] > mlives[2] > mlives[3]                   # more, fewer, minimal live rows than the capture batch
+    assert got[-1][0] == got[0][0] and np.array_equal(got[-1][1], got[0][1])      # A again: the same bits as the first time
+    for n in live:
+        assert np.array_equal(got[-1][2][n], got[0][2][n]), n
+    for i, bt in enumerate(batches[:-1]):
+        dref = {k: (None if v is None else v.to(DEV)) for k, v in bt.items()}
+        ref, rnamed, _ = _make_step(cfg, gs, dref, False, False, 0.0)
+        ref.run()
+        rl, rg, rgr = _snapshot(ref, rnamed, live)
+        ref.close()
+        l, g, gr = got[i]
+        assert abs(l - rl) < 2e-6 * max(1.0, abs(rl)), (REPLAY_SEQ[i], l, rl)
+        assert np.abs(g - rg).max() < 2e-6, (REPLAY_SEQ[i], float(np.abs(g - rg).max()))
+        for n in live:
+            assert _rel(gr[n], rgr[n]) < 2e-5, (REPLAY_SEQ[i], n, _rel(gr[n], rgr[n]))
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_captured_plan_graph_replay_with_dropout_equals_fresh_capture(split):
+    """Dropout ON: the masks are functions of (seed, seed cell, compact row), so a replay on batch k with the cell at value c must
+    give the SAME BITS as a fresh token-plan step whose first run on batch k happens with the cell at c -- whatever the replayed
+    step's buffers held before (rows beyond the new M_live keep the previous batch's values)."""
+    cfg = synth.make_config("P19")
+    gs = synth.make_structure(cfg, "ones")
+    B = 128
+    seq = ["full_length", "random", "short", "min_length", "first_time_zero", "random"]
+    batches = [_seq_batch(cfg, B, c, seed=17 + 5 * i) for i, c in enumerate(seq)]
+    dv = {k: (None if v is None else v.to(DEV).clone()) for k, v in batches[0].items()}
+    step, named, live = _make_step(cfg, gs, dv, True, True, 0.2, split=split)
+    got = []
+    for k, bt in enumerate(batches):
+        _load_into(dv, bt)
+        step.seed_cell.fill_(1000 + k)                                      # the graph bumps it by one before its first kernel
+        step.run()
+        got.append(_snapshot(step, named, live))
+    step.close()
+    assert len({g[0] for g in got}) == len(got)
+    for k, bt in enumerate(batches):
+        dref = {kk: (None if v is None else v.to(DEV)) for kk, v in bt.items()}
+        ref, rnamed, _ = _make_step(cfg, gs, dref, True, False, 0.2)      # eager token-plan step on fresh (zeroed) buffers
+        ref.seed_cell.fill_(1000 + k)
+        ref.run()
+        rl, rg, rgr = _snapshot(ref, rnamed, live)
+        ref.close()
+        l, g, gr = got[k]
+        assert np.isfinite(l) and l == rl, (seq[k], l, rl)
+        assert np.array_equal(g, rg), seq[k]
+        for n in live:
+            assert np.array_equal(gr[n], rgr[n]), (seq[k], n, _rel(gr[n], rgr[n]))
+
+
+POISON_GROUPS = ["z", "x", "dx", "enc_saved", "enc_ws", "k1_saved", "k1_ws", "head"]
+
+
+@pytest.mark.parametrize("group", POISON_GROUPS)
+def test_token_plan_step_ignores_stale_buffer_contents(group):
+    """A diverged step can leave inf / NaN in rows that a later, shorter batch does not rewrite (rows at or beyond M_live; the
+    padded layout rewrote every row every step).  Fill each scratch / saved buffer group of the step with NaN bit patterns
+    (fp32 NaN = bf16 NaN pair) between two runs on the same batch: the second run must give the same bits as the first."""
+    cfg = synth.make_config("P19")
+    gs = synth.make_structure(cfg, "ones")
+    batch = _seq_batch(cfg, 96, "random", seed=5)
+    dv = {k: (None if v is None else v.to(DEV).clone()) for k, v in batch.items()}
+    step, named, live = _make_step(cfg, gs, dv, True, True, 0.0)
+    step.run()
+    first = _snapshot(step, named, live)
+    bufs = {"z": [step.z], "x": step.x[1:], "dx": step.dx, "enc_saved": step.enc_saved, "enc_ws": [step.enc_ws],
+            "k1_saved": [step.k1_saved], "k1_ws": [step.k1_ws],
+            "head": [t for t in (step.head_ws, step.feat, step.dfeat, step.hid, step.dhid) if t is not None]}[group]
+    for t in bufs:
+        t.view(torch.uint8).reshape(-1)[: t.numel() * t.element_size() // 4 * 4].view(torch.int32).fill_(0x7FC07FC0)
+    step.run()
+    second = _snapshot(step, named, live)
+    step.close()
+    assert np.isfinite(second[0]) and second[0] == first[0], (group, first[0], second[0])
+    assert np.array_equal(second[1], first[1]), group
+    for n in live:
+        assert np.array_equal(second[2][n], first[2][n]), (group, n)
