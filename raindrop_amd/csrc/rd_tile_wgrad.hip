@@ -44,6 +44,9 @@ struct TwArgs { TwProb p[4]; int n, S; const __bf16* ones; TwColsum cs[2]; int n
 
 struct Frag { bf16x8 ah[TW_NA], al[TW_NA], bh[TW_NB], bl[TW_NB]; };
 
+// ONE: the single-product arithmetic mode (RD_PREC_BF16: hi * hi only).  The lo halves of the tiles are neither read nor multiplied --
+// half the operand bytes of a kernel that is a pure stream, one third of its MFMAs.
+template <bool ONE>
 __global__ __launch_bounds__(TW_THR) void k_twg(TwArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,13 +85,13 @@ __global__ __launch_bounds__(TW_THR) void k_twg(TwArgs a) {
     for (int t = 0; t < TW_NA; ++t) {
       const __bf16* qa = ghost ? zt : pa[t] + s * stepA;
       f.ah[t] = *reinterpret_cast<const bf16x8*>(qa);
-      f.al[t] = *reinterpret_cast<const bf16x8*>(qa + TILE);
+      if (!ONE) f.al[t] = *reinterpret_cast<const bf16x8*>(qa + TILE);
     }
 #pragma unroll
     for (int t = 0; t < TW_NB; ++t) {
       const __bf16* qb = pb[t] + s * sb[t];
       f.bh[t] = *reinterpret_cast<const bf16x8*>(qb);
-      f.bl[t] = *reinterpret_cast<const bf16x8*>(qb + TILE);
+      if (!ONE) f.bl[t] = *reinterpret_cast<const bf16x8*>(qb + TILE);
     }
   };
   f32x4 acc[TW_NA][TW_NB];
@@ -97,16 +100,18 @@ __global__ __launch_bounds__(TW_THR) void k_twg(TwArgs a) {
 #pragma unroll
     for (int ki = 0; ki < TW_NB; ++ki) acc[ni][ki] = (f32x4){0.f, 0.f, 0.f, 0.f};
   auto mma = [&](const Frag& f) {
+    if (!ONE) {
 #pragma unroll
-    for (int ni = 0; ni < TW_NA; ++ni)
+      for (int ni = 0; ni < TW_NA; ++ni)
 #pragma unroll
-      for (int ki = 0; ki < TW_NB; ++ki)
-        acc[ni][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.al[ni], f.bh[ki], acc[ni][ki], 0, 0, 0);
+        for (int ki = 0; ki < TW_NB; ++ki)
+          acc[ni][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.al[ni], f.bh[ki], acc[ni][ki], 0, 0, 0);
 #pragma unroll
-    for (int ni = 0; ni < TW_NA; ++ni)
+      for (int ni = 0; ni < TW_NA; ++ni)
 #pragma unroll
-      for (int ki = 0; ki < TW_NB; ++ki)
-        acc[ni][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ah[ni], f.bl[ki], acc[ni][ki], 0, 0, 0);
+        for (int ki = 0; ki < TW_NB; ++ki)
+          acc[ni][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ah[ni], f.bl[ki], acc[ni][ki], 0, 0, 0);
+    }
 #pragma unroll
     for (int ni = 0; ni < TW_NA; ++ni)
 #pragma unroll
@@ -222,7 +227,7 @@ size_t tile_wgrad_part_floats(int N, int K) {
 bool tile_wgrad_ok(int N, int K) {
   const char* e = getenv("RD_TILE_WGRAD");           // read per call (tests compare both paths in one process)
   const bool on = !(e && atoi(e) == 0);
-  return on && precision() == RD_PREC_BF16X3 && (K % 4) == 0 && N >= 16 && K >= 16;
+  return on && precision() != RD_PREC_FP32 && (K % 4) == 0 && N >= 16 && K >= 16;
 }
 
 struct TileWgradJob { const void *tA, *tB; float* part; float *dW, *db; int N, K; };
@@ -244,8 +249,13 @@ int launch_tile_wgrad(long M, int njobs, const TileWgradJob* jobs, const void* o
     P.wg0 = wg; wg += 8 * P.nmem;
     P.q0 = q; P.nq = j.N * (P.ldp >> 2); q += (P.nq + 511) / 512 * 512;
   }
-  RD_LDS_ATTR(k_twg, TW_LDS);
-  hipLaunchKernelGGL(k_twg, dim3(wg), dim3(TW_THR), TW_LDS, st, a);
+  if (precision() == RD_PREC_BF16) {
+    RD_LDS_ATTR(k_twg<true>, TW_LDS);
+    hipLaunchKernelGGL(k_twg<true>, dim3(wg), dim3(TW_THR), TW_LDS, st, a);
+  } else {
+    RD_LDS_ATTR(k_twg<false>, TW_LDS);
+    hipLaunchKernelGGL(k_twg<false>, dim3(wg), dim3(TW_THR), TW_LDS, st, a);
+  }
   int rc = check_launch("k_twg");
   if (rc) return rc;
   if (ncs < 0 || ncs > 2) return fail(RD_EINVAL, "tile_wgrad: 0..2 column-sum jobs");

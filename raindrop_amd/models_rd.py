@@ -102,10 +102,16 @@ class Raindrop(nn.Module):
         self.n_classes, self.d_static = n_classes, d_static
         self._graph_cache = None
         self._drop_calls = 0
-        if 36 * self.dim + 36 != d_model + 36:
-            raise _lib.RaindropHipError("Raindrop (legacy): d_model (%d) must be a multiple of 36 -- upstream concatenates a "
+        # upstream hard-wires 36 everywhere (code/models_rd.py:75-84: TransformerConv(in_channels=36), Linear(d_inp, 36), a 36-wide
+        # encoding) while forward slices src[:, :, :d_inp]: only d_inp = 36 is a consistent model
+        if d_inp != 36:
+            raise _lib.RaindropHipError("Raindrop (legacy): d_inp = %d is unsupported (RD_EUNSUPPORTED) -- upstream hard-wires 36 "
+                                        "sensors (code/models_rd.py:75-84: TransformerConv(in_channels=36), Linear(d_inp, 36)); "
+                                        "use Raindrop_v2 for other sensor counts" % d_inp)
+        if d_inp * self.dim != d_model:
+            raise _lib.RaindropHipError("Raindrop (legacy): d_model (%d) must be a multiple of d_inp (%d) -- upstream concatenates a "
                                         "[.., 36*int(d_model/d_inp)] graph output with a 36-wide encoding for an encoder of "
-                                        "width d_model + 36 (code/models_rd.py:75,84,168)" % d_model)
+                                        "width d_model + 36 (code/models_rd.py:75,84,168)" % (d_model, d_inp))
         self.init_weights()
 
     def init_weights(self):

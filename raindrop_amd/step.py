@@ -183,7 +183,8 @@ class TrainStep:
 
     def _body(self, part=None):
         """Enqueue one forward + loss + backward on the current stream (no host sync).  part 'a' / 'b': the two halves of the split
-        form (see __init__); None: everything."""
+        form (see __init__); 'begin' / 'k1f' / 'mid' / 'k1b': the step cut around the message-passing stage (capture_segments:
+        bench.py times the K1 launches as they run INSIDE the step); None: everything."""
         if part == "b":
             return self._body_tail(self.nl - 2)
         m, b, P, G, sp = self.model, self.batch, self.P, self.G, self.sp
@@ -194,23 +195,31 @@ class TrainStep:
         W1, b1 = P["ob_propagation.lin_value.weight"], P["ob_propagation.lin_value.bias"]
         W2, b2 = P["ob_propagation_layer2.lin_value.weight"], P["ob_propagation_layer2.lin_value.bias"]
         ssum = self.graph_info["ssum"]
-        prep = self.prep_enc or self.prep_k1
-        prep_args = (self.nl if self.prep_enc else 0, self._prep_w, self._prep_saved, self._prep_bytes,
-                     _p(W1) if self.prep_k1 else None, _p(W2) if self.prep_k1 else None, _p(self.k1_saved), self.k1_saved.numel(), st)
-        cell = _p(self.seed_cell) if self.p_drop > 0.0 else None
-        if self.plan is not None and prep and self.one_begin:             # plan + seed bump + every weight split: ONE launch
-            c("rd_step_begin", sp, _p(b["lengths"]), _p(self.plan), cell, 1, *prep_args)
-        else:
-            if self.plan is not None:                                      # lengths -> token plan (+ the seed bump: one launch)
-                c("rd_token_plan", sp, _p(b["lengths"]), _p(self.plan), cell, 1, st)
-            elif self.p_drop > 0.0:
-                c("rd_seed_cell_advance", _p(self.seed_cell), 1, st)       # fresh masks per replay
-            if prep:
-                c("rd_step_prepare", sp, *prep_args)
+        if part == "k1b":
+            return self._k1_bwd(self.dx[self.nl % 2], st)
+        if part in (None, "a", "begin"):
+            prep = self.prep_enc or self.prep_k1
+            prep_args = (self.nl if self.prep_enc else 0, self._prep_w, self._prep_saved, self._prep_bytes,
+                         _p(W1) if self.prep_k1 else None, _p(W2) if self.prep_k1 else None, _p(self.k1_saved), self.k1_saved.numel(), st)
+            cell = _p(self.seed_cell) if self.p_drop > 0.0 else None
+            if self.plan is not None and prep and self.one_begin:             # plan + seed bump + every weight split: ONE launch
+                c("rd_step_begin", sp, _p(b["lengths"]), _p(self.plan), cell, 1, *prep_args)
+            else:
+                if self.plan is not None:                                      # lengths -> token plan (+ the seed bump: one launch)
+                    c("rd_token_plan", sp, _p(b["lengths"]), _p(self.plan), cell, 1, st)
+                elif self.p_drop > 0.0:
+                    c("rd_seed_cell_advance", _p(self.seed_cell), 1, st)       # fresh masks per replay
+                if prep:
+                    c("rd_step_prepare", sp, *prep_args)
+            if part == "begin":
+                return
         # ---------------- forward ----------------
-        c("rd_sensor_stage_fwd_prepared" if self.prep_k1 else "rd_sensor_stage_fwd", sp, _p(b["src"]), _p(b["times"]), _p(b["lengths"]), _p(self.ts), _p(P["R_u"]), _p(W1),
-          _p(b1), _p(W2), _p(b2), _p(ssum), self.p_drop, self.seed, _p(self.z), _p(self.mask), _p(self.k1_saved),
-          self.k1_saved.numel(), st)
+        if part in (None, "a", "k1f"):
+            c("rd_sensor_stage_fwd_prepared" if self.prep_k1 else "rd_sensor_stage_fwd", sp, _p(b["src"]), _p(b["times"]), _p(b["lengths"]), _p(self.ts), _p(P["R_u"]), _p(W1),
+              _p(b1), _p(W2), _p(b2), _p(ssum), self.p_drop, self.seed, _p(self.z), _p(self.mask), _p(self.k1_saved),
+              self.k1_saved.numel(), st)
+            if part == "k1f":
+                return
         for i in range(self.nl):
             c("rd_encoder_layer_fwd", sp, i | (0x10000 if self.prep_enc else 0), _p(self.x[i]), _p(self.mask), ctypes.byref(self.enc_w[i]), self.p_drop,
               self.seed, _p(self.x[i + 1]), _p(self.enc_saved[i]), self.enc_saved[i].numel(), _p(self.enc_ws),
@@ -229,28 +238,31 @@ class TrainStep:
         if part == "a":                                   # the last layer's backward closes part A
             self._enc_bwd(self.nl - 1, cur, self.dx[1], st)
             return
-        self._body_tail(self.nl - 1, cur)
+        self._body_tail(self.nl - 1, cur, k1=(part != "mid"))
 
     def _enc_bwd(self, i, cur, nxt, st):
         self._call("rd_encoder_layer_bwd", self.sp, i, _p(self.x[i]), _p(self.mask), ctypes.byref(self.enc_w[i]), self.p_drop,
                    self.seed, _p(self.enc_saved[i]), self.enc_saved[i].numel(), _p(cur), _p(nxt), ctypes.byref(self.enc_g[i]),
                    _p(self.enc_ws), self.enc_ws.numel(), st)
 
-    def _body_tail(self, top, cur=None):
-        """Backward of encoder layers top .. 0 and of the sensor stage; the entry gradient is dx[0] for the top layer of the stack
-        (written by the head) and alternates between the two buffers from there."""
-        b, P, G, sp = self.batch, self.P, self.G, self.sp
+    def _body_tail(self, top, cur=None, k1=True):
+        """Backward of encoder layers top .. 0 and (k1) of the sensor stage; the entry gradient is dx[0] for the top layer of the
+        stack (written by the head) and alternates between the two buffers from there."""
         st = ops._stream()
-        D = self.D
         if cur is None:                                   # layer `top` reads what layer top + 1 wrote
             cur = self.dx[(self.nl - 1 - top) % 2]
         for i in range(top, -1, -1):
             nxt = self.dx[1] if cur is self.dx[0] else self.dx[0]
             self._enc_bwd(i, cur, nxt, st)
             cur = nxt
+        if k1:
+            self._k1_bwd(cur, st)
+
+    def _k1_bwd(self, cur, st):
+        b, P, G, sp = self.batch, self.P, self.G, self.sp
         W1, W2 = P["ob_propagation.lin_value.weight"], P["ob_propagation_layer2.lin_value.weight"]
         self._call("rd_msgpass_bwd", sp, _p(b["src"]), _p(P["R_u"]), _p(W1), _p(W2), _p(self.graph_info["ssum"]), self.p_drop,
-                   _p(self.k1_saved), self.k1_saved.numel(), _p(self.z), _p(cur), D, _p(G["ob_propagation.lin_value.weight"]),
+                   _p(self.k1_saved), self.k1_saved.numel(), _p(self.z), _p(cur), self.D, _p(G["ob_propagation.lin_value.weight"]),
                    _p(G["ob_propagation.lin_value.bias"]), _p(G["ob_propagation_layer2.lin_value.weight"]),
                    _p(G["ob_propagation_layer2.lin_value.bias"]), _p(G["R_u"]), _p(self.k1_ws), self.k1_ws.numel(), st)
 
@@ -380,6 +392,31 @@ class TrainStep:
             with torch.no_grad(), torch.cuda.graph(self.graph_b, pool=self.graph.pool()):
                 self._body("b")
         self._with_cell(cap)
+
+    def capture_segments(self, parts=("begin", "k1f", "mid", "k1b")):
+        """The same step as consecutive hipGraphs, one per part (measurement only: bench.py brackets the 'k1f' / 'k1b' replays with
+        HIP events, so the message-passing launches are timed with the cache state, clocks and neighbours they have in the step).
+        Replaying the graphs in order is one step."""
+        graphs = []
+
+        def cap():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(2):
+                    for pt in parts:
+                        self._body(pt)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            pool = None
+            for pt in parts:
+                g = torch.cuda.CUDAGraph()
+                with torch.no_grad(), (torch.cuda.graph(g) if pool is None else torch.cuda.graph(g, pool=pool)):
+                    self._body(pt)
+                pool = g.pool()
+                graphs.append(g)
+        self._with_cell(cap)
+        return graphs
 
     # ------------------------------------------------------------------------------------------
     def _early_names(self):

@@ -251,3 +251,65 @@ def test_rccl_one_rank_collectives_between_graph_replays():
     mp.spawn(_rccl_worker, args=(world, port, ret), nprocs=1, join=True)
     (l0, g0), (l1, g1) = ret[0]
     assert l0 == l1 and np.array_equal(g0, g1)
+
+
+def _tuned_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from raindrop_amd import dp, synth
+    from raindrop_amd.step import TrainStep
+    from tests.helpers import build_ours
+    dev = torch.device("cuda", 0)
+    cfg = synth.make_config("P19")
+    m = build_ours(cfg, synth.make_structure(cfg, "sparse"), dev, 21).train()
+    named = dict(m.named_parameters())
+    flat = dp.FlatGradAllReduce([(n, named[n]) for n in synth.live_parameter_names(cfg)], n_buckets=2)
+    full = synth.make_batch(cfg, 64, seed=33)
+    b = {k: (None if v is None else v.to(dev)) for k, v in dp.shard_batch(full, rank, world).items()}
+    ts = TrainStep(m, flat, b, p_drop=0.0, use_graph=True, autotune=True)      # split form + tuner: both on by default at N > 1
+    loss = float(ts.run_allreduce())
+    torch.cuda.synchronize()
+    ret[rank] = (ts.tuned_rows32, ts.tuned_waves16, ts.split, loss, flat.flat.detach().cpu().numpy().copy())
+    ts.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_tune_to_the_same_kernel_variants():
+    """Under torch.distributed the capture-time tuner sums every variant's time over the ranks before choosing: both ranks must end
+    up with the SAME (rows32, waves16) -- the step is then the same program on every rank and the one a single process would tune
+    to -- and the all-reduced gradients are bit-identical."""
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_tuned_worker, args=(world, port, ret), nprocs=world, join=True)
+    a, b = ret[0], ret[1]
+    assert a[0] is not None and a[1] is not None and a[2] and b[2]
+    assert (a[0], a[1]) == (b[0], b[1]), (a[:2], b[:2])
+    assert a[0] in (15, 0, 3, 12) and a[1] in (12, 15)
+    assert np.array_equal(a[4], b[4])
+
+
+def test_train_step_refuses_what_it_does_not_implement():
+    """TrainStep implements the default branch and (split form) relies on the forward order of the flat buffer: both are checked."""
+    from raindrop_amd import _lib, dp, synth
+    from raindrop_amd.step import TrainStep
+    from tests.helpers import build_ours
+    dev = torch.device("cuda", 0)
+    cfg = synth.make_config("P19")
+    gs = synth.make_structure(cfg, "sparse")
+    b = {k: (None if v is None else v.to(dev)) for k, v in synth.make_batch(cfg, 8, seed=3).items()}
+    m = build_ours(cfg, gs, dev, 21, use_beta=True).train()
+    named = dict(m.named_parameters())
+    flat = dp.FlatGradAllReduce([(n, named[n]) for n in synth.live_parameter_names(cfg)])
+    with pytest.raises(_lib.RaindropHipError, match="use_beta"):
+        TrainStep(m, flat, b, use_graph=False)
+    m = build_ours(cfg, gs, dev, 21).train()
+    named = dict(m.named_parameters())
+    live = set(synth.live_parameter_names(cfg))
+    wrong = [(n, p) for n, p in m.named_parameters() if n in live]          # registration order: R_u, ob_propagation* behind the encoder
+    flat = dp.FlatGradAllReduce(wrong)
+    with pytest.raises(_lib.RaindropHipError, match="FORWARD order"):
+        TrainStep(m, flat, b, use_graph=False, split=True)
+    TrainStep(m, flat, b, use_graph=False, split=False).run()               # the one-graph form takes any order
+    torch.cuda.synchronize()
