@@ -18,6 +18,10 @@
 //   [.. + B]          order[r]              sample at rank r
 //   [.. + B]          len[r]                clamp(lengths[order[r]], 0, T)
 //   [.. + B]          cnt[t], t = 0..T      number of samples with len > t
+//   [.. + T + 1]      coff[r], r = 0..B     first 32-row chunk of rank r in the PER-SAMPLE chunk space (rank r owns ceil(len_r / 32)
+//                                           chunks; coff[B] = their total, also at [5]): the row order in which the fused attention
+//                                           kernels (rd_attnfuse.hip) export x and dqkv as weight-gradient row tiles -- a sample's
+//                                           rows start a chunk there, so a workgroup that owns one sample writes whole tile parts
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -27,14 +31,15 @@ namespace rd {
 namespace plan {
 
 constexpr int HDR = 8;
-constexpr int I_MLIVE = 0, I_S32 = 1, I_B = 2, I_T = 3, I_SLACK = 4;
+constexpr int I_MLIVE = 0, I_S32 = 1, I_B = 2, I_T = 3, I_SLACK = 4, I_SCHUNK = 5;
 
 __host__ __device__ inline int off_base() { return HDR; }
 __host__ __device__ inline int rank_base(int B) { return HDR + B + 1; }
 __host__ __device__ inline int order_base(int B) { return HDR + 2 * B + 1; }
 __host__ __device__ inline int len_base(int B) { return HDR + 3 * B + 1; }
 __host__ __device__ inline int cnt_base(int B) { return HDR + 4 * B + 1; }
-__host__ __device__ inline size_t ints(int B, int T) { return (size_t)HDR + 4 * (size_t)B + 1 + T + 1; }
+__host__ __device__ inline int coff_base(int B, int T) { return HDR + 4 * B + 1 + T + 1; }
+__host__ __device__ inline size_t ints(int B, int T) { return (size_t)HDR + 5 * (size_t)B + 2 + T + 1; }
 
 
 #if defined(__HIPCC__)
@@ -111,7 +116,15 @@ __device__ inline void token_plan_body(const int64_t* __restrict__ lengths, int3
     if (r == B) { p[plan::I_MLIVE] = s; p[plan::I_S32] = (s + 31) >> 5; }
   }
   for (int t = tid; t <= T; t += nthr) cntg[t] = cnt[t];
-  if (tid == 0) { p[plan::I_B] = B; p[plan::I_T] = T; p[plan::I_SLACK] = 0; p[5] = 0; p[6] = 0; p[7] = 0; }
+  // coff[r] = sum over the r longest samples of ceil(len / 32) = sum_c min(r, cnt[32 c])   (a sample has a chunk c iff len > 32 c)
+  int* coff = p + plan::coff_base(B, T);
+  for (int r = tid; r <= B; r += nthr) {
+    int s = 0;
+    for (int t = 0; t < T; t += 32) s += min(r, cnt[t]);
+    coff[r] = s;
+    if (r == B) p[plan::I_SCHUNK] = s;
+  }
+  if (tid == 0) { p[plan::I_B] = B; p[plan::I_T] = T; p[plan::I_SLACK] = 0; p[6] = 0; p[7] = 0; }
 }
 #endif
 

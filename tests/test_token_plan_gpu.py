@@ -28,7 +28,8 @@ def _plan_ref(lengths, T):
     lenr = L[order]
     off = np.concatenate([[0], np.cumsum(lenr)])
     cnt = np.array([(L > t).sum() for t in range(T + 1)])
-    return dict(off=off, rank=rank, order=order, lenr=lenr, cnt=cnt, mlive=int(off[-1]))
+    coff = np.concatenate([[0], np.cumsum((lenr + 31) // 32)])
+    return dict(off=off, rank=rank, order=order, lenr=lenr, cnt=cnt, coff=coff, mlive=int(off[-1]))
 
 
 @pytest.mark.parametrize("B,T,seed", [(256, 60, 0), (1, 60, 1), (37, 60, 2), (5, 16, 3), (1000, 60, 4)])
@@ -53,7 +54,8 @@ def test_token_plan_bit_exact(B, T, seed):
     assert np.array_equal(p[o:o + B], ref["rank"]); o += B
     assert np.array_equal(p[o:o + B], ref["order"]); o += B
     assert np.array_equal(p[o:o + B], ref["lenr"]); o += B
-    assert np.array_equal(p[o:o + T + 1], ref["cnt"])
+    assert np.array_equal(p[o:o + T + 1], ref["cnt"]); o += T + 1
+    assert np.array_equal(p[o:o + B + 1], ref["coff"]) and p[5] == ref["coff"][-1]
 
 
 def _run_step(cfg, gs, batch, token_plan, use_graph, p_drop=0.0, steps=1, seed_params=7):
