@@ -62,7 +62,7 @@ struct RowGemmArgs {
 
 // one weight matrix -> hi/lo planes; transpose != 0 writes split(W^T): rows k, cols n
 struct SplitJob { const float* W; int N, K, transpose; __bf16* hi; __bf16* lo; int rows, cols_p; };
-constexpr int WS_MAXJOBS = 24, WS_MAXONES = 4;
+constexpr int WS_MAXJOBS = 48, WS_MAXONES = 4;
 struct SplitJobs { SplitJob j[WS_MAXJOBS]; int n; __bf16* ones[WS_MAXONES];   // ones: constant tiles of the weight-gradient streams (or null)
                    // optional: the step's token plan (rd_plan.h) by the workgroup (0, n) of the same launch (rd_step_begin)
                    const int64_t* plan_lengths; int32_t* plan_out; int plan_B, plan_T; uint64_t* seed_cell; uint64_t seed_delta; };

@@ -16,6 +16,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "rd_common.h"
 #include "rd_plan.h"
 #include "rd_rng.h"
@@ -27,7 +29,9 @@ size_t rowgemm_plane_elems(int rows, int cols);
 int launch_wsplit(int njobs, const float* const* W, const int* N, const int* K, const int* transpose, __bf16* const* hi,
                   __bf16* const* lo, void* ones, hipStream_t st);
 // weight gradients from exported row tiles (rd_tile_wgrad.hip)
-struct TileWgradJob { const void *tA, *tB; float* part; float *dW, *db; int N, K; };
+// s32 / S: this job's own chunk count (device / bound) when its row tiles live in another chunk space than the launch's; hd != 0: the
+// A tiles' columns are in the fused attention's head-padded layout ((which, head) blocks of hdp columns, hd of them real)
+struct TileWgradJob { const void *tA, *tB; float* part; float *dW, *db; int N, K; const int32_t* s32; int S; int hd, hdp, H, D; };
 size_t tile_elems(long M, int cols);
 size_t tile_wgrad_ones_elems();
 size_t tile_wgrad_part_floats(int N, int K);
@@ -38,6 +42,17 @@ int launch_tile_wgrad(long M, int njobs, const TileWgradJob* jobs, const void* o
 void rowgemm_export_next(void* tiles);
 void rowgemm_set_mlive(const int32_t* p);
 // row-local chains of the layer as one launch per direction (rd_encfuse.hip)
+bool attnfuse_ok(int T, int D, int H, int hd);
+size_t attnfuse_wf_elems(int H);
+size_t attnfuse_wb_elems(int H);
+int attnfuse_split_specs(const float* in_proj_w, int D, int H, int hd, void* wf, void* wb, WsplitSpec* out);
+int attnfuse_padded_cols(int H);
+int attnfuse_nth();
+int launch_attn_fused_fwd(const float* x, const void* wf, const float* bias, const int32_t* plan, int T, int B, int D, int H, int hd,
+                          float p_drop, uint64_t seed, uint32_t site, float* out, float* lse, hipStream_t st);
+int launch_attn_fused_bwd(const float* x, const void* wf, const void* wb, const float* bias, const int32_t* plan, int T, int B, int D, int H,
+                          int hd, float p_drop, uint64_t seed, uint32_t site, const float* out, const float* lse, const float* dout,
+                          const float* ds1, float* dx, void* xt, void* dt, hipStream_t st);
 bool encfuse_ok(int D, int H);
 int launch_enc_post_fwd(long M, int D, int H, const float* attn, const float* x, const void* Wo, const void* W1, const void* W2,
                         const float* bo, const float* b1, const float* b2, const float* g1, const float* be1, const float* g2,
@@ -2361,8 +2376,12 @@ static bool attn_big(const EncDims& e) {
   return e.Hd > 96 || (v && atoi(v) != 0);
 }
 
+// chunks of the per-sample chunk space (rd_plan.h: coff): every sample up to ceil(T / 32)
+static size_t attn_chunks(const EncDims& e) { return (size_t)e.B * cdiv(e.T, 32); }
+
 struct EncSaved { float *qkv, *attn, *lse, *s1, *st1, *x1, *h, *s2, *st2; __bf16* pl[8][2];
                   __bf16* xt[4]; __bf16* ones;        // row tiles of x, attn, x1, h (operands of the weight-gradient stream)
+                  __bf16 *afw, *abw;                  // fused attention (rd_attnfuse.hip): per-head in_proj tiles, forward / input-gradient form
                   float *pbig, *pdbig;                // wide heads only: P and dropout(P), [B*H][T][T] each
                   size_t bytes; };
 // weight tiles kept from forward to backward: 0 in_proj, 1 out_proj, 2 lin1, 3 lin2, 4 out_proj^T, 5 lin2^T, 6 lin1^T, 7 in_proj^T
@@ -2378,8 +2397,14 @@ EncSaved carve_saved(const EncDims& e, void* base) {
   for (int i = 0; i < 8; ++i)
     for (int h = 0; h < 2; ++h) v.pl[i][h] = (__bf16*)take((rowgemm_plane_elems(prow[i], pcol[i]) + 1) / 2);
   const int xcols[4] = {e.D, e.D, e.D, e.nhid};
-  for (int i = 0; i < 4; ++i) v.xt[i] = (__bf16*)take((tile_elems(e.M, xcols[i]) + 1) / 2);
+  for (int i = 0; i < 4; ++i) {
+    size_t n = tile_elems(e.M, xcols[i]);
+    if (i == 0) n = std::max(n, attn_chunks(e) * (size_t)cdiv(e.D, 16) * 1024);     // x tiles in the per-sample chunk space (fused attention)
+    v.xt[i] = (__bf16*)take((n + 1) / 2);
+  }
   v.ones = (__bf16*)take((tile_wgrad_ones_elems() + 1) / 2);
+  v.afw = (__bf16*)take((attnfuse_wf_elems(e.H) + 1) / 2);
+  v.abw = (__bf16*)take((attnfuse_wb_elems(e.H) + 1) / 2);
   const size_t big = attn_big(e) ? (size_t)e.B * e.H * e.T * e.T : 0;
   v.pbig = take(big); v.pdbig = take(big);
   v.bytes = off;
@@ -2408,8 +2433,13 @@ EncWs carve_ws(const EncDims& e, void* base) {
   w.splitk = take(sk);
   w.colsum = take(colsum_ws_floats((int)e.M, 3 * e.D > e.nhid ? 3 * e.D : e.nhid));
   const int dcols[4] = {e.D, e.nhid, e.D, 3 * e.D};
-  for (int i = 0; i < 4; ++i) w.dt[i] = (__bf16*)take((tile_elems(e.M, dcols[i]) + 1) / 2);
-  const int pn[4] = {e.D, e.nhid, e.D, 3 * e.D}, pk[4] = {e.nhid, e.D, e.D, e.D};
+  const int padc = attnfuse_padded_cols(e.H);                       // head-padded dqkv columns of the fused attention's export
+  for (int i = 0; i < 4; ++i) {
+    size_t n = tile_elems(e.M, dcols[i]);
+    if (i == 3) n = std::max(n, attn_chunks(e) * (size_t)(padc / 16) * 1024);
+    w.dt[i] = (__bf16*)take((n + 1) / 2);
+  }
+  const int pn[4] = {e.D, e.nhid, e.D, std::max(3 * e.D, padc)}, pk[4] = {e.nhid, e.D, e.D, e.D};
   for (int i = 0; i < 4; ++i) w.twpart[i] = take(tile_wgrad_part_floats(pn[i], pk[i]));
   w.dsbig = take(attn_big(e) ? (size_t)e.B * e.H * e.T * e.T : 0);
   w.bytes = off;
@@ -2498,12 +2528,16 @@ static int enc_split_specs(const EncDims& e, const rd_encoder_weights* w, const 
   const int Ns[8] = {3 * e.D, e.D, e.nhid, e.D, e.D, e.D, e.nhid, 3 * e.D};
   const int Ks[8] = {e.D, e.D, e.D, e.nhid, e.D, e.nhid, e.D, e.D};
   const int Tr[8] = {0, 0, 0, 0, 1, 1, 1, 1};
-  const int njobs = (all8 || rowgemm_ok(e.D, 3 * e.D, 3 * e.D, e.D)) ? 8 : 7;
+  int njobs = (all8 || rowgemm_ok(e.D, 3 * e.D, 3 * e.D, e.D)) ? 8 : 7;
   for (int i = 0; i < njobs; ++i) out[i] = WsplitSpec{Ws[i], Ns[i], Ks[i], Tr[i], v.pl[i][0]};
+  // the fused attention's per-head in_proj tiles (6 H more jobs of a few tiles each; whether a call takes that path depends on the
+  // token plan, which a prepare call does not see: split whenever the shape is in its envelope)
+  if (!all8 && attnfuse_ok(e.T, e.D, e.H, e.Hd)) njobs += attnfuse_split_specs(w->in_proj_w, e.D, e.H, e.Hd, v.afw, v.abw, out + njobs);
   return njobs;
 }
+constexpr int ENC_MAX_SPECS = 8 + 12;                  // per layer: 8 orientations + (fused attention, H = 2) 6 H
 static int enc_prepare(const EncDims& e, const rd_encoder_weights* w, const EncSaved& v, bool tw, hipStream_t st) {
-  WsplitSpec specs[8];
+  WsplitSpec specs[ENC_MAX_SPECS];
   const int n = enc_split_specs(e, w, v, specs);
   void* on[1] = {v.ones};
   return launch_wsplit_specs(n, specs, tw ? 1 : 0, on, st);
@@ -2542,7 +2576,7 @@ static int step_prepare_impl(const rd_shape* s, int32_t nlayers, const rd_encode
   const bool rg = rowgemm_ok(3 * e.D, e.D, e.D, 3 * e.D) && rowgemm_ok(e.D, e.D, e.D, e.D) &&
                   rowgemm_ok(e.nhid, e.D, e.D, e.nhid) && rowgemm_ok(e.D, e.nhid, e.nhid, e.D);
   const bool tw = rg && tile_path(e);
-  WsplitSpec specs[24]; void* ones[4]; int n = 0, no = 0;
+  WsplitSpec specs[2 * ENC_MAX_SPECS + 8]; void* ones[4]; int n = 0, no = 0;
   if (rg)
     for (int l = 0; l < nlayers; ++l) {
       RD_REQUIRE(w[l] && enc_saved[l], "NULL tensor");
@@ -2608,11 +2642,15 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
   const int32_t* tp = token_plan();
   RD_REQUIRE(!tp || (tw && !attn_big(e)), "token plan: this shape / mode does not run on the row-block + tile-stream path");
   struct MliveScope { MliveScope(const int32_t* p) { rowgemm_set_mlive(p); } ~MliveScope() { rowgemm_set_mlive(nullptr); } } mscope(tp);
+  // in_proj + attention core as ONE launch (rd_attnfuse.hip): a workgroup owns a sample, qkv never reaches memory
+  const bool afuse = tp && tw && encfuse_ok(e.D, e.nhid) && attnfuse_ok(e.T, e.D, e.H, e.Hd);      // (same condition as the backward's)
   if (rg) {
     if (!prepared && (rc = enc_prepare(e, w, v, tw, st))) return rc;
-    if (tw) rowgemm_export_next(v.xt[0]);
-    if ((rc = launch_rowgemm(e.M, 3 * e.D, e.D, x, e.D, v.pl[0][0], v.pl[0][1], v.qkv, 3 * e.D, w->in_proj_b, 0, nullptr, 0,
-                             0.f, nullptr, 0, 0.f, 0, 0, st))) return rc;
+    if (!afuse) {
+      if (tw) rowgemm_export_next(v.xt[0]);
+      if ((rc = launch_rowgemm(e.M, 3 * e.D, e.D, x, e.D, v.pl[0][0], v.pl[0][1], v.qkv, 3 * e.D, w->in_proj_b, 0, nullptr, 0,
+                               0.f, nullptr, 0, 0.f, 0, 0, st))) return rc;
+    }
   } else {
     // widths beyond the row-block kernels (SYN256: D = 1040): the tiled family -- in the bf16 modes on its panel form, with the
     // layer's eight weight orientations split here (kept in `saved` for the backward)
@@ -2628,7 +2666,10 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
   a.T = e.T; a.B = e.B; a.D = e.D; a.H = e.H; a.hd = e.Hd;
   a.scale = 1.0f / sqrtf((float)e.Hd); a.p_drop = p_drop; a.seed = seed; a.site = SITE_ATTN_PROB + L; a.seed_cell = seed_cell();
   a.plan = tp;
-  if (attn_big(e)) { if ((rc = attn_big_fwd(a, v.pbig, v.pdbig, st))) return rc; }
+  if (afuse) {
+    if ((rc = launch_attn_fused_fwd(x, v.afw, w->in_proj_b, tp, e.T, e.B, e.D, e.H, e.Hd, p_drop, seed, SITE_ATTN_PROB + L, v.attn, v.lse, st)))
+      return rc;
+  } else if (attn_big(e)) { if ((rc = attn_big_fwd(a, v.pbig, v.pdbig, st))) return rc; }
   else if ((rc = dispatch_attn(a, 0, st))) return rc;
   // out-projection / second FFN layer with the residual add + LayerNorm in their epilogue (a workgroup owns complete rows)
   static const bool ln_fuse_env = [] { const char* e = getenv("RD_LN_FUSE"); return !(e && atoi(e) == 0); }();
@@ -2757,7 +2798,12 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   a.T = e.T; a.B = e.B; a.D = e.D; a.H = e.H; a.hd = e.Hd;
   a.scale = 1.0f / sqrtf((float)e.Hd); a.p_drop = p_drop; a.seed = seed; a.site = SITE_ATTN_PROB + L; a.seed_cell = seed_cell();
   a.plan = tp;
-  if (attn_big(e)) {
+  // fused form (rd_attnfuse.hip): attention backward + dx = dqkv W_in + ds1 + the row tiles of x and dqkv, one launch
+  const bool afuse = tp && tw && fuse && attnfuse_ok(e.T, e.D, e.H, e.Hd);
+  if (afuse) {
+    if ((rc = launch_attn_fused_bwd(x, v.afw, v.abw, w->in_proj_b, tp, e.T, e.B, e.D, e.H, e.Hd, p_drop, seed, SITE_ATTN_PROB + L, v.attn, v.lse,
+                                    ws.da, ws.ds1, dx, v.xt[0], ws.dt[3], st))) return rc;
+  } else if (attn_big(e)) {
     if ((rc = attn_big_bwd(a, v.pbig, v.pdbig, ws.dsbig, st))) return rc;
   } else if (e.T <= TS) {
     if ((rc = dispatch_attn(a, 3, st))) return rc;          // single tile: S, P, dP, dS formed once
@@ -2768,19 +2814,25 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   // ---- input projection --------------------------------------------------------------------------
   if (!tw && (rc = linear_bwd_w(e.M, 3 * e.D, e.D, ws.dqkv, x, g->in_proj_w, g->in_proj_b, ws.splitk, ws.colsum, sw)))
     return rc;
-  if (tw) rowgemm_export_next(ws.dt[3]);
-  if (rg && rowgemm_ok(e.D, 3 * e.D, 3 * e.D, e.D))           // dx = dqkv W_in + ds1: row-block form, K = 3D (was 70 us as a tiled GEMM)
+  if (afuse) {
+  } else if (tw) rowgemm_export_next(ws.dt[3]);
+  if (afuse) rc = RD_OK;
+  else if (rg && rowgemm_ok(e.D, 3 * e.D, 3 * e.D, e.D))      // dx = dqkv W_in + ds1: row-block form, K = 3D (was 70 us as a tiled GEMM)
     rc = launch_rowgemm(e.M, e.D, 3 * e.D, ws.dqkv, 3 * e.D, v.pl[7][0], v.pl[7][1], dx, e.D, nullptr, 0, nullptr, 0, 0.f, ws.ds1,
                         e.D, 0.f, 0, 0, st);
   else
     rc = linear_bwd_x_t(e.M, 3 * e.D, e.D, ws.dqkv, w->in_proj_w, panel ? v.pl[7][0] : nullptr, dx, nullptr, 0.f, ws.ds1, st);
   if (rc) return rc;
   if (tw) {
-    const TileWgradJob jobs[4] = {
-        {ws.dt[3], v.xt[0], ws.twpart[3], g->in_proj_w, g->in_proj_b, 3 * e.D, e.D},      // dqkv^T x
-        {ws.dt[1], v.xt[2], ws.twpart[1], g->lin1_w, g->lin1_b, e.nhid, e.D},             // du^T x1
-        {ws.dt[0], v.xt[3], ws.twpart[0], g->lin2_w, g->lin2_b, e.D, e.nhid},             // df^T h
-        {ws.dt[2], v.xt[1], ws.twpart[2], g->out_proj_w, g->out_proj_b, e.D, e.D}};       // dout^T attn
+    TileWgradJob jobs[4] = {
+        {ws.dt[3], v.xt[0], ws.twpart[3], g->in_proj_w, g->in_proj_b, 3 * e.D, e.D, nullptr, 0, 0, 0, 0, 0},      // dqkv^T x
+        {ws.dt[1], v.xt[2], ws.twpart[1], g->lin1_w, g->lin1_b, e.nhid, e.D, nullptr, 0, 0, 0, 0, 0},             // du^T x1
+        {ws.dt[0], v.xt[3], ws.twpart[0], g->lin2_w, g->lin2_b, e.D, e.nhid, nullptr, 0, 0, 0, 0, 0},             // df^T h
+        {ws.dt[2], v.xt[1], ws.twpart[2], g->out_proj_w, g->out_proj_b, e.D, e.D, nullptr, 0, 0, 0, 0, 0}};       // dout^T attn
+    if (afuse) {   // x and dqkv tiles come from the fused attention backward: per-sample chunk space, head-padded dqkv columns
+      jobs[0].N = attnfuse_padded_cols(e.H); jobs[0].s32 = tp + plan::I_SCHUNK; jobs[0].S = (int)attn_chunks(e);
+      jobs[0].hd = e.Hd; jobs[0].hdp = 16 * attnfuse_nth(); jobs[0].H = e.H; jobs[0].D = e.D;
+    }
     const TileColsumJob cs[2] = {{ws.lnpart, lnrows, 2 * e.D, e.D, g->norm2_w, g->norm2_b},
                                  {ws.lnpart1, lnrows, 2 * e.D, e.D, g->norm1_w, g->norm1_b}};
     return launch_tile_wgrad(e.M, 4, jobs, v.ones, 2, cs, st, tp ? tp + plan::I_S32 : nullptr);

@@ -36,6 +36,8 @@ struct TwProb {
   int nctA, nctB, N, K, nbk, nmem, ldp;
   int wg0;                                         // first workgroup of the problem in the grid (multiple of 8)
   int q0, nq;                                      // reduce kernel: first quad-thread group of the problem, count
+  const int32_t* s32x; int Sx;                     // this problem's own chunk count (device / bound) or null: the launch's
+  int hd, hdp, H, D;                               // hd != 0: rows of the A tiles are head-padded ((which, head) blocks of hdp, hd real)
 };
 // column sums riding on the reduce launch: the LayerNorm dgamma | dbeta partials of the layer ([M rows][N], out1 = first n1 sums)
 struct TwColsum { const float* x; int M, N, n1; float *out1, *out2; };
@@ -58,7 +60,9 @@ __global__ __launch_bounds__(TW_THR) void k_twg(TwArgs a) {
   if (mi >= P.nmem) return;
   const int bn = mi / P.nbk, bk = mi - bn * P.nbk;
   const int nctA = P.nctA, nctB = P.nctB;
-  const int S = a.s32 ? min(a.S, __builtin_amdgcn_readfirstlane(*a.s32)) : a.S;   // chunks beyond the live rows hold nothing (never exported)
+  const int32_t* sp = P.s32x ? P.s32x : a.s32;
+  const int Sb = P.s32x ? P.Sx : a.S;
+  const int S = sp ? min(Sb, __builtin_amdgcn_readfirstlane(*sp)) : Sb;           // chunks beyond the live rows hold nothing (never exported)
   const int ntile = S > sl ? (S - sl + TW_SLICES - 1) / TW_SLICES : 0;        // chunks of this slice: sl, sl + 8, ...
 
   // operand tile pointers of chunk 0 (+ lane offset) and their per-chunk strides.  The B column tile with index nctB is
@@ -197,7 +201,14 @@ __global__ __launch_bounds__(TWR_THR) void k_twg_reduce(TwArgs a) {
   const int qpr = P.ldp >> 2;
   const int ec = live ? e : 0;
   const int n = ec / qpr, k = 4 * (ec - n * qpr);
-  const bool is_w = k < P.K, is_b = (k == 16 * P.nctB) && P.db != nullptr;
+  int nr = n;                                       // row of dW / db this partial row belongs to
+  bool rok = true;
+  if (P.hd) {                                       // head-padded rows: (which, head, c) -> which D + head hd + c, c < hd
+    const int blk = P.H * P.hdp, which = n / blk, rem = n - which * blk, hh = rem / P.hdp, c = rem - hh * P.hdp;
+    rok = c < P.hd;
+    nr = which * P.D + hh * P.hd + c;
+  }
+  const bool is_w = rok && k < P.K, is_b = rok && (k == 16 * P.nctB) && P.db != nullptr;
   const size_t stride = (size_t)16 * P.nctA * P.ldp;
   const float* p = P.part + (size_t)n * P.ldp + k + (size_t)(4 * half) * stride;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -211,8 +222,8 @@ __global__ __launch_bounds__(TWR_THR) void k_twg_reduce(TwArgs a) {
   const float4 r = make_float4(__shfl_down(s.x, 1, 2), __shfl_down(s.y, 1, 2), __shfl_down(s.z, 1, 2), __shfl_down(s.w, 1, 2));
   if (live && half == 0) {
     s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
-    if (is_w) *reinterpret_cast<float4*>(P.dW + (size_t)n * P.K + k) = s;
-    else if (is_b) P.db[n] = s.x;
+    if (is_w) *reinterpret_cast<float4*>(P.dW + (size_t)nr * P.K + k) = s;
+    else if (is_b) P.db[nr] = s.x;
   }
 }
 
@@ -230,7 +241,7 @@ bool tile_wgrad_ok(int N, int K) {
   return on && precision() != RD_PREC_FP32 && (K % 4) == 0 && N >= 16 && K >= 16;
 }
 
-struct TileWgradJob { const void *tA, *tB; float* part; float *dW, *db; int N, K; };
+struct TileWgradJob { const void *tA, *tB; float* part; float *dW, *db; int N, K; const int32_t* s32; int S; int hd, hdp, H, D; };
 // up to four products over the same M rows; part_i: tile_wgrad_part_floats(N_i, K_i) floats.  cs: 0..2 column-sum jobs
 // (x [M rows][N] contiguous -> out1[0..n1), out2[0..N-n1)) carried by the reduce launch.
 struct TileColsumJob { const float* x; int M, N, n1; float *out1, *out2; };
@@ -248,6 +259,7 @@ int launch_tile_wgrad(long M, int njobs, const TileWgradJob* jobs, const void* o
     P.nbk = cdiv(P.nctB + 1, TW_NB); P.nmem = cdiv(P.nctA, TW_NA) * P.nbk; P.ldp = 16 * (P.nctB + 1);
     P.wg0 = wg; wg += 8 * P.nmem;
     P.q0 = q; P.nq = j.N * (P.ldp >> 2); q += (P.nq + 511) / 512 * 512;
+    P.s32x = j.s32; P.Sx = j.S; P.hd = j.hd; P.hdp = j.hdp; P.H = j.H; P.D = j.D;
   }
   if (precision() == RD_PREC_BF16) {
     RD_LDS_ATTR(k_twg<true>, TW_LDS);

@@ -31,7 +31,8 @@ HOT = [
     (("k_enc_post_fwdILi160ELi288E",), 128), (("k_enc_pre_bwdILi160ELi288E",), 128),
     (("k_rowgemmILi5ELi32ELi2ELb0ELb0ELi8E",), 128),                                         # two 8-wave workgroups per CU
     (("k_rowgemmILi15ELi32ELi1ELb0ELb0ELi8E",), 128),                                        # two per CU: ONE round of 266 workgroups
-    (("5k_twgE",), None), (("k_twg_reduce",), None),
+    (("5k_twgILb0E",), None), (("5k_twgILb1E",), None), (("k_twg_reduce",), None),
+    (("k_attn_fwd_fusedILi5ELi5E",), 256), (("k_attn_bwd_fusedILi5ELi5E",), 256),             # 8 waves per workgroup, one workgroup per CU
     (("k_attn_fwd_one_b16wILi5ELb1E",), 128), (("k_attn_bwd_one_b16wILi5ELb1E",), 128),
     (("k_attn_fwd_b16ILi5ELb1ELb0E",), 256), (("k_attn_bwd_dq_b16ILi5ELb1ELb0E",), 256), (("k_attn_bwd_dkv_b16ILi5ELb1ELb0E",), 256),
     (("k_head_rowsILi1E",), 128), (("k_head_wgrad",), None), (("k_gemm_panelILi2E",), 256), (("k_adam",), None), (("k_wsplit",), None),

@@ -322,3 +322,29 @@ def test_token_plan_step_ignores_stale_buffer_contents(group):
     assert np.array_equal(second[1], first[1]), group
     for n in live:
         assert np.array_equal(second[2][n], first[2][n]), (group, n)
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.2])
+@pytest.mark.parametrize("case", ["random", "full_length", "min_length", "first_time_zero"])
+def test_fused_attention_launch_vs_the_three_launches_it_replaces(case, p_drop, monkeypatch):
+    """rd_attnfuse.hip (in_proj + attention + in_proj's input gradient as one launch per direction, row tiles exported in the
+    per-sample chunk space) against the round-3 path (RD_ATTN_FUSE=0: QKV row-block product, attention per (sample, head), QKV
+    input-gradient product) on the same token plan, same seed cell -- dropout masks are identical functions of (seed, rank, head,
+    query, key), so the two agree to the order of a few fp32 sums: loss 2e-6, logits 2e-6, every gradient 2e-5 of its max-norm."""
+    cfg = synth.make_config("P19")
+    gs = synth.make_structure(cfg, "sparse")
+    batch = _seq_batch(cfg, 64, case, seed=77)
+    res = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("RD_ATTN_FUSE", fuse)
+        dv = {k: (None if v is None else v.to(DEV).clone()) for k, v in batch.items()}
+        step, named, live = _make_step(cfg, gs, dv, True, False, p_drop)
+        step.seed_cell.fill_(5)
+        step.run()
+        res.append(_snapshot(step, named, live))
+        step.close()
+    (l1, g1, gr1), (l0, g0, gr0) = res
+    assert np.isfinite(l1) and abs(l1 - l0) < 2e-6 * max(1.0, abs(l0)), (l1, l0)
+    assert np.abs(g1 - g0).max() < 2e-6, float(np.abs(g1 - g0).max())
+    for n in live:
+        assert _rel(gr1[n], gr0[n]) < 2e-5, (n, _rel(gr1[n], gr0[n]))
