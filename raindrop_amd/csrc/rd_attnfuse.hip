@@ -51,7 +51,13 @@ struct FAttnArgs {
   int T, B, D, H, hd;
   float scale, p_drop; uint64_t seed; uint32_t site; const uint64_t* seed_cell;
   int one;                                           // RD_PREC_BF16: hi * hi only
+  unsigned long long* stamps;                        // debug (tools/attnfuse_timing.py): clock64 per phase, wave 0 of workgroup 0
 };
+static unsigned long long* g_af_stamps = nullptr;
+#define AFSTAMP(i)                                                                                  \
+  do {                                                                                              \
+    if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[(i)] = clock64();                 \
+  } while (0)
 
 __device__ __forceinline__ float g16_max(float v) {
 #define RD_ROR(v, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (n), 0xf, 0xf, false))
@@ -167,82 +173,87 @@ __device__ __forceinline__ void x_store(const XRows<KCX>& r, __bf16* Xh, __bf16*
 }
 
 // ---- Q | K | V of one head: [TS x D] x W_h^T + b -> TRANSPOSED planes T[which][hi, lo][HDP][LDT] --------------------------------
-// Wave w owns the column tiles w and w + 8 of the head's 3 NTH (its weight panel: 2 x KCX x (hi, lo) fragments straight from L2)
-// and all four row tiles: each panel fragment is loaded once per workgroup.  Rows >= Tv and features >= hd are stored as zeros
-// (what the padded kernels' zero padding gives: dead keys stay finite, padded features add nothing).
-template <int NTH, int KCX, bool SEQ = false>
-__device__ __forceinline__ void qkv_project(const __bf16* Xh, const __bf16* Xl, const __bf16* wf_h, const float* bias, int D, int hd, int h,
-                                            int Tv, __bf16* Tp, int wave, int lane, bool one) {
-  constexpr int NCT3 = 3 * NTH, HDP = 32 * ((16 * NTH + 31) / 32), LDX = 32 * KCX + 8;
+// Wave w owns the column tiles w and w + 8 of the head's 3 NTH and all four row tiles: each weight fragment is loaded once per
+// workgroup, straight from L2 into registers.  That stream -- 150 KB per head and workgroup, every workgroup of the launch at the same
+// time -- is what the projection costs (phase stamps: 9-10 k cycles with the panel requested where it is used, ~2 k of them MFMA):
+// the panel of a head is therefore REQUESTED A WHOLE HEAD EARLIER (qkv_request: at kernel entry for head 0, right behind the
+// previous head's projection for the next), into registers that are free through the attention phases.
+// Rows >= Tv and features >= hd are stored as zeros (what the padded kernels' zero padding gives: dead keys stay finite, padded
+// features add nothing).
+template <int KCX>
+struct QkvPanel { bf8 h[2][KCX], l[2][KCX]; float bs[2]; };
+
+template <int NTH, int KCX>
+__device__ __forceinline__ void qkv_request(QkvPanel<KCX>& p, const __bf16* wf_h, const float* bias, int D, int hd, int h, int wave, int lane) {
+  constexpr int NCT3 = 3 * NTH;
   static_assert(NCT3 <= 2 * AF_WV, "two column tiles per wave");
-  constexpr int NS = SEQ ? 1 : 2;                            // column tiles multiplied at a time (SEQ: one after the other -- the
-                                                             // backward kernel has no registers for two panels beside its accumulators)
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int ct = min(wave + AF_WV * s, NCT3 - 1);          // clamped: unconditional loads (wave 7 has one tile: its second is a copy)
+    const __bf16* t = wf_h + (size_t)ct * (KCX * 2 * 512) + lane * 8;
+#pragma unroll
+    for (int kc = 0; kc < KCX; ++kc) {
+      p.h[s][kc] = *reinterpret_cast<const bf8*>(t + (kc * 2 + 0) * 512);
+      p.l[s][kc] = *reinterpret_cast<const bf8*>(t + (kc * 2 + 1) * 512);
+    }
+    const int whc = ct / NTH, cl = 16 * (ct - whc * NTH) + (lane & 15);
+    p.bs[s] = bias[whc * D + h * hd + min(cl, hd - 1)];
+  }
+}
+
+template <int NTH, int KCX>
+__device__ __forceinline__ void qkv_project(const QkvPanel<KCX>& p, const __bf16* Xh, const __bf16* Xl, int hd, int Tv, __bf16* Tp, int wave,
+                                            int lane, bool one) {
+  constexpr int NCT3 = 3 * NTH, HDP = 32 * ((16 * NTH + 31) / 32), LDX = 32 * KCX + 8;
   const bool two = wave + AF_WV < NCT3;                      // wave-uniform
   const int aoff = (lane & 15) * LDX + 8 * (lane >> 4);
+  f32x4 acc[2][4];
 #pragma unroll
-  for (int pass = 0; pass < 2 / NS; ++pass) {
-    if (SEQ && pass == 1 && !two) break;
-    bf8 ph[NS][KCX], pl[NS][KCX];
-    float bs[NS]; int whc[NS], cl[NS];
+  for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int ct = min(wave + AF_WV * (SEQ ? pass : s), NCT3 - 1);     // clamped: unconditional loads
-      const __bf16* t = wf_h + (size_t)ct * (KCX * 2 * 512) + lane * 8;
+    for (int rt = 0; rt < 4; ++rt) acc[s][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (!one) {
 #pragma unroll
-      for (int kc = 0; kc < KCX; ++kc) {
-        ph[s][kc] = *reinterpret_cast<const bf8*>(t + (kc * 2 + 0) * 512);
-        pl[s][kc] = *reinterpret_cast<const bf8*>(t + (kc * 2 + 1) * 512);
-      }
-      whc[s] = ct / NTH; cl[s] = 16 * (ct - whc[s] * NTH) + (lane & 15);
-      bs[s] = bias[whc[s] * D + h * hd + min(cl[s], hd - 1)];
-    }
-    f32x4 acc[NS][4];
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) acc[s][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (!one) {
-#pragma unroll
-      for (int kc = 0; kc < KCX; ++kc) {
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-          const bf8 ah = *reinterpret_cast<const bf8*>(Xh + rt * 16 * LDX + aoff + kc * 32);
-          const bf8 al = *reinterpret_cast<const bf8*>(Xl + rt * 16 * LDX + aoff + kc * 32);
-#pragma unroll
-          for (int s = 0; s < NS; ++s) {
-            acc[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ph[s][kc], acc[s][rt], 0, 0, 0);
-            acc[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, pl[s][kc], acc[s][rt], 0, 0, 0);
-            acc[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ph[s][kc], acc[s][rt], 0, 0, 0);
-          }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int kc = 0; kc < KCX; ++kc) {
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-          const bf8 ah = *reinterpret_cast<const bf8*>(Xh + rt * 16 * LDX + aoff + kc * 32);
-#pragma unroll
-          for (int s = 0; s < NS; ++s) acc[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ph[s][kc], acc[s][rt], 0, 0, 0);
-        }
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      if (!SEQ && s == 1 && !two) break;
-      __bf16* Ph = Tp + (size_t)(whc[s] * 2) * HDP * LDT;
-      __bf16* Pl = Ph + (size_t)HDP * LDT;
-      const bool cok = cl[s] < hd;
+    for (int kc = 0; kc < KCX; ++kc) {
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
-        const int r0 = 16 * rt + 4 * (lane >> 4);
-        float v[4];
+        const bf8 ah = *reinterpret_cast<const bf8*>(Xh + rt * 16 * LDX + aoff + kc * 32);
+        const bf8 al = *reinterpret_cast<const bf8*>(Xl + rt * 16 * LDX + aoff + kc * 32);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (cok && r0 + r < Tv) ? acc[s][rt][r] + bs[s] : 0.f;
-        store_t4(Ph, Pl, cl[s], r0, v);
+        for (int s = 0; s < 2; ++s) {
+          acc[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, p.h[s][kc], acc[s][rt], 0, 0, 0);
+          acc[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, p.l[s][kc], acc[s][rt], 0, 0, 0);
+          acc[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, p.h[s][kc], acc[s][rt], 0, 0, 0);
+        }
       }
     }
-    if (SEQ) __builtin_amdgcn_sched_barrier(0);
+  } else {
+#pragma unroll
+    for (int kc = 0; kc < KCX; ++kc) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const bf8 ah = *reinterpret_cast<const bf8*>(Xh + rt * 16 * LDX + aoff + kc * 32);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) acc[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, p.h[s][kc], acc[s][rt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    if (s == 1 && !two) break;
+    const int ct = wave + AF_WV * s;
+    const int whc = ct / NTH, cl = 16 * (ct - whc * NTH) + (lane & 15);
+    __bf16* Ph = Tp + (size_t)(whc * 2) * HDP * LDT;
+    __bf16* Pl = Ph + (size_t)HDP * LDT;
+    const bool cok = cl < hd;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const int r0 = 16 * rt + 4 * (lane >> 4);
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (cok && r0 + r < Tv) ? acc[s][rt][r] + p.bs[s] : 0.f;
+      store_t4(Ph, Pl, cl, r0, v);
+    }
   }
 }
 
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(AF_THR) void k_attn_fwd_fused(FAttnArgs a) {
   float* ost = reinterpret_cast<float*>(Kh);                 // output stage [TS][LDO] overlays K^T (hi + lo: dead once S is formed)
   static_assert(HDP >= TS, "P^T must fit inside the Q^T plane");
   static_assert((size_t)TS * LDO * 4 <= (size_t)2 * HDP * LDT * 2, "output stage must fit inside the K^T planes");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wq = wave & 3, wh = wave >> 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wq = wave & 3, wh = wave >> 2;   // wave: uniform (scalar registers)
   const int b = blockIdx.x;                                  // rank of the sample (plan order)
   const int Tv = __builtin_amdgcn_readfirstlane(a.plan[plan::len_base(a.B) + b]);
   if (Tv <= 0) return;
@@ -288,18 +299,33 @@ __global__ __launch_bounds__(AF_THR) void k_attn_fwd_fused(FAttnArgs a) {
   uint64_t seedv = a.seed;
   XRows<KCX> xr;
   x_request<KCX>(xr, a.x, row0, Tv, a.D, tid);
+  QkvPanel<KCX> pan;                                         // head 0's weight panel: requested behind the rows, used after the first barrier
+  qkv_request<NTH, KCX>(pan, a.wf, a.bias, a.D, a.hd, 0, wave, lane);
+  __builtin_amdgcn_sched_barrier(0);
   if (a.p_drop > 0.f && a.seed_cell) seedv += load_uniform_u64(a.seed_cell);
   zero_pad_rows<NTH>(Tp, tid);
+  AFSTAMP(0);
   x_store<KCX>(xr, Xh, Xl, Tv, a.D, tid);
-  __syncthreads();
+  AFSTAMP(1);
+  lds_barrier();
+  AFSTAMP(2);
   const float inv_keep = 1.0f / (1.0f - a.p_drop);
   const bool one = a.one != 0;
   const int qr0 = wq * 16 + 4 * (lane >> 4);                 // first of this lane's four query rows
   for (int h = 0; h < a.H; ++h) {
     const int bh = b * a.H + h;
     if (h > 0) zero_pad_rows<NTH>(Tp, tid);                  // the previous head's output stage ran over K^T's padding rows
-    qkv_project<NTH, KCX>(Xh, Xl, a.wf + (size_t)h * (3 * NTH * KCX * 2 * 512), a.bias, a.D, a.hd, h, Tv, Tp, wave, lane, one);
-    __syncthreads();
+    qkv_project<NTH, KCX>(pan, Xh, Xl, a.hd, Tv, Tp, wave, lane, one);
+    __builtin_amdgcn_sched_barrier(0);
+    {   // the NEXT head's panel into the registers this one has just released (past the last head: head 0's again, unused --
+        // an unconditional request keeps the wait counts in front of the attention phases exact, DESIGN rule 17)
+      const int hn = h + 1 < a.H ? h + 1 : 0;
+      qkv_request<NTH, KCX>(pan, a.wf + (size_t)hn * (3 * NTH * KCX * 2 * 512), a.bias, a.D, a.hd, hn, wave, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    AFSTAMP(3 + 8 * h);
+    lds_barrier();
+    AFSTAMP(4 + 8 * h);
     // ---- S = Q K^T: query tile wq, key tiles 2 wh, 2 wh + 1 ----
     f32x4 s[2];
 #pragma unroll
@@ -321,7 +347,8 @@ __global__ __launch_bounds__(AF_THR) void k_attn_fwd_fused(FAttnArgs a) {
       mx[r] = g16_max(mx[r]);
       if ((lane & 15) == 0) mxs[wh * TS + qr0 + r] = mx[r];
     }
-    __syncthreads();                                         // partial maxima visible; everybody is done with Q^T and K^T
+    AFSTAMP(5 + 8 * h);
+    lds_barrier();                                         // partial maxima visible; everybody is done with Q^T and K^T
     float m_i[4], rsum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 4; ++r) m_i[r] = fmaxf(mxs[qr0 + r], mxs[TS + qr0 + r]);
@@ -344,7 +371,9 @@ __global__ __launch_bounds__(AF_THR) void k_attn_fwd_fused(FAttnArgs a) {
       rsum[r] = g16_sum(rsum[r]);
       if ((lane & 15) == 0) sms[wh * TS + qr0 + r] = rsum[r];
     }
-    __syncthreads();
+    AFSTAMP(6 + 8 * h);
+    lds_barrier();
+    AFSTAMP(7 + 8 * h);
     float l_i[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) l_i[r] = sms[qr0 + r] + sms[TS + qr0 + r];
@@ -363,7 +392,9 @@ __global__ __launch_bounds__(AF_THR) void k_attn_fwd_fused(FAttnArgs a) {
         if (t0 + j < NTH) ost[q * LDO + 16 * (t0 + j) + (lane & 15)] = o[j][r] * inv;
       if (wh == 0 && (lane & 15) == 0 && q < Tv) a.lse[(long)bh * a.T + q] = m_i[r] + logf(l_i[r]);
     }
-    __syncthreads();
+    AFSTAMP(8 + 8 * h);
+    lds_barrier();
+    AFSTAMP(9 + 8 * h);
     // ---- attention rows of this head out: 16-byte stores, a row's hd floats contiguous ----
     {
       const int qpr = a.hd >> 2;
@@ -372,7 +403,8 @@ __global__ __launch_bounds__(AF_THR) void k_attn_fwd_fused(FAttnArgs a) {
         *reinterpret_cast<float4*>(a.out + (row0 + q) * a.D + h * a.hd + 4 * c4) = *reinterpret_cast<const float4*>(ost + q * LDO + 4 * c4);
       }
     }
-    __syncthreads();                                         // the next head's projection rewrites the planes the stage lives in
+    lds_barrier();                                         // the next head's projection rewrites the planes the stage lives in
+    AFSTAMP(10 + 8 * h);
   }
 }
 
@@ -411,44 +443,66 @@ __device__ __forceinline__ void head_mask(HRegs<NTH>& h) {
     if (!((h.ok >> i) & 1u)) h.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// dx accumulators += d{Q,K,V}^T planes (A, read transposed: reduction = head feature) x W_in(which, head)^T tiles, for the NS column
-// tiles wave, wave + 8 of dx and all four row tiles.  ONE: hi * hi only.
-template <int NTH, int KCX, int NS, bool ONE>
-__device__ __forceinline__ void dx_accumulate(f32x4 (&dxa)[2][4], const __bf16* Tp, const __bf16* wb_h, int wave, int lane) {
-  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), KB = HDP / 32, NCT = 2 * KCX;
+// ---- dx += d{Q,K,V} W_in(which, head): the input gradient of in_proj, accumulated in registers over which and heads ------------
+// A = the transposed d{Q,K,V} planes (read transposed: reduction = head feature), B = W_in(which, head)^T tiles straight from L2.
+// Wave w owns the column tiles w and w + 8 (NS = 2: waves 0, 1 at NCT = 10) of dx and all four row tiles.  Like the projection's,
+// the panels are requested ahead: `which` 0 behind barrier (D) -- two phases before its use --, `which` + 1 before the products
+// of `which` (two panels alive).
+template <int KB>
+struct DxPanel { bf8 h[2][KB], l[2][KB]; };
+
+template <int KCX, int KB, int NS>
+__device__ __forceinline__ void dx_request(DxPanel<KB>& p, const __bf16* wb_h, int which, int wave, int lane) {
+  constexpr int NCT = 2 * KCX;
 #pragma unroll
-  for (int which = 0; which < 3; ++which) {
-    bf8 ph[NS][KB], pl[NS][KB];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const __bf16* t = wb_h + ((size_t)which * NCT + wave + AF_WV * s) * (KB * 2 * 512) + lane * 8;
-#pragma unroll
-      for (int kc = 0; kc < KB; ++kc) {
-        ph[s][kc] = *reinterpret_cast<const bf8*>(t + (kc * 2 + 0) * 512);
-        if (!ONE) pl[s][kc] = *reinterpret_cast<const bf8*>(t + (kc * 2 + 1) * 512);
-      }
-    }
-    const __bf16* Ah = Tp + (size_t)(which * 2) * HDP * LDT;
-    const __bf16* Al = Ah + (size_t)HDP * LDT;
+  for (int s = 0; s < NS; ++s) {
+    const __bf16* t = wb_h + ((size_t)which * NCT + wave + AF_WV * s) * (KB * 2 * 512) + lane * 8;
 #pragma unroll
     for (int kc = 0; kc < KB; ++kc) {
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        const bf8 ah = frag_t(Ah, LDT, 32 * kc, 16 * rt, lane);
-        if (!ONE) {
-          const bf8 al = frag_t(Al, LDT, 32 * kc, 16 * rt, lane);
-#pragma unroll
-          for (int s = 0; s < NS; ++s) {
-            dxa[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ph[s][kc], dxa[s][rt], 0, 0, 0);
-            dxa[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, pl[s][kc], dxa[s][rt], 0, 0, 0);
-          }
-        }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) dxa[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ph[s][kc], dxa[s][rt], 0, 0, 0);
-      }
+      p.h[s][kc] = *reinterpret_cast<const bf8*>(t + (kc * 2 + 0) * 512);
+      p.l[s][kc] = *reinterpret_cast<const bf8*>(t + (kc * 2 + 1) * 512);
     }
-    __builtin_amdgcn_sched_barrier(0);               // one panel alive at a time (the scheduler would hoist all three: spills)
   }
+}
+template <int NTH, int KB, int NS, bool ONE>
+__device__ __forceinline__ void dx_mma(f32x4 (&dxa)[2][4], const DxPanel<KB>& p, const __bf16* Tp, int which, int lane) {
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32);
+  const __bf16* Ah = Tp + (size_t)(which * 2) * HDP * LDT;
+  const __bf16* Al = Ah + (size_t)HDP * LDT;
+#pragma unroll
+  for (int kc = 0; kc < KB; ++kc) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const bf8 ah = frag_t(Ah, LDT, 32 * kc, 16 * rt, lane);
+      if (!ONE) {
+        const bf8 al = frag_t(Al, LDT, 32 * kc, 16 * rt, lane);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          dxa[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, p.h[s][kc], dxa[s][rt], 0, 0, 0);
+          dxa[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, p.l[s][kc], dxa[s][rt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) dxa[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, p.h[s][kc], dxa[s][rt], 0, 0, 0);
+    }
+  }
+}
+// p0: the panel of `which` 0, already requested
+template <int NTH, int KCX, int NS, bool ONE>
+__device__ __forceinline__ void dx_phase(f32x4 (&dxa)[2][4], DxPanel<(16 * NTH + 31) / 32>& p0, const __bf16* Tp, const __bf16* wb_h, int wave,
+                                         int lane) {
+  constexpr int KB = (16 * NTH + 31) / 32;
+  DxPanel<KB> p1;
+  dx_request<KCX, KB, NS>(p1, wb_h, 1, wave, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  dx_mma<NTH, KB, NS, ONE>(dxa, p0, Tp, 0, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  dx_request<KCX, KB, NS>(p0, wb_h, 2, wave, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  dx_mma<NTH, KB, NS, ONE>(dxa, p1, Tp, 1, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  dx_mma<NTH, KB, NS, ONE>(dxa, p0, Tp, 2, lane);
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 template <int NTH, int KCX>
@@ -472,7 +526,7 @@ __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
   __bf16* Ol = Oh + TS * LDB;
   float* lse_s = reinterpret_cast<float*>(Ol + TS * LDB);
   float* dl_s = lse_s + TS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wq = wave & 3, wh = wave >> 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wq = wave & 3, wh = wave >> 2;   // wave: uniform (scalar registers)
   const int b = blockIdx.x;
   const int Tv = __builtin_amdgcn_readfirstlane(a.plan[plan::len_base(a.B) + b]);
   if (Tv <= 0) return;
@@ -483,8 +537,6 @@ __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
   if (a.p_drop > 0.f && a.seed_cell) seedv += load_uniform_u64(a.seed_cell);
   const float inv_keep = 1.0f / (1.0f - a.p_drop);
   const bool one = a.one != 0;
-  const int qr0 = wq * 16 + 4 * (lane >> 4);
-  zero_pad_rows<NTH>(Tp, tid);
   // dx accumulators: wave w owns the column tiles w and w + 8 (< NCT) of dx and all four row tiles, over BOTH heads
   f32x4 dxa[2][4];
 #pragma unroll
@@ -492,9 +544,11 @@ __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) dxa[s][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const bool two = wave + AF_WV < NCT;                       // wave-uniform
+  constexpr int NQ = (TS * 8 * KCX + AF_THR - 1) / AF_THR;
+  QkvPanel<KCX> pan;
   for (int h = 0; h < a.H; ++h) {
     const int bh = b * a.H + h;
-    // ---- requests: x rows (all threads), dO and O slices of the head + LSE (waves 4-7) ----
+    // ---- requests: x rows (all threads), dO and O slices of the head + LSE (waves 4-7), then the projection's weight panel ----
     // (the thread index goes through an opaque move per head: everything derived from it -- five row / column predicates and
     // addresses per tile -- is loop-invariant, and hoisted out of the head loop it stayed live across the whole kernel: spills)
     int tl = tid;
@@ -508,12 +562,20 @@ __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
       head_request<NTH>(ov, a.out + row0 * a.D + h * a.hd, a.D, Tv, a.hd, lt);
       lrow = a.lse[(long)bh * a.T + min(lt >> 2, Tv - 1)];
     }
+    // (the lane index too: the panels' 20 + 36 tile-part addresses are loop-invariant and were kept in registers across the loop)
+    int lq = lane;
+    asm volatile("" : "+v"(lq));
+    qkv_request<NTH, KCX>(pan, a.wf + (size_t)h * (3 * NTH * KCX * 2 * 512), a.bias, a.D, a.hd, h, wave, lq);
+    AFSTAMP(32 + 16 * h);
     __builtin_amdgcn_sched_barrier(0);
+    if (h == 0) zero_pad_rows<NTH>(Tp, tl);
     x_store<KCX>(xr, Xh, Xl, Tv, a.D, tl);
-    __syncthreads();                                         // (A) x planes complete; the previous head's dQ^T.. / dO planes are dead
+    AFSTAMP(33 + 16 * h);
+    lds_barrier();                                           // (A) x planes complete; the previous head's dQ^T.. / dO planes are dead
+    AFSTAMP(34 + 16 * h);
     if (h == 0) {
       // ---- row tiles of x (rd_encfuse.hip export_tiles; 32-row chunks of the per-sample chunk space) ----
-      const int i16 = lane & 15, G = lane >> 4;
+      const int i16 = lq & 15, G = lq >> 4;
       for (int t = wave; t < nchunk * NCT * 2; t += AF_WV) {
         const int plane = t & 1, cj = t >> 1;
         const int c = cj / NCT, j = cj - c * NCT;
@@ -521,7 +583,7 @@ __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
         const sh4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sh4 __attribute__((address_space(3)))*)(src));
         const sh4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sh4 __attribute__((address_space(3)))*)(src + 4 * LDX));
         const sh8 o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        *reinterpret_cast<sh8*>(a.xt + (((size_t)(c0 + c) * NCT + j) * 2 + plane) * 512 + lane * 8) = o;
+        *reinterpret_cast<sh8*>(a.xt + (((size_t)(c0 + c) * NCT + j) * 2 + plane) * 512 + lq * 8) = o;
       }
     }
     if (wh == 1) {
@@ -552,25 +614,33 @@ __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
       }
       if ((lt & 3) == 0) { dl_s[lt >> 2] = d; lse_s[lt >> 2] = lrow; }
     }
-    __builtin_amdgcn_sched_barrier(0);                       // the dO / O registers are dead before the projection's panels are requested
-    qkv_project<NTH, KCX, true>(Xh, Xl, a.wf + (size_t)h * (3 * NTH * KCX * 2 * 512), a.bias, a.D, a.hd, h, Tv, Tp, wave, lane, one);
-    __syncthreads();                                         // (B) Q^T, K^T, V^T, dO, delta, LSE complete; the x planes are dead
+    AFSTAMP(35 + 16 * h);
+    __builtin_amdgcn_sched_barrier(0);
+    qkv_project<NTH, KCX>(pan, Xh, Xl, a.hd, Tv, Tp, wave, lq, one);
+    AFSTAMP(36 + 16 * h);
+    lds_barrier();                                           // (B) Q^T, K^T, V^T, dO, delta, LSE complete; the x planes are dead
+    AFSTAMP(37 + 16 * h);
     // ---- S = Q K^T, dP = dO V^T for query tile wq, key tiles 2 wh, 2 wh + 1 ----
+    // (every phase works from its own opaque copy of the lane index: the LDS addresses of its fragments are loop-invariant, the
+    // planes span 150 KB -- beyond one base + 16-bit offset -- and hoisted out of the head loop they cost ~90 registers: spills)
+    int l1 = lane;
+    asm volatile("" : "+v"(l1));
+    const int qr1 = wq * 16 + 4 * (l1 >> 4);
     f32x4 s[2], dp[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) { s[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[j] = s[j]; }
-    mma_b16<2, true, true>(s, Qh, Ql, LDT, wq * 16, Kh + 32 * wh, Kl + 32 * wh, LDT, HDP, lane, one);
-    mma_b16<2, false, true>(dp, Oh, Ol, LDB, wq * 16, Vh + 32 * wh, Vl + 32 * wh, LDT, HDP, lane, one);
+    mma_b16<2, true, true>(s, Qh, Ql, LDT, wq * 16, Kh + 32 * wh, Kl + 32 * wh, LDT, HDP, l1, one);
+    mma_b16<2, false, true>(dp, Oh, Ol, LDB, wq * 16, Vh + 32 * wh, Vl + 32 * wh, LDT, HDP, l1, one);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int key = 16 * (2 * wh + j) + (lane & 15);
+      const int key = 16 * (2 * wh + j) + (l1 & 15);
       const bool dead = key >= Tv;
       float k4[4] = {1.f, 1.f, 1.f, 1.f};
-      if (a.p_drop > 0.f) attn_keep4(k4, seedv, a.site, bh, a.T, qr0, min(key, a.T - 1), a.p_drop, inv_keep);
+      if (a.p_drop > 0.f) attn_keep4(k4, seedv, a.site, bh, a.T, qr1, min(key, a.T - 1), a.p_drop, inv_keep);
       float pm[4], ds[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = qr0 + r;
+        const int row = qr1 + r;
         pm[r] = 0.f; ds[r] = 0.f;
         if (!dead && row < Tv) {
           const float p = __expf(s[j][r] * a.scale - lse_s[row]);
@@ -578,37 +648,50 @@ __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
           ds[r] = p * (dp[j][r] * k4[r] - dl_s[row]) * a.scale;
         }
       }
-      store_t4(Ph, Pl, key, qr0, pm);
-      store_t4(Sh, Sl, key, qr0, ds);
+      store_t4(Ph, Pl, key, qr1, pm);
+      store_t4(Sh, Sl, key, qr1, ds);
     }
-    __syncthreads();                                         // (C)
+    AFSTAMP(38 + 16 * h);
+    lds_barrier();                                           // (C)
+    AFSTAMP(39 + 16 * h);
     const int t0 = wh * NA;                                  // first head-dim tile of this half
+    int l2 = lane;
+    asm volatile("" : "+v"(l2));
     f32x4 dq[NA], dk[NA], dv[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) { dq[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[j] = dq[j]; dv[j] = dq[j]; }
-    mma_b16<NA, true, false>(dq, Sh, Sl, LDT, wq * 16, Kh + 16 * t0 * LDT, Kl + 16 * t0 * LDT, LDT, TS, lane, one);     // dQ = dS K      (rows: queries)
+    mma_b16<NA, true, false>(dq, Sh, Sl, LDT, wq * 16, Kh + 16 * t0 * LDT, Kl + 16 * t0 * LDT, LDT, TS, l2, one);     // dQ = dS K      (rows: queries)
+    mma_b16<NA, false, false>(dk, Sh, Sl, LDT, wq * 16, Qh + 16 * t0 * LDT, Ql + 16 * t0 * LDT, LDT, TS, l2, one);    // dK = dS^T Q    (rows: keys)
+    mma_b16<NA, false, true>(dv, Ph, Pl, LDT, wq * 16, Oh + 16 * t0, Ol + 16 * t0, LDB, TS, l2, one);                 // dV = (P o M)^T dO
+    AFSTAMP(40 + 16 * h);
+    lds_barrier();                                           // (D) everybody is done with Q^T, K^T, V^T, the score planes and dO
+    AFSTAMP(41 + 16 * h);
+    // the first input-gradient panel of this head: in flight through the next two phases
+    const __bf16* wb_h = a.wb + (size_t)h * (3 * NCT * KB * 2 * 512);
+    DxPanel<KB> dp0;
+    int ld = lane;
+    asm volatile("" : "+v"(ld));
+    if (two) dx_request<KCX, KB, 2>(dp0, wb_h, 0, wave, ld); else dx_request<KCX, KB, 1>(dp0, wb_h, 0, wave, ld);
     __builtin_amdgcn_sched_barrier(0);
-    mma_b16<NA, false, false>(dk, Sh, Sl, LDT, wq * 16, Qh + 16 * t0 * LDT, Ql + 16 * t0 * LDT, LDT, TS, lane, one);    // dK = dS^T Q    (rows: keys)
-    __builtin_amdgcn_sched_barrier(0);
-    mma_b16<NA, false, true>(dv, Ph, Pl, LDT, wq * 16, Oh + 16 * t0, Ol + 16 * t0, LDB, TS, lane, one);                 // dV = (P o M)^T dO
-    __syncthreads();                                         // (D) everybody is done with Q^T, K^T, V^T, the score planes and dO
     // ---- dQ, dK, dV -> transposed planes in place of Q^T, K^T, V^T (rows >= Tv and features >= hd come out as exact zeros) ----
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       if (t0 + j < NTH) {
-        const int f = 16 * (t0 + j) + (lane & 15);
+        const int f = 16 * (t0 + j) + (ld & 15), qr2 = wq * 16 + 4 * (ld >> 4);
         const float vq[4] = {dq[j][0], dq[j][1], dq[j][2], dq[j][3]};
         const float vk[4] = {dk[j][0], dk[j][1], dk[j][2], dk[j][3]};
         const float vv[4] = {dv[j][0], dv[j][1], dv[j][2], dv[j][3]};
-        store_t4(Qh, Ql, f, qr0, vq);
-        store_t4(Kh, Kl, f, qr0, vk);
-        store_t4(Vh, Vl, f, qr0, vv);
+        store_t4(Qh, Ql, f, qr2, vq);
+        store_t4(Kh, Kl, f, qr2, vk);
+        store_t4(Vh, Vl, f, qr2, vv);
       }
     }
-    __syncthreads();                                         // (E)
+    AFSTAMP(42 + 16 * h);
+    lds_barrier();                                           // (E)
+    AFSTAMP(43 + 16 * h);
     // ---- (a) row tiles of dqkv, head-padded column layout: tile (which, h, j) ----
     {
-      const int i16 = lane & 15, G = lane >> 4;
+      const int i16 = ld & 15, G = ld >> 4;
       const int nctp = 3 * a.H * NTH;
       for (int t = wave; t < 3 * NTH * nchunk * 2; t += AF_WV) {
         const int plane = t & 1, u = t >> 1;
@@ -617,20 +700,30 @@ __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
         const __bf16* src = Tp + ((size_t)(which * 2 + plane) * HDP + 16 * j + i16) * LDT + 32 * c + 8 * G;
         const sh8 o = *reinterpret_cast<const sh8*>(src);
         const int jt = (which * a.H + h) * NTH + j;
-        *reinterpret_cast<sh8*>(a.dt + (((size_t)(c0 + c) * nctp + jt) * 2 + plane) * 512 + lane * 8) = o;
+        *reinterpret_cast<sh8*>(a.dt + (((size_t)(c0 + c) * nctp + jt) * 2 + plane) * 512 + ld * 8) = o;
       }
     }
+    AFSTAMP(44 + 16 * h);
     // ---- (b) dx += dQ W_q,h + dK W_k,h + dV W_v,h ----
-    {
-      const __bf16* wb_h = a.wb + (size_t)h * (3 * NCT * KB * 2 * 512);
-      if (two) { if (one) dx_accumulate<NTH, KCX, 2, true>(dxa, Tp, wb_h, wave, lane); else dx_accumulate<NTH, KCX, 2, false>(dxa, Tp, wb_h, wave, lane); }
-      else { if (one) dx_accumulate<NTH, KCX, 1, true>(dxa, Tp, wb_h, wave, lane); else dx_accumulate<NTH, KCX, 1, false>(dxa, Tp, wb_h, wave, lane); }
-    }
+    if (two) { if (one) dx_phase<NTH, KCX, 2, true>(dxa, dp0, Tp, wb_h, wave, ld); else dx_phase<NTH, KCX, 2, false>(dxa, dp0, Tp, wb_h, wave, ld); }
+    else { if (one) dx_phase<NTH, KCX, 1, true>(dxa, dp0, Tp, wb_h, wave, ld); else dx_phase<NTH, KCX, 1, false>(dxa, dp0, Tp, wb_h, wave, ld); }
+    AFSTAMP(45 + 16 * h);
     // no barrier here: the next head first rewrites the x planes (R1, not read above) and reaches its barrier (A) before it
     // touches R2 / R3
   }
-  __syncthreads();                                           // the last head's readers of R1 (barrier D) are long past; R2 readers done
   // ---- dx = accumulated products + ds1 -> rows out as 16-byte stores ----
+  // (R1 was last read before barrier (D) of the last head: free).  The residual rows are requested first: they travel under the
+  // tail of the products and the stage writes.
+  float4 r4[NQ];
+  {
+    const int qpr = a.D >> 2;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int e = tid + i * AF_THR, q = e / qpr, c4 = e - q * qpr;
+      r4[i] = *reinterpret_cast<const float4*>(a.ds1 + (row0 + min(q, Tv - 1)) * a.D + 4 * c4);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     if (s == 1 && !two) break;
@@ -640,16 +733,20 @@ __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) dxs[(16 * rt + 4 * (lane >> 4) + r) * LDS_DX + 16 * ct + (lane & 15)] = dxa[s][rt][r];
   }
-  __syncthreads();
+  AFSTAMP(64);
+  lds_barrier();
   {
     const int qpr = a.D >> 2;
-    for (int e = tid; e < Tv * qpr; e += AF_THR) {
-      const int q = e / qpr, c4 = e - q * qpr;
-      const float4 r4 = *reinterpret_cast<const float4*>(a.ds1 + (row0 + q) * a.D + 4 * c4);
-      const float4 s4 = *reinterpret_cast<const float4*>(dxs + q * LDS_DX + 4 * c4);
-      *reinterpret_cast<float4*>(a.dx + (row0 + q) * a.D + 4 * c4) = make_float4(s4.x + r4.x, s4.y + r4.y, s4.z + r4.z, s4.w + r4.w);
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int e = tid + i * AF_THR, q = e / qpr, c4 = e - q * qpr;
+      if (q < Tv) {
+        const float4 s4 = *reinterpret_cast<const float4*>(dxs + q * LDS_DX + 4 * c4);
+        *reinterpret_cast<float4*>(a.dx + (row0 + q) * a.D + 4 * c4) = make_float4(s4.x + r4[i].x, s4.y + r4[i].y, s4.z + r4[i].z, s4.w + r4[i].w);
+      }
     }
   }
+  AFSTAMP(65);
 }
 
 template <int NTH, int KCX>
@@ -661,6 +758,8 @@ constexpr size_t bwd_lds() {
 constexpr int AF_NTH = 5, AF_KCX = 5;
 
 }  // namespace
+
+extern "C" void rd_debug_set_attnfuse_stamps(void* p) { g_af_stamps = (unsigned long long*)p; }   // not part of the ABI
 
 // ---- host interface (rd_temporal.hip) -----------------------------------------------------------------------------------------
 // RD_ATTN_FUSE=0: the round-3 launches (QKV row-block product + attention per (sample, head) + QKV input-gradient product)
@@ -693,7 +792,7 @@ static void fill_args(FAttnArgs& a, const float* x, const void* wf, const void* 
   a.x = x; a.wf = (const __bf16*)wf; a.wb = (const __bf16*)wb; a.bias = bias; a.plan = plan;
   a.T = T; a.B = B; a.D = D; a.H = H; a.hd = hd;
   a.scale = 1.0f / sqrtf((float)hd); a.p_drop = p_drop; a.seed = seed; a.site = site; a.seed_cell = seed_cell();
-  a.one = precision() == RD_PREC_BF16;
+  a.one = precision() == RD_PREC_BF16; a.stamps = g_af_stamps;
 }
 
 int launch_attn_fused_fwd(const float* x, const void* wf, const float* bias, const int32_t* plan, int T, int B, int D, int H, int hd,

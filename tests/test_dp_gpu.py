@@ -255,6 +255,7 @@ def test_rccl_one_rank_collectives_between_graph_replays():
 
 def _tuned_worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.pop("RD_RG_ROWS32", None); os.environ.pop("RD_RG_WAVES16", None)      # pinned knobs switch the tuner off
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from raindrop_amd import dp, synth
