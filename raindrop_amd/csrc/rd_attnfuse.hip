@@ -213,19 +213,29 @@ __device__ __forceinline__ void qkv_project(const QkvPanel<KCX>& p, const __bf16
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) acc[s][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (!one) {
+    // per reduction step: the A fragments of all four row tiles, then the three split products as three SWEEPS over the eight
+    // (column tile, row tile) accumulators -- consecutive MFMAs never touch the same accumulator (a dependent MFMA waits for its
+    // predecessor's passes: the tile-after-tile order ran the matrix pipe at ~50 %)
 #pragma unroll
     for (int kc = 0; kc < KCX; ++kc) {
+      bf8 ah[4], al[4];
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
-        const bf8 ah = *reinterpret_cast<const bf8*>(Xh + rt * 16 * LDX + aoff + kc * 32);
-        const bf8 al = *reinterpret_cast<const bf8*>(Xl + rt * 16 * LDX + aoff + kc * 32);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          acc[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, p.h[s][kc], acc[s][rt], 0, 0, 0);
-          acc[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, p.l[s][kc], acc[s][rt], 0, 0, 0);
-          acc[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, p.h[s][kc], acc[s][rt], 0, 0, 0);
-        }
+        ah[rt] = *reinterpret_cast<const bf8*>(Xh + rt * 16 * LDX + aoff + kc * 32);
+        al[rt] = *reinterpret_cast<const bf8*>(Xl + rt * 16 * LDX + aoff + kc * 32);
       }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], p.h[s][kc], acc[s][rt], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.l[s][kc], acc[s][rt], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.h[s][kc], acc[s][rt], 0, 0, 0);
     }
   } else {
 #pragma unroll
@@ -417,19 +427,20 @@ constexpr size_t fwd_lds() {
 // ------------------------------------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------------------------------------
-// head slice [TS x hd] of a [M, D] tensor: 4 threads per row (thread (r, q): the 16-byte chunks q, q + 4, .. of row r), threads
-// 0..255; every load unconditional from a clamped address, padding applied by the consumer through `ok`
+// head slice [TS x hd] of a [M, D] tensor: 8 threads per row over the whole workgroup (thread (r, q): the 16-byte chunks q, q + 8, ..
+// of row r); every load unconditional from a clamped address, padding applied by the consumer through `ok`
 template <int NTH>
-struct HRegs { float4 v[NTH]; unsigned ok; };
+struct HRegs { float4 v[(4 * NTH + 7) / 8]; unsigned ok; };
 template <int NTH>
-__device__ __forceinline__ void head_request(HRegs<NTH>& h, const float* base, long ld, int Tv, int hd, int lt) {
-  const int t = lt >> 2;
+__device__ __forceinline__ void head_request(HRegs<NTH>& h, const float* base, long ld, int Tv, int hd, int tl) {
+  constexpr int NCH = (4 * NTH + 7) / 8;
+  const int t = tl >> 3;
   const bool rok = t < Tv;
   const float* src = base + (long)(rok ? t : 0) * ld;
   unsigned ok = 0;
 #pragma unroll
-  for (int i = 0; i < NTH; ++i) {
-    const int c = 4 * (lt & 3) + 16 * i;
+  for (int i = 0; i < NCH; ++i) {
+    const int c = 4 * ((tl & 7) + 8 * i);
     const bool cok = c < hd;
     h.v[i] = *reinterpret_cast<const float4*>(src + (cok ? c : 0));
     if (rok && cok) ok |= 1u << i;
@@ -438,8 +449,9 @@ __device__ __forceinline__ void head_request(HRegs<NTH>& h, const float* base, l
 }
 template <int NTH>
 __device__ __forceinline__ void head_mask(HRegs<NTH>& h) {
+  constexpr int NCH = (4 * NTH + 7) / 8;
 #pragma unroll
-  for (int i = 0; i < NTH; ++i)
+  for (int i = 0; i < NCH; ++i)
     if (!((h.ok >> i) & 1u)) h.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
@@ -471,20 +483,26 @@ __device__ __forceinline__ void dx_mma(f32x4 (&dxa)[2][4], const DxPanel<KB>& p,
   const __bf16* Al = Ah + (size_t)HDP * LDT;
 #pragma unroll
   for (int kc = 0; kc < KB; ++kc) {
+    bf8 ah[4], al[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
-      const bf8 ah = frag_t(Ah, LDT, 32 * kc, 16 * rt, lane);
-      if (!ONE) {
-        const bf8 al = frag_t(Al, LDT, 32 * kc, 16 * rt, lane);
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-          dxa[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, p.h[s][kc], dxa[s][rt], 0, 0, 0);
-          dxa[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, p.l[s][kc], dxa[s][rt], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < NS; ++s) dxa[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, p.h[s][kc], dxa[s][rt], 0, 0, 0);
+      ah[rt] = frag_t(Ah, LDT, 32 * kc, 16 * rt, lane);
+      if (!ONE) al[rt] = frag_t(Al, LDT, 32 * kc, 16 * rt, lane);
     }
+    if (!ONE) {                                    // three sweeps over the accumulators (see qkv_project)
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) dxa[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], p.h[s][kc], dxa[s][rt], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) dxa[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.l[s][kc], dxa[s][rt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) dxa[s][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.h[s][kc], dxa[s][rt], 0, 0, 0);
   }
 }
 // p0: the panel of `which` 0, already requested
@@ -546,6 +564,11 @@ __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
   const bool two = wave + AF_WV < NCT;                       // wave-uniform
   constexpr int NQ = (TS * 8 * KCX + AF_THR - 1) / AF_THR;
   QkvPanel<KCX> pan;
+  // dO and O slices of a head + its LSE: requested one head AHEAD (head 0: here), so that only x is waited for at a head's start
+  HRegs<NTH> dov, ov; float lrow;
+  head_request<NTH>(dov, a.dout + row0 * a.D, a.D, Tv, a.hd, tid);
+  head_request<NTH>(ov, a.out + row0 * a.D, a.D, Tv, a.hd, tid);
+  lrow = a.lse[(long)(b * a.H) * a.T + min(tid >> 3, Tv - 1)];
   for (int h = 0; h < a.H; ++h) {
     const int bh = b * a.H + h;
     // ---- requests: x rows (all threads), dO and O slices of the head + LSE (waves 4-7), then the projection's weight panel ----
@@ -553,15 +576,8 @@ __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
     // addresses per tile -- is loop-invariant, and hoisted out of the head loop it stayed live across the whole kernel: spills)
     int tl = tid;
     asm volatile("" : "+v"(tl));
-    const int lt = tl & 255;
     XRows<KCX> xr;
     x_request<KCX>(xr, a.x, row0, Tv, a.D, tl);
-    HRegs<NTH> dov, ov; float lrow = 0.f;
-    if (wh == 1) {                                           // wave-uniform
-      head_request<NTH>(dov, a.dout + row0 * a.D + h * a.hd, a.D, Tv, a.hd, lt);
-      head_request<NTH>(ov, a.out + row0 * a.D + h * a.hd, a.D, Tv, a.hd, lt);
-      lrow = a.lse[(long)bh * a.T + min(lt >> 2, Tv - 1)];
-    }
     // (the lane index too: the panels' 20 + 36 tile-part addresses are loop-invariant and were kept in registers across the loop)
     int lq = lane;
     asm volatile("" : "+v"(lq));
@@ -586,33 +602,36 @@ __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
         *reinterpret_cast<sh8*>(a.xt + (((size_t)(c0 + c) * NCT + j) * 2 + plane) * 512 + lq * 8) = o;
       }
     }
-    if (wh == 1) {
-      // dO -> [query][head dim] planes (zero padded to HDP columns); delta = rowsum(dO * O) in fp32
+    {
+      // dO -> [query][head dim] planes (zero padded to HDP columns); delta = rowsum(dO * O) in fp32: 8 threads per row
+      constexpr int NCH = (4 * NTH + 7) / 8;
       head_mask<NTH>(dov);
       head_mask<NTH>(ov);
       float d = 0.f;
 #pragma unroll
-      for (int i = 0; i < NTH; ++i)
+      for (int i = 0; i < NCH; ++i)
         d += (dov.v[i].x * ov.v[i].x + dov.v[i].y * ov.v[i].y) + (dov.v[i].z * ov.v[i].z + dov.v[i].w * ov.v[i].w);
       d += __shfl_xor(d, 1);
       d += __shfl_xor(d, 2);
-      const int o = (lt >> 2) * LDB + 4 * (lt & 3);
+      d += __shfl_xor(d, 4);
+      const int o = (tl >> 3) * LDB + 4 * (tl & 7);
 #pragma unroll
-      for (int i = 0; i < NTH; ++i) {
+      for (int i = 0; i < NCH; ++i) {
+        static_assert(32 * NCH == HDP, "8 threads x NCH chunks cover exactly the padded head width (chunks >= hd arrive as zeros)");
         const float v[4] = {dov.v[i].x, dov.v[i].y, dov.v[i].z, dov.v[i].w};
         bf4 hi, lo;
         split4(v, hi, lo);
-        *reinterpret_cast<bf4*>(Oh + o + 16 * i) = hi;
-        *reinterpret_cast<bf4*>(Ol + o + 16 * i) = lo;
+        *reinterpret_cast<bf4*>(Oh + o + 32 * i) = hi;
+        *reinterpret_cast<bf4*>(Ol + o + 32 * i) = lo;
       }
-      if (16 * NTH < HDP) {
-        bf4 z;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) z[c] = (__bf16)0.f;
-        *reinterpret_cast<bf4*>(Oh + o + 16 * NTH) = z;
-        *reinterpret_cast<bf4*>(Ol + o + 16 * NTH) = z;
-      }
-      if ((lt & 3) == 0) { dl_s[lt >> 2] = d; lse_s[lt >> 2] = lrow; }
+      if ((tl & 7) == 0) { dl_s[tl >> 3] = d; lse_s[tl >> 3] = lrow; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {   // the NEXT head's dO / O / LSE (past the last head: head 0's again, unused -- unconditional, DESIGN rule 17)
+      const int hn = h + 1 < a.H ? h + 1 : 0;
+      head_request<NTH>(dov, a.dout + row0 * a.D + hn * a.hd, a.D, Tv, a.hd, tl);
+      head_request<NTH>(ov, a.out + row0 * a.D + hn * a.hd, a.D, Tv, a.hd, tl);
+      lrow = a.lse[(long)(b * a.H + hn) * a.T + min(tl >> 3, Tv - 1)];
     }
     AFSTAMP(35 + 16 * h);
     __builtin_amdgcn_sched_barrier(0);
