@@ -69,11 +69,11 @@ def parse():
 def _use_token_plan(cfg):
     """The step runs on the token plan (include/raindrop_hip.h) wherever raindrop_amd.step.TrainStep supports it: the isolated
     roofline loops then measure the kernels on the same layout."""
-    K = cfg["max_len"] * cfg["d_ob"]
+    from raindrop_amd.step import plan_supported
+    prec = {"fp32": 0, "bf16x3": 1, "bf16": 2}[os.environ.get("RD_PRECISION", "bf16x3")]
     D = cfg["d_inp"] * cfg["d_ob"] + 16
-    return (os.environ.get("RD_TOKEN_PLAN", "1") != "0" and os.environ.get("RD_PRECISION", "bf16x3") == "bf16x3" and cfg["d_ob"] == 4
-            and cfg["d_inp"] <= 64 and K <= 240 and K % 16 == 0 and cfg["max_len"] <= 64 and (D + 31) // 32 == 5
-            and (cfg["nhid"] + 31) // 32 == 9)
+    return (os.environ.get("RD_TOKEN_PLAN", "1") != "0"
+            and plan_supported(cfg["d_inp"], cfg["d_ob"], cfg["max_len"], D, cfg["nhead"], cfg["nhid"], prec))
 
 
 def _make_plan(shp, lengths):

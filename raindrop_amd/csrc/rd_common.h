@@ -129,6 +129,9 @@ struct GemmArgs {
   // scatter == 1: rows are (b,f) pairs of a [B,F,K] tensor, columns (t,c); element goes to the
   // [T,B,ldz] layout z[(t*sB + b)*ldz + f*sd + c]   (code/models_rd.py:338-342)
   int scatter; int sB, sF, sd; long ldz;
+  // token plan (rd_plan.h) for the scatter: first row / clamped length of SAMPLE b (plan brow / blen) or null -- element (b, f, t, c)
+  // then goes to row sp_row0[b] + t of z and steps t >= sp_len[b] are not stored (those rows do not exist)
+  const int32_t *sp_row0, *sp_len;
   unsigned long long* stamps;     // debug phase stamps (set by launch_gemm; null in normal runs)
   int one_product;                // RD_PREC_BF16: hi*hi only (set by launch_gemm)
   // batched form (nbatch > 1, nsplit <= 1): problem z = (o, i) = (z / batch_inner, z % batch_inner) reads A + o*a_bo + i*a_bi,

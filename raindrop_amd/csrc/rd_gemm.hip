@@ -101,7 +101,8 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x4 (&acc)[2][2], 
         if (g.scatter && !raw) {
           const int b = m / g.sF, f = m - b * g.sF;
           const int t = n / g.sd, c = n - t * g.sd;
-          g.C[((long)t * g.sB + b) * g.ldz + f * g.sd + c] = v;
+          if (g.sp_row0) { if (t < g.sp_len[b]) g.C[((long)g.sp_row0[b] + t) * g.ldz + f * g.sd + c] = v; }
+          else g.C[((long)t * g.sB + b) * g.ldz + f * g.sd + c] = v;
         } else {
           Cz[(long)m * g.sc_m + n] = v;
         }
@@ -318,7 +319,7 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, f32x4 (&acc)[MI][N
   // general loop below interleaves loads, flag tests and stores per iteration; measured 11 k cycles per 64 x 128 tile against
   // a 25 k-cycle main loop in the panel kernel.
   if (!raw && (vec || (svec && !g.posmask)) && !g.residual && !(g.drop_p > 0.f)) {
-    float rsc[ITER]; float4 pm[ITER]; int bq[ITER], fq[ITER];
+    float rsc[ITER]; float4 pm[ITER]; int bq[ITER], fq[ITER], r0q[ITER], lnq[ITER];
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int e = tid + it * NTHR;
@@ -326,8 +327,11 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, f32x4 (&acc)[MI][N
       const int mc = min(m0 + rl, g.M - 1), nc = min(n0 + 4 * q, g.N - 4);        // clamped: always legal addresses
       rsc[it] = g.rowscale ? g.rowscale[mc % g.rs_period] : 1.f;
       pm[it] = g.posmask ? *reinterpret_cast<const float4*>(g.posmask + (long)mc * g.pm_m + nc) : make_float4(1.f, 1.f, 1.f, 1.f);
-      bq[it] = 0; fq[it] = 0;
-      if (svec) { bq[it] = mc / g.sF; fq[it] = mc - bq[it] * g.sF; }
+      bq[it] = 0; fq[it] = 0; r0q[it] = 0; lnq[it] = 0x7fffffff;
+      if (svec) {
+        bq[it] = mc / g.sF; fq[it] = mc - bq[it] * g.sF;
+        if (g.sp_row0) { r0q[it] = g.sp_row0[bq[it]]; lnq[it] = g.sp_len[bq[it]]; }      // uniform flag; requested with the rest
+      }
     }
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
@@ -347,6 +351,11 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, f32x4 (&acc)[MI][N
         if (g.posmask) x = (pmv[c] > 0.f) ? x : 0.f;
         if (g.cscale != 0.f) x *= g.cscale;
         v[c] = x;
+      }
+      if (svec && g.sp_row0) {                            // token plan: row of step t = first row of the sample + t; padded steps have none
+        if ((n >> 2) < lnq[it])
+          *reinterpret_cast<float4*>(g.C + ((long)r0q[it] + (n >> 2)) * g.ldz + fq[it] * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        continue;
       }
       float* dst = svec ? g.C + ((long)(n >> 2) * g.sB + bq[it]) * g.ldz + fq[it] * 4 : Cz + (long)m * g.sc_m + n;
       *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
@@ -425,12 +434,17 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, f32x4 (&acc)[MI][N
     if (g.scatter && !raw) {
       const int b = m / g.sF, f = m - b * g.sF;
       if (svec) {                                     // d_ob = 4: the column quad is one (t, b, f) cell of z
-        *reinterpret_cast<float4*>(g.C + ((long)(n >> 2) * g.sB + b) * g.ldz + f * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        if (g.sp_row0) {
+          if ((n >> 2) < g.sp_len[b])
+            *reinterpret_cast<float4*>(g.C + ((long)g.sp_row0[b] + (n >> 2)) * g.ldz + f * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        } else
+          *reinterpret_cast<float4*>(g.C + ((long)(n >> 2) * g.sB + b) * g.ldz + f * 4) = make_float4(v[0], v[1], v[2], v[3]);
         continue;
       }
       for (int c = 0; c < nv; ++c) {
         const int t = (n + c) / g.sd, cc = (n + c) - t * g.sd;
-        g.C[((long)t * g.sB + b) * g.ldz + f * g.sd + cc] = v[c];
+        if (g.sp_row0) { if (t < g.sp_len[b]) g.C[((long)g.sp_row0[b] + t) * g.ldz + f * g.sd + cc] = v[c]; }
+        else g.C[((long)t * g.sB + b) * g.ldz + f * g.sd + cc] = v[c];
       }
     } else if (vec) {
       *reinterpret_cast<float4*>(Cz + (long)m * g.sc_m + n) = make_float4(v[0], v[1], v[2], v[3]);

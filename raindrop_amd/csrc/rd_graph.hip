@@ -1,6 +1,7 @@
 // rd_graph.hip -- sensor-graph construction (integer work, bit-exact), per-target edge softmax
 // with wavefront-shuffle reductions, and the positional-encoding / padding-mask kernel.
 #include "rd_common.h"
+#include "rd_plan.h"
 
 namespace rd {
 namespace {
@@ -96,12 +97,18 @@ __global__ __launch_bounds__(256) void k_pe_mask(const float* __restrict__ times
                                                  const int64_t* __restrict__ lengths,
                                                  const float* __restrict__ ts, float* __restrict__ z,
                                                  uint8_t* __restrict__ mask, int T, int B, int D,
-                                                 int Dm, int H) {
+                                                 int Dm, int H, const int32_t* __restrict__ sp_row0, const int32_t* __restrict__ sp_len) {
   const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (i >= (long)T * B) return;
   const int t = (int)(i / B), b = (int)(i - (long)t * B);
+  mask[(long)b * T + t] = (uint8_t)((int64_t)t >= lengths[b]);
+  long zrow = i;
+  if (sp_row0) {                                   // token plan: the step's row is sample b's first row + t; padded steps have none
+    if (t >= sp_len[b]) return;
+    zrow = (long)sp_row0[b] + t;
+  }
   const float tm = times[i];
-  float* row = z + i * D + Dm;
+  float* row = z + zrow * D + Dm;
   for (int k = 0; k < H; ++k) {
     const float a = tm / ts[k];
     float sn, cs;
@@ -109,7 +116,6 @@ __global__ __launch_bounds__(256) void k_pe_mask(const float* __restrict__ times
     row[k] = sn;
     row[H + k] = cs;
   }
-  mask[(long)b * T + t] = (uint8_t)((int64_t)t >= lengths[b]);
 }
 
 // torch_geometric.utils.softmax over an explicit edge list (duplicates allowed), normalised by
@@ -196,8 +202,10 @@ extern "C" int rd_pe_mask(const rd_shape* s, const float* times, const int64_t* 
   RD_REQUIRE(times && lengths && timescales && z && mask, "NULL tensor");
   const long n = (long)s->T * s->B;
   const int Dm = s->F * s->d_ob, D = Dm + s->d_pe;
+  const int32_t* tp = token_plan();                  // registered plan: the PE rows follow it (rd_plan.h brow / blen)
   hipLaunchKernelGGL(k_pe_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     times, lengths, timescales, z, mask, s->T, s->B, D, Dm, s->d_pe / 2);
+                     times, lengths, timescales, z, mask, s->T, s->B, D, Dm, s->d_pe / 2,
+                     tp ? tp + plan::brow_base(s->B, s->T) : nullptr, tp ? tp + plan::blen_base(s->B, s->T) : nullptr);
   return check_launch("k_pe_mask");
 }
 

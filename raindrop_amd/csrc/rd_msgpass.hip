@@ -67,18 +67,25 @@ __global__ __launch_bounds__(256) void k_msg_dz2(const float* __restrict__ dz,
                                                  const float* __restrict__ z,
                                                  const float* __restrict__ ssum,
                                                  float* __restrict__ dz2, int B, int T, int F, int d,
-                                                 long ldz) {
+                                                 long ldz, const int32_t* __restrict__ sp_row0, const int32_t* __restrict__ sp_len) {
   const int b = blockIdx.x;
   const int Fd = F * d;
   const long total = (long)T * Fd;
+  // token plan: sample b's step t lives at row sp_row0[b] + t of z / dz; steps >= sp_len[b] have no row and a zero gradient
+  const long row0 = sp_row0 ? sp_row0[b] : b;
+  const long rstep = sp_row0 ? 1 : B;
+  const int len = sp_row0 ? sp_len[b] : T;
   // iterate in the SOURCE order (t, f, c) so the strided global reads are coalesced
   for (long i = blockIdx.y * (long)blockDim.x + threadIdx.x; i < total;
        i += (long)gridDim.y * blockDim.x) {
     const int t = (int)(i / Fd);
     const int fc = (int)(i - (long)t * Fd);
     const int f = fc / d, c = fc - f * d;
-    const long zi = ((long)t * B + b) * ldz + fc;
-    const float g = (z[zi] > 0.f) ? dz[zi] * ssum[f] : 0.f;
+    float g = 0.f;
+    if (t < len) {
+      const long zi = (row0 + (long)t * rstep) * ldz + fc;
+      g = (z[zi] > 0.f) ? dz[zi] * ssum[f] : 0.f;
+    }
     dz2[((long)b * F + f) * ((long)T * d) + t * d + c] = g;
   }
 }
@@ -254,7 +261,10 @@ extern "C" int rd_msgpass_fwd(const rd_shape* s, const float* src, const float* 
     return fused_msgpass_fwd(L, src, R_u, b1, b2, ssum, fv.wt, p_drop, seed, fv.tpX, fv.tpY1, fv.m1, fv.m2, fv.mx, z, ldz,
                              st, nullptr, nullptr, nullptr, nullptr, 0);
   }
-  if (token_plan()) return fail(RD_EUNSUPPORTED, "token plan: only the fused message-passing path (F <= 64, K <= 240, bf16x3) reads it");
+  // token plan on the unfused path (round 4): the products run on all B*F graph rows as before -- lin_value mixes ALL of a
+  // sensor's time steps, observed ones past `lengths` included -- only the last product's scatter follows the plan: step t of
+  // sample b goes to row brow[b] + t, steps >= blen[b] are not stored (nothing ever reads them)
+  const int32_t* tp = token_plan();
   {
     const long per = (long)F * K;
     int gy = (int)((per + 255) / 256); if (gy > 64) gy = 64;
@@ -278,6 +288,7 @@ extern "C" int rd_msgpass_fwd(const rd_shape* s, const float* src, const float* 
   g.A = y1save; g.B = W2; g.bias = b2;
   if (tiles) g.Btiles = v.wt[1];
   g.C = z; g.scatter = 1; g.sB = B; g.sF = F; g.sd = d; g.ldz = ldz;
+  if (tp) { g.sp_row0 = tp + plan::brow_base(B, T); g.sp_len = tp + plan::blen_base(B, T); }
   return launch_gemm(g, st);
 }
 
@@ -304,7 +315,6 @@ static int sensor_stage_fwd_impl(const rd_shape* s, const float* src, const floa
     return fused_msgpass_fwd(L, src, R_u, b1, b2, ssum, fv.wt, p_drop, seed, fv.tpX, fv.tpY1, fv.m1, fv.m2, fv.mx, z, ldz,
                              st, times, lengths, timescales, mask, s->d_pe);
   }
-  if (token_plan()) return fail(RD_EUNSUPPORTED, "token plan: only the fused message-passing path (F <= 64, K <= 240, bf16x3) reads it");
   if ((rc = rd_pe_mask(s, times, lengths, timescales, z, mask, stream))) return rc;
   return rd_msgpass_fwd(s, src, R_u, W1, b1, W2, b2, ssum, p_drop, seed, z, ldz, saved, saved_bytes, stream);
 }
@@ -384,7 +394,7 @@ extern "C" int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* 
       return rc;
     return fused_dw(L, P, fv.tpX, fv.tpY1, fw.tpD1, fw.tpD2, fw.ones, fw.part, fw.rupart, dW1, db1, dW2, db2, dR_u, st);
   }
-  if (token_plan()) return fail(RD_EUNSUPPORTED, "token plan: only the fused message-passing path (F <= 64, K <= 240, bf16x3) reads it");
+  const int32_t* tp = token_plan();
   MsgWs w = carve(s, workspace);
   RD_REQUIRE(workspace && workspace_bytes >= w.bytes, "workspace too small: %zu < %zu",
              workspace_bytes, w.bytes);
@@ -392,7 +402,8 @@ extern "C" int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* 
   {
     const long per = (long)F * K;
     int gy = (int)((per + 255) / 256); if (gy > 64) gy = 64;
-    hipLaunchKernelGGL(k_msg_dz2, dim3(B, gy), dim3(256), 0, st, dz, z, ssum, w.dz2, B, T, F, d, (long)ldz);
+    hipLaunchKernelGGL(k_msg_dz2, dim3(B, gy), dim3(256), 0, st, dz, z, ssum, w.dz2, B, T, F, d, (long)ldz,
+                       tp ? tp + plan::brow_base(B, T) : nullptr, tp ? tp + plan::blen_base(B, T) : nullptr);
     if ((rc = check_launch("k_msg_dz2"))) return rc;
   }
   // dz1 = (dz2 W2) * ssum[f] * (y1 > 0)

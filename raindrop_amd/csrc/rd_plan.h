@@ -22,6 +22,9 @@
 //                                           chunks; coff[B] = their total, also at [5]): the row order in which the fused attention
 //                                           kernels (rd_attnfuse.hip) export x and dqkv as weight-gradient row tiles -- a sample's
 //                                           rows start a chunk there, so a workgroup that owns one sample writes whole tile parts
+//   [.. + B + 1]      brow[b], b = 0..B-1   first row of SAMPLE b (= off[rank[b]]) and
+//   [.. + B]          blen[b]               its clamped length: one independent look-up each for kernels that walk the caller's
+//                                           sample order (the unfused message passing's scatter / gather, rd_pe_mask)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -39,7 +42,9 @@ __host__ __device__ inline int order_base(int B) { return HDR + 2 * B + 1; }
 __host__ __device__ inline int len_base(int B) { return HDR + 3 * B + 1; }
 __host__ __device__ inline int cnt_base(int B) { return HDR + 4 * B + 1; }
 __host__ __device__ inline int coff_base(int B, int T) { return HDR + 4 * B + 1 + T + 1; }
-__host__ __device__ inline size_t ints(int B, int T) { return (size_t)HDR + 5 * (size_t)B + 2 + T + 1; }
+__host__ __device__ inline int brow_base(int B, int T) { return HDR + 5 * B + 2 + T + 1; }
+__host__ __device__ inline int blen_base(int B, int T) { return HDR + 6 * B + 2 + T + 1; }
+__host__ __device__ inline size_t ints(int B, int T) { return (size_t)HDR + 7 * (size_t)B + 2 + T + 1; }
 
 
 #if defined(__HIPCC__)
@@ -107,6 +112,9 @@ __device__ inline void token_plan_body(const int64_t* __restrict__ lengths, int3
     const int l = len[b];
     const int r = cnt[l] + cc[(b >> 6) * T1 + l] + within[b];
     rank[b] = r; order[r] = b; lenr[r] = l;
+    int s = 0;                                             // off[r], per sample (the off[] loop below recomputes it per rank)
+    for (int t = 0; t < T; ++t) s += min(r, cnt[t]);
+    p[plan::brow_base(B, T) + b] = s; p[plan::blen_base(B, T) + b] = l;
   }
   // off[r] = sum of the r longest lengths = sum_t min(r, cnt[t])   (the samples with len > t are the first cnt[t] ranks)
   for (int r = tid; r <= B; r += nthr) {

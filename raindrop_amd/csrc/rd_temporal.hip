@@ -1246,7 +1246,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_one_b16w(AttnArgs a, int one) 
 //    alpha = 1 -- and is skipped: one 64-bit "tile has a live key" word per sample, built from the key mask before the loop;
 //  * the NEXT tile's rows are requested while the current tile is computed (register double buffer) and the loop's barriers
 //    order LDS only (lds_barrier: no vmcnt drain).
-// Same masks, same dropout quads (attn_quad), same saved LSE as the fp32 kernels; padded layout only.
+// Same masks, same dropout quads (attn_quad), same saved LSE as the fp32 kernels; padded layout or token plan (AttnRows).
 // ------------------------------------------------------------------------------------------------
 constexpr int QW = 8;                   // waves per workgroup: 16-row blocks of the owned dimension
 constexpr int QROWS = 16 * QW;
@@ -1420,25 +1420,30 @@ __global__ __launch_bounds__(64 * QW) void k_attn_fwd_b16(AttnArgs a) {
   const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
   const int qw0 = blockIdx.x * QROWS + wave * 16;             // the wave's first query
   const int q = qw0 + (lane & 15);
-  const long rs = (long)a.B * 3 * a.D;
-  const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
+  // token plan (round 4): workgroup index b is a RANK, the sample's Tv = len rows sit at row0 .. (AttnRows); keys >= Tv are what
+  // the mask would have removed, query / key super-tiles past Tv do not exist
+  const AttnRows ar = attn_rows(a, b);
+  const int Tv = ar.Tv;
+  if ((int)blockIdx.x * QROWS >= Tv) return;                  // (padded layout: Tv == T, never)
+  const long rs = ar.rstep * 3 * a.D;
+  const float* qb = a.qkv + ar.row0 * 3 * a.D + h * a.hd;
   const uint8_t* mrow = a.mask + (long)b * a.T;
-  const int nt = (a.T + TS - 1) / TS;
+  const int nt = (Tv + TS - 1) / TS;
   // requests: my query row, key tile 0 (threads 0..255: K, 256..511: V; processed whether live or not -- a dead tile is an identity)
   RawFrag<NKS> qraw;
-  raw_load<NKS, VEC>(qraw, qb + (long)min(q, a.T - 1) * rs, a.hd, G);
+  raw_load<NKS, VEC>(qraw, qb + (long)min(q, Tv - 1) * rs, a.hd, G);
   const bool isv = tid >= 256;
   const int lt = tid & 255;
   const float* kvb = qb + (isv ? 2 : 1) * a.D;
   HeadRegs<NTH> kvr;
-  head_load_t<NTH, VEC>(kvr, kvb, rs, 0, a.T, a.hd, lt);
-  uint8_t mbyte = mrow[min(tid & 63, a.T - 1)];
-  const uint64_t live = live_key_tiles(mrow, a.T, lane) | 1ull;
+  head_load_t<NTH, VEC>(kvr, kvb, rs, 0, Tv, a.hd, lt);
+  uint8_t mbyte = a.plan ? (uint8_t)0 : mrow[min(tid & 63, Tv - 1)];
+  const uint64_t live = a.plan ? ~0ull : (live_key_tiles(mrow, Tv, lane) | 1ull);
   uint64_t seedv = a.seed;
   if (a.p_drop > 0.f && a.seed_cell) seedv += load_uniform_u64(a.seed_cell);
   const float inv_keep = 1.0f / (1.0f - a.p_drop);
   abf8 qh[NKS], ql[NKS];
-  raw_zero<NKS>(qraw, q < a.T, a.hd, G);
+  raw_zero<NKS>(qraw, q < Tv, a.hd, G);
   raw_split<NKS>(qraw, qh, ql);
   float m_i = -INFINITY, l_i = 0.f;                            // l_i: this lane's keys only; combined over the 4 lane rows at the end
   f32x4 o[NTH];                                               // O^T: rows = head columns, column = my query
@@ -1449,11 +1454,11 @@ __global__ __launch_bounds__(64 * QW) void k_attn_fwd_b16(AttnArgs a) {
     const int k0 = kt * TS;
     lds_barrier();                                            // the previous tile's products have read the planes
     head_store_b16<NTH>(kvr, isv ? Vh : Kh, isv ? Vl : Kl, LDB, HDP, lt);
-    if (tid < TS) reinterpret_cast<uint8_t*>(mk)[tid] = (k0 + tid < a.T) ? mbyte : (uint8_t)1;
+    if (tid < TS) reinterpret_cast<uint8_t*>(mk)[tid] = (k0 + tid < Tv) ? mbyte : (uint8_t)1;
     const int kn = next_live_tile(live, kt + 1, nt);
     if (kn < nt) {                                            // in flight during this tile's products
-      head_load_t<NTH, VEC>(kvr, kvb, rs, kn * TS, a.T, a.hd, lt);
-      mbyte = mrow[min(kn * TS + (tid & 63), a.T - 1)];
+      head_load_t<NTH, VEC>(kvr, kvb, rs, kn * TS, Tv, a.hd, lt);
+      if (!a.plan) mbyte = mrow[min(kn * TS + (tid & 63), Tv - 1)];
     }
     lds_barrier();
     f32x4 s[4];
@@ -1494,9 +1499,9 @@ __global__ __launch_bounds__(64 * QW) void k_attn_fwd_b16(AttnArgs a) {
     kt = kn;
   }
   const float l = rows4_sum(l_i);
-  if (q < a.T) {
+  if (q < Tv) {
     const float inv = 1.0f / l;
-    float* orow = a.out + ((long)q * a.B + b) * a.D + h * a.hd;
+    float* orow = a.out + (ar.row0 + (long)q * ar.rstep) * a.D + h * a.hd;
 #pragma unroll
     for (int ct = 0; ct < NTH; ++ct) store_cols4<VEC>(orow, 16 * ct + 4 * G, a.hd, o[ct], inv);
     if (G == 0) a.lse[(long)bh * a.T + q] = m_i + logf(l);
@@ -1517,28 +1522,31 @@ __global__ __launch_bounds__(64 * QW) void k_attn_bwd_dq_b16(AttnArgs a) {
   const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
   const int qw0 = blockIdx.x * QROWS + wave * 16;
   const int q = qw0 + (lane & 15);
-  const int qc = min(q, a.T - 1);
-  const long rs = (long)a.B * 3 * a.D, ro = (long)a.B * a.D;
-  const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
+  const AttnRows ar = attn_rows(a, b);                        // token plan: see k_attn_fwd_b16
+  const int Tv = ar.Tv;
+  if ((int)blockIdx.x * QROWS >= Tv) return;
+  const int qc = min(q, Tv - 1);
+  const long rs = ar.rstep * 3 * a.D, ro = ar.rstep * a.D;
+  const float* qb = a.qkv + ar.row0 * 3 * a.D + h * a.hd;
   const uint8_t* mrow = a.mask + (long)b * a.T;
-  const int nt = (a.T + TS - 1) / TS;
+  const int nt = (Tv + TS - 1) / TS;
   RawFrag<NKS> qraw, doraw, oraw;
   raw_load<NKS, VEC>(qraw, qb + (long)qc * rs, a.hd, G);
-  raw_load<NKS, VEC>(doraw, a.dout + (long)b * a.D + h * a.hd + (long)qc * ro, a.hd, G);
-  raw_load<NKS, VEC>(oraw, a.out + (long)b * a.D + h * a.hd + (long)qc * ro, a.hd, G);
+  raw_load<NKS, VEC>(doraw, a.dout + ar.row0 * a.D + h * a.hd + (long)qc * ro, a.hd, G);
+  raw_load<NKS, VEC>(oraw, a.out + ar.row0 * a.D + h * a.hd + (long)qc * ro, a.hd, G);
   const float lse_q = a.lse[(long)bh * a.T + qc];
   const bool isv = tid >= 256;
   const int lt = tid & 255;
   const float* kvb = qb + (isv ? 2 : 1) * a.D;
   HeadRegs<NTH> kvr;
-  head_load_t<NTH, VEC>(kvr, kvb, rs, 0, a.T, a.hd, lt);
-  uint8_t mbyte = mrow[min(tid & 63, a.T - 1)];
-  const uint64_t live = live_key_tiles(mrow, a.T, lane) | 1ull;
+  head_load_t<NTH, VEC>(kvr, kvb, rs, 0, Tv, a.hd, lt);
+  uint8_t mbyte = a.plan ? (uint8_t)0 : mrow[min(tid & 63, Tv - 1)];
+  const uint64_t live = a.plan ? ~0ull : (live_key_tiles(mrow, Tv, lane) | 1ull);
   uint64_t seedv = a.seed;
   if (a.p_drop > 0.f && a.seed_cell) seedv += load_uniform_u64(a.seed_cell);
   const float inv_keep = 1.0f / (1.0f - a.p_drop);
   abf8 qh[NKS], ql[NKS], gh[NKS], gl[NKS];                     // Q and dO rows of my query, as B operands
-  const bool qok = q < a.T;
+  const bool qok = q < Tv;
   raw_zero<NKS>(qraw, qok, a.hd, G);
   raw_zero<NKS>(doraw, qok, a.hd, G);
   raw_zero<NKS>(oraw, qok, a.hd, G);
@@ -1562,11 +1570,11 @@ __global__ __launch_bounds__(64 * QW) void k_attn_bwd_dq_b16(AttnArgs a) {
     const int k0 = kt * TS;
     lds_barrier();
     head_store_b16<NTH>(kvr, isv ? Vh : Kh, isv ? Vl : Kl, LDB, HDP, lt);
-    if (tid < TS) reinterpret_cast<uint8_t*>(mk)[tid] = (k0 + tid < a.T) ? mbyte : (uint8_t)1;
+    if (tid < TS) reinterpret_cast<uint8_t*>(mk)[tid] = (k0 + tid < Tv) ? mbyte : (uint8_t)1;
     const int kn = next_live_tile(live, kt + 1, nt);
     if (kn < nt) {
-      head_load_t<NTH, VEC>(kvr, kvb, rs, kn * TS, a.T, a.hd, lt);
-      mbyte = mrow[min(kn * TS + (tid & 63), a.T - 1)];
+      head_load_t<NTH, VEC>(kvr, kvb, rs, kn * TS, Tv, a.hd, lt);
+      if (!a.plan) mbyte = mrow[min(kn * TS + (tid & 63), Tv - 1)];
     }
     lds_barrier();
     f32x4 s[4], dp[4];
@@ -1594,7 +1602,7 @@ __global__ __launch_bounds__(64 * QW) void k_attn_bwd_dq_b16(AttnArgs a) {
     kt = kn;
   }
   if (qok) {
-    float* row = a.dqkv + ((long)q * a.B + b) * 3 * a.D + h * a.hd;
+    float* row = a.dqkv + (ar.row0 + (long)q * ar.rstep) * 3 * a.D + h * a.hd;
 #pragma unroll
     for (int ct = 0; ct < NTH; ++ct) store_cols4<VEC>(row, 16 * ct + 4 * G, a.hd, dq[ct], 1.f);
   }
@@ -1616,24 +1624,27 @@ __global__ __launch_bounds__(64 * QW) void k_attn_bwd_dkv_b16(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4;
   const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
   const int key = blockIdx.x * QROWS + wave * 16 + (lane & 15);
-  const int kc = min(key, a.T - 1);
-  const long rs = (long)a.B * 3 * a.D, ro = (long)a.B * a.D;
-  const float* qb = a.qkv + (long)b * 3 * a.D + h * a.hd;
-  const float* dob = a.dout + (long)b * a.D + h * a.hd;
+  const AttnRows ar = attn_rows(a, b);                        // token plan: see k_attn_fwd_b16 (rows >= Tv do not exist: nothing to zero)
+  const int Tv = ar.Tv;
+  if ((int)blockIdx.x * QROWS >= Tv) return;
+  const int kc = min(key, Tv - 1);
+  const long rs = ar.rstep * 3 * a.D, ro = ar.rstep * a.D;
+  const float* qb = a.qkv + ar.row0 * 3 * a.D + h * a.hd;
+  const float* dob = a.dout + ar.row0 * a.D + h * a.hd;
   const uint8_t* mrow = a.mask + (long)b * a.T;
   RawFrag<NKS> kraw, vraw;
   raw_load<NKS, VEC>(kraw, qb + a.D + (long)kc * rs, a.hd, G);
   raw_load<NKS, VEC>(vraw, qb + 2 * a.D + (long)kc * rs, a.hd, G);
-  const uint8_t mkey = mrow[kc];
+  const uint8_t mkey = a.plan ? (uint8_t)0 : mrow[kc];
   // first query tile (threads 0..255: Q, 256..511: dO), lse / delta of its rows (threads 0..63)
   const bool isg = tid >= 256;
   const int lt = tid & 255;
   const float* tb = isg ? dob : qb;
   const long ts = isg ? ro : rs;
   HeadRegs<NTH> tr;
-  head_load_t<NTH, VEC>(tr, tb, ts, 0, a.T, a.hd, lt);
-  float lq = a.lse[(long)bh * a.T + min(tid & 63, a.T - 1)], dlq = a.delta[(long)bh * a.T + min(tid & 63, a.T - 1)];
-  const bool dead = key >= a.T || mkey;
+  head_load_t<NTH, VEC>(tr, tb, ts, 0, Tv, a.hd, lt);
+  float lq = a.lse[(long)bh * a.T + min(tid & 63, Tv - 1)], dlq = a.delta[(long)bh * a.T + min(tid & 63, Tv - 1)];
+  const bool dead = key >= Tv || mkey;
   const bool wave_live = __ballot(!dead) != 0ull;
   if (tid == 0) any_live_s = 0;
   __syncthreads();
@@ -1645,21 +1656,21 @@ __global__ __launch_bounds__(64 * QW) void k_attn_bwd_dkv_b16(AttnArgs a) {
   for (int ct = 0; ct < NTH; ++ct) { dk[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[ct] = dk[ct]; }
   if (any_live) {
     abf8 kh[NKS], kl[NKS], vh[NKS], vl[NKS];
-    raw_zero<NKS>(kraw, key < a.T, a.hd, G);
-    raw_zero<NKS>(vraw, key < a.T, a.hd, G);
+    raw_zero<NKS>(kraw, key < Tv, a.hd, G);
+    raw_zero<NKS>(vraw, key < Tv, a.hd, G);
     raw_split<NKS>(kraw, kh, kl);
     raw_split<NKS>(vraw, vh, vl);
     uint64_t seedv = a.seed;
     if (a.p_drop > 0.f && a.seed_cell) seedv += load_uniform_u64(a.seed_cell);
     const float inv_keep = 1.0f / (1.0f - a.p_drop);
-    for (int q0 = 0; q0 < a.T; q0 += TS) {
+    for (int q0 = 0; q0 < Tv; q0 += TS) {
       lds_barrier();                                          // the previous query tile's products have read the planes
       head_store_b16<NTH>(tr, isg ? Oh : Qh, isg ? Ol : Ql, LDB, HDP, lt);
       if (tid < TS) { lse_s[tid] = lq; dl_s[tid] = dlq; }
-      if (q0 + TS < a.T) {                                    // next query tile, in flight during this one's products
-        head_load_t<NTH, VEC>(tr, tb, ts, q0 + TS, a.T, a.hd, lt);
-        lq = a.lse[(long)bh * a.T + min(q0 + TS + (tid & 63), a.T - 1)];
-        dlq = a.delta[(long)bh * a.T + min(q0 + TS + (tid & 63), a.T - 1)];
+      if (q0 + TS < Tv) {                                     // next query tile, in flight during this one's products
+        head_load_t<NTH, VEC>(tr, tb, ts, q0 + TS, Tv, a.hd, lt);
+        lq = a.lse[(long)bh * a.T + min(q0 + TS + (tid & 63), Tv - 1)];
+        dlq = a.delta[(long)bh * a.T + min(q0 + TS + (tid & 63), Tv - 1)];
       }
       lds_barrier();
       if (!wave_live) continue;                               // uniform per wave; the barriers above are still met
@@ -1680,7 +1691,7 @@ __global__ __launch_bounds__(64 * QW) void k_attn_bwd_dkv_b16(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           pm[j][r] = 0.f; ds[j][r] = 0.f;
-          if (!dead && qj + r < a.T) {
+          if (!dead && qj + r < Tv) {
             const float p = __expf(s[j][r] * a.scale - lr[r]);
             pm[j][r] = p * k4[r];
             ds[j][r] = p * (dp[j][r] * k4[r] - dr[r]) * a.scale;
@@ -1691,8 +1702,8 @@ __global__ __launch_bounds__(64 * QW) void k_attn_bwd_dkv_b16(AttnArgs a) {
       mma_planeT_acc<NTH, ONE>(dk, Qh, Ql, LDB, ds, lane);     // dK^T += Q^T dS
     }
   }
-  if (key < a.T) {
-    float* row = a.dqkv + ((long)key * a.B + b) * 3 * a.D + h * a.hd;
+  if (key < Tv) {
+    float* row = a.dqkv + (ar.row0 + (long)key * ar.rstep) * 3 * a.D + h * a.hd;
 #pragma unroll
     for (int ct = 0; ct < NTH; ++ct) {
       store_cols4<VEC>(row + a.D, 16 * ct + 4 * G, a.hd, dk[ct], 1.f);
@@ -1721,7 +1732,7 @@ static bool attn_vec_ok(const AttnArgs& a) {
 
 static bool attn_b16_mt_ok(const AttnArgs& a) {
   const char* e = getenv("RD_ATTN_B16_MT");           // read per call (tests compare both paths in one process)
-  return !(e && atoi(e) == 0) && precision() != RD_PREC_FP32 && a.T > TS && a.hd <= 96 && !a.plan;
+  return !(e && atoi(e) == 0) && precision() != RD_PREC_FP32 && a.T > TS && a.hd <= 96;
 }
 #define ATTN_LAUNCH_MT(K, grid, lds, arg)                                                                \
   do {                                                                                                   \
@@ -1917,8 +1928,8 @@ int attn_big_bwd(const AttnArgs& a, const float* P, const float* PD, float* dS, 
 }
 
 int dispatch_attn(const AttnArgs& a, int which, hipStream_t st) {
-  if (a.plan && !((which == 0 || which == 3) && attn_b16_ok(a)))
-    return fail(RD_EUNSUPPORTED, "token plan: only the single-tile split-bf16 attention (T <= 64, head_dim <= 96, bf16 modes) reads it");
+  if (a.plan && !(((which == 0 || which == 3) && attn_b16_ok(a)) || (which <= 2 && attn_b16_mt_ok(a))))
+    return fail(RD_EUNSUPPORTED, "token plan: only the split-bf16 attention kernels (head_dim <= 96, bf16 modes) read it");
   if ((which == 0 || which == 3) && attn_b16_ok(a)) {
     switch (cdiv(a.hd, 16)) {
       case 1: return launch_attn_b16<1>(a, which, st);

@@ -32,6 +32,20 @@ def _p(t):
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
+def plan_supported(d_inp, d_ob, T, D, nhead, nhid, precision):
+    """Shapes / modes whose whole step runs on kernels that read a token plan (include/raindrop_hip.h "token plan"): a bf16
+    arithmetic mode (precision 1 = bf16x3, 2 = bf16), the fused row-local encoder chains (ceil(D / 32) == 5 and
+    ceil(nhid / 32) == 9: the P19 and P12 widths), head_dim <= 96 (single-tile attention for T <= 64 -- with in_proj fused in,
+    rd_attnfuse.hip -- or the multi-tile kernels beyond), and either message-passing form (fused LDS-resident for F <= 64,
+    K <= 240 in bf16x3, else the panel products whose last scatter follows the plan).  Round 3 had this for the P19 envelope
+    only; P12 (T = 215) joined in round 4.  The usual A/B switches of the kernels it relies on turn it off."""
+    hd = D // nhead
+    env_on = all(os.environ.get(k, "1") != "0" for k in ("RD_ROWGEMM", "RD_TILE_WGRAD", "RD_ATTN_B16", "RD_ATTN_B16_MT", "RD_LN_FUSE",
+                                                         "RD_LNB_FUSE", "RD_ENC_FUSE", "RD_HEAD_FUSED"))
+    return (precision in (1, 2) and hd * nhead == D and hd <= 96 and (D + 31) // 32 == 5 and (nhid + 31) // 32 == 9
+            and D % 4 == 0 and nhid % 4 == 0 and env_on and os.environ.get("RD_ATTN_BIG", "0") == "0")
+
+
 class TrainStep:
     def __init__(self, model, flat, batch, p_drop=None, use_graph=True, seed=1234, autotune=True, token_plan=None, split=None):
         """model: raindrop_amd.models_rd.Raindrop_v2 on a ROCm device; flat: FlatGradAllReduce over the
@@ -127,16 +141,8 @@ class TrainStep:
         return tuple(p.data_ptr() for p in self.P.values()) + tuple(g.data_ptr() for g in self.G.values())
 
     def _plan_supported(self):
-        """Shapes whose whole step runs on the kernels that read a token plan (the P19 envelope, split-bf16 arithmetic)."""
         m = self.model
-        K = self.T * m.d_ob
-        hd = self.D // m.nhead
-        return (self.lib.rd_get_precision() == 1 and m.d_ob == 4 and m.d_inp <= 64 and K <= 240 and K % 16 == 0
-                and self.T <= 64 and hd <= 96 and (self.D + 31) // 32 == 5 and (m.nhid + 31) // 32 == 9
-                and os.environ.get("RD_K1_FUSED", "1") != "0" and os.environ.get("RD_ROWGEMM", "1") != "0"
-                and os.environ.get("RD_TILE_WGRAD", "1") != "0" and os.environ.get("RD_ATTN_B16", "1") != "0"
-                and os.environ.get("RD_LN_FUSE", "1") != "0" and os.environ.get("RD_LNB_FUSE", "1") != "0"
-                and os.environ.get("RD_ATTN_BIG", "0") == "0")
+        return plan_supported(m.d_inp, m.d_ob, self.T, self.D, m.nhead, m.nhid, self.lib.rd_get_precision())
 
     # ------------------------------------------------------------------------------------------
     def _alloc(self):

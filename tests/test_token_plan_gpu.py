@@ -55,7 +55,9 @@ def test_token_plan_bit_exact(B, T, seed):
     assert np.array_equal(p[o:o + B], ref["order"]); o += B
     assert np.array_equal(p[o:o + B], ref["lenr"]); o += B
     assert np.array_equal(p[o:o + T + 1], ref["cnt"]); o += T + 1
-    assert np.array_equal(p[o:o + B + 1], ref["coff"]) and p[5] == ref["coff"][-1]
+    assert np.array_equal(p[o:o + B + 1], ref["coff"]) and p[5] == ref["coff"][-1]; o += B + 1
+    assert np.array_equal(p[o:o + B], ref["off"][ref["rank"]]); o += B              # brow[b]: first row of sample b
+    assert np.array_equal(p[o:o + B], np.clip(lengths, 0, T))                      # blen[b]
 
 
 def _run_step(cfg, gs, batch, token_plan, use_graph, p_drop=0.0, steps=1, seed_params=7):
@@ -348,3 +350,66 @@ def test_fused_attention_launch_vs_the_three_launches_it_replaces(case, p_drop, 
     assert np.abs(g1 - g0).max() < 2e-6, float(np.abs(g1 - g0).max())
     for n in live:
         assert _rel(gr1[n], gr0[n]) < 2e-5, (n, _rel(gr1[n], gr0[n]))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Round 4: the plan beyond the P19 envelope -- P12 (T = 215: the panel-product message passing whose last scatter follows the plan,
+# the multi-tile attention kernels on plan rows, the D = 160 / nhid = 288 chains) and the single-product (bf16) arithmetic mode.
+# ------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg_name,B,mode", [("P12", 12, 1), ("P12", 40, 1), ("P19", 48, 2), ("P12", 12, 2)])
+@pytest.mark.parametrize("case", ["random", "min_length", "first_time_zero"])
+def test_token_plan_beyond_the_p19_envelope(cfg_name, B, mode, case):
+    """TrainStep on the compact layout against TrainStep on the padded layout, same batch, same parameters, dropout off, in the
+    arithmetic mode `mode` (1 = bf16x3, 2 = bf16 single product: compared with ITSELF on the padded layout, so the bounds stay
+    the summation-order ones -- loss 2e-6, logits 2e-6 (2e-5 in the single-product mode, whose per-sample arithmetic follows the
+    row tiling), gradients 2e-5 of max-norm (1e-3 in the single-product mode: 8-bit mantissas amplify every reordering)."""
+    cfg = synth.make_config(cfg_name)
+    gs = synth.make_structure(cfg, "sparse")
+    batch = _case_batch(cfg, B, case, seed=91)
+    _lib.call("rd_set_precision", mode)
+    try:
+        la, ga, gra, sa = _run_step(cfg, gs, batch, True, True, steps=2)
+        lb, gb, grb, sb_ = _run_step(cfg, gs, batch, False, True, steps=2)
+    finally:
+        _lib.call("rd_set_precision", 1)
+    ltol, gtol = (2e-6, 2e-5) if mode == 1 else (2e-5, 1e-3)
+    assert la[0] == la[1]
+    assert abs(la[1] - lb[1]) < ltol * max(1.0, abs(lb[1])), (la, lb)
+    assert np.abs(ga - gb).max() < ltol, float(np.abs(ga - gb).max())
+    for n in gra:
+        assert _rel(gra[n], grb[n]) < gtol, (n, _rel(gra[n], grb[n]))
+    p = sa.plan.cpu().numpy()
+    assert p[0] == int(torch.clamp(batch["lengths"], 0, cfg["max_len"]).sum())
+    sa.close(); sb_.close()
+
+
+def test_p12_plan_graph_replayed_on_new_batches_with_dropout():
+    """The P12 step captured once and replayed on batches of other lengths, dropout on: bit-equal to a fresh eager step on the same
+    plan and seed cell (the multi-tile attention and the plan-following scatter see rows of the previous batch beyond M_live)."""
+    cfg = synth.make_config("P12")
+    gs = synth.make_structure(cfg, "ones")
+    B = 24
+    seq = ["full_length", "random", "short", "random"]
+    batches = [_seq_batch(cfg, B, c, seed=27 + 5 * i) for i, c in enumerate(seq)]
+    dv = {k: (None if v is None else v.to(DEV).clone()) for k, v in batches[0].items()}
+    step, named, live = _make_step(cfg, gs, dv, True, True, 0.2)
+    assert step.plan is not None
+    got = []
+    for k, bt in enumerate(batches):
+        _load_into(dv, bt)
+        step.seed_cell.fill_(500 + k)
+        step.run()
+        got.append(_snapshot(step, named, live))
+    step.close()
+    for k, bt in enumerate(batches):
+        dref = {kk: (None if v is None else v.to(DEV)) for kk, v in bt.items()}
+        ref, rnamed, _ = _make_step(cfg, gs, dref, True, False, 0.2)
+        ref.seed_cell.fill_(500 + k)
+        ref.run()
+        rl, rg, rgr = _snapshot(ref, rnamed, live)
+        ref.close()
+        l, g, gr = got[k]
+        assert np.isfinite(l) and l == rl, (seq[k], l, rl)
+        assert np.array_equal(g, rg), seq[k]
+        for n in live:
+            assert np.array_equal(gr[n], rgr[n]), (seq[k], n, _rel(gr[n], rgr[n]))
