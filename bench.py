@@ -361,7 +361,7 @@ def _enc_pmc_traffic(B, cfg):
         return None, "unavailable: %r" % (e,)
 
 
-ENC_SOURCES = ("rd_temporal.hip", "rd_rowgemm.hip", "rd_encfuse.hip", "rd_tile_wgrad.hip", "rd_plan.hip")
+ENC_SOURCES = ("rd_temporal.hip", "rd_rowgemm.hip", "rd_encfuse.hip", "rd_attnfuse.hip", "rd_tile_wgrad.hip", "rd_plan.hip", "rd_plan.h")
 
 
 def enc_source_hash():

@@ -177,7 +177,7 @@ size_t rd_msgpass_saved_bytes(const rd_shape* s);       /* forward -> backward h
  * planes; other shapes, bf16 modes: W1, W2, W2^T, W1^T as native tiles, 4 x 4 ceil16(K) ceil32(K) bytes).
  * p_drop > 0 applies nn.Dropout to the embedding h (code/models_rd.py:296) with a counter-based mask
  * that is a pure function of (seed, element index); p_drop = 0 in eval mode.
- * Shapes with F <= 64, d_ob = 4, K = T*d_ob <= 240, K % 16 == 0 (P19) run as ONE fused
+ * Shapes with F <= 48, d_ob = 4, K = T*d_ob <= 240, K % 16 == 0 (P19) run as ONE fused
  * LDS-resident kernel per batch (one workgroup per sample); others as two panel products (rd_gemm.hip:
  * k_gemm_panel) behind the observation-embedding kernel. */
 int rd_msgpass_fwd(const rd_shape* s, const float* src, const float* R_u, const float* W1,

@@ -758,7 +758,13 @@ extern "C" void rd_debug_set_encfuse_stamps(void* p) { g_ef_stamps = (unsigned l
 bool encfuse_ok(int D, int H) {
   const char* e = getenv("RD_ENC_FUSE");               // read per call (tests compare the fused and the unfused path in one process)
   const bool enabled = !(e && atoi(e) == 0);
-  return enabled && precision() != RD_PREC_FP32 && (D + 31) / 32 == KCD && (H + 31) / 32 == KCH && (D % 4) == 0 && (H % 4) == 0;
+  // widths: the two compiled-in pairs (P19, P12).  The runtime-width instantiation of the backward chain spills 84 bytes per lane
+  // (DESIGN rule 11): it runs only when asked for explicitly (RD_ENC_SPECIALIZE=0: the A/B and the parity test of the two);
+  // any other width in the envelope takes the separate row-block launches.
+  const char* sp = getenv("RD_ENC_SPECIALIZE");
+  const bool runtime_widths = sp && atoi(sp) == 0;
+  return enabled && precision() != RD_PREC_FP32 && (D + 31) / 32 == KCD && (H + 31) / 32 == KCH && (D % 4) == 0 && (H % 4) == 0 &&
+         (runtime_widths || ef_specialize(D, H) != 0);
 }
 
 // RD_ENC_FUSE_TALL=0 pins the block height to 32 rows (A/B of the device-side choice)

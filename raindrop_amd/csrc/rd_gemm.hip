@@ -101,8 +101,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x4 (&acc)[2][2], 
         if (g.scatter && !raw) {
           const int b = m / g.sF, f = m - b * g.sF;
           const int t = n / g.sd, c = n - t * g.sd;
-          if (g.sp_row0) { if (t < g.sp_len[b]) g.C[((long)g.sp_row0[b] + t) * g.ldz + f * g.sd + c] = v; }
-          else g.C[((long)t * g.sB + b) * g.ldz + f * g.sd + c] = v;
+          g.C[((long)t * g.sB + b) * g.ldz + f * g.sd + c] = v;
         } else {
           Cz[(long)m * g.sc_m + n] = v;
         }
@@ -319,7 +318,10 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, f32x4 (&acc)[MI][N
   // general loop below interleaves loads, flag tests and stores per iteration; measured 11 k cycles per 64 x 128 tile against
   // a 25 k-cycle main loop in the panel kernel.
   if (!raw && (vec || (svec && !g.posmask)) && !g.residual && !(g.drop_p > 0.f)) {
-    float rsc[ITER]; float4 pm[ITER]; int bq[ITER], fq[ITER], r0q[ITER], lnq[ITER];
+    // scatter: element offset of the thread's (b, f) cell at step 0 and the sample's live steps (same two registers per row as
+    // before the token plan: the step stride carries the layout -- sB * ldz on the padded layout, ldz on the plan's)
+    float rsc[ITER]; float4 pm[ITER]; int boff[ITER], lnq[ITER];
+    const long tstride = g.sp_row0 ? g.ldz : (long)g.sB * g.ldz;
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int e = tid + it * NTHR;
@@ -327,10 +329,12 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, f32x4 (&acc)[MI][N
       const int mc = min(m0 + rl, g.M - 1), nc = min(n0 + 4 * q, g.N - 4);        // clamped: always legal addresses
       rsc[it] = g.rowscale ? g.rowscale[mc % g.rs_period] : 1.f;
       pm[it] = g.posmask ? *reinterpret_cast<const float4*>(g.posmask + (long)mc * g.pm_m + nc) : make_float4(1.f, 1.f, 1.f, 1.f);
-      bq[it] = 0; fq[it] = 0; r0q[it] = 0; lnq[it] = 0x7fffffff;
+      boff[it] = 0; lnq[it] = 0x7fffffff;
       if (svec) {
-        bq[it] = mc / g.sF; fq[it] = mc - bq[it] * g.sF;
-        if (g.sp_row0) { r0q[it] = g.sp_row0[bq[it]]; lnq[it] = g.sp_len[bq[it]]; }      // uniform flag; requested with the rest
+        const int bb = mc / g.sF, ff = mc - bb * g.sF;
+        int r0 = bb;
+        if (g.sp_row0) { r0 = g.sp_row0[bb]; lnq[it] = g.sp_len[bb]; }                    // uniform flag; requested with the rest
+        boff[it] = (int)(r0 * g.ldz) + ff * 4;
       }
     }
 #pragma unroll
@@ -352,12 +356,8 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, f32x4 (&acc)[MI][N
         if (g.cscale != 0.f) x *= g.cscale;
         v[c] = x;
       }
-      if (svec && g.sp_row0) {                            // token plan: row of step t = first row of the sample + t; padded steps have none
-        if ((n >> 2) < lnq[it])
-          *reinterpret_cast<float4*>(g.C + ((long)r0q[it] + (n >> 2)) * g.ldz + fq[it] * 4) = make_float4(v[0], v[1], v[2], v[3]);
-        continue;
-      }
-      float* dst = svec ? g.C + ((long)(n >> 2) * g.sB + bq[it]) * g.ldz + fq[it] * 4 : Cz + (long)m * g.sc_m + n;
+      if (svec && (n >> 2) >= lnq[it]) continue;          // token plan: padded steps have no row
+      float* dst = svec ? g.C + (long)(n >> 2) * tstride + boff[it] : Cz + (long)m * g.sc_m + n;
       *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
     }
     return;
@@ -434,17 +434,12 @@ __device__ __forceinline__ void epilogue_t(const GemmArgs& g, f32x4 (&acc)[MI][N
     if (g.scatter && !raw) {
       const int b = m / g.sF, f = m - b * g.sF;
       if (svec) {                                     // d_ob = 4: the column quad is one (t, b, f) cell of z
-        if (g.sp_row0) {
-          if ((n >> 2) < g.sp_len[b])
-            *reinterpret_cast<float4*>(g.C + ((long)g.sp_row0[b] + (n >> 2)) * g.ldz + f * 4) = make_float4(v[0], v[1], v[2], v[3]);
-        } else
-          *reinterpret_cast<float4*>(g.C + ((long)(n >> 2) * g.sB + b) * g.ldz + f * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(g.C + ((long)(n >> 2) * g.sB + b) * g.ldz + f * 4) = make_float4(v[0], v[1], v[2], v[3]);
         continue;
       }
-      for (int c = 0; c < nv; ++c) {
+      for (int c = 0; c < nv; ++c) {                  // (the token plan's scatter takes the straight path above: launch_gemm checks)
         const int t = (n + c) / g.sd, cc = (n + c) - t * g.sd;
-        if (g.sp_row0) { if (t < g.sp_len[b]) g.C[((long)g.sp_row0[b] + t) * g.ldz + f * g.sd + cc] = v[c]; }
-        else g.C[((long)t * g.sB + b) * g.ldz + f * g.sd + cc] = v[c];
+        g.C[((long)t * g.sB + b) * g.ldz + f * g.sd + cc] = v[c];
       }
     } else if (vec) {
       *reinterpret_cast<float4*>(Cz + (long)m * g.sc_m + n) = make_float4(v[0], v[1], v[2], v[3]);
@@ -952,6 +947,10 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (!bkc && a.sb_n != 1) return fail(RD_EINVAL, "gemm: B needs a unit stride");
   if (a.nbatch > 1 && (a.nsplit > 1 || a.A2 || a.rowsum || a.scatter || a.batch_inner < 1))
     return fail(RD_EINVAL, "gemm: the batched form takes plain single-pass products only");
+  // the token plan's scatter exists on the straight epilogue of the bf16 kernels only (16-byte cells, no mask / residual / dropout)
+  if (a.sp_row0 && !(a.scatter && a.sd == 4 && (a.N & 3) == 0 && (a.ldz & 3) == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0 &&
+                     !a.posmask && !a.residual && !(a.drop_p > 0.f) && a.nsplit <= 1 && a.sp_len && precision() != RD_PREC_FP32))
+    return fail(RD_EUNSUPPORTED, "gemm: the plan-following scatter needs d_ob = 4, 16-byte cells and a plain epilogue in a bf16 mode");
   dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), a.nbatch > 1 ? a.nbatch : (a.nsplit > 1 ? a.nsplit : 1));
   GemmArgs g = a;
   g.seed_cell = seed_cell();

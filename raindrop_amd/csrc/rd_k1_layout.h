@@ -1,5 +1,5 @@
 // rd_k1_layout.h -- device-memory formats shared by the fused message-passing kernels (rd_msgpass_fused.hip)
-// and their weight-gradient kernel (rd_msgpass_dw.hip).  Fused envelope: F <= 64 sensors, d_ob = 4,
+// and their weight-gradient kernel (rd_msgpass_dw.hip).  Fused envelope: F <= 48 sensors, d_ob = 4,
 // K = T*d_ob <= 240, K % 16 == 0 (the P19 shape).
 //
 // Everything an MFMA operand is loaded from is stored as NATIVE TILES: one v_mfma_f32_16x16x32_bf16 operand

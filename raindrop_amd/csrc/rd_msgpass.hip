@@ -201,7 +201,7 @@ FusedWs carve_fused_ws(const k1::Layout& L, const k1::DwPlan& P, void* base) {
 }
 bool fused_envelope(const rd_shape* s) {      // shape part of fused_msgpass_ok (sizes must not depend on the precision mode)
   const int K = s->T * s->d_ob;
-  return s->d_ob == 4 && s->F <= 64 && K <= 240 && (K % 16) == 0 && K >= 16;
+  return s->d_ob == 4 && s->F <= 48 && K <= 240 && (K % 16) == 0 && K >= 16;
 }
 
 int check_shape(const rd_shape* s) {

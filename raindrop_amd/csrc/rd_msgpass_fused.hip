@@ -1,5 +1,5 @@
 // rd_msgpass_fused.hip -- kernel K1, fused LDS-resident form for small sensor graphs
-// (F <= 64 sensors, K = T*d_ob <= 240 and a multiple of 16: the P19 shape, K = 240).
+// (F <= 48 sensors, K = T*d_ob <= 240 and a multiple of 16: the P19 shape, K = 240).
 //
 // One workgroup owns one sample.  Its sensor graph node features X [F, K] are built in LDS straight
 // from src (observation embedding, code/models_rd.py:290-296 + the [T,F*d] -> [F,T*d] re-layout of
@@ -956,7 +956,9 @@ int launch_fused_shape(const FusedArgs& a, const k1::Layout& L, bool bwd, hipStr
     case 1: return launch_fused<1, 0, 0>(a, bwd, st);
     case 2: return launch_fused<2, 0, 0>(a, bwd, st);
     case 3: return launch_fused<3, 0, 0>(a, bwd, st);
-    default: return launch_fused<4, 0, 0>(a, bwd, st);
+    // (RT = 4, 48 < F <= 64: its runtime-shape instantiation spilled 68-88 bytes per lane and no dataset has such a sensor count --
+    // round 4 narrowed the envelope to F <= 48, fused_msgpass_ok; those shapes take the panel-product path)
+    default: return fail(RD_EUNSUPPORTED, "fused message passing: F = %d > 48", L.F);
   }
 }
 
@@ -977,7 +979,7 @@ bool fused_msgpass_ok(const rd_shape* s) {
   const int K = s->T * s->d_ob;
   // staging tile [F][244] fp32 must fit inside two bf16 planes [RT*16][264]; d_ob == 4 only
   // index arithmetic of the kernels is 32-bit with 24-bit multiplies: B*T rows < 2^22 (with ldz < 1024, checked at the call)
-  return enabled && precision() == RD_PREC_BF16X3 && s->d_ob == 4 && s->F <= 64 && K <= 240 && (K % 16) == 0 && K >= 16 &&
+  return enabled && precision() == RD_PREC_BF16X3 && s->d_ob == 4 && s->F <= 48 && K <= 240 && (K % 16) == 0 && K >= 16 &&
          (long)s->B * s->T < (1L << 22);
 }
 

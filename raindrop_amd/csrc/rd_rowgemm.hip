@@ -501,7 +501,9 @@ int launch_wsplit_plan(int njobs, const WsplitSpec* specs, int nones, void* cons
   }
   const size_t lds = plan_out ? plan::lds_bytes(B, T) : 0;
   if (lds > 64 * 1024) return fail(RD_EINVAL, "rd_step_begin: B x T too large for the one-workgroup token plan (%d, %d)", B, T);
-  hipLaunchKernelGGL(k_wsplit, dim3(64, njobs + (plan_out ? 1 : 0)), dim3(256), lds, st, jobs);
+  // workgroups per job: a job is 25-150 tiles of one wave-iteration each; RD_WSPLIT_GX (A/B only) overrides the default
+  static const int gx = [] { const char* e = getenv("RD_WSPLIT_GX"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 64; }();
+  hipLaunchKernelGGL(k_wsplit, dim3(gx, njobs + (plan_out ? 1 : 0)), dim3(256), lds, st, jobs);
   return check_launch("k_wsplit");
 }
 

@@ -42,7 +42,7 @@ def plan_supported(d_inp, d_ob, T, D, nhead, nhid, precision):
     hd = D // nhead
     env_on = all(os.environ.get(k, "1") != "0" for k in ("RD_ROWGEMM", "RD_TILE_WGRAD", "RD_ATTN_B16", "RD_ATTN_B16_MT", "RD_LN_FUSE",
                                                          "RD_LNB_FUSE", "RD_ENC_FUSE", "RD_HEAD_FUSED"))
-    return (precision in (1, 2) and hd * nhead == D and hd <= 96 and (D + 31) // 32 == 5 and (nhid + 31) // 32 == 9
+    return (precision in (1, 2) and d_ob == 4 and hd * nhead == D and hd <= 96 and (D + 31) // 32 == 5 and (nhid + 31) // 32 == 9
             and D % 4 == 0 and nhid % 4 == 0 and env_on and os.environ.get("RD_ATTN_BIG", "0") == "0")
 
 
