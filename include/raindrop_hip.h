@@ -96,10 +96,15 @@ int rd_seed_cell_advance(uint64_t* device_cell, uint64_t delta, void* stream);
  * write ONLY those rows -- buffers keep their padded sizes, the first plan[0] rows are used -- and skip the arithmetic whose
  * operand is an exactly-zero padded step.  Logits, loss and all parameter gradients are the same function of the inputs as
  * without a plan (up to the order of the fp32 sums over tokens); z / x / dx at padded steps, which nothing reads, are not
- * produced.  Supported where the step runs on its fast paths (fused message passing, row-block encoder with single-tile
- * attention, fused head: the P19 shape); other shapes return RD_EUNSUPPORTED while a plan is registered.
- * plan_out: rd_token_plan_bytes(s) bytes of int32 (layout: raindrop_amd/csrc/rd_plan.h; [0] = live rows).  If seed_cell is not
- * NULL the launch also adds `delta` to it (rd_seed_cell_advance folded in: one launch fewer per step). */
+ * produced.  Supported where the step runs on plan-aware kernels: a bf16 arithmetic mode, d_ob = 4, the fused row-local encoder
+ * chains (ceil(D / 32) == 5, ceil(nhid / 32) == 9: P19 and P12), head_dim <= 96, the fused head -- at any T (T <= 64: in_proj + attention
+ * as one launch per direction, rd_attnfuse.hip; beyond: the multi-tile attention kernels on plan rows) and with either message-passing
+ * form (fused LDS-resident, or the panel products whose last scatter follows the plan; rd_pe_mask writes the PE rows the same way).
+ * Other shapes / modes return RD_EUNSUPPORTED while a plan is registered (raindrop_amd.step.plan_supported is the host-side test).
+ * plan_out: rd_token_plan_bytes(s) bytes of int32 (layout: raindrop_amd/csrc/rd_plan.h; [0] = live rows, [1] = their 32-row chunks,
+ * [5] = chunks of the per-sample chunk space the fused attention exports its weight-gradient row tiles in; per-rank off / len,
+ * per-sample rank / first row / length).  If seed_cell is not NULL the launch also adds `delta` to it (rd_seed_cell_advance folded
+ * in: one launch fewer per step). */
 size_t rd_token_plan_bytes(const rd_shape* s);
 int rd_token_plan(const rd_shape* s, const int64_t* lengths, int32_t* plan_out, uint64_t* seed_cell, uint64_t delta,
                   void* stream);
