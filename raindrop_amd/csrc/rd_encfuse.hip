@@ -186,6 +186,7 @@ struct PostFwdArgs {
   const __bf16 *Wo, *W1, *W2;                       // operand tiles of out_proj [D,D], linear1 [H,D], linear2 [D,H]
   const float *bo, *b1, *b2, *g1, *be1, *g2, *be2;
   float *s1, *x1, *st1, *h, *s2, *y, *st2;          // saved pre-norm sums, normalised rows, (mean, rstd), FFN hidden, output
+  uint8_t* hgate;                                   // LEAN form: [M][H / 4] gate bytes (bit c: h[4 q + c] > 0) instead of the fp32 h and x1
   __bf16 *xt_attn, *xt_x1, *xt_h;                   // row tiles for the weight gradients (null: not wanted)
   int M, D, H, ncu;
   float p; uint64_t seed; uint32_t site_ao, site_fh, site_fo; const uint64_t* seed_cell;
@@ -236,7 +237,7 @@ __device__ __forceinline__ void ln_load3(float4 (&r)[LNQ], const float* src, int
 // bs / gg / bb: the bias, gamma, beta vectors in LDS (zero padded to KPD).
 __device__ __forceinline__ void ln_rows4(const float* stage, const float4 (&res)[LNQ], const float* bs, const float* gg, const float* bb, int D,
                                          int m0, int M, int wave, int lane, float p, float inv_keep, uint64_t seed, uint32_t site,
-                                         float* s_out, float* y_out, float* stats, __bf16* Ph, __bf16* Pl) {
+                                         float* s_out, float* y_out, float* stats, __bf16* Ph, __bf16* Pl, float2* mr_out = nullptr) {
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const int g = lane >> 4, i16 = lane & 15, rl = 4 * wave + g;
   const long m = m0 + rl;
@@ -283,16 +284,21 @@ __device__ __forceinline__ void ln_rows4(const float* stage, const float4 (&res)
     if (rok && c < D) {
       const float4 g4 = *reinterpret_cast<const float4*>(gg + c), b4 = *reinterpret_cast<const float4*>(bb + c);
       o = make_float4(d[k].x * rstd * g4.x + b4.x, d[k].y * rstd * g4.y + b4.y, d[k].z * rstd * g4.z + b4.z, d[k].w * rstd * g4.w + b4.w);
-      *reinterpret_cast<float4*>(y_out + m * D + c) = o;
+      if (y_out) *reinterpret_cast<float4*>(y_out + m * D + c) = o;
     }
     if (Ph && c < KPD) split_store4(Ph + rl * LDD + c, Pl + rl * LDD + c, o);
   }
   if (i16 == 0 && rok) { stats[2 * m] = mean; stats[2 * m + 1] = rstd; }
+  if (mr_out) *mr_out = make_float2(mean, rstd);                // every lane of the row holds the same two values
 }
 
 // DC / HC: model width and FFN width as compile-time constants (0: read from the arguments).  These chains are instruction-issue
 // bound; with the widths known the row / quad index arithmetic (64-bit multiplies at quarter rate, divisions) folds away.
-template <int RT, int DC, int HC>
+// LEAN (the training step on the token plan, whose backward is the fused chain + the tile stream): what only the UNFUSED backward
+// or the chain itself would read is not written -- the FFN hidden h leaves as row tiles (weight gradient) and as one gate BYTE
+// per column quad (the backward needs h > 0, nothing else: 9.2 MB of fp32 written and read back per layer at P19), and the
+// normalised x1 (residual of LayerNorm2) is recomputed from the saved pre-norm sum and statistics instead of stored and re-read.
+template <int RT, int DC, int HC, bool LEAN>
 __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned char* esm, int M) {
   constexpr int ROWS = 16 * RT;
   __bf16* Ah = reinterpret_cast<__bf16*>(esm);                 // [ROWS][LDD]: attn, then x1
@@ -367,7 +373,9 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
   Panel<KCD> p1;                                               // linear1 (column tiles 0..15) streams in under the LayerNorm epilogue
   load_panel<KCD, 0, KCD, true>(p1, a.W1, ntH, wave, lane);    // (requested BEHIND the barrier: issuing it blocks a wave for a while)
   // ---- + bias, dropout, + x, LayerNorm1 -> s1, x1 (global), x1 planes ----
-  if (lnw) ln_rows4(stage, xr, cst, cst + KPD, cst + 2 * KPD, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_ao, a.s1, a.x1, a.st1, Ah, Al);
+  float2 st1v = make_float2(0.f, 0.f);                         // LEAN: this lane's LayerNorm1 (mean, rstd), kept for the residual of LayerNorm2
+  if (lnw) ln_rows4(stage, xr, cst, cst + KPD, cst + 2 * KPD, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_ao, a.s1, LEAN ? nullptr : a.x1,
+                    a.st1, Ah, Al, &st1v);
   EFSTAMP(5);
   lds_barrier();
   EFSTAMP(6);
@@ -414,7 +422,10 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
           o.x = u.x >= a.p ? o.x * inv_keep : 0.f; o.y = u.y >= a.p ? o.y * inv_keep : 0.f;
           o.z = u.z >= a.p ? o.z * inv_keep : 0.f; o.w = u.w >= a.p ? o.w * inv_keep : 0.f;
         }
-        *reinterpret_cast<float4*>(a.h + (long)m * H + n) = o;
+        if (LEAN)
+          a.hgate[(long)m * qpr + q] = (uint8_t)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
+        else
+          *reinterpret_cast<float4*>(a.h + (long)m * H + n) = o;
       }
       split_store4(Hh + rl * LDH + n, Hl + rl * LDH + n, o);
     }
@@ -422,7 +433,9 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
   // LayerNorm2's residual x1: read back by the very lane that stored it (pass layout).  The tall variant has no registers to carry
   // the three quads through linear2's product beside its 72-register panel (they spilled: 23 MB of scratch writes per launch): it
   // requests them behind the product instead.
-  auto load_res2 = [&]() { if (lnw) ln_load3(xr, a.x1, D, m0, M, wave, lane); };
+  // LEAN: x1 was never stored -- the lane re-reads the pre-norm sum it wrote (s1) and re-normalises with the (mean, rstd) it kept
+  // (the same expression, in the same order, as LayerNorm1's output)
+  auto load_res2 = [&]() { if (lnw) ln_load3(xr, LEAN ? a.s1 : a.x1, D, m0, M, wave, lane); };
   if constexpr (RT < 3) load_res2();
   EFSTAMP(9);
   lds_barrier();
@@ -440,19 +453,31 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
   lds_barrier();
   EFSTAMP(12);
   // ---- + bias, dropout, + x1, LayerNorm2 -> s2, y ----
+  if (LEAN && lnw) {
+#pragma unroll
+    for (int k = 0; k < LNQ; ++k) {
+      const int c = 4 * ((lane & 15) + 16 * k);
+      if (c < D && m0 + 4 * wave + (lane >> 4) < M) {
+        const float4 g4 = *reinterpret_cast<const float4*>(cst + KPD + c), b4 = *reinterpret_cast<const float4*>(cst + 2 * KPD + c);
+        const float mean = st1v.x, rstd = st1v.y;
+        xr[k] = make_float4((xr[k].x - mean) * rstd * g4.x + b4.x, (xr[k].y - mean) * rstd * g4.y + b4.y,
+                            (xr[k].z - mean) * rstd * g4.z + b4.z, (xr[k].w - mean) * rstd * g4.w + b4.w);
+      }
+    }
+  }
   if (lnw) ln_rows4(stage, xr, cst + 3 * KPD, cst + 4 * KPD, cst + 5 * KPD, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_fo, a.s2, a.y, a.st2,
                     nullptr, nullptr);
   EFSTAMP(13);
   if (a.stamps && tid == 0) { a.stamps[256 + 1024 + 2 * blockIdx.x] = wall_clock64(); a.stamps[256 + 1024 + 2 * blockIdx.x + 1] = clock64(); }
 }
 
-template <int DC, int HC>
+template <int DC, int HC, bool LEAN>
 __global__ __launch_bounds__(EF_THR) void k_enc_post_fwd(PostFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
   int M = a.M;
   if (a.mlive) M = min(M, __builtin_amdgcn_readfirstlane(*a.mlive));
-  if (pick_rt(M, a.ncu) == 3) post_fwd_body<3, DC, HC>(a, esm, M);
-  else post_fwd_body<2, DC, HC>(a, esm, M);
+  if (pick_rt(M, a.ncu) == 3) post_fwd_body<3, DC, HC, LEAN>(a, esm, M);
+  else post_fwd_body<2, DC, HC, LEAN>(a, esm, M);
 }
 
 constexpr size_t post_fwd_lds(int rt) {
@@ -466,6 +491,7 @@ struct PreBwdArgs {
   const float* dy;                                  // [M, D] gradient of the layer output
   const float *s2, *st2, *g2;                       // LayerNorm2: saved pre-norm sum, (mean, rstd), gamma
   const float* h;                                   // [M, H] FFN hidden after ReLU and dropout (gate: h > 0)
+  const uint8_t* hgate;                             // LEAN form: [M][H / 4] gate bytes written by the LEAN forward chain (h is null)
   const float *s1, *st1, *g1;                       // LayerNorm1
   const __bf16 *W2t, *W1t, *Wot;                    // operand tiles of linear2^T, linear1^T, out_proj^T
   float *ds2, *ds1, *da;                            // [M, D]: gradients of the LayerNorm2 / LayerNorm1 inputs (residual branches), of attn
@@ -532,7 +558,7 @@ __device__ __forceinline__ void lnb_rows4(const float4 (&dyq)[LNQ], const float4
   }
 }
 
-template <int RT, int DC, int HC>
+template <int RT, int DC, int HC, bool LEAN>
 __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char* esm, int M) {
   constexpr int ROWS = 16 * RT;
   __bf16* Ah = reinterpret_cast<__bf16*>(esm);                 // [ROWS][LDD]: df, then dout
@@ -587,14 +613,15 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   // the next product
   constexpr int hq = KPH / 4;
   constexpr int HIT = (ROWS * hq + EF_THR - 1) / EF_THR;
-  float4 hv[HIT];
+  float4 hv[LEAN ? 1 : HIT]; uint8_t hb[LEAN ? HIT : 1];
 #pragma unroll
   for (int it = 0; it < HIT; ++it) {
     const int e = tid + it * EF_THR;
     const int rl = e / hq, q = e - rl * hq;
     // UNCONDITIONAL from a clamped address (rows >= M have a zero gradient in the stage, columns >= H and rows >= ROWS are not
     // consumed): a conditional load is a phi of {0, value} and the compiler waited for each one right behind its request
-    hv[it] = *reinterpret_cast<const float4*>(a.h + (long)min(m0 + min(rl, ROWS - 1), M - 1) * H + min(4 * q, H - 4));
+    if (LEAN) hb[it] = a.hgate[(long)min(m0 + min(rl, ROWS - 1), M - 1) * (H >> 2) + min(q, (H >> 2) - 1)];
+    else hv[it] = *reinterpret_cast<const float4*>(a.h + (long)min(m0 + min(rl, ROWS - 1), M - 1) * H + min(4 * q, H - 4));
   }
   EFSTAMP(2);
   lds_barrier();
@@ -640,8 +667,12 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
         float4 o = zero4;
         if (4 * q < H) {
           const float4 s4 = *reinterpret_cast<const float4*>(stage + rl * STG + 4 * q);
-          o = make_float4(hv[it].x > 0.f ? s4.x * ks : 0.f, hv[it].y > 0.f ? s4.y * ks : 0.f, hv[it].z > 0.f ? s4.z * ks : 0.f,
-                          hv[it].w > 0.f ? s4.w * ks : 0.f);
+          if (LEAN)
+            o = make_float4((hb[it] & 1) ? s4.x * ks : 0.f, (hb[it] & 2) ? s4.y * ks : 0.f, (hb[it] & 4) ? s4.z * ks : 0.f,
+                            (hb[it] & 8) ? s4.w * ks : 0.f);
+          else
+            o = make_float4(hv[it].x > 0.f ? s4.x * ks : 0.f, hv[it].y > 0.f ? s4.y * ks : 0.f, hv[it].z > 0.f ? s4.z * ks : 0.f,
+                            hv[it].w > 0.f ? s4.w * ks : 0.f);
         }
         split_store4(Hh + rl * LDH + 4 * q, Hl + rl * LDH + 4 * q, o);
       }
@@ -721,13 +752,13 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   EFSTAMP(14);
 }
 
-template <int DC, int HC>
+template <int DC, int HC, bool LEAN>
 __global__ __launch_bounds__(EF_THR) void k_enc_pre_bwd(PreBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
   int M = a.M;
   if (a.mlive) M = min(M, __builtin_amdgcn_readfirstlane(*a.mlive));
-  if (pick_rt(M, a.ncu) == 3) pre_bwd_body<3, DC, HC>(a, esm, M);
-  else pre_bwd_body<2, DC, HC>(a, esm, M);
+  if (pick_rt(M, a.ncu) == 3) pre_bwd_body<3, DC, HC, LEAN>(a, esm, M);
+  else pre_bwd_body<2, DC, HC, LEAN>(a, esm, M);
 }
 
 // Widths compiled in for the two datasets that fit these kernels: 1 = P19 (152, 272), 2 = P12 (160, 288); 0 = runtime widths.
@@ -778,7 +809,7 @@ int launch_enc_post_fwd(long M, int D, int H, const float* attn, const float* x,
                         const float* bo, const float* b1, const float* b2, const float* g1, const float* be1, const float* g2,
                         const float* be2, float* s1, float* x1, float* st1, float* h, float* s2, float* y, float* st2,
                         void* xt_attn, void* xt_x1, void* xt_h, float p, uint64_t seed, uint32_t site_ao, uint32_t site_fh,
-                        uint32_t site_fo, const int32_t* mlive, hipStream_t st) {
+                        uint32_t site_fo, const int32_t* mlive, void* hgate, hipStream_t st) {
   PostFwdArgs a{};
   a.attn = attn; a.x = x; a.Wo = (const __bf16*)Wo; a.W1 = (const __bf16*)W1; a.W2 = (const __bf16*)W2;
   a.bo = bo; a.b1 = b1; a.b2 = b2; a.g1 = g1; a.be1 = be1; a.g2 = g2; a.be2 = be2;
@@ -788,16 +819,18 @@ int launch_enc_post_fwd(long M, int D, int H, const float* attn, const float* x,
   a.seed_cell = seed_cell(); a.mlive = mlive; a.one = precision() == RD_PREC_BF16; a.stamps = g_ef_stamps;
   constexpr size_t lds = post_fwd_lds(EF_RTMAX);
   const int spec = ef_specialize(D, H);
-  if (spec == 1) {
-    RD_LDS_ATTR((k_enc_post_fwd<152, 272>), lds);
-    hipLaunchKernelGGL((k_enc_post_fwd<152, 272>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a);
-  } else if (spec == 2) {
-    RD_LDS_ATTR((k_enc_post_fwd<160, 288>), lds);
-    hipLaunchKernelGGL((k_enc_post_fwd<160, 288>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a);
-  } else {
-    RD_LDS_ATTR((k_enc_post_fwd<0, 0>), lds);
-    hipLaunchKernelGGL((k_enc_post_fwd<0, 0>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a);
-  }
+  a.hgate = (uint8_t*)hgate;
+#define RD_POST_FWD(DCV, HCV)                                                                                        \
+  do {                                                                                                               \
+    if (hgate) { RD_LDS_ATTR((k_enc_post_fwd<DCV, HCV, true>), lds);                                                 \
+                 hipLaunchKernelGGL((k_enc_post_fwd<DCV, HCV, true>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a); }   \
+    else { RD_LDS_ATTR((k_enc_post_fwd<DCV, HCV, false>), lds);                                                      \
+           hipLaunchKernelGGL((k_enc_post_fwd<DCV, HCV, false>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a); } \
+  } while (0)
+  if (spec == 1) RD_POST_FWD(152, 272);
+  else if (spec == 2) RD_POST_FWD(160, 288);
+  else RD_POST_FWD(0, 0);
+#undef RD_POST_FWD
   return check_launch("k_enc_post_fwd");
 }
 
@@ -806,7 +839,7 @@ int encfuse_part_rows(long M) { return (int)((M + 31) / 32); }
 int launch_enc_pre_bwd(long M, int D, int H, const float* dy, const float* s2, const float* st2, const float* g2, const float* h,
                        const float* s1, const float* st1, const float* g1, const void* W2t, const void* W1t, const void* Wot,
                        float* ds2, float* ds1, float* da, float* part2, float* part1, void* xt_df, void* xt_du, void* xt_dout, float p,
-                       uint64_t seed, uint32_t site_fo, uint32_t site_ao, const int32_t* mlive, hipStream_t st) {
+                       uint64_t seed, uint32_t site_fo, uint32_t site_ao, const int32_t* mlive, const void* hgate, hipStream_t st) {
   PreBwdArgs a{};
   a.dy = dy; a.s2 = s2; a.st2 = st2; a.g2 = g2; a.h = h; a.s1 = s1; a.st1 = st1; a.g1 = g1;
   a.W2t = (const __bf16*)W2t; a.W1t = (const __bf16*)W1t; a.Wot = (const __bf16*)Wot;
@@ -816,16 +849,18 @@ int launch_enc_pre_bwd(long M, int D, int H, const float* dy, const float* s2, c
   a.seed_cell = seed_cell(); a.mlive = mlive; a.one = precision() == RD_PREC_BF16; a.stamps = g_ef_stamps;
   constexpr size_t lds = pre_bwd_lds(EF_RTMAX);
   const int spec = ef_specialize(D, H);
-  if (spec == 1) {
-    RD_LDS_ATTR((k_enc_pre_bwd<152, 272>), lds);
-    hipLaunchKernelGGL((k_enc_pre_bwd<152, 272>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a);
-  } else if (spec == 2) {
-    RD_LDS_ATTR((k_enc_pre_bwd<160, 288>), lds);
-    hipLaunchKernelGGL((k_enc_pre_bwd<160, 288>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a);
-  } else {
-    RD_LDS_ATTR((k_enc_pre_bwd<0, 0>), lds);
-    hipLaunchKernelGGL((k_enc_pre_bwd<0, 0>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a);
-  }
+  a.hgate = (const uint8_t*)hgate;
+#define RD_PRE_BWD(DCV, HCV)                                                                                        \
+  do {                                                                                                              \
+    if (hgate) { RD_LDS_ATTR((k_enc_pre_bwd<DCV, HCV, true>), lds);                                                 \
+                 hipLaunchKernelGGL((k_enc_pre_bwd<DCV, HCV, true>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a); }   \
+    else { RD_LDS_ATTR((k_enc_pre_bwd<DCV, HCV, false>), lds);                                                      \
+           hipLaunchKernelGGL((k_enc_pre_bwd<DCV, HCV, false>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a); } \
+  } while (0)
+  if (spec == 1) RD_PRE_BWD(152, 272);
+  else if (spec == 2) RD_PRE_BWD(160, 288);
+  else RD_PRE_BWD(0, 0);
+#undef RD_PRE_BWD
   return check_launch("k_enc_pre_bwd");
 }
 

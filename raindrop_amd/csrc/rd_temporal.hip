@@ -58,12 +58,12 @@ int launch_enc_post_fwd(long M, int D, int H, const float* attn, const float* x,
                         const float* bo, const float* b1, const float* b2, const float* g1, const float* be1, const float* g2,
                         const float* be2, float* s1, float* x1, float* st1, float* h, float* s2, float* y, float* st2,
                         void* xt_attn, void* xt_x1, void* xt_h, float p, uint64_t seed, uint32_t site_ao, uint32_t site_fh,
-                        uint32_t site_fo, const int32_t* mlive, hipStream_t st);
+                        uint32_t site_fo, const int32_t* mlive, void* hgate, hipStream_t st);
 int encfuse_part_rows(long M);
 int launch_enc_pre_bwd(long M, int D, int H, const float* dy, const float* s2, const float* st2, const float* g2, const float* h,
                        const float* s1, const float* st1, const float* g1, const void* W2t, const void* W1t, const void* Wot,
                        float* ds2, float* ds1, float* da, float* part2, float* part1, void* xt_df, void* xt_du, void* xt_dout, float p,
-                       uint64_t seed, uint32_t site_fo, uint32_t site_ao, const int32_t* mlive, hipStream_t st);
+                       uint64_t seed, uint32_t site_fo, uint32_t site_ao, const int32_t* mlive, const void* hgate, hipStream_t st);
 bool rowgemm_lnb_ok(int N, int K);
 int rowgemm_lnb_part_rows(long M);
 int launch_rowgemm_lnb(long M, int N, int K, const float* dy, const float* s, const float* stats, const float* g, float* ds_out,
@@ -2457,6 +2457,14 @@ EncWs carve_ws(const EncDims& e, void* base) {
   return w;
 }
 
+// LEAN chains (rd_encfuse.hip): on the token plan with the tile-stream weight gradients -- the training step's configuration,
+// where forward and backward of a layer are known to take the fused chains -- the forward does not write the fp32 FFN hidden and
+// x1: the gate bytes live at the start of the (then unused) h buffer.  RD_ENC_LEAN=0: the round-3 contract (A/B).
+static bool enc_lean(const int32_t* tp, bool tw) {
+  const char* e = getenv("RD_ENC_LEAN");               // read per call
+  return tp && tw && !(e && atoi(e) == 0);
+}
+
 // the whole layer runs on row-block products and all four weight gradients can take the tile stream
 static bool tile_path(const EncDims& e) {
   return rowgemm_ok(3 * e.D, e.D, e.D, 3 * e.D) && rowgemm_ok(e.D, e.D, e.D, e.D) && rowgemm_ok(e.nhid, e.D, e.D, e.nhid) &&
@@ -2692,7 +2700,8 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
     return launch_enc_post_fwd(e.M, e.D, e.nhid, v.attn, x, v.pl[1][0], v.pl[2][0], v.pl[3][0], w->out_proj_b, w->lin1_b, w->lin2_b,
                                w->norm1_w, w->norm1_b, w->norm2_w, w->norm2_b, v.s1, v.x1, v.st1, v.h, v.s2, y, v.st2,
                                tw ? v.xt[1] : nullptr, tw ? v.xt[2] : nullptr, tw ? v.xt[3] : nullptr, p_drop, seed,
-                               SITE_ATTN_OUT + L, SITE_FFN_HID + L, SITE_FFN_OUT + L, tp ? tp + plan::I_MLIVE : nullptr, st);
+                               SITE_ATTN_OUT + L, SITE_FFN_HID + L, SITE_FFN_OUT + L, tp ? tp + plan::I_MLIVE : nullptr,
+                               enc_lean(tp, tw) ? (void*)v.h : nullptr, st);
   if (tw) rowgemm_export_next(v.xt[1]);
   if (lnf1) {
     if ((rc = launch_rowgemm_ln(e.M, e.D, e.D, v.attn, v.pl[1][0], w->out_proj_b, x, w->norm1_w, w->norm1_b, v.s1, v.x1, v.st1,
@@ -2762,7 +2771,8 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   const int lnrows = fuse ? encfuse_part_rows(e.M) : (lnf ? rowgemm_lnb_part_rows(e.M) : lnb);
   if (fuse && (rc = launch_enc_pre_bwd(e.M, e.D, e.nhid, dy, v.s2, v.st2, w->norm2_w, v.h, v.s1, v.st1, w->norm1_w, v.pl[5][0], v.pl[6][0],
                                        v.pl[4][0], ws.ds2, ws.ds1, ws.da, ws.lnpart, ws.lnpart1, ws.dt[0], ws.dt[1], ws.dt[2], p_drop, seed,
-                                       SITE_FFN_OUT + L, SITE_ATTN_OUT + L, tp ? tp + plan::I_MLIVE : nullptr, st))) return rc;
+                                       SITE_FFN_OUT + L, SITE_ATTN_OUT + L, tp ? tp + plan::I_MLIVE : nullptr,
+                                       enc_lean(tp, tw) ? (const void*)v.h : nullptr, st))) return rc;
   // ---- LayerNorm 2:  ds2 (residual path), df = ds2 o mask(ffn out) -------------------------------
   if (!lnf && (rc = launch_ln_bwd(dy, v.s2, v.st2, w->norm2_w, ws.ds2, ws.df, ws.lnpart, (int)e.M, e.D, p_drop, seed,
                                   SITE_FFN_OUT + L, st))) return rc;
