@@ -13,9 +13,9 @@
 //             stream, (b) dx += d{Q,K,V} W_{h}: accumulated over both heads IN REGISTERS, + ds1 (the residual branch) -> dx rows.
 //             dqkv never exists in memory as fp32; the cross-head sum needs no second pass because a workgroup owns both heads.
 // The weight-gradient stream (rd_tile_wgrad.hip) needs x and dqkv as row tiles of 32 rows.  A sample's rows do not start on a
-// 32-row boundary of the compact token order, so these kernels export in the plan's PER-SAMPLE chunk space (rd_plan.h: coff):
-// rank r owns chunks coff[r] .. coff[r + 1], rows past its length are zero.  dW = dqkv^T x is a sum over rows: any order works as
-// long as both operands use the same one.  dqkv's columns are exported in a head-padded layout ((q|k|v, head) blocks of 16 NTH
+// 32-row boundary of the compact token order, so these kernels export in the plan's PER-SAMPLE group space (rd_plan.h: coff):
+// rank r owns the 16-row groups coff[r] .. coff[r + 1] (two groups = one 32-row chunk), rows past its length are zero.
+// dW = dqkv^T x is a sum over rows: any order works as long as both operands use the same one.  dqkv's columns are exported in a head-padded layout ((q|k|v, head) blocks of 16 NTH
 // columns); k_twg_reduce maps them back to in_proj's rows.
 //
 // Same arithmetic as the kernels it replaces (split-bf16 products with fp32 accumulation in the same order of the reduction
@@ -549,8 +549,10 @@ __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
   const int Tv = __builtin_amdgcn_readfirstlane(a.plan[plan::len_base(a.B) + b]);
   if (Tv <= 0) return;
   const long row0 = __builtin_amdgcn_readfirstlane(a.plan[plan::off_base() + b]);
-  const int c0 = __builtin_amdgcn_readfirstlane(a.plan[plan::coff_base(a.B, a.T) + b]);     // first chunk of the sample's row tiles
-  const int nchunk = (Tv + 31) >> 5;
+  const int g0 = __builtin_amdgcn_readfirstlane(a.plan[plan::coff_base(a.B, a.T) + b]);     // first 16-row group of the sample's row tiles
+  const int ngrp = (Tv + 15) >> 4;
+  // the group space ends with this sample AND on an odd group: the second half of the last chunk belongs to nobody -> zeros
+  const bool tail_zero = (g0 + ngrp) == __builtin_amdgcn_readfirstlane(a.plan[plan::coff_base(a.B, a.T) + a.B]) && ((g0 + ngrp) & 1);
   uint64_t seedv = a.seed;
   if (a.p_drop > 0.f && a.seed_cell) seedv += load_uniform_u64(a.seed_cell);
   const float inv_keep = 1.0f / (1.0f - a.p_drop);
@@ -590,16 +592,29 @@ __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
     lds_barrier();                                           // (A) x planes complete; the previous head's dQ^T.. / dO planes are dead
     AFSTAMP(34 + 16 * h);
     if (h == 0) {
-      // ---- row tiles of x (rd_encfuse.hip export_tiles; 32-row chunks of the per-sample chunk space) ----
-      const int i16 = lq & 15, G = lq >> 4;
-      for (int t = wave; t < nchunk * NCT * 2; t += AF_WV) {
+      // ---- row tiles of x: 16-row groups of the per-sample group space (rd_encfuse.hip export_tiles' lane map: a wave-read
+      // covers TWO groups, lanes 0-31 the even one of the pair, 32-63 the odd one) ----
+      const int i16 = lq & 15, g2 = (lq >> 4) & 1, sub = lq >> 5;
+      const int npair = (ngrp + 1) >> 1;
+      for (int t = wave; t < npair * NCT * 2; t += AF_WV) {
         const int plane = t & 1, cj = t >> 1;
-        const int c = cj / NCT, j = cj - c * NCT;
-        const __bf16* src = (plane ? Xl : Xh) + (32 * c + 8 * G + (i16 >> 2)) * LDX + 16 * j + 4 * (i16 & 3);
+        const int pr = cj / NCT, j = cj - pr * NCT;
+        const int lg = 2 * pr + sub;                          // local group of this half-wave
+        const __bf16* src = (plane ? Xl : Xh) + (16 * min(lg, ngrp - 1) + 8 * g2 + (i16 >> 2)) * LDX + 16 * j + 4 * (i16 & 3);
         const sh4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sh4 __attribute__((address_space(3)))*)(src));
         const sh4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sh4 __attribute__((address_space(3)))*)(src + 4 * LDX));
         const sh8 o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        *reinterpret_cast<sh8*>(a.xt + (((size_t)(c0 + c) * NCT + j) * 2 + plane) * 512 + lq * 8) = o;
+        const int gg = g0 + lg;
+        if (lg < ngrp)
+          *reinterpret_cast<sh8*>(a.xt + (((size_t)(gg >> 1) * NCT + j) * 2 + plane) * 512 + (32 * (gg & 1) + 16 * g2 + i16) * 8) = o;
+      }
+      if (tail_zero) {
+        const int gg = g0 + ngrp;                             // the unowned odd group
+        const sh8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = tid; i < NCT * 2 * 32; i += AF_THR) {
+          const int slot = i & 31, jp = i >> 5;
+          *reinterpret_cast<sh8*>(a.xt + ((size_t)(gg >> 1) * NCT * 2 + jp) * 512 + (32 + slot) * 8) = z;
+        }
       }
     }
     {
@@ -708,18 +723,33 @@ __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
     AFSTAMP(42 + 16 * h);
     lds_barrier();                                           // (E)
     AFSTAMP(43 + 16 * h);
-    // ---- (a) row tiles of dqkv, head-padded column layout: tile (which, h, j) ----
+    // ---- (a) row tiles of dqkv, head-padded column layout: tile (which, h, j); 16-row groups as for x ----
     {
-      const int i16 = ld & 15, G = ld >> 4;
+      const int i16 = ld & 15, g2 = (ld >> 4) & 1, sub = ld >> 5;
       const int nctp = 3 * a.H * NTH;
-      for (int t = wave; t < 3 * NTH * nchunk * 2; t += AF_WV) {
+      const int npair = (ngrp + 1) >> 1;
+      for (int t = wave; t < 3 * NTH * npair * 2; t += AF_WV) {
         const int plane = t & 1, u = t >> 1;
-        const int c = u / (3 * NTH), wj = u - c * (3 * NTH);
+        const int pr = u / (3 * NTH), wj = u - pr * (3 * NTH);
         const int which = wj / NTH, j = wj - which * NTH;
-        const __bf16* src = Tp + ((size_t)(which * 2 + plane) * HDP + 16 * j + i16) * LDT + 32 * c + 8 * G;
+        const int lg = 2 * pr + sub;
+        const __bf16* src = Tp + ((size_t)(which * 2 + plane) * HDP + 16 * j + i16) * LDT + 16 * min(lg, ngrp - 1) + 8 * g2;
         const sh8 o = *reinterpret_cast<const sh8*>(src);
         const int jt = (which * a.H + h) * NTH + j;
-        *reinterpret_cast<sh8*>(a.dt + (((size_t)(c0 + c) * nctp + jt) * 2 + plane) * 512 + ld * 8) = o;
+        const int gg = g0 + lg;
+        if (lg < ngrp)
+          *reinterpret_cast<sh8*>(a.dt + (((size_t)(gg >> 1) * nctp + jt) * 2 + plane) * 512 + (32 * (gg & 1) + 16 * g2 + i16) * 8) = o;
+      }
+      if (tail_zero) {
+        const int gg = g0 + ngrp;
+        const sh8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = tid; i < 3 * NTH * 2 * 32; i += AF_THR) {
+          const int slot = i & 31, jp = i >> 5;               // jp = (which-j index, plane) of this head's 3 NTH column tiles
+          const int wj = jp >> 1, plane = jp & 1;
+          const int which = wj / NTH, j = wj - which * NTH;
+          const int jt = (which * a.H + h) * NTH + j;
+          *reinterpret_cast<sh8*>(a.dt + (((size_t)(gg >> 1) * nctp + jt) * 2 + plane) * 512 + (32 + slot) * 8) = z;
+        }
       }
     }
     AFSTAMP(44 + 16 * h);

@@ -18,10 +18,13 @@
 //   [.. + B]          order[r]              sample at rank r
 //   [.. + B]          len[r]                clamp(lengths[order[r]], 0, T)
 //   [.. + B]          cnt[t], t = 0..T      number of samples with len > t
-//   [.. + T + 1]      coff[r], r = 0..B     first 32-row chunk of rank r in the PER-SAMPLE chunk space (rank r owns ceil(len_r / 32)
-//                                           chunks; coff[B] = their total, also at [5]): the row order in which the fused attention
-//                                           kernels (rd_attnfuse.hip) export x and dqkv as weight-gradient row tiles -- a sample's
-//                                           rows start a chunk there, so a workgroup that owns one sample writes whole tile parts
+//   [.. + T + 1]      coff[r], r = 0..B     first 16-ROW GROUP of rank r in the PER-SAMPLE group space: rank r owns ceil(len_r / 16)
+//                                           groups, two groups make a 32-row chunk of the weight-gradient stream (group g = rows
+//                                           16 (g & 1) .. of chunk g >> 1); [5] = ceil(coff[B] / 2) = chunks.  This is the row
+//                                           order in which the fused attention kernels (rd_attnfuse.hip) export x and dqkv as
+//                                           row tiles -- a sample's rows start a group there, so the workgroup that owns one
+//                                           sample writes whole 16-byte tile slots (rows past its length: zeros; the unowned
+//                                           second half of the last chunk is zeroed by the owner of the last group)
 //   [.. + B + 1]      brow[b], b = 0..B-1   first row of SAMPLE b (= off[rank[b]]) and
 //   [.. + B]          blen[b]               its clamped length: one independent look-up each for kernels that walk the caller's
 //                                           sample order (the unfused message passing's scatter / gather, rd_pe_mask)
@@ -124,13 +127,13 @@ __device__ inline void token_plan_body(const int64_t* __restrict__ lengths, int3
     if (r == B) { p[plan::I_MLIVE] = s; p[plan::I_S32] = (s + 31) >> 5; }
   }
   for (int t = tid; t <= T; t += nthr) cntg[t] = cnt[t];
-  // coff[r] = sum over the r longest samples of ceil(len / 32) = sum_c min(r, cnt[32 c])   (a sample has a chunk c iff len > 32 c)
+  // coff[r] = sum over the r longest samples of ceil(len / 16) = sum_g min(r, cnt[16 g])   (a sample has a group g iff len > 16 g)
   int* coff = p + plan::coff_base(B, T);
   for (int r = tid; r <= B; r += nthr) {
     int s = 0;
-    for (int t = 0; t < T; t += 32) s += min(r, cnt[t]);
+    for (int t = 0; t < T; t += 16) s += min(r, cnt[t]);
     coff[r] = s;
-    if (r == B) p[plan::I_SCHUNK] = s;
+    if (r == B) p[plan::I_SCHUNK] = (s + 1) >> 1;
   }
   if (tid == 0) { p[plan::I_B] = B; p[plan::I_T] = T; p[plan::I_SLACK] = 0; p[6] = 0; p[7] = 0; }
 }

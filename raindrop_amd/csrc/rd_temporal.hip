@@ -2387,8 +2387,8 @@ static bool attn_big(const EncDims& e) {
   return e.Hd > 96 || (v && atoi(v) != 0);
 }
 
-// chunks of the per-sample chunk space (rd_plan.h: coff): every sample up to ceil(T / 32)
-static size_t attn_chunks(const EncDims& e) { return (size_t)e.B * cdiv(e.T, 32); }
+// chunks of the per-sample group space (rd_plan.h: coff): every sample up to ceil(T / 16) groups of 16 rows, two groups per chunk
+static size_t attn_chunks(const EncDims& e) { return ((size_t)e.B * cdiv(e.T, 16) + 1) / 2; }
 
 struct EncSaved { float *qkv, *attn, *lse, *s1, *st1, *x1, *h, *s2, *st2; __bf16* pl[8][2];
                   __bf16* xt[4]; __bf16* ones;        // row tiles of x, attn, x1, h (operands of the weight-gradient stream)

@@ -28,7 +28,7 @@ def _plan_ref(lengths, T):
     lenr = L[order]
     off = np.concatenate([[0], np.cumsum(lenr)])
     cnt = np.array([(L > t).sum() for t in range(T + 1)])
-    coff = np.concatenate([[0], np.cumsum((lenr + 31) // 32)])
+    coff = np.concatenate([[0], np.cumsum((lenr + 15) // 16)])          # 16-row groups of the per-sample group space
     return dict(off=off, rank=rank, order=order, lenr=lenr, cnt=cnt, coff=coff, mlive=int(off[-1]))
 
 
@@ -55,7 +55,7 @@ def test_token_plan_bit_exact(B, T, seed):
     assert np.array_equal(p[o:o + B], ref["order"]); o += B
     assert np.array_equal(p[o:o + B], ref["lenr"]); o += B
     assert np.array_equal(p[o:o + T + 1], ref["cnt"]); o += T + 1
-    assert np.array_equal(p[o:o + B + 1], ref["coff"]) and p[5] == ref["coff"][-1]; o += B + 1
+    assert np.array_equal(p[o:o + B + 1], ref["coff"]) and p[5] == (ref["coff"][-1] + 1) // 2; o += B + 1
     assert np.array_equal(p[o:o + B], ref["off"][ref["rank"]]); o += B              # brow[b]: first row of sample b
     assert np.array_equal(p[o:o + B], np.clip(lengths, 0, T))                      # blen[b]
 

@@ -1,11 +1,11 @@
 #!/bin/bash
-out=$GRAFT_REPO_ROOT/gpurun_out/c6; mkdir -p $out
+out=$GRAFT_REPO_ROOT/gpurun_out/c7; mkdir -p $out
 cd $GRAFT_REPO_ROOT
 timeout 900 python -m pytest tests/test_token_plan_gpu.py -m gpu -q --maxfail=8 > $out/pytest_plan.log 2>&1; echo "pytest_plan rc=$?" >> $out/rc.txt
 tail -5 $out/pytest_plan.log
 export RD_RG_ROWS32=15 RD_RG_WAVES16=12
 run() { env "$@" timeout 120 python tools/step_only.py 300 2>&1 | tail -1 | sed "s/^/$* /" >> $out/ab.txt; }
-for rep in 1 2 3; do run RD_ENC_LEAN=1; run RD_ENC_LEAN=0; done
+for rep in 1 2 3; do run RD_X=1; done
 cat $out/ab.txt
 unset RD_RG_ROWS32 RD_RG_WAVES16
 timeout 900 python -m pytest tests -m gpu -q --maxfail=20 > $out/pytest_all.log 2>&1; echo "pytest_all rc=$?" >> $out/rc.txt
