@@ -168,20 +168,22 @@ def k1_roofline(model, cfg, batch, reps=20):
 
 
 def k1_in_step(model, flat, batch, iters=40):
-    """The K1 launches timed INSIDE the training step: the step is captured as four consecutive hipGraphs (TrainStep.capture_segments:
-    first launch | message-passing forward | encoder + head forward and backward | message-passing backward) and every replay of
-    the two K1 graphs is bracketed by HIP events on the replay stream, while the loop runs whole steps back to back.  Unlike the
-    isolated loop (same ~108 MB of buffers re-used: resident in the 256 MiB Infinity Cache) the kernels see the cache state the
-    step leaves them.  Returns (fwd_ms, bwd_ms, begin_ms, step_ms): medians over `iters` steps; each interval includes the start of
-    its graph (a few us)."""
+    """The K1 launches -- and the encoder layers -- timed INSIDE the training step: the step is captured as six consecutive hipGraphs
+    (TrainStep.capture_segments: first launch | message-passing forward | encoder forward | head + loss | encoder backward |
+    message-passing backward) and every replay is bracketed by HIP events on the replay stream, while the loop runs whole steps
+    back to back.  Unlike the isolated loops (same buffers re-used: resident in the 256 MiB Infinity Cache, which hides exactly the
+    HBM traffic the round-4 kernels remove) the kernels see the cache state the step leaves them.  Returns a dict of medians over
+    `iters` steps (ms); each interval includes the start of its graph (a few us)."""
     from raindrop_amd.step import TrainStep
     ts = TrainStep(model, flat, batch, use_graph=False, autotune=False)
-    graphs = ts.capture_segments(("begin", "k1f", "mid", "k1b"))
+    parts = ("begin", "k1f", "enc", "head", "encb", "k1b")
+    graphs = ts.capture_segments(parts)
     for _ in range(5):
         for g in graphs:
             g.replay()
     torch.cuda.synchronize()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(iters)]
+    n = len(parts)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(n + 1)] for _ in range(iters)]
     for it in range(iters):
         ev[it][0].record()
         for k, g in enumerate(graphs):
@@ -189,10 +191,12 @@ def k1_in_step(model, flat, batch, iters=40):
             ev[it][k + 1].record()
     torch.cuda.synchronize()
     med = lambda v: sorted(v)[len(v) // 2]
-    seg = [med([ev[it][k].elapsed_time(ev[it][k + 1]) for it in range(iters)]) for k in range(4)]
-    step_ms = med([ev[it][0].elapsed_time(ev[it][4]) for it in range(iters)])
+    out = {p: med([ev[it][k].elapsed_time(ev[it][k + 1]) for it in range(iters)]) for k, p in enumerate(parts)}
+    out["step"] = med([ev[it][0].elapsed_time(ev[it][n]) for it in range(iters)])
+    out["nl"] = ts.nl
+    out["mlive"] = int(ts.plan[0]) if ts.plan is not None else None
     ts.close()
-    return seg[1], seg[3], seg[0], step_ms
+    return out
 
 
 def encoder_roofline(model, cfg, B, iters=50, lengths=None):
@@ -263,7 +267,7 @@ def encoder_roofline(model, cfg, B, iters=50, lengths=None):
             "algorithmic_bytes_live_rows": live * (18 * D + 2 * nhid) * 4,
             "frac_live_rows": round(live * (18 * D + 2 * nhid) * 4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "us": round(ms * 1e3, 2),
             "mfma": {"algorithmic_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
-                     "frac_issued": round(3 * flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 5)}}
+                     "frac_issued": round(_products() * flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 5)}}
 
 
 def roofline_isolated(args):
@@ -376,6 +380,12 @@ def enc_source_hash():
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
 
 
+def _products():
+    """bf16 MFMA products issued per fp32-equivalent multiply-add in the current arithmetic mode: 3 for split-bf16 (hi*hi + hi*lo +
+    lo*hi), 1 for the single-product bf16 mode (the exact-fp32 mode runs on the f32 MFMA: its bf16-peak fraction is reported as if 3)."""
+    return 1 if os.environ.get("RD_PRECISION", "bf16x3") == "bf16" else 3
+
+
 def _roofline_dict(B, F, K, fwd, bwd, how):
     traffic, traffic_src = _pmc_traffic(B, F, K)
     bytes_fwd = B * 12 * F * K + 8 * (K * K + K)
@@ -393,8 +403,8 @@ def _roofline_dict(B, F, K, fwd, bwd, how):
             "algorithmic_bytes": alg, "fwd_us": round(fwd * 1e3, 2), "bwd_us": round(bwd * 1e3, 2),
             "fwd_frac": round(bytes_fwd / (fwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             "bwd_frac": round(bytes_bwd / (bwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-            "mfma": {"algorithmic_tflops": round(tf, 2), "issued_bf16_tflops": round(3 * tf, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
-                     "frac_issued": round(3 * tf / MFMA_BF16_PEAK_TFLOPS, 5),
+            "mfma": {"algorithmic_tflops": round(tf, 2), "issued_bf16_tflops": round(_products() * tf, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                     "frac_issued": round(_products() * tf / MFMA_BF16_PEAK_TFLOPS, 5), "products_per_flop": _products(),
                      "note": "12 F K^2 flops per sample fwd+bwd (SURVEY 8d); x3 MFMA products in split-bf16 mode; "
                              "arithmetic intensity 0.375 K flop/B: HBM-bound below K ~ 314 with bf16 MFMA, MFMA-bound above"}}
 
@@ -664,7 +674,8 @@ def main():
         k1 = k1_roofline(model, cfg, batch)
         try:
             # the line's `frac` is the IN-STEP figure: the isolated loop's becomes `frac_isolated`
-            f_ms, b_ms, begin_ms, seg_step_ms = k1_in_step(model, flat, batch)
+            seg = k1_in_step(model, flat, batch)
+            f_ms, b_ms, begin_ms, seg_step_ms = seg["k1f"], seg["k1b"], seg["begin"], seg["step"]
             # the step's first launch splits the encoder's weights as well: K1's share of it by tile elements
             Kk = cfg["max_len"] * cfg["d_ob"]
             Dd, Hh = cfg["d_inp"] * cfg["d_ob"] + 16, cfg["nhid"]
@@ -681,16 +692,37 @@ def main():
             k1["fwd_us"], k1["bwd_us"] = round(f_ms * 1e3, 2), round(b_ms * 1e3, 2)
             k1["in_step"] = {"fwd_us": round(f_ms * 1e3, 2), "bwd_us": round(b_ms * 1e3, 2), "first_launch_us": round(begin_ms * 1e3, 2),
                              "k1_share_of_first_launch": round(share, 3), "us": round(us, 2),
-                             "segmented_step_us": round(seg_step_ms * 1e3, 2)}
+                             "segmented_step_us": round(seg_step_ms * 1e3, 2),
+                             "segments_us": {p: round(seg[p] * 1e3, 2) for p in ("begin", "k1f", "enc", "head", "encb", "k1b")}}
+            k1["encoder_in_step"] = {"us_per_layer": round((seg["enc"] + seg["encb"]) * 1e3 / seg["nl"], 2), "mlive": seg["mlive"], "nl": seg["nl"]}
             k1["kernel"] = ("K1 message passing fwd+bwd AS THEY RUN IN THE TRAINING STEP (rd_sensor_stage_fwd + rd_msgpass_bwd incl. PE/mask, dW/db "
-                            "reductions, + K1's share of the step's first launch = its weight split): the step captured as 4 consecutive "
-                            "hipGraphs, the two K1 graphs bracketed by HIP events on the replay stream, medians over 40 whole steps; "
+                            "reductions, + K1's share of the step's first launch = its weight split): the step captured as 6 consecutive "
+                            "hipGraphs, each bracketed by HIP events on the replay stream, medians over 40 whole steps; "
                             "`isolated` is the round-1..3 figure")
         except Exception as e:                                   # the isolated figure survives
             k1["in_step_error"] = repr(e)[:300]
         print("K1ROOFLINE " + json.dumps(k1), flush=True)
         try:
-            print("ENCROOFLINE " + json.dumps(encoder_roofline(model, cfg, args.batch, lengths=batch["lengths"])), flush=True)
+            enc = encoder_roofline(model, cfg, args.batch, lengths=batch["lengths"])
+            eis = k1.get("encoder_in_step")
+            if eis:
+                # the object's time and fractions are the IN-STEP ones; the isolated loop's (Infinity-Cache-resident) stay alongside
+                enc["isolated"] = {"us": enc["us"], "frac": enc["frac"], "frac_live_rows": enc["frac_live_rows"]}
+                us = eis["us_per_layer"]
+                enc["us"] = us
+                enc["achieved"] = round(enc["algorithmic_bytes"] / (us * 1e-6) / 1e9, 2)
+                enc["frac"] = round(enc["achieved"] / HBM_PEAK_GBS, 5)
+                enc["frac_live_rows"] = round(enc["algorithmic_bytes_live_rows"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+                enc["kernel"] = ("one TransformerEncoderLayer fwd+bwd AS IT RUNS IN THE TRAINING STEP: (encoder-forward graph + encoder-backward "
+                                 "graph of the segmented step) / %d layers, HIP events, medians over 40 steps; on the step's token plan: %s live "
+                                 "rows; `isolated` = layer 0 alone as hipGraph replays on re-used buffers" % (eis["nl"], eis["mlive"]))
+            if enc["algorithmic_bytes_live_rows"] != enc["algorithmic_bytes"]:
+                # token plan on: the kernels touch the live rows only -- `frac` is against THOSE bytes; the padded-layout
+                # figure stays as frac_padded_layout
+                enc["frac_padded_layout"] = enc["frac"]
+                enc["frac"] = enc["frac_live_rows"]
+                enc["achieved"] = round(enc["algorithmic_bytes_live_rows"] / (enc["us"] * 1e-6) / 1e9, 2)
+            print("ENCROOFLINE " + json.dumps(enc), flush=True)
         except Exception as e:                                   # the K1 object must survive a failure here
             print("ENCROOFLINE_FAILED %r" % (e,), file=sys.stderr, flush=True)
         return

@@ -37,7 +37,13 @@ struct HeadArgs {
   float *feat, *hid, *dhid, *demb, *dlog, *lossr;   // workspace: [B,dh] x3, [B,Fe], [B,C], [B]
   int T, B, D, ds, Fe, dh, C;
   const int32_t* plan;             // token plan (rd_plan.h) or null: r / dr hold the live rows only, sample b at rows off[rank[b]] + t
+  unsigned long long* stamps;      // debug (tools/head_timing.py): clock64 per phase, thread 0 of workgroup 0
 };
+static unsigned long long* g_head_stamps = nullptr;
+#define HSTAMP(i)                                                                           \
+  do {                                                                                      \
+    if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[(i)] = clock64();         \
+  } while (0)
 
 // first row and row step of sample b's time steps in r / dr, and how many of them are live
 struct HeadRows { long row0, rstep; int Tv; };
@@ -79,6 +85,7 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
   const int b0 = blockIdx.x * RB;
   const int T = a.T, B = a.B, D = a.D, dh = a.dh, C = a.C, D4 = D >> 2;
 
+  HSTAMP(0);
   // ---- W0 rows of this wave -> registers (requested first: they are needed after the masked mean) ----
   // UNCONDITIONAL loads from clamped addresses: rows j >= dh are never used (wave-uniform tests below) and columns k >= dh only
   // reach accumulator slots nobody reads.  As conditional loads (a phi of {0, value} each) the compiler waited for them one
@@ -117,6 +124,7 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
     }
     for (int i = tid + HR_THR; i < nw2; i += HR_THR) w2s[i] = a.w2[i];                // C * dh > 1024 only
   }
+  HSTAMP(1);
   // ---- masked mean: thread = (sample r, column quad c4, time group tg) ----
   const int P = RB * D4;
   const int ntg = min(HR_THR / P, 16);
@@ -144,7 +152,9 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
     if (tg < ntg) *reinterpret_cast<float4*>(red + ((size_t)tg * P + pair) * 4) = s;
     if (tid < RB) invl[tid] = (b0 + tid < B) ? 1.0f / (float)(a.lengths[b0 + tid] + 1) : 0.f;
   }
+  HSTAMP(2);
   __syncthreads();
+  HSTAMP(3);
   if (tid < P) {
     const int r = tid / D4, c4 = tid - r * D4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -171,6 +181,7 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
     feat[r][D + j] = s;
   }
   __syncthreads();
+  HSTAMP(4);
   // ---- hid = relu(W0 feat + b0): wave w owns outputs j = w, w+16, ...; lanes split the reduction ----
 #pragma unroll
   for (int jj = 0; jj < HR_RJ; ++jj) {
@@ -190,6 +201,7 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
     }
   }
   __syncthreads();
+  HSTAMP(5);
   // ---- logits: wave = (r, c) ----
   for (int o = wave; o < RB * C; o += HR_WAVES) {
     const int r = o / C, c = o - r * C;
@@ -199,6 +211,7 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
     if (lane == 0) lg[r][c] = p + b2s[c];
   }
   __syncthreads();
+  HSTAMP(6);
   // ---- softmax cross entropy per sample, dlogits = (softmax - onehot) / B ----
   if (tid < RB && b0 + tid < B) {
     const int r = tid, b = b0 + r;
@@ -223,6 +236,7 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
     for (int c = 0; c < C; ++c) dl[tid][c] = 0.f;
   }
   __syncthreads();
+  HSTAMP(7);
   // ---- dhid = (dlogits W2) gated by hid > 0: thread = (r, j); rows out to the workspace for the weight gradients ----
   for (int e = tid; e < RB * dh; e += HR_THR) {
     const int r = e / dh, j = e - r * dh, b = b0 + r;
@@ -238,6 +252,7 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
     }
   }
   __syncthreads();
+  HSTAMP(8);
   // ---- dfeat = dhid W0: the same registers; this wave's rows give a partial for every column, waves combined in order ----
   {
     float acc[RB][HR_KI];
@@ -263,6 +278,7 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
       for (int i = 0; i < HR_KI; ++i) red[((size_t)wave * RB + r) * HR_LD + lane + 64 * i] = acc[r][i];
   }
   __syncthreads();
+  HSTAMP(9);
   for (int e = tid; e < RB * HR_LD; e += HR_THR) {
     const int r = e / HR_LD, k = e - r * HR_LD;
     float s = 0.f;
@@ -273,6 +289,7 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
     if (k >= D && k < dh && b < B) a.demb[(long)b * a.Fe + (k - D)] = s;   // gradient of the static embedding's output
   }
   __syncthreads();
+  HSTAMP(10);
   // ---- masked mean backward: dr[t,b,:] = valid ? dfeat[b,:D] / (len + 1) : 0   (code/models_rd.py:379, autograd) ----
   HeadRows hr1{};                                                        // RB == 1: the workgroup's one sample, looked up once
   if (RB == 1 && b0 < B) hr1 = head_rows_uniform(a, b0);
@@ -286,6 +303,7 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
     const float4 v = *reinterpret_cast<const float4*>(&dfeat[r][4 * c4]);
     *reinterpret_cast<float4*>(a.dr + (hr.row0 + (long)t * hr.rstep) * D + 4 * c4) = make_float4(v.x * il, v.y * il, v.z * il, v.w * il);
   }
+  HSTAMP(11);
 }
 
 // dW[n,k] = sum_b u[b,n] v[b,k], db[n] = sum_b u[b,n]: 16 x 16 output tile per workgroup, thread = one output
@@ -337,6 +355,8 @@ __global__ __launch_bounds__(256) void k_head_wgrad(HwArgs a) {
 
 using namespace rd;
 
+extern "C" void rd_debug_set_head_stamps(void* p) { g_head_stamps = (unsigned long long*)p; }   // not part of the ABI
+
 extern "C" size_t rd_head_train_workspace_bytes(int32_t B, int32_t dh, int32_t C) {
   if (B < 0 || dh <= 0 || C <= 0) return 0;
   return align_up(((size_t)4 * B * dh + (size_t)B * C + B) * sizeof(float), 256);
@@ -370,7 +390,7 @@ extern "C" int rd_head_train(const rd_shape* s, int32_t D, int32_t d_static, int
   a.feat = ws; a.hid = a.feat + (size_t)B * dh; a.dhid = a.hid + (size_t)B * dh; a.demb = a.dhid + (size_t)B * dh;
   a.dlog = a.demb + (size_t)B * dh; a.lossr = a.dlog + (size_t)B * C;
   a.T = s->T; a.B = B; a.D = D; a.ds = d_static; a.Fe = Fe; a.dh = dh; a.C = C;
-  a.plan = token_plan();
+  a.plan = token_plan(); a.stamps = g_head_stamps;
   // one sample per workgroup (B workgroups: every CU busy at B = 256); MEASURED in-step: 1.077 -> 1.056 ms/step against RB = 2
   static const int rb1 = [] { const char* e = getenv("RD_HEAD_RB1"); return e ? atoi(e) : 1; }();
   if (rb1) hipLaunchKernelGGL(k_head_rows<1>, dim3(B), dim3(HR_THR), 0, st, a);

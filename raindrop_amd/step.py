@@ -189,8 +189,9 @@ class TrainStep:
 
     def _body(self, part=None):
         """Enqueue one forward + loss + backward on the current stream (no host sync).  part 'a' / 'b': the two halves of the split
-        form (see __init__); 'begin' / 'k1f' / 'mid' / 'k1b': the step cut around the message-passing stage (capture_segments:
-        bench.py times the K1 launches as they run INSIDE the step); None: everything."""
+        form (see __init__); 'begin' / 'k1f' / 'mid' / 'k1b': the step cut around the message-passing stage, 'enc' / 'head' / 'encb':
+        'mid' cut further into encoder forward | head + loss | encoder backward (capture_segments: bench.py times the K1 launches
+        and the encoder layers as they run INSIDE the step); None: everything."""
         if part == "b":
             return self._body_tail(self.nl - 2)
         m, b, P, G, sp = self.model, self.batch, self.P, self.G, self.sp
@@ -226,10 +227,15 @@ class TrainStep:
               self.k1_saved.numel(), st)
             if part == "k1f":
                 return
-        for i in range(self.nl):
-            c("rd_encoder_layer_fwd", sp, i | (0x10000 if self.prep_enc else 0), _p(self.x[i]), _p(self.mask), ctypes.byref(self.enc_w[i]), self.p_drop,
-              self.seed, _p(self.x[i + 1]), _p(self.enc_saved[i]), self.enc_saved[i].numel(), _p(self.enc_ws),
-              self.enc_ws.numel(), st)
+        if part == "encb":
+            return self._body_tail(self.nl - 1, self.dx[0], k1=False)
+        if part != "head":
+            for i in range(self.nl):
+                c("rd_encoder_layer_fwd", sp, i | (0x10000 if self.prep_enc else 0), _p(self.x[i]), _p(self.mask), ctypes.byref(self.enc_w[i]), self.p_drop,
+                  self.seed, _p(self.x[i + 1]), _p(self.enc_saved[i]), self.enc_saved[i].numel(), _p(self.enc_ws),
+                  self.enc_ws.numel(), st)
+            if part == "enc":
+                return
         cur = self.dx[0]
         if self.head_fused:
             e = (lambda n: _p(P[n]) if Fe else None)
@@ -241,6 +247,8 @@ class TrainStep:
               _p(G["mlp_static.2.weight"]), _p(G["mlp_static.2.bias"]), _p(cur), _p(self.head_ws), self.head_ws.numel(), st)
         else:
             self._head_by_operator(cur, st)
+        if part == "head":
+            return
         if part == "a":                                   # the last layer's backward closes part A
             self._enc_bwd(self.nl - 1, cur, self.dx[1], st)
             return
