@@ -86,6 +86,16 @@ int rd_get_precision(void);
 int rd_set_seed_cell(const uint64_t* device_cell);
 int rd_seed_cell_advance(uint64_t* device_cell, uint64_t delta, void* stream);
 
+/* Side branch for trailing launches.  rd_set_side_stream registers (per host thread, consumed when a call is enqueued; NULL
+ * clears) a second stream: launches that only produce parameter gradients nothing later in the backward pass reads -- the slice
+ * reduces of rd_encoder_layer_bwd's weight-gradient stream, rd_head_train's weight-gradient tiles and loss mean -- are then
+ * ordered behind the caller's stream and enqueued THERE, beside whatever the caller enqueues next.  The caller owns the join:
+ * rd_side_join(stream) makes `stream` wait for the side branch (call it before reading those gradients / the loss on `stream`,
+ * and before the end of a stream capture that forked).  With no side stream registered nothing changes.  Results are identical
+ * either way (the same kernels on the same data; only their overlap changes). */
+int rd_set_side_stream(void* stream);
+int rd_side_join(void* stream);
+
 /* ---- token plan: the padding mask as a layout --------------------------------------------------------------------------
  * code/models_rd.py:298-299 builds mask[b,t] = (t >= lengths[b]) and uses it twice: as src_key_padding_mask of the encoder
  * (:358) and in the masked mean (:366-367,379).  Between them the two uses remove every padded step from the logits AND from

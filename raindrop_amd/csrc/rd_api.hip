@@ -27,6 +27,30 @@ int precision() {
   return g_precision;
 }
 
+static thread_local hipStream_t g_side = nullptr;
+static thread_local bool g_side_busy = false;          // something was forked since the last join
+static hipEvent_t side_event(int which) {
+  static thread_local hipEvent_t ev[2] = {nullptr, nullptr};
+  if (!ev[which] && hipEventCreateWithFlags(&ev[which], hipEventDisableTiming) != hipSuccess) ev[which] = nullptr;
+  return ev[which];
+}
+hipStream_t side_fork(hipStream_t main_stream) {
+  if (!g_side || g_side == main_stream) return main_stream;
+  hipEvent_t e = side_event(0);
+  if (!e || hipEventRecord(e, main_stream) != hipSuccess || hipStreamWaitEvent(g_side, e, 0) != hipSuccess) return main_stream;
+  g_side_busy = true;
+  return g_side;
+}
+int side_join(hipStream_t main_stream) {
+  if (!g_side || !g_side_busy || g_side == main_stream) return RD_OK;
+  hipEvent_t e = side_event(1);
+  if (!e) return fail(RD_EINVAL, "side_join: no event");
+  RD_HIP(hipEventRecord(e, g_side));
+  RD_HIP(hipStreamWaitEvent(main_stream, e, 0));
+  g_side_busy = false;
+  return RD_OK;
+}
+
 int fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -50,6 +74,8 @@ namespace {
 __global__ void k_seed_advance(uint64_t* cell, uint64_t delta) { *cell += delta; }
 }
 extern "C" int rd_set_seed_cell(const uint64_t* device_cell) { g_seed_cell = device_cell; return RD_OK; }
+extern "C" int rd_set_side_stream(void* stream) { g_side = (hipStream_t)stream; g_side_busy = false; return RD_OK; }
+extern "C" int rd_side_join(void* main_stream) { return side_join((hipStream_t)main_stream); }
 extern "C" int rd_seed_cell_advance(uint64_t* device_cell, uint64_t delta, void* stream) {
   RD_REQUIRE(device_cell != nullptr, "NULL cell");
   hipLaunchKernelGGL(k_seed_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, device_cell, delta);

@@ -42,6 +42,16 @@ const uint64_t* seed_cell();
 // process-wide arithmetic mode of the dense contractions (rd_set_precision / env RD_PRECISION)
 int precision();
 
+// Side branch for TRAILING launches (rd_set_side_stream, per host thread, read at enqueue like the seed cell).  A few launches of
+// the step produce only parameter gradients that nothing later in the backward chain reads -- the slice reduces of the weight-
+// gradient streams, the head's weight-gradient tiles -- yet in one stream each sits on the critical path for its 5-15 us.
+// side_fork(main) orders a registered side stream behind everything enqueued on `main` so far and returns it (or `main` when none
+// is registered): the trailing launch goes there and runs beside what follows on `main`.  side_join(main) makes `main` wait for the
+// side stream; the OWNER of the stream (raindrop_amd.step.TrainStep) calls rd_side_join at the end of a step / of a captured graph,
+// the library itself before it rewrites a buffer a forked launch reads.  Under stream capture both become graph dependencies.
+hipStream_t side_fork(hipStream_t main_stream);
+int side_join(hipStream_t main_stream);
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // one weight matrix W [N,K] (row-major fp32) -> native matrix-core operand tiles [ceil16(rows)/16][ceil32(cols)/32][hi, lo][64][8]

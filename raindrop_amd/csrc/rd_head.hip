@@ -409,6 +409,7 @@ extern "C" int rd_head_train(const rd_shape* s, int32_t D, int32_t d_static, int
   add(a.dlog, C, C, a.hid, dh, dh, g_w2, g_b2);                          // d mlp_static[2]
   if (Fe) add(a.demb, Fe, Fe, stat, d_static, d_static, g_emb_w, g_emb_b);   // d emb
   h.n = n;
-  hipLaunchKernelGGL(k_head_wgrad, dim3(blk), dim3(256), 0, st, h);
+  // weight gradients + the loss mean: nothing in the backward chain reads them -> side branch (rd_common.h side_fork)
+  hipLaunchKernelGGL(k_head_wgrad, dim3(blk), dim3(256), 0, side_fork(st), h);
   return check_launch("k_head_wgrad");
 }

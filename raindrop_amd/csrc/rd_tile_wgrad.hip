@@ -261,6 +261,10 @@ int launch_tile_wgrad(long M, int njobs, const TileWgradJob* jobs, const void* o
     P.q0 = q; P.nq = j.N * (P.ldp >> 2); q += (P.nq + 511) / 512 * 512;
     P.s32x = j.s32; P.Sx = j.S; P.hd = j.hd; P.hdp = j.hdp; P.H = j.H; P.D = j.D;
   }
+  // a reduce launch of an earlier call may still be reading partials / LayerNorm partial matrices on the side branch: this call
+  // rewrites workspace of the same kind (callers with one workspace per layer never wait here for long)
+  int rcj = side_join(st);
+  if (rcj) return rcj;
   if (precision() == RD_PREC_BF16) {
     RD_LDS_ATTR(k_twg<true>, TW_LDS);
     hipLaunchKernelGGL(k_twg<true>, dim3(wg), dim3(TW_THR), TW_LDS, st, a);
@@ -277,7 +281,8 @@ int launch_tile_wgrad(long M, int njobs, const TileWgradJob* jobs, const void* o
     a.cs[i].x = cs[i].x; a.cs[i].M = cs[i].M; a.cs[i].N = cs[i].N; a.cs[i].n1 = cs[i].n1; a.cs[i].out1 = cs[i].out1; a.cs[i].out2 = cs[i].out2;
     ncb += cdiv(cs[i].N, 64);
   }
-  hipLaunchKernelGGL(k_twg_reduce, dim3(a.nblk_w + ncb), dim3(TWR_THR), 0, st, a);
+  // the reduce only produces parameter gradients: it goes to the side branch (rd_common.h side_fork) when one is registered
+  hipLaunchKernelGGL(k_twg_reduce, dim3(a.nblk_w + ncb), dim3(TWR_THR), 0, side_fork(st), a);
   return check_launch("k_twg_reduce");
 }
 

@@ -86,6 +86,11 @@ class TrainStep:
         self.G = gview
         self._alloc()
         self.seed_cell = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        # side branch for the trailing launches of the step (the weight-gradient reduces, the head's weight gradients: nothing in
+        # the backward chain reads them).  MEASURED round 4, same box, 3 x 300 steps each: 0.554 ms/step with the branch against
+        # 0.521 without -- the fourth time a forked graph loses here (the fork / join edges cost more than the 5-8 us launches
+        # they take off the chain).  Off by default; RD_SIDE_REDUCE=1 turns it on (results are identical).
+        self.side = torch.cuda.Stream(device=self.dev) if os.environ.get("RD_SIDE_REDUCE", "0") == "1" else None
         # token plan: the step's fast paths only (fused message passing, row-block encoder, fused head)
         self.plan = None
         if self._want_plan and self.head_fused and self._plan_supported():
@@ -159,7 +164,10 @@ class TrainStep:
         self.nl = len(m.transformer_encoder.layers)
         self.x = [self.z] + [torch.zeros((T, B, D), **f32) for _ in range(self.nl)]
         self.enc_saved = [u8(lib.rd_encoder_layer_saved_bytes(sp)) for _ in range(self.nl)]
-        self.enc_ws = u8(lib.rd_encoder_layer_workspace_bytes(sp))
+        # one workspace per layer: a layer's trailing reduce launch (side branch, rd_set_side_stream) reads its partials while the
+        # next layer's backward already writes its own
+        self.enc_wss = [u8(lib.rd_encoder_layer_workspace_bytes(sp)) for _ in range(self.nl)]
+        self.enc_ws = self.enc_wss[0]
         self.dx = [torch.zeros((T, B, D), **f32) for _ in range(2)]        # ping-pong gradient buffers
         self.Fe = m.d_inp if m.static else 0
         self.feat = torch.empty((B, D + self.Fe), **f32)
@@ -188,6 +196,12 @@ class TrainStep:
         _lib.call(name, *a)
 
     def _body(self, part=None):
+        """_body_impl + the join of the side branch: launches forked inside this part (weight-gradient reduces, the head's weight
+        gradients: rd_set_side_stream) are complete, in stream order, when the part is."""
+        self._body_impl(part)
+        _lib.call("rd_side_join", ops._stream())
+
+    def _body_impl(self, part=None):
         """Enqueue one forward + loss + backward on the current stream (no host sync).  part 'a' / 'b': the two halves of the split
         form (see __init__); 'begin' / 'k1f' / 'mid' / 'k1b': the step cut around the message-passing stage, 'enc' / 'head' / 'encb':
         'mid' cut further into encoder forward | head + loss | encoder backward (capture_segments: bench.py times the K1 launches
@@ -232,8 +246,8 @@ class TrainStep:
         if part != "head":
             for i in range(self.nl):
                 c("rd_encoder_layer_fwd", sp, i | (0x10000 if self.prep_enc else 0), _p(self.x[i]), _p(self.mask), ctypes.byref(self.enc_w[i]), self.p_drop,
-                  self.seed, _p(self.x[i + 1]), _p(self.enc_saved[i]), self.enc_saved[i].numel(), _p(self.enc_ws),
-                  self.enc_ws.numel(), st)
+                  self.seed, _p(self.x[i + 1]), _p(self.enc_saved[i]), self.enc_saved[i].numel(), _p(self.enc_wss[i]),
+                  self.enc_wss[i].numel(), st)
             if part == "enc":
                 return
         cur = self.dx[0]
@@ -257,7 +271,7 @@ class TrainStep:
     def _enc_bwd(self, i, cur, nxt, st):
         self._call("rd_encoder_layer_bwd", self.sp, i, _p(self.x[i]), _p(self.mask), ctypes.byref(self.enc_w[i]), self.p_drop,
                    self.seed, _p(self.enc_saved[i]), self.enc_saved[i].numel(), _p(cur), _p(nxt), ctypes.byref(self.enc_g[i]),
-                   _p(self.enc_ws), self.enc_ws.numel(), st)
+                   _p(self.enc_wss[i]), self.enc_wss[i].numel(), st)
 
     def _body_tail(self, top, cur=None, k1=True):
         """Backward of encoder layers top .. 0 and (k1) of the sensor stage; the entry gradient is dx[0] for the top layer of the
@@ -320,11 +334,13 @@ class TrainStep:
         dropping a TrainStep can no longer leave a dangling pointer behind."""
         _lib.call("rd_set_seed_cell", _p(self.seed_cell))
         _lib.call("rd_set_token_plan", _p(self.plan))
+        _lib.call("rd_set_side_stream", ctypes.c_void_p(self.side.cuda_stream) if self.side is not None else None)
         try:
             return fn()
         finally:
             _lib.call("rd_set_seed_cell", None)
             _lib.call("rd_set_token_plan", None)
+            _lib.call("rd_set_side_stream", None)
 
     def _capture(self):
         """Capture the step as one hipGraph (two in the split form).  With `autotune`, the step is captured once per setting of the
