@@ -30,7 +30,7 @@ int fused_msgpass_fwd(const k1::Layout& L, const float* src, const float* R_u, c
                       const int64_t* lengths, const float* tscale, uint8_t* mask, int d_pe);
 int fused_msgpass_bwd(const k1::Layout& L, const float* src, const float* ssum, const void* wt, float p_drop,
                       const void* m1, const void* m2, const void* mx, const float* dz, int ldz, void* tpD1, void* tpD2,
-                      void* ones, float* rupart, hipStream_t st);
+                      void* ones, float* rupart, hipStream_t st, const void* tpX = nullptr, const void* tpY1 = nullptr);
 int fused_dw(const k1::Layout& L, const k1::DwPlan& P, const void* tpX, const void* tpY1, const void* tpD1,
              const void* tpD2, const void* ones, float* part, const float* rupart, float* dW1, float* db1, float* dW2, float* db2,
              float* dRu, hipStream_t st);
@@ -390,7 +390,7 @@ extern "C" int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* 
     RD_REQUIRE(saved_bytes >= fv.bytes, "saved buffer too small");
     FusedWs fw = carve_fused_ws(L, P, workspace);
     RD_REQUIRE(workspace && workspace_bytes >= fw.bytes, "workspace too small: %zu < %zu", workspace_bytes, fw.bytes);
-    if ((rc = fused_msgpass_bwd(L, src, ssum, fv.wt, p_drop, fv.m1, fv.m2, fv.mx, dz, ldz, fw.tpD1, fw.tpD2, fw.ones, fw.rupart, st)))
+    if ((rc = fused_msgpass_bwd(L, src, ssum, fv.wt, p_drop, fv.m1, fv.m2, fv.mx, dz, ldz, fw.tpD1, fw.tpD2, fw.ones, fw.rupart, st, fv.tpX, fv.tpY1)))
       return rc;
     return fused_dw(L, P, fv.tpX, fv.tpY1, fw.tpD1, fw.tpD2, fw.ones, fw.part, fw.rupart, dW1, db1, dW2, db2, dR_u, st);
   }

@@ -930,6 +930,24 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
     a.rupart[(size_t)(m24(sb, Fd) + i)] = v;
   }
   RD_STAMP(9);
+  // ---- warm the weight-gradient stream's COLD operands.  rd_msgpass_dw.hip runs right behind this kernel and streams four tile
+  // tensors: dZ1 / dZ2 are written here (Infinity-Cache-hot), X / Y1 were written by the forward, a whole encoder forward +
+  // backward ago (~700 MB of traffic: long evicted) -- in the step k_dw took 21 us against 12 in the isolated loop (slow box).
+  // The LAST instructions of the last wave touch one dword per 128-byte line of this sample's X and Y1 tiles: fire-and-forget
+  // loads (inline asm: the destination registers are never read and nothing follows that could reuse them), so no wave waits and no
+  // register is held through the kernel (eight live registers across it spilled).  The lines are in the memory-side cache when
+  // k_dw asks; workgroups finish at different times, so most touches are well ahead of it.
+  if (a.tpX && __builtin_amdgcn_readfirstlane(wave) == NWAVE - 1) {
+    const int bytes = dm.q * nct * 2 * TILE * (int)sizeof(__bf16);      // main tiles of this sample: contiguous
+    const char* bx = reinterpret_cast<const char*>(tp_tile(const_cast<__bf16*>(a.tpX), nct, sb * dm.q, 0));
+    const char* by = reinterpret_cast<const char*>(tp_tile(const_cast<__bf16*>(a.tpY1), nct, sb * dm.q, 0));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int o = min((lane + 64 * u) * 128, max(bytes - 128, 0));
+      float t0, t1;
+      asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "=&v"(t0), "=&v"(t1) : "v"(bx + o), "v"(by + o) : "memory");
+    }
+  }
 }
 
 template <int RT, int FC, int TC>
@@ -1005,9 +1023,13 @@ int fused_msgpass_fwd(const k1::Layout& L, const float* src, const float* R_u, c
 
 int fused_msgpass_bwd(const k1::Layout& L, const float* src, const float* ssum, const void* wt, float p_drop,
                       const void* m1, const void* m2, const void* mx, const float* dz, int ldz, void* tpD1, void* tpD2,
-                      void* ones, float* rupart, hipStream_t st) {
+                      void* ones, float* rupart, hipStream_t st, const void* tpX, const void* tpY1) {
   FusedArgs a{};
   fill_layout(a, L);
+  {   // the forward's row tiles, only touched here (RD_K1_WARM=0: not at all; A/B)
+    static const bool warm = [] { const char* e = getenv("RD_K1_WARM"); return !(e && atoi(e) == 0); }();
+    a.tpX = warm ? (__bf16*)const_cast<void*>(tpX) : nullptr; a.tpY1 = warm ? (__bf16*)const_cast<void*>(tpY1) : nullptr;
+  }
   a.src = src; a.ssum = ssum; a.wt = (const __bf16*)wt;
   a.m1 = (uint16_t*)const_cast<void*>(m1); a.m2 = (uint16_t*)const_cast<void*>(m2); a.mx = (uint8_t*)const_cast<void*>(mx);
   a.dz = dz; a.ldz = ldz; a.tpD1 = (__bf16*)tpD1; a.tpD2 = (__bf16*)tpD2; a.ones = (__bf16*)ones; a.rupart = rupart;
