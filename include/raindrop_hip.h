@@ -96,6 +96,15 @@ int rd_seed_cell_advance(uint64_t* device_cell, uint64_t delta, void* stream);
 int rd_set_side_stream(void* stream);
 int rd_side_join(void* stream);
 
+/* Deferred trailing launches (round 4; what replaced the side branch as the default of raindrop_amd.step.TrainStep).  With
+ * rd_set_defer_trailing(1) (per host thread, consumed at enqueue) the same launches are not enqueued at all but PARKED -- one at a
+ * time -- and the next rd_encoder_layer_bwd that runs its fused backward chain appends them to that launch as extra workgroups, which
+ * run on the CUs the chain leaves idle.  A parked launch nobody picks up runs stand-alone when the next one is parked or when
+ * rd_flush_trailing(stream) is called: call it before reading those gradients / the loss, and before the end of a stream capture.
+ * Results are identical in every mode (same arithmetic on the same data). */
+int rd_set_defer_trailing(int32_t on);
+int rd_flush_trailing(void* stream);
+
 /* ---- token plan: the padding mask as a layout --------------------------------------------------------------------------
  * code/models_rd.py:298-299 builds mask[b,t] = (t >= lengths[b]) and uses it twice: as src_key_padding_mask of the encoder
  * (:358) and in the masked mean (:366-367,379).  Between them the two uses remove every padded step from the logits AND from

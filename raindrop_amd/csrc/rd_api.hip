@@ -5,6 +5,7 @@
 
 #include "rd_common.h"
 #include "rd_rng.h"
+#include "rd_trailing.h"
 
 namespace rd {
 
@@ -51,6 +52,33 @@ int side_join(hipStream_t main_stream) {
   return RD_OK;
 }
 
+// ---- trailing launches parked for the next backward chain launch (rd_trailing.h) ----
+int launch_twg_reduce_standalone(const TwArgs& a, int nblocks, hipStream_t st);
+int launch_head_wgrad_standalone(const HwArgs& h, hipStream_t st);
+static thread_local bool g_defer = false;
+static thread_local RiderArgs g_parked{};
+bool trailing_deferred() { return g_defer; }
+int trailing_launch(const RiderArgs& r, hipStream_t st) {
+  if (r.kind == RIDER_TWG) return launch_twg_reduce_standalone(r.tw, r.nblocks, st);
+  if (r.kind == RIDER_HEAD) return launch_head_wgrad_standalone(r.hw, st);
+  return RD_OK;
+}
+int trailing_park(const RiderArgs& r, hipStream_t st) {
+  if (g_parked.kind != RIDER_NONE) {                       // nobody picked the previous one up: it runs now, on its own
+    const RiderArgs old = g_parked;
+    g_parked.kind = RIDER_NONE;
+    const int rc = trailing_launch(old, st);
+    if (rc) return rc;
+  }
+  g_parked = r;
+  return RD_OK;
+}
+RiderArgs trailing_take() {
+  RiderArgs r = g_parked;
+  g_parked.kind = RIDER_NONE;
+  return r;
+}
+
 int fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -74,6 +102,12 @@ namespace {
 __global__ void k_seed_advance(uint64_t* cell, uint64_t delta) { *cell += delta; }
 }
 extern "C" int rd_set_seed_cell(const uint64_t* device_cell) { g_seed_cell = device_cell; return RD_OK; }
+extern "C" int rd_set_defer_trailing(int32_t on) { g_defer = on != 0; return RD_OK; }
+extern "C" int rd_flush_trailing(void* stream) {
+  if (g_parked.kind == RIDER_NONE) return RD_OK;
+  const RiderArgs r = trailing_take();
+  return trailing_launch(r, (hipStream_t)stream);
+}
 extern "C" int rd_set_side_stream(void* stream) { g_side = (hipStream_t)stream; g_side_busy = false; return RD_OK; }
 extern "C" int rd_side_join(void* main_stream) { return side_join((hipStream_t)main_stream); }
 extern "C" int rd_seed_cell_advance(uint64_t* device_cell, uint64_t delta, void* stream) {

@@ -25,6 +25,7 @@
 
 #include "rd_common.h"
 #include "rd_rng.h"
+#include "rd_trailing.h"
 
 namespace rd {
 namespace {
@@ -752,9 +753,12 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   EFSTAMP(14);
 }
 
+// Workgroups >= nmain are RIDERS (rd_trailing.h): they run a parked trailing launch -- the head's weight-gradient tiles, the
+// previous layer's slice reduce -- on the CUs this chain leaves idle (178-266 workgroups of one per CU on 256 CUs).
 template <int DC, int HC, bool LEAN>
-__global__ __launch_bounds__(EF_THR) void k_enc_pre_bwd(PreBwdArgs a) {
+__global__ __launch_bounds__(EF_THR) void k_enc_pre_bwd(PreBwdArgs a, RiderArgs rider, int nmain) {
   extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
+  if ((int)blockIdx.x >= nmain) { rider_body(rider, (int)blockIdx.x - nmain, esm); return; }
   int M = a.M;
   if (a.mlive) M = min(M, __builtin_amdgcn_readfirstlane(*a.mlive));
   if (pick_rt(M, a.ncu) == 3) pre_bwd_body<3, DC, HC, LEAN>(a, esm, M);
@@ -848,14 +852,17 @@ int launch_enc_pre_bwd(long M, int D, int H, const float* dy, const float* s2, c
   a.M = (int)M; a.D = D; a.H = H; a.ncu = ef_ncu(); a.p = p; a.seed = seed; a.site_fo = site_fo; a.site_ao = site_ao;
   a.seed_cell = seed_cell(); a.mlive = mlive; a.one = precision() == RD_PREC_BF16; a.stamps = g_ef_stamps;
   constexpr size_t lds = pre_bwd_lds(EF_RTMAX);
+  static_assert(lds >= 4 * HW_GROUP_LDS, "the riders' LDS must fit the chain's");
   const int spec = ef_specialize(D, H);
   a.hgate = (const uint8_t*)hgate;
+  const RiderArgs rider = trailing_take();             // a parked trailing launch (or kind 0) rides in this one
+  const int nmain = cdiv((int)M, 32), grid = nmain + (rider.kind != RIDER_NONE ? rider.nblocks : 0);
 #define RD_PRE_BWD(DCV, HCV)                                                                                        \
   do {                                                                                                              \
     if (hgate) { RD_LDS_ATTR((k_enc_pre_bwd<DCV, HCV, true>), lds);                                                 \
-                 hipLaunchKernelGGL((k_enc_pre_bwd<DCV, HCV, true>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a); }   \
+                 hipLaunchKernelGGL((k_enc_pre_bwd<DCV, HCV, true>), dim3(grid), dim3(EF_THR), lds, st, a, rider, nmain); }   \
     else { RD_LDS_ATTR((k_enc_pre_bwd<DCV, HCV, false>), lds);                                                      \
-           hipLaunchKernelGGL((k_enc_pre_bwd<DCV, HCV, false>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a); } \
+           hipLaunchKernelGGL((k_enc_pre_bwd<DCV, HCV, false>), dim3(grid), dim3(EF_THR), lds, st, a, rider, nmain); } \
   } while (0)
   if (spec == 1) RD_PRE_BWD(152, 272);
   else if (spec == 2) RD_PRE_BWD(160, 288);

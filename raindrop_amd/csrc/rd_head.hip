@@ -20,6 +20,7 @@
 //                 the mean of the per-sample losses -- all fixed-order sums, no atomics.
 #include "rd_common.h"
 #include "rd_plan.h"
+#include "rd_trailing.h"
 
 namespace rd {
 namespace {
@@ -306,54 +307,23 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
   HSTAMP(11);
 }
 
-// dW[n,k] = sum_b u[b,n] v[b,k], db[n] = sum_b u[b,n]: 16 x 16 output tile per workgroup, thread = one output
-struct HwJob { const float* u; const float* v; float *dW, *db; int ldu, ldv, N, K, tiles_k, blk0; };
-struct HwArgs { HwJob j[3]; int n, B; const float* lossr; float* loss; };
-
+// dW[n,k] = sum_b u[b,n] v[b,k], db[n] = sum_b u[b,n]: 16 x 16 output tile per workgroup, thread = one output (rd_trailing.h)
 __global__ __launch_bounds__(256) void k_head_wgrad(HwArgs a) {
   __shared__ float us[256][16], vs[256][17];
-  HwJob J = a.j[0];
-#pragma unroll
-  for (int i = 1; i < 3; ++i)
-    if (i < a.n && (int)blockIdx.x >= a.j[i].blk0) J = a.j[i];
-  const int local = blockIdx.x - J.blk0;
-  const int tn = local / J.tiles_k, tk = local - tn * J.tiles_k;
-  const int tid = threadIdx.x, ni = tid >> 4, ki = tid & 15;
-  const int n = 16 * tn + ni, k = 16 * tk + ki;
-  float acc = 0.f, bacc = 0.f;
-  for (int bb = 0; bb < a.B; bb += 256) {
-    float ur[16], vr[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int e = tid + 256 * i, row = e >> 4, col = e & 15, b = bb + row;
-      ur[i] = 0.f; vr[i] = 0.f;
-      if (b < a.B && 16 * tn + col < J.N) ur[i] = J.u[(long)b * J.ldu + 16 * tn + col];
-      if (b < a.B && 16 * tk + col < J.K) vr[i] = J.v[(long)b * J.ldv + 16 * tk + col];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int e = tid + 256 * i, row = e >> 4, col = e & 15;
-      us[row][col] = ur[i]; vs[row][col] = vr[i];
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (int b = 0; b < 256; ++b) { acc += us[b][ni] * vs[b][ki]; bacc += us[b][ni]; }
-  }
-  if (n < J.N && k < J.K) J.dW[(long)n * J.K + k] = acc;
-  if (tk == 0 && ki == 0 && n < J.N && J.db) J.db[n] = bacc;
-  if (blockIdx.x == 0 && tid < 64) {                  // loss = mean of the per-sample losses (lane-strided, then lanes in order)
-    float s = 0.f;
-    for (int b = tid; b < a.B; b += 64) s += a.lossr[b];
-    s = wsum64(s);
-    if (tid == 0) *a.loss = s / (float)a.B;
-  }
+  head_wgrad_body(a, (int)blockIdx.x, (int)threadIdx.x, us, vs);
 }
 
 }  // namespace
 }  // namespace rd
 
 using namespace rd;
+
+namespace rd {
+int launch_head_wgrad_standalone(const HwArgs& h, hipStream_t st) {
+  hipLaunchKernelGGL(k_head_wgrad, dim3(h.ntiles), dim3(256), 0, st, h);
+  return check_launch("k_head_wgrad");
+}
+}  // namespace rd
 
 extern "C" void rd_debug_set_head_stamps(void* p) { g_head_stamps = (unsigned long long*)p; }   // not part of the ABI
 
@@ -408,8 +378,14 @@ extern "C" int rd_head_train(const rd_shape* s, int32_t D, int32_t d_static, int
   add(a.dhid, dh, dh, a.feat, dh, dh, g_w0, g_b0);                       // d mlp_static[0]
   add(a.dlog, C, C, a.hid, dh, dh, g_w2, g_b2);                          // d mlp_static[2]
   if (Fe) add(a.demb, Fe, Fe, stat, d_static, d_static, g_emb_w, g_emb_b);   // d emb
-  h.n = n;
-  // weight gradients + the loss mean: nothing in the backward chain reads them -> side branch (rd_common.h side_fork)
+  h.n = n; h.ntiles = blk;
+  // weight gradients + the loss mean: nothing in the backward chain reads them.  Deferred mode: parked for the next backward chain
+  // launch's idle workgroups (rd_trailing.h: four tiles per 1024-thread block); else side branch if registered, else here.
+  if (trailing_deferred()) {
+    RiderArgs r{};
+    r.kind = RIDER_HEAD; r.nblocks = cdiv(blk, 4); r.hw = h;
+    return trailing_park(r, st);
+  }
   hipLaunchKernelGGL(k_head_wgrad, dim3(blk), dim3(256), 0, side_fork(st), h);
   return check_launch("k_head_wgrad");
 }

@@ -19,6 +19,7 @@
 // chunk of the slice through a ring of three register buffers; they are summed through LDS in wave order at the end.
 // k_twg_reduce adds the 8 slice partials in slice order (deterministic; no floating-point atomics).
 #include "rd_common.h"
+#include "rd_trailing.h"
 
 namespace rd {
 namespace {
@@ -28,21 +29,6 @@ constexpr int TILE = 512;                          // bf16 elements of one tile 
 constexpr int TW_THR = 256, TW_NA = 5, TW_NB = 6, TW_SLICES = 8;
 constexpr int TW_LDC = 16 * TW_NB + 4;             // fp32 row stride of a wave's block in LDS
 constexpr int TW_LDS = 4 * 16 * TW_NA * TW_LDC * 4;   // 128 KB: the four waves' blocks for the final sum
-
-struct TwProb {
-  const __bf16 *tA, *tB;                           // dY tiles [S][nctA][2][512], X tiles [S][nctB][2][512]
-  float* part;                                     // [TW_SLICES][16 nctA][ldp]
-  float *dW, *db;                                  // [N][K], [N] (db may be null)
-  int nctA, nctB, N, K, nbk, nmem, ldp;
-  int wg0;                                         // first workgroup of the problem in the grid (multiple of 8)
-  int q0, nq;                                      // reduce kernel: first quad-thread group of the problem, count
-  const int32_t* s32x; int Sx;                     // this problem's own chunk count (device / bound) or null: the launch's
-  int hd, hdp, H, D;                               // hd != 0: rows of the A tiles are head-padded ((which, head) blocks of hdp, hd real)
-};
-// column sums riding on the reduce launch: the LayerNorm dgamma | dbeta partials of the layer ([M rows][N], out1 = first n1 sums)
-struct TwColsum { const float* x; int M, N, n1; float *out1, *out2; };
-struct TwArgs { TwProb p[4]; int n, S; const __bf16* ones; TwColsum cs[2]; int ncs, nblk_w;
-                const int32_t* s32; };             // device count of live 32-row chunks (token plan, rd_plan.h: plan[1]) or null
 
 struct Frag { bf16x8 ah[TW_NA], al[TW_NA], bh[TW_NB], bl[TW_NB]; };
 
@@ -160,71 +146,9 @@ __global__ __launch_bounds__(TW_THR) void k_twg(TwArgs a) {
   }
 }
 
-// dW, db = sum over the 8 slices in slice order.  Thread pair (2 lanes) per output quad: lane 0 sums slices 0..3, lane 1
-// slices 4..7, combined in that order.  Workgroups >= nblk_w: column sums (same arithmetic and order as k_colsum_small,
-// rd_gemm.hip: 64 columns x 16 row groups, four interleaved accumulators, fixed-order combine).
-constexpr int TWR_THR = 1024;
 __global__ __launch_bounds__(TWR_THR) void k_twg_reduce(TwArgs a) {
-  if ((int)blockIdx.x >= a.nblk_w) {
-    __shared__ float red[16][64];
-    const int cb = blockIdx.x - a.nblk_w;
-    const int bpj0 = (a.cs[0].N + 63) / 64;
-    const TwColsum J = cb < bpj0 ? a.cs[0] : a.cs[1];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = (cb < bpj0 ? cb : cb - bpj0) * 64 + cl;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (c < J.N) {
-      int r = rg;
-      for (; r + 48 < J.M; r += 64) {
-        s0 += J.x[(long)r * J.N + c]; s1 += J.x[(long)(r + 16) * J.N + c];
-        s2 += J.x[(long)(r + 32) * J.N + c]; s3 += J.x[(long)(r + 48) * J.N + c];
-      }
-      for (; r < J.M; r += 16) s0 += J.x[(long)r * J.N + c];
-    }
-    red[rg][cl] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (rg == 0 && c < J.N) {
-      float v = 0.f;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) v += red[q][cl];
-      if (c < J.n1) J.out1[c] = v; else J.out2[c - J.n1] = v;
-    }
-    return;
-  }
-  const int g = (int)((blockIdx.x * (long)TWR_THR + threadIdx.x) >> 1), half = threadIdx.x & 1;
-  TwProb P = a.p[0];                                // q0 are multiples of 512: a workgroup never straddles two problems
-#pragma unroll
-  for (int i = 1; i < 4; ++i)
-    if (i < a.n && (int)blockIdx.x * (TWR_THR / 2) >= a.p[i].q0) P = a.p[i];
-  const int e = g - P.q0;
-  const bool live = e < P.nq;
-  const int qpr = P.ldp >> 2;
-  const int ec = live ? e : 0;
-  const int n = ec / qpr, k = 4 * (ec - n * qpr);
-  int nr = n;                                       // row of dW / db this partial row belongs to
-  bool rok = true;
-  if (P.hd) {                                       // head-padded rows: (which, head, c) -> which D + head hd + c, c < hd
-    const int blk = P.H * P.hdp, which = n / blk, rem = n - which * blk, hh = rem / P.hdp, c = rem - hh * P.hdp;
-    rok = c < P.hd;
-    nr = which * P.D + hh * P.hd + c;
-  }
-  const bool is_w = rok && k < P.K, is_b = rok && (k == 16 * P.nctB) && P.db != nullptr;
-  const size_t stride = (size_t)16 * P.nctA * P.ldp;
-  const float* p = P.part + (size_t)n * P.ldp + k + (size_t)(4 * half) * stride;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (live && (is_w || is_b)) {
-    float4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)u * stride);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
-  }
-  const float4 r = make_float4(__shfl_down(s.x, 1, 2), __shfl_down(s.y, 1, 2), __shfl_down(s.z, 1, 2), __shfl_down(s.w, 1, 2));
-  if (live && half == 0) {
-    s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
-    if (is_w) *reinterpret_cast<float4*>(P.dW + (size_t)nr * P.K + k) = s;
-    else if (is_b) P.db[nr] = s.x;
-  }
+  __shared__ float red[16][64];
+  twg_reduce_body(a, (int)blockIdx.x, red);
 }
 
 }  // namespace
@@ -281,8 +205,19 @@ int launch_tile_wgrad(long M, int njobs, const TileWgradJob* jobs, const void* o
     a.cs[i].x = cs[i].x; a.cs[i].M = cs[i].M; a.cs[i].N = cs[i].N; a.cs[i].n1 = cs[i].n1; a.cs[i].out1 = cs[i].out1; a.cs[i].out2 = cs[i].out2;
     ncb += cdiv(cs[i].N, 64);
   }
-  // the reduce only produces parameter gradients: it goes to the side branch (rd_common.h side_fork) when one is registered
+  // the reduce only produces parameter gradients.  Deferred mode (rd_set_defer_trailing): it is parked and rides in the next
+  // backward chain launch's idle workgroups (rd_trailing.h); else it goes to the side branch when one is registered, else here.
+  if (trailing_deferred()) {
+    RiderArgs r{};
+    r.kind = RIDER_TWG; r.nblocks = a.nblk_w + ncb; r.tw = a;
+    return trailing_park(r, st);
+  }
   hipLaunchKernelGGL(k_twg_reduce, dim3(a.nblk_w + ncb), dim3(TWR_THR), 0, side_fork(st), a);
+  return check_launch("k_twg_reduce");
+}
+
+int launch_twg_reduce_standalone(const TwArgs& a, int nblocks, hipStream_t st) {
+  hipLaunchKernelGGL(k_twg_reduce, dim3(nblocks), dim3(TWR_THR), 0, st, a);
   return check_launch("k_twg_reduce");
 }
 

@@ -91,6 +91,11 @@ class TrainStep:
         # 0.521 without -- the fourth time a forked graph loses here (the fork / join edges cost more than the 5-8 us launches
         # they take off the chain).  Off by default; RD_SIDE_REDUCE=1 turns it on (results are identical).
         self.side = torch.cuda.Stream(device=self.dev) if os.environ.get("RD_SIDE_REDUCE", "0") == "1" else None
+        # trailing launches (the head's weight-gradient tiles, a layer's slice reduce) parked and appended to the next backward
+        # chain launch as extra workgroups on its idle CUs (include/raindrop_hip.h rd_set_defer_trailing).  Not in the two-graph
+        # data-parallel form: the first gradient bucket's all-reduce starts between the graphs and needs the last layer's reduce
+        # inside the first.  RD_TRAILING_RIDE=0: every launch on its own (A/B).
+        self.ride = (not self.split) and self.side is None and os.environ.get("RD_TRAILING_RIDE", "1") != "0"
         # token plan: the step's fast paths only (fused message passing, row-block encoder, fused head)
         self.plan = None
         if self._want_plan and self.head_fused and self._plan_supported():
@@ -199,6 +204,7 @@ class TrainStep:
         """_body_impl + the join of the side branch: launches forked inside this part (weight-gradient reduces, the head's weight
         gradients: rd_set_side_stream) are complete, in stream order, when the part is."""
         self._body_impl(part)
+        _lib.call("rd_flush_trailing", ops._stream())              # a parked trailing launch nobody picked up (layer 0's reduce)
         _lib.call("rd_side_join", ops._stream())
 
     def _body_impl(self, part=None):
@@ -335,12 +341,14 @@ class TrainStep:
         _lib.call("rd_set_seed_cell", _p(self.seed_cell))
         _lib.call("rd_set_token_plan", _p(self.plan))
         _lib.call("rd_set_side_stream", ctypes.c_void_p(self.side.cuda_stream) if self.side is not None else None)
+        _lib.call("rd_set_defer_trailing", 1 if self.ride else 0)
         try:
             return fn()
         finally:
             _lib.call("rd_set_seed_cell", None)
             _lib.call("rd_set_token_plan", None)
             _lib.call("rd_set_side_stream", None)
+            _lib.call("rd_set_defer_trailing", 0)
 
     def _capture(self):
         """Capture the step as one hipGraph (two in the split form).  With `autotune`, the step is captured once per setting of the
