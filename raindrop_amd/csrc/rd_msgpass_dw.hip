@@ -18,6 +18,7 @@
 // slices: 8 partials per layer (3.9 MB) instead of 32.  k_dw_reduce sums the partials in slice order and also
 // folds the per-sample dR_u partials of the backward kernel.
 #include "rd_common.h"
+#include "rd_trailing.h"
 #include "rd_k1_layout.h"
 #include "rd_plan.h"
 
@@ -170,13 +171,22 @@ struct RedArgs {
   int nblk_dw;
 };
 
-__global__ __launch_bounds__(256) void k_dw_reduce(RedArgs a) {
-  const int tid = threadIdx.x;
-  if ((int)blockIdx.x < a.nblk_dw) {
+// 1024-thread workgroups (round 4): block b < ceil(nblk_dw / 4) = FOUR of the former 256-thread blocks of the slice sum (same
+// thread -> element map, same order: bit-identical), then the dR_u blocks (their first 256 threads), then RIDERS (rd_trailing.h):
+// the parked slice reduce of encoder layer 0's weight-gradient stream, which nothing picked up, runs here instead of as a launch
+// of its own.
+__global__ __launch_bounds__(1024) void k_dw_reduce(RedArgs a, RiderArgs rider, int nmain) {
+  __shared__ float rlds[16][64];
+  if ((int)blockIdx.x >= nmain) { rider_body(rider, (int)blockIdx.x - nmain, reinterpret_cast<unsigned char*>(rlds)); return; }
+  const int nb4 = (a.nblk_dw + 3) >> 2;
+  const int tid = threadIdx.x & 255;
+  const int vblock = (int)blockIdx.x < nb4 ? (int)blockIdx.x * 4 + (int)(threadIdx.x >> 8) : a.nblk_dw + ((int)blockIdx.x - nb4);
+  if ((int)blockIdx.x < nb4) {
+    if (vblock >= a.nblk_dw) return;
     // 4 neighbouring lanes share one output quad: lane p sums slices [p*chunk, (p+1)*chunk) in order, then the four
     // sub-sums are added in lane order (fixed order: deterministic); 4x the loads in flight of one thread per quad
     const int qpr = a.ldp >> 2;
-    const long e = ((long)blockIdx.x * 256 + tid) >> 2;
+    const long e = ((long)vblock * 256 + tid) >> 2;
     const int p4 = tid & 3;
     const bool live = e < (long)2 * a.K * qpr;
     const long ec = live ? e : 0;
@@ -216,12 +226,13 @@ __global__ __launch_bounds__(256) void k_dw_reduce(RedArgs a) {
     }
     return;
   }
-  // ---- dR_u: workgroup handles 32 columns; 8 groups of threads split the samples, combined in fixed order ----
-  __shared__ float red[8][32];
-  const int c0 = ((int)blockIdx.x - a.nblk_dw) * 32;
+  // ---- dR_u: workgroup handles 32 columns; 8 groups of (its first 256) threads split the samples, combined in fixed order ----
+  float (*red)[32] = reinterpret_cast<float (*)[32]>(rlds);
+  const bool act = threadIdx.x < 256;
+  const int c0 = (vblock - a.nblk_dw) * 32;
   const int pgrp = tid >> 5, c = tid & 31;
   float v = 0.f;
-  if (c0 + c < a.Fd) {
+  if (act && c0 + c < a.Fd) {
     const float* rp = a.rupart + c0 + c;
     int b = pgrp;
     for (; b + 56 < a.B; b += 64) {                    // 8 independent loads in flight, added in order
@@ -233,13 +244,13 @@ __global__ __launch_bounds__(256) void k_dw_reduce(RedArgs a) {
     }
     for (; b < a.B; b += 8) v += rp[(size_t)b * a.Fd];
   }
-  red[pgrp][c] = v;
+  if (act) red[pgrp][c] = v;
   __syncthreads();
-  if (tid < 32 && c0 + tid < a.Fd) {
+  if (threadIdx.x < 32 && c0 + (int)threadIdx.x < a.Fd) {
     float s = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) s += red[g][tid];
-    a.dRu[c0 + tid] = s;
+    for (int g = 0; g < 8; ++g) s += red[g][threadIdx.x];
+    a.dRu[c0 + threadIdx.x] = s;
   }
 }
 
@@ -264,7 +275,11 @@ int fused_dw(const k1::Layout& L, const k1::DwPlan& P, const void* tpX, const vo
   r.dW1 = dW1; r.db1 = db1; r.dW2 = dW2; r.db2 = db2;
   r.rupart = rupart; r.dRu = dRu; r.B = L.B; r.Fd = L.F * 4;
   r.nblk_dw = (int)(((long)2 * L.K * (P.ldp >> 2) * 4 + 255) / 256);
-  hipLaunchKernelGGL(k_dw_reduce, dim3(r.nblk_dw + cdiv(r.Fd, 32)), dim3(256), 0, st, r);
+  // a parked slice reduce (encoder layer 0's: rd_trailing.h) rides here; anything else parked runs on its own first
+  RiderArgs rider = trailing_take();
+  if (rider.kind != RIDER_NONE && rider.kind != RIDER_TWG) { if ((rc = trailing_launch(rider, st))) return rc; rider.kind = RIDER_NONE; }
+  const int nmain = cdiv(r.nblk_dw, 4) + cdiv(r.Fd, 32);
+  hipLaunchKernelGGL(k_dw_reduce, dim3(nmain + (rider.kind != RIDER_NONE ? rider.nblocks : 0)), dim3(1024), 0, st, r, rider, nmain);
   return check_launch("k_dw_reduce");
 }
 

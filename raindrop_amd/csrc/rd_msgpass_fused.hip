@@ -941,12 +941,16 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
     const int bytes = dm.q * nct * 2 * TILE * (int)sizeof(__bf16);      // main tiles of this sample: contiguous
     const char* bx = reinterpret_cast<const char*>(tp_tile(const_cast<__bf16*>(a.tpX), nct, sb * dm.q, 0));
     const char* by = reinterpret_cast<const char*>(tp_tile(const_cast<__bf16*>(a.tpY1), nct, sb * dm.q, 0));
+    // The compiler does not know these loads are asynchronous: every destination must be a register NOTHING else writes before the
+    // wave ends (the first version let it recycle one as the next address temporary -- the returning load then corrupted the
+    // address: a memory fault at F = 48).  Eight distinct outputs, kept alive to the end by the empty asm below.
+    float t[8];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int o = min((lane + 64 * u) * 128, max(bytes - 128, 0));
-      float t0, t1;
-      asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "=&v"(t0), "=&v"(t1) : "v"(bx + o), "v"(by + o) : "memory");
+      asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "=&v"(t[2 * u]), "=&v"(t[2 * u + 1]) : "v"(bx + o), "v"(by + o) : "memory");
     }
+    asm volatile("" ::"v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(t[6]), "v"(t[7]));
   }
 }
 

@@ -1,7 +1,7 @@
 #!/bin/bash
-out=$GRAFT_REPO_ROOT/gpurun_out/c13; mkdir -p $out; rm -f $out/ab.txt
+out=$GRAFT_REPO_ROOT/gpurun_out/c15; mkdir -p $out; rm -f $out/ab.txt
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_token_plan_gpu.py tests/test_dp_gpu.py -m gpu -q --maxfail=8 > $out/pytest.log 2>&1; echo "pytest rc=$?" >> $out/rc.txt
+timeout 900 python -m pytest tests -m gpu -q --maxfail=10 > $out/pytest.log 2>&1; echo "pytest rc=$?" >> $out/rc.txt
 tail -4 $out/pytest.log
 export RD_RG_ROWS32=15 RD_RG_WAVES16=12
 run() { env "$@" timeout 120 python tools/step_only.py 300 2>&1 | tail -1 | sed "s/^/$* /" >> $out/ab.txt; }
