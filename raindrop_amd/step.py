@@ -456,6 +456,33 @@ class TrainStep:
         self._with_cell(cap)
         return graphs
 
+    def capture_marked(self, parts=("begin", "k1f", "enc", "head", "encb", "k1b")):
+        """The step as ONE hipGraph with an external timing event recorded in front of every part and behind the last
+        (torch.cuda.Event(enable_timing=True, external=True): event-record NODES of the graph): per-part device times of the real
+        step, without the ~10 us a graph boundary costs per segment.  Returns (graph, events); raises where the runtime cannot
+        capture external event records (callers fall back to capture_segments)."""
+        events = [torch.cuda.Event(enable_timing=True, external=True) for _ in range(len(parts) + 1)]
+        out = []
+
+        def cap():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(2):
+                    for pt in parts:
+                        self._body(pt)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(g):
+                for k, pt in enumerate(parts):
+                    events[k].record()
+                    self._body(pt)
+                events[len(parts)].record()
+            out.append(g)
+        self._with_cell(cap)
+        return out[0], events
+
     # ------------------------------------------------------------------------------------------
     def _early_names(self):
         """Parameters whose gradients the first all-reduce bucket of the split form carries: the last encoder layer's and the
