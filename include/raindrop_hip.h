@@ -384,17 +384,25 @@ int rd_batch_gather(int32_t T, int32_t B, int32_t W, int32_t d_static, int64_t N
  * shared); p_t [T,16] per sample (stride pt_bstride floats, 0 = shared).  Outputs: out [B,N,K]; edge_index_out
  * [B][2,Kk] int64 and alpha_out [B][Kk] (the pruned edges in pruning order and their mean scores: what the reference
  * returns as (self.edge_index, self._alpha)), Kk = rd_graph_beta_kept(E); beta_save [B,N,T] and kept int32 [B,Kk] are
- * handed to the backward.  N <= 64, E <= 4096 (one workgroup per graph, graph staged in LDS); d_ob must be 4. */
+ * handed to the backward.  d_ob must be 4.  Two forms behind the same entry points: graphs with N <= 64 nodes and E <= 4096 edges
+ * whose per-step scores fit one workgroup's LDS run as ONE launch per direction (graph staged in LDS); anything larger, up to
+ * N <= 1024 nodes and 2^28 edges (round 4: SYN256's 256 sensors x 65 536 edges x 512 steps), runs as a sequence of
+ * element-parallel launches with the per-sample state -- sort keys, kept-edge lists by source and by target, softmax statistics
+ * -- in `workspace` (256-byte aligned, rd_graph_beta_workspace_bytes(..) bytes, 0 where the LDS form applies: then the two
+ * workspace arguments are ignored).  Same pruning order (descending score, ties by edge id) and the same order of every sum in
+ * both forms.  The reference has no limit (code/Ob_propagation.py:161-185). */
 int32_t rd_graph_beta_kept(int32_t E);
+size_t rd_graph_beta_workspace_bytes(int32_t B, int32_t N, int32_t K, int32_t T, int32_t E);
 int rd_graph_beta_fwd(int32_t B, int32_t N, int32_t K, int32_t T, int32_t d_ob, int32_t E, const float* V, const float* H,
                       const float* map_weights, const float* p_t, int64_t pt_bstride, const int64_t* edge_index,
                       int64_t row_stride, const float* edge_weights, int64_t w_bstride, float* out, int64_t* edge_index_out,
-                      float* alpha_out, float* beta_save, int32_t* kept, void* stream);
+                      float* alpha_out, float* beta_save, int32_t* kept, void* workspace, size_t workspace_bytes, void* stream);
 /* Backward: dout [B,N,K] -> dV [B,N,K], dH [B,N,T*32], dmap_part [B,N,16] (sum over B = d map_weights), dw [B,E] or NULL. */
 int rd_graph_beta_bwd(int32_t B, int32_t N, int32_t K, int32_t T, int32_t d_ob, int32_t E, const float* V, const float* H,
                       const float* map_weights, const float* p_t, int64_t pt_bstride, const int64_t* edge_index,
                       int64_t row_stride, const float* edge_weights, int64_t w_bstride, const float* beta_save,
-                      const int32_t* kept, const float* dout, float* dV, float* dH, float* dmap_part, float* dw, void* stream);
+                      const int32_t* kept, const float* dout, float* dV, float* dH, float* dmap_part, float* dw, void* workspace,
+                      size_t workspace_bytes, void* stream);
 /* code/models_rd.py:345-346: distance = mean(cdist(alpha_all.T, alpha_all.T, p=2)) for alpha_all [E,B] (one column of edge
  * scores per sample); workspace B floats.  Identically 0 on the shipped path (equal columns); evaluated here in general. */
 int rd_structure_distance(int32_t E, int32_t B, const float* alpha_all, float* workspace, float* distance, void* stream);

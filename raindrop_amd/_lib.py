@@ -101,10 +101,11 @@ SIGNATURES = {
     "rd_head_train": (c_int32, [_SHP, c_int32, c_int32, c_int32, c_int32] + [_P] * 20 + [_P, c_size_t, _P]),
     "rd_batch_gather": (c_int32, [c_int32, c_int32, c_int32, c_int32, ctypes.c_int64] + [_P] * 12),
     "rd_graph_beta_kept": (c_int32, [c_int32]),
+    "rd_graph_beta_workspace_bytes": (c_size_t, [c_int32] * 5),
     "rd_graph_beta_fwd": (c_int32, [c_int32] * 6 + [_P, _P, _P, _P, ctypes.c_int64, _P, ctypes.c_int64, _P, ctypes.c_int64]
-                          + [_P] * 5 + [_P]),
+                          + [_P] * 5 + [_P, c_size_t, _P]),
     "rd_graph_beta_bwd": (c_int32, [c_int32] * 6 + [_P, _P, _P, _P, ctypes.c_int64, _P, ctypes.c_int64, _P, ctypes.c_int64]
-                          + [_P] * 7 + [_P]),
+                          + [_P] * 7 + [_P, c_size_t, _P]),
     "rd_structure_distance": (c_int32, [c_int32, c_int32, _P, _P, _P, _P]),
     "rd_prep_stats_workspace_bytes": (c_size_t, [ctypes.c_int64, c_int32]),
     "rd_prep_stats": (c_int32, [ctypes.c_int64, c_int32, _P, _P, _P, _P, c_size_t, _P]),

@@ -11,7 +11,10 @@
 // Also here: the structure-distance regulariser of code/models_rd.py:345-346, mean pairwise L2 distance between the
 // samples' edge-score vectors (identically 0 on the shipped path, non-trivial as soon as the scores differ per sample).
 // Ties in the pruning sort are broken by edge order (lower edge id first).
+#include <stdlib.h>
+
 #include "rd_common.h"
+#include "rd_graph_beta.h"
 
 namespace rd {
 namespace {
@@ -19,31 +22,6 @@ namespace {
 constexpr int GB_THR = 256;
 constexpr int GB_MAXE = 4096;            // edges per graph held in LDS (N <= 64 nodes)
 constexpr int GB_MAXN = 64;
-
-struct BetaArgs {
-  const float *V, *H;                    // [B,N,K] relu(lin_value(x)),  [B,N,T*32] increase_dim(x)
-  const float *map_w, *p_t;              // [N,16], [B or 1][T,16]
-  const int64_t* ei; int64_t ei_stride;  // edge_index rows (source; target), shared by the batch
-  const float* w; long w_bstride;        // [E] edge weights (per-sample stride, 0 = shared)
-  long pt_bstride;
-  float* out;                            // [B,N,K]
-  int64_t* ei_out; float* alpha_out;     // [B][2,Kk] kept edges in pruning order, [B][Kk] mean kept score
-  float* beta_save;                      // [B,N,T]
-  int32_t* kept;                         // [B][Kk] original edge ids in pruning order (for backward)
-  // backward
-  const float* dout; float *dV, *dH, *dmap_part, *dw;   // dmap_part [B,N,16]; dw [B,E] or null
-  int B, N, K, T, d, E, Kk;
-};
-
-// edge endpoint -> node index that is always legal (raindrop_amd.ops.graph_beta validates the range and raises like the
-// reference's index_select; the kernels must not read out of range whatever they are handed)
-__device__ __forceinline__ int node_of(int64_t v, int N) { return v < 0 ? 0 : (v >= N ? N - 1 : (int)v); }
-
-__device__ __forceinline__ unsigned sortable_desc(float x) {          // larger float -> smaller key
-  unsigned u = __float_as_uint(x);
-  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);                     // ascending order-preserving map
-  return ~u;
-}
 
 // shared LDS layout helpers
 struct Lds {
@@ -323,14 +301,23 @@ __global__ __launch_bounds__(256) void k_distance_reduce(const float* __restrict
   if (threadIdx.x == 0) *out = red[0] / ((float)B * (float)B);
 }
 
-int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+int next_pow2(int x) { return beta_next_pow2(x); }
 
 int check_beta(int B, int N, int K, int T, int d, int E) {
   RD_REQUIRE(B >= 0 && N > 0 && K > 0 && T > 0 && d > 0 && E >= 0, "bad dims");
   RD_REQUIRE(T * d == K, "K (%d) must equal T*d_ob (%d*%d)", K, T, d);
   if (d * 8 != 32) return fail(RD_EUNSUPPORTED, "the beta branch needs d_ob == 4 (increase_dim output viewed as [T, 32], Ob_propagation.py:165)");
-  if (N > GB_MAXN || E > GB_MAXE) return fail(RD_EUNSUPPORTED, "graph too large for the LDS-staged kernel (N <= %d, E <= %d)", GB_MAXN, GB_MAXE);
   return RD_OK;
+}
+
+// RD_BETA_LARGE=1 (tests): the workspace form also for graphs the LDS-staged kernels take.  Read per call.
+bool force_large() { const char* e = getenv("RD_BETA_LARGE"); return e && atoi(e) != 0; }
+// does one workgroup's LDS hold the graph?  (forward: every step's scores + the sort keys; backward: the edge lists + one chunk of steps)
+bool fits_lds(int N, int T, int E, bool bwd) {
+  if (N > GB_MAXN || E > GB_MAXE || force_large()) return false;
+  const int Kk = (int)((double)E * 0.5), Kc = Kk > 0 ? Kk : 1;
+  if (bwd) return lds_bytes(N, bwd_chunk(N, T, Kc), 0, Kc, true) <= 160 * 1024;
+  return lds_bytes(N, T, next_pow2(E > 1 ? E : 2), Kc, false) <= 160 * 1024;
 }
 
 }  // namespace
@@ -340,11 +327,19 @@ using namespace rd;
 
 extern "C" int32_t rd_graph_beta_kept(int32_t E) { return (int32_t)((double)E * 0.5); }      /* K = int(E * 0.5), :180 */
 
+// bytes of workspace rd_graph_beta_fwd / _bwd need for these dimensions: 0 where the LDS-staged kernels take the graph
+extern "C" size_t rd_graph_beta_workspace_bytes(int32_t B, int32_t N, int32_t K, int32_t T, int32_t E) {
+  (void)K;
+  if (B <= 0 || N <= 0 || T <= 0 || E < 0) return 0;
+  if (fits_lds(N, T, E, false) && fits_lds(N, T, E, true)) return 0;
+  return beta_large_ws_bytes(B, N, T, E);
+}
+
 extern "C" int rd_graph_beta_fwd(int32_t B, int32_t N, int32_t K, int32_t T, int32_t d_ob, int32_t E, const float* V,
                                  const float* H, const float* map_weights, const float* p_t, int64_t pt_bstride,
                                  const int64_t* edge_index, int64_t row_stride, const float* edge_weights, int64_t w_bstride,
                                  float* out, int64_t* edge_index_out, float* alpha_out, float* beta_save, int32_t* kept,
-                                 void* stream) {
+                                 void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_beta(B, N, K, T, d_ob, E);
   if (rc) return rc;
   if (B == 0) return RD_OK;
@@ -355,11 +350,9 @@ extern "C" int rd_graph_beta_fwd(int32_t B, int32_t N, int32_t K, int32_t T, int
   a.w = edge_weights; a.w_bstride = w_bstride; a.out = out; a.ei_out = edge_index_out; a.alpha_out = alpha_out;
   a.beta_save = beta_save; a.kept = kept;
   a.B = B; a.N = N; a.K = K; a.T = T; a.d = d_ob; a.E = E; a.Kk = rd_graph_beta_kept(E);
+  if (!fits_lds(N, T, E, false)) return beta_large_fwd(a, workspace, workspace_bytes, (hipStream_t)stream);
   const int P2 = next_pow2(E > 1 ? E : 2);
   const size_t lds = lds_bytes(N, T, P2, a.Kk > 0 ? a.Kk : 1, false);
-  if (lds > 160 * 1024)
-    return fail(RD_EUNSUPPORTED, "rd_graph_beta_fwd: the per-step scores of one graph (3 x N*T floats + the sort keys = %zu bytes) exceed "
-                "the 160 KB of LDS (N=%d, T=%d, E=%d)", lds, N, T, E);
   RD_LDS_ATTR(k_graph_beta_fwd, 160 * 1024);
   hipLaunchKernelGGL(k_graph_beta_fwd, dim3(B), dim3(GB_THR), lds, (hipStream_t)stream, a, P2);
   return check_launch("k_graph_beta_fwd");
@@ -369,7 +362,7 @@ extern "C" int rd_graph_beta_bwd(int32_t B, int32_t N, int32_t K, int32_t T, int
                                  const float* H, const float* map_weights, const float* p_t, int64_t pt_bstride,
                                  const int64_t* edge_index, int64_t row_stride, const float* edge_weights, int64_t w_bstride,
                                  const float* beta_save, const int32_t* kept, const float* dout, float* dV, float* dH,
-                                 float* dmap_part, float* dw, void* stream) {
+                                 float* dmap_part, float* dw, void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_beta(B, N, K, T, d_ob, E);
   if (rc) return rc;
   if (B == 0) return RD_OK;
@@ -380,10 +373,10 @@ extern "C" int rd_graph_beta_bwd(int32_t B, int32_t N, int32_t K, int32_t T, int
   a.w = edge_weights; a.w_bstride = w_bstride; a.beta_save = const_cast<float*>(beta_save); a.kept = const_cast<int32_t*>(kept);
   a.dout = dout; a.dV = dV; a.dH = dH; a.dmap_part = dmap_part; a.dw = dw;
   a.B = B; a.N = N; a.K = K; a.T = T; a.d = d_ob; a.E = E; a.Kk = rd_graph_beta_kept(E);
+  if (!fits_lds(N, T, E, true)) return beta_large_bwd(a, workspace, workspace_bytes, (hipStream_t)stream);
   const int Kc = a.Kk > 0 ? a.Kk : 1;
   const int Tc = bwd_chunk(N, T, Kc);
   const size_t lds = lds_bytes(N, Tc, 0, Kc, true);
-  if (lds > 160 * 1024) return fail(RD_EUNSUPPORTED, "rd_graph_beta_bwd: edge lists do not fit LDS (N=%d, E=%d)", N, E);
   RD_LDS_ATTR(k_graph_beta_bwd, 160 * 1024);
   hipLaunchKernelGGL(k_graph_beta_bwd, dim3(B), dim3(GB_THR), lds, (hipStream_t)stream, a, Tc);
   return check_launch("k_graph_beta_bwd");

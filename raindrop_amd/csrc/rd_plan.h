@@ -51,59 +51,28 @@ __host__ __device__ inline size_t ints(int B, int T) { return (size_t)HDR + 7 * 
 
 
 #if defined(__HIPCC__)
-// LDS ints the plan needs: len [B], cnt [T + 2], within [B], cc [ceil(B / 64)][T + 1]
-__host__ __device__ inline size_t lds_bytes(int B, int T) { return ((size_t)2 * B + T + 2 + (size_t)((B + 63) / 64) * (T + 1)) * sizeof(int); }
+// LDS ints the plan needs: the clamped lengths [B], padded to a multiple of 4 (read back as int4)
+__host__ __device__ inline size_t lds_bytes(int B, int T) { (void)T; return (size_t)((B + 3) / 4 * 4) * sizeof(int); }
 
-// The whole plan by ONE workgroup of any size (a multiple of 64 threads).  rank of b = (samples strictly longer) + (equally long
-// samples with a smaller index): a stable counting sort made of ballots and prefix sums only, so nothing depends on an execution
-// order.  Wave w takes the 64-sample chunks w, w + nw, ..: for every length value v one ballot gives the chunk's count of v and,
-// by the lower-lane bits, every member's position among the chunk's v's; the chunk counts are prefix-summed over the chunks per v
-// (thread per v).  Also bumps the dropout seed cell (one launch fewer per step).
+// The whole plan by ONE workgroup of any size.  rank of b = (samples strictly longer) + (equally long samples with a smaller
+// index): every thread counts that for its own sample in ONE pass over the lengths (LDS broadcast reads, four per request), and
+// the same pass sums the lengths and the 16-row groups of the samples in front of it -- its first row and first group.  Nothing
+// depends on an execution order, and after the one barrier behind the length load no phase waits for another (round 4: the
+// ballot / prefix-sum / suffix-sum form this replaces had four barriers and three 60-step dependent loops behind them; it was
+// the critical path of the step's first launch).  Also bumps the dropout seed cell (one launch fewer per step).
 __device__ inline void token_plan_body(const int64_t* __restrict__ lengths, int32_t* __restrict__ p, int B, int T, uint64_t* seed_cell,
                                        uint64_t delta, int* psm) {
-  const int nthr = blockDim.x, nw = nthr >> 6;
-  const int nchunk = (B + 63) >> 6, T1 = T + 1;
-  int* len = psm;                 // [B]
-  int* cnt = psm + B;             // [T + 2]: histogram, then cnt[t] = #(len > t)
-  int* within = cnt + T + 2;      // [B]: equally long samples with a smaller index inside the same chunk
-  int* cc = within + B;           // [nchunk][T + 1]: count of v in chunk, then in the chunks before it
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int b = tid; b < B; b += nthr) {
-    const int64_t l = lengths[b];
-    len[b] = (int)(l < 0 ? 0 : (l > T ? T : l));
+  const int nthr = blockDim.x, tid = threadIdx.x;
+  const int B4 = (B + 3) >> 2;
+  int* len = psm;                 // [4 B4], entries >= B hold -1 (shorter than everything, counted by nobody)
+  for (int b = tid; b < 4 * B4; b += nthr) {
+    int l = -1;
+    if (b < B) { const int64_t v = lengths[b]; l = (int)(v < 0 ? 0 : (v > T ? T : v)); }
+    len[b] = l;
   }
-  __syncthreads();
-  for (int ch = wave; ch < nchunk; ch += nw) {
-    const int b = ch * 64 + lane;
-    const int l = b < B ? len[b] : -1;
-    int sl = 0;
-    for (int v = 0; v <= T; ++v) {
-      const unsigned long long m = __ballot(l == v);
-      if (l == v) sl = __popcll(m & ((1ull << lane) - 1ull));
-      if (lane == 0) cc[ch * T1 + v] = __popcll(m);
-    }
-    if (b < B) within[b] = sl;
-  }
-  __syncthreads();
-  for (int v = tid; v <= T; v += nthr) {
-    int run = 0;
-    for (int ch = 0; ch < nchunk; ++ch) { const int t = cc[ch * T1 + v]; cc[ch * T1 + v] = run; run += t; }
-    cnt[v] = run;
-  }
-  __syncthreads();
-  // cnt[t] = number of samples with len > t  (T + 1 entries, cnt[T] = 0): exclusive suffix sum of the histogram
-  if (wave == 0) {
-    if (T1 <= 64) {
-      const int h = lane <= T ? cnt[lane] : 0;
-      int sfx = h;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_down(sfx, o); if (lane + o < 64) sfx += v; }
-      if (lane <= T) cnt[lane] = sfx - h;
-    } else if (lane == 0) {
-      int above = 0;
-      for (int t = T; t >= 0; --t) { const int h = cnt[t]; cnt[t] = above; above += h; }
-    }
-    if (lane == 0 && seed_cell) *seed_cell += delta;
+  if (tid == 0) {
+    p[plan::I_B] = B; p[plan::I_T] = T; p[plan::I_SLACK] = 0; p[6] = 0; p[7] = 0;
+    if (seed_cell) *seed_cell += delta;
   }
   __syncthreads();
   int* off = p + plan::off_base();
@@ -111,31 +80,41 @@ __device__ inline void token_plan_body(const int64_t* __restrict__ lengths, int3
   int* order = p + plan::order_base(B);
   int* lenr = p + plan::len_base(B);
   int* cntg = p + plan::cnt_base(B);
+  int* coff = p + plan::coff_base(B, T);
+  const int4* len4 = reinterpret_cast<const int4*>(len);
   for (int b = tid; b < B; b += nthr) {
     const int l = len[b];
-    const int r = cnt[l] + cc[(b >> 6) * T1 + l] + within[b];
+    int r = 0, row = 0, grp = 0;
+    for (int q = 0; q < B4; ++q) {
+      const int4 v = len4[q];
+      const int lv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int o = 4 * q + c;
+        const bool before = lv[c] > l || (lv[c] == l && o < b);
+        r += before ? 1 : 0;
+        row += before ? lv[c] : 0;
+        grp += before ? (lv[c] + 15) >> 4 : 0;
+      }
+    }
     rank[b] = r; order[r] = b; lenr[r] = l;
-    int s = 0;                                             // off[r], per sample (the off[] loop below recomputes it per rank)
-    for (int t = 0; t < T; ++t) s += min(r, cnt[t]);
-    p[plan::brow_base(B, T) + b] = s; p[plan::blen_base(B, T) + b] = l;
+    off[r] = row; coff[r] = grp;                 // first row / first 16-row group of rank r = sums over the r samples in front
+    p[plan::brow_base(B, T) + b] = row; p[plan::blen_base(B, T) + b] = l;
+    if (r == B - 1) {                            // the last rank closes both prefix arrays
+      const int m = row + l, g = grp + ((l + 15) >> 4);
+      off[B] = m; coff[B] = g;
+      p[plan::I_MLIVE] = m; p[plan::I_S32] = (m + 31) >> 5; p[plan::I_SCHUNK] = (g + 1) >> 1;
+    }
   }
-  // off[r] = sum of the r longest lengths = sum_t min(r, cnt[t])   (the samples with len > t are the first cnt[t] ranks)
-  for (int r = tid; r <= B; r += nthr) {
-    int s = 0;
-    for (int t = 0; t < T; ++t) s += min(r, cnt[t]);
-    off[r] = s;
-    if (r == B) { p[plan::I_MLIVE] = s; p[plan::I_S32] = (s + 31) >> 5; }
+  // cnt[t] = number of samples with len > t  (T + 1 entries, cnt[T] = 0)
+  for (int t = tid; t <= T; t += nthr) {
+    int c = 0;
+    for (int q = 0; q < B4; ++q) {
+      const int4 v = len4[q];
+      c += (v.x > t ? 1 : 0) + (v.y > t ? 1 : 0) + (v.z > t ? 1 : 0) + (v.w > t ? 1 : 0);
+    }
+    cntg[t] = c;
   }
-  for (int t = tid; t <= T; t += nthr) cntg[t] = cnt[t];
-  // coff[r] = sum over the r longest samples of ceil(len / 16) = sum_g min(r, cnt[16 g])   (a sample has a group g iff len > 16 g)
-  int* coff = p + plan::coff_base(B, T);
-  for (int r = tid; r <= B; r += nthr) {
-    int s = 0;
-    for (int t = 0; t < T; t += 16) s += min(r, cnt[t]);
-    coff[r] = s;
-    if (r == B) p[plan::I_SCHUNK] = (s + 1) >> 1;
-  }
-  if (tid == 0) { p[plan::I_B] = B; p[plan::I_T] = T; p[plan::I_SLACK] = 0; p[6] = 0; p[7] = 0; }
 }
 #endif
 

@@ -18,7 +18,7 @@ constexpr int PL_THR = 1024;
 // One workgroup; the body is rd_plan.h's token_plan_body (shared with the step's combined first launch, rd_step_begin).
 __global__ __launch_bounds__(PL_THR) void k_token_plan(const int64_t* __restrict__ lengths, int32_t* __restrict__ p, int B, int T,
                                                       uint64_t* seed_cell, uint64_t delta) {
-  extern __shared__ int psm[];
+  extern __shared__ __attribute__((aligned(16))) int psm[];
   plan::token_plan_body(lengths, p, B, T, seed_cell, delta, psm);
 }
 

@@ -72,16 +72,20 @@ struct SplitJobs { SplitJob j[WS_MAXJOBS]; int n; __bf16* ones[WS_MAXONES];   //
 // base of the tile array, `lo` is unused (kept for the job layout).  One workgroup row per job; a wave converts one
 // (ntile, kc) tile per iteration.
 __global__ __launch_bounds__(256) void k_wsplit(SplitJobs jobs) {
-  if ((int)blockIdx.y == jobs.n) {                  // the extra block row of rd_step_begin: lengths -> token plan (+ seed bump)
-    extern __shared__ int wsm_plan[];
+  // rd_step_begin: block row 0 is the token plan (+ seed bump), ONE workgroup.  It is the longest chain of the launch, so it has to
+  // be dispatched FIRST: as the last block row (rounds 3-4) it started behind ~2600 split workgroups and the launch took the SUM
+  // of both (16-18 us on a slow box for a 10-us plan and 6 us of splits).
+  const int job = jobs.plan_out ? (int)blockIdx.y - 1 : (int)blockIdx.y;
+  if (job < 0) {
+    extern __shared__ __attribute__((aligned(16))) int wsm_plan[];
     if (blockIdx.x == 0) plan::token_plan_body(jobs.plan_lengths, jobs.plan_out, jobs.plan_B, jobs.plan_T, jobs.seed_cell, jobs.seed_delta, wsm_plan);
     return;
   }
-  const SplitJob jb = jobs.j[blockIdx.y];
+  const SplitJob jb = jobs.j[job];
   const int ntile = jb.rows >> 4, nkc = jb.cols_p >> 5;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, G = lane >> 4;
   const int src_rows = jb.transpose ? jb.K : jb.N, src_cols = jb.transpose ? jb.N : jb.K;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && wave < WS_MAXONES && jobs.ones[wave]) {
+  if (blockIdx.x == 0 && job == 0 && wave < WS_MAXONES && jobs.ones[wave]) {
     // [ones hi: column 0 = 1][zeros][zeros] (rd_tile_wgrad.hip: the B operand whose output column is the bias gradient)
     bf16x8 o, z;
 #pragma unroll

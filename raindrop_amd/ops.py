@@ -402,9 +402,10 @@ class _GraphBeta(torch.autograd.Function):
         kept = torch.empty((B, max(Kk, 1)), dtype=torch.int32, device=dev)
         pts = 0 if p_t.shape[0] == 1 else T * 16
         ws = 0 if edge_weights.shape[0] == 1 else E
+        scratch = _workspace(lib.rd_graph_beta_workspace_bytes(B, N, K, T, E), dev)     # 0 bytes where the graph fits LDS
         _lib.call("rd_graph_beta_fwd", B, N, K, T, d_ob, E, _ptr(V), _ptr(H), _ptr(map_w), _ptr(p_t), pts, _ptr(edge_index),
                   edge_index.stride(0), _ptr(edge_weights), ws, _ptr(out), _ptr(ei_out), _ptr(alpha), _ptr(beta), _ptr(kept),
-                  _stream())
+                  _ptr(scratch), scratch.numel(), _stream())
         ctx.save_for_backward(V, H, map_w, p_t, edge_index, edge_weights, beta, kept)
         ctx.dims = (B, N, K, T, d_ob, E, pts, ws)
         ctx.mark_non_differentiable(ei_out, alpha)
@@ -419,9 +420,10 @@ class _GraphBeta(torch.autograd.Function):
         dmap_part = torch.empty((B, N, 16), dtype=torch.float32, device=V.device)
         want_dw = ctx.needs_input_grad[5]
         dw = torch.empty((B, E), dtype=torch.float32, device=V.device) if want_dw else None
+        scratch = _workspace(_lib.load().rd_graph_beta_workspace_bytes(B, N, K, T, E), V.device)
         _lib.call("rd_graph_beta_bwd", B, N, K, T, d_ob, E, _ptr(V), _ptr(H), _ptr(map_w), _ptr(p_t), pts, _ptr(edge_index),
                   edge_index.stride(0), _ptr(edge_weights), ws, _ptr(beta), _ptr(kept), _ptr(dout), _ptr(dV), _ptr(dH),
-                  _ptr(dmap_part), _ptr(dw), _stream())
+                  _ptr(dmap_part), _ptr(dw), _ptr(scratch), scratch.numel(), _stream())
         dmap = dmap_part[0] if B == 1 else _colsum_rows(dmap_part.view(B, N * 16)).view(N, 16)
         if want_dw and edge_weights.shape[0] == 1 and B > 1:
             dw = _colsum_rows(dw).view(1, E)

@@ -243,6 +243,59 @@ def beta_batched_case():
     print("beta_batched -> %s (%.1f KB), distance %.6f" % (os.path.basename(path), os.path.getsize(path) / 1024, dist.item()))
 
 
+def beta_large_case():
+    """The use_beta operator on a graph that does not fit one workgroup's LDS -- 256 nodes (SYN256's sensor count), ~19.6 k edges
+    (sparse random structure with distinct weights: no pruning ties), T = 6 steps -- by the REFERENCE class, per sample:
+    outputs, pruned edge lists, returned scores, gradients of <y, R>.  Exercises the workspace form of rd_graph_beta_fwd / _bwd
+    (rd_graph_beta_large.hip): a 32 768-key sort in 4096-key chunks, per-node lists over 9.8 k kept edges."""
+    ref = ref_loader.load()
+    n, T, d, B = 256, 6, 4, 2
+    K = T * d
+    op = ref.run(ref.Ob_propagation.Observation_progation, in_channels=K, out_channels=K, heads=1, n_nodes=n, ob_dim=d)
+    synth.fill_params_(op, seed=31)
+    # ~13 k float32 scores collide now and then, and the reference's argsort (unstable) orders tied edges arbitrarily: take the
+    # first seed of a fixed list whose scores are all distinct, so that the pruned edge LIST is reproducible bit for bit
+    for seed in range(654, 700):
+        rng = np.random.default_rng(seed)
+        adj = (rng.uniform(0.5, 1.5, (n, n)) * (rng.random((n, n)) < 0.2)).astype(np.float32)
+        ei, ew = O2.build_graph(adj)
+        X = torch.from_numpy((rng.standard_normal((B, n, K)) * 0.5).astype(np.float32)).requires_grad_(True)
+        PT = torch.from_numpy(rng.standard_normal((B, T, 16)).astype(np.float32))
+        R = torch.from_numpy(rng.standard_normal((B, n, K)).astype(np.float32))
+        ys, eis, alphas = [], [], []
+        for b in range(B):
+            y, (ei_b, a_b) = ref.run(op.forward, X[b], p_t=PT[b], edge_index=torch.from_numpy(ei), edge_weights=torch.from_numpy(ew),
+                                     use_beta=True, edge_attr=None, return_attention_weights=True)
+            ys.append(y); eis.append(ei_b); alphas.append(a_b)
+        # ties anywhere in the FULL score list matter (a tie across the pruning boundary changes the kept set): recompute them all
+        full = [O2.beta_edge_scores(X[b].detach(), PT[b], torch.from_numpy(ei), torch.from_numpy(ew), op.increase_dim.weight.detach(),
+                                    op.increase_dim.bias.detach(), op.map_weights.detach(), d).numpy() for b in range(B)]
+        if all(np.unique(f).size == f.size for f in full):
+            break
+        print("  seed %d: tied scores, next" % seed)
+    else:
+        raise SystemExit("beta_large: no tie-free seed")
+    Y = torch.stack(ys)
+    params = [op.lin_value.weight, op.lin_value.bias, op.increase_dim.weight, op.increase_dim.bias, op.map_weights]
+    grads = torch.autograd.grad((Y * R).sum(), [X] + params)
+    for b in range(B):
+        a = alphas[b].detach().numpy().ravel()
+        assert np.all(np.diff(a) < 0), "tied scores: the reference's argsort order would not be reproducible"
+        y2, (ei2, a2) = O2.observation_propagation_beta(X[b].detach(), PT[b], torch.from_numpy(ei), torch.from_numpy(ew),
+                                                        op.lin_value.weight.detach(), op.lin_value.bias.detach(),
+                                                        op.increase_dim.weight.detach(), op.increase_dim.bias.detach(),
+                                                        op.map_weights.detach(), d)
+        assert float((y2 - ys[b].detach()).abs().max()) < 1e-5 and torch.equal(ei2, eis[b])
+    out = dict(adj=adj, X=X.detach().numpy(), PT=PT.numpy(), R=R.numpy(), Y=Y.detach().numpy(),
+               ei=torch.stack(eis).numpy().astype(np.int32), alpha=torch.stack([a.detach() for a in alphas]).numpy(),
+               gX=grads[0].numpy(), gWv=grads[1].numpy(), gbv=grads[2].numpy(), gWi=grads[3].numpy(), gbi=grads[4].numpy(),
+               gmap=grads[5].numpy(), dims=np.array([n, T, d, B]))
+    path = os.path.join(HERE, "beta_large.npz")
+    np.savez_compressed(path, **out)
+    print("beta_large   -> %s (%.1f KB), E = %d, kept %d" % (os.path.basename(path), os.path.getsize(path) / 1024, ei.shape[1],
+                                                            eis[0].shape[1]))
+
+
 def legacy_v1_case():
     """The legacy `Raindrop` class (code/models_rd.py:46-191; exported by `from models_rd import *`, never built by the script),
     run by the reference itself at the only shape its forward admits (215 steps, 36 sensors hard-coded at :150,:155):
@@ -307,6 +360,8 @@ if __name__ == "__main__":
         state_dict_surface()
     if not only or "beta_batched" in only:
         beta_batched_case()
+    if not only or "beta_large" in only:
+        beta_large_case()
     if not only or "legacy_v1" in only:
         legacy_v1_case()
     for case in MODEL_CASES:

@@ -107,3 +107,28 @@ def test_operator_goldens():
                                  t(g["tc_ws"]), t(g["tc_bs"]))
     assert np.abs(y2.numpy() - g["tc_y"]).max() < 1e-6
     assert np.abs(a2.numpy() - g["tc_alpha"]).max() < 1e-7
+
+
+def test_large_graph_beta_golden():
+    """O2's use_beta operator against the reference's outputs on the 256-node, 13 k-edge fixture (tests/golden/beta_large.npz:
+    the graph size the workspace form of rd_graph_beta_fwd exists for); scores are distinct by construction of the fixture, so
+    the pruned edge list is reproducible bit for bit."""
+    import os
+    from raindrop_amd import synth
+    from raindrop_amd.Ob_propagation import Observation_progation
+    from tests.helpers import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "beta_large.npz"))
+    n, T, d, B = (int(v) for v in g["dims"])
+    K = T * d
+    op = Observation_progation(K, K, n_nodes=n, ob_dim=d, heads=1)
+    synth.fill_params_(op, seed=31)
+    t = torch.from_numpy
+    ei, ew = O2.build_graph(g["adj"])
+    assert ei.shape[1] > 8192 and n > 64                                         # beyond the LDS-staged kernels' envelope
+    for b in range(B):
+        y, (ei2, a2) = O2.observation_propagation_beta(t(g["X"][b]), t(g["PT"][b]), t(ei), t(ew), op.lin_value.weight.detach(),
+                                                       op.lin_value.bias.detach(), op.increase_dim.weight.detach(),
+                                                       op.increase_dim.bias.detach(), op.map_weights.detach(), d)
+        assert np.array_equal(ei2.numpy(), g["ei"][b])
+        assert np.abs(a2.numpy().ravel() - g["alpha"][b].ravel()).max() < 1e-7
+        assert np.abs(y.numpy() - g["Y"][b]).max() < 1e-5
