@@ -51,18 +51,31 @@ __host__ __device__ inline size_t ints(int B, int T) { return (size_t)HDR + 7 * 
 
 
 #if defined(__HIPCC__)
-// LDS ints the plan needs: the clamped lengths [B], padded to a multiple of 4 (read back as int4)
+// LDS ints a plan workgroup needs: the clamped lengths [B], padded to a multiple of 4
 __host__ __device__ inline size_t lds_bytes(int B, int T) { (void)T; return (size_t)((B + 3) / 4 * 4) * sizeof(int); }
 
-// The whole plan by ONE workgroup of any size.  rank of b = (samples strictly longer) + (equally long samples with a smaller
-// index): every thread counts that for its own sample in ONE pass over the lengths (LDS broadcast reads, four per request), and
-// the same pass sums the lengths and the 16-row groups of the samples in front of it -- its first row and first group.  Nothing
-// depends on an execution order, and after the one barrier behind the length load no phase waits for another (round 4: the
-// ballot / prefix-sum / suffix-sum form this replaces had four barriers and three 60-step dependent loops behind them; it was
-// the critical path of the step's first launch).  Also bumps the dropout seed cell (one launch fewer per step).
-__device__ inline void token_plan_body(const int64_t* __restrict__ lengths, int32_t* __restrict__ p, int B, int T, uint64_t* seed_cell,
-                                       uint64_t delta, int* psm) {
-  const int nthr = blockDim.x, tid = threadIdx.x;
+// integer sum over the 64 lanes of a wave on the DPP path (rd_common.h's wave_sum64_dpp for ints), result uniform
+__device__ __forceinline__ int wave_isum64(int v) {
+#define RD_DPP_IADD(ctrl, rmask) v += __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false)
+  RD_DPP_IADD(0x111, 0xf); RD_DPP_IADD(0x112, 0xf); RD_DPP_IADD(0x114, 0xf); RD_DPP_IADD(0x118, 0xf);
+  RD_DPP_IADD(0x142, 0xa); RD_DPP_IADD(0x143, 0xc);
+#undef RD_DPP_IADD
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// The plan, by `nparts` workgroups of any size (a multiple of 64 threads) that do not talk to each other: every output is a
+// function of the length vector alone.  rank of b = (samples strictly longer) + (equally long samples with a smaller index);
+// a WAVE counts that for one sample -- lanes stride over the other samples, three DPP sums -- and the same pass sums the lengths
+// and the 16-row groups of the samples in front of it: its first row and first group.  Part `part` takes the samples (and, for
+// cnt[], the steps) part * waves + wave, + nparts * waves, ...  Nothing depends on an execution order.
+// (Round 4.  Rounds 3's form -- one workgroup, ballots over the T + 1 length values, prefix and suffix sums behind four barriers,
+// three 60-step dependent loops -- took ~10 us and was the critical path of the step's first launch; the first rewrite, one THREAD
+// per sample scanning all B lengths, was 14 instructions x B per thread and no faster.)
+// Part 0 also writes the header and bumps the dropout seed cell (one launch fewer per step).
+__device__ inline void token_plan_part(const int64_t* __restrict__ lengths, int32_t* __restrict__ p, int B, int T, uint64_t* seed_cell,
+                                       uint64_t delta, int* psm, int part, int nparts) {
+  const int nthr = blockDim.x, tid = threadIdx.x, lane = tid & 63, nw = nthr >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int B4 = (B + 3) >> 2;
   int* len = psm;                 // [4 B4], entries >= B hold -1 (shorter than everything, counted by nobody)
   for (int b = tid; b < 4 * B4; b += nthr) {
@@ -70,7 +83,7 @@ __device__ inline void token_plan_body(const int64_t* __restrict__ lengths, int3
     if (b < B) { const int64_t v = lengths[b]; l = (int)(v < 0 ? 0 : (v > T ? T : v)); }
     len[b] = l;
   }
-  if (tid == 0) {
+  if (part == 0 && tid == 0) {
     p[plan::I_B] = B; p[plan::I_T] = T; p[plan::I_SLACK] = 0; p[6] = 0; p[7] = 0;
     if (seed_cell) *seed_cell += delta;
   }
@@ -81,39 +94,34 @@ __device__ inline void token_plan_body(const int64_t* __restrict__ lengths, int3
   int* lenr = p + plan::len_base(B);
   int* cntg = p + plan::cnt_base(B);
   int* coff = p + plan::coff_base(B, T);
-  const int4* len4 = reinterpret_cast<const int4*>(len);
-  for (int b = tid; b < B; b += nthr) {
+  for (int b = part * nw + wave; b < B; b += nparts * nw) {       // wave-uniform
     const int l = len[b];
     int r = 0, row = 0, grp = 0;
-    for (int q = 0; q < B4; ++q) {
-      const int4 v = len4[q];
-      const int lv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int o = 4 * q + c;
-        const bool before = lv[c] > l || (lv[c] == l && o < b);
-        r += before ? 1 : 0;
-        row += before ? lv[c] : 0;
-        grp += before ? (lv[c] + 15) >> 4 : 0;
-      }
+    for (int o = lane; o < 4 * B4; o += 64) {
+      const int lv = len[o];
+      const bool before = lv > l || (lv == l && o < b);
+      r += before ? 1 : 0;
+      row += before ? lv : 0;
+      grp += before ? (lv + 15) >> 4 : 0;
     }
-    rank[b] = r; order[r] = b; lenr[r] = l;
-    off[r] = row; coff[r] = grp;                 // first row / first 16-row group of rank r = sums over the r samples in front
-    p[plan::brow_base(B, T) + b] = row; p[plan::blen_base(B, T) + b] = l;
-    if (r == B - 1) {                            // the last rank closes both prefix arrays
-      const int m = row + l, g = grp + ((l + 15) >> 4);
-      off[B] = m; coff[B] = g;
-      p[plan::I_MLIVE] = m; p[plan::I_S32] = (m + 31) >> 5; p[plan::I_SCHUNK] = (g + 1) >> 1;
+    r = wave_isum64(r); row = wave_isum64(row); grp = wave_isum64(grp);
+    if (lane == 0) {
+      rank[b] = r; order[r] = b; lenr[r] = l;
+      off[r] = row; coff[r] = grp;               // first row / first 16-row group of rank r = sums over the r samples in front
+      p[plan::brow_base(B, T) + b] = row; p[plan::blen_base(B, T) + b] = l;
+      if (r == B - 1) {                          // the last rank closes both prefix arrays
+        const int m = row + l, g = grp + ((l + 15) >> 4);
+        off[B] = m; coff[B] = g;
+        p[plan::I_MLIVE] = m; p[plan::I_S32] = (m + 31) >> 5; p[plan::I_SCHUNK] = (g + 1) >> 1;
+      }
     }
   }
   // cnt[t] = number of samples with len > t  (T + 1 entries, cnt[T] = 0)
-  for (int t = tid; t <= T; t += nthr) {
+  for (int t = part * nw + wave; t <= T; t += nparts * nw) {
     int c = 0;
-    for (int q = 0; q < B4; ++q) {
-      const int4 v = len4[q];
-      c += (v.x > t ? 1 : 0) + (v.y > t ? 1 : 0) + (v.z > t ? 1 : 0) + (v.w > t ? 1 : 0);
-    }
-    cntg[t] = c;
+    for (int o = lane; o < 4 * B4; o += 64) c += len[o] > t ? 1 : 0;
+    c = wave_isum64(c);
+    if (lane == 0) cntg[t] = c;
   }
 }
 #endif

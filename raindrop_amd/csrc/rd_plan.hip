@@ -15,11 +15,12 @@ namespace {
 
 constexpr int PL_THR = 1024;
 
-// One workgroup; the body is rd_plan.h's token_plan_body (shared with the step's combined first launch, rd_step_begin).
+// PL_PARTS independent workgroups; the body is rd_plan.h's token_plan_part (shared with the step's combined first launch, rd_step_begin).
+constexpr int PL_PARTS = 16;
 __global__ __launch_bounds__(PL_THR) void k_token_plan(const int64_t* __restrict__ lengths, int32_t* __restrict__ p, int B, int T,
                                                       uint64_t* seed_cell, uint64_t delta) {
   extern __shared__ __attribute__((aligned(16))) int psm[];
-  plan::token_plan_body(lengths, p, B, T, seed_cell, delta, psm);
+  plan::token_plan_part(lengths, p, B, T, seed_cell, delta, psm, blockIdx.x, gridDim.x);
 }
 
 }  // namespace
@@ -38,7 +39,7 @@ extern "C" int rd_token_plan(const rd_shape* s, const int64_t* lengths, int32_t*
   RD_REQUIRE(lengths && plan_out, "NULL tensor");
   const size_t lds = plan::lds_bytes(s->B, s->T);
   RD_REQUIRE(lds <= 64 * 1024, "rd_token_plan: B x T too large for one workgroup (%d, %d)", s->B, s->T);
-  hipLaunchKernelGGL(k_token_plan, dim3(1), dim3(PL_THR), lds, (hipStream_t)stream, lengths, plan_out, s->B, s->T, seed_cell, delta);
+  hipLaunchKernelGGL(k_token_plan, dim3(PL_PARTS), dim3(PL_THR), lds, (hipStream_t)stream, lengths, plan_out, s->B, s->T, seed_cell, delta);
   return check_launch("k_token_plan");
 }
 

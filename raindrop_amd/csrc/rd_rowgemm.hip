@@ -65,20 +65,20 @@ struct SplitJob { const float* W; int N, K, transpose; __bf16* hi; __bf16* lo; i
 constexpr int WS_MAXJOBS = 48, WS_MAXONES = 4;
 struct SplitJobs { SplitJob j[WS_MAXJOBS]; int n; __bf16* ones[WS_MAXONES];   // ones: constant tiles of the weight-gradient streams (or null)
                    // optional: the step's token plan (rd_plan.h) by the workgroup (0, n) of the same launch (rd_step_begin)
-                   const int64_t* plan_lengths; int32_t* plan_out; int plan_B, plan_T; uint64_t* seed_cell; uint64_t seed_delta; };
+                   const int64_t* plan_lengths; int32_t* plan_out; int plan_B, plan_T, plan_first; uint64_t* seed_cell; uint64_t seed_delta; };
 
 // Output: NATIVE MFMA operand tiles [ntile = rows/16][kc = cols_p/32][hi, lo][64 lanes][8] (one contiguous kilobyte per
 // wave-load; rd_k1_layout.h has the measurement: 61 B/clk/CU against 16 B/clk for a row-major plane).  `hi` is the
 // base of the tile array, `lo` is unused (kept for the job layout).  One workgroup row per job; a wave converts one
 // (ntile, kc) tile per iteration.
 __global__ __launch_bounds__(256) void k_wsplit(SplitJobs jobs) {
-  // rd_step_begin: block row 0 is the token plan (+ seed bump), ONE workgroup.  It is the longest chain of the launch, so it has to
-  // be dispatched FIRST: as the last block row (rounds 3-4) it started behind ~2600 split workgroups and the launch took the SUM
-  // of both (16-18 us on a slow box for a 10-us plan and 6 us of splits).
-  const int job = jobs.plan_out ? (int)blockIdx.y - 1 : (int)blockIdx.y;
-  if (job < 0) {
+  // rd_step_begin: one block row is the token plan (+ seed bump): its workgroups each take a share of the samples
+  // (rd_plan.h: token_plan_part).  First row by default (RD_PLAN_FIRST=0: last, as in rounds 3-4 when the plan was ONE
+  // workgroup's ~10-us chain that started behind ~2600 split workgroups: the launch took the sum of both).
+  const int job = (jobs.plan_out && jobs.plan_first) ? (int)blockIdx.y - 1 : (int)blockIdx.y;
+  if (job < 0 || job == jobs.n) {
     extern __shared__ __attribute__((aligned(16))) int wsm_plan[];
-    if (blockIdx.x == 0) plan::token_plan_body(jobs.plan_lengths, jobs.plan_out, jobs.plan_B, jobs.plan_T, jobs.seed_cell, jobs.seed_delta, wsm_plan);
+    plan::token_plan_part(jobs.plan_lengths, jobs.plan_out, jobs.plan_B, jobs.plan_T, jobs.seed_cell, jobs.seed_delta, wsm_plan, blockIdx.x, gridDim.x);
     return;
   }
   const SplitJob jb = jobs.j[job];
@@ -495,6 +495,8 @@ int launch_wsplit_plan(int njobs, const WsplitSpec* specs, int nones, void* cons
   if (njobs < 1 || njobs > WS_MAXJOBS || nones < 0 || nones > WS_MAXONES) return fail(RD_EINVAL, "wsplit: %d jobs, %d constant tiles", njobs, nones);
   SplitJobs jobs{};
   jobs.n = njobs;
+  static const int plan_first = [] { const char* e = getenv("RD_PLAN_FIRST"); return !(e && atoi(e) == 0); }();
+  jobs.plan_first = plan_first;
   jobs.plan_lengths = lengths; jobs.plan_out = plan_out; jobs.plan_B = B; jobs.plan_T = T; jobs.seed_cell = seed_cell_dev; jobs.seed_delta = delta;
   for (int i = 0; i < nones; ++i) jobs.ones[i] = (__bf16*)ones[i];
   for (int i = 0; i < njobs; ++i) {
@@ -504,7 +506,7 @@ int launch_wsplit_plan(int njobs, const WsplitSpec* specs, int nones, void* cons
     j.rows = (rows + 15) / 16 * 16; j.cols_p = (cols + 31) / 32 * 32;
   }
   const size_t lds = plan_out ? plan::lds_bytes(B, T) : 0;
-  if (lds > 64 * 1024) return fail(RD_EINVAL, "rd_step_begin: B x T too large for the one-workgroup token plan (%d, %d)", B, T);
+  if (lds > 64 * 1024) return fail(RD_EINVAL, "rd_step_begin: B too large for the token plan workgroups (%d, %d)", B, T);
   // workgroups per job: a job is 25-150 tiles of one wave-iteration each; RD_WSPLIT_GX (A/B only) overrides the default
   static const int gx = [] { const char* e = getenv("RD_WSPLIT_GX"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 64; }();
   hipLaunchKernelGGL(k_wsplit, dim3(gx, njobs + (plan_out ? 1 : 0)), dim3(256), lds, st, jobs);

@@ -170,18 +170,18 @@ def test_workspace_form_equals_lds_form(monkeypatch):
     assert np.abs(Yl.cpu().numpy() - g["Y"]).max() < 1e-5
 
 
-def _assert_pruned_list_matches(ei_got, alpha_got, ei_ref, alpha_ref):
+def _assert_pruned_list_matches(ei_got, alpha_got, ei_ref, alpha_ref, max_swapped):
     """Pruned edge lists agree except where the reference's own scores are within rounding of each other: this implementation
     sums a score over the T steps, the reference averages the T*d repeated channels with torch's vectorised mean, so two scores
     a few ulps apart can come out in the other order (exact ties are excluded from the fixture by construction)."""
-    assert np.abs(alpha_got - alpha_ref).max() <= 2e-6 * np.abs(alpha_ref).max()          # the sorted VALUES agree
+    assert np.abs(alpha_got - alpha_ref).max() <= 1e-6                                    # the sorted VALUES agree (scores are O(0.1))
     assert np.all(np.diff(alpha_got) <= 0)
     bad = np.nonzero((ei_got != ei_ref).any(axis=0))[0]
-    assert bad.size <= max(2, ei_ref.shape[1] // 200), bad.size
+    assert bad.size <= max_swapped, bad.size
     score = {(int(s), int(t)): float(a) for s, t, a in zip(ei_ref[0], ei_ref[1], alpha_ref)}
     for q in bad:
         ref_score = score.get((int(ei_got[0, q]), int(ei_got[1, q])), float(alpha_ref[-1]))   # not kept upstream: a boundary swap
-        assert abs(ref_score - float(alpha_ref[q])) <= 4e-6 * np.abs(alpha_ref).max(), (int(q), ref_score, float(alpha_ref[q]))
+        assert abs(ref_score - float(alpha_ref[q])) <= 2e-6, (int(q), ref_score, float(alpha_ref[q]))
 
 
 def test_large_graph_matches_reference_fixture(monkeypatch):
@@ -191,13 +191,22 @@ def test_large_graph_matches_reference_fixture(monkeypatch):
     g = np.load(os.path.join(GOLDEN, "beta_large.npz"))
     n, T, d, B = (int(v) for v in g["dims"])
     assert ops._lib.load().rd_graph_beta_workspace_bytes(B, n, T * d, T, 13360) > 0
-    Y, ei2, alpha, grads = _beta_run(g, 31, False, monkeypatch)
-    for b in range(B):
-        _assert_pruned_list_matches(ei2[b].cpu().numpy(), alpha[b].cpu().numpy(), g["ei"][b].astype(np.int64), g["alpha"][b].ravel())
-    assert np.abs(Y.cpu().numpy() - g["Y"]).max() < 2e-5 * max(1.0, np.abs(g["Y"]).max())
-    for name, got in zip(["gX", "gWv", "gbv", "gWi", "gbi", "gmap"], grads[:6]):
-        ref = g[name]
-        assert np.abs(got.cpu().numpy() - ref).max() <= 5e-5 * np.abs(ref).max() + 1e-9, name
+    # exact-fp32 products for increase_dim / lin_value: the 13 k scores then agree with the reference's to ~1e-8 and the pruned
+    # list comes out identical but for a handful of near-ties; in the default split-bf16 mode H carries ~1e-6 of rounding, which
+    # reorders the ~1 % of neighbours whose scores are closer than that (1 311 of 6 680 gaps of the fixture are below 1e-6)
+    for mode, max_swapped in ((0, 8), (1, 400)):
+        ops._lib.call("rd_set_precision", mode)
+        try:
+            Y, ei2, alpha, grads = _beta_run(g, 31, False, monkeypatch)
+        finally:
+            ops._lib.call("rd_set_precision", 1)
+        for b in range(B):
+            _assert_pruned_list_matches(ei2[b].cpu().numpy(), alpha[b].cpu().numpy(), g["ei"][b].astype(np.int64), g["alpha"][b].ravel(),
+                                        max_swapped)
+        assert np.abs(Y.cpu().numpy() - g["Y"]).max() < 2e-5 * max(1.0, np.abs(g["Y"]).max())
+        for name, got in zip(["gX", "gWv", "gbv", "gWi", "gbi", "gmap"], grads[:6]):
+            ref = g[name]
+            assert np.abs(got.cpu().numpy() - ref).max() <= (5e-5 if mode == 0 else 2e-4) * np.abs(ref).max() + 1e-9, (mode, name)
 
 
 def test_syn256_sized_graph_properties():
