@@ -24,6 +24,7 @@ def make_config(name):
         "P19": (34, 60, 6, 2, True),       # Raindrop.py:113-116,136-138
         "SYN256": (256, 512, 6, 2, True),  # BASELINE.json configs[4] (stress shape)
         "TINY": (5, 7, 3, 2, True),        # edge-case shape for fast tests
+        "WIDE80": (80, 24, 6, 2, True),    # more sensors than one workgroup's LDS holds as a graph (use_beta operator beyond 64 nodes)
     }
     d_inp, max_len, d_static, n_classes, static = table[name]
     d_model = d_inp * D_OB

@@ -45,13 +45,14 @@ MODEL_CASES = [
     ("syn256_b2", "SYN256", 2, "sparse", 8, 10),
 ]
 FULL_LIMIT = {"p19_b256": 4096, "p12_b32": 4096, "syn256_b2": 4096, "p19_beta_sparse": 4096, "p19_beta_ones": 4096,
-              "p12_beta_sparse": 4096}
+              "p12_beta_sparse": 4096, "wide80_beta_sparse": 4096}
 # the paper's branch: the reference with its `use_beta = False` literal (code/models_rd.py:317) flipped IN MEMORY by
 # oracle/ref_loader.load_models_rd_with_beta(); Raindrop_v2(use_beta=True, compute_distance=True) here
 BETA_CASES = [
     ("p19_beta_sparse", "P19", 8, "sparse", 11, 12),
     ("p19_beta_ones", "P19", 8, "ones", 13, 14),
     ("p12_beta_sparse", "P12", 3, "sparse", 15, 16),
+    ("wide80_beta_sparse", "WIDE80", 3, "sparse", 17, 18),     # 80 sensors: the graph operator's workspace form at model level
 ]
 
 
@@ -338,7 +339,7 @@ def state_dict_surface():
     """Names and shapes of the reference's state_dict per dataset config (checkpoint surface,
     code/Raindrop.py:374,381).  Under the CPU shim `R_u` is a registered parameter."""
     out = {}
-    for cfg_name in ("TINY", "P19", "P12", "PAM", "SYN256"):
+    for cfg_name in ("TINY", "P19", "P12", "PAM", "SYN256", "WIDE80"):
         cfg = synth.make_config(cfg_name)
         model = ref_loader.build_raindrop_v2(cfg, synth.make_structure(cfg, "ones"))
         out[cfg_name] = {k: list(v.shape) for k, v in model.state_dict().items()}

@@ -10,7 +10,7 @@ from raindrop_amd import synth
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 MODEL_CASES = ["tiny_sparse", "p19_ones", "p19_sparse", "p12_ones", "pam_ones", "p19_b256", "p12_b32", "syn256_b2"]
 # the paper's branch (reference with its use_beta literal flipped in memory, tests/golden/make_goldens.py BETA_CASES)
-BETA_CASES = ["p19_beta_sparse", "p19_beta_ones", "p12_beta_sparse"]
+BETA_CASES = ["p19_beta_sparse", "p19_beta_ones", "p12_beta_sparse", "wide80_beta_sparse"]
 
 
 def load_golden(name):
