@@ -92,10 +92,11 @@ class TrainStep:
         # they take off the chain).  Off by default; RD_SIDE_REDUCE=1 turns it on (results are identical).
         self.side = torch.cuda.Stream(device=self.dev) if os.environ.get("RD_SIDE_REDUCE", "0") == "1" else None
         # trailing launches (the head's weight-gradient tiles, a layer's slice reduce) parked and appended to the next backward
-        # chain launch as extra workgroups on its idle CUs (include/raindrop_hip.h rd_set_defer_trailing).  Not in the two-graph
-        # data-parallel form: the first gradient bucket's all-reduce starts between the graphs and needs the last layer's reduce
-        # inside the first.  RD_TRAILING_RIDE=0: every launch on its own (A/B).
-        self.ride = (not self.split) and self.side is None and os.environ.get("RD_TRAILING_RIDE", "1") != "0"
+        # chain launch as extra workgroups on its idle CUs (include/raindrop_hip.h rd_set_defer_trailing).  Also in the two-graph
+        # data-parallel form: every part ends with rd_flush_trailing (_body), so the last layer's reduce -- whose results the first
+        # gradient bucket's all-reduce needs between the graphs -- is launched on its own at the end of graph A instead of riding
+        # in graph B; the head's tiles ride inside A, layer 0's reduce inside B.  RD_TRAILING_RIDE=0: every launch on its own (A/B).
+        self.ride = self.side is None and os.environ.get("RD_TRAILING_RIDE", "1") != "0"
         # token plan: the step's fast paths only (fused message passing, row-block encoder, fused head)
         self.plan = None
         if self._want_plan and self.head_fused and self._plan_supported():
