@@ -274,7 +274,7 @@ int rd_step_prepare(const rd_shape* s, int32_t nlayers, const rd_encoder_weights
                     const size_t* enc_saved_bytes, const float* W1, const float* W2, void* k1_saved, size_t k1_saved_bytes,
                     void* stream);
 int rd_step_prepare_covers(const rd_shape* s, int32_t* encoder, int32_t* sensor_stage);
-/* rd_token_plan and rd_step_prepare as ONE launch (the plan is built by one extra workgroup of the weight-split kernel): what a
+/* rd_token_plan and rd_step_prepare as ONE launch (the plan is built by one extra block row of the weight-split kernel: independent workgroups, a wave per sample): what a
  * hipGraph training step enqueues first.  seed_cell_dev / delta as in rd_token_plan (NULL: no bump). */
 int rd_step_begin(const rd_shape* s, const int64_t* lengths, int32_t* plan_out, uint64_t* seed_cell_dev, uint64_t delta,
                   int32_t nlayers, const rd_encoder_weights* const* w, void* const* enc_saved, const size_t* enc_saved_bytes,
