@@ -816,6 +816,22 @@ def main():
         assert worst < 2e-5, "--feed: replayed graph loss differs from the eager recomputation by %.3g" % worst
         feed_check = {"batches": 4, "max_rel_loss_diff_vs_eager": worst}
 
+    # the unchanged loop with the captured module step (raindrop_amd/graph_module.py, RD_MODULE_GRAPH=1): model.forward -> criterion
+    # -> loss.backward() -> flat.finish() + Adam, the model's forward and backward as two hipGraphs behind the nn.Module surface.
+    # Measured after the timed region, same batch; never allowed to cost the line.
+    t_module = None
+    if world == 1 and not args.no_roofline:
+        try:
+            model.graph_step = True
+            eager_step(); eager_step()
+            if getattr(model, "_graph_runners", None) and any(r for r in model._graph_runners.values()):
+                t_module = time_mode(eager_step, n=20)
+        except Exception as e:                                           # pragma: no cover
+            print("MODULE_GRAPH_FAILED %r" % (e,), file=sys.stderr, flush=True)
+        finally:
+            model.graph_step = False
+            model.__dict__.pop("_graph_runners", None)
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         metric = ("samples/sec fwd+bwd, P19 34-sensor batch=256; % HBM roofline on msg-pass kernel" if (cfg["name"], B) == ("P19", 256)
@@ -842,6 +858,9 @@ def main():
                        # the drop-in path of code/Raindrop.py:319-323 (model.forward -> criterion -> loss.backward() through autograd, one
                        # C-ABI call per operator, + flat.finish() + Adam), same batch, same kernels: what the unmodified script gets
                        "eager_ms_per_step": None if t_eager is None else round(t_eager * 1e3, 4),
+                       # the same loop with the model's forward / backward captured as two hipGraphs behind the nn.Module surface
+                       # (RD_MODULE_GRAPH=1; the loss, autograd's accumulation into p.grad and the optimizer stay the loop's)
+                       "module_graph_ms_per_step": None if t_module is None else round(t_module * 1e3, 4),
                        "token_plan": ("on: the padding mask (code/models_rd.py:298-299) applied as a layout -- only the %d live (sample, step) rows "
                                       "of %d are stored and processed; logits, loss and every gradient are the same function of the inputs "
                                       "(tests/test_token_plan_gpu.py); config.padded_layout_ms_per_step is the same step with every padded row "

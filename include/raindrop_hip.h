@@ -353,6 +353,19 @@ int rd_head_train(const rd_shape* s, int32_t D, int32_t d_static, int32_t Fe, in
                   const int64_t* y, float* loss, float* logits, float* g_emb_w, float* g_emb_b, float* g_w0,
                   float* g_b0, float* g_w2, float* g_b2, float* dr, void* workspace, size_t workspace_bytes,
                   void* stream);
+/* The same head around a loss the CALLER evaluates -- the reference's loop: outputs = model(..); loss = criterion(outputs, y);
+ * loss.backward() (code/Raindrop.py:317-323).  rd_head_forward stops at the logits; rd_head_backward recomputes the head's
+ * forward phases (a masked mean and two small products) and continues from the caller's d loss / d logits [B,C].  Same kernel,
+ * arithmetic, support test and workspace as rd_head_train.  raindrop_amd.graph_module (the captured module step) uses them. */
+int rd_head_forward(const rd_shape* s, int32_t D, int32_t d_static, int32_t Fe, int32_t C, const float* r, const uint8_t* mask,
+                    const int64_t* lengths, const float* stat, const float* emb_w, const float* emb_b, const float* w0,
+                    const float* b0, const float* w2, const float* b2, float* logits, void* workspace, size_t workspace_bytes,
+                    void* stream);
+int rd_head_backward(const rd_shape* s, int32_t D, int32_t d_static, int32_t Fe, int32_t C, const float* r, const uint8_t* mask,
+                     const int64_t* lengths, const float* stat, const float* emb_w, const float* emb_b, const float* w0,
+                     const float* b0, const float* w2, const float* b2, const float* dlogits, float* g_emb_w, float* g_emb_b,
+                     float* g_w0, float* g_b0, float* g_w2, float* g_b2, float* dr, void* workspace, size_t workspace_bytes,
+                     void* stream);
 size_t rd_linear_bwd_weight_workspace_bytes(int32_t M, int32_t N, int32_t K);
 /* dW[N,K] = dy[M,N]^T x[M,K];  db[N] = sum_m dy[m,:]  (db may be NULL).  Deterministic split
  * over M with a fixed-order reduction. */

@@ -99,6 +99,8 @@ SIGNATURES = {
     "rd_head_train_supported": (c_int32, [c_int32, c_int32, c_int32]),
     "rd_head_train_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "rd_head_train": (c_int32, [_SHP, c_int32, c_int32, c_int32, c_int32] + [_P] * 20 + [_P, c_size_t, _P]),
+    "rd_head_forward": (c_int32, [_SHP, c_int32, c_int32, c_int32, c_int32] + [_P] * 11 + [_P, c_size_t, _P]),
+    "rd_head_backward": (c_int32, [_SHP, c_int32, c_int32, c_int32, c_int32] + [_P] * 18 + [_P, c_size_t, _P]),
     "rd_batch_gather": (c_int32, [c_int32, c_int32, c_int32, c_int32, ctypes.c_int64] + [_P] * 12),
     "rd_graph_beta_kept": (c_int32, [c_int32]),
     "rd_graph_beta_workspace_bytes": (c_size_t, [c_int32] * 5),

@@ -37,6 +37,9 @@ struct HeadArgs {
   float *logits, *dr;
   float *feat, *hid, *dhid, *demb, *dlog, *lossr;   // workspace: [B,dh] x3, [B,Fe], [B,C], [B]
   int T, B, D, ds, Fe, dh, C;
+  const float* dlog_in;            // mode 2: d loss / d logits [B,C] from the caller (an autograd backward) instead of the cross entropy
+  int mode;                        // 0: forward + loss + backward (rd_head_train); 1: forward only, logits out (rd_head_forward);
+                                   // 2: forward recomputed + backward from dlog_in (rd_head_backward)
   const int32_t* plan;             // token plan (rd_plan.h) or null: r / dr hold the live rows only, sample b at rows off[rank[b]] + t
   unsigned long long* stamps;      // debug (tools/head_timing.py): clock64 per phase, thread 0 of workgroup 0
 };
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
   {
     const int nw2 = C * dh;
     const float pb0 = a.b0[min(tid, dh - 1)], pw2 = a.w2[min(tid, nw2 - 1)], pb2 = a.b2[min(tid, C - 1)];
-    const long long py = a.y[min(b0 + min(tid, RB - 1), B - 1)];
+    const long long py = a.mode == 0 ? a.y[min(b0 + min(tid, RB - 1), B - 1)] : 0;   // uniform
     float pew = 0.f, peb = 0.f, pst = 0.f;
     if (emb_lds) {                                     // uniform
       const int ne = a.Fe * a.ds, ns = RB * a.ds, ts = min(tid, ns - 1), rs = ts / a.ds;
@@ -213,8 +216,19 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
   }
   __syncthreads();
   HSTAMP(6);
+  if (a.mode == 1) {                                   // rd_head_forward: the logits are the result
+    if (tid < RB * C && b0 + tid / C < B) a.logits[(long)(b0 + tid / C) * C + tid % C] = lg[tid / C][tid % C];
+    return;
+  }
   // ---- softmax cross entropy per sample, dlogits = (softmax - onehot) / B ----
-  if (tid < RB && b0 + tid < B) {
+  if (a.mode == 2) {                                   // rd_head_backward: d loss / d logits comes from the caller
+    if (tid < RB * C) {
+      const int r = tid / C, c = tid - r * C, b = b0 + r;
+      const float d = b < B ? a.dlog_in[(long)b * C + c] : 0.f;
+      dl[r][c] = d;
+      if (b < B) a.dlog[(long)b * C + c] = d;
+    }
+  } else if (tid < RB && b0 + tid < B) {
     const int r = tid, b = b0 + r;
     float m = lg[r][0];
     for (int c = 1; c < C; ++c) m = fmaxf(m, lg[r][c]);
@@ -338,24 +352,61 @@ extern "C" int rd_head_train_supported(int32_t D, int32_t Fe, int32_t C) {
   return (D % 4) == 0 && D > 0 && Fe >= 0 && D + Fe <= 256 && C >= 1 && C <= 16 && 2 * (D / 4) <= HR_THR;
 }
 
+static int head_launch(int mode, const rd_shape* s, int32_t D, int32_t d_static, int32_t Fe, int32_t C, const float* r,
+                       const uint8_t* mask, const int64_t* lengths, const float* stat, const float* emb_w, const float* emb_b,
+                       const float* w0, const float* b0, const float* w2, const float* b2, const int64_t* y, const float* dlog_in,
+                       float* loss, float* logits, float* g_emb_w, float* g_emb_b, float* g_w0, float* g_b0, float* g_w2,
+                       float* g_b2, float* dr, void* workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int rd_head_train(const rd_shape* s, int32_t D, int32_t d_static, int32_t Fe, int32_t C, const float* r,
                              const uint8_t* mask, const int64_t* lengths, const float* stat, const float* emb_w,
                              const float* emb_b, const float* w0, const float* b0, const float* w2, const float* b2,
                              const int64_t* y, float* loss, float* logits, float* g_emb_w, float* g_emb_b, float* g_w0,
                              float* g_b0, float* g_w2, float* g_b2, float* dr, void* workspace, size_t workspace_bytes,
                              void* stream) {
+  RD_REQUIRE(y && loss && logits && g_w0 && g_b0 && g_w2 && g_b2 && dr, "NULL tensor");
+  return head_launch(0, s, D, d_static, Fe, C, r, mask, lengths, stat, emb_w, emb_b, w0, b0, w2, b2, y, nullptr, loss, logits, g_emb_w,
+                     g_emb_b, g_w0, g_b0, g_w2, g_b2, dr, workspace, workspace_bytes, stream);
+}
+
+// The same head as two calls around a loss the CALLER evaluates (the reference's training loop: `criterion(outputs, y)` in
+// code/Raindrop.py:319-322, then loss.backward()): rd_head_forward stops at the logits; rd_head_backward recomputes the forward
+// phases (a masked mean and two small products: cheaper than saving and re-reading them) and continues from the caller's
+// d loss / d logits.  Same kernel, same arithmetic, same workspace as rd_head_train.
+extern "C" int rd_head_forward(const rd_shape* s, int32_t D, int32_t d_static, int32_t Fe, int32_t C, const float* r,
+                               const uint8_t* mask, const int64_t* lengths, const float* stat, const float* emb_w,
+                               const float* emb_b, const float* w0, const float* b0, const float* w2, const float* b2,
+                               float* logits, void* workspace, size_t workspace_bytes, void* stream) {
+  RD_REQUIRE(logits, "NULL tensor");
+  return head_launch(1, s, D, d_static, Fe, C, r, mask, lengths, stat, emb_w, emb_b, w0, b0, w2, b2, nullptr, nullptr, nullptr, logits,
+                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+extern "C" int rd_head_backward(const rd_shape* s, int32_t D, int32_t d_static, int32_t Fe, int32_t C, const float* r,
+                                const uint8_t* mask, const int64_t* lengths, const float* stat, const float* emb_w,
+                                const float* emb_b, const float* w0, const float* b0, const float* w2, const float* b2,
+                                const float* dlogits, float* g_emb_w, float* g_emb_b, float* g_w0, float* g_b0, float* g_w2,
+                                float* g_b2, float* dr, void* workspace, size_t workspace_bytes, void* stream) {
+  RD_REQUIRE(dlogits && g_w0 && g_b0 && g_w2 && g_b2 && dr, "NULL tensor");
+  return head_launch(2, s, D, d_static, Fe, C, r, mask, lengths, stat, emb_w, emb_b, w0, b0, w2, b2, nullptr, dlogits, nullptr, nullptr,
+                     g_emb_w, g_emb_b, g_w0, g_b0, g_w2, g_b2, dr, workspace, workspace_bytes, stream);
+}
+
+static int head_launch(int mode, const rd_shape* s, int32_t D, int32_t d_static, int32_t Fe, int32_t C, const float* r,
+                       const uint8_t* mask, const int64_t* lengths, const float* stat, const float* emb_w, const float* emb_b,
+                       const float* w0, const float* b0, const float* w2, const float* b2, const int64_t* y, const float* dlog_in,
+                       float* loss, float* logits, float* g_emb_w, float* g_emb_b, float* g_w0, float* g_b0, float* g_w2,
+                       float* g_b2, float* dr, void* workspace, size_t workspace_bytes, void* stream) {
   RD_REQUIRE(s && s->T > 0 && s->B > 0, "bad shape");
   RD_REQUIRE(rd_head_train_supported(D, Fe, C), "head_train: unsupported sizes D=%d Fe=%d C=%d", D, Fe, C);
-  RD_REQUIRE(r && mask && lengths && w0 && b0 && w2 && b2 && y && loss && logits && g_w0 && g_b0 && g_w2 && g_b2 && dr && workspace,
-             "NULL tensor");
-  RD_REQUIRE(Fe == 0 || (stat && emb_w && emb_b && g_emb_w && g_emb_b && d_static > 0), "static embedding tensors missing");
+  RD_REQUIRE(r && mask && lengths && w0 && b0 && w2 && b2 && workspace, "NULL tensor");
+  RD_REQUIRE(Fe == 0 || (stat && emb_w && emb_b && d_static > 0 && (mode == 1 || (g_emb_w && g_emb_b))), "static embedding tensors missing");
   const int B = s->B, dh = D + Fe;
   RD_REQUIRE(workspace_bytes >= rd_head_train_workspace_bytes(B, dh, C), "workspace too small");
   RD_REQUIRE((reinterpret_cast<uintptr_t>(r) & 15) == 0 && (reinterpret_cast<uintptr_t>(dr) & 15) == 0, "r / dr must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   HeadArgs a{};
   a.r = r; a.mask = mask; a.lengths = lengths; a.stat = stat; a.emb_w = emb_w; a.emb_b = emb_b; a.w0 = w0; a.b0 = b0; a.w2 = w2;
-  a.b2 = b2; a.y = y; a.logits = logits; a.dr = dr;
+  a.b2 = b2; a.y = y; a.logits = logits; a.dr = dr; a.mode = mode; a.dlog_in = dlog_in;
   float* ws = (float*)workspace;
   a.feat = ws; a.hid = a.feat + (size_t)B * dh; a.dhid = a.hid + (size_t)B * dh; a.demb = a.dhid + (size_t)B * dh;
   a.dlog = a.demb + (size_t)B * dh; a.lossr = a.dlog + (size_t)B * C;
@@ -366,9 +417,9 @@ extern "C" int rd_head_train(const rd_shape* s, int32_t D, int32_t d_static, int
   if (rb1) hipLaunchKernelGGL(k_head_rows<1>, dim3(B), dim3(HR_THR), 0, st, a);
   else hipLaunchKernelGGL(k_head_rows<2>, dim3(cdiv(B, 2)), dim3(HR_THR), 0, st, a);
   int rc = check_launch("k_head_rows");
-  if (rc) return rc;
+  if (rc || mode == 1) return rc;
   HwArgs h{};
-  h.B = B; h.lossr = a.lossr; h.loss = loss;
+  h.B = B; h.lossr = a.lossr; h.loss = loss;             // loss == null (rd_head_backward): no loss mean
   int blk = 0, n = 0;
   auto add = [&](const float* u, int ldu, int N, const float* v, int ldv, int K, float* dW, float* db) {
     HwJob& J = h.j[n++];

@@ -137,7 +137,7 @@ __device__ __forceinline__ void head_wgrad_body(const HwArgs& a, int tile, int t
   }
   if (on && n < J.N && k < J.K) J.dW[(long)n * J.K + k] = acc;
   if (on && tk == 0 && ki == 0 && n < J.N && J.db) J.db[n] = bacc;
-  if (tile == 0 && t < 64) {                          // loss = mean of the per-sample losses (lane-strided, then lanes in order)
+  if (tile == 0 && t < 64 && a.loss) {                // loss = mean of the per-sample losses (lane-strided, then lanes in order)
     float s = 0.f;
     for (int b = t; b < a.B; b += 64) s += a.lossr[b];
     s = wave_sum64_dpp(s);

@@ -1,0 +1,136 @@
+"""The captured step behind the nn.Module surface: what an UNCHANGED training loop gets.
+
+code/Raindrop.py:310-324 runs, per batch,
+
+    outputs, local_structure_regularization, _ = model.forward(P, Pstatic, Ptime, lengths)
+    loss = criterion(outputs, y);  loss.backward();  optimizer.step()
+
+With `RD_MODULE_GRAPH=1` (or `model.graph_step = True`) `Raindrop_v2.forward` routes a TRAINING call through two hipGraphs
+instead of one C-ABI call per operator under autograd:
+
+  * forward  = the inputs copied into the step's static buffers, then graph F: token plan + weight splits, sensor stage,
+               encoder layers, classifier head up to the logits (`TrainStep` part 'mf');
+  * backward = one autograd node for the whole model: the loop's d loss / d logits copied in, then graph B: head backward,
+               encoder backward, sensor-stage backward (part 'mb') -- every live parameter's gradient lands in one flat buffer, a
+               copy of which is handed to autograd as views (so `p.grad`, `optimizer.zero_grad()` and torch's own Adam behave
+               exactly as with the eager path).
+
+Same kernels, token plan and dropout scheme as `raindrop_amd.step.TrainStep` (masks are a function of the step's seed cell, which
+the forward graph bumps per replay); the loss stays the caller's.  Calls the captured step does not cover fall back to the eager
+operators, silently and per call: evaluation / no-grad calls, `use_beta` / `compute_distance` models, another batch size or
+device than the captured one is handled by capturing a second runner, torch.distributed with more than one rank (use
+`TrainStep` + `dp.FlatGradAllReduce` there).
+
+One training forward may be outstanding at a time: a second forward before the first one's backward would overwrite the
+activations the backward graph reads -- the backward of the stale call raises instead of returning wrong gradients."""
+import os
+
+import torch
+
+from . import _lib, dp, synth
+
+
+def enabled(model):
+    flag = getattr(model, "graph_step", None)
+    if flag is None:
+        flag = os.environ.get("RD_MODULE_GRAPH", "0") == "1"
+    return bool(flag)
+
+
+class _Runner:
+    """One captured (forward graph, backward graph) pair for one model, batch shape and device."""
+
+    def __init__(self, model, T, B, dev):
+        from .step import TrainStep
+        nl = len(model.transformer_encoder.layers)
+        names = synth.live_parameter_names(dict(static=model.static, nlayers=nl))
+        named = dict(model.named_parameters())
+        self.names = names
+        self.params = [named[n] for n in names]
+        old_grads = [p.grad for p in self.params]
+        self.flat = dp.FlatGradAllReduce(list(zip(names, self.params)), n_buckets=1)
+        for p, g in zip(self.params, old_grads):                       # the flat buffer is the step's output here, not p.grad's home
+            p.grad = g
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.batch = dict(src=torch.zeros((T, B, 2 * model.d_inp), **f32), times=torch.zeros((T, B), **f32),
+                          lengths=torch.zeros((B,), dtype=torch.int64, device=dev),
+                          static=torch.zeros((B, model.d_static), **f32) if model.static else None)
+        self.step = TrainStep(model, self.flat, self.batch, use_graph=False, autotune=False, split=False, module_mode=True)
+        if not self.step.head_fused:
+            raise _lib.RaindropHipError("graph_module: classifier head sizes outside rd_head_forward / rd_head_backward")
+        self.graph_f, self.graph_b = self.step.capture_segments(("mf", "mb"))
+        self.ptrs = self._ptrs()
+        self.gen = 0
+
+    def _ptrs(self):
+        return tuple(p.data_ptr() for p in self.params)
+
+    def stale(self):
+        """parameters were moved or replaced since the capture (the graphs hold their addresses)"""
+        return self._ptrs() != self.ptrs
+
+    def forward(self, src, static, times, lengths):
+        b = self.batch
+        b["src"].copy_(src); b["times"].copy_(times); b["lengths"].copy_(lengths)
+        if b["static"] is not None:
+            b["static"].copy_(static)
+        self.gen += 1
+        self.graph_f.replay()
+        return self.step.logits.clone()
+
+    def backward(self, dlogits):
+        self.step.dlogits.copy_(dlogits)
+        self.graph_b.replay()
+        g = self.flat.flat.clone()                                     # a fresh buffer per step: autograd may keep (or steal) the views
+        return [g[o:e].view_as(p) for (o, e), p in zip(self.flat.slices, self.params)]
+
+
+class _GraphStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, runner, src, static, times, lengths, *params):
+        ctx.runner = runner
+        out = runner.forward(src, static, times, lengths)
+        ctx.gen = runner.gen
+        ctx.needs = [p.requires_grad for p in params]
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dlogits):
+        r = ctx.runner
+        if ctx.gen != r.gen:
+            raise _lib.RaindropHipError("graph_module: backward of a forward call that is no longer the latest one -- the captured "
+                                        "step keeps ONE set of activations (run forward and backward in pairs, or unset "
+                                        "RD_MODULE_GRAPH / model.graph_step for this pattern)")
+        grads = r.backward(dlogits.contiguous().float())
+        return (None, None, None, None, None) + tuple(g if need else None for g, need in zip(grads, ctx.needs))
+
+
+def forward(model, src, static, times, lengths):
+    """logits [B,C] through the captured step, or None where this call is not covered (the caller continues on the eager path)."""
+    if not (model.training and torch.is_grad_enabled()) or model.use_beta or model.compute_distance:
+        return None
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return None
+    if model.static and static is None:
+        return None
+    T, B = src.shape[0], src.shape[1]
+    if B == 0:
+        return None
+    dev = src.device
+    runners = model.__dict__.setdefault("_graph_runners", {})
+    key = (T, B, str(dev), float(model.dropout.p), int(_lib.load().rd_get_precision()))
+    r = runners.get(key)
+    if r is not None and r.stale():
+        r = None
+    if r is None:
+        if runners.get(key, 0) is False:                               # capture failed before for this key: do not retry every call
+            return None
+        try:
+            r = _Runner(model, T, B, dev)
+        except _lib.RaindropHipError:
+            runners[key] = False
+            return None
+        runners[key] = r
+    return _GraphStep.apply(r, src, static, times, lengths, *r.params)

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 from torch.nn.parameter import Parameter
 
-from . import _lib, ops
+from . import _lib, graph_module, ops
 from .Ob_propagation import Observation_progation, glorot
 from .transformer_conv import TransformerConv
 
@@ -317,6 +317,12 @@ class Raindrop_v2(nn.Module):
         if maxlen != self.max_len:
             raise _lib.RaindropHipError("src.shape[0] (%d) must equal max_len (%d): lin_value is "
                                         "Linear(max_len*d_ob, .)" % (maxlen, self.max_len))
+        # the whole training step as two hipGraphs behind this surface (RD_MODULE_GRAPH=1 / self.graph_step = True;
+        # raindrop_amd/graph_module.py): training calls only, the loss and the optimizer stay the caller's
+        if graph_module.enabled(self):
+            out = graph_module.forward(self, src, static, times, lengths)
+            if out is not None:
+                return out, torch.zeros((), dtype=torch.float32, device=dev), None
         p_drop = float(self.dropout.p) if self.training else 0.0
         self._drop_calls += 1
         seed = (torch.initial_seed() * 1000003 + self._drop_calls + ops.rank_seed_offset()) & 0x7FFFFFFFFFFFFFFF

@@ -47,7 +47,8 @@ def plan_supported(d_inp, d_ob, T, D, nhead, nhid, precision):
 
 
 class TrainStep:
-    def __init__(self, model, flat, batch, p_drop=None, use_graph=True, seed=1234, autotune=True, token_plan=None, split=None):
+    def __init__(self, model, flat, batch, p_drop=None, use_graph=True, seed=1234, autotune=True, token_plan=None, split=None,
+                 module_mode=False):
         """model: raindrop_amd.models_rd.Raindrop_v2 on a ROCm device; flat: FlatGradAllReduce over the
         live parameters (its buffer receives the gradients); batch: dict(src, static, times, lengths, y)
         of device tensors that are REUSED every step (copy new data into them).
@@ -55,6 +56,9 @@ class TrainStep:
         code/models_rd.py:298-299 applied as a layout; same logits, loss and gradients).  None = environment RD_TOKEN_PLAN
         (default on) where the shape supports it."""
         self.model, self.flat, self.batch = model, flat, batch
+        # module_mode (raindrop_amd.graph_module): the loss is the CALLER's -- the step is cut into parts 'mf' (forward up to the
+        # logits) and 'mb' (backward from self.dlogits, which the caller fills), batch carries no labels
+        self.module_mode = bool(module_mode)
         # split: capture the step as TWO graphs -- (A) forward + loss + the backward of the head and the last encoder layer, (B) the
         # rest of the backward pass -- so that a data-parallel caller can start the all-reduce of the gradients A has finished
         # (run(between=...)) beside B.  None = on when torch.distributed runs more than one rank (RD_DP_OVERLAP=0 turns it off).
@@ -70,7 +74,7 @@ class TrainStep:
         cfgp = float(model.dropout.p) if p_drop is None else float(p_drop)
         self.p_drop = cfgp if model.training else 0.0
         self.seed = (int(seed) + ops.rank_seed_offset()) & 0x7FFFFFFFFFFFFFFF     # ranks draw different dropout masks
-        self._validate(model, batch)
+        self._validate(model, batch, labels=not self.module_mode)
         T, B = batch["src"].shape[0], batch["src"].shape[1]
         self.T, self.B = T, B
         self.shp = _lib.shape(B, T, model.d_inp, model.d_ob, d_pe=model.d_pe, nhead=model.nhead, nhid=model.nhid,
@@ -119,7 +123,7 @@ class TrainStep:
             self._capture()
 
     @staticmethod
-    def _validate(model, batch):
+    def _validate(model, batch, labels=True):
         """The step hands raw data_ptr()s to the C-ABI: everything the autograd wrappers check per call is checked here
         once (dtype, contiguity, device, shapes, label range).  Labels are read on the host ONCE, at construction."""
         # The step enqueues the DEFAULT branch of the sensor stage (rd_sensor_stage_fwd / rd_msgpass_bwd: code/models_rd.py:317's
@@ -130,7 +134,9 @@ class TrainStep:
                                         "surface only (model.forward + autograd); the captured step implements the default branch")
         T, B = batch["src"].shape[0], batch["src"].shape[1]
         want = {"src": (torch.float32, (T, B, 2 * model.d_inp)), "times": (torch.float32, (T, B)),
-                "lengths": (torch.int64, (B,)), "y": (torch.int64, (B,))}
+                "lengths": (torch.int64, (B,))}
+        if labels:
+            want["y"] = (torch.int64, (B,))
         if model.static:
             want["static"] = (torch.float32, (B, model.d_static))
         dev = batch["src"].device
@@ -143,7 +149,7 @@ class TrainStep:
                     k, dt, shape, t.dtype, tuple(t.shape)))
         if T != model.max_len:
             raise _lib.RaindropHipError("TrainStep: src.shape[0] (%d) must equal max_len (%d)" % (T, model.max_len))
-        if B > 0:
+        if B > 0 and labels:
             lo, hi = int(batch["y"].min()), int(batch["y"].max())
             if lo < 0 or hi >= model.n_classes:
                 raise _lib.RaindropHipError("TrainStep: labels must lie in [0, %d), got [%d, %d]" % (model.n_classes, lo, hi))
@@ -225,7 +231,10 @@ class TrainStep:
         ssum = self.graph_info["ssum"]
         if part == "k1b":
             return self._k1_bwd(self.dx[self.nl % 2], st)
-        if part in (None, "a", "begin"):
+        if part == "mb":                                  # module mode: backward from the caller's d loss / d logits
+            self._head_module(self.dx[0], st, backward=True)
+            return self._body_tail(self.nl - 1, self.dx[0])
+        if part in (None, "a", "begin", "mf"):
             prep = self.prep_enc or self.prep_k1
             prep_args = (self.nl if self.prep_enc else 0, self._prep_w, self._prep_saved, self._prep_bytes,
                          _p(W1) if self.prep_k1 else None, _p(W2) if self.prep_k1 else None, _p(self.k1_saved), self.k1_saved.numel(), st)
@@ -242,7 +251,7 @@ class TrainStep:
             if part == "begin":
                 return
         # ---------------- forward ----------------
-        if part in (None, "a", "k1f"):
+        if part in (None, "a", "k1f", "mf"):
             c("rd_sensor_stage_fwd_prepared" if self.prep_k1 else "rd_sensor_stage_fwd", sp, _p(b["src"]), _p(b["times"]), _p(b["lengths"]), _p(self.ts), _p(P["R_u"]), _p(W1),
               _p(b1), _p(W2), _p(b2), _p(ssum), self.p_drop, self.seed, _p(self.z), _p(self.mask), _p(self.k1_saved),
               self.k1_saved.numel(), st)
@@ -258,6 +267,8 @@ class TrainStep:
             if part == "enc":
                 return
         cur = self.dx[0]
+        if part == "mf":                                  # module mode: forward ends with the logits
+            return self._head_module(cur, st, backward=False)
         if self.head_fused:
             e = (lambda n: _p(P[n]) if Fe else None)
             ge = (lambda n: _p(G[n]) if Fe else None)
@@ -300,6 +311,22 @@ class TrainStep:
                    _p(self.k1_saved), self.k1_saved.numel(), _p(self.z), _p(cur), self.D, _p(G["ob_propagation.lin_value.weight"]),
                    _p(G["ob_propagation.lin_value.bias"]), _p(G["ob_propagation_layer2.lin_value.weight"]),
                    _p(G["ob_propagation_layer2.lin_value.bias"]), _p(G["R_u"]), _p(self.k1_ws), self.k1_ws.numel(), st)
+
+    def _head_module(self, cur, st, backward):
+        """The classifier head around a loss the caller evaluates (module mode): rd_head_forward -> self.logits, rd_head_backward
+        from self.dlogits -> the head's parameter gradients and the encoder stack's entry gradient `cur`."""
+        m, b, P, G, sp = self.model, self.batch, self.P, self.G, self.sp
+        D, Fe = self.D, self.Fe
+        e = (lambda n: _p(P[n]) if Fe else None)
+        ge = (lambda n: _p(G[n]) if Fe else None)
+        common = (sp, D, m.d_static if Fe else 0, Fe, m.n_classes, _p(self.x[-1]), _p(self.mask), _p(b["lengths"]),
+                  _p(b["static"]) if Fe else None, e("emb.weight"), e("emb.bias"), _p(P["mlp_static.0.weight"]),
+                  _p(P["mlp_static.0.bias"]), _p(P["mlp_static.2.weight"]), _p(P["mlp_static.2.bias"]))
+        if not backward:
+            return self._call("rd_head_forward", *common, _p(self.logits), _p(self.head_ws), self.head_ws.numel(), st)
+        self._call("rd_head_backward", *common, _p(self.dlogits), ge("emb.weight"), ge("emb.bias"), _p(G["mlp_static.0.weight"]),
+                   _p(G["mlp_static.0.bias"]), _p(G["mlp_static.2.weight"]), _p(G["mlp_static.2.bias"]), _p(cur), _p(self.head_ws),
+                   self.head_ws.numel(), st)
 
     def _head_by_operator(self, cur, st):
         """masked mean -> [agg | emb] -> mlp_static -> cross entropy and their backward, one C-ABI call per operator."""

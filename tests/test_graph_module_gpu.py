@@ -1,0 +1,122 @@
+"""GPU: the captured step behind the nn.Module surface (raindrop_amd/graph_module.py, RD_MODULE_GRAPH=1): what the reference's
+unchanged loop -- model.forward, criterion, loss.backward(), torch's optimizer (code/Raindrop.py:310-324) -- gets, against the
+eager operator-by-operator autograd path of the same module."""
+import numpy as np
+import pytest
+import torch
+
+from raindrop_amd import _lib, synth
+from tests.helpers import build_ours
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def _close(got, ref):
+    """to rounding (5e-5 of the max-norm) -- or, where a ReLU gate whose pre-activation is within ~1e-6 of zero opens on one path
+    only (the two paths sum in different orders), a few rows off by a visible amount: relative L2 below 2e-3 (DESIGN (c))"""
+    a, b = got.cpu().numpy().astype(np.float64), ref.cpu().numpy().astype(np.float64)
+    return _rel(a, b) < 5e-5 or float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)) < 2e-3
+
+
+def _batch(cfg, B, seed):
+    return {k: (None if v is None else v.to(DEV)) for k, v in synth.make_batch(cfg, B, seed=seed).items()}
+
+
+def _loop_step(m, dv, graph):
+    """one iteration of the reference's loop body on module m; returns (logits, loss, {name: grad})"""
+    m.graph_step = graph
+    for p in m.parameters():
+        p.grad = None
+    logits, dist, _ = m(dv["src"], dv["static"], dv["times"], dv["lengths"])
+    loss = torch.nn.functional.cross_entropy(logits, dv["y"])
+    loss.backward()
+    return logits.detach().clone(), float(loss), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}, dist
+
+
+@pytest.mark.parametrize("cfg_name,B", [("P19", 8), ("P19", 37), ("P12", 4), ("PAM", 2)])
+def test_module_graph_step_matches_eager_autograd(cfg_name, B):
+    """Dropout off: logits, loss and every live gradient of the two-graph module step equal the eager autograd path's (the
+    captured step runs the token plan and the fused kernels where the shape has them, the eager path the padded layout: the same
+    function of the inputs; fused head in fp32 FMA against the mode's products: 5e-5).  Replays on a SECOND batch (the graphs
+    were captured on the first) and after an optimizer step (parameters change in place) must follow."""
+    cfg = synth.make_config(cfg_name)
+    gs = synth.make_structure(cfg, "sparse")
+    m = build_ours(cfg, gs, DEV, 7).train()                     # dropout p forced to 0 by build_ours
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    live = set(synth.live_parameter_names(cfg))
+    for it, seed in enumerate((41, 42, 43)):
+        dv = _batch(cfg, B, seed)
+        lg_e, loss_e, g_e, _ = _loop_step(m, dv, False)
+        lg_g, loss_g, g_g, dist = _loop_step(m, dv, True)
+        assert float(dist) == 0.0
+        assert set(g_g) == set(g_e) == live, (sorted(set(g_g) ^ live), sorted(set(g_e) ^ live))
+        assert np.abs(lg_g.cpu().numpy() - lg_e.cpu().numpy()).max() < 2e-5, it
+        assert abs(loss_g - loss_e) < 5e-6, it
+        for n in sorted(live):
+            assert _close(g_g[n], g_e[n]), (it, n, _rel(g_g[n].cpu().numpy(), g_e[n].cpu().numpy()))
+        opt.step()                                              # torch's own Adam on p.grad (the graph path's, here)
+    assert len(m._graph_runners) == 1                           # one capture served all three batches
+
+
+def test_module_graph_step_dropout_and_fallbacks():
+    """Dropout on: fresh masks per call (the forward graph bumps the seed cell), reproducible across identical models; evaluation and
+    no-grad calls, a model with use_beta, and a stale backward do what the module docstring says."""
+    cfg = synth.make_config("P19")
+    dv = _batch(cfg, 16, 5)
+    seqs = []
+    for _ in range(2):
+        m = build_ours(cfg, synth.make_structure(cfg, "ones"), DEV, 7).train()
+        m.dropout.p = 0.2
+        seqs.append([_loop_step(m, dv, True)[1] for _ in range(3)])
+    assert len(set(seqs[0])) == 3 and seqs[0] == seqs[1]
+    # evaluation / no-grad calls stay on the eager path and do not disturb the runner
+    m.eval()
+    with torch.no_grad():
+        lg_eval = m(dv["src"], dv["static"], dv["times"], dv["lengths"])[0]
+    m.graph_step = False
+    with torch.no_grad():
+        lg_ref = m(dv["src"], dv["static"], dv["times"], dv["lengths"])[0]
+    assert torch.equal(lg_eval, lg_ref)
+    # two forwards, then the backward of the first: refused, not wrong
+    m.train(); m.graph_step = True
+    l1 = m(dv["src"], dv["static"], dv["times"], dv["lengths"])[0]
+    l2 = m(dv["src"], dv["static"], dv["times"], dv["lengths"])[0]
+    with pytest.raises(_lib.RaindropHipError):
+        l1.sum().backward()
+    l2.sum().backward()                                         # the latest one is fine
+    # gradient accumulation over two forward/backward pairs without zero_grad: p.grad is the sum (autograd accumulates copies)
+    m.dropout.p = 0.0
+    for p in m.parameters():
+        p.grad = None
+    for _ in range(2):
+        m(dv["src"], dv["static"], dv["times"], dv["lengths"])[0].square().sum().backward()
+    twice = m.mlp_static[2].weight.grad.clone()
+    for p in m.parameters():
+        p.grad = None
+    m(dv["src"], dv["static"], dv["times"], dv["lengths"])[0].square().sum().backward()
+    assert torch.allclose(twice, 2 * m.mlp_static[2].weight.grad, rtol=1e-6, atol=0)
+    # the paper's branch is not covered by the captured step: eager path, gradients for increase_dim
+    mb = build_ours(cfg, synth.make_structure(cfg, "sparse"), DEV, 7, use_beta=True).train()
+    mb.graph_step = True
+    mb(dv["src"], dv["static"], dv["times"], dv["lengths"])[0].sum().backward()
+    assert mb.ob_propagation.increase_dim.weight.grad is not None and not getattr(mb, "_graph_runners", {})
+
+
+def test_module_graph_step_environment_switch(monkeypatch):
+    """RD_MODULE_GRAPH=1 turns the captured step on for an unchanged script (no attribute on the model)."""
+    cfg = synth.make_config("TINY")
+    dv = _batch(cfg, 3, 9)
+    m = build_ours(cfg, synth.make_structure(cfg, "ones"), DEV, 7).train()
+    monkeypatch.setenv("RD_MODULE_GRAPH", "1")
+    lg = m(dv["src"], dv["static"], dv["times"], dv["lengths"])[0]
+    assert len(getattr(m, "_graph_runners", {})) == 1 and lg.grad_fn is not None
+    monkeypatch.delenv("RD_MODULE_GRAPH")
+    m2 = build_ours(cfg, synth.make_structure(cfg, "ones"), DEV, 7).train()
+    lg2 = m2(dv["src"], dv["static"], dv["times"], dv["lengths"])[0]
+    assert not getattr(m2, "_graph_runners", {})
+    assert np.abs(lg.detach().cpu().numpy() - lg2.detach().cpu().numpy()).max() < 2e-5
