@@ -37,6 +37,7 @@ size_t tile_wgrad_ones_elems();
 size_t tile_wgrad_part_floats(int N, int K);
 bool tile_wgrad_ok(int N, int K);
 struct TileColsumJob { const float* x; int M, N, n1; float *out1, *out2; };
+int launch_rows_to_tiles(long M, int n, const float* const* x, const long* ld, const int* cols, void* const* tiles, hipStream_t st);   // rd_tiles_export.hip
 int launch_tile_wgrad(long M, int njobs, const TileWgradJob* jobs, const void* ones, int ncs, const TileColsumJob* cs,
                       hipStream_t st, const int32_t* s32);
 void rowgemm_export_next(void* tiles);
@@ -2676,7 +2677,8 @@ extern "C" int rd_encoder_layer_fwd(const rd_shape* s, int32_t layer, const floa
     if (panel) {
       WsplitSpec specs[8];
       const int n = enc_split_specs(e, w, v, specs, true);
-      if ((rc = launch_wsplit_specs(n, specs, 0, nullptr, st))) return rc;
+      void* on[1] = {v.ones};                                // the constant tile of the streamed weight gradients (backward, tw2)
+      if ((rc = launch_wsplit_specs(n, specs, 1, on, st))) return rc;
     }
     if ((rc = linear_fwd_t(e.M, 3 * e.D, e.D, x, w->in_proj_w, panel ? v.pl[0][0] : nullptr, w->in_proj_b, v.qkv, 0, 0.f, 0, 0, st))) return rc;
   }
@@ -2758,6 +2760,13 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   // its reduce launch also column-sums the two LayerNorm partial matrices
   const bool tw = rg && tile_path(e);
   const bool panel = !rg && precision() != RD_PREC_FP32;      // the forward split the eight weight orientations into `saved`
+  // tw2 (round 4): widths beyond the row-block kernels (SYN256: D = 1040).  The four weight gradients as the same tile stream,
+  // fed by ONE stand-alone conversion pass over the eight operands (rd_tiles_export.hip) instead of four split-K GEMMs that
+  // convert both fp32 operands once per 64 x 64 output tile (52 % of SYN256's step: 11.2 -> 7.65 ms with this).  Narrow layers keep the
+  // GEMMs (PAM, D = 84: 2.96 vs 3.04 ms -- the conversion pass costs more than it saves).  RD_TILE_WGRAD_GENERIC=0: the GEMMs (A/B).
+  static const bool tw2_env = [] { const char* v = getenv("RD_TILE_WGRAD_GENERIC"); return !(v && atoi(v) == 0); }();
+  const bool tw2 = panel && tw2_env && e.M >= 1024 && e.D >= 256 && tile_wgrad_ok(3 * e.D, e.D) && tile_wgrad_ok(e.D, e.D) && tile_wgrad_ok(e.nhid, e.D) &&
+                   tile_wgrad_ok(e.D, e.nhid);
   const int32_t* tp = token_plan();
   RD_REQUIRE(!tp || (tw && !attn_big(e)), "token plan: this shape / mode does not run on the row-block + tile-stream path");
   struct MliveScope { MliveScope(const int32_t* p) { rowgemm_set_mlive(p); } ~MliveScope() { rowgemm_set_mlive(nullptr); } } mscope(tp);
@@ -2779,7 +2788,7 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   // lnpart is a [blocks, 2D] matrix (dgamma | dbeta per block): column-sum it in fixed order
   if (!tw && (rc = launch_colsum2(ws.lnpart, lnb, 2 * e.D, 2 * e.D, g->norm2_w, e.D, g->norm2_b, ws.lnred, st))) return rc;
   // ---- FFN ---------------------------------------------------------------------------------------
-  if (!tw && (rc = linear_bwd_w(e.M, e.D, e.nhid, ws.df, v.h, g->lin2_w, g->lin2_b, ws.splitk, ws.colsum, sw))) return rc;
+  if (!tw && !tw2 && (rc = linear_bwd_w(e.M, e.D, e.nhid, ws.df, v.h, g->lin2_w, g->lin2_b, ws.splitk, ws.colsum, sw))) return rc;
   if (fuse) {
   } else if (rg) {                                                 // du = (df W2) gated by h>0, * keep
     if (tw) rowgemm_export_next(ws.dt[0]);
@@ -2790,7 +2799,7 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
                                     p_drop > 0.f ? keep : 0.f, nullptr, 0, 0.f, 0, 0, st))) return rc;
   } else if ((rc = linear_bwd_x_t(e.M, e.D, e.nhid, ws.df, w->lin2_w, panel ? v.pl[5][0] : nullptr, ws.du, v.h, p_drop > 0.f ? keep : 0.f, nullptr, st)))
     return rc;
-  if (!tw && (rc = linear_bwd_w(e.M, e.nhid, e.D, ws.du, v.x1, g->lin1_w, g->lin1_b, ws.splitk, ws.colsum, sw))) return rc;
+  if (!tw && !tw2 && (rc = linear_bwd_w(e.M, e.nhid, e.D, ws.du, v.x1, g->lin1_w, g->lin1_b, ws.splitk, ws.colsum, sw))) return rc;
   if (fuse) {
   } else if (rg) {
     if (tw) rowgemm_export_next(ws.dt[1]);
@@ -2802,7 +2811,7 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
                                   p_drop, seed, SITE_ATTN_OUT + L, st))) return rc;
   if (!tw && (rc = launch_colsum2(ws.lnpart, lnb, 2 * e.D, 2 * e.D, g->norm1_w, e.D, g->norm1_b, ws.lnred, st))) return rc;
   // ---- attention output projection ---------------------------------------------------------------
-  if (!tw && (rc = linear_bwd_w(e.M, e.D, e.D, ws.dout, v.attn, g->out_proj_w, g->out_proj_b, ws.splitk, ws.colsum, sw)))
+  if (!tw && !tw2 && (rc = linear_bwd_w(e.M, e.D, e.D, ws.dout, v.attn, g->out_proj_w, g->out_proj_b, ws.splitk, ws.colsum, sw)))
     return rc;
   if (fuse) {
   } else if (rg) {
@@ -2833,7 +2842,7 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
     if ((rc = dispatch_attn(a, 2, st))) return rc;
   }
   // ---- input projection --------------------------------------------------------------------------
-  if (!tw && (rc = linear_bwd_w(e.M, 3 * e.D, e.D, ws.dqkv, x, g->in_proj_w, g->in_proj_b, ws.splitk, ws.colsum, sw)))
+  if (!tw && !tw2 && (rc = linear_bwd_w(e.M, 3 * e.D, e.D, ws.dqkv, x, g->in_proj_w, g->in_proj_b, ws.splitk, ws.colsum, sw)))
     return rc;
   if (afuse) {
   } else if (tw) rowgemm_export_next(ws.dt[3]);
@@ -2857,6 +2866,21 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
     const TileColsumJob cs[2] = {{ws.lnpart, lnrows, 2 * e.D, e.D, g->norm2_w, g->norm2_b},
                                  {ws.lnpart1, lnrows, 2 * e.D, e.D, g->norm1_w, g->norm1_b}};
     return launch_tile_wgrad(e.M, 4, jobs, v.ones, 2, cs, st, tp ? tp + plan::I_S32 : nullptr);
+  }
+  if (tw2) {
+    // every operand of the four products is complete and still in place (ws.* are this call's, v.* the forward's): one conversion
+    // launch, then the stream.  The LayerNorm column sums went their own way above (launch_colsum2).
+    const float* src[8] = {ws.df, ws.du, ws.dout, ws.dqkv, x, v.attn, v.x1, v.h};
+    const long ld[8] = {e.D, e.nhid, e.D, 3L * e.D, e.D, e.D, e.D, e.nhid};
+    const int cols[8] = {e.D, e.nhid, e.D, 3 * e.D, e.D, e.D, e.D, e.nhid};
+    void* dst[8] = {ws.dt[0], ws.dt[1], ws.dt[2], ws.dt[3], v.xt[0], v.xt[1], v.xt[2], v.xt[3]};
+    if ((rc = launch_rows_to_tiles(e.M, 8, src, ld, cols, dst, st))) return rc;
+    TileWgradJob jobs[4] = {
+        {ws.dt[3], v.xt[0], ws.twpart[3], g->in_proj_w, g->in_proj_b, 3 * e.D, e.D, nullptr, 0, 0, 0, 0, 0},      // dqkv^T x
+        {ws.dt[1], v.xt[2], ws.twpart[1], g->lin1_w, g->lin1_b, e.nhid, e.D, nullptr, 0, 0, 0, 0, 0},             // du^T x1
+        {ws.dt[0], v.xt[3], ws.twpart[0], g->lin2_w, g->lin2_b, e.D, e.nhid, nullptr, 0, 0, 0, 0, 0},             // df^T h
+        {ws.dt[2], v.xt[1], ws.twpart[2], g->out_proj_w, g->out_proj_b, e.D, e.D, nullptr, 0, 0, 0, 0, 0}};       // dout^T attn
+    return launch_tile_wgrad(e.M, 4, jobs, v.ones, 0, nullptr, st, nullptr);
   }
   return rc;
 }
