@@ -2764,7 +2764,8 @@ extern "C" int rd_encoder_layer_bwd(const rd_shape* s, int32_t layer, const floa
   // fed by ONE stand-alone conversion pass over the eight operands (rd_tiles_export.hip) instead of four split-K GEMMs that
   // convert both fp32 operands once per 64 x 64 output tile (52 % of SYN256's step: 11.2 -> 7.65 ms with this).  Narrow layers keep the
   // GEMMs (PAM, D = 84: 2.96 vs 3.04 ms -- the conversion pass costs more than it saves).  RD_TILE_WGRAD_GENERIC=0: the GEMMs (A/B).
-  static const bool tw2_env = [] { const char* v = getenv("RD_TILE_WGRAD_GENERIC"); return !(v && atoi(v) == 0); }();
+  const char* tw2_v = getenv("RD_TILE_WGRAD_GENERIC");        // read per call (tests compare both paths in one process)
+  const bool tw2_env = !(tw2_v && atoi(tw2_v) == 0);
   const bool tw2 = panel && tw2_env && e.M >= 1024 && e.D >= 256 && tile_wgrad_ok(3 * e.D, e.D) && tile_wgrad_ok(e.D, e.D) && tile_wgrad_ok(e.nhid, e.D) &&
                    tile_wgrad_ok(e.D, e.nhid);
   const int32_t* tp = token_plan();

@@ -122,11 +122,11 @@ def forward(model, src, static, times, lengths):
     runners = model.__dict__.setdefault("_graph_runners", {})
     key = (T, B, str(dev), float(model.dropout.p), int(_lib.load().rd_get_precision()))
     r = runners.get(key)
+    if r is False:                                                     # capture failed before for this key: do not retry every call
+        return None
     if r is not None and r.stale():
         r = None
     if r is None:
-        if runners.get(key, 0) is False:                               # capture failed before for this key: do not retry every call
-            return None
         try:
             r = _Runner(model, T, B, dev)
         except _lib.RaindropHipError:

@@ -254,6 +254,13 @@ class Raindrop_v2(nn.Module):
             state_dict[key] = self.R_u.detach()
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
+    def __getstate__(self):
+        """pickling / copy.deepcopy: the captured step's runners (hipGraphs, raindrop_amd/graph_module.py) stay behind; a copy
+        captures its own on its first training call"""
+        d = dict(self.__dict__)
+        d.pop("_graph_runners", None)
+        return d
+
     def init_weights(self):
         """code/models_rd.py:271-276."""
         initrange = 1e-10

@@ -534,6 +534,46 @@ def test_encoder_tile_weight_gradients_match_split_k(T, B, precision_mode, monke
             assert np.abs(a - r).max() <= 2e-5 * np.abs(r).max(), (name, float(np.abs(a - r).max() / np.abs(r).max()))
 
 
+@pytest.mark.parametrize("T,B,F", [(16, 65, 68), (40, 27, 68)])
+def test_wide_encoder_tile_weight_gradients_match_split_k(T, B, F, precision_mode, monkeypatch):
+    """Widths beyond the row-block kernels (D = 288, nhid = 544: the panel / tiled GEMM path SYN256 takes): the layer's four weight
+    gradients through the stand-alone conversion pass + tile stream (rd_tiles_export.hip, round 4) against the four split-K GEMMs
+    they replace (RD_TILE_WGRAD_GENERIC=0), same split-bf16 arithmetic, same dropout masks: identical output and input gradient,
+    weight gradients within 2e-5 of the tensor's max-norm.  T*B = 1040 / 1080 rows: a partial last 32-row chunk, and
+    column counts (288, 544, 864) that are not multiples of the 64-column conversion blocks."""
+    if precision_mode != "bf16x3":
+        pytest.skip("the tile stream exists in the bf16 modes only")
+    from raindrop_amd import _lib, ops
+    nhead = 4
+    D, nhid = F * 4 + 16, 2 * F * 4
+    rng = np.random.default_rng(T * B)
+    x = torch.from_numpy(rng.standard_normal((T, B, D)).astype(np.float32)).to(DEV)
+    lengths = torch.from_numpy(rng.integers(1, T + 1, size=B)).long()
+    mask = torch.from_numpy(O2.padding_mask(lengths.numpy(), T)).to(DEV)
+    dy = torch.from_numpy(rng.standard_normal((T, B, D)).astype(np.float32)).to(DEV)
+    p = _enc_params(D, nhid, seed=B)
+    shp = _lib.shape(B, T, F, 4, nhead=nhead, nhid=nhid)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RD_TILE_WGRAD_GENERIC", mode)
+        xd = x.clone().requires_grad_(True)
+        pd = [p[n].to(DEV).requires_grad_(True) for n in ops.ENC_PARAM_NAMES]
+        y = ops.encoder_layer(xd, mask, shp, 1, 0.2, 1234, pd)
+        g = torch.autograd.grad(y, [xd] + pd, dy)
+        torch.cuda.synchronize()
+        out[mode] = (y.detach().cpu().numpy(), [t.cpu().numpy() for t in g])
+    monkeypatch.delenv("RD_TILE_WGRAD_GENERIC")
+    assert np.array_equal(out["1"][0], out["0"][0])
+    differ = 0
+    for name, a, r in zip(["x"] + list(ops.ENC_PARAM_NAMES), out["1"][1], out["0"][1]):
+        if name == "x" or name.startswith("norm"):
+            assert np.array_equal(a, r), name                            # untouched by the switch
+        else:
+            assert np.abs(a - r).max() <= 2e-5 * np.abs(r).max(), (name, float(np.abs(a - r).max() / np.abs(r).max()))
+            differ += int(not np.array_equal(a, r))
+    assert differ > 0                                                    # the switch did select another kernel
+
+
 @pytest.mark.parametrize("T,B,F", [(60, 5, 34), (130, 2, 17), (12, 3, 3)])
 def test_materialised_attention_matches_tiled(T, B, F, monkeypatch):
     """The materialised-score attention of wide heads (batched GEMMs around a row softmax; RD_ATTN_BIG=1 forces it at any
