@@ -120,3 +120,26 @@ def test_module_graph_step_environment_switch(monkeypatch):
     lg2 = m2(dv["src"], dv["static"], dv["times"], dv["lengths"])[0]
     assert not getattr(m2, "_graph_runners", {})
     assert np.abs(lg.detach().cpu().numpy() - lg2.detach().cpu().numpy()).max() < 2e-5
+
+
+def test_module_graph_step_recaptures_when_it_must():
+    """A second batch size gets its own captured pair; a parameter whose storage was replaced (the graphs hold addresses) makes
+    the runner stale: the next call captures again instead of training a dangling copy."""
+    cfg = synth.make_config("P19")
+    m = build_ours(cfg, synth.make_structure(cfg, "ones"), DEV, 7).train()
+    live = sorted(synth.live_parameter_names(cfg))
+    for B in (8, 5, 8):
+        dv = _batch(cfg, B, 60 + B)
+        _, loss_e, g_e, _ = _loop_step(m, dv, False)
+        _, loss_g, g_g, _ = _loop_step(m, dv, True)
+        assert abs(loss_g - loss_e) < 5e-6
+        assert all(_close(g_g[n], g_e[n]) for n in live)
+    assert len(m._graph_runners) == 2
+    old = m._graph_runners[next(k for k in m._graph_runners if k[1] == 8)]
+    w = m.mlp_static[0].weight
+    w.data = (w.data * 1.5).clone()                              # new storage, new values
+    dv = _batch(cfg, 8, 77)
+    _, loss_e, g_e, _ = _loop_step(m, dv, False)
+    _, loss_g, g_g, _ = _loop_step(m, dv, True)
+    assert m._graph_runners[next(k for k in m._graph_runners if k[1] == 8)] is not old
+    assert abs(loss_g - loss_e) < 5e-6 and all(_close(g_g[n], g_e[n]) for n in live)
