@@ -14,6 +14,8 @@
 // This file holds the shape-generic path (any T, F): the [B*F, K] x [K, K] products run on the
 // tiled MFMA GEMM (rd_gemm.hip) with the ReLU / aggregate-scale / layout-scatter fused into its
 // epilogue.  The LDS-resident fused kernel for small K lives in rd_msgpass_fused.hip.
+#include <stdlib.h>
+
 #include "rd_common.h"
 #include "rd_k1_layout.h"
 #include "rd_plan.h"
@@ -34,6 +36,16 @@ int fused_msgpass_bwd(const k1::Layout& L, const float* src, const float* ssum, 
 int fused_dw(const k1::Layout& L, const k1::DwPlan& P, const void* tpX, const void* tpY1, const void* tpD1,
              const void* tpD2, const void* ones, float* part, const float* rupart, float* dW1, float* db1, float* dW2, float* db2,
              float* dRu, hipStream_t st);
+// streamed weight gradients from row tiles (rd_tile_wgrad.hip, rd_tiles_export.hip; declarations as in rd_temporal.hip)
+struct TileWgradJob { const void *tA, *tB; float* part; float *dW, *db; int N, K; const int32_t* s32; int S; int hd, hdp, H, D; };
+struct TileColsumJob { const float* x; int M, N, n1; float *out1, *out2; };
+size_t tile_elems(long M, int cols);
+size_t tile_wgrad_ones_elems();
+size_t tile_wgrad_part_floats(int N, int K);
+bool tile_wgrad_ok(int N, int K);
+int launch_rows_to_tiles(long M, int n, const float* const* x, const long* ld, const int* cols, void* const* tiles, hipStream_t st);
+int launch_tile_wgrad(long M, int njobs, const TileWgradJob* jobs, const void* ones, int ncs, const TileColsumJob* cs,
+                      hipStream_t st, const int32_t* s32);
 
 namespace {
 
@@ -133,8 +145,16 @@ __global__ __launch_bounds__(256) void k_rows_to_tokens(const float* __restrict_
   }
 }
 
+// Shapes whose two weight gradients dW_l = dZ_l^T in_l ([K, K], reduction over the B*F graph rows) take the conversion pass + tile
+// stream instead of the split-K GEMM pair: enough rows to amortise the conversion and a K the stream's 5 x 6-tile blocks fill
+// and many more rows than columns (P12: 9216 x 860: 1.70 -> 1.64 ms/step, 1.45 -> 1.37 in the single-product mode; not SYN256's
+// 4096 x 2048, where the pass + stream come out 1 % behind the GEMM pair, nor PAM's 1088 rows).  Part of the workspace LAYOUT, so it
+// must not depend on the arithmetic mode or the environment.
+static bool wgrad_stream_shape(long M, long K) { return M >= 2048 && K >= 512 && (K % 4) == 0 && M >= 4 * K; }
+
 struct MsgWs {
   float *dz2, *dz1, *dx, *splitk, *colsum, *rupart;
+  void* tl[4]; float* part[2];      // wgrad_stream_shape: row tiles of dz2, y1, dz1, x; slice partials of dW2, dW1
   size_t bytes;
   int nsplit, kps;
 };
@@ -155,13 +175,19 @@ MsgWs carve(const rd_shape* s, void* base) {
   w.splitk = take((size_t)2 * wgrad_ws_floats(M, (int)K, (int)K));
   w.colsum = take(colsum_ws_floats((int)M, (int)K));
   w.rupart = take(B * F * s->d_ob);
+  for (int i = 0; i < 4; ++i) w.tl[i] = nullptr;
+  w.part[0] = w.part[1] = nullptr;
+  if (wgrad_stream_shape(M, K)) {
+    for (int i = 0; i < 4; ++i) w.tl[i] = take((tile_elems(M, (int)K) + 1) / 2);
+    for (int i = 0; i < 2; ++i) w.part[i] = take(tile_wgrad_part_floats((int)K, (int)K));
+  }
   w.bytes = off;
   return w;
 }
 
 // wt: W1, W2, W2^T, W1^T as native operand tiles (k_wsplit; bf16 modes): the B operands of the two forward products and of the two
 // input-gradient products (launch_gemm's panel form), written once by the forward and kept for the backward
-struct MsgSaved { float *xsave, *y1save; void* wt[4]; int ntile, nkc; size_t bytes; };
+struct MsgSaved { float *xsave, *y1save; void* wt[4]; void* ones; int ntile, nkc; size_t bytes; };
 MsgSaved carve_saved(const rd_shape* s, void* base) {
   const size_t M = (size_t)s->B * s->F, K = (size_t)s->T * s->d_ob;
   MsgSaved v; size_t off = 0;
@@ -171,6 +197,7 @@ MsgSaved carve_saved(const rd_shape* s, void* base) {
   v.y1save = (float*)take(M * K * sizeof(float));
   const size_t plane = ((K + 15) / 16 * 16) * ((K + 31) / 32 * 32);                    // elements of one plane (rd_rowgemm.hip: k_wsplit)
   for (int i = 0; i < 4; ++i) v.wt[i] = take(2 * plane * 2);                           // hi + lo, bf16
+  v.ones = take(tile_wgrad_ones_elems() * 2);                                          // constant tile of the streamed weight gradients
   v.ntile = ((int)K + 15) / 16; v.nkc = ((int)K + 31) / 32;
   v.bytes = off;
   return v;
@@ -275,7 +302,8 @@ extern "C" int rd_msgpass_fwd(const rd_shape* s, const float* src, const float* 
   const bool tiles = precision() != RD_PREC_FP32;      // the split weights feed the panel form of launch_gemm (bf16 modes)
   if (tiles) {
     const WsplitSpec specs[4] = {{W1, K, K, 0, v.wt[0]}, {W2, K, K, 0, v.wt[1]}, {W2, K, K, 1, v.wt[2]}, {W1, K, K, 1, v.wt[3]}};
-    if ((rc = launch_wsplit_specs(4, specs, 0, nullptr, st))) return rc;
+    void* on[1] = {v.ones};
+    if ((rc = launch_wsplit_specs(4, specs, 1, on, st))) return rc;
   }
   GemmArgs g{};
   g.M = M; g.N = K; g.K = K; g.nsplit = 1;
@@ -430,6 +458,19 @@ extern "C" int rd_msgpass_bwd(const rd_shape* s, const float* src, const float* 
   if ((rc = launch_colsum(w.rupart, B, F * d, F * d, dR_u, w.colsum, st))) return rc;
   }
   // weight gradients dW_l = dz_l^T in_l (+ bias gradients as row sums of dz_l^T), split over the B*F rows
+  // Large shapes in the bf16 modes (round 4): one conversion pass over the four operands + the tile stream of rd_tile_wgrad.hip,
+  // instead of the split-K GEMM pair that converts both fp32 operands once per 64 x 64 output tile (12.5 % of P12's step, 10 % of
+  // SYN256's).  RD_K1_WGRAD_STREAM=0: the GEMMs (A/B; read per call).
+  const char* ws_env = getenv("RD_K1_WGRAD_STREAM");
+  if (w.tl[0] && precision() != RD_PREC_FP32 && tile_wgrad_ok(K, K) && !(ws_env && atoi(ws_env) == 0)) {
+    const float* srcs[4] = {w.dz2, y1save, w.dz1, xsave};
+    const long ld[4] = {K, K, K, K};
+    const int cols[4] = {K, K, K, K};
+    if ((rc = launch_rows_to_tiles(M, 4, srcs, ld, cols, w.tl, st))) return rc;
+    TileWgradJob jobs[2] = {{w.tl[0], w.tl[1], w.part[0], dW2, db2, K, K, nullptr, 0, 0, 0, 0, 0},       // dz2^T y1
+                            {w.tl[2], w.tl[3], w.part[1], dW1, db1, K, K, nullptr, 0, 0, 0, 0, 0}};      // dz1^T x
+    return launch_tile_wgrad(M, 2, jobs, sv.ones, 0, nullptr, st, nullptr);
+  }
   if ((rc = launch_wgrad2(M, K, K, w.dz2, y1save, dW2, db2, w.dz1, xsave, dW1, db1, w.splitk, st))) return rc;
   return RD_OK;
 }

@@ -980,6 +980,44 @@ def test_k1_fused_vs_generic_same_arithmetic(F, T, B, kind, precision_mode, monk
         assert _rel2(a, r) < 1e-3, (n, _rel2(a, r))
 
 
+@pytest.mark.parametrize("F,T,B", [(36, 215, 100), (18, 130, 120)])
+def test_unfused_k1_streamed_weight_gradients_match_split_k(F, T, B, precision_mode, monkeypatch):
+    """The unfused message passing at shapes with >= 2048 graph rows and K >= 512 (P12: 36 sensors x 215 steps): its two [K, K] weight
+    gradients through the conversion pass + tile stream (round 4) against the split-K GEMM pair (RD_K1_WGRAD_STREAM=0), same
+    split-bf16 arithmetic and dropout masks: identical output and R_u gradient, dW / db within 2e-5 of the tensor's max-norm.
+    B*F = 3600 / 2160 rows (>= 4 K) end in a partial 32-row chunk; K = 860 / 520 is not a multiple of the 64-column conversion blocks."""
+    if precision_mode != "bf16x3":
+        pytest.skip("the tile stream exists in the bf16 modes only")
+    from raindrop_amd import _lib, ops
+    d = 4
+    K = T * d
+    rng = np.random.default_rng(F * T)
+    b = synth.make_batch(dict(d_inp=F, max_len=T, static=True, d_static=3, n_classes=2), B, seed=B)
+    names = ["R_u", "W1", "b1", "W2", "b2"]
+    shapes = [(1, F * d), (K, K), (K,), (K, K), (K,)]
+    p = {n: synth.param_values("k1w." + n, s, seed=9).to(DEV) for n, s in zip(names, shapes)}
+    adj, _, _ = ops.graph_build(torch.ones(F, F, device=DEV))
+    _, ssum = ops.edge_softmax_dense(adj)
+    shp = _lib.shape(B, T, F, d)
+    dz = torch.from_numpy(rng.standard_normal((T, B, F * d + 16)).astype(np.float32)).to(DEV)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RD_K1_WGRAD_STREAM", mode)
+        q = {n: t.clone().requires_grad_(True) for n, t in p.items()}
+        z, mask = ops.sensor_stage(b["src"].to(DEV), b["times"].to(DEV), b["lengths"].to(DEV), ops.timescales(T).to(DEV), ssum,
+                                   q["R_u"], q["W1"], q["b1"], q["W2"], q["b2"], shp, 0.2, 11)
+        g = torch.autograd.grad(z, [q[n] for n in names], dz)
+        torch.cuda.synchronize()
+        res[mode] = [z.detach().cpu().numpy()] + [x.cpu().numpy() for x in g]
+    monkeypatch.delenv("RD_K1_WGRAD_STREAM")
+    assert np.array_equal(res["1"][0], res["0"][0]) and np.array_equal(res["1"][1], res["0"][1])      # z, dR_u: untouched by the switch
+    differ = 0
+    for n, a, r in zip(names[1:], res["1"][2:], res["0"][2:]):
+        assert np.abs(a - r).max() <= 2e-5 * np.abs(r).max(), (n, float(np.abs(a - r).max() / np.abs(r).max()))
+        differ += int(not np.array_equal(a, r))
+    assert differ > 0                                                    # the switch did select another kernel
+
+
 @pytest.mark.parametrize("B,p_drop", [(7, 0.0), (256, 0.2)])
 def test_k1_shape_specialised_kernels_equal_generic_instantiation(B, p_drop, precision_mode, monkeypatch):
     """The P19 shape runs instantiations of the fused kernels with F = 34, T = 60 as compile-time constants (index arithmetic
