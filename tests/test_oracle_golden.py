@@ -132,3 +132,25 @@ def test_large_graph_beta_golden():
         assert np.array_equal(ei2.numpy(), g["ei"][b])
         assert np.abs(a2.numpy().ravel() - g["alpha"][b].ravel()).max() < 1e-7
         assert np.abs(y.numpy() - g["Y"][b]).max() < 1e-5
+
+
+def test_restatement_in_float64_bounds_the_fp32_reference_error():
+    """How far the fp32 CPU reference order itself is from exact arithmetic (the yardstick for the GPU ties in
+    tests/test_token_plan_gpu.py::test_benchmarked_step_against_float64): the restatement on the same fp32 parameters and inputs
+    in float64 vs fp32 -- logits within 1e-6, every gradient within 5e-6 in relative L2 at P19, B = 37."""
+    from tests.helpers import build_ours
+    cfg = synth.make_config("P19")
+    gs = synth.make_structure(cfg, "sparse")
+    batch = synth.make_batch(cfg, 37, seed=3)
+    live = set(synth.live_parameter_names(cfg))
+    m = build_ours(cfg, gs, "cpu", 7)
+    p32 = {n: t.detach().clone().requires_grad_(True) for n, t in m.named_parameters() if n in live}
+    p64 = {n: t.detach().double().requires_grad_(True) for n, t in m.named_parameters() if n in live}
+    b64 = {k: (v.double() if (v is not None and v.is_floating_point()) else v) for k, v in batch.items()}
+    lg32, ls32, gr32 = O2.step_fwd_bwd(p32, cfg, batch, gs, faithful=False)
+    lg64, ls64, gr64 = O2.step_fwd_bwd(p64, cfg, b64, gs.double(), faithful=False)
+    assert lg64.dtype == torch.float64
+    assert float((lg32.double() - lg64).abs().max()) < 1e-6
+    assert abs(float(ls32) - float(ls64)) < 1e-6
+    for n in gr64:
+        assert float((gr32[n].double() - gr64[n]).norm() / (gr64[n].norm() + 1e-300)) < 5e-6, n
