@@ -140,3 +140,40 @@ if __name__ == "__main__":
         build_variant(sys.argv[i + 1], sys.argv[i + 2:])
     else:
         build(force="--force" in sys.argv)
+
+
+def kernel_code_sizes(lib=None):
+    """{mangled kernel name: code bytes} of every gfx950 kernel in the built library: the clang offload bundles inside the shared
+    object ("__CLANG_OFFLOAD_BUNDLE__", one per translation unit) each hold an AMDGPU ELF; its FUNC symbols' sizes are the kernels'
+    code lengths.  tests/test_kernel_resources.py keeps the own-code touch lengths (rd_common.h touch_own_code) below them."""
+    import struct
+    d = open(lib or LIB, "rb").read()
+    out, pos = {}, 0
+    while True:
+        i = d.find(b"__CLANG_OFFLOAD_BUNDLE__", pos)
+        if i < 0:
+            break
+        pos = i + 24
+        nb = struct.unpack_from("<Q", d, i + 24)[0]
+        o = i + 32
+        for _ in range(nb):
+            off, size, tl = struct.unpack_from("<QQQ", d, o); o += 24
+            triple = d[o:o + tl].decode(errors="replace"); o += tl
+            if "gfx950" not in triple or size == 0:
+                continue
+            e = d[i + off:i + off + size]
+            if e[:4] != b"\x7fELF":
+                continue
+            shoff, = struct.unpack_from("<Q", e, 0x28)
+            shentsize, shnum = struct.unpack_from("<HH", e, 0x3A)
+            secs = [struct.unpack_from("<IIQQQQIIQQ", e, shoff + k * shentsize) for k in range(shnum)]
+            for s in secs:
+                if s[1] != 2:                                    # SHT_SYMTAB
+                    continue
+                stroff = secs[s[6]][4]
+                for k in range(s[5] // 24):
+                    name, info, _, _, _, sz = struct.unpack_from("<IBBHQQ", e, s[4] + 24 * k)
+                    if (info & 15) == 2 and sz:                  # STT_FUNC
+                        end = e.index(b"\0", stroff + name)
+                        out[e[stroff + name:end].decode()] = sz
+    return out

@@ -289,6 +289,7 @@ __device__ __forceinline__ void zero_pad_rows(__bf16* Tp, int tid) {
 template <int NTH, int KCX>
 __global__ __launch_bounds__(AF_THR) void k_attn_fwd_fused(FAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  RD_TOUCH_CODE(12800);                                      // own code -> L2 (rd_common.h; 14.0 KB kernel)
   constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDX = 32 * KCX + 8, NA = (NTH + 1) / 2;
   constexpr int LDO = 16 * NTH + 4;                          // fp32 row stride of the output stage
   __bf16* Xh = reinterpret_cast<__bf16*>(fsm);
@@ -526,6 +527,7 @@ __device__ __forceinline__ void dx_phase(f32x4 (&dxa)[2][4], DxPanel<(16 * NTH +
 template <int NTH, int KCX>
 __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  RD_TOUCH_CODE(28672);                                      // own code -> L2 (30.3 KB kernel)
   constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDX = 32 * KCX + 8, NA = (NTH + 1) / 2, KB = HDP / 32, LDB = HDP + 8;
   constexpr int NCT = 2 * KCX;                               // 16-column tiles of D (padded to 32 KCX)
   constexpr int LDS_DX = 32 * KCX + 4;                       // fp32 row stride of the dx stage

@@ -90,6 +90,40 @@ __device__ __forceinline__ void load_uniform_2xi32(const int32_t* p, const int32
   asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(x), "=&s"(y) : "s"(p), "s"(q) : "memory");
 }
 
+// Request this kernel's OWN code into the L2 of the XCD it runs on: lane t asks for one dword of the t-th 128-byte line after the
+// current PC (`bytes` <= the code that follows; lanes past the range sit out), then the requesting waves wait once.  Why: a kernel
+// of the step runs once per step, ~0.9 GB of traffic after its previous run -- its code is in no cache, and on the pool's SLOW boxes
+// instruction fetch has no look-ahead: every 128 bytes of straight-line code are a serialized ~840-tick trip to memory
+// (tools/probe_clocks.hip: 405 ticks per 64-byte line cold against 80 warm; the fast boxes prefetch: 81 / 51).  One parallel
+// batch of loads up front turns them into L2 hits.  Data loads and instruction fetches share the L2.
+__device__ __forceinline__ void touch_own_code(int tid, int bytes) {
+  if (bytes <= 0) return;                                   // uniform
+  uint64_t pc;
+  asm volatile("s_getpc_b64 %0" : "=s"(pc));
+  const int nl = bytes >> 7;
+  if (tid < nl) {
+    const char* p = reinterpret_cast<const char*>(pc) + (size_t)tid * 128;
+    int t;
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(t) : "v"(p) : "memory");
+  }
+}
+
+// -DRD_NO_CODE_TOUCH: A/B builds without it (python -m raindrop_amd.build --variant notouch -DRD_NO_CODE_TOUCH).  `first` bounds the
+// workgroups that do it in launches of many small workgroups (the first ones dispatched cover every XCD).
+#ifdef RD_NO_CODE_TOUCH
+#define RD_TOUCH_CODE(bytes) ((void)0)
+#define RD_TOUCH_CODE_FIRST(bytes, lin, first) ((void)0)
+#else
+#define RD_TOUCH_CODE(bytes) ::rd::touch_own_code((int)threadIdx.x, (bytes))
+#define RD_TOUCH_CODE_FIRST(bytes, lin, first) ::rd::touch_own_code((int)threadIdx.x, (int)(lin) < (first) ? (bytes) : 0)
+#endif
+
+// a uniform 64-bit value and two uniform 32-bit ones, three independent scalar loads behind one wait
+__device__ __forceinline__ void load_uniform_u64_2xi32(const uint64_t* l, const int32_t* p, const int32_t* q, uint64_t& v, int& x, int& y) {
+  asm volatile("s_load_dwordx2 %0, %3, 0x0\n\ts_load_dword %1, %4, 0x0\n\ts_load_dword %2, %5, 0x0\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(v), "=&s"(x), "=&s"(y) : "s"(l), "s"(p), "s"(q) : "memory");
+}
+
 // Sum over the 64 lanes of a wavefront on the DPP path, result uniform (every lane gets it).  row_shr 1/2/4/8 leave each
 // 16-lane row's total in its last lane, row_bcast15 / row_bcast31 carry the totals up to lane 63, v_readlane makes it
 // uniform: six VALU instructions with DPP modifiers instead of six LDS-crossbar round trips (`__shfl_xor` compiles to

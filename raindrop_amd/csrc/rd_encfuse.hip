@@ -475,6 +475,7 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
 template <int DC, int HC, bool LEAN>
 __global__ __launch_bounds__(EF_THR) void k_enc_post_fwd(PostFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
+  RD_TOUCH_CODE(31744);                                  // own code -> L2 (rd_common.h; the smallest instantiation is 32.6 KB)
   int M = a.M;
   if (a.mlive) M = min(M, __builtin_amdgcn_readfirstlane(*a.mlive));
   if (pick_rt(M, a.ncu) == 3) post_fwd_body<3, DC, HC, LEAN>(a, esm, M);
@@ -758,6 +759,7 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
 template <int DC, int HC, bool LEAN>
 __global__ __launch_bounds__(EF_THR) void k_enc_pre_bwd(PreBwdArgs a, RiderArgs rider, int nmain) {
   extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
+  RD_TOUCH_CODE(40960);                                  // own code -> L2, the riders' bodies included (smallest instantiation: 41.9 KB)
   if ((int)blockIdx.x >= nmain) { rider_body(rider, (int)blockIdx.x - nmain, esm); return; }
   int M = a.M;
   if (a.mlive) M = min(M, __builtin_amdgcn_readfirstlane(*a.mlive));

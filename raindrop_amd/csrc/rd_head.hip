@@ -26,7 +26,7 @@ namespace rd {
 namespace {
 
 constexpr int HR_THR = 1024, HR_WAVES = 16;
-constexpr int HR_RJ = 16, HR_KI = 4;               // W0 rows per wave (dh <= 256), column slots per lane (dh <= 256)
+constexpr int HR_RJ = 16, HR_KI = 4;               // most W0 rows per wave / 64-column slots per lane (dh <= 256); k_head_rows<RB, NRJ, NKI> fetches what dh needs
 constexpr int HR_LD = 256;                         // row stride of the per-sample vectors in LDS
 constexpr int HR_EMBW = 1024, HR_DS = 64;         // static embedding held in LDS when Fe * d_static <= 1024 and d_static <= 64 (else read in place; keeps the two-sample variant under 64 KB of static LDS)
 
@@ -42,6 +42,7 @@ struct HeadArgs {
                                    // 2: forward recomputed + backward from dlog_in (rd_head_backward)
   const int32_t* plan;             // token plan (rd_plan.h) or null: r / dr hold the live rows only, sample b at rows off[rank[b]] + t
   unsigned long long* stamps;      // debug (tools/head_timing.py): clock64 per phase, thread 0 of workgroup 0
+  int touch_bytes;                 // > 0: bytes of this kernel's own code requested into L2 at its start (rd_common.h touch_own_code)
 };
 static unsigned long long* g_head_stamps = nullptr;
 #define HSTAMP(i)                                                                           \
@@ -54,20 +55,18 @@ struct HeadRows { long row0, rstep; int Tv; };
 __device__ __forceinline__ HeadRows head_rows(const HeadArgs& a, int b) {
   HeadRows h;
   if (a.plan) {
-    const int rk = a.plan[plan::rank_base(a.B) + b];
-    h.row0 = a.plan[plan::off_base() + rk]; h.rstep = 1; h.Tv = a.plan[plan::len_base(a.B) + rk];
+    h.row0 = a.plan[plan::brow_base(a.B, a.T) + b]; h.rstep = 1; h.Tv = a.plan[plan::blen_base(a.B, a.T) + b];
   } else { h.row0 = b; h.rstep = a.B; h.Tv = a.T; }
   return h;
 }
 
-// the same for a workgroup-uniform sample, through the scalar cache: the two dependent plan look-ups do not queue behind the
-// 64 W0 loads per lane that were requested just before (vector memory returns in order)
+// the same for a workgroup-uniform sample, through the scalar cache, from the plan's by-sample arrays (brow / blen: ONE round trip;
+// off[rank[b]] was two dependent ones)
 __device__ __forceinline__ HeadRows head_rows_uniform(const HeadArgs& a, int b) {
   HeadRows h;
   if (a.plan) {
-    const int rk = load_uniform_i32(a.plan + plan::rank_base(a.B) + b);
     int row0, tv;
-    load_uniform_2xi32(a.plan + plan::off_base() + rk, a.plan + plan::len_base(a.B) + rk, row0, tv);
+    load_uniform_2xi32(a.plan + plan::brow_base(a.B, a.T) + b, a.plan + plan::blen_base(a.B, a.T) + b, row0, tv);
     h.row0 = row0; h.rstep = 1; h.Tv = tv;
   } else { h.row0 = b; h.rstep = a.B; h.Tv = a.T; }
   return h;
@@ -75,7 +74,10 @@ __device__ __forceinline__ HeadRows head_rows_uniform(const HeadArgs& a, int b) 
 
 __device__ __forceinline__ float wsum64(float v) { return wave_sum64_dpp(v); }
 
-template <int RB>
+// NRJ / NKI: W0 rows per wave and 64-column slots per lane that are actually FETCHED (16 NRJ >= dh, 64 NKI >= dh).  The generic
+// <16, 4> form requests 256 x 256 clamped elements whatever dh is -- at P19 (dh = 186) 262 KB of address-unit traffic for a 138-KB
+// matrix, and that request phase was the first 5.7 k of the kernel's 30 k cycles (tools/head_timing.py); <12, 3> requests 192 x 192.
+template <int RB, int NRJ, int NKI>
 __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
   __shared__ __attribute__((aligned(16))) float feat[RB][HR_LD], hid[RB][HR_LD], dhid[RB][HR_LD], dfeat[RB][HR_LD];
   __shared__ __attribute__((aligned(16))) float red[HR_WAVES * RB * HR_LD];     // mean-phase and wave partials
@@ -85,36 +87,79 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
   // round trips during which the workgroup's other waves sat at the next barrier (SQ counters: 80 % of the wave cycles waiting)
   __shared__ float w2s[16 * HR_LD], embb[HR_LD], b2s[16], embws[HR_EMBW], stats[RB][HR_DS];
   __shared__ long long ys[RB];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b0 = blockIdx.x * RB;
   const int T = a.T, B = a.B, D = a.D, dh = a.dh, C = a.C, D4 = D >> 2;
 
   HSTAMP(0);
-  // ---- W0 rows of this wave -> registers (requested first: they are needed after the masked mean) ----
-  // UNCONDITIONAL loads from clamped addresses: rows j >= dh are never used (wave-uniform tests below) and columns k >= dh only
-  // reach accumulator slots nobody reads.  As conditional loads (a phi of {0, value} each) the compiler waited for them one
-  // group at a time -- two dozen dependent round trips at the head of a kernel whose 256 workgroups all run at once, so its
-  // duration IS one workgroup's latency chain.
-  float w[HR_RJ][HR_KI];
-#pragma unroll
-  for (int jj = 0; jj < HR_RJ; ++jj) {
-    const int jc = min(wave + HR_WAVES * jj, dh - 1);
-#pragma unroll
-    for (int i = 0; i < HR_KI; ++i) w[jj][i] = a.w0[(long)jc * dh + min(lane + 64 * i, dh - 1)];
-  }
-  // small operands -> LDS: ALL requests first (unconditional, clamped indices), then the stores.  Written as `if (tid < n) lds[tid] =
+  RD_TOUCH_CODE(a.touch_bytes);
+  // Request order = the order the data is NEEDED (vector memory returns in order): small operands (they go out while the plan
+  // look-up is on its way through the scalar cache), the sample's rows for the masked mean, then W0, which nothing reads before
+  // the mean is reduced.  Round 3 had W0 first: the mean then waited for all of W0 (10.4 k cycles into the kernel).
+  // ---- small operands: ALL requests first (unconditional, clamped indices), stored to LDS below.  Written as `if (tid < n) lds[tid] =
   // g[tid];` per array each was its own load -> wait -> store block: seven dependent round trips at the top of the kernel.
   const bool emb_lds = a.Fe > 0 && a.Fe * a.ds <= HR_EMBW && a.ds <= HR_DS;
-  {
-    const int nw2 = C * dh;
-    const float pb0 = a.b0[min(tid, dh - 1)], pw2 = a.w2[min(tid, nw2 - 1)], pb2 = a.b2[min(tid, C - 1)];
-    const long long py = a.mode == 0 ? a.y[min(b0 + min(tid, RB - 1), B - 1)] : 0;   // uniform
-    float pew = 0.f, peb = 0.f, pst = 0.f;
-    if (emb_lds) {                                     // uniform
-      const int ne = a.Fe * a.ds, ns = RB * a.ds, ts = min(tid, ns - 1), rs = ts / a.ds;
-      pew = a.emb_w[min(tid, ne - 1)]; peb = a.emb_b[min(tid, a.Fe - 1)];
-      pst = a.stat[(long)min(b0 + rs, B - 1) * a.ds + (ts - rs * a.ds)];
+  const int nw2 = C * dh;
+  const float pb0 = a.b0[min(tid, dh - 1)], pw2 = a.w2[min(tid, nw2 - 1)], pb2 = a.b2[min(tid, C - 1)];
+  const long long py = a.mode == 0 ? a.y[min(b0 + min(tid, RB - 1), B - 1)] : 0;   // uniform
+  float pew = 0.f, peb = 0.f, pst = 0.f;
+  if (emb_lds) {                                     // uniform
+    const int ne = a.Fe * a.ds, ns = RB * a.ds, ts = min(tid, ns - 1), rs = ts / a.ds;
+    pew = a.emb_w[min(tid, ne - 1)]; peb = a.emb_b[min(tid, a.Fe - 1)];
+    pst = a.stat[(long)min(b0 + rs, B - 1) * a.ds + (ts - rs * a.ds)];
+  }
+  // ---- masked mean: thread = (sample r, column quad c4, time group tg); four steps per pass requested together (clamped rows, the
+  // step's validity applied to the value).  Threads beyond the ntg groups request a duplicate and add nothing.
+  const int P = RB * D4;
+  const int ntg = min(HR_THR / P, 16);
+  const int pair = tid % P, tg = tid / P;
+  const int mr = pair / D4, mc4 = pair - mr * D4, mb = b0 + mr;
+  const bool mlive = tg < ntg && mb < B;
+  // the sample's length (for 1 / (len + 1)) and its rows.  One sample per workgroup: three scalar loads behind ONE wait -- as a
+  // vector load of a uniform address the compiler read the length back with v_readfirstlane at once, i.e. behind `vmcnt(0)`.
+  long long plen; HeadRows hr;
+  if (RB == 1) {
+    const int bu = __builtin_amdgcn_readfirstlane(b0);                 // b0 < B: the grid is B workgroups
+    uint64_t lv; int row0 = bu, tv = T;
+    if (a.plan) load_uniform_u64_2xi32(reinterpret_cast<const uint64_t*>(a.lengths) + bu, a.plan + plan::brow_base(B, T) + bu,
+                                       a.plan + plan::blen_base(B, T) + bu, lv, row0, tv);
+    else lv = load_uniform_u64(reinterpret_cast<const uint64_t*>(a.lengths) + bu);
+    plen = (long long)lv;
+    hr.row0 = row0; hr.rstep = a.plan ? 1 : B; hr.Tv = tv;
+  } else {
+    plen = a.lengths[min(b0 + min(tid, RB - 1), B - 1)];
+    hr = head_rows(a, min(mb, B - 1));
+  }
+  float4 mv[4]; bool mok[4]; unsigned char mk[4] = {0, 0, 0, 0};
+  auto request_rows = [&](int t0) {
+    if (!a.plan) {                                                     // uniform: the padded layout's per-step mask bytes
+#pragma unroll
+      for (int u = 0; u < 4; ++u) mk[u] = a.mask[(long)min(mb, B - 1) * T + min(t0 + u * ntg, T - 1)];
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * ntg, tc = max(min(t, hr.Tv - 1), 0);
+      mok[u] = mlive && t < hr.Tv;
+      const long row = mok[u] ? hr.row0 + (long)tc * hr.rstep : 0;     // row 0 of r always exists
+      mv[u] = *reinterpret_cast<const float4*>(a.r + row * D + 4 * mc4);
+    }
+  };
+  request_rows(min(tg, ntg - 1));
+  __builtin_amdgcn_sched_barrier(0);                       // the rows' requests stay IN FRONT of W0's (the fourth was moved behind them)
+  // ---- W0 rows of this wave -> registers.  UNCONDITIONAL loads from clamped addresses: rows j >= dh are never used and columns
+  // k >= dh only meet zeros (hid) or reach accumulator slots nobody reads (dfeat).  As conditional loads (a phi of {0, value} each)
+  // the compiler waited for them one group at a time -- two dozen dependent round trips at the head of a kernel whose 256
+  // workgroups all run at once, so its duration IS one workgroup's latency chain.
+  float w[NRJ][NKI];
+#pragma unroll
+  for (int jj = 0; jj < NRJ; ++jj) {
+    const int jc = min(wave + HR_WAVES * jj, dh - 1);
+#pragma unroll
+    for (int i = 0; i < NKI; ++i) w[jj][i] = a.w0[(long)jc * dh + min(lane + 64 * i, dh - 1)];
+  }
+  HSTAMP(1);
+  // ---- small operands -> LDS ----
+  {
     if (tid < HR_LD) b0s[tid] = pb0;
     if (tid < nw2) w2s[tid] = pw2;
     if (tid < C) b2s[tid] = pb2;
@@ -127,37 +172,26 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
       for (int i = tid + HR_THR; i < ne; i += HR_THR) embws[i] = a.emb_w[i];          // HR_EMBW <= HR_THR: never runs; kept for safety
     }
     for (int i = tid + HR_THR; i < nw2; i += HR_THR) w2s[i] = a.w2[i];                // C * dh > 1024 only
+    if (tid < RB) invl[tid] = (b0 + tid < B) ? 1.0f / (float)(plen + 1) : 0.f;
   }
-  HSTAMP(1);
-  // ---- masked mean: thread = (sample r, column quad c4, time group tg) ----
-  const int P = RB * D4;
-  const int ntg = min(HR_THR / P, 16);
+  // ---- the rows: first pass (in flight since the top), further passes for T > 4 ntg steps ----
   {
-    const int pair = tid % P, tg = tid / P;
-    const int r = pair / D4, c4 = pair - r * D4, b = b0 + r;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tg < ntg && b < B) {
-      const HeadRows hr = RB == 1 ? head_rows_uniform(a, __builtin_amdgcn_readfirstlane(b)) : head_rows(a, b);
-      // four steps per pass, requested together (clamped rows, the step's validity applied to the value): one round trip per
-      // pass instead of one per step
-      for (int t0 = tg; t0 < hr.Tv; t0 += 4 * ntg) {
-        float4 v[4]; bool ok[4];
+    // the first pass is NOT a loop iteration: inside one loop the waits are computed for the back edge (only that pass's four
+    // requests outstanding = vmcnt(0) at the last use), which on entry would also wait for all of W0
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int t = t0 + u * ntg, tc = min(t, hr.Tv - 1);
-          ok[u] = t < hr.Tv && (a.plan || !a.mask[(long)b * T + tc]);
-          v[u] = *reinterpret_cast<const float4*>(a.r + (hr.row0 + (long)tc * hr.rstep) * D + 4 * c4);
-        }
+    for (int u = 0; u < 4; ++u)
+      if (mok[u] && !mk[u]) { s.x += mv[u].x; s.y += mv[u].y; s.z += mv[u].z; s.w += mv[u].w; }
+    for (int pass = 1; pass * 4 * ntg < T; ++pass) {       // T > 4 ntg steps only (uniform trip count; the flags drop steps past the sample's length)
+      request_rows(min(tg, ntg - 1) + pass * 4 * ntg);
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (ok[u]) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
-      }
+      for (int u = 0; u < 4; ++u)
+        if (mok[u] && !mk[u]) { s.x += mv[u].x; s.y += mv[u].y; s.z += mv[u].z; s.w += mv[u].w; }
     }
     if (tg < ntg) *reinterpret_cast<float4*>(red + ((size_t)tg * P + pair) * 4) = s;
-    if (tid < RB) invl[tid] = (b0 + tid < B) ? 1.0f / (float)(a.lengths[b0 + tid] + 1) : 0.f;
   }
   HSTAMP(2);
-  __syncthreads();
+  lds_barrier();                                           // LDS only: W0 stays in flight (no thread reads global memory another wrote)
   HSTAMP(3);
   if (tid < P) {
     const int r = tid / D4, c4 = tid - r * D4;
@@ -184,27 +218,53 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
     }
     feat[r][D + j] = s;
   }
-  __syncthreads();
+  lds_barrier();
   HSTAMP(4);
-  // ---- hid = relu(W0 feat + b0): wave w owns outputs j = w, w+16, ...; lanes split the reduction ----
+  // ---- hid = relu(W0 feat + b0): wave w owns outputs j = w, w+16, ...; lanes split the reduction.  Branch-free over the wave's
+  // rows: behind `if (j < dh)` every row was its own basic block and the NRJ wave sums (six dependent DPP steps each) ran one after
+  // the other -- 7.3 k cycles for 16 rows; as straight-line code the scheduler interleaves the independent chains. ----
+  {
+    float fv[RB][NKI];
 #pragma unroll
-  for (int jj = 0; jj < HR_RJ; ++jj) {
-    const int j = wave + HR_WAVES * jj;
-    if (j < dh) {                                      // wave-uniform
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int i = 0; i < NKI; ++i) {
+        const int k = lane + 64 * i;
+        const float f = feat[r][k];                        // k < HR_LD always; columns >= dh hold nothing
+        fv[r][i] = k < dh ? f : 0.f;
+      }
+    float ps[NRJ][RB];
+#pragma unroll
+    for (int jj = 0; jj < NRJ; ++jj)
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
         float p = 0.f;
 #pragma unroll
-        for (int i = 0; i < HR_KI; ++i) {
-          const int k = lane + 64 * i;
-          if (k < dh) p += feat[r][k] * w[jj][i];
-        }
-        p = wsum64(p);
-        if (lane == 0) hid[r][j] = fmaxf(p + b0s[j], 0.f);
+        for (int i = 0; i < NKI; ++i) p += fv[r][i] * w[jj][i];
+        ps[jj][r] = p;
+      }
+    // the wave sums step by step ACROSS the rows (rd_common.h wave_sum64_dpp, same order of additions per row): as NRJ calls in a
+    // row the chains were emitted one after the other on one register
+#define HR_DPP_STEP(ctrl, rmask)                                                                                              \
+  _Pragma("unroll") for (int jj = 0; jj < NRJ; ++jj) _Pragma("unroll") for (int r = 0; r < RB; ++r)                           \
+    ps[jj][r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ps[jj][r]), ctrl, rmask, 0xf, false))
+    HR_DPP_STEP(0x111, 0xf); HR_DPP_STEP(0x112, 0xf); HR_DPP_STEP(0x114, 0xf); HR_DPP_STEP(0x118, 0xf);
+    HR_DPP_STEP(0x142, 0xa); HR_DPP_STEP(0x143, 0xc);
+#undef HR_DPP_STEP
+#pragma unroll
+    for (int jj = 0; jj < NRJ; ++jj)
+#pragma unroll
+      for (int r = 0; r < RB; ++r) ps[jj][r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ps[jj][r]), 63));
+#pragma unroll
+    for (int jj = 0; jj < NRJ; ++jj) {
+      const int j = wave + HR_WAVES * jj;
+      if (lane == 0 && j < dh) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) hid[r][j] = fmaxf(ps[jj][r] + b0s[j], 0.f);
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
   HSTAMP(5);
   // ---- logits: wave = (r, c) ----
   for (int o = wave; o < RB * C; o += HR_WAVES) {
@@ -214,7 +274,7 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
     p = wsum64(p);
     if (lane == 0) lg[r][c] = p + b2s[c];
   }
-  __syncthreads();
+  lds_barrier();
   HSTAMP(6);
   if (a.mode == 1) {                                   // rd_head_forward: the logits are the result
     if (tid < RB * C && b0 + tid / C < B) a.logits[(long)(b0 + tid / C) * C + tid % C] = lg[tid / C][tid % C];
@@ -250,7 +310,7 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
   } else if (tid < RB) {
     for (int c = 0; c < C; ++c) dl[tid][c] = 0.f;
   }
-  __syncthreads();
+  lds_barrier();
   HSTAMP(7);
   // ---- dhid = (dlogits W2) gated by hid > 0: thread = (r, j); rows out to the workspace for the weight gradients ----
   for (int e = tid; e < RB * dh; e += HR_THR) {
@@ -266,57 +326,56 @@ __global__ __launch_bounds__(HR_THR) void k_head_rows(HeadArgs a) {
       a.feat[(long)b * dh + j] = feat[r][j];
     }
   }
-  __syncthreads();
+  lds_barrier();
   HSTAMP(8);
   // ---- dfeat = dhid W0: the same registers; this wave's rows give a partial for every column, waves combined in order ----
   {
-    float acc[RB][HR_KI];
+    float acc[RB][NKI];
 #pragma unroll
     for (int r = 0; r < RB; ++r)
 #pragma unroll
-      for (int i = 0; i < HR_KI; ++i) acc[r][i] = 0.f;
+      for (int i = 0; i < NKI; ++i) acc[r][i] = 0.f;
 #pragma unroll
-    for (int jj = 0; jj < HR_RJ; ++jj) {
-      const int j = wave + HR_WAVES * jj;
-      if (j < dh) {
+    for (int jj = 0; jj < NRJ; ++jj) {
+      const int j = wave + HR_WAVES * jj;                  // < HR_LD; rows >= dh contribute zero (their W0 registers hold a clamped duplicate)
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-          const float d = dhid[r][j];
+      for (int r = 0; r < RB; ++r) {
+        const float dv = dhid[r][j];
+        const float d = j < dh ? dv : 0.f;
 #pragma unroll
-          for (int i = 0; i < HR_KI; ++i) acc[r][i] += d * w[jj][i];
-        }
+        for (int i = 0; i < NKI; ++i) acc[r][i] += d * w[jj][i];
       }
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r)
 #pragma unroll
-      for (int i = 0; i < HR_KI; ++i) red[((size_t)wave * RB + r) * HR_LD + lane + 64 * i] = acc[r][i];
+      for (int i = 0; i < NKI; ++i) red[((size_t)wave * RB + r) * HR_LD + lane + 64 * i] = acc[r][i];
   }
-  __syncthreads();
+  lds_barrier();
   HSTAMP(9);
   for (int e = tid; e < RB * HR_LD; e += HR_THR) {
     const int r = e / HR_LD, k = e - r * HR_LD;
     float s = 0.f;
+    if (k < 64 * NKI) {                                    // columns beyond the fetched slots were never written (and are >= dh)
 #pragma unroll
-    for (int q = 0; q < HR_WAVES; ++q) s += red[((size_t)q * RB + r) * HR_LD + k];
+      for (int q = 0; q < HR_WAVES; ++q) s += red[((size_t)q * RB + r) * HR_LD + k];
+    }
     dfeat[r][k] = s;
     const int b = b0 + r;
     if (k >= D && k < dh && b < B) a.demb[(long)b * a.Fe + (k - D)] = s;   // gradient of the static embedding's output
   }
-  __syncthreads();
+  lds_barrier();
   HSTAMP(10);
   // ---- masked mean backward: dr[t,b,:] = valid ? dfeat[b,:D] / (len + 1) : 0   (code/models_rd.py:379, autograd) ----
-  HeadRows hr1{};                                                        // RB == 1: the workgroup's one sample, looked up once
-  if (RB == 1 && b0 < B) hr1 = head_rows_uniform(a, b0);
   for (int e = tid; e < RB * T * D4; e += HR_THR) {
     const int c4 = e % D4, rt = e / D4;
     const int t = rt % T, r = rt / T, b = b0 + r;
     if (b >= B) continue;
-    const HeadRows hr = RB == 1 ? hr1 : head_rows(a, b);
-    if (t >= hr.Tv) continue;                                           // token plan: padded steps have no row
+    const HeadRows hq = RB == 1 ? hr : head_rows(a, b);                  // RB == 1: the look-up of the top of the kernel
+    if (t >= hq.Tv) continue;                                           // token plan: padded steps have no row
     const float il = (!a.plan && a.mask[(long)b * T + t]) ? 0.f : invl[r];
     const float4 v = *reinterpret_cast<const float4*>(&dfeat[r][4 * c4]);
-    *reinterpret_cast<float4*>(a.dr + (hr.row0 + (long)t * hr.rstep) * D + 4 * c4) = make_float4(v.x * il, v.y * il, v.z * il, v.w * il);
+    *reinterpret_cast<float4*>(a.dr + (hq.row0 + (long)t * hq.rstep) * D + 4 * c4) = make_float4(v.x * il, v.y * il, v.z * il, v.w * il);
   }
   HSTAMP(11);
 }
@@ -412,10 +471,15 @@ static int head_launch(int mode, const rd_shape* s, int32_t D, int32_t d_static,
   a.dlog = a.demb + (size_t)B * dh; a.lossr = a.dlog + (size_t)B * C;
   a.T = s->T; a.B = B; a.D = D; a.ds = d_static; a.Fe = Fe; a.dh = dh; a.C = C;
   a.plan = token_plan(); a.stamps = g_head_stamps;
-  // one sample per workgroup (B workgroups: every CU busy at B = 256); MEASURED in-step: 1.077 -> 1.056 ms/step against RB = 2
-  static const int rb1 = [] { const char* e = getenv("RD_HEAD_RB1"); return e ? atoi(e) : 1; }();
-  if (rb1) hipLaunchKernelGGL(k_head_rows<1>, dim3(B), dim3(HR_THR), 0, st, a);
-  else hipLaunchKernelGGL(k_head_rows<2>, dim3(cdiv(B, 2)), dim3(HR_THR), 0, st, a);
+  // own-code touch: 14.5 KB of the 15.4 KB <1, 12, 3> kernel, 16 KB of the 16.9 KB generic one (tests/test_kernel_resources.py keeps the
+  // constants below the code lengths); RD_CODE_TOUCH=0 switches it off (A/B)
+  static const int touch = [] { const char* e = getenv("RD_CODE_TOUCH"); return e ? atoi(e) : 1; }();
+  // one sample per workgroup (B workgroups: every CU busy at B = 256); two samples per workgroup measured inside the noise twice
+  // (rounds 2 and 4) and is no longer built (its hid phase spilled at 128 registers).
+  // W0 fetched as 192 x 192 where that covers it (P19: dh = 186), else 256 x 256 (RD_HEAD_NARROW=0: always the latter)
+  static const int narrow = [] { const char* e = getenv("RD_HEAD_NARROW"); return e ? atoi(e) : 1; }();
+  if (narrow && dh <= 192) { a.touch_bytes = touch ? 14848 : 0; hipLaunchKernelGGL((k_head_rows<1, 12, 3>), dim3(B), dim3(HR_THR), 0, st, a); }
+  else { a.touch_bytes = touch ? 16384 : 0; hipLaunchKernelGGL((k_head_rows<1, HR_RJ, HR_KI>), dim3(B), dim3(HR_THR), 0, st, a); }
   int rc = check_launch("k_head_rows");
   if (rc || mode == 1) return rc;
   HwArgs h{};

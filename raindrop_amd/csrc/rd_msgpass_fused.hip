@@ -454,6 +454,7 @@ __device__ __forceinline__ void tstore_leftover_planes(const __bf16* Ph, const _
 template <int RT, int FC, int TC>
 __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  RD_TOUCH_CODE(14336);                                  // own code -> L2 (rd_common.h; the smallest instantiation is 15.5 KB)
   constexpr int ROWS = RT * 16;
   constexpr bool ALIAS = RT > 3;                         // F > 48: the fp32 copy of X has to share the Y planes' space
   constexpr size_t PLANES = (size_t)4 * ROWS * LDX * sizeof(__bf16);
@@ -699,6 +700,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
 template <int RT, int FC, int TC>
 __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  RD_TOUCH_CODE(11264);                                  // own code -> L2 (the smallest instantiation is 12.5 KB)
   constexpr int ROWS = RT * 16;
   constexpr bool ALIAS = RT > 3;
   constexpr size_t PLANES = (size_t)4 * ROWS * LDX * sizeof(__bf16);

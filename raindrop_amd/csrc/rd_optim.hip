@@ -9,6 +9,7 @@ namespace {
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g,
                                               float* __restrict__ m, float* __restrict__ v, long n, float lr,
                                               float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+  RD_TOUCH_CODE_FIRST(2432, blockIdx.x, 64);             // own code -> L2 by the first workgroups (rd_common.h; 3.0 KB kernel)
   const long i4 = (blockIdx.x * (long)blockDim.x + threadIdx.x) * 4;
   if (i4 >= n) return;
   const float step_size = lr / bc1;

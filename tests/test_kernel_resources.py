@@ -77,3 +77,23 @@ def test_resource_remark_parser_keeps_real_warnings():
     usage, rest = build._parse_resource_remarks(err)
     assert usage == {"_Z1kPf": {"vgprs": 37, "agprs": 0, "scratch": 12, "occupancy": 8, "vgpr_spill": 3, "lds": 4096}}
     assert "unused variable" in rest and "int x;" in rest and "remark" not in rest and "float b1" not in rest
+
+
+# (kernel name fragment, bytes of its own code the kernel requests into L2 at its start: rd_common.h touch_own_code)
+CODE_TOUCH = [("k_msg_fwd_fused", 14336), ("k_msg_bwd_fused", 11264), ("k_attn_fwd_fused", 12800), ("k_attn_bwd_fused", 28672),
+              ("k_enc_post_fwd", 31744), ("k_enc_pre_bwd", 40960), ("4k_dwE", 6144), ("k_dw_reduce", 9216), ("6k_adam", 2432),
+              ("k_wsplit", 4096), ("5k_twgI", 7936), ("k_head_rowsILi1ELi12ELi3E", 14848), ("k_head_rowsILi1ELi16ELi4E", 16384)]
+
+
+@pytest.mark.parametrize("frag,touch", CODE_TOUCH, ids=[c[0] for c in CODE_TOUCH])
+def test_own_code_touch_stays_inside_the_kernel(frag, touch):
+    """touch_own_code reads [pc, pc + bytes) right behind the kernel's first instructions: every instantiation must be longer than
+    that (384 bytes of slack for the prologue in front of the s_getpc), and the constant in the source must be the one listed here."""
+    import os
+    import re
+    build.build(verbose=False)
+    sizes = [v for k, v in build.kernel_code_sizes().items() if frag in k]
+    assert sizes, frag
+    assert min(sizes) >= touch + 384, (frag, min(sizes), touch)
+    src = "".join(open(os.path.join(build.CSRC, f)).read() for f in sorted(os.listdir(build.CSRC)) if f.endswith(".hip"))
+    assert re.search(r"(RD_TOUCH_CODE(_FIRST)?\(%d\b|touch \? %d :)" % (touch, touch), src), (frag, touch)

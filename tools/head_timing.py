@@ -27,7 +27,7 @@ ts.run()
 torch.cuda.synchronize()
 lib.rd_debug_set_head_stamps(None)
 s = stamps.cpu().tolist()
-N = ["start", "W0 + small operands requested", "masked-mean rows summed", "barrier", "mean reduced + emb; barrier", "hid (W0 feat); barrier",
+N = ["start", "small operands, rows, W0 requested", "masked-mean rows summed", "barrier", "mean reduced + emb; barrier", "hid (W0 feat); barrier",
      "logits; barrier", "softmax / loss; barrier", "dhid + workspace rows; barrier", "dfeat partials; barrier", "dfeat reduced; barrier", "dr rows out"]
 t0, prev = s[0], s[0]
 for i, name in enumerate(N):
