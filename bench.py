@@ -363,6 +363,37 @@ def k1_roofline_events(model, cfg, batch, reps=20):
     return _roofline_dict(B, F, K, fwd, bwd, "eager launches timed with HIP events (includes host launch gaps)")
 
 
+def box_kind():
+    """Which kind of box ran this line (DESIGN.md "Box variance"): clock64 ticks per 64-byte line of COLD straight-line code (32 KB, one
+    wave, right after a 1-GB fill) and of the same code warm.  The pool's fast boxes fetch instructions ahead (~80 cold / ~50 warm),
+    the slow ones do not (~400-450 / ~75-95).  Never allowed to cost the line."""
+    try:
+        import ctypes
+        from raindrop_amd import _lib
+        lib = _lib.load()
+        fn = lib.rd_debug_ifetch_probe
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        fn.restype = None
+        t = torch.zeros(1, dtype=torch.int64, device="cuda")
+        scr = torch.zeros(64, dtype=torch.float32, device="cuda")
+        big = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        out = []
+        for _ in range(2):
+            big.fill_(1.0); torch.cuda.synchronize()
+            fn(t.data_ptr(), scr.data_ptr(), st); torch.cuda.synchronize()
+            cold = int(t.item())
+            fn(t.data_ptr(), scr.data_ptr(), st); torch.cuda.synchronize()
+            out.append((cold, int(t.item())))
+        del big
+        cold, warm = min(o[0] for o in out) / 512.0, min(o[1] for o in out) / 512.0
+        return {"cold_code_ticks_per_64B_line": round(cold, 1), "warm_code_ticks_per_64B_line": round(warm, 1),
+                "kind": "fast (instruction fetch looks ahead)" if cold < 200 else "slow (cold code is fetched one trip to memory at a time)",
+                "how": "32 KB of straight-line dependent v_fma_f32, one wave, clock64; cold = right after a 1-GB fill"}
+    except Exception as e:                                               # pragma: no cover
+        return {"error": repr(e)[:200]}
+
+
 K1_SOURCES = ("rd_msgpass_fused.hip", "rd_msgpass_dw.hip", "rd_msgpass.hip", "rd_k1_layout.h")
 
 
@@ -882,6 +913,7 @@ def main():
             except Exception as e:                                       # pragma: no cover
                 line["roofline"] = {"error": repr(e)[:200]}
             if world == 1:
+                line["config"]["box"] = box_kind()
                 line["config"]["fp32_mode_ms_per_step"] = fp32_mode_ms(args)
                 if token_plan_on:
                     line["config"]["padded_layout_ms_per_step"] = padded_layout_ms(args)

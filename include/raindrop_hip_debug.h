@@ -18,6 +18,7 @@ void rd_debug_set_gemm_stamps(void* device_u64);     /* k_gemm_bf16x3           
 void rd_debug_set_encfuse_stamps(void* device_u64);  /* k_enc_post_fwd / k_enc_pre_bwd       (tools/encfuse_timing.py) */
 void rd_debug_set_head_stamps(void* device_u64);     /* k_head_rows                          (tools/head_timing.py)    */
 void rd_debug_set_attnfuse_stamps(void* device_u64); /* k_attn_fwd_fused / k_attn_bwd_fused  (tools/attnfuse_timing.py) */
+void rd_debug_ifetch_probe(void* ticks_device_u64, void* scratch_64_floats, void* stream);   /* 32 KB of straight-line code, one wave: clock64 ticks (bench.py config.box; tools/probe_clocks.hip) */
 void rd_debug_set_splitk_want(int workgroups);       /* target workgroup count of the split-K weight-gradient plan     */
 
 #ifdef __cplusplus

@@ -36,10 +36,28 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
   }
 }
 
+// What kind of box is this?  (DESIGN.md "Box variance")  32 KB of straight-line code -- 4096 dependent 8-byte v_fma_f32, nothing the
+// compiler can fold --, one wave, clock64 around it: cold (its code in no cache) about 80 ticks per 64-byte line where the hardware
+// fetches instructions ahead, 400-450 where it does not; warm 45-55 / 75-95.  tools/probe_clocks.hip is the standalone form.
+__global__ __launch_bounds__(64) void k_ifetch_probe(float* out, unsigned long long* t, float a, float b) {
+  float x = (float)threadIdx.x;
+  const unsigned long long c0 = clock64();
+  asm volatile(".rept 4096\n\tv_fma_f32 %0, %0, %1, %2\n\t.endr" : "+v"(x) : "v"(a), "v"(b));
+  const unsigned long long c1 = clock64();
+  out[threadIdx.x] = x;
+  if (threadIdx.x == 0) t[0] = c1 - c0;
+}
+
 }  // namespace
 }  // namespace rd
 
 using namespace rd;
+
+// not part of the ABI (include/raindrop_hip_debug.h): ticks of the probe block -> ticks_dev[0]; scratch_dev: 64 floats
+extern "C" void rd_debug_ifetch_probe(void* ticks_dev, void* scratch_dev, void* stream) {
+  hipLaunchKernelGGL(k_ifetch_probe, dim3(1), dim3(64), 0, (hipStream_t)stream, (float*)scratch_dev, (unsigned long long*)ticks_dev,
+                     1.0000001f, 0.5f);
+}
 
 extern "C" int rd_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                             float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
