@@ -10,7 +10,7 @@
 // Why: the head is 256 rows x 186 features -- about 50 MFLOP -- but as separate operators it was 15 launches of
 // latency-bound kernels (three forward products, the loss, two input-gradient and three weight-gradient products
 // with their split-K reduces, the masked mean and its backward): ~114 us of a 0.85 ms step at ~4.5 us of fixed cost per
-// launch.  Here a workgroup owns RB samples end to end:
+// launch.  Here a workgroup owns one sample (RB = 1; the template keeps the count) end to end:
 //   k_head_rows   masked mean -> emb -> W0 (+ReLU) -> W2 -> softmax/loss -> dlogits -> dhid -> dfeat -> dr.
 //                 W0 is read ONCE per workgroup, coalesced, into registers: wave w holds rows j = w, w+16, ... with lane l
 //                 owning columns l, l+64, ...; the forward product reduces over lanes (one wave sum per output), the
@@ -28,7 +28,7 @@ namespace {
 constexpr int HR_THR = 1024, HR_WAVES = 16;
 constexpr int HR_RJ = 16, HR_KI = 4;               // most W0 rows per wave / 64-column slots per lane (dh <= 256); k_head_rows<RB, NRJ, NKI> fetches what dh needs
 constexpr int HR_LD = 256;                         // row stride of the per-sample vectors in LDS
-constexpr int HR_EMBW = 1024, HR_DS = 64;         // static embedding held in LDS when Fe * d_static <= 1024 and d_static <= 64 (else read in place; keeps the two-sample variant under 64 KB of static LDS)
+constexpr int HR_EMBW = 1024, HR_DS = 64;         // static embedding held in LDS when Fe * d_static <= 1024 and d_static <= 64 (else read in place)
 
 struct HeadArgs {
   const float* r; const uint8_t* mask; const int64_t* lengths; const float* stat;
