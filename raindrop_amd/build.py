@@ -134,14 +134,6 @@ def build_variant(name, extra):
     return lib
 
 
-if __name__ == "__main__":
-    if "--variant" in sys.argv:                     # python -m raindrop_amd.build --variant philox -DRD_RNG_PHILOX
-        i = sys.argv.index("--variant")
-        build_variant(sys.argv[i + 1], sys.argv[i + 2:])
-    else:
-        build(force="--force" in sys.argv)
-
-
 def kernel_code_sizes(lib=None):
     """{mangled kernel name: code bytes} of every gfx950 kernel in the built library: the clang offload bundles inside the shared
     object ("__CLANG_OFFLOAD_BUNDLE__", one per translation unit) each hold an AMDGPU ELF; its FUNC symbols' sizes are the kernels'
@@ -177,3 +169,11 @@ def kernel_code_sizes(lib=None):
                         end = e.index(b"\0", stroff + name)
                         out[e[stroff + name:end].decode()] = sz
     return out
+
+
+if __name__ == "__main__":
+    if "--variant" in sys.argv:                     # python -m raindrop_amd.build --variant philox -DRD_RNG_PHILOX
+        i = sys.argv.index("--variant")
+        build_variant(sys.argv[i + 1], sys.argv[i + 2:])
+    else:
+        build(force="--force" in sys.argv)

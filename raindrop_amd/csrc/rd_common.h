@@ -118,6 +118,16 @@ __device__ __forceinline__ void touch_own_code(int tid, int bytes) {
 #define RD_TOUCH_CODE_FIRST(bytes, lin, first) ::rd::touch_own_code((int)threadIdx.x, (int)(lin) < (first) ? (bytes) : 0)
 #endif
 
+// The kernels OUTSIDE the P19 step (tiled / panel GEMMs, row-block products, multi-tile and padded-layout attention, LayerNorm
+// kernels: P12, PAM, SYN256, the eager surface) carry the same prologue behind -DRD_TOUCH_ALL only: written and size-checked
+// (tests/test_kernel_resources.py) in round 4 after the GPU budget was spent, NOT yet measured -- build the A/B library with
+// `python -m raindrop_amd.build --variant touchall -DRD_TOUCH_ALL`, compare on a slow box, then make it the default.
+#if defined(RD_TOUCH_ALL) && !defined(RD_NO_CODE_TOUCH)
+#define RD_TOUCH_CODE_X(bytes, lin, first) ::rd::touch_own_code((int)threadIdx.x, (int)(lin) < (first) ? (bytes) : 0)
+#else
+#define RD_TOUCH_CODE_X(bytes, lin, first) ((void)0)
+#endif
+
 // a uniform 64-bit value and two uniform 32-bit ones, three independent scalar loads behind one wait
 __device__ __forceinline__ void load_uniform_u64_2xi32(const uint64_t* l, const int32_t* p, const int32_t* q, uint64_t& v, int& x, int& y) {
   asm volatile("s_load_dwordx2 %0, %3, 0x0\n\ts_load_dword %1, %4, 0x0\n\ts_load_dword %2, %5, 0x0\n\ts_waitcnt lgkmcnt(0)"

@@ -153,6 +153,7 @@ __device__ __forceinline__ void rg_load_panel_part(RPanel<KP, RG_NJ>& p, const _
 
 template <int KC, int RG_ROWS, int RG_NJ, bool LN, bool LNB, int WV>
 __global__ __launch_bounds__(64 * WV) void k_rowgemm(RowGemmArgs a) {
+  RD_TOUCH_CODE_X(4096, blockIdx.x, 512);
   // SPLIT (the K = 3D = 456 input gradient of the QKV projection): the 15-step weight panel is 120 VGPRs -- with them the kernel
   // needs 178, ONE 8-wave workgroup per CU, and the 266 32-row workgroups of 8497 live rows run in two rounds on 256 CUs (the
   // second for 10 of them).  Holding half a panel at a time keeps the kernel under 128 registers: two workgroups per CU, one round.

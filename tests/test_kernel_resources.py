@@ -97,3 +97,24 @@ def test_own_code_touch_stays_inside_the_kernel(frag, touch):
     assert min(sizes) >= touch + 384, (frag, min(sizes), touch)
     src = "".join(open(os.path.join(build.CSRC, f)).read() for f in sorted(os.listdir(build.CSRC)) if f.endswith(".hip"))
     assert re.search(r"(RD_TOUCH_CODE(_FIRST)?\(%d\b|touch \? %d :)" % (touch, touch), src), (frag, touch)
+
+
+# the same prologue in the kernels outside the P19 step, compiled in behind -DRD_TOUCH_ALL only (rd_common.h RD_TOUCH_CODE_X: written
+# in round 4 after the GPU budget was spent, to be measured before it becomes the default).  The lengths are checked against the
+# DEFAULT build's code sizes (the kernels are a few dozen bytes longer with the prologue).
+CODE_TOUCH_X = [("6k_gemmI", 25088), ("13k_gemm_bf16x3I", 28160), ("12k_gemm_panelI", 28160), ("9k_rowgemmI", 4096),
+                ("19k_attn_fwd_one_b16wI", 5632), ("19k_attn_bwd_one_b16wI", 6144), ("14k_attn_fwd_b16I", 6912),
+                ("17k_attn_bwd_dq_b16I", 7040), ("18k_attn_bwd_dkv_b16I", 6016), ("14k_add_ln_fwd_vE", 5120), ("10k_ln_bwd_rI", 5120),
+                ("10k_ln_bwd_vE", 6144)]
+
+
+@pytest.mark.parametrize("frag,touch", CODE_TOUCH_X, ids=[c[0] for c in CODE_TOUCH_X])
+def test_optional_code_touch_lengths_fit(frag, touch):
+    import os
+    import re
+    build.build(verbose=False)
+    sizes = [v for k, v in build.kernel_code_sizes().items() if frag in k]
+    assert sizes, frag
+    assert min(sizes) >= touch + 384, (frag, min(sizes), touch)
+    src = "".join(open(os.path.join(build.CSRC, f)).read() for f in sorted(os.listdir(build.CSRC)) if f.endswith(".hip"))
+    assert re.search(r"RD_TOUCH_CODE_X\(%d\b" % touch, src), (frag, touch)
