@@ -139,35 +139,65 @@ def kernel_code_sizes(lib=None):
     object ("__CLANG_OFFLOAD_BUNDLE__", one per translation unit) each hold an AMDGPU ELF; its FUNC symbols' sizes are the kernels'
     code lengths.  tests/test_kernel_resources.py keeps the own-code touch lengths (rd_common.h touch_own_code) below them."""
     import struct
+    out = {}
+    for e in _code_objects(lib):
+        shoff, = struct.unpack_from("<Q", e, 0x28)
+        shentsize, shnum = struct.unpack_from("<HH", e, 0x3A)
+        secs = [struct.unpack_from("<IIQQQQIIQQ", e, shoff + k * shentsize) for k in range(shnum)]
+        for s in secs:
+            if s[1] != 2:                                        # SHT_SYMTAB
+                continue
+            stroff = secs[s[6]][4]
+            for k in range(s[5] // 24):
+                name, info, _, _, _, sz = struct.unpack_from("<IBBHQQ", e, s[4] + 24 * k)
+                if (info & 15) == 2 and sz:                      # STT_FUNC
+                    end = e.index(b"\0", stroff + name)
+                    out[e[stroff + name:end].decode()] = sz
+    return out
+
+
+def _code_objects(lib=None):
+    """The gfx950 ELF images inside the built library (one per translation unit)."""
+    import struct
     d = open(lib or LIB, "rb").read()
-    out, pos = {}, 0
+    pos = 0
     while True:
         i = d.find(b"__CLANG_OFFLOAD_BUNDLE__", pos)
         if i < 0:
-            break
+            return
         pos = i + 24
         nb = struct.unpack_from("<Q", d, i + 24)[0]
         o = i + 32
         for _ in range(nb):
             off, size, tl = struct.unpack_from("<QQQ", d, o); o += 24
             triple = d[o:o + tl].decode(errors="replace"); o += tl
-            if "gfx950" not in triple or size == 0:
-                continue
-            e = d[i + off:i + off + size]
-            if e[:4] != b"\x7fELF":
-                continue
-            shoff, = struct.unpack_from("<Q", e, 0x28)
-            shentsize, shnum = struct.unpack_from("<HH", e, 0x3A)
-            secs = [struct.unpack_from("<IIQQQQIIQQ", e, shoff + k * shentsize) for k in range(shnum)]
-            for s in secs:
-                if s[1] != 2:                                    # SHT_SYMTAB
-                    continue
-                stroff = secs[s[6]][4]
-                for k in range(s[5] // 24):
-                    name, info, _, _, _, sz = struct.unpack_from("<IBBHQQ", e, s[4] + 24 * k)
-                    if (info & 15) == 2 and sz:                  # STT_FUNC
-                        end = e.index(b"\0", stroff + name)
-                        out[e[stroff + name:end].decode()] = sz
+            if "gfx950" in triple and size and d[i + off:i + off + 4] == b"\x7fELF":
+                yield d[i + off:i + off + size]
+
+
+def getpc_offsets(lib=None):
+    """{mangled kernel name: byte offset of its (first) s_getpc_b64 from the kernel's entry} by disassembly (llvm-objdump of the
+    ROCm LLVM): where touch_own_code's range starts.  Empty when the disassembler is not installed."""
+    import tempfile
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    out = {}
+    if not os.path.exists(objdump):
+        return out
+    with tempfile.TemporaryDirectory() as tmp:
+        for n, e in enumerate(_code_objects(lib)):
+            f = os.path.join(tmp, "co%d.elf" % n)
+            with open(f, "wb") as fh:
+                fh.write(e)
+            txt = subprocess.run([objdump, "-d", "--no-show-raw-insn", f], capture_output=True, text=True).stdout
+            cur, start = None, 0
+            for line in txt.splitlines():
+                m = re.match(r"^([0-9a-f]+) <(.+)>:$", line)
+                if m:
+                    cur, start = m.group(2), int(m.group(1), 16)
+                elif cur and "s_getpc_b64" in line and cur not in out:
+                    a = re.search(r"//\s*([0-9A-Fa-f]+):", line)
+                    if a:
+                        out[cur] = int(a.group(1), 16) - start
     return out
 
 

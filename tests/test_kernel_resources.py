@@ -118,3 +118,18 @@ def test_optional_code_touch_lengths_fit(frag, touch):
     assert min(sizes) >= touch + 384, (frag, min(sizes), touch)
     src = "".join(open(os.path.join(build.CSRC, f)).read() for f in sorted(os.listdir(build.CSRC)) if f.endswith(".hip"))
     assert re.search(r"RD_TOUCH_CODE_X\(%d\b" % touch, src), (frag, touch)
+
+
+def test_own_code_touch_starts_right_behind_the_entry():
+    """The touched range is [address behind s_getpc_b64, + bytes): the s_getpc must sit within the slack the length tests leave
+    (384 bytes) of the kernel's entry in EVERY instantiation -- the compiler is free to schedule the prologue in front of it."""
+    build.build(verbose=False)
+    offs = build.getpc_offsets()
+    if not offs:
+        pytest.skip("llvm-objdump not installed")
+    sizes = build.kernel_code_sizes()
+    touched = [k for k in offs if any(f in k for f, _ in CODE_TOUCH)]
+    assert len(touched) >= 20, touched
+    for k in touched:
+        t = max(t for f, t in CODE_TOUCH if f in k)
+        assert offs[k] <= 256 and offs[k] + 8 + t <= sizes[k], (k, offs[k], t, sizes[k])
