@@ -101,9 +101,16 @@ int rd_side_join(void* stream);
  * time -- and the next rd_encoder_layer_bwd that runs its fused backward chain appends them to that launch as extra workgroups, which
  * run on the CUs the chain leaves idle.  A parked launch nobody picks up runs stand-alone when the next one is parked or when
  * rd_flush_trailing(stream) is called: call it before reading those gradients / the loss, and before the end of a stream capture.
- * Results are identical in every mode (same arithmetic on the same data). */
+ * Results are identical in every mode (same arithmetic on the same data).
+ * Two rules for a C-ABI caller: (1) a parked slice reduce of layer i -- including the LayerNorm dgamma / dbeta column sums over the
+ * layer's partial matrices -- runs INSIDE layer i-1's backward launch, beside workgroups that rewrite the partials and row tiles of
+ * the workspace THEY were given: while the mode is on, every layer needs its OWN rd_encoder_layer workspace until
+ * rd_flush_trailing (raindrop_amd.step.TrainStep: `enc_wss`); sharing one workspace across layers is only legal with the mode off.
+ * (2) The slot holds raw device pointers.  rd_set_defer_trailing(0) and rd_set_side_stream(NULL) DISCARD whatever is still parked
+ * (so does rd_drop_trailing): leave the mode through them on every error path, flush before leaving it on the normal one. */
 int rd_set_defer_trailing(int32_t on);
 int rd_flush_trailing(void* stream);
+int rd_drop_trailing(void);
 
 /* ---- token plan: the padding mask as a layout --------------------------------------------------------------------------
  * code/models_rd.py:298-299 builds mask[b,t] = (t >= lengths[b]) and uses it twice: as src_key_padding_mask of the encoder

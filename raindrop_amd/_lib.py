@@ -46,6 +46,7 @@ SIGNATURES = {
     "rd_side_join": (c_int32, [_P]),
     "rd_set_defer_trailing": (c_int32, [c_int32]),
     "rd_flush_trailing": (c_int32, [_P]),
+    "rd_drop_trailing": (c_int32, []),
     "rd_seed_cell_advance": (c_int32, [_P, ctypes.c_uint64, _P]),
     "rd_token_plan_bytes": (c_size_t, [_SHP]),
     "rd_token_plan": (c_int32, [_SHP, _P, _P, _P, ctypes.c_uint64, _P]),

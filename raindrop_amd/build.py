@@ -25,6 +25,37 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-I", INCLUDE]
 
 
+# Own-code touch lengths (rd_common.h touch_own_code): (kernel name fragment, bytes the kernel requests behind its s_getpc_b64).  The
+# loads must stay inside the kernel's code in EVERY instantiation -- a different compiler version or flag set can shrink a kernel, and
+# a load past the end of the last kernel of a code object is a memory fault -- so the build itself checks them against the linked
+# library (check_code_touch, called by build() and build_variant()) and FAILS on violation; tests/test_kernel_resources.py re-checks.
+CODE_TOUCH = [("k_msg_fwd_fused", 14336), ("k_msg_bwd_fused", 11264), ("k_attn_fwd_fused", 12800), ("k_attn_bwd_fused", 28672),
+              ("k_enc_post_fwd", 31744), ("k_enc_pre_bwd", 40960), ("4k_dwE", 6144), ("k_dw_reduce", 9216), ("6k_adam", 2432),
+              ("k_wsplit", 4096), ("5k_twgI", 7936), ("k_head_rowsILi1ELi12ELi3E", 14848), ("k_head_rowsILi1ELi16ELi4E", 16384)]
+# the kernels outside the P19 step (RD_TOUCH_CODE_X)
+CODE_TOUCH_X = [("6k_gemmI", 25088), ("13k_gemm_bf16x3I", 28160), ("12k_gemm_panelI", 28160), ("9k_rowgemmI", 4096),
+                ("19k_attn_fwd_one_b16wI", 5632), ("19k_attn_bwd_one_b16wI", 6144), ("14k_attn_fwd_b16I", 6912),
+                ("17k_attn_bwd_dq_b16I", 7040), ("18k_attn_bwd_dkv_b16I", 6016), ("14k_add_ln_fwd_vE", 5120), ("10k_ln_bwd_rI", 5120),
+                ("10k_ln_bwd_vE", 6144)]
+CODE_TOUCH_SLACK = 384          # bytes allowed for the prologue in front of the s_getpc_b64
+
+
+def check_code_touch(lib=None):
+    """Raise if any touched range could leave its kernel (see CODE_TOUCH)."""
+    sizes = kernel_code_sizes(lib)
+    bad = []
+    for frag, touch in CODE_TOUCH + CODE_TOUCH_X:
+        ks = {k: v for k, v in sizes.items() if frag in k}
+        if not ks:
+            bad.append("%s: no such kernel in the library" % frag)
+        for k, v in ks.items():
+            if v < touch + CODE_TOUCH_SLACK:
+                bad.append("%s: %d bytes of code, touches %d (+%d slack)" % (k, v, touch, CODE_TOUCH_SLACK))
+    if bad:
+        raise RuntimeError("own-code touch lengths exceed the built kernels (rd_common.h touch_own_code; raindrop_amd/build.py "
+                           "CODE_TOUCH):\n  " + "\n  ".join(bad))
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -112,6 +143,8 @@ def build(force=False, verbose=True):
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (res.stdout, res.stderr))
+    if rebuilt:
+        check_code_touch(LIB)
     if verbose:
         print("libraindrop_hip.so: %s (%d sources, %s)" % (
             LIB, len(srcs), "rebuilt" if rebuilt else "up to date"))
@@ -130,6 +163,8 @@ def build_variant(name, extra):
     res = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (res.stdout, res.stderr))
+    if "-DRD_NO_CODE_TOUCH" not in extra:
+        check_code_touch(lib)
     print(lib)
     return lib
 

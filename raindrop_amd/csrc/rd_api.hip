@@ -76,6 +76,7 @@ int trailing_park(const RiderArgs& r, hipStream_t st) {
 RiderArgs trailing_take() {
   RiderArgs r = g_parked;
   g_parked.kind = RIDER_NONE;
+  if (!g_defer) r.kind = RIDER_NONE;                       // a slot left behind by a caller that has switched the mode off is dropped, never launched
   return r;
 }
 
@@ -102,13 +103,25 @@ namespace {
 __global__ void k_seed_advance(uint64_t* cell, uint64_t delta) { *cell += delta; }
 }
 extern "C" int rd_set_seed_cell(const uint64_t* device_cell) { g_seed_cell = device_cell; return RD_OK; }
-extern "C" int rd_set_defer_trailing(int32_t on) { g_defer = on != 0; return RD_OK; }
+// Switching the mode OFF discards whatever is still parked: the slot holds raw device pointers of the step that parked it, and a
+// caller that leaves the mode through an error path (a capture that raised) must not have them enqueued -- or baked into a later
+// graph -- by the next chain launch of this host thread.  A normal caller has flushed (rd_flush_trailing) before, so nothing is lost.
+extern "C" int rd_set_defer_trailing(int32_t on) {
+  g_defer = on != 0;
+  if (!g_defer) g_parked.kind = RIDER_NONE;
+  return RD_OK;
+}
+extern "C" int rd_drop_trailing(void) { g_parked.kind = RIDER_NONE; return RD_OK; }
 extern "C" int rd_flush_trailing(void* stream) {
   if (g_parked.kind == RIDER_NONE) return RD_OK;
   const RiderArgs r = trailing_take();
   return trailing_launch(r, (hipStream_t)stream);
 }
-extern "C" int rd_set_side_stream(void* stream) { g_side = (hipStream_t)stream; g_side_busy = false; return RD_OK; }
+extern "C" int rd_set_side_stream(void* stream) {
+  g_side = (hipStream_t)stream; g_side_busy = false;
+  if (stream == nullptr) g_parked.kind = RIDER_NONE;       // same rule as rd_set_defer_trailing(0)
+  return RD_OK;
+}
 extern "C" int rd_side_join(void* main_stream) { return side_join((hipStream_t)main_stream); }
 extern "C" int rd_seed_cell_advance(uint64_t* device_cell, uint64_t delta, void* stream) {
   RD_REQUIRE(device_cell != nullptr, "NULL cell");

@@ -119,10 +119,10 @@ __device__ __forceinline__ void touch_own_code(int tid, int bytes) {
 #endif
 
 // The kernels OUTSIDE the P19 step (tiled / panel GEMMs, row-block products, multi-tile and padded-layout attention, LayerNorm
-// kernels: P12, PAM, SYN256, the eager surface) carry the same prologue behind -DRD_TOUCH_ALL only: written and size-checked
-// (tests/test_kernel_resources.py) in round 4 after the GPU budget was spent, NOT yet measured -- build the A/B library with
-// `python -m raindrop_amd.build --variant touchall -DRD_TOUCH_ALL`, compare on a slow box, then make it the default.
-#if defined(RD_TOUCH_ALL) && !defined(RD_NO_CODE_TOUCH)
+// kernels: P12, PAM, SYN256, the eager surface) carry the same prologue (RD_TOUCH_CODE_X).  Written in round 4, measured and made the
+// default in round 5 (one call, alternating libraries, a box whose probe says "fast": P12 bf16 1.460 -> 1.428 ms/step, PAM 2.93 ->
+// 2.85, SYN256 7.75 -> 7.57, P19 unchanged; profiles/r05_touchall_ab.txt).  -DRD_NO_TOUCH_ALL builds the library without it (A/B).
+#if !defined(RD_NO_TOUCH_ALL) && !defined(RD_NO_CODE_TOUCH)
 #define RD_TOUCH_CODE_X(bytes, lin, first) ::rd::touch_own_code((int)threadIdx.x, (int)(lin) < (first) ? (bytes) : 0)
 #else
 #define RD_TOUCH_CODE_X(bytes, lin, first) ((void)0)

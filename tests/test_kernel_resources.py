@@ -79,10 +79,18 @@ def test_resource_remark_parser_keeps_real_warnings():
     assert "unused variable" in rest and "int x;" in rest and "remark" not in rest and "float b1" not in rest
 
 
-# (kernel name fragment, bytes of its own code the kernel requests into L2 at its start: rd_common.h touch_own_code)
-CODE_TOUCH = [("k_msg_fwd_fused", 14336), ("k_msg_bwd_fused", 11264), ("k_attn_fwd_fused", 12800), ("k_attn_bwd_fused", 28672),
-              ("k_enc_post_fwd", 31744), ("k_enc_pre_bwd", 40960), ("4k_dwE", 6144), ("k_dw_reduce", 9216), ("6k_adam", 2432),
-              ("k_wsplit", 4096), ("5k_twgI", 7936), ("k_head_rowsILi1ELi12ELi3E", 14848), ("k_head_rowsILi1ELi16ELi4E", 16384)]
+# (kernel name fragment, bytes of its own code the kernel requests into L2 at its start: rd_common.h touch_own_code) -- the table lives in
+# raindrop_amd/build.py, which also checks it against the linked library at BUILD time (check_code_touch)
+CODE_TOUCH = build.CODE_TOUCH
+
+
+def test_build_checks_code_touch_lengths(monkeypatch):
+    """The build fails when a touched range would leave its kernel."""
+    build.build(verbose=False)
+    build.check_code_touch()
+    monkeypatch.setattr(build, "CODE_TOUCH", [("4k_dwE", 1 << 20)])
+    with pytest.raises(RuntimeError, match="own-code touch"):
+        build.check_code_touch()
 
 
 @pytest.mark.parametrize("frag,touch", CODE_TOUCH, ids=[c[0] for c in CODE_TOUCH])
@@ -99,13 +107,9 @@ def test_own_code_touch_stays_inside_the_kernel(frag, touch):
     assert re.search(r"(RD_TOUCH_CODE(_FIRST)?\(%d\b|touch \? %d :)" % (touch, touch), src), (frag, touch)
 
 
-# the same prologue in the kernels outside the P19 step, compiled in behind -DRD_TOUCH_ALL only (rd_common.h RD_TOUCH_CODE_X: written
-# in round 4 after the GPU budget was spent, to be measured before it becomes the default).  The lengths are checked against the
-# DEFAULT build's code sizes (the kernels are a few dozen bytes longer with the prologue).
-CODE_TOUCH_X = [("6k_gemmI", 25088), ("13k_gemm_bf16x3I", 28160), ("12k_gemm_panelI", 28160), ("9k_rowgemmI", 4096),
-                ("19k_attn_fwd_one_b16wI", 5632), ("19k_attn_bwd_one_b16wI", 6144), ("14k_attn_fwd_b16I", 6912),
-                ("17k_attn_bwd_dq_b16I", 7040), ("18k_attn_bwd_dkv_b16I", 6016), ("14k_add_ln_fwd_vE", 5120), ("10k_ln_bwd_rI", 5120),
-                ("10k_ln_bwd_vE", 6144)]
+# the same prologue in the kernels outside the P19 step (rd_common.h RD_TOUCH_CODE_X: written in round 4, measured and made the default in
+# round 5)
+CODE_TOUCH_X = build.CODE_TOUCH_X
 
 
 @pytest.mark.parametrize("frag,touch", CODE_TOUCH_X, ids=[c[0] for c in CODE_TOUCH_X])
