@@ -158,7 +158,7 @@ __device__ __forceinline__ void x_request(XRows<KCX>& r, const float* x, long ro
 }
 template <int KCX>
 __device__ __forceinline__ void x_store(const XRows<KCX>& r, __bf16* Xh, __bf16* Xl, int Tv, int D, int tid) {
-  constexpr int kq = 8 * KCX, NIT = (TS * kq) / AF_THR, LDX = 32 * KCX + 8;
+  constexpr int kq = 8 * KCX, NIT = (TS * kq) / AF_THR, LDX = 32 * KCX + 16;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int i = tid + it * AF_THR;
@@ -204,7 +204,7 @@ __device__ __forceinline__ void qkv_request(QkvPanel<KCX>& p, const __bf16* wf_h
 template <int NTH, int KCX>
 __device__ __forceinline__ void qkv_project(const QkvPanel<KCX>& p, const __bf16* Xh, const __bf16* Xl, int hd, int Tv, __bf16* Tp, int wave,
                                             int lane, bool one) {
-  constexpr int NCT3 = 3 * NTH, HDP = 32 * ((16 * NTH + 31) / 32), LDX = 32 * KCX + 8;
+  constexpr int NCT3 = 3 * NTH, HDP = 32 * ((16 * NTH + 31) / 32), LDX = 32 * KCX + 16;
   const bool two = wave + AF_WV < NCT3;                      // wave-uniform
   const int aoff = (lane & 15) * LDX + 8 * (lane >> 4);
   f32x4 acc[2][4];
@@ -290,7 +290,7 @@ template <int NTH, int KCX>
 __global__ __launch_bounds__(AF_THR) void k_attn_fwd_fused(FAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
   RD_TOUCH_CODE(12800);                                      // own code -> L2 (rd_common.h; 14.0 KB kernel)
-  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDX = 32 * KCX + 8, NA = (NTH + 1) / 2;
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDX = 32 * KCX + 16, NA = (NTH + 1) / 2;
   constexpr int LDO = 16 * NTH + 4;                          // fp32 row stride of the output stage
   __bf16* Xh = reinterpret_cast<__bf16*>(fsm);
   __bf16* Xl = Xh + TS * LDX;
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(AF_THR) void k_attn_fwd_fused(FAttnArgs a) {
 
 template <int NTH, int KCX>
 constexpr size_t fwd_lds() {
-  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDX = 32 * KCX + 8;
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDX = 32 * KCX + 16;
   return (size_t)2 * TS * LDX * 2 + (size_t)6 * HDP * LDT * 2 + (size_t)4 * TS * 4;
 }
 
@@ -528,7 +528,7 @@ template <int NTH, int KCX>
 __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
   RD_TOUCH_CODE(28672);                                      // own code -> L2 (30.3 KB kernel)
-  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDX = 32 * KCX + 8, NA = (NTH + 1) / 2, KB = HDP / 32, LDB = HDP + 8;
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDX = 32 * KCX + 16, NA = (NTH + 1) / 2, KB = HDP / 32, LDB = HDP + 16;
   constexpr int NCT = 2 * KCX;                               // 16-column tiles of D (padded to 32 KCX)
   constexpr int LDS_DX = 32 * KCX + 4;                       // fp32 row stride of the dx stage
   // R1: x planes, then the score planes of the head, at the end the dx stage
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
 
 template <int NTH, int KCX>
 constexpr size_t bwd_lds() {
-  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDX = 32 * KCX + 8, LDB = HDP + 8;
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDX = 32 * KCX + 16, LDB = HDP + 16;
   return (size_t)2 * TS * LDX * 2 + (size_t)6 * HDP * LDT * 2 + (size_t)2 * TS * LDB * 2 + (size_t)2 * TS * 4;
 }
 

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-constexpr int BK2 = 64, LDB = BK2 + 8;   // bf16 elements; 144-B rows (16-B aligned, conflict-free b128)
+constexpr int BK2 = 64, LDB = BK2 + 16;  // bf16 elements; 160-byte rows (32 bytes mod 64: conflict-free fragment reads, rd_encfuse.hip LDD)
 
 // Tile = (32*MI) x (32*NI) outputs per 256-thread workgroup (2x2 waves, each 16*MI x 16*NI), K step 64.
 // Staging of a ROWS x 64 fp32 tile (ROWS = 32*MI or 32*NI):

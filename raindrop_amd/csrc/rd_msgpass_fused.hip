@@ -22,9 +22,13 @@
 // The backward kernel here does the activation-side chain dz -> dZ2 -> dZ1 -> dX -> dR_u and emits dZ2, dZ1
 // as row tiles; no fp32 copy of X, Y1, dZ1 or dZ2 exists in HBM.
 //
-// Layout in LDS (RT = ceil(F/16) row tiles): four bf16 planes [RT*16][264] (X hi/lo, Y1 hi/lo;
-// 528-B rows keep ds_read_b128 conflict-free) plus fp32 staging tiles [F][244] aliased on top of the plane
-// pair that is dead at that point (coalesced [F,K] <-> [T,F*d] transposes and the row-tile transposes).
+// Layout in LDS (RT = ceil(F/16) row tiles): four bf16 planes [RT*16][256] (X hi/lo, Y1 hi/lo), rows of exactly 512 bytes whose
+// 16-byte chunks are XOR-swizzled by the row (pofs): the MFMA A-fragment read -- lane (r, G) takes 16 bytes of row r at chunk
+// 4 kc + G -- is serviced by gfx950 in 16-lane groups {r 0-3 G, r 12-15 G, r 4-11 G+1} over 64 banks, and NO padded row stride keeps
+// those 16 accesses on distinct bank quads (rounds 1-4 used 528-byte rows: tools/probe_ldsfrag.hip measures 127 B/clk/CU for that,
+// 224 for the swizzle, 32 for plain 512-byte rows -- the two K x K products were LDS-bound, 6.2 k cycles of fragment reads against
+// 4.9 k cycles of MFMAs).  One fp32 staging tile [F][244] aliases the plane pair that is dead at that point (the [F,K] <-> [T,F*d]
+// transposes); the row tiles leave straight from the planes through transposing LDS reads (ds_read_b64_tr_b16).
 #include <stdlib.h>
 
 #include "rd_common.h"
@@ -38,6 +42,18 @@
 #define RD_ABL 0
 #endif
 
+// bytes of its own code each kernel requests into L2 at its start (rd_common.h touch_own_code; checked against the built library:
+// raindrop_amd/build.py CODE_TOUCH)
+// RD_K1_BLATE: group B requests the first weight panel of a kernel BEHIND the first barrier instead of under the cold loads the
+// kernel starts with.  Measured (stamps in the step, round 5): the vector memory pipe is in order -- panel requests issued behind the
+// cold observation / dz loads (~6 k cycles) are not accepted until those return, so a wave that requests its panel before it
+// consumes them reaches the barrier ~1.8 k cycles later; group A's half of the panel fits under the latency, group B's does not.
+#ifndef RD_K1_BLATE
+#define RD_K1_BLATE 1
+#endif
+#define RD_K1_FWD_TOUCH 14080
+#define RD_K1_BWD_TOUCH 11264
+
 namespace rd {
 namespace {
 
@@ -48,8 +64,12 @@ using k1::TILE;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int LDX = KP + 8;      // bf16 elements per LDS plane row (528 B)
+constexpr int LDX = KP;          // bf16 elements per LDS plane row (512 B); chunks of 8 elements swizzled by the row: pofs()
 constexpr int LDS_F = 244;       // fp32 staging row stride (conflict-free for both access orders)
+// element offset of (row, col) in a split plane: 16-byte chunk (col >> 3) lands at chunk ^ (row & 15) within its half row
+__device__ __forceinline__ int pofs(int row, int col) {
+  return row * LDX + (col & 128) + ((((col >> 3) ^ row) & 15) << 3) + (col & 7);
+}
 // MEASURED in-step, library variants A/B'd in one call: 1024 threads is neutral on the pool's fast boxes (0.714 vs 0.714 ms/step)
 // and 3 % faster on its slow ones (0.911 -> 0.884), where these instruction-issue-bound kernels stretch the most.
 #ifndef RD_K1_NTHR
@@ -58,6 +78,7 @@ constexpr int LDS_F = 244;       // fp32 staging row stride (conflict-free for b
 constexpr int NTHR = RD_K1_NTHR; // 512: 8 wavefronts, wave w owns output column tiles {w, w+8}; 1024: 16 wavefronts, one tile each
 constexpr int NWAVE = NTHR / 64, NJ = 16 / NWAVE;
 constexpr int CPT = 2048 / NTHR; // cells (t, f) per thread and batch of loads (F*T <= 2048 needs one batch)
+constexpr int GTHR = NTHR / 2, GWAVE = NWAVE / 2;   // threads / waves of one of the two groups (A: waves [0, GWAVE), B: the rest)
 
 struct FusedArgs {
   const float *src, *R_u, *b1, *b2, *ssum;
@@ -114,10 +135,26 @@ __device__ __forceinline__ Dim dims_of(const FusedArgs& a) {
 // 24-bit multiply (full rate; v_mul_lo_u32 issues at quarter rate): both factors < 2^24, product < 2^32
 __device__ __forceinline__ unsigned m24(unsigned x, unsigned y) { return __umul24(x, y); }
 
+// Debug stamps (tools/k1_stamps.py; a.stamps is null in production).  Per kernel K1_STAMP_WORDS 64-bit words:
+//   [4 workgroups][16 waves][16 phases] clock64() of lane 0 -- the first four workgroups (with a token plan: the four LONGEST samples);
+//   then [<= 1024 workgroups][4]: start clock64 / start wall_clock64 (thread 0), end clock64 / end wall_clock64 (max over the waves).
+// The backward kernel's block sits K1_STAMP_WORDS behind the forward's.
+constexpr int K1_STAMP_WORDS = 4 * 16 * 16 + 4 * 1024;
 #define RD_STAMP(i)                                                                              \
   do {                                                                                           \
     if (a.stamps && blockIdx.x < 4 && (threadIdx.x & 63) == 0)                                   \
-      a.stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = clock64();                    \
+      a.stamps[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 16 + (i)] = clock64();                   \
+  } while (0)
+#define RD_STAMP_WG_START()                                                                      \
+  do {                                                                                           \
+    if (a.stamps && threadIdx.x == 0 && blockIdx.x < 1024) {                                     \
+      a.stamps[1024 + 4 * blockIdx.x] = clock64(); a.stamps[1024 + 4 * blockIdx.x + 1] = wall_clock64(); }   \
+  } while (0)
+#define RD_STAMP_WG_END()                                                                        \
+  do {                                                                                           \
+    if (a.stamps && (threadIdx.x & 63) == 0 && blockIdx.x < 1024) {                              \
+      atomicMax(a.stamps + 1024 + 4 * blockIdx.x + 2, (unsigned long long)clock64());            \
+      atomicMax(a.stamps + 1024 + 4 * blockIdx.x + 3, (unsigned long long)wall_clock64()); }     \
   } while (0)
 
 __device__ __forceinline__ const __bf16* wtiles(const FusedArgs& a, const Dim& d, int layer, int orient) {
@@ -218,21 +255,20 @@ __device__ __forceinline__ void store_split_pair(__bf16* Ph, __bf16* Pl, int row
   const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, true);   // lane ^ 1
   const unsigned word = odd ? (recv | (lb << 16)) : (hb | (recv << 16));
   __bf16* P = odd ? Pl : Ph;
-  *reinterpret_cast<unsigned*>(P + row * LDX + (n & ~1)) = word;
+  *reinterpret_cast<unsigned*>(P + pofs(row, n & ~1)) = word;
 }
 
 // zero what the products read but no phase writes: pad columns [K, KP) of rows [0, crow) and whole pad rows
-// [prow, rows) of one plane, with 16-byte stores (K % 16 == 0; a row is 528 bytes)
+// [prow, rows) of one plane, with 16-byte stores (K % 16 == 0; a row is 512 bytes, a whole row of zeros is its own swizzle)
 __device__ __forceinline__ void zero_plane_pads(__bf16* P, int rows, int prow, int crow, int K, int tid) {
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  char* base = reinterpret_cast<char*>(P);
   const int nrow16 = (rows - prow) * LDX * (int)sizeof(__bf16) / 16;
-  float4* q = reinterpret_cast<float4*>(base + (size_t)prow * LDX * sizeof(__bf16));
+  float4* q = reinterpret_cast<float4*>(P + (size_t)prow * LDX);
   for (int i = tid; i < nrow16; i += NTHR) q[i] = z;
   const int n16 = (KP - K) / 8;                           // 16-byte chunks of pad columns per row
   for (int i = tid; i < crow * n16; i += NTHR) {
     const int r = i / n16, c = i - r * n16;
-    *reinterpret_cast<float4*>(base + ((size_t)r * LDX + K) * sizeof(__bf16) + 16 * c) = z;
+    *reinterpret_cast<float4*>(P + pofs(r, K + 8 * c)) = z;
   }
 }
 
@@ -250,14 +286,22 @@ __device__ __forceinline__ void zero_plane_pads(__bf16* P, int rows, int prow, i
 #endif
 template <int RT, typename Mid>
 __device__ __forceinline__ void mma_mid(f32x4 (&acc)[NJ][RT], const __bf16* Ah, const __bf16* Al, Panel& p, int lane, int kclim, Mid&& mid) {
-  const int aoff = (lane & 15) * LDX + 8 * (lane >> 4);
+  // fragment of (step kc, row tile rt): row 16 rt + r, chunk 4 kc + G -> swizzled chunk ((kc & 3) << 2 | G) ^ r in half (kc >> 2) of
+  // the row (pofs): four lane offsets, one per kc & 3; row tile, half row and the hi / lo plane are immediates
+  int aoffk[4];
+  {
+    const int r = lane & 15, g0 = ((lane >> 4) ^ r) & 15;
+#pragma unroll
+    for (int k3 = 0; k3 < 4; ++k3) aoffk[k3] = r * LDX + ((g0 << 3) ^ (k3 << 5));
+  }
+#define RD_AOFF(kc) (aoffk[(kc) & 3] + ((kc) >> 2) * 128)
   if (RD_ABL & 2) { mid(); return; }
   bf16x8 ah[RT], al[RT];
   if (RD_K1_ROLL) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * LDX + aoff);
-      al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * LDX + aoff);
+      ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * LDX + RD_AOFF(0));
+      al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * LDX + RD_AOFF(0));
     }
   }
 #pragma unroll
@@ -266,8 +310,8 @@ __device__ __forceinline__ void mma_mid(f32x4 (&acc)[NJ][RT], const __bf16* Ah, 
       if (!RD_K1_ROLL) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-          ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * LDX + aoff + kc * 32);
-          al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * LDX + aoff + kc * 32);
+          ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * LDX + RD_AOFF(kc));
+          al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * LDX + RD_AOFF(kc));
         }
       }
 #pragma unroll
@@ -279,8 +323,8 @@ __device__ __forceinline__ void mma_mid(f32x4 (&acc)[NJ][RT], const __bf16* Ah, 
           acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.h[jj][kc], acc[jj][rt], 0, 0, 0);
         }
         if (RD_K1_ROLL && kc + 1 < NKC) {                          // in-bounds whatever kclim is: the planes hold NKC steps
-          ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * LDX + aoff + (kc + 1) * 32);
-          al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * LDX + aoff + (kc + 1) * 32);
+          ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * LDX + RD_AOFF(kc + 1));
+          al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * LDX + RD_AOFF(kc + 1));
         }
       }
       if (RD_K1_ROLL && kc + 1 < NKC) {
@@ -299,6 +343,7 @@ __device__ __forceinline__ void mma_mid(f32x4 (&acc)[NJ][RT], const __bf16* Ah, 
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+#undef RD_AOFF
 }
 template <int RT>
 __device__ __forceinline__ void mma_panel(f32x4 (&acc)[NJ][RT], const __bf16* Ah, const __bf16* Al,
@@ -306,21 +351,15 @@ __device__ __forceinline__ void mma_panel(f32x4 (&acc)[NJ][RT], const __bf16* Ah
   mma_mid<RT>(acc, Ah, Al, p, lane, kclim, [] {});
 }
 
-// srow[rt][r] = ssum[16 rt + 4 g + r] (0 beyond F): one 16-byte load per row tile when F % 4 == 0 puts the quad inside
-// the array, scalar loads otherwise (every VMEM instruction costs the address unit 16 cycles whatever its width)
+// srow[rt][r] = ssum[16 rt + 4 g + r] (0 beyond F) from the workgroup's LDS copy Ss[RT * 16] (written before the first barrier by
+// its first RT * 16 threads): read where an epilogue needs it, one 16-byte LDS read per row tile.  (Rounds 2-4 loaded the twelve
+// values from global memory at the kernel's start and carried them through both products: 12 of 128 registers.)
 template <int RT>
-__device__ __forceinline__ void load_srow(float (&srow)[RT][4], const float* __restrict__ ssum, int F, int lane) {
+__device__ __forceinline__ void load_srow(float (&srow)[RT][4], const float* Ss, int lane) {
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    const int row0 = rt * 16 + 4 * (lane >> 4);
-    if ((F & 3) == 0 && (reinterpret_cast<uintptr_t>(ssum) & 15) == 0) {
-      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row0 < F) q = *reinterpret_cast<const float4*>(ssum + row0);
-      srow[rt][0] = q.x; srow[rt][1] = q.y; srow[rt][2] = q.z; srow[rt][3] = q.w;
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) srow[rt][r] = row0 + r < F ? ssum[row0 + r] : 0.f;
-    }
+    const float4 q = *reinterpret_cast<const float4*>(Ss + rt * 16 + 4 * (lane >> 4));
+    srow[rt][0] = q.x; srow[rt][1] = q.y; srow[rt][2] = q.z; srow[rt][3] = q.w;
   }
 }
 
@@ -355,55 +394,42 @@ __device__ __forceinline__ __bf16* tp_tile(__bf16* tp, int nct, int s, int j) {
   return tp + ((size_t)s * nct + j) * (2 * TILE);
 }
 
-// Staging-sourced: S = fp32 [F][LDS_F] tile of sample b in LDS -> row tiles.  A slot = 8 consecutive graph rows of
-// one column: read down the column (conflict-free across the 16 columns of a lane group), split, one 16-byte
-// store per part; consecutive lanes write consecutive 16-byte slots of a tile.
-// jlim / jlimL: only column tiles j < jlim of the main tiles and j < jlimL of the leftover rows are written (the consumer
-// reads no further: rd_msgpass_dw.hip skips the column blocks that are all padding for a sample).
-__device__ __forceinline__ void tstore_stage(const float* S, __bf16* tp, const Dim& a, int b, int tid, int jlim, int jlimL) {
+// Plane-sourced, main tiles: the split planes of the tensor are complete in LDS, and a row tile part IS a transposed 32 x 16 block of
+// one plane -- lane (c = lane & 15, G = lane >> 4) holds rows 8 G .. 8 G + 7 of column 16 j + c.  ds_read_b64_tr_b16
+// (tools/probe_tr16.hip): in a 16-lane group lane i passes the address of row i >> 2, columns 4 (i & 3) .. of a 4 x 16 block and
+// receives column i; two reads = the lane's 8 rows, one 16-byte store per lane, a contiguous kilobyte per wave.  No fp32 copy of the
+// tensor, no conversion (rounds 2-4 kept an fp32 tile [F][244] for this: 8 strided LDS reads + 24 conversions per slot, 46 KB of LDS).
+// Task t = (main tile m, column tile j < jlim, part): dealt to the `nw` waves of the calling group (gw = the wave's index in it).
+__device__ __forceinline__ void tstore_planes_main(const __bf16* Ph, const __bf16* Pl, __bf16* tp, const Dim& a, int b, int gw, int nw,
+                                                   int lane, int jlim) {
   if (RD_ABL & 4) return;
-  const int nct = a.nct;
-  const int nslot = a.q * jlim * 64;
-  for (int idx = tid; idx < nslot; idx += NTHR) {
-    const int L = idx & 63, t2 = idx >> 6;
-    const int m = a.q == 1 ? 0 : t2 / jlim, j = t2 - m * jlim;
-    const float* p = S + (32 * m + 8 * (L >> 4)) * LDS_F + 16 * j + (L & 15);
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = p[e * LDS_F];
-    bf16x8 h, l;
-    split8(v, h, l);
-    __bf16* dst = tp_tile(tp, nct, b * a.q + m, j) + L * 8;
-    st16(dst, h);
-    st16(dst + TILE, l);
-  }
-  if (a.rem) {
-    const int s = a.B * a.q + b / a.per, slot = b % a.per;
-    const int KL = 16 * jlimL;
-    // thread -> (leftover row li = tid / 256 + 4 pass, column n = tid % 256): K <= 256, no division
-    for (int li = tid >> 8; li < a.rem; li += NTHR >> 8) {
-      const int n = tid & 255;
-      if (n < KL) {
-        const float x = S[(32 * a.q + li) * LDS_F + n];
-        const int r = slot * a.rem + li;
-        const __bf16 h = (__bf16)x, l = (__bf16)(x - (float)h);
-        __bf16* dst = tp_tile(tp, nct, s, n >> 4) + ((n & 15) + 16 * (r >> 3)) * 8 + (r & 7);
-        st2(dst, h); st2(dst + TILE, l);
-      }
-    }
+  typedef short v4s __attribute__((ext_vector_type(4)));
+  typedef short v8s __attribute__((ext_vector_type(8)));
+  const int i16 = lane & 15, G = lane >> 4;
+  const int ntask = a.q * jlim * 2;
+  for (int t = gw; t < ntask; t += nw) {
+    const int part = t & 1, mj = t >> 1;
+    const int m = a.q == 1 ? 0 : mj / jlim, j = mj - m * jlim;
+    const int row = 32 * m + 8 * G + (i16 >> 2), col = 16 * j + 4 * (i16 & 3);
+    const __bf16* P = part ? Pl : Ph;
+    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(P + pofs(row, col)));
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(P + pofs(row + 4, col)));
+    const v8s o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    *reinterpret_cast<v8s*>(tp_tile(tp, a.nct, b * a.q + m, j) + part * TILE + lane * 8) = o;
   }
 }
 
 // positions of a leftover tile that no sample covers: zeros, written by the workgroup whose sample sits at position 0
-__device__ __forceinline__ void tzero_uncovered(__bf16* tp, const Dim& a, int b, int tid) {
+// (t / nthr: the calling threads' index and count -- a whole workgroup or one group of it)
+__device__ __forceinline__ void tzero_uncovered(__bf16* tp, const Dim& a, int b, int t, int nthr) {
   if (a.rem == 0 || (b % a.per) != 0) return;
   const int first = b / a.per * a.per;
   const int nvalid = min(a.per, a.B - first);
   const int r0 = nvalid * a.rem;
   const int s = a.B * a.q + b / a.per;
   const __bf16 zero = (__bf16)0.f;
-  for (int rr = tid >> 8; rr < 32 - r0; rr += NTHR >> 8) {
-    const int n = tid & 255, r = r0 + rr;
+  for (int rr = t >> 8; rr < 32 - r0; rr += nthr >> 8) {
+    const int n = t & 255, r = r0 + rr;
     if (n < a.K) {
       __bf16* dst = tp_tile(tp, a.nct, s, n >> 4) + ((n & 15) + 16 * (r >> 3)) * 8 + (r & 7);
       st2(dst, zero); st2(dst + TILE, zero);
@@ -428,17 +454,19 @@ __device__ __forceinline__ void tstore_acc(__bf16* tp, const Dim& a, int b, int 
     st8(dst + TILE, lv);
   }
 }
-// leftover rows (32 q + li, li < rem) of a tensor whose split planes [row][LDX] are complete in LDS
+// leftover rows (32 q + li, li < rem) of a tensor whose split planes are complete in LDS, columns [0, KL); by the calling threads
+// t of nthr (a whole workgroup or one group of it; nthr a multiple of 256)
 __device__ __forceinline__ void tstore_leftover_planes(const __bf16* Ph, const __bf16* Pl, __bf16* tp, const Dim& a,
-                                                       int b, int tid) {
+                                                       int b, int t, int nthr, int KL) {
   if (a.rem == 0 || (RD_ABL & 4)) return;
   const int s = a.B * a.q + b / a.per, slot = b % a.per;
-  for (int li = tid >> 8; li < a.rem; li += NTHR >> 8) {
-    const int n = tid & 255, r = slot * a.rem + li;
-    if (n < a.K) {
+  for (int li = t >> 8; li < a.rem; li += nthr >> 8) {
+    const int n = t & 255, r = slot * a.rem + li;
+    if (n < KL) {
       __bf16* dst = tp_tile(tp, a.nct, s, n >> 4) + ((n & 15) + 16 * (r >> 3)) * 8 + (r & 7);
-      st2(dst, Ph[(32 * a.q + li) * LDX + n]);
-      st2(dst + TILE, Pl[(32 * a.q + li) * LDX + n]);
+      const int o = pofs(32 * a.q + li, n);
+      st2(dst, Ph[o]);
+      st2(dst + TILE, Pl[o]);
     }
   }
 }
@@ -446,30 +474,33 @@ __device__ __forceinline__ void tstore_leftover_planes(const __bf16* Ph, const _
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-// Schedule.  The 8 waves form two groups (waves 0-3 / 4-7; wave w and w+4 share a SIMD).  Wherever a phase consists
-// of a matrix-core part and a VALU / LDS / memory part, the two groups run the parts in OPPOSITE order, so each
-// SIMD's matrix pipe works for one wave while its partner wave splits, stores or issues loads (measured: a
-// GEMM of the two waves of a SIMD is pipe-bound, 2 x 144 MFMA x 16 cycles; a wave blocks while it issues a
-// 32-load weight panel, ~2 k cycles for half the workgroup).
+// Schedule.  The waves form two groups (A: the first half, B: the second; waves w, w + 4, w + 8, w + 12 share a SIMD, so every SIMD
+// holds both).  Wherever a phase consists of a matrix-core part and a VALU / LDS / memory part, the two groups run the parts in
+// OPPOSITE order, so each SIMD's matrix pipe works for one group while the other splits, stores or issues loads.  Round 5, from the
+// phase stamps of all 16 waves inside the captured step (tools/k1_stamps.py --step): the first barrier was released at 9.3 k cycles
+// although the observations (cold: ~6 k cycles) were consumed by 7.5 k -- group B requested its weight panel AFTER consuming them,
+// behind group A's in the address unit's queue; every wave now requests it before it waits for the observations.  Behind the
+// barrier group B does the work that depends on nothing a product makes (positional encoding: off the kernel's tail) while the
+// matrix pipe serves group A's product first (older waves win the arbitration), and group A exports X's row tiles behind its
+// product while group B multiplies.
 template <int RT, int FC, int TC>
 __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  RD_TOUCH_CODE(14336);                                  // own code -> L2 (rd_common.h; the smallest instantiation is 15.5 KB)
+  RD_TOUCH_CODE(RD_K1_FWD_TOUCH);                        // own code -> L2 (rd_common.h)
   constexpr int ROWS = RT * 16;
-  constexpr bool ALIAS = RT > 3;                         // F > 48: the fp32 copy of X has to share the Y planes' space
   constexpr size_t PLANES = (size_t)4 * ROWS * LDX * sizeof(__bf16);
-  constexpr size_t XS_BYTES = ALIAS ? 0 : (size_t)ROWS * LDS_F * sizeof(float);
   __bf16* Xh = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* Xl = Xh + ROWS * LDX;
   __bf16* Yh = Xl + ROWS * LDX;
   __bf16* Yl = Yh + ROWS * LDX;
-  float* Ys = reinterpret_cast<float*>(smem_raw);        // fp32 [F][LDS_F] staging of Y2, aliases the X planes
-  float* Xs = ALIAS ? reinterpret_cast<float*>(Yh) : reinterpret_cast<float*>(smem_raw + PLANES);   // fp32 copy of X
-  uint16_t* M1 = reinterpret_cast<uint16_t*>(smem_raw + PLANES + XS_BYTES);                          // [ROWS][16]
+  float* Ys = reinterpret_cast<float*>(smem_raw);        // fp32 [F][LDS_F] staging of Y2, aliases the X planes (F * 976 <= 2 * ROWS * 512)
+  uint16_t* M1 = reinterpret_cast<uint16_t*>(smem_raw + PLANES);                                     // [ROWS][16]
   uint16_t* M2 = M1 + ROWS * 16;
-  int* LinW = reinterpret_cast<int*>(M2 + ROWS * 16);     // [NWAVE] per-wave "1 + last observed step" (the slot the backward uses for ssum)
+  float* Ss = reinterpret_cast<float*>(M2 + ROWS * 16);   // [ROWS]: ssum (0 beyond F)
+  int* LinW = reinterpret_cast<int*>(Ss + ROWS);          // [NWAVE] per-wave "1 + last observed step"
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool grpB = __builtin_amdgcn_readfirstlane(wave) >= NWAVE / 2;   // scalar: the group branches are real branches
+  const bool grpB = __builtin_amdgcn_readfirstlane(wave) >= GWAVE;       // scalar: the group branches are real branches
+  const int gt = tid & (GTHR - 1), gw = __builtin_amdgcn_readfirstlane(wave) & (GWAVE - 1);   // index inside the group
   const Tok tk = tok_of(a);
   const int b = tk.b, sb = tk.sb, L = tk.L;
   const Dim dm = dims_of<FC, TC>(a);
@@ -480,10 +511,15 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   // (rd_plan.h): a wave whose column tiles are all padding skips its layer-2 weight stream, product and epilogue.
   const bool live2 = 4 * __builtin_amdgcn_readfirstlane(wave) < L;
 
+  RD_STAMP_WG_START();
+#ifdef RD_K1_EMPTY                                       // timing aid: what the bare launch of this grid costs (results are garbage)
+  RD_STAMP_WG_END(); return;
+#endif
   RD_STAMP(0);
   Panel pw;
-  float srow[RT][4];                                     // aggregate coefficient of this lane's rows
-  load_srow<RT>(srow, a.ssum, F, lane);
+  float sfv = 0.f;                                       // ssum -> LDS (last wave; the epilogues read their rows' coefficients there)
+  const int sfi = tid - (NTHR - 64);
+  if (sfi >= 0 && sfi < F) sfv = a.ssum[sfi];
   float bias1[NJ], bias2[NJ];                            // both layers' biases: ahead of the weight stream
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
@@ -491,11 +527,10 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
     bias1[jj] = a.b1[n]; bias2[jj] = a.b2[n];
   }
 
-  // ---- observation embedding -> X planes (+ fp32 copy for the row-tile transpose, + gate byte) ----
+  // ---- observation embedding -> X planes (+ gate byte) ----
   // thread -> cell (t, f) with f fastest: a wave-load of src covers two or three 136-byte row segments (with t
   // fastest it touched 64 cache lines, and the 64 such loads of the workgroup cost more tag look-ups than the
-  // whole weight panel).  LDS: the 16-byte fp32 stores are conflict-free at stride 244, the 8-byte plane
-  // stores 2-way.
+  // whole weight panel).
   constexpr int UNR = CPT;
   const int total = F * T;
   uint64_t seed_eff = a.seed;
@@ -524,14 +559,13 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
         x[0] = (km[u] & 1) ? x[0] * inv_keep : 0.f; x[1] = (km[u] & 2) ? x[1] * inv_keep : 0.f;
         x[2] = (km[u] & 4) ? x[2] * inv_keep : 0.f; x[3] = (km[u] & 8) ? x[3] * inv_keep : 0.f;
       }
-      split_store4(Xh + m24(f, LDX) + 4 * t, Xl + m24(f, LDX) + 4 * t, x);
-      *reinterpret_cast<float4*>(Xs + m24(f, LDS_F) + 4 * t) = make_float4(x[0], x[1], x[2], x[3]);
+      const int o = pofs(f, 4 * t);                           // the cell's 4 channels: half a 16-byte chunk of row f
+      split_store4(Xh + o, Xl + o, x);
       a.mx[(size_t)(m24(sb, total) + m24(t, F) + f)] =        // [slot][t][f]: consecutive lanes, consecutive bytes
           (uint8_t)((x[0] > 0.f ? 1 : 0) | (x[1] > 0.f ? 2 : 0) | (x[2] > 0.f ? 4 : 0) | (x[3] > 0.f ? 8 : 0));
     }
   };
-  // dropout masks: one Philox call = the 4 channel masks of a (t, f) cell; ~0.5 k cycles of integer multiplies per
-  // call and wave, no memory traffic
+  // dropout masks: one generator call = the 4 channel masks of a (t, f) cell; no memory traffic
   auto embed_masks = [&]() {
     if (a.p_drop > 0.f) {
 #pragma unroll
@@ -543,21 +577,35 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
     }
   };
   if (!(RD_ABL & 16)) embed_issue(tid);
-  // device seed cell (rd_set_seed_cell) on the scalar path: a vector load would queue behind the panel
+  // positional encoding + padding mask (code/models_rd.py:28-38,298-299) depend on nothing the products make: group B computes
+  // them behind the first barrier, under group A's product; the first pass's operands are requested here, behind the observations
+  const bool pe_on = a.times != nullptr;
+  const int H = dm.H, npe = L * H;
+  float pe_time = 0.f, pe_ts = 1.f;
+  if (pe_on && grpB) {
+    const int i = min(gt, max(npe - 1, 0));
+    const int t = i / H, k = i - t * H;
+    pe_time = a.times[(size_t)(m24(t, B) + b)]; pe_ts = a.tscale[k];
+  }
+  // device seed cell (rd_set_seed_cell) and the sample's length on the scalar path: a vector load would queue behind the panel
   if (a.seed_cell) seed_eff += load_uniform_u64(a.seed_cell);
-  // pads only: X rows >= F and columns >= K (the embedding writes the rest)
+  int64_t len_b = 0;
+  if (pe_on) len_b = (int64_t)load_uniform_u64(reinterpret_cast<const uint64_t*>(a.lengths + b));
+  // pads only: X rows >= F and columns >= K (the embedding writes the rest); Y1's pad columns (its epilogue writes every row)
   zero_plane_pads(Xh, ROWS, F, F, K, tid); zero_plane_pads(Xl, ROWS, F, F, K, tid);
-  if (!ALIAS) { zero_plane_pads(Yh, ROWS, ROWS, ROWS, K, tid); zero_plane_pads(Yl, ROWS, ROWS, ROWS, K, tid); }
-  // group B does its arithmetic BEFORE requesting its weight panel, group A after: one-sided uniform branches around
-  // a single panel load (an if/else with the panel in both arms makes the allocator spill the panel)
-  if (grpB && !(RD_ABL & 16)) { embed_masks(); embed_consume(); }
+  zero_plane_pads(Yh, ROWS, ROWS, ROWS, K, tid); zero_plane_pads(Yl, ROWS, ROWS, ROWS, K, tid);
   RD_STAMP(10);
-  load_panel(pw, wtiles(a, dm, 0, 0), nct, wave, lane);
+  // every wave requests its W1 panel under the observations' latency (cold in the step: ~6 k cycles), BEFORE it consumes them:
+  // the request only queues in the address unit, the barrier below waits for LDS traffic alone
+  if (!(RD_ABL & 16)) embed_masks();
+  if (!RD_K1_BLATE || !grpB) load_panel(pw, wtiles(a, dm, 0, 0), nct, wave, lane);
   RD_STAMP(11);
-  if (!grpB && !(RD_ABL & 16)) { embed_masks(); embed_consume(); }
-  if (!(RD_ABL & 16))
+  if (!(RD_ABL & 16)) {
+    embed_consume();
     for (int base = tid + NTHR * UNR; base < total; base += NTHR * UNR) { embed_issue(base); embed_masks(); embed_consume(); }
+  }
   if (lane == 0) LinW[wave] = lin_w;
+  if (sfi >= 0 && sfi < ROWS) { pin(sfv); Ss[sfi] = sfv; }
   RD_STAMP(1);
   lds_barrier();
   RD_STAMP(2);
@@ -573,13 +621,26 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
     if (a.plan && lin > L) atomicMax(const_cast<int*>(a.plan) + plan::I_SLACK, lin - L);
   }
 
-  // ---- layer 1: Y1 = relu(X W1^T + b1) * ssum;  X leaves as row tiles for dW1 (reads the fp32 copy) --------
+  // ---- layer 1: Y1 = relu(X W1^T + b1) * ssum;  X leaves as row tiles for dW1 (group B, straight from the planes) --------
   f32x4 acc[NJ][RT];
   zero_acc<RT>(acc);
-  if (grpB) {                                                // group B transposes while group A multiplies ...
-    tstore_stage(Xs, a.tpX, dm, sb, tid, nct, nct);
-    tzero_uncovered(a.tpX, dm, sb, tid);
-    tzero_uncovered(a.tpY1, dm, sb, tid);
+  if (grpB) {                                                // group B: the positional encoding while group A multiplies ...
+    if (RD_K1_BLATE) load_panel(pw, wtiles(a, dm, 0, 0), nct, wave, lane);
+    if (pe_on && !(RD_ABL & 8)) {
+      pin(pe_time); pin(pe_ts);
+      for (int i = gt; i < npe; i += GTHR) {
+        const int t = i / H, k = i - t * H;
+        float tm = pe_time, ts = pe_ts;
+        if (i != gt) { tm = a.times[(size_t)(m24(t, B) + b)]; ts = a.tscale[k]; }
+        const float ang = tm / ts;
+        float* row = a.z + (size_t)(m24(tk.row0 + m24(t, tk.rstride), dm.ldz) + F * 4);
+        float sn, cs;
+        sincosf(ang, &sn, &cs);                                // one argument reduction for the pair
+        row[k] = sn;
+        row[H + k] = cs;
+      }
+      for (int t = gt; t < T; t += GTHR) a.mask[(size_t)(m24(b, T) + t)] = (uint8_t)((int64_t)t >= len_b);
+    }
   }
   RD_STAMP(13);
   mma_mid<RT>(acc, Xh, Xl, pw, lane, kclim1, [&] {
@@ -588,17 +649,16 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   RD_STAMP(3);
   if (live2) load_panel_kc<NKC / 2, NKC>(pw, wtiles(a, dm, 1, 0), nct, wave, lane);   // second half
   RD_STAMP(12);
-  if (!grpB) {                                               // ... and the other way round
-    tstore_stage(Xs, a.tpX, dm, sb, tid, nct, nct);
-    tzero_uncovered(a.tpX, dm, sb, tid);
-    tzero_uncovered(a.tpY1, dm, sb, tid);
-  }
-  if (ALIAS) {                                               // the fp32 copy of X lives in the Y planes: everybody must be done with it
-    lds_barrier();
-    zero_plane_pads(Yh, ROWS, ROWS, ROWS, K, tid); zero_plane_pads(Yl, ROWS, ROWS, ROWS, K, tid);
+  if (!grpB) {                                               // ... and group A, whose product the matrix pipe served first, exports X's row tiles
+    tstore_planes_main(Xh, Xl, a.tpX, dm, sb, gw, GWAVE, lane, nct);
+    tstore_leftover_planes(Xh, Xl, a.tpX, dm, sb, gt, GTHR, K);
+    tzero_uncovered(a.tpX, dm, sb, gt, GTHR);
+    tzero_uncovered(a.tpY1, dm, sb, gt, GTHR);
   }
   RD_STAMP(14);
   // branch-free epilogue: pad rows carry srow == 0 and land in the planes' pad rows
+  float srow[RT][4];                                     // aggregate coefficient of this lane's rows
+  load_srow<RT>(srow, Ss, lane);
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
     const int j = wave + NWAVE * jj;
@@ -627,12 +687,13 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   // gate bits of layer 1 -> global (rows < F: 32 bytes each); leftover rows of Y1 -> row tiles
   for (int i = tid; i < 2 * F; i += NTHR)
     reinterpret_cast<uint4*>(a.m1 + (size_t)m24(sb, F * 16))[i] = reinterpret_cast<const uint4*>(M1)[i];
-  tstore_leftover_planes(Yh, Yl, a.tpY1, dm, sb, tid);
+  tstore_leftover_planes(Yh, Yl, a.tpY1, dm, sb, tid, NTHR, K);
 
   // ---- layer 2: Y2 = relu(Y1 W2^T + b2) * ssum -> fp32 staging (live column tiles only) ------------
   zero_acc<RT>(acc);
   if (live2) mma_panel<RT>(acc, Yh, Yl, pw, lane);
   RD_STAMP(6);
+  load_srow<RT>(srow, Ss, lane);
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
     const int j = wave + NWAVE * jj;
@@ -674,22 +735,8 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
       a.z[(size_t)(m24(tk.row0 + m24(t, tk.rstride), ldz) + q)] = Ys[(q >> 2) * LDS_F + t * 4 + (q & 3)];
     }
   }
-  // ---- positional encoding + padding mask of this sample (code/models_rd.py:28-38,298-299) ----
-  if (a.times != nullptr) {
-    const int H = dm.H;
-    for (int i = tid; i < L * H; i += NTHR) {
-      const int t = i / H, k = i - t * H;
-      const float ang = a.times[(size_t)(m24(t, B) + b)] / a.tscale[k];
-      float* row = a.z + (size_t)(m24(tk.row0 + m24(t, tk.rstride), ldz) + F * 4);
-      float sn, cs;
-      sincosf(ang, &sn, &cs);                                  // one argument reduction for the pair
-      row[k] = sn;
-      row[H + k] = cs;
-    }
-    const int64_t len = a.lengths[b];
-    for (int t = tid; t < T; t += NTHR) a.mask[(size_t)(m24(b, T) + t)] = (uint8_t)((int64_t)t >= len);
-  }
   RD_STAMP(9);
+  RD_STAMP_WG_END();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -700,30 +747,27 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
 template <int RT, int FC, int TC>
 __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  RD_TOUCH_CODE(11264);                                  // own code -> L2 (the smallest instantiation is 12.5 KB)
+  RD_TOUCH_CODE(RD_K1_BWD_TOUCH);                        // own code -> L2 (rd_common.h)
   constexpr int ROWS = RT * 16;
-  constexpr bool ALIAS = RT > 3;
   constexpr size_t PLANES = (size_t)4 * ROWS * LDX * sizeof(__bf16);
-  constexpr size_t ST_BYTES = ALIAS ? 0 : (size_t)ROWS * LDS_F * sizeof(float);
   __bf16* Dh = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* Dl = Dh + ROWS * LDX;
   __bf16* Eh = Dl + ROWS * LDX;
   __bf16* El = Eh + ROWS * LDX;
-  float* St = ALIAS ? reinterpret_cast<float*>(Eh) : reinterpret_cast<float*>(smem_raw + PLANES);   // fp32 [F][LDS_F]: dZ2
-  float* Sx = reinterpret_cast<float*>(Dh);              // second staging tile (dX), aliases the D planes
-  uint16_t* M1 = reinterpret_cast<uint16_t*>(smem_raw + PLANES + ST_BYTES);   // [ROWS][16]: Y1 > 0
+  float* Sx = reinterpret_cast<float*>(Dh);              // fp32 [F][LDS_F] staging tile of dX, aliases the D planes (dead by then)
+  uint16_t* M1 = reinterpret_cast<uint16_t*>(smem_raw + PLANES);              // [ROWS][16]: Y1 > 0
   uint16_t* M2 = M1 + ROWS * 16;                                               // [ROWS][16]: Y2 > 0
   float* Ss = reinterpret_cast<float*>(M2 + ROWS * 16);                        // [ROWS]: ssum
   float* Rp = reinterpret_cast<float*>(Eh);              // dR_u partial sums [groups][F*4], aliases the E planes (dead by then)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool grpB = __builtin_amdgcn_readfirstlane(wave) >= NWAVE / 2;   // scalar: the group branches are real branches
+  const bool grpB = __builtin_amdgcn_readfirstlane(wave) >= GWAVE;       // scalar: the group branches are real branches
+  const int gt = tid & (GTHR - 1), gw = __builtin_amdgcn_readfirstlane(wave) & (GWAVE - 1);
   const Tok tk = tok_of(a);
   const int b = tk.b, sb = tk.sb, L = tk.L;
   const Dim dm = dims_of<FC, TC>(a);
   const int T = dm.T, F = dm.F, K = dm.K, B = dm.B;
   const int nct = dm.nct;
   const int Fd = F * 4;
-  const int kq = K / 4;
   // dz is exactly zero at the padded steps t >= L (rd_plan.h) -- on the padded layout L == T.  So dZ2's columns >= 4L are zero:
   // the product dZ2 W2 stops after the last 32-column chunk with a live step, and rd_msgpass_dw.hip reads dZ2's column blocks
   // (64 columns = 16 steps) only for samples that are live there -- only those blocks are exported.
@@ -739,6 +783,10 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
     jlimL = min(nct, 4 * ((Lg + 15) >> 4));
   }
 
+  RD_STAMP_WG_START();
+#ifdef RD_K1_EMPTY
+  RD_STAMP_WG_END(); return;
+#endif
   RD_STAMP(0);
   if (blockIdx.x == 0 && tid < 192) {                                 // constant operand tiles [ones][zeros][zeros]: column 0 of the 16 is one
     bf16x8 o;
@@ -747,23 +795,22 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
     *reinterpret_cast<bf16x8*>(a.ones + tid * 8) = o;
   }
   Panel pw;
-  float srow[RT][4];
-  load_srow<RT>(srow, a.ssum, F, lane);
 
-  // ---- dZ2 = dz * ssum * (Y2 > 0), dz read coalesced in [t, f*d+c] order and transposed through LDS; the gate
-  // bits of both layers come from the forward pass (2 x 32 bytes per graph row).
-  // thread -> cell (t, f), f fastest: one 16-byte load per cell (the 4 channels), one 16-byte LDS store
+  // ---- dZ2 = dz * ssum * (Y2 > 0): dz read coalesced in [t, f*d+c] order, gated, split and stored straight into the D planes
+  // (row f, columns 4t .. 4t+3: half a 16-byte chunk, like the forward's embedding); the gate bits of both layers come from the
+  // forward pass (2 x 32 bytes per graph row) and wait in LDS.  (Rounds 2-4 went through an fp32 tile [F][244] and a second pass.)
+  // thread -> cell (t, f), f fastest: one 16-byte load per cell (the 4 channels)
   constexpr int GU = CPT;
   const int total = F * T;
   const int ldz = dm.ldz;
   const bool vec4 = (ldz & 3) == 0;
-  float4 dd[GU]; int gt[GU], gfi[GU];
+  float4 dd[GU]; int gtt[GU], gfi[GU];
   auto gather_issue = [&](int base) {
 #pragma unroll
     for (int u = 0; u < GU; ++u) {
       const int i = min(base + u * NTHR, total - 1);            // clamped duplicates rewrite the same cell
-      cell_tf(i, F, gt[u], gfi[u]);
-      const int tl = min(gt[u], max(L - 1, 0));                 // padded steps: a legal address, zeroed at the consumer
+      cell_tf(i, F, gtt[u], gfi[u]);
+      const int tl = min(gtt[u], max(L - 1, 0));                // padded steps: a legal address, zeroed at the consumer
       const float* p = a.dz + (size_t)(m24(tk.row0 + m24(tl, tk.rstride), ldz) + 4 * gfi[u]);
       if (vec4) dd[u] = *reinterpret_cast<const float4*>(p);
       else dd[u] = make_float4(p[0], p[1], p[2], p[3]);
@@ -773,13 +820,14 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
 #pragma unroll
     for (int u = 0; u < GU; ++u) {
       pin(dd[u]);
-      const int f = gfi[u], k = 4 * gt[u];
+      const int f = gfi[u], k = 4 * gtt[u];
       const float sf = Ss[f];
       unsigned bits = (unsigned)M2[f * 16 + (k >> 4)] >> (k & 15);           // 4 consecutive gate bits (k % 4 == 0)
-      if (gt[u] >= L) bits = 0;
-      *reinterpret_cast<float4*>(St + m24(f, LDS_F) + k) =
-          make_float4((bits & 1) ? dd[u].x * sf : 0.f, (bits & 2) ? dd[u].y * sf : 0.f, (bits & 4) ? dd[u].z * sf : 0.f,
-                      (bits & 8) ? dd[u].w * sf : 0.f);
+      if (gtt[u] >= L) bits = 0;
+      const float x[4] = {(bits & 1) ? dd[u].x * sf : 0.f, (bits & 2) ? dd[u].y * sf : 0.f, (bits & 4) ? dd[u].z * sf : 0.f,
+                          (bits & 8) ? dd[u].w * sf : 0.f};
+      const int o = pofs(f, k);
+      split_store4(Dh + o, Dl + o, x);
     }
   };
   uint4 mw = make_uint4(0, 0, 0, 0);
@@ -789,17 +837,17 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   float sfv = 0.f;
   if (tid >= NTHR - 64 && tid - (NTHR - 64) < F) sfv = a.ssum[tid - (NTHR - 64)];      // last wave: ssum -> LDS
   if (!(RD_ABL & 16)) gather_issue(tid);
-  load_panel(pw, wtiles(a, dm, 1, 1), nct, wave, lane);          // W2^T panel queues behind the gather
+  if (!RD_K1_BLATE || !grpB) load_panel(pw, wtiles(a, dm, 1, 1), nct, wave, lane);          // W2^T panel queues behind the gather
   RD_STAMP(10);
-  // D planes: zero the pads (rows >= F, columns >= K); the staging tile is fully written for rows < F, columns < K
+  // D planes: zero the pads (rows >= F, columns >= K; the gather writes the rest); E planes: pad columns (the epilogue writes every row)
   zero_plane_pads(Dh, ROWS, F, F, K, tid); zero_plane_pads(Dl, ROWS, F, F, K, tid);
-  if (!ALIAS) { zero_plane_pads(Eh, ROWS, ROWS, ROWS, K, tid); zero_plane_pads(El, ROWS, ROWS, ROWS, K, tid); }
+  zero_plane_pads(Eh, ROWS, ROWS, ROWS, K, tid); zero_plane_pads(El, ROWS, ROWS, ROWS, K, tid);
   if (tid < 4 * F) {
     pin(mw.x); pin(mw.y); pin(mw.z); pin(mw.w);
     if (tid < 2 * F) reinterpret_cast<uint4*>(M1)[tid] = mw;
     else reinterpret_cast<uint4*>(M2)[tid - 2 * F] = mw;
   }
-  if (tid >= NTHR - 64 && tid - (NTHR - 64) < F) { pin(sfv); Ss[tid - (NTHR - 64)] = sfv; }
+  if (tid >= NTHR - 64 && tid - (NTHR - 64) < ROWS) { pin(sfv); Ss[tid - (NTHR - 64)] = sfv; }   // 0 beyond F
   RD_STAMP(11);
   lds_barrier();
   RD_STAMP(12);
@@ -810,20 +858,8 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   RD_STAMP(13);
   lds_barrier();
   RD_STAMP(1);
-  // staging -> D planes (row-major, the A operand of the next product)
-  for (int i = tid; i < F * kq; i += NTHR) {
-    int f, kk;
-    cell_tf(i, kq, f, kk);                                     // i < 2^15, kq <= 64
-    const int k = 4 * kk;
-    const float4 v = *reinterpret_cast<const float4*>(St + m24(f, LDS_F) + k);
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    split_store4(Dh + m24(f, LDX) + k, Dl + m24(f, LDX) + k, x);
-  }
-  RD_STAMP(2);
-  lds_barrier();
-  RD_STAMP(3);
 
-  // ---- dZ1 = (dZ2 W2) * ssum * (Y1 > 0); dZ2 leaves as row tiles for dW2 (reads the staging tile) ---------
+  // ---- dZ1 = (dZ2 W2) * ssum * (Y1 > 0); dZ2 leaves as row tiles for dW2 (group B, straight from the planes) ---------
   // inputs of the dR_u pass: thread -> (time group tg, sensor f), f fastest (coalesced); its cells are t = tg, tg+TG, ...
   const int TG = NTHR / F;                                   // >= 8
   const int rtg = tid / F, rf = tid - rtg * F;
@@ -840,25 +876,23 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   };
   f32x4 acc[NJ][RT];
   zero_acc<RT>(acc);
-  if (grpB) {
-    tstore_stage(St, a.tpD2, dm, sb, tid, jlim, jlimL);
-    tzero_uncovered(a.tpD2, dm, sb, tid);
-    tzero_uncovered(a.tpD1, dm, sb, tid);
-  }
+  if (RD_K1_BLATE && grpB) load_panel(pw, wtiles(a, dm, 1, 1), nct, wave, lane);
+  RD_STAMP(2);
   mma_mid<RT>(acc, Dh, Dl, pw, lane, kclim2, [&] {
     if (liveX) load_panel_kc<0, NKC / 2>(pw, wtiles(a, dm, 0, 1), nct, wave, lane);   // W1^T, first half of the reduction
   });
   RD_STAMP(4);
   if (liveX) load_panel_kc<NKC / 2, NKC>(pw, wtiles(a, dm, 0, 1), nct, wave, lane);
   if (ract) ru_issue(rtg);
-  RD_STAMP(14);
-  if (!grpB) {
-    tstore_stage(St, a.tpD2, dm, sb, tid, jlim, jlimL);
-    tzero_uncovered(a.tpD2, dm, sb, tid);
-    tzero_uncovered(a.tpD1, dm, sb, tid);
+  if (!grpB) {                                               // group A (served first by the matrix pipe) exports dZ2 while group B multiplies
+    tstore_planes_main(Dh, Dl, a.tpD2, dm, sb, gw, GWAVE, lane, jlim);
+    tstore_leftover_planes(Dh, Dl, a.tpD2, dm, sb, gt, GTHR, 16 * jlimL);
+    tzero_uncovered(a.tpD2, dm, sb, gt, GTHR);
+    tzero_uncovered(a.tpD1, dm, sb, gt, GTHR);
   }
-  if (ALIAS) lds_barrier();                                    // staging tile lives in the E planes: everybody must be done with it
-  if (ALIAS) { zero_plane_pads(Eh, ROWS, ROWS, ROWS, K, tid); zero_plane_pads(El, ROWS, ROWS, ROWS, K, tid); }
+  RD_STAMP(14);
+  float srow[RT][4];
+  load_srow<RT>(srow, Ss, lane);
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
     const int j = wave + NWAVE * jj;
@@ -882,7 +916,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   RD_STAMP(5);
   lds_barrier();
   RD_STAMP(15);
-  tstore_leftover_planes(Eh, El, a.tpD1, dm, sb, tid);
+  tstore_leftover_planes(Eh, El, a.tpD1, dm, sb, tid, NTHR, K);
 
   // ---- dX = dZ1 W1 -> fp32 staging (the D planes are dead); observed column tiles only -----------
   zero_acc<RT>(acc);
@@ -932,6 +966,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
     a.rupart[(size_t)(m24(sb, Fd) + i)] = v;
   }
   RD_STAMP(9);
+  RD_STAMP_WG_END();
   // ---- warm the weight-gradient stream's COLD operands.  rd_msgpass_dw.hip runs right behind this kernel and streams four tile
   // tensors: dZ1 / dZ2 are written here (Infinity-Cache-hot), X / Y1 were written by the forward, a whole encoder forward +
   // backward ago (~700 MB of traffic: long evicted) -- in the step k_dw took 21 us against 12 in the isolated loop (slow box).
@@ -958,8 +993,8 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
 
 template <int RT, int FC, int TC>
 int launch_fused(const FusedArgs& a, bool bwd, hipStream_t st) {
-  const size_t lds = (size_t)4 * RT * 16 * LDX * sizeof(__bf16) + (RT > 3 ? 0 : (size_t)RT * 16 * LDS_F * sizeof(float)) +
-                     (size_t)2 * RT * 16 * 16 * sizeof(uint16_t) + (size_t)RT * 16 * sizeof(float);
+  const size_t lds = (size_t)4 * RT * 16 * LDX * sizeof(__bf16) + (size_t)2 * RT * 16 * 16 * sizeof(uint16_t) +
+                     (size_t)RT * 16 * sizeof(float) + (size_t)NWAVE * sizeof(int);   // planes, gate words of both layers, ssum, LinW (forward)
   if (!bwd) {
     RD_LDS_ATTR((k_msg_fwd_fused<RT, FC, TC>), lds);
     hipLaunchKernelGGL((k_msg_fwd_fused<RT, FC, TC>), dim3(a.B), dim3(NTHR), lds, st, a);
@@ -1001,7 +1036,7 @@ bool fused_msgpass_ok(const rd_shape* s) {
   const char* e = getenv("RD_K1_FUSED");
   const bool enabled = !(e && atoi(e) == 0);
   const int K = s->T * s->d_ob;
-  // staging tile [F][244] fp32 must fit inside two bf16 planes [RT*16][264]; d_ob == 4 only
+  // staging tile [F][244] fp32 must fit inside two bf16 planes [RT*16][256]; d_ob == 4 only
   // index arithmetic of the kernels is 32-bit with 24-bit multiplies: B*T rows < 2^22 (with ldz < 1024, checked at the call)
   return enabled && precision() == RD_PREC_BF16X3 && s->d_ob == 4 && s->F <= 48 && K <= 240 && (K % 16) == 0 && K >= 16 &&
          (long)s->B * s->T < (1L << 22);
@@ -1039,7 +1074,7 @@ int fused_msgpass_bwd(const k1::Layout& L, const float* src, const float* ssum, 
   a.src = src; a.ssum = ssum; a.wt = (const __bf16*)wt;
   a.m1 = (uint16_t*)const_cast<void*>(m1); a.m2 = (uint16_t*)const_cast<void*>(m2); a.mx = (uint8_t*)const_cast<void*>(mx);
   a.dz = dz; a.ldz = ldz; a.tpD1 = (__bf16*)tpD1; a.tpD2 = (__bf16*)tpD2; a.ones = (__bf16*)ones; a.rupart = rupart;
-  a.p_drop = p_drop; a.stamps = g_stamps;
+  a.p_drop = p_drop; a.stamps = g_stamps ? g_stamps + K1_STAMP_WORDS : nullptr;
   a.plan = token_plan();
   a.lin = reinterpret_cast<int*>(reinterpret_cast<char*>(const_cast<void*>(mx)) + k1::lin_offset(L.B, L.T, L.F));
   return launch_fused_shape(a, L, true, st);

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64 * WV) void k_rowgemm(RowGemmArgs a) {
   constexpr int RG_WAVES = WV, RG_THR = 64 * WV;
   constexpr int RT = RG_ROWS / 16, RG_CPR = RG_WAVES * RG_NJ * 16, RG_LDS_STAGE = RG_CPR + 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
-  constexpr int KPc = KC * 32, LDA = KPc + 8;       // bf16 elements per A-plane row
+  constexpr int KPc = KC * 32, LDA = KPc + 16;      // bf16 elements per A-plane row: + 32 bytes (conflict-free fragment reads, rd_encfuse.hip LDD)
   __bf16* Ah = reinterpret_cast<__bf16*>(rsm);
   __bf16* Al = Ah + RG_ROWS * LDA;
   float* stage = reinterpret_cast<float*>(Al + RG_ROWS * LDA);         // [64][260] fp32
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(64 * WV) void k_rowgemm(RowGemmArgs a) {
 
 template <int KC, int ROWS, int NJ, bool LN = false, bool LNB = false, int WV = 8>
 int launch_rowgemm_kc(const RowGemmArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)2 * ROWS * (KC * 32 + 8) * sizeof(__bf16) + (size_t)ROWS * (WV * NJ * 16 + 4) * sizeof(float) +
+  const size_t lds = (size_t)2 * ROWS * (KC * 32 + 16) * sizeof(__bf16) + (size_t)ROWS * (WV * NJ * 16 + 4) * sizeof(float) +
                      (LNB ? (size_t)WV * 2 * KC * 32 * sizeof(float) : 0);
   RD_LDS_ATTR((k_rowgemm<KC, ROWS, NJ, LN, LNB, WV>), lds);
   hipLaunchKernelGGL((k_rowgemm<KC, ROWS, NJ, LN, LNB, WV>), dim3(cdiv(a.M, ROWS)), dim3(64 * WV), lds, st, a);

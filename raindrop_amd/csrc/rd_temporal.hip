@@ -773,7 +773,7 @@ __device__ __forceinline__ void store_t4(__bf16* Ph, __bf16* Pl, int key, int q4
 template <int NTH, bool VEC>
 __global__ __launch_bounds__(256) void k_attn_fwd_one_b16(AttnArgs a, int one) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
-  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8;
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 16;
   __bf16* Qh = reinterpret_cast<__bf16*>(bsm);
   __bf16* Ql = Qh + TS * LDB;
   __bf16* Kh = Ql + TS * LDB;
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd_one_b16(AttnArgs a, int one) {
 template <int NTH, bool VEC>
 __global__ __launch_bounds__(256) void k_attn_bwd_one_b16(AttnArgs a, int one) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
-  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8;
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 16;
   __bf16* Qh = reinterpret_cast<__bf16*>(bsm);
   __bf16* Ql = Qh + TS * LDB;
   __bf16* Kh = Ql + TS * LDB;
@@ -995,7 +995,7 @@ template <int NTH, bool VEC>
 __global__ __launch_bounds__(512) void k_attn_fwd_one_b16w(AttnArgs a, int one) {
   RD_TOUCH_CODE_X(5632, blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y, 512);
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
-  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8, NA = (NTH + 1) / 2;
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 16, NA = (NTH + 1) / 2;
   __bf16* Qh = reinterpret_cast<__bf16*>(bsm);
   __bf16* Ql = Qh + TS * LDB;
   __bf16* Kh = Ql + TS * LDB;
@@ -1119,7 +1119,7 @@ template <int NTH, bool VEC>
 __global__ __launch_bounds__(512) void k_attn_bwd_one_b16w(AttnArgs a, int one) {
   RD_TOUCH_CODE_X(6144, blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y, 512);
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
-  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8, NA = (NTH + 1) / 2;
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 16, NA = (NTH + 1) / 2;
   __bf16* Qh = reinterpret_cast<__bf16*>(bsm);
   __bf16* Ql = Qh + TS * LDB;
   __bf16* Kh = Ql + TS * LDB;
@@ -1414,7 +1414,7 @@ template <int NTH, bool VEC, bool ONE>
 __global__ __launch_bounds__(64 * QW) void k_attn_fwd_b16(AttnArgs a) {
   RD_TOUCH_CODE_X(6912, blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y, 512);
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
-  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8, NKS = HDP / 32;
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 16, NKS = HDP / 32;
   __bf16* Kh = reinterpret_cast<__bf16*>(bsm);
   __bf16* Kl = Kh + TS * LDB;
   __bf16* Vh = Kl + TS * LDB;
@@ -1517,7 +1517,7 @@ template <int NTH, bool VEC, bool ONE>
 __global__ __launch_bounds__(64 * QW) void k_attn_bwd_dq_b16(AttnArgs a) {
   RD_TOUCH_CODE_X(7040, blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y, 512);
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
-  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8, NKS = HDP / 32;
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 16, NKS = HDP / 32;
   __bf16* Kh = reinterpret_cast<__bf16*>(bsm);
   __bf16* Kl = Kh + TS * LDB;
   __bf16* Vh = Kl + TS * LDB;
@@ -1619,7 +1619,7 @@ template <int NTH, bool VEC, bool ONE>
 __global__ __launch_bounds__(64 * QW) void k_attn_bwd_dkv_b16(AttnArgs a) {
   RD_TOUCH_CODE_X(6016, blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y, 512);
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
-  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8, NKS = HDP / 32;
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 16, NKS = HDP / 32;
   __bf16* Qh = reinterpret_cast<__bf16*>(bsm);
   __bf16* Ql = Qh + TS * LDB;
   __bf16* Oh = Ql + TS * LDB;                       // dO
@@ -1750,7 +1750,7 @@ static bool attn_b16_mt_ok(const AttnArgs& a) {
 template <int NTH>
 int launch_attn_b16_mt(const AttnArgs& a, int which, hipStream_t st) {
   const bool vec = attn_vec_ok(a);
-  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8;
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 16;
   const bool one = precision() == RD_PREC_BF16;
   const dim3 grid(cdiv(a.T, QROWS), a.B * a.H);
   const size_t planes = (size_t)4 * TS * LDB * sizeof(__bf16);
@@ -1773,7 +1773,7 @@ static bool attn_b16_ok(const AttnArgs& a) {
 template <int NTH>
 int launch_attn_b16(const AttnArgs& a_in, int which, hipStream_t st) {
   const bool vec = attn_vec_ok(a_in);
-  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 8;
+  constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 16;
   const int one = precision() == RD_PREC_BF16;
   AttnArgs a = a_in;
   a.stamps = g_attn_stamps;

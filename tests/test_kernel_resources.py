@@ -104,7 +104,7 @@ def test_own_code_touch_stays_inside_the_kernel(frag, touch):
     assert sizes, frag
     assert min(sizes) >= touch + 384, (frag, min(sizes), touch)
     src = "".join(open(os.path.join(build.CSRC, f)).read() for f in sorted(os.listdir(build.CSRC)) if f.endswith(".hip"))
-    assert re.search(r"(RD_TOUCH_CODE(_FIRST)?\(%d\b|touch \? %d :)" % (touch, touch), src), (frag, touch)
+    assert re.search(r"(RD_TOUCH_CODE(_FIRST)?\(%d\b|touch \? %d :|#define RD_\w+_TOUCH %d\b)" % (touch, touch, touch), src), (frag, touch)
 
 
 # the same prologue in the kernels outside the P19 step (rd_common.h RD_TOUCH_CODE_X: written in round 4, measured and made the default in
