@@ -24,8 +24,10 @@
 //   so no reduction slot is wasted on padding (P19: 256 main + 16 leftover tiles = 8704 / 32 exactly).  Positions
 //   of a leftover tile that no sample covers are written as zeros by the sample that owns position 0.
 //
-// ReLU gates as bits: m[b][f < F][16] uint16, bit (k & 15) of word (k >> 4) = (value[b,f,k] > 0); the observation
-// embedding's gate as one byte per (b, f, t) with bit c = (X[b,f,4t+c] > 0).
+// ReLU gates.  Y1 > 0 (m1): the 64-bit LANE MASKS of the epilogue that made the values, [slot][column tile j][row tile rt][e < 4]: bit
+// l = (Y1[16 rt + (l & 15)][16 j + 4 (l >> 4) + e] > 0) -- the backward's epilogue owns the same elements per lane and applies a mask as
+// the SGPR-pair operand of one v_cndmask.  Y2 > 0 (m2) and X > 0 (mx): one byte per (slot, t, f) cell with bit c = channel c, the
+// order in which the forward's scatter / embedding and the backward's dz gather / dR_u pass walk the cells.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -39,7 +41,7 @@ constexpr int TILE = 512;          // bf16 elements of one operand fragment (1 K
 
 struct Layout {
   int B, T, F, K, nct, RT, q, rem, per, S;
-  size_t wt_bytes, tp_bytes, gate_bytes, mx_bytes;
+  size_t wt_bytes, tp_bytes, g1_bytes, g2_bytes, mx_bytes;
 };
 
 // the per-sample "1 + last observed step" array rides behind the embedding's gate bytes
@@ -52,7 +54,8 @@ inline Layout make_layout(int B, int T, int F) {
   L.S = B * L.q + (L.rem ? (B + L.per - 1) / L.per : 0);
   L.wt_bytes = (size_t)4 * L.nct * NKC * 2 * TILE * 2;
   L.tp_bytes = (size_t)L.S * L.nct * 2 * TILE * 2;
-  L.gate_bytes = (size_t)B * F * 16 * sizeof(uint16_t);
+  L.g1_bytes = (size_t)B * L.nct * L.RT * 4 * sizeof(uint64_t);
+  L.g2_bytes = (size_t)B * F * T;
   L.mx_bytes = lin_offset(B, T, F) + (size_t)B * sizeof(int);      // gate bytes, then lin[B] (int per sample slot)
   return L;
 }

@@ -210,7 +210,7 @@ FusedSaved carve_fused_saved(const k1::Layout& L, void* base) {
   auto take = [&](size_t bytes) { void* p = base ? (void*)((char*)base + off) : nullptr;
                                   off += align_up(bytes, 256); return p; };
   v.wt = take(L.wt_bytes); v.tpX = take(L.tp_bytes); v.tpY1 = take(L.tp_bytes);
-  v.m1 = take(L.gate_bytes); v.m2 = take(L.gate_bytes); v.mx = take(L.mx_bytes);
+  v.m1 = take(L.g1_bytes); v.m2 = take(L.g2_bytes); v.mx = take(L.mx_bytes);
   v.bytes = off;
   return v;
 }

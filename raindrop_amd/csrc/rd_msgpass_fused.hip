@@ -51,8 +51,8 @@
 #ifndef RD_K1_BLATE
 #define RD_K1_BLATE 1
 #endif
-#define RD_K1_FWD_TOUCH 14080
-#define RD_K1_BWD_TOUCH 11264
+#define RD_K1_FWD_TOUCH 12544
+#define RD_K1_BWD_TOUCH 9728
 
 namespace rd {
 namespace {
@@ -86,7 +86,10 @@ struct FusedArgs {
   const __bf16* wt;              // weight tiles [layer 2][orient 2][nct][NKC][hi/lo][64][8]
   __bf16* ones;                  // bwd writes the constant bias-gradient operand tile of rd_msgpass_dw.hip here
   __bf16 *tpX, *tpY1, *tpD1, *tpD2;   // row tiles of X, Y1 (fwd writes) and dZ1, dZ2 (bwd writes)
-  uint16_t *m1, *m2; uint8_t* mx;     // gates: Y1 > 0, Y2 > 0 (bit per element), X > 0 (byte per (f,t))
+  // gates (rd_k1_layout.h): m1 = Y1 > 0 as 64-bit lane masks [slot][column tile][RT][4] of the epilogue that made them (the backward's
+  // epilogue has the same lane -> element map and applies them as v_cndmask operands); m2 = Y2 > 0 and mx = X > 0 as one byte per
+  // (slot, t, f) cell, bit c = channel c
+  uint64_t* m1; uint8_t *m2, *mx;
   float* z;
   const float* dz;               // bwd
   float* rupart;
@@ -244,18 +247,43 @@ __device__ __forceinline__ void load_panel(Panel& p, const __bf16* __restrict__ 
 __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(float4& x) { asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w)); }
 __device__ __forceinline__ void pin(unsigned& x) { asm volatile("" : "+v"(x)); }
-// Split value -> hi/lo planes with ONE 4-byte LDS store per lane: the MFMA accumulator layout puts columns
-// n (even lane) and n+1 (odd lane) of a row in neighbouring lanes; the pair swaps one half through a DPP
-// quad permute (no LDS traffic), the even lane stores (hi[n], hi[n+1]) to the hi plane and the odd lane
-// (lo[n], lo[n+1]) to the lo plane.  Must be called by all 64 lanes; n = column of this lane.
-__device__ __forceinline__ void store_split_pair(__bf16* Ph, __bf16* Pl, int row, int n, int lane, __bf16 h, __bf16 l) {
-  const unsigned hb = __builtin_bit_cast(unsigned short, h), lb = __builtin_bit_cast(unsigned short, l);
-  const bool odd = lane & 1;
-  const unsigned send = odd ? hb : lb;
-  const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, true);   // lane ^ 1
-  const unsigned word = odd ? (recv | (lb << 16)) : (hb | (recv << 16));
-  __bf16* P = odd ? Pl : Ph;
-  *reinterpret_cast<unsigned*>(P + pofs(row, n & ~1)) = word;
+// four consecutive columns (n0 % 4 == 0) of one row -> hi / lo planes: two packed conversions and one 8-byte LDS store per plane
+__device__ __forceinline__ void store_split_quad(__bf16* Ph, __bf16* Pl, int row, int n0, const float (&y)[4]) {
+  const int o = pofs(row, n0);
+  split_store4(Ph + o, Pl + o, y);
+}
+// 64-bit lane mask (a __ballot) -> lanes 2 k, 2 k + 1 of a collector register; lanes [0, 2 n) of it are stored by ONE instruction later
+// (v_writelane_b32 by inline asm: this compiler has no builtin for it; K is a compile-time constant after unrolling.  The mask comes
+// straight out of a v_cmp, and a VALU write of an SGPR needs 4 wait states before v_writelane reads it -- the compiler's hazard
+// recognizer does not look inside an asm statement, and without the s_nop the LOW half arrived stale on the device: half of the
+// columns of dZ1 gated by garbage, nondeterministically.)
+template <int K>
+__device__ __forceinline__ void collect_mask(int& gv, unsigned long long m) {
+  asm("s_nop 3\n\tv_writelane_b32 %0, %1, %3\n\tv_writelane_b32 %0, %2, %4"
+      : "+v"(gv) : "s"((unsigned)(m & 0xffffffffull)), "s"((unsigned)(m >> 32)), "n"(2 * K), "n"(2 * K + 1));
+}
+// x where this lane's bit of the uniform mask is set, 0 elsewhere: one v_cndmask with the mask as its SGPR-pair operand
+__device__ __forceinline__ float gate_by_mask(float x, unsigned long long m) {
+  float r;
+  asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(m));
+  return r;
+}
+// the RT * 4 masks of one (sample slot, column tile) through the scalar cache: RT 32-byte loads, one wait
+template <int RT>
+__device__ __forceinline__ void load_masks(const uint64_t* p, unsigned long long (&m)[RT * 4]) {
+  typedef unsigned u8v __attribute__((ext_vector_type(8)));
+  u8v v[RT];
+  if constexpr (RT == 1)
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v[0]) : "s"(p) : "memory");
+  else if constexpr (RT == 2)
+    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v[0]), "=&s"(v[1]) : "s"(p) : "memory");
+  else
+    asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx8 %1, %3, 0x20\n\ts_load_dwordx8 %2, %3, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(v[0]), "=&s"(v[1]), "=&s"(v[2]) : "s"(p) : "memory");
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[rt * 4 + i] = (unsigned long long)v[rt][2 * i] | ((unsigned long long)v[rt][2 * i + 1] << 32);
 }
 
 // zero what the products read but no phase writes: pad columns [K, KP) of rows [0, crow) and whole pad rows
@@ -318,9 +346,13 @@ __device__ __forceinline__ void mma_mid(f32x4 (&acc)[NJ][RT], const __bf16* Ah, 
       for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) {
-          acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], p.h[jj][kc], acc[jj][rt], 0, 0, 0);
-          acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.l[jj][kc], acc[jj][rt], 0, 0, 0);
-          acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.h[jj][kc], acc[jj][rt], 0, 0, 0);
+          // the WEIGHT fragment is the A operand: the accumulator then holds, per lane (c = lane & 15, g = lane >> 4), the FOUR
+          // CONSECUTIVE COLUMNS 16 j + 4 g .. of row 16 rt + c -- 8 contiguous bytes of a row-major plane, 16 of the fp32 staging
+          // tile -- instead of four rows of one column (rounds 1-4: a DPP pair exchange + a 4-byte store per element, 27
+          // instructions each; the epilogues were a third of the kernel's instructions)
+          acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p.h[jj][kc], al[rt], acc[jj][rt], 0, 0, 0);
+          acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p.l[jj][kc], ah[rt], acc[jj][rt], 0, 0, 0);
+          acc[jj][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p.h[jj][kc], ah[rt], acc[jj][rt], 0, 0, 0);
         }
         if (RD_K1_ROLL && kc + 1 < NKC) {                          // in-bounds whatever kclim is: the planes hold NKC steps
           ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * LDX + RD_AOFF(kc + 1));
@@ -351,16 +383,13 @@ __device__ __forceinline__ void mma_panel(f32x4 (&acc)[NJ][RT], const __bf16* Ah
   mma_mid<RT>(acc, Ah, Al, p, lane, kclim, [] {});
 }
 
-// srow[rt][r] = ssum[16 rt + 4 g + r] (0 beyond F) from the workgroup's LDS copy Ss[RT * 16] (written before the first barrier by
-// its first RT * 16 threads): read where an epilogue needs it, one 16-byte LDS read per row tile.  (Rounds 2-4 loaded the twelve
-// values from global memory at the kernel's start and carried them through both products: 12 of 128 registers.)
+// srow[rt] = ssum[16 rt + c] (0 beyond F), the aggregate coefficient of the lane's row in each row tile, from the workgroup's LDS copy
+// Ss[RT * 16] (written before the first barrier): read where an epilogue needs it.  (Rounds 2-4 carried twelve coefficients per lane
+// -- four rows per row tile -- from the kernel's start through both products: 12 of 128 registers.)
 template <int RT>
-__device__ __forceinline__ void load_srow(float (&srow)[RT][4], const float* Ss, int lane) {
+__device__ __forceinline__ void load_srow(float (&srow)[RT], const float* Ss, int lane) {
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    const float4 q = *reinterpret_cast<const float4*>(Ss + rt * 16 + 4 * (lane >> 4));
-    srow[rt][0] = q.x; srow[rt][1] = q.y; srow[rt][2] = q.z; srow[rt][3] = q.w;
-  }
+  for (int rt = 0; rt < RT; ++rt) srow[rt] = Ss[rt * 16 + (lane & 15)];
 }
 
 template <int RT>
@@ -437,23 +466,6 @@ __device__ __forceinline__ void tzero_uncovered(__bf16* tp, const Dim& a, int b,
   }
 }
 
-// Accumulator-sourced, main tiles: the MFMA C layout gives each lane 4 consecutive rows of one column = half a slot.
-// h/l[i] = split value at (row 16 rt + 4 g + i, column 16 j + c).  Row tiles rt >= 2 q hold leftover rows: those are
-// stored from the LDS planes after the epilogue's barrier (tstore_leftover_planes), two store instructions per wave
-// instead of sixteen mostly-masked ones.
-__device__ __forceinline__ void tstore_acc(__bf16* tp, const Dim& a, int b, int j, int rt, int lane,
-                                           const __bf16 (&h)[4], const __bf16 (&l)[4]) {
-  if (RD_ABL & 4) return;
-  const int c = lane & 15, g = lane >> 4;
-  if (rt < 2 * a.q) {                                    // uniform: this row tile is half of a main tile
-    bf16x4 hv, lv;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { hv[i] = h[i]; lv[i] = l[i]; }
-    __bf16* dst = tp_tile(tp, a.nct, b * a.q + (rt >> 1), j) + (c + 16 * (2 * (rt & 1) + (g >> 1))) * 8 + 4 * (g & 1);
-    st8(dst, hv);
-    st8(dst + TILE, lv);
-  }
-}
 // leftover rows (32 q + li, li < rem) of a tensor whose split planes are complete in LDS, columns [0, KL); by the calling threads
 // t of nthr (a whole workgroup or one group of it; nthr a multiple of 256)
 __device__ __forceinline__ void tstore_leftover_planes(const __bf16* Ph, const __bf16* Pl, __bf16* tp, const Dim& a,
@@ -494,9 +506,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   __bf16* Yh = Xl + ROWS * LDX;
   __bf16* Yl = Yh + ROWS * LDX;
   float* Ys = reinterpret_cast<float*>(smem_raw);        // fp32 [F][LDS_F] staging of Y2, aliases the X planes (F * 976 <= 2 * ROWS * 512)
-  uint16_t* M1 = reinterpret_cast<uint16_t*>(smem_raw + PLANES);                                     // [ROWS][16]
-  uint16_t* M2 = M1 + ROWS * 16;
-  float* Ss = reinterpret_cast<float*>(M2 + ROWS * 16);   // [ROWS]: ssum (0 beyond F)
+  float* Ss = reinterpret_cast<float*>(smem_raw + PLANES);   // [ROWS]: ssum (0 beyond F)
   int* LinW = reinterpret_cast<int*>(Ss + ROWS);          // [NWAVE] per-wave "1 + last observed step"
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool grpB = __builtin_amdgcn_readfirstlane(wave) >= GWAVE;       // scalar: the group branches are real branches
@@ -520,11 +530,11 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   float sfv = 0.f;                                       // ssum -> LDS (last wave; the epilogues read their rows' coefficients there)
   const int sfi = tid - (NTHR - 64);
   if (sfi >= 0 && sfi < F) sfv = a.ssum[sfi];
-  float bias1[NJ], bias2[NJ];                            // both layers' biases: ahead of the weight stream
+  float4 bias1[NJ], bias2[NJ];                           // both layers' biases of the lane's four columns: ahead of the weight stream
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
-    const int n = 16 * min(wave + NWAVE * jj, nct - 1) + (lane & 15);
-    bias1[jj] = a.b1[n]; bias2[jj] = a.b2[n];
+    const int n0 = 16 * min(wave + NWAVE * jj, nct - 1) + 4 * (lane >> 4);
+    bias1[jj] = *reinterpret_cast<const float4*>(a.b1 + n0); bias2[jj] = *reinterpret_cast<const float4*>(a.b2 + n0);
   }
 
   // ---- observation embedding -> X planes (+ gate byte) ----
@@ -656,37 +666,34 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
     tzero_uncovered(a.tpY1, dm, sb, gt, GTHR);
   }
   RD_STAMP(14);
-  // branch-free epilogue: pad rows carry srow == 0 and land in the planes' pad rows
-  float srow[RT][4];                                     // aggregate coefficient of this lane's rows
+  // branch-free epilogue: pad rows carry srow == 0 and land in the planes' pad rows.  Lane (c, g): row 16 rt + c, columns 16 j + 4 g ..
+  float srow[RT];                                        // aggregate coefficient of this lane's row in each row tile
   load_srow<RT>(srow, Ss, lane);
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
     const int j = wave + NWAVE * jj;
     if (j < nct) {                                              // wave-uniform
-      const int n = 16 * j + (lane & 15);
-      const float bias = bias1[jj];
+      const int n0 = 16 * j + 4 * (lane >> 4);
+      const float4 bias = bias1[jj];
+      int gv = 0;                                               // gate masks Y1 > 0 of this column tile: [RT][4] x 64 bits, two lanes each
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        __bf16 hh[4], ll[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rt * 16 + 4 * (lane >> 4) + r;
-          const float y = fmaxf(acc[jj][rt][r] + bias, 0.f) * srow[rt][r];
-          hh[r] = (__bf16)y; ll[r] = (__bf16)(y - (float)hh[r]);
-          store_split_pair(Yh, Yl, row, n, lane, hh[r], ll[r]);
-          const unsigned long long bal = __ballot(y > 0.f);
-          if ((lane & 15) == 0) M1[row * 16 + j] = (uint16_t)(bal >> (16 * (lane >> 4)));
-        }
-        tstore_acc(a.tpY1, dm, sb, j, rt, lane, hh, ll);
+        const float y[4] = {fmaxf(acc[jj][rt][0] + bias.x, 0.f) * srow[rt], fmaxf(acc[jj][rt][1] + bias.y, 0.f) * srow[rt],
+                            fmaxf(acc[jj][rt][2] + bias.z, 0.f) * srow[rt], fmaxf(acc[jj][rt][3] + bias.w, 0.f) * srow[rt]};
+        store_split_quad(Yh, Yl, rt * 16 + (lane & 15), n0, y);
+        // (rt is a compile-time constant after unrolling; the collector slots are immediates)
+        if (rt == 0) { collect_mask<0>(gv, __ballot(y[0] > 0.f)); collect_mask<1>(gv, __ballot(y[1] > 0.f)); collect_mask<2>(gv, __ballot(y[2] > 0.f)); collect_mask<3>(gv, __ballot(y[3] > 0.f)); }
+        if (rt == 1) { collect_mask<4>(gv, __ballot(y[0] > 0.f)); collect_mask<5>(gv, __ballot(y[1] > 0.f)); collect_mask<6>(gv, __ballot(y[2] > 0.f)); collect_mask<7>(gv, __ballot(y[3] > 0.f)); }
+        if (rt == 2) { collect_mask<8>(gv, __ballot(y[0] > 0.f)); collect_mask<9>(gv, __ballot(y[1] > 0.f)); collect_mask<10>(gv, __ballot(y[2] > 0.f)); collect_mask<11>(gv, __ballot(y[3] > 0.f)); }
       }
+      if (lane < RT * 8) reinterpret_cast<int*>(a.m1 + (size_t)(m24(sb, nct) + j) * (RT * 4))[lane] = gv;
     }
   }
   RD_STAMP(4);
   lds_barrier();
   RD_STAMP(5);
-  // gate bits of layer 1 -> global (rows < F: 32 bytes each); leftover rows of Y1 -> row tiles
-  for (int i = tid; i < 2 * F; i += NTHR)
-    reinterpret_cast<uint4*>(a.m1 + (size_t)m24(sb, F * 16))[i] = reinterpret_cast<const uint4*>(M1)[i];
+  // Y1 -> row tiles for dW2, straight from the planes (every wave takes its share of the 2 q nct tile parts; the leftover rows as before)
+  tstore_planes_main(Yh, Yl, a.tpY1, dm, sb, __builtin_amdgcn_readfirstlane(wave), NWAVE, lane, nct);
   tstore_leftover_planes(Yh, Yl, a.tpY1, dm, sb, tid, NTHR, K);
 
   // ---- layer 2: Y2 = relu(Y1 W2^T + b2) * ssum -> fp32 staging (live column tiles only) ------------
@@ -698,42 +705,34 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   for (int jj = 0; jj < NJ; ++jj) {
     const int j = wave + NWAVE * jj;
     if (j < nct && 4 * j < L) {                                 // wave-uniform
-      const int n = 16 * j + (lane & 15);
-      const float bias = bias2[jj];
+      const int n0 = 16 * j + 4 * (lane >> 4);
+      const float4 bias = bias2[jj];
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rt * 16 + 4 * (lane >> 4) + r;      // rows >= F land in the staging tile's slack
-          const float y = fmaxf(acc[jj][rt][r] + bias, 0.f) * srow[rt][r];
-          Ys[row * LDS_F + n] = y;
-          const unsigned long long bal = __ballot(y > 0.f);
-          if ((lane & 15) == 0) M2[row * 16 + j] = (uint16_t)(bal >> (16 * (lane >> 4)));
-        }
+      for (int rt = 0; rt < RT; ++rt) {                         // rows >= F land in the staging tile's slack
+        *reinterpret_cast<float4*>(Ys + (rt * 16 + (lane & 15)) * LDS_F + n0) =
+            make_float4(fmaxf(acc[jj][rt][0] + bias.x, 0.f) * srow[rt], fmaxf(acc[jj][rt][1] + bias.y, 0.f) * srow[rt],
+                        fmaxf(acc[jj][rt][2] + bias.z, 0.f) * srow[rt], fmaxf(acc[jj][rt][3] + bias.w, 0.f) * srow[rt]);
+      }
     }
   }
   RD_STAMP(7);
   lds_barrier();
   RD_STAMP(8);
-  for (int i = tid; i < 2 * F; i += NTHR)
-    reinterpret_cast<uint4*>(a.m2 + (size_t)m24(sb, F * 16))[i] = reinterpret_cast<const uint4*>(M2)[i];
   // ---- [F, T*d] -> z[row(t), f*d + c]: thread -> (t, f) with f fastest moves the 4 channels of a cell as one 16-byte
   // LDS read (conflict-free at stride 244) and one 16-byte store; consecutive lanes write consecutive addresses.
-  // Live steps only (t < L; L == T on the padded layout).
+  // Live steps only (t < L; L == T on the padded layout).  The cell's gate byte (Y2 > 0, bit c = channel c; what the backward's dz
+  // gather needs, in ITS thread order) leaves with it: [slot][t][f], consecutive lanes -> consecutive bytes.
   const int ldz = dm.ldz;
   if (RD_ABL & 8) return;
-  if ((ldz & 3) == 0) {
-    for (int i = tid; i < L * F; i += NTHR) {
-      int t, f;
-      cell_tf(i, F, t, f);
-      st16f(a.z + (size_t)(m24(tk.row0 + m24(t, tk.rstride), ldz) + 4 * f), *reinterpret_cast<const float4*>(Ys + m24(f, LDS_F) + 4 * t));
-    }
-  } else {
-    const int Fd = F * 4;
-    for (int i = tid; i < L * Fd; i += NTHR) {
-      const int t = i / Fd, q = i - t * Fd;
-      a.z[(size_t)(m24(tk.row0 + m24(t, tk.rstride), ldz) + q)] = Ys[(q >> 2) * LDS_F + t * 4 + (q & 3)];
-    }
+  for (int i = tid; i < L * F; i += NTHR) {
+    int t, f;
+    cell_tf(i, F, t, f);
+    const float4 y = *reinterpret_cast<const float4*>(Ys + m24(f, LDS_F) + 4 * t);
+    float* dst = a.z + (size_t)(m24(tk.row0 + m24(t, tk.rstride), ldz) + 4 * f);
+    if ((ldz & 3) == 0) st16f(dst, y);
+    else { dst[0] = y.x; dst[1] = y.y; dst[2] = y.z; dst[3] = y.w; }
+    a.m2[(size_t)(m24(sb, total) + m24(t, F) + f)] =
+        (uint8_t)((y.x > 0.f ? 1 : 0) | (y.y > 0.f ? 2 : 0) | (y.z > 0.f ? 4 : 0) | (y.w > 0.f ? 8 : 0));
   }
   RD_STAMP(9);
   RD_STAMP_WG_END();
@@ -755,9 +754,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   __bf16* Eh = Dl + ROWS * LDX;
   __bf16* El = Eh + ROWS * LDX;
   float* Sx = reinterpret_cast<float*>(Dh);              // fp32 [F][LDS_F] staging tile of dX, aliases the D planes (dead by then)
-  uint16_t* M1 = reinterpret_cast<uint16_t*>(smem_raw + PLANES);              // [ROWS][16]: Y1 > 0
-  uint16_t* M2 = M1 + ROWS * 16;                                               // [ROWS][16]: Y2 > 0
-  float* Ss = reinterpret_cast<float*>(M2 + ROWS * 16);                        // [ROWS]: ssum
+  float* Ss = reinterpret_cast<float*>(smem_raw + PLANES);                    // [ROWS]: ssum (0 beyond F)
   float* Rp = reinterpret_cast<float*>(Eh);              // dR_u partial sums [groups][F*4], aliases the E planes (dead by then)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool grpB = __builtin_amdgcn_readfirstlane(wave) >= GWAVE;       // scalar: the group branches are real branches
@@ -804,7 +801,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   const int total = F * T;
   const int ldz = dm.ldz;
   const bool vec4 = (ldz & 3) == 0;
-  float4 dd[GU]; int gtt[GU], gfi[GU];
+  float4 dd[GU]; int gtt[GU], gfi[GU]; unsigned gb[GU]; float gs[GU];
   auto gather_issue = [&](int base) {
 #pragma unroll
     for (int u = 0; u < GU; ++u) {
@@ -814,15 +811,17 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
       const float* p = a.dz + (size_t)(m24(tk.row0 + m24(tl, tk.rstride), ldz) + 4 * gfi[u]);
       if (vec4) dd[u] = *reinterpret_cast<const float4*>(p);
       else dd[u] = make_float4(p[0], p[1], p[2], p[3]);
+      gb[u] = a.m2[(size_t)(m24(sb, total) + m24(tl, F) + gfi[u])];      // the cell's gate byte (the forward's scatter wrote it in this order)
+      gs[u] = a.ssum[gfi[u]];
     }
   };
   auto gather_consume = [&]() {
 #pragma unroll
     for (int u = 0; u < GU; ++u) {
-      pin(dd[u]);
+      pin(dd[u]); pin(gb[u]); pin(gs[u]);
       const int f = gfi[u], k = 4 * gtt[u];
-      const float sf = Ss[f];
-      unsigned bits = (unsigned)M2[f * 16 + (k >> 4)] >> (k & 15);           // 4 consecutive gate bits (k % 4 == 0)
+      const float sf = gs[u];
+      unsigned bits = gb[u];
       if (gtt[u] >= L) bits = 0;
       const float x[4] = {(bits & 1) ? dd[u].x * sf : 0.f, (bits & 2) ? dd[u].y * sf : 0.f, (bits & 4) ? dd[u].z * sf : 0.f,
                           (bits & 8) ? dd[u].w * sf : 0.f};
@@ -830,27 +829,19 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
       split_store4(Dh + o, Dl + o, x);
     }
   };
-  uint4 mw = make_uint4(0, 0, 0, 0);
-  if (tid < 4 * F)                                           // threads [0,2F): M1 rows, [2F,4F): M2 rows
-    mw = tid < 2 * F ? reinterpret_cast<const uint4*>(a.m1 + (size_t)m24(sb, F * 16))[tid]
-                     : reinterpret_cast<const uint4*>(a.m2 + (size_t)m24(sb, F * 16))[tid - 2 * F];
   float sfv = 0.f;
-  if (tid >= NTHR - 64 && tid - (NTHR - 64) < F) sfv = a.ssum[tid - (NTHR - 64)];      // last wave: ssum -> LDS
+  if (tid >= NTHR - 64 && tid - (NTHR - 64) < F) sfv = a.ssum[tid - (NTHR - 64)];      // last wave: ssum -> LDS (the epilogue's coefficients)
   if (!(RD_ABL & 16)) gather_issue(tid);
   if (!RD_K1_BLATE || !grpB) load_panel(pw, wtiles(a, dm, 1, 1), nct, wave, lane);          // W2^T panel queues behind the gather
+  // the gate masks Y1 > 0 of this wave's column tile: uniform, through the scalar cache, under the gather's latency
+  unsigned long long g1m[RT * 4];
+  load_masks<RT>(a.m1 + (size_t)(m24(sb, nct) + min(__builtin_amdgcn_readfirstlane(wave), nct - 1)) * (RT * 4), g1m);
   RD_STAMP(10);
   // D planes: zero the pads (rows >= F, columns >= K; the gather writes the rest); E planes: pad columns (the epilogue writes every row)
   zero_plane_pads(Dh, ROWS, F, F, K, tid); zero_plane_pads(Dl, ROWS, F, F, K, tid);
   zero_plane_pads(Eh, ROWS, ROWS, ROWS, K, tid); zero_plane_pads(El, ROWS, ROWS, ROWS, K, tid);
-  if (tid < 4 * F) {
-    pin(mw.x); pin(mw.y); pin(mw.z); pin(mw.w);
-    if (tid < 2 * F) reinterpret_cast<uint4*>(M1)[tid] = mw;
-    else reinterpret_cast<uint4*>(M2)[tid - 2 * F] = mw;
-  }
   if (tid >= NTHR - 64 && tid - (NTHR - 64) < ROWS) { pin(sfv); Ss[tid - (NTHR - 64)] = sfv; }   // 0 beyond F
   RD_STAMP(11);
-  lds_barrier();
-  RD_STAMP(12);
   if (!(RD_ABL & 16)) {
     gather_consume();
     for (int base = tid + GU * NTHR; base < total; base += GU * NTHR) { gather_issue(base); gather_consume(); }
@@ -891,31 +882,26 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
     tzero_uncovered(a.tpD1, dm, sb, gt, GTHR);
   }
   RD_STAMP(14);
-  float srow[RT][4];
+  float srow[RT];
   load_srow<RT>(srow, Ss, lane);
-#pragma unroll
-  for (int jj = 0; jj < NJ; ++jj) {
-    const int j = wave + NWAVE * jj;
+  static_assert(NJ == 1, "the gate masks are loaded for one column tile per wave");
+  {
+    const int j = wave;
     if (j < nct) {                                              // wave-uniform; body is branch-free
-      const int n = 16 * j + (lane & 15);
+      const int n0 = 16 * j + 4 * (lane >> 4);
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        __bf16 hh[4], ll[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rt * 16 + 4 * (lane >> 4) + r;      // pad rows: srow == 0
-          const bool open = (M1[row * 16 + j] >> (lane & 15)) & 1;
-          const float g = open ? acc[jj][rt][r] * srow[rt][r] : 0.f;
-          hh[r] = (__bf16)g; ll[r] = (__bf16)(g - (float)hh[r]);
-          store_split_pair(Eh, El, row, n, lane, hh[r], ll[r]);
-        }
-        tstore_acc(a.tpD1, dm, sb, j, rt, lane, hh, ll);
+      for (int rt = 0; rt < RT; ++rt) {                         // pad rows: srow == 0
+        const float gq[4] = {gate_by_mask(acc[0][rt][0] * srow[rt], g1m[rt * 4 + 0]), gate_by_mask(acc[0][rt][1] * srow[rt], g1m[rt * 4 + 1]),
+                             gate_by_mask(acc[0][rt][2] * srow[rt], g1m[rt * 4 + 2]), gate_by_mask(acc[0][rt][3] * srow[rt], g1m[rt * 4 + 3])};
+        store_split_quad(Eh, El, rt * 16 + (lane & 15), n0, gq);
       }
     }
   }
   RD_STAMP(5);
   lds_barrier();
   RD_STAMP(15);
+  // dZ1 -> row tiles for dW1, straight from the planes
+  tstore_planes_main(Eh, El, a.tpD1, dm, sb, __builtin_amdgcn_readfirstlane(wave), NWAVE, lane, nct);
   tstore_leftover_planes(Eh, El, a.tpD1, dm, sb, tid, NTHR, K);
 
   // ---- dX = dZ1 W1 -> fp32 staging (the D planes are dead); observed column tiles only -----------
@@ -926,11 +912,11 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   for (int jj = 0; jj < NJ; ++jj) {
     const int j = wave + NWAVE * jj;
     if (j < nct && 4 * j < lin) {
-      const int n = 16 * j + (lane & 15);
+      const int n = 16 * j + 4 * (lane >> 4);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Sx[(rt * 16 + 4 * (lane >> 4) + r) * LDS_F + n] = acc[jj][rt][r];
+        *reinterpret_cast<float4*>(Sx + (rt * 16 + (lane & 15)) * LDS_F + n) =
+            make_float4(acc[jj][rt][0], acc[jj][rt][1], acc[jj][rt][2], acc[jj][rt][3]);
     }
   }
   RD_STAMP(7);
@@ -993,8 +979,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
 
 template <int RT, int FC, int TC>
 int launch_fused(const FusedArgs& a, bool bwd, hipStream_t st) {
-  const size_t lds = (size_t)4 * RT * 16 * LDX * sizeof(__bf16) + (size_t)2 * RT * 16 * 16 * sizeof(uint16_t) +
-                     (size_t)RT * 16 * sizeof(float) + (size_t)NWAVE * sizeof(int);   // planes, gate words of both layers, ssum, LinW (forward)
+  const size_t lds = (size_t)4 * RT * 16 * LDX * sizeof(__bf16) + (size_t)RT * 16 * sizeof(float) + (size_t)NWAVE * sizeof(int);   // planes, ssum, LinW (forward)
   if (!bwd) {
     RD_LDS_ATTR((k_msg_fwd_fused<RT, FC, TC>), lds);
     hipLaunchKernelGGL((k_msg_fwd_fused<RT, FC, TC>), dim3(a.B), dim3(NTHR), lds, st, a);
@@ -1055,7 +1040,7 @@ int fused_msgpass_fwd(const k1::Layout& L, const float* src, const float* R_u, c
   fill_layout(a, L);
   a.times = times; a.lengths = lengths; a.tscale = tscale; a.mask = mask; a.d_pe = d_pe;
   a.src = src; a.R_u = R_u; a.b1 = b1; a.b2 = b2; a.ssum = ssum; a.wt = (const __bf16*)wt;
-  a.tpX = (__bf16*)tpX; a.tpY1 = (__bf16*)tpY1; a.m1 = (uint16_t*)m1; a.m2 = (uint16_t*)m2; a.mx = (uint8_t*)mx;
+  a.tpX = (__bf16*)tpX; a.tpY1 = (__bf16*)tpY1; a.m1 = (uint64_t*)m1; a.m2 = (uint8_t*)m2; a.mx = (uint8_t*)mx;
   a.z = z; a.ldz = ldz;
   a.p_drop = p_drop; a.seed = seed; a.seed_cell = seed_cell(); a.stamps = g_stamps;
   a.plan = token_plan(); a.lin = reinterpret_cast<int*>(reinterpret_cast<char*>(mx) + k1::lin_offset(L.B, L.T, L.F));
@@ -1072,7 +1057,7 @@ int fused_msgpass_bwd(const k1::Layout& L, const float* src, const float* ssum, 
     a.tpX = warm ? (__bf16*)const_cast<void*>(tpX) : nullptr; a.tpY1 = warm ? (__bf16*)const_cast<void*>(tpY1) : nullptr;
   }
   a.src = src; a.ssum = ssum; a.wt = (const __bf16*)wt;
-  a.m1 = (uint16_t*)const_cast<void*>(m1); a.m2 = (uint16_t*)const_cast<void*>(m2); a.mx = (uint8_t*)const_cast<void*>(mx);
+  a.m1 = (uint64_t*)const_cast<void*>(m1); a.m2 = (uint8_t*)const_cast<void*>(m2); a.mx = (uint8_t*)const_cast<void*>(mx);
   a.dz = dz; a.ldz = ldz; a.tpD1 = (__bf16*)tpD1; a.tpD2 = (__bf16*)tpD2; a.ones = (__bf16*)ones; a.rupart = rupart;
   a.p_drop = p_drop; a.stamps = g_stamps ? g_stamps + K1_STAMP_WORDS : nullptr;
   a.plan = token_plan();

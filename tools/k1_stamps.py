@@ -20,13 +20,14 @@ m = Raindrop_v2(cfg["d_inp"], cfg["d_model"], 2, cfg["nhid"], 2, 0.2, cfg["max_l
                 synth.make_structure(cfg, "ones")).to(dev).train()
 b = {k: (None if v is None else v.to(dev)) for k, v in synth.make_batch(cfg, B, seed=100).items()}
 
-FWD = [(0, "start (own code touched)"), (10, "[B: masks + embed consumed]"), (11, "W1 panel issued"), (1, "embed phase done"), (2, "barrier 1"),
-       (13, "[B: X row tiles stored]"), (3, "GEMM1 (+ W2 first half issued)"), (12, "W2 second half issued"), (14, "[A: X row tiles stored]"),
-       (4, "epilogue 1"), (5, "barrier 2"), (6, "GEMM2"), (7, "epilogue 2"), (8, "barrier 3"), (9, "scatter z + PE (end)")]
-BWD = [(0, "start"), (10, "dz gather + W2^T panel issued"), (11, "pads zeroed, masks in LDS"), (12, "barrier"), (13, "dz -> staging"), (1, "barrier"),
-       (2, "staging -> D planes"), (3, "barrier"), (4, "GEMM dZ2 W2 [B: after row tiles]"), (14, "W1^T 2nd half + dR_u loads issued"),
-       (5, "epilogue dZ1 [A: after row tiles]"), (15, "barrier"), (6, "GEMM dZ1 W1"), (7, "dX -> staging"), (8, "barrier + dR_u pass 1"),
-       (9, "barrier + pass 2 (end)")]
+FWD = [(0, "start (own code touched)"), (10, "loads issued, pads zeroed"), (11, "masks made, W1 panel issued (A)"), (1, "observations consumed"),
+       (2, "barrier 1"), (13, "[B: W1 panel issued, PE + mask written]"), (3, "GEMM1 (+ W2 first half issued)"), (12, "W2 second half issued"),
+       (14, "[A: X row tiles stored]"), (4, "epilogue 1"), (5, "barrier 2"), (6, "Y1 row tiles + GEMM2"), (7, "epilogue 2"), (8, "barrier 3"),
+       (9, "scatter z + gate bytes (end)")]
+BWD = [(0, "start"), (10, "gather + W2^T panel (A) issued, gate masks loaded"), (11, "pads zeroed"), (13, "dz consumed -> D planes"), (1, "barrier 1"),
+       (2, "[B: W2^T panel issued]"), (4, "GEMM dZ2 W2 (+ W1^T first half issued)"), (14, "W1^T 2nd half, dR_u loads [A: dZ2 row tiles]"),
+       (5, "epilogue dZ1"), (15, "barrier 2"), (6, "dZ1 row tiles + GEMM dZ1 W1"), (7, "dX -> staging"), (8, "barrier 3 + dR_u pass 1"),
+       (9, "barrier 4 + pass 2 (end)")]
 
 
 def show(tag, s, names):
