@@ -646,6 +646,8 @@ def main():
     if world > 1:
         dp.broadcast_parameters(model, src=0)
     model.train()
+    model.graph_step = False    # the timed step below is raindrop_amd.step.TrainStep; `eager_step` = the operator-by-operator module surface (the
+                                # module's DEFAULT, the captured step behind model.forward, is measured separately at the end: config.eager_ms_per_step)
     B = args.batch
     batch = synth.make_batch(cfg, B, seed=100 + rank)             # each rank its own shard (weak scaling)
     batch = {k: (None if v is None else v.to(dev)) for k, v in batch.items()}
@@ -853,7 +855,8 @@ def main():
     t_module = None
     if world == 1 and not args.no_roofline:
         try:
-            model.graph_step = True
+            model.graph_step = None                                       # the module's default: what an unchanged loop gets
+            os.environ.pop("RD_MODULE_GRAPH", None)
             eager_step(); eager_step()
             if getattr(model, "_graph_runners", None) and any(r for r in model._graph_runners.values()):
                 t_module = time_mode(eager_step, n=20)
@@ -886,12 +889,14 @@ def main():
                        "batch_source": ("rd_batch_gather from a device-resident dataset (N=8192) every step" if feed_next
                                         else "one resident batch re-used (inputs in HBM before the timed region)"),
                        "arithmetic": ARITH[prec],
-                       # the drop-in path of code/Raindrop.py:319-323 (model.forward -> criterion -> loss.backward() through autograd, one
-                       # C-ABI call per operator, + flat.finish() + Adam), same batch, same kernels: what the unmodified script gets
-                       "eager_ms_per_step": None if t_eager is None else round(t_eager * 1e3, 4),
-                       # the same loop with the model's forward / backward captured as two hipGraphs behind the nn.Module surface
-                       # (RD_MODULE_GRAPH=1; the loss, autograd's accumulation into p.grad and the optimizer stay the loop's)
+                       # the drop-in path of code/Raindrop.py:319-323 (model.forward -> criterion -> loss.backward() through autograd, +
+                       # flat.finish() + Adam), same batch, same kernels: what the unmodified script gets BY DEFAULT -- since round 5 the
+                       # model's forward / backward as two hipGraphs behind the nn.Module surface (raindrop_amd/graph_module.py; the
+                       # loss, autograd's accumulation into p.grad and the optimizer stay the loop's)
+                       "eager_ms_per_step": round((t_module if t_module is not None else t_eager) * 1e3, 4) if (t_module or t_eager) else None,
                        "module_graph_ms_per_step": None if t_module is None else round(t_module * 1e3, 4),
+                       # the same loop with RD_MODULE_GRAPH=0: one C-ABI call per operator under autograd (rounds 1-4's default)
+                       "operator_by_operator_ms_per_step": None if t_eager is None else round(t_eager * 1e3, 4),
                        "token_plan": ("on: the padding mask (code/models_rd.py:298-299) applied as a layout -- only the %d live (sample, step) rows "
                                       "of %d are stored and processed; logits, loss and every gradient are the same function of the inputs "
                                       "(tests/test_token_plan_gpu.py); config.padded_layout_ms_per_step is the same step with every padded row "

@@ -117,7 +117,7 @@ class Observation_progation(nn.Module):
         if self.heads != 1:
             raise _lib.RaindropHipError("RD_EUNSUPPORTED: heads != 1")
         V = ops.linear(x, self.lin_value.weight, self.lin_value.bias, act=1)
-        H = ops.linear(x, self.increase_dim.weight, self.increase_dim.bias)
+        H = ops.linear(x, self.increase_dim.weight, self.increase_dim.bias, exact=True)     # feeds the top-K pruning: exact fp32 in every mode
         out, ei2, alpha = ops.graph_beta(V.unsqueeze(0), H.unsqueeze(0), self.map_weights, p_t.unsqueeze(0).float(), edge_index,
                                          edge_weights.reshape(1, -1).float(), self.ob_dim)
         out = out[0]

@@ -51,6 +51,10 @@
 #ifndef RD_K1_BLATE
 #define RD_K1_BLATE 1
 #endif
+// RD_K1_ALATE (experiment): group A behind the barrier too -- nothing but the kernel's small first loads in the address unit's queue
+#ifndef RD_K1_ALATE
+#define RD_K1_ALATE 0
+#endif
 #define RD_K1_FWD_TOUCH 12544
 #define RD_K1_BWD_TOUCH 9728
 
@@ -268,22 +272,21 @@ __device__ __forceinline__ float gate_by_mask(float x, unsigned long long m) {
   asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(m));
   return r;
 }
-// the RT * 4 masks of one (sample slot, column tile) through the scalar cache: RT 32-byte loads, one wait
+// the RT * 4 masks of one (sample slot, column tile): lane l < RT * 8 requests dword l (one wave-wide load, issued with the kernel's first
+// loads; the compiler's own vmcnt bookkeeping covers it), unpack_masks moves them to SGPR pairs with v_readlane where the epilogue
+// needs them.  (A scalar s_load with its wait in the same asm statement stalled every wave for 3-7 k cycles at the kernel's start:
+// the masks are cold -- the forward wrote them a whole encoder pass ago.)
 template <int RT>
-__device__ __forceinline__ void load_masks(const uint64_t* p, unsigned long long (&m)[RT * 4]) {
-  typedef unsigned u8v __attribute__((ext_vector_type(8)));
-  u8v v[RT];
-  if constexpr (RT == 1)
-    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v[0]) : "s"(p) : "memory");
-  else if constexpr (RT == 2)
-    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v[0]), "=&s"(v[1]) : "s"(p) : "memory");
-  else
-    asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx8 %1, %3, 0x20\n\ts_load_dwordx8 %2, %3, 0x40\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(v[0]), "=&s"(v[1]), "=&s"(v[2]) : "s"(p) : "memory");
+__device__ __forceinline__ int request_masks(const uint64_t* p, int lane) {
+  int v = 0;
+  if (lane < RT * 8) v = reinterpret_cast<const int*>(p)[lane];
+  return v;
+}
+template <int RT>
+__device__ __forceinline__ void unpack_masks(int v, unsigned long long (&m)[RT * 4]) {
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) m[rt * 4 + i] = (unsigned long long)v[rt][2 * i] | ((unsigned long long)v[rt][2 * i + 1] << 32);
+  for (int k = 0; k < RT * 4; ++k)
+    m[k] = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(v, 2 * k) | ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(v, 2 * k + 1) << 32);
 }
 
 // zero what the products read but no phase writes: pad columns [K, KP) of rows [0, crow) and whole pad rows
@@ -608,7 +611,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   // every wave requests its W1 panel under the observations' latency (cold in the step: ~6 k cycles), BEFORE it consumes them:
   // the request only queues in the address unit, the barrier below waits for LDS traffic alone
   if (!(RD_ABL & 16)) embed_masks();
-  if (!RD_K1_BLATE || !grpB) load_panel(pw, wtiles(a, dm, 0, 0), nct, wave, lane);
+  if (!RD_K1_ALATE && (!RD_K1_BLATE || !grpB)) load_panel(pw, wtiles(a, dm, 0, 0), nct, wave, lane);
   RD_STAMP(11);
   if (!(RD_ABL & 16)) {
     embed_consume();
@@ -634,8 +637,9 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   // ---- layer 1: Y1 = relu(X W1^T + b1) * ssum;  X leaves as row tiles for dW1 (group B, straight from the planes) --------
   f32x4 acc[NJ][RT];
   zero_acc<RT>(acc);
+  if (RD_K1_ALATE && !grpB) load_panel(pw, wtiles(a, dm, 0, 0), nct, wave, lane);
   if (grpB) {                                                // group B: the positional encoding while group A multiplies ...
-    if (RD_K1_BLATE) load_panel(pw, wtiles(a, dm, 0, 0), nct, wave, lane);
+    if (RD_K1_BLATE || RD_K1_ALATE) load_panel(pw, wtiles(a, dm, 0, 0), nct, wave, lane);
     if (pe_on && !(RD_ABL & 8)) {
       pin(pe_time); pin(pe_ts);
       for (int i = gt; i < npe; i += GTHR) {
@@ -832,10 +836,9 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   float sfv = 0.f;
   if (tid >= NTHR - 64 && tid - (NTHR - 64) < F) sfv = a.ssum[tid - (NTHR - 64)];      // last wave: ssum -> LDS (the epilogue's coefficients)
   if (!(RD_ABL & 16)) gather_issue(tid);
-  if (!RD_K1_BLATE || !grpB) load_panel(pw, wtiles(a, dm, 1, 1), nct, wave, lane);          // W2^T panel queues behind the gather
-  // the gate masks Y1 > 0 of this wave's column tile: uniform, through the scalar cache, under the gather's latency
-  unsigned long long g1m[RT * 4];
-  load_masks<RT>(a.m1 + (size_t)(m24(sb, nct) + min(__builtin_amdgcn_readfirstlane(wave), nct - 1)) * (RT * 4), g1m);
+  if (!RD_K1_ALATE && (!RD_K1_BLATE || !grpB)) load_panel(pw, wtiles(a, dm, 1, 1), nct, wave, lane);          // W2^T panel queues behind the gather
+  // the gate masks Y1 > 0 of this wave's column tile: requested under the gather's latency
+  const int g1v = request_masks<RT>(a.m1 + (size_t)(m24(sb, nct) + min(__builtin_amdgcn_readfirstlane(wave), nct - 1)) * (RT * 4), lane);
   RD_STAMP(10);
   // D planes: zero the pads (rows >= F, columns >= K; the gather writes the rest); E planes: pad columns (the epilogue writes every row)
   zero_plane_pads(Dh, ROWS, F, F, K, tid); zero_plane_pads(Dl, ROWS, F, F, K, tid);
@@ -867,7 +870,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   };
   f32x4 acc[NJ][RT];
   zero_acc<RT>(acc);
-  if (RD_K1_BLATE && grpB) load_panel(pw, wtiles(a, dm, 1, 1), nct, wave, lane);
+  if (RD_K1_ALATE || (RD_K1_BLATE && grpB)) load_panel(pw, wtiles(a, dm, 1, 1), nct, wave, lane);
   RD_STAMP(2);
   mma_mid<RT>(acc, Dh, Dl, pw, lane, kclim2, [&] {
     if (liveX) load_panel_kc<0, NKC / 2>(pw, wtiles(a, dm, 0, 1), nct, wave, lane);   // W1^T, first half of the reduction
@@ -885,6 +888,8 @@ __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   float srow[RT];
   load_srow<RT>(srow, Ss, lane);
   static_assert(NJ == 1, "the gate masks are loaded for one column tile per wave");
+  unsigned long long g1m[RT * 4];
+  unpack_masks<RT>(g1v, g1m);
   {
     const int j = wave;
     if (j < nct) {                                              // wave-uniform; body is branch-free

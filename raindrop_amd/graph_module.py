@@ -5,8 +5,8 @@ code/Raindrop.py:310-324 runs, per batch,
     outputs, local_structure_regularization, _ = model.forward(P, Pstatic, Ptime, lengths)
     loss = criterion(outputs, y);  loss.backward();  optimizer.step()
 
-With `RD_MODULE_GRAPH=1` (or `model.graph_step = True`) `Raindrop_v2.forward` routes a TRAINING call through two hipGraphs
-instead of one C-ABI call per operator under autograd:
+By DEFAULT (round 5; `RD_MODULE_GRAPH=0` or `model.graph_step = False` switch it off) `Raindrop_v2.forward` routes a TRAINING call
+through two hipGraphs instead of one C-ABI call per operator under autograd:
 
   * forward  = the inputs copied into the step's static buffers, then graph F: token plan + weight splits, sensor stage,
                encoder layers, classifier head up to the logits (`TrainStep` part 'mf');
@@ -21,9 +21,12 @@ operators, silently and per call: evaluation / no-grad calls, `use_beta` / `comp
 device than the captured one is handled by capturing a second runner, torch.distributed with more than one rank (use
 `TrainStep` + `dp.FlatGradAllReduce` there).
 
-One training forward may be outstanding at a time: a second forward before the first one's backward would overwrite the
-activations the backward graph reads -- the backward of the stale call raises instead of returning wrong gradients."""
+One captured forward may be outstanding at a time (the backward graph reads the activations the forward graph left): a training
+forward that arrives while the previous captured call's autograd node is still alive and has not run its backward takes the eager
+path for that call (both backwards then work, as with the eager operators); should a stale node's backward be reached anyway it
+raises instead of returning wrong gradients."""
 import os
+import weakref
 
 import torch
 
@@ -33,7 +36,7 @@ from . import _lib, dp, synth
 def enabled(model):
     flag = getattr(model, "graph_step", None)
     if flag is None:
-        flag = os.environ.get("RD_MODULE_GRAPH", "0") == "1"
+        flag = os.environ.get("RD_MODULE_GRAPH", "1") != "0"
     return bool(flag)
 
 
@@ -61,6 +64,12 @@ class _Runner:
         self.graph_f, self.graph_b = self.step.capture_segments(("mf", "mb"))
         self.ptrs = self._ptrs()
         self.gen = 0
+        self.last_ctx = None                                           # weak reference to the autograd node of the latest captured forward
+
+    def busy(self):
+        """the latest captured forward still waits for its backward (its autograd node is alive and has not run)"""
+        c = self.last_ctx() if self.last_ctx is not None else None
+        return c is not None and not getattr(c, "rd_done", True)
 
     def _ptrs(self):
         return tuple(p.data_ptr() for p in self.params)
@@ -92,6 +101,8 @@ class _GraphStep(torch.autograd.Function):
         out = runner.forward(src, static, times, lengths)
         ctx.gen = runner.gen
         ctx.needs = [p.requires_grad for p in params]
+        ctx.rd_done = False
+        runner.last_ctx = weakref.ref(ctx)
         return out
 
     @staticmethod
@@ -103,6 +114,7 @@ class _GraphStep(torch.autograd.Function):
                                         "step keeps ONE set of activations (run forward and backward in pairs, or unset "
                                         "RD_MODULE_GRAPH / model.graph_step for this pattern)")
         grads = r.backward(dlogits.contiguous().float())
+        ctx.rd_done = True
         return (None, None, None, None, None) + tuple(g if need else None for g, need in zip(grads, ctx.needs))
 
 
@@ -116,7 +128,7 @@ def forward(model, src, static, times, lengths):
     if model.static and static is None:
         return None
     T, B = src.shape[0], src.shape[1]
-    if B == 0:
+    if B == 0 or src.device.type != "cuda":
         return None
     dev = src.device
     runners = model.__dict__.setdefault("_graph_runners", {})
@@ -133,4 +145,6 @@ def forward(model, src, static, times, lengths):
             runners[key] = False
             return None
         runners[key] = r
+    if r.busy():                                                       # the previous captured call may still be backpropagated: leave its activations alone
+        return None
     return _GraphStep.apply(r, src, static, times, lengths, *r.params)

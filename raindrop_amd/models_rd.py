@@ -298,7 +298,7 @@ class Raindrop_v2(nn.Module):
         l1, l2 = self.ob_propagation, self.ob_propagation_layer2
         X = ops.obs_embed(src, self.R_u, shp, p_drop, seed).view(B * F_, K)
         V = ops.linear(X, l1.lin_value.weight, l1.lin_value.bias, act=1).view(B, F_, K)
-        H = ops.linear(X, l1.increase_dim.weight, l1.increase_dim.bias).view(B, F_, T * 32)
+        H = ops.linear(X, l1.increase_dim.weight, l1.increase_dim.bias, exact=True).view(B, F_, T * 32)   # edge scores -> top-K: exact fp32
         p_t = z[:, :, F_ * d:].permute(1, 0, 2).contiguous()                       # [B,T,16]: layout only
         y1, ei2, alpha1 = ops.graph_beta(V, H, l1.map_weights, p_t, g["edge_index"], g["edge_weights"].view(1, -1), d)
         _, ssum2 = ops.edge_softmax_list_batched(ei2, alpha1, F_, norm_row=1)
@@ -324,7 +324,7 @@ class Raindrop_v2(nn.Module):
         if maxlen != self.max_len:
             raise _lib.RaindropHipError("src.shape[0] (%d) must equal max_len (%d): lin_value is "
                                         "Linear(max_len*d_ob, .)" % (maxlen, self.max_len))
-        # the whole training step as two hipGraphs behind this surface (RD_MODULE_GRAPH=1 / self.graph_step = True;
+        # the whole training step as two hipGraphs behind this surface (the default; RD_MODULE_GRAPH=0 / self.graph_step = False: off;
         # raindrop_amd/graph_module.py): training calls only, the loss and the optimizer stay the caller's
         if graph_module.enabled(self):
             out = graph_module.forward(self, src, static, times, lengths)

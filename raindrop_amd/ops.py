@@ -160,13 +160,23 @@ class _Linear(torch.autograd.Function):
     """y = act(x W^T + b) through rd_linear_fwd; backward through rd_linear_bwd_{input,weight}."""
 
     @staticmethod
-    def forward(ctx, x, W, b, act):
+    def forward(ctx, x, W, b, act, exact=False):
         _check(x, W, b)
         N, K = W.shape
         x2 = x.reshape(-1, K)
         M = x2.shape[0]
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        _lib.call("rd_linear_fwd", M, N, K, _ptr(x2), K, _ptr(W), _ptr(b), _ptr(y), N, int(act), _stream())
+        # exact: the product on the fp32 matrix instruction (bitwise an fmaf chain) whatever the process's precision mode -- for values
+        # that feed INDEX work (the use_beta branch's edge scores -> top-K pruning): a few MFLOP, and index work is bit-exact by contract.
+        # The mode is read when a launch is chosen (host side, at enqueue), so switching it around one call is safe on one host thread.
+        prev = _lib.load().rd_get_precision() if exact else None
+        if exact and prev != 0:
+            _lib.call("rd_set_precision", 0)
+        try:
+            _lib.call("rd_linear_fwd", M, N, K, _ptr(x2), K, _ptr(W), _ptr(b), _ptr(y), N, int(act), _stream())
+        finally:
+            if exact and prev != 0:
+                _lib.call("rd_set_precision", prev)
         ctx.act = int(act)
         ctx.has_bias = b is not None
         ctx.save_for_backward(x2, W, y if act else None)
@@ -195,11 +205,11 @@ class _Linear(torch.autograd.Function):
             ws = _workspace(nbytes, dev)
             _lib.call("rd_linear_bwd_weight", M, N, K, _ptr(dy2), N, _ptr(x2), K, _ptr(dW), _ptr(db),
                       _ptr(ws), ws.numel(), _stream())
-        return dx, dW, db, None
+        return dx, dW, db, None, None
 
 
-def linear(x, W, b=None, act=0):
-    return _Linear.apply(x.contiguous(), W.contiguous(), None if b is None else b.contiguous(), act)
+def linear(x, W, b=None, act=0, exact=False):
+    return _Linear.apply(x.contiguous(), W.contiguous(), None if b is None else b.contiguous(), act, bool(exact))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -245,10 +245,10 @@ def beta_batched_case():
 
 
 def beta_large_case():
-    """The use_beta operator on a graph that does not fit one workgroup's LDS -- 256 nodes (SYN256's sensor count), ~19.6 k edges
+    """The use_beta operator on a graph that does not fit one workgroup's LDS -- 256 nodes (SYN256's sensor count), 13 360 edges
     (sparse random structure with distinct weights: no pruning ties), T = 6 steps -- by the REFERENCE class, per sample:
     outputs, pruned edge lists, returned scores, gradients of <y, R>.  Exercises the workspace form of rd_graph_beta_fwd / _bwd
-    (rd_graph_beta_large.hip): a 32 768-key sort in 4096-key chunks, per-node lists over 9.8 k kept edges."""
+    (rd_graph_beta_large.hip): a 16 384-key sort in 4096-key chunks, per-node lists over 6 680 kept edges."""
     ref = ref_loader.load()
     n, T, d, B = 256, 6, 4, 2
     K = T * d

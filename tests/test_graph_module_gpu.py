@@ -1,4 +1,4 @@
-"""GPU: the captured step behind the nn.Module surface (raindrop_amd/graph_module.py, RD_MODULE_GRAPH=1): what the reference's
+"""GPU: the captured step behind the nn.Module surface (raindrop_amd/graph_module.py; the DEFAULT since round 5): what the reference's
 unchanged loop -- model.forward, criterion, loss.backward(), torch's optimizer (code/Raindrop.py:310-324) -- gets, against the
 eager operator-by-operator autograd path of the same module."""
 import numpy as np
@@ -82,13 +82,32 @@ def test_module_graph_step_dropout_and_fallbacks():
     with torch.no_grad():
         lg_ref = m(dv["src"], dv["static"], dv["times"], dv["lengths"])[0]
     assert torch.equal(lg_eval, lg_ref)
-    # two forwards, then the backward of the first: refused, not wrong
-    m.train(); m.graph_step = True
+    # two forwards before a backward: the second call takes the eager path (the first one's activations stay in the runner), both
+    # backwards work and give what two eager calls give
+    m.train(); m.graph_step = True; m.dropout.p = 0.0
+    for p in m.parameters():
+        p.grad = None
     l1 = m(dv["src"], dv["static"], dv["times"], dv["lengths"])[0]
     l2 = m(dv["src"], dv["static"], dv["times"], dv["lengths"])[0]
+    assert sum(bool(r and r.busy()) for r in m._graph_runners.values()) == 1      # the runner of this dropout setting holds l1's activations
+    l1.sum().backward()
+    l2.sum().backward()
+    both = m.mlp_static[2].weight.grad.clone()
+    m.graph_step = False
+    for p in m.parameters():
+        p.grad = None
+    m(dv["src"], dv["static"], dv["times"], dv["lengths"])[0].sum().backward()
+    assert torch.allclose(both, 2 * m.mlp_static[2].weight.grad, rtol=1e-3, atol=1e-6)   # one captured + one eager call against two eager ones
+    # a captured forward whose output was dropped without a backward does not block the next one
+    m.graph_step = True
+    m(dv["src"], dv["static"], dv["times"], dv["lengths"])
+    assert not any(r.busy() for r in m._graph_runners.values() if r)
+    # a stale autograd node (forced: the runner's generation moved on) refuses instead of returning wrong gradients
+    l1 = m(dv["src"], dv["static"], dv["times"], dv["lengths"])[0]
+    next(r for r in m._graph_runners.values() if r and r.busy()).gen += 1
     with pytest.raises(_lib.RaindropHipError):
         l1.sum().backward()
-    l2.sum().backward()                                         # the latest one is fine
+    m.dropout.p = 0.2
     # gradient accumulation over two forward/backward pairs without zero_grad: p.grad is the sum (autograd accumulates copies)
     m.dropout.p = 0.0
     for p in m.parameters():
@@ -100,22 +119,38 @@ def test_module_graph_step_dropout_and_fallbacks():
         p.grad = None
     m(dv["src"], dv["static"], dv["times"], dv["lengths"])[0].square().sum().backward()
     assert torch.allclose(twice, 2 * m.mlp_static[2].weight.grad, rtol=1e-6, atol=0)
-    # the paper's branch is not covered by the captured step: eager path, gradients for increase_dim
+    # the paper's branch is not covered by the captured step: eager path -- BIT-equal to the switch being off --, gradients for increase_dim
     mb = build_ours(cfg, synth.make_structure(cfg, "sparse"), DEV, 7, use_beta=True).train()
-    mb.graph_step = True
-    mb(dv["src"], dv["static"], dv["times"], dv["lengths"])[0].sum().backward()
-    assert mb.ob_propagation.increase_dim.weight.grad is not None and not getattr(mb, "_graph_runners", {})
+    res = []
+    for flag in (True, False, None):                            # None: the default
+        mb.graph_step = flag
+        for p in mb.parameters():
+            p.grad = None
+        lg = mb(dv["src"], dv["static"], dv["times"], dv["lengths"])[0]
+        lg.sum().backward()
+        res.append((lg.detach().clone(), mb.ob_propagation.increase_dim.weight.grad.clone(), mb.R_u.grad.clone()))
+    assert not getattr(mb, "_graph_runners", {})
+    for r in res[1:]:
+        assert all(torch.equal(x, y) for x, y in zip(res[0], r))
+    # evaluation with gradients enabled (model.eval(), no torch.no_grad()): eager path, bit-equal to the switch being off
+    m.eval(); m.graph_step = None
+    lg_a = m(dv["src"], dv["static"], dv["times"], dv["lengths"])[0]
+    m.graph_step = False
+    lg_b = m(dv["src"], dv["static"], dv["times"], dv["lengths"])[0]
+    assert torch.equal(lg_a, lg_b)
 
 
 def test_module_graph_step_environment_switch(monkeypatch):
-    """RD_MODULE_GRAPH=1 turns the captured step on for an unchanged script (no attribute on the model)."""
+    """An unchanged script (no attribute on the model, nothing in the environment) gets the captured step; RD_MODULE_GRAPH=0
+    switches it off."""
     cfg = synth.make_config("TINY")
     dv = _batch(cfg, 3, 9)
     m = build_ours(cfg, synth.make_structure(cfg, "ones"), DEV, 7).train()
-    monkeypatch.setenv("RD_MODULE_GRAPH", "1")
+    monkeypatch.delenv("RD_MODULE_GRAPH", raising=False)
+    assert getattr(m, "graph_step", None) is None
     lg = m(dv["src"], dv["static"], dv["times"], dv["lengths"])[0]
     assert len(getattr(m, "_graph_runners", {})) == 1 and lg.grad_fn is not None
-    monkeypatch.delenv("RD_MODULE_GRAPH")
+    monkeypatch.setenv("RD_MODULE_GRAPH", "0")
     m2 = build_ours(cfg, synth.make_structure(cfg, "ones"), DEV, 7).train()
     lg2 = m2(dv["src"], dv["static"], dv["times"], dv["lengths"])[0]
     assert not getattr(m2, "_graph_runners", {})

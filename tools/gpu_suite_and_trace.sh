@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 5, call c1: full GPU suite + step kernel trace of the current library against the round-4 library (base), alternating, one call
-# usage: tools/r5_call_c1.sh <outdir under gpurun_out> [variant libs to trace besides base and default ...]
+# round 5: full GPU suite + step kernel trace of the current library against the round-4 library (base), alternating, one call
+# usage: tools/gpu_suite_and_trace.sh <outdir under gpurun_out> [variant libs to trace besides base and default ...]
 d=${1:-c1}; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/$d; mkdir -p $out; cd $GRAFT_REPO_ROOT
 python tools/box_kind.py > $out/box.txt 2>&1
