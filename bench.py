@@ -229,14 +229,16 @@ def k1_in_step(model, flat, batch, iters=40):
         torch.cuda.synchronize()
         g_step = med([a_.elapsed_time(b_) for a_, b_ in e2])
         one.close()
-        ovh = max(0.0, (out["step"] - g_step) / n)       # / n, not n - 1: the conservative split (agrees with the rocprofv3 kernel sums)
-        out["raw"] = {p: out[p] for p in parts}
-        for p in parts[1:]:
-            out[p] = max(out[p] - ovh, 0.0)
+        ovh = max(0.0, (out["step"] - g_step) / n)
+        # The parts stay as MEASURED (each interval contains the start of its graph: conservative).  The boundary-corrected values
+        # -- a uniform share of (segmented step - one-graph step) taken off every part but the first -- are kept beside them under
+        # their own key: round 4 reported those as the headline, and the uniform subtraction over-credits the short segments (a
+        # corrected K1 forward came out shorter than the kernel's own minimum duration in the rocprofv3 trace).
+        out["corrected"] = {p: (out[p] if p == parts[0] else max(out[p] - ovh, 0.0)) for p in parts}
         out["graph_step"], out["boundary_overhead"] = g_step, ovh
-        out["how"] = ("six consecutive hipGraphs, HIP events between their replays; the cost of a graph boundary -- (segmented step - the same "
-                      "step as one graph) / 6 = %.1f us here -- is taken off every part but the first (external event-record nodes inside "
-                      "one graph are not available on ROCm)" % (ovh * 1e3))
+        out["how"] = ("six consecutive hipGraphs, HIP events between their replays, intervals as measured (each contains one graph start; "
+                      "external event-record nodes inside one graph are not available on ROCm); (segmented step - the same step as one "
+                      "graph) / 6 = %.1f us per boundary here" % (ovh * 1e3))
     out["nl"] = ts.nl
     out["mlive"] = int(ts.plan[0]) if ts.plan is not None else None
     ts.close()
@@ -405,6 +407,25 @@ def k1_source_hash():
         with open(os.path.join(ROOT, "raindrop_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
+
+
+def _k1_rocprof(alg_bytes, shape):
+    """The K1 kernels' durations inside the captured step from the committed rocprofv3 kernel trace (tools/k1_rocprof_json.py over
+    `rocprofv3 --kernel-trace -- python tools/step_only.py`: the profiler cannot run inside the timed process), valid only for the
+    kernel sources it was taken on (sha1 stamp).  This is the figure a reader recomputes from profiles/*_step_kernel_stats.txt."""
+    try:
+        path = os.path.join(ROOT, "raindrop_amd", "k1_rocprof.json")
+        with open(path) as fh:
+            d = json.load(fh)
+        if list(d.get("shape", [])) != list(shape):
+            return None                                   # the trace is of another workload (it is taken on the P19 benchmark batch)
+        if d.get("source_sha1") != k1_source_hash():
+            return {"stale": "kernel sources changed since the trace was taken", "frac": None}
+        us = float(d["k1_us_per_step"])
+        return {"us": round(us, 2), "frac": round(alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5), "kernels_us": d.get("kernels_us"),
+                "box": d.get("box"), "source": d.get("source")}
+    except Exception:
+        return None
 
 
 def _pmc_traffic(B, F, K):
@@ -763,21 +784,43 @@ def main():
             enc_el = cfg["nlayers"] * 2 * (3 * Dd * Dd + Dd * Dd + 2 * Dd * Hh)
             share = k1_el / float(k1_el + enc_el)
             us = (f_ms + b_ms + share * begin_ms) * 1e3
+            corr = seg.get("corrected")
+            us_corr = (corr["k1f"] + corr["k1b"] + share * corr["begin"]) * 1e3 if corr else None
             k1["isolated"] = {"frac": k1["frac"], "achieved": k1["achieved"], "fwd_us": k1["fwd_us"], "bwd_us": k1["bwd_us"],
                               "how": "hipGraph replays of the K1 calls alone (8 per graph), same buffers every call: a ~108 MB working "
                                      "set that stays in the 256 MiB Infinity Cache"}
             k1["frac_isolated"] = k1["frac"]
-            k1["achieved"] = round(k1["algorithmic_bytes"] / (us * 1e-6) / 1e9, 2)
-            k1["frac"] = round(k1["achieved"] / HBM_PEAK_GBS, 5)
+            # Three in-step figures, all on the line.  `frac` is the one a reader can recompute from the committed kernel trace
+            # (profiles/r05_step_kernel_stats.txt): the rocprofv3 kernel sum -- the profiler cannot run inside this process, so it
+            # comes from raindrop_amd/k1_rocprof.json, valid only while the kernel sources are the ones it was taken on (sha1 stamp).
+            # The LIVE figures of this run are the HIP-event ones: `frac_events` = the K1 segments as measured (each interval
+            # contains the start of a hipGraph, ~10 us: conservative), `frac_events_boundary_corrected` = with (segmented step -
+            # one-graph step) / 6 taken off every part but the first (round 4's headline; over-credits short segments).  With a stale
+            # trace `frac` falls back to the boundary-corrected event figure and says so in `frac_source`.
+            fr_ev = round(k1["algorithmic_bytes"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+            fr_corr = round(k1["algorithmic_bytes"] / (us_corr * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if us_corr else None
+            rp = _k1_rocprof(k1["algorithmic_bytes"], (args.batch, cfg["d_inp"], cfg["max_len"] * cfg["d_ob"]))
+            k1["frac_events"], k1["frac_events_boundary_corrected"] = fr_ev, fr_corr
+            if rp:
+                k1["rocprof"] = rp
+                k1["frac_rocprof"] = rp.get("frac")
+            if rp and rp.get("frac"):
+                k1["frac"], k1["frac_source"] = rp["frac"], "rocprofv3 kernel sum of the captured step (raindrop_amd/k1_rocprof.json, sources unchanged since)"
+                k1["achieved"] = round(k1["algorithmic_bytes"] / (rp["us"] * 1e-6) / 1e9, 2)
+            else:
+                k1["frac"] = fr_corr if fr_corr else fr_ev
+                k1["frac_source"] = "HIP events of this run" + (", graph boundaries calibrated out" if fr_corr else "") + " (no fresh rocprofv3 trace of these sources)"
+                k1["achieved"] = round(k1["frac"] * HBM_PEAK_GBS, 2)
             k1["fwd_us"], k1["bwd_us"] = round(f_ms * 1e3, 2), round(b_ms * 1e3, 2)
             k1["in_step"] = {"fwd_us": round(f_ms * 1e3, 2), "bwd_us": round(b_ms * 1e3, 2), "first_launch_us": round(begin_ms * 1e3, 2),
                              "k1_share_of_first_launch": round(share, 3), "us": round(us, 2),
                              "segmented_step_us": round(seg_step_ms * 1e3, 2), "how": seg["how"],
                              "one_graph_step_us": round(seg.get("graph_step", 0.0) * 1e3, 2),
                              "graph_boundary_us": round(seg.get("boundary_overhead", 0.0) * 1e3, 2),
-                             "raw_segments_us": {p: round(v * 1e3, 2) for p, v in seg.get("raw", {}).items()},
+                             "boundary_corrected_segments_us": {p: round(v * 1e3, 2) for p, v in (seg.get("corrected") or {}).items()},
                              "segments_us": {p: round(seg[p] * 1e3, 2) for p in ("begin", "k1f", "enc", "head", "encb", "k1b")}}
-            k1["encoder_in_step"] = {"us_per_layer": round((seg["enc"] + seg["encb"]) * 1e3 / seg["nl"], 2), "mlive": seg["mlive"], "nl": seg["nl"]}
+            k1["encoder_in_step"] = {"us_per_layer": round((seg["enc"] + seg["encb"]) * 1e3 / seg["nl"], 2), "mlive": seg["mlive"], "nl": seg["nl"],
+                                     "us_per_layer_boundary_corrected": (round((corr["enc"] + corr["encb"]) * 1e3 / seg["nl"], 2) if corr else None)}
             k1["kernel"] = ("K1 message passing fwd+bwd AS THEY RUN IN THE TRAINING STEP (rd_sensor_stage_fwd + rd_msgpass_bwd incl. PE/mask, dW/db "
                             "reductions, + K1's share of the step's first launch = its weight split): HIP events between the parts of the "
                             "captured step (" + seg["how"] + "), medians over 40 whole steps; `isolated` is the round-1..3 figure")
@@ -828,6 +871,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(loss).item()
+    # host side of a step: what this process spends ENQUEUEING one step (graph replay(s), all-reduce calls and waits, the Adam launch),
+    # measured as 40 steps issued back to back without a synchronisation in between (the device runs behind; the queue absorbs them)
+    torch.cuda.synchronize()
+    th0 = time.perf_counter()
+    for _ in range(40):
+        step()
+    host_us = (time.perf_counter() - th0) / 40 * 1e6
+    torch.cuda.synchronize()
     feed_check = None
     if feed_next is not None and tstep is not None and world == 1:
         # --feed: the captured graph has just been replayed on a new batch every step.  Check that path against an eager recomputation:
@@ -905,6 +956,7 @@ def main():
                        "tuned": (None if tstep is None else {"rowgemm_rows32": tstep.tuned_rows32, "rowgemm_waves16": tstep.tuned_waves16,
                                                              "how": "capture-time A/B of the row-block kernels' workgroup shapes, per-variant "
                                                                     "times summed over the ranks (every rank runs the same variants)"}),
+                       "host_us_per_step": round(host_us, 1),
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "grad_allreduce_bytes": flat.nbytes()},
         }

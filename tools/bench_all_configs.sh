@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4: the bench lines of every configuration (P19 full line; P12 both bf16 modes at B = 256 with rooflines; PAM; SYN256)
+# the bench lines of every configuration (rounds 4-5) (P19 full line; P12 both bf16 modes at B = 256 with rooflines; PAM; SYN256)
 out=$GRAFT_REPO_ROOT/gpurun_out/$1; mkdir -p $out
 cd $GRAFT_REPO_ROOT
 timeout 600 python bench.py --steps 50 --warmup 10 > $out/bench_P19.json 2> $out/bench_P19.err
