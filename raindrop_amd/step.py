@@ -36,7 +36,7 @@ def plan_supported(d_inp, d_ob, T, D, nhead, nhid, precision):
     """Shapes / modes whose whole step runs on kernels that read a token plan (include/raindrop_hip.h "token plan"): a bf16
     arithmetic mode (precision 1 = bf16x3, 2 = bf16), the fused row-local encoder chains (ceil(D / 32) == 5 and
     ceil(nhid / 32) == 9: the P19 and P12 widths), head_dim <= 96 (single-tile attention for T <= 64 -- with in_proj fused in,
-    rd_attnfuse.hip -- or the multi-tile kernels beyond), and either message-passing form (fused LDS-resident for F <= 64,
+    rd_attnfuse.hip -- or the multi-tile kernels beyond), and either message-passing form (fused LDS-resident for F <= 48,
     K <= 240 in bf16x3, else the panel products whose last scatter follows the plan).  Round 3 had this for the P19 envelope
     only; P12 (T = 215) joined in round 4.  The usual A/B switches of the kernels it relies on turn it off."""
     hd = D // nhead
