@@ -733,9 +733,27 @@ def main():
         from raindrop_amd.step import TrainStep
         tstep = TrainStep(model, flat, batch)
 
+    # The whole step -- forward + loss + backward, the all-reduce(s) and Adam -- as ONE hipGraph (TrainStep.capture_full, round 5): the
+    # default on one GPU (same kernels, one replay per step on the host); at N > 1 opt-in (RD_STEP_FULL=1: RCCL collectives under
+    # stream capture are tested on a one-rank group only -- tests/test_dp_gpu.py -- so the default there stays two graphs + eager
+    # collectives + the Adam launch).  A failed capture falls back to that form.
+    full_graph = [False]
+    if tstep is not None and not args.no_optimizer and os.environ.get("RD_STEP_FULL", "1" if world == 1 else "0") == "1":
+        try:
+            tstep.capture_full(opt)
+            full_graph[0] = True
+        except Exception as e:                                   # pragma: no cover
+            print("capture_full failed (%r): two-part step" % (e,), file=sys.stderr, flush=True)
+    if world > 1:                                               # a collective decision, like the probe above
+        fk = torch.tensor([1.0 if full_graph[0] else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(fk, op=dist.ReduceOp.MIN)
+        full_graph[0] = bool(fk.item() > 0.5)
+
     def graph_step():
         if feed_next is not None:
             feed_next()
+        if full_graph[0]:
+            return tstep.run_full()
         loss = tstep.run_allreduce()           # N > 1: the last layer's + head's gradients are all-reduced beside the rest of the backward
         if not args.no_optimizer:
             opt.step()
@@ -935,6 +953,9 @@ def main():
                                        "+RCCL flat-grad all-reduce" if world > 1 else "",
                                        "" if args.no_optimizer else "+Adam", cfg["dropout"]),
                        "step_mode": ("eager autograd" if tstep is None else
+                                     "ONE hipGraph per step: fwd+CE+bwd%s + Adam (device-side step state)" % (
+                                         ", both all-reduce buckets captured (the first beside the rest of the backward)" if world > 1 else "")
+                                     if full_graph[0] else
                                      "two hipGraphs (fwd+CE+bwd of head and last layer | rest of bwd), first all-reduce bucket between them, + Adam"
                                      if tstep.split else "hipGraph(fwd+CE+bwd) + eager all-reduce/Adam"),
                        "batch_source": ("rd_batch_gather from a device-resident dataset (N=8192) every step" if feed_next

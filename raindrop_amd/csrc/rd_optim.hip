@@ -39,6 +39,52 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
 // What kind of box is this?  (DESIGN.md "Box variance")  32 KB of straight-line code -- 4096 dependent 8-byte v_fma_f32, nothing the
 // compiler can fold --, one wave, clock64 around it: cold (its code in no cache) about 80 ticks per 64-byte line where the hardware
 // fetches instructions ahead, 400-450 where it does not; warm 45-55 / 75-95.  tools/probe_clocks.hip is the standalone form.
+// The same update with the optimizer's step state on the DEVICE: a captured launch cannot carry the host's bias corrections (they
+// change every step), and an extra one-thread launch in front of the update costs the step 3 % (measured: a kernel boundary + two
+// double-precision pow() on one lane).  The state is TWO slots {t, beta1^t, beta2^t} (doubles); every workgroup reads both, takes
+// the one with the larger t as current, derives step t + 1's corrections with one multiply each, and workgroup 0 writes the OTHER
+// slot -- nobody reads that slot before the next launch: race-free without a barrier, one launch, deterministic.
+// (beta^t by repeated multiplication differs from pow() by ~t 2^-53 relative: far below the float the correction is rounded to.)
+struct AdamState { double t, p1, p2, pad; };
+__global__ __launch_bounds__(256) void k_adam_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                  float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
+                                                  AdamState* __restrict__ state) {
+  RD_TOUCH_CODE_FIRST(2432, blockIdx.x, 64);
+  const AdamState s0 = state[0], s1 = state[1];
+  const bool cur1 = s1.t > s0.t;
+  const AdamState c = cur1 ? s1 : s0;
+  const double np1 = c.p1 * (double)b1, np2 = c.p2 * (double)b2;
+  const float bc1 = (float)(1.0 - np1), bc2_sqrt = (float)sqrt(1.0 - np2);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    AdamState nx; nx.t = c.t + 1.0; nx.p1 = np1; nx.p2 = np2; nx.pad = 0.0;
+    state[cur1 ? 0 : 1] = nx;
+  }
+  const long i4 = (blockIdx.x * (long)blockDim.x + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  const float step_size = lr / bc1;
+  if (i4 + 3 < n) {
+    float4 pp = *reinterpret_cast<float4*>(p + i4), gg = *reinterpret_cast<const float4*>(g + i4);
+    float4 mm = *reinterpret_cast<float4*>(m + i4), vv = *reinterpret_cast<float4*>(v + i4);
+    float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      const float gr = G[c4] + wd * P[c4];
+      M[c4] = b1 * M[c4] + (1.f - b1) * gr;
+      V[c4] = b2 * V[c4] + (1.f - b2) * gr * gr;
+      P[c4] -= step_size * M[c4] / (sqrtf(V[c4]) / bc2_sqrt + eps);
+    }
+    *reinterpret_cast<float4*>(p + i4) = pp; *reinterpret_cast<float4*>(m + i4) = mm;
+    *reinterpret_cast<float4*>(v + i4) = vv;
+  } else {
+    for (long i = i4; i < n; ++i) {
+      const float gr = g[i] + wd * p[i];
+      m[i] = b1 * m[i] + (1.f - b1) * gr;
+      v[i] = b2 * v[i] + (1.f - b2) * gr * gr;
+      p[i] -= step_size * m[i] / (sqrtf(v[i]) / bc2_sqrt + eps);
+    }
+  }
+}
+
 __global__ __launch_bounds__(64) void k_ifetch_probe(float* out, unsigned long long* t, float a, float b) {
   float x = (float)threadIdx.x;
   const unsigned long long c0 = clock64();
@@ -74,4 +120,19 @@ extern "C" int rd_adam_step(int64_t n, float* param, const float* grad, float* e
   hipLaunchKernelGGL(k_adam, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, grad,
                      exp_avg, exp_avg_sq, (long)n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
   return check_launch("k_adam");
+}
+
+// rd_adam_step with the step state on the device: `state` = 64 bytes (two slots of {t, beta1^t, beta2^t, pad} as doubles; the slot
+// with the larger t is current; initialise slot 0 = {t, beta1^t, beta2^t}, slot 1 = {-1, ..}) -- ONE launch a hipGraph can replay.
+extern "C" int rd_adam_step_dev(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                float lr, float beta1, float beta2, float eps, float weight_decay, void* state,
+                                void* stream) {
+  RD_REQUIRE(n > 0 && state != nullptr, "bad n / NULL optimizer state");
+  RD_REQUIRE(param && grad && exp_avg && exp_avg_sq, "NULL tensor");
+  RD_REQUIRE(((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
+               reinterpret_cast<uintptr_t>(exp_avg_sq) | reinterpret_cast<uintptr_t>(state)) & 15) == 0, "buffers must be 16-byte aligned");
+  const long threads = (n + 3) / 4;
+  hipLaunchKernelGGL(k_adam_dev, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                     exp_avg, exp_avg_sq, (long)n, lr, beta1, beta2, eps, weight_decay, (AdamState*)state);
+  return check_launch("k_adam_dev");
 }

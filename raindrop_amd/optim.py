@@ -22,10 +22,38 @@ class FlatAdam:
 
     def step(self):
         self.t += 1
+        self._cell_stale = True              # a captured step that follows re-syncs the device step state (TrainStep.run_full)
         p, g = self.param.data, self.param.grad
         _lib.call("rd_adam_step", p.numel(), ops._ptr(p), ops._ptr(g), ops._ptr(self.exp_avg), ops._ptr(self.exp_avg_sq),
                   float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
                   self.t, ops._stream())
+
+    def step_captured(self):
+        """The update as ONE launch a hipGraph can hold (rd_adam_step_dev: the step count and beta^t live on the device, two slots,
+        every launch advances them).  Call it inside a capture (raindrop_amd.step.TrainStep.capture_full); every replay is one
+        step -- the owner of the graph keeps `self.t` in step (`note_replay`)."""
+        self.sync_step_cell(create_only=True)
+        p, g = self.param.data, self.param.grad
+        _lib.call("rd_adam_step_dev", p.numel(), ops._ptr(p), ops._ptr(g), ops._ptr(self.exp_avg), ops._ptr(self.exp_avg_sq),
+                  float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
+                  ops._ptr(self.step_cell), ops._stream())
+
+    def sync_step_cell(self, create_only=False):
+        """Make the device step state agree with `self.t` (before capturing, after load_state_dict, after eager steps)."""
+        fresh = getattr(self, "step_cell", None) is None
+        if fresh:
+            self.step_cell = torch.zeros((8,), dtype=torch.float64, device=self.param.device)   # two slots {t, beta1^t, beta2^t, -}
+        if fresh or not create_only:
+            t = float(self.t)
+            self.step_cell.copy_(torch.tensor([t, float(self.betas[0]) ** t, float(self.betas[1]) ** t, 0.0, -1.0, 0.0, 0.0, 0.0],
+                                              dtype=torch.float64))
+
+    def device_steps(self):
+        """steps taken according to the device state (the larger of the two slots' counts)"""
+        return int(max(float(self.step_cell[0]), float(self.step_cell[4])))
+
+    def note_replay(self):
+        self.t += 1
 
     def zero_grad(self, set_to_none=False):
         self.param.grad.zero_()

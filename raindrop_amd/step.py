@@ -590,7 +590,61 @@ class TrainStep:
         flat.allreduce_wait(rest)
         return loss
 
+    # ------------------------------------------------------------------------------------------
+    def capture_full(self, opt):
+        """The WHOLE step as ONE hipGraph (round 5; opt-in): forward + loss + backward, the gradient all-reduce(s) and the optimizer.
+        At N > 1 the first bucket's collective (last encoder layer + head) is started between the two halves of the backward and
+        joined behind the second one's -- the collectives' own stream forks from and joins the captured stream (RCCL supports
+        stream capture; tested on a one-rank group: tests/test_dp_gpu.py) --, then `opt.step_captured()` (FlatAdam: device step
+        cell + rd_adam_step_dev).  The host side of a step is then ONE replay (run_full).  Raises whatever the capture raises;
+        the caller falls back to run_allreduce() + opt.step()."""
+        flat = self.flat
+        opt.sync_step_cell()
+
+        def cap():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(2):                                         # warm-up outside the capture (RCCL's lazy inits, too)
+                    self._body()
+                    flat.allreduce()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(g):
+                if self.split:
+                    off = self.early_grad_offset()
+                    self._body("a")
+                    h1 = flat.allreduce_range_async(off, flat.flat.numel())
+                    self._body("b")
+                    h0 = flat.allreduce_range_async(0, off)
+                    flat.allreduce_wait(h1)
+                    flat.allreduce_wait(h0)
+                else:
+                    self._body()
+                    flat.allreduce()
+                opt.step_captured()
+            self.graph_full = g
+        self._with_cell(cap)
+        opt.sync_step_cell()                                               # the warm-up did not step the optimizer; neither did the capture
+        self._full_opt = opt
+        return self.graph_full
+
+    def run_full(self):
+        """One replay of capture_full's graph = one training step including the optimizer; returns the loss tensor."""
+        if self._param_ptrs() != self._ptrs:
+            raise _lib.RaindropHipError("TrainStep: a parameter or gradient buffer moved since construction: build a new TrainStep")
+        if getattr(self._full_opt, "_cell_stale", False):                  # host-side steps were taken since: device state follows self.t
+            self._full_opt.sync_step_cell()
+            self._full_opt._cell_stale = False
+        self.graph_full.replay()
+        self._full_opt.note_replay()
+        for p, v in zip(self.flat.params, self.flat.views):
+            p.grad = v
+        return self.loss
+
     def close(self):
         """Kept for callers of the round-1 API: the seed cell is no longer registered outside run() / capture."""
+        self.graph_full = None
         self.graph = None
         self.graph_b = None

@@ -253,6 +253,62 @@ def test_rccl_one_rank_collectives_between_graph_replays():
     assert l0 == l1 and np.array_equal(g0, g1)
 
 
+def _rccl_full_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from raindrop_amd import dp, synth
+    from raindrop_amd.models_rd import Raindrop_v2
+    from raindrop_amd.optim import FlatAdam
+    from raindrop_amd.step import TrainStep
+    dev = torch.device("cuda", 0)
+    cfg = synth.make_config("P19")
+    out = []
+    for full in (False, True):
+        m = Raindrop_v2(cfg["d_inp"], cfg["d_model"], cfg["nhead"], cfg["nhid"], cfg["nlayers"], cfg["dropout"], cfg["max_len"],
+                        cfg["d_static"], cfg["MAX"], 0.5, cfg["aggreg"], cfg["n_classes"], synth.make_structure(cfg, "sparse"),
+                        sensor_wise_mask=False)
+        synth.fill_params_(m, seed=21)
+        m = m.to(dev).train()
+        named = dict(m.named_parameters())
+        flat = dp.FlatGradAllReduce([(n, named[n]) for n in synth.live_parameter_names(cfg)], n_buckets=2, force_collective=True)
+        opt = FlatAdam(flat.flatten_parameters(), lr=1e-3)
+        b = {k: (None if v is None else v.to(dev)) for k, v in synth.make_batch(cfg, 16, seed=33).items()}
+        ts = TrainStep(m, flat, b, p_drop=0.2, use_graph=True, seed=77, autotune=False, split=True)
+        if full:
+            ts.capture_full(opt)
+        ts.seed_cell.zero_()
+        losses = []
+        for _ in range(4):
+            if full:
+                losses.append(float(ts.run_full()))
+            else:
+                losses.append(float(ts.run_allreduce())); opt.step()
+        torch.cuda.synchronize()
+        out.append((losses, opt.t, flat.flat.detach().cpu().numpy().copy(), opt.param.detach().cpu().numpy().copy()))
+        ts.close()
+        del ts
+    ret[0] = out
+    dist.destroy_process_group()
+
+
+def test_rccl_one_rank_whole_step_as_one_graph():
+    """TrainStep.capture_full: forward + loss + backward, BOTH asynchronous AVG all-reduces (one-rank `nccl` group, issued for real:
+    RCCL under stream capture, the collectives' stream forked from and joined to the captured one) and the optimizer (device step
+    cell + rd_adam_step_dev) as ONE hipGraph; four replays with dropout on against four eager-collective steps (two graphs, two
+    dist.all_reduce calls, FlatAdam.step with host-computed bias corrections): the same losses, gradients bit-equal, parameters
+    equal to rounding of the device-side bias corrections (double precision on both sides)."""
+    world, port = 1, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rccl_full_worker, args=(world, port, ret), nprocs=1, join=True)
+    (l0, t0, g0, p0), (l1, t1, g1, p1) = ret[0]
+    assert t0 == t1 == 4
+    assert np.abs(p0 - p1).max() <= 4e-7 * max(1.0, np.abs(p0).max()), np.abs(p0 - p1).max()
+    assert np.allclose(l0, l1, rtol=1e-6, atol=1e-7), (l0, l1)
+    assert np.abs(g0 - g1).max() <= 1e-6 * max(np.abs(g0).max(), 1e-30)
+
+
 def _tuned_worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     os.environ.pop("RD_RG_ROWS32", None); os.environ.pop("RD_RG_WAVES16", None)      # pinned knobs switch the tuner off

@@ -685,6 +685,19 @@ def test_flat_adam_matches_torch_adam():
         ref.grad = g.clone(); opt.step()
         mine.grad.copy_(g.to(DEV)); fa.step()
     assert np.abs(mine.detach().cpu().numpy() - ref.detach().numpy()).max() < 2e-6
+    # the capturable form (device step cell, bias corrections computed on the device): continues the SAME optimizer state
+    dev_p = torch.nn.Parameter(mine.detach().clone()); dev_p.grad = torch.zeros(n, device=DEV)
+    fb = FlatAdam(dev_p, lr=1e-3)
+    fb.exp_avg.copy_(fa.exp_avg); fb.exp_avg_sq.copy_(fa.exp_avg_sq); fb.t = fa.t
+    fb.sync_step_cell()
+    for s in range(3):
+        g = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(DEV)
+        mine.grad.copy_(g); fa.step()
+        dev_p.grad.copy_(g); fb.step_captured(); fb.note_replay()
+    assert fb.t == fa.t and fb.device_steps() == fa.t
+    # (beta^t by repeated multiplication against pow(): the float correction may differ in its last bit -> parameters within an ulp or two)
+    a_, b_ = dev_p.detach().cpu().numpy(), mine.detach().cpu().numpy()
+    assert np.abs(a_ - b_).max() <= 4e-7 * max(1.0, np.abs(b_).max())
 
 
 def test_seed_cell_changes_masks_per_replay():

@@ -20,10 +20,15 @@ flat = dp.FlatGradAllReduce([(n, named[n]) for n in synth.live_parameter_names(c
 opt = FlatAdam(flat.flatten_parameters(), lr=1e-4)
 ts = TrainStep(m, flat, b, split=True if os.environ.get('RD_SPLIT') == '1' else None)   # RD_SPLIT=1: the two-graph form of N > 1 (cost of the split)
 import time
+full = os.environ.get("RD_FULL") == "1"          # RD_FULL=1: the whole step incl. all-reduce and Adam as ONE hipGraph (TrainStep.capture_full)
+if full:
+    ts.capture_full(opt)
+one = (lambda: ts.run_full()) if full else (lambda: (ts.run_allreduce(), opt.step()))
+ts.seed_cell.zero_()                              # the same dropout mask sequence whatever the capture's warm-up replays did
 for _ in range(3):
-    ts.run_allreduce(); opt.step()
+    one()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(steps):
-    ts.run_allreduce(); opt.step()
-torch.cuda.synchronize(); t1 = time.perf_counter()
-print("loss", float(ts.loss), "ms/step %.4f" % ((t1 - t0) * 1e3 / steps))
+    one()
+th = time.perf_counter(); torch.cuda.synchronize(); t1 = time.perf_counter()
+print("loss", float(ts.loss), "ms/step %.4f" % ((t1 - t0) * 1e3 / steps), "host us/step %.1f" % ((th - t0) * 1e6 / steps), "(one graph per step)" if full else "")
