@@ -18,8 +18,10 @@ through two hipGraphs instead of one C-ABI call per operator under autograd:
 Same kernels, token plan and dropout scheme as `raindrop_amd.step.TrainStep` (masks are a function of the step's seed cell, which
 the forward graph bumps per replay); the loss stays the caller's.  Calls the captured step does not cover fall back to the eager
 operators, silently and per call: evaluation / no-grad calls, `use_beta` / `compute_distance` models, another batch size or
-device than the captured one is handled by capturing a second runner, torch.distributed with more than one rank (use
-`TrainStep` + `dp.FlatGradAllReduce` there).
+device than the captured one is handled by capturing a second runner (the `RD_MODULE_GRAPH_MAX` = 4 most recently created are
+kept: each holds a step's activations), torch.distributed with more than one rank (use `TrainStep` + `dp.FlatGradAllReduce`
+there).  A capture that fails -- sizes outside the fused head, or an error inside the capture -- is reported once per shape with a
+warning, and those calls run on the eager operators.
 
 One captured forward may be outstanding at a time (the backward graph reads the activations the forward graph left): a training
 forward that arrives while the previous captured call's autograd node is still alive and has not run its backward takes the eager
@@ -38,6 +40,13 @@ def enabled(model):
     if flag is None:
         flag = os.environ.get("RD_MODULE_GRAPH", "1") != "0"
     return bool(flag)
+
+
+def _max_runners():
+    try:
+        return max(1, int(os.environ.get("RD_MODULE_GRAPH_MAX", "4")))
+    except ValueError:
+        return 4
 
 
 class _Runner:
@@ -139,9 +148,21 @@ def forward(model, src, static, times, lengths):
     if r is not None and r.stale():
         r = None
     if r is None:
+        runners.pop(key, None)
+        # a runner keeps a whole step's activations: a loop that varies its batch size keeps the most recent few, not all of them
+        live = [k for k, v in runners.items() if v is not False]
+        while len(live) >= _max_runners():
+            old = next((k for k in live if not runners[k].busy()), None)
+            if old is None:                                            # every kept runner waits for a backward: this call goes the eager way
+                return None
+            live.remove(old)
+            del runners[old]
         try:
             r = _Runner(model, T, B, dev)
-        except _lib.RaindropHipError:
+        except (_lib.RaindropHipError, RuntimeError) as e:             # outside the captured step's envelope, or the capture itself failed
+            import warnings
+            warnings.warn("raindrop_amd.graph_module: no captured step for T=%d B=%d (%s: %s); these calls run operator by operator"
+                          % (T, B, type(e).__name__, str(e).splitlines()[0] if str(e) else ""))
             runners[key] = False
             return None
         runners[key] = r

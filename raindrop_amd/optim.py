@@ -19,6 +19,12 @@ class FlatAdam:
         self.exp_avg = torch.zeros_like(flat_param.data)
         self.exp_avg_sq = torch.zeros_like(flat_param.data)
         self.t = 0
+        self.step_cell = None                # device step state of the captured form (step_captured)
+        self._cell_stale = False
+
+    def hyper(self):
+        """the values a captured launch holds as constants (TrainStep.run_full captures again when they change)"""
+        return (float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay))
 
     def step(self):
         self.t += 1
@@ -61,3 +67,12 @@ class FlatAdam:
     def state_dict(self):
         return dict(t=self.t, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lr=self.lr, betas=self.betas,
                     eps=self.eps, weight_decay=self.weight_decay)
+
+    def load_state_dict(self, sd):
+        """In place (the moment buffers keep their addresses: a captured step stays valid); the device step state follows at the
+        next captured step."""
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.t = int(sd["t"])
+        self.lr, self.betas, self.eps, self.weight_decay = sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]
+        self._cell_stale = True

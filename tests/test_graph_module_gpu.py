@@ -178,3 +178,19 @@ def test_module_graph_step_recaptures_when_it_must():
     _, loss_g, g_g, _ = _loop_step(m, dv, True)
     assert m._graph_runners[next(k for k in m._graph_runners if k[1] == 8)] is not old
     assert abs(loss_g - loss_e) < 5e-6 and all(_close(g_g[n], g_e[n]) for n in live)
+
+
+def test_module_graph_step_keeps_a_bounded_number_of_runners(monkeypatch):
+    """Each runner holds a whole step's activations: a loop that varies its batch size keeps the RD_MODULE_GRAPH_MAX most recently
+    created ones (the oldest idle one goes), and the results stay those of the eager path."""
+    monkeypatch.setenv("RD_MODULE_GRAPH_MAX", "2")
+    cfg = synth.make_config("P19")
+    m = build_ours(cfg, synth.make_structure(cfg, "ones"), DEV, 9).train()
+    live = sorted(synth.live_parameter_names(cfg))
+    for B in (4, 6, 8, 4):
+        dv = _batch(cfg, B, 80 + B)
+        _, loss_e, g_e, _ = _loop_step(m, dv, False)
+        _, loss_g, g_g, _ = _loop_step(m, dv, True)
+        assert abs(loss_g - loss_e) < 5e-6 and all(_close(g_g[n], g_e[n]) for n in live)
+        assert len(m._graph_runners) <= 2
+    assert sorted(k[1] for k in m._graph_runners) == [4, 8]      # 6 was the oldest when 4 came back
