@@ -5,6 +5,8 @@ with this model unchanged.  `FlatAdam` is the fast path: because the live parame
 gradients already live in two flat buffers, the whole update is ONE elementwise HIP kernel
 (rd_adam_step) instead of a 35-tensor multi-tensor launch.  Same formula as torch (no amsgrad).
 """
+import ctypes
+
 import torch
 
 from . import _lib, ops
@@ -50,9 +52,11 @@ class FlatAdam:
         if fresh:
             self.step_cell = torch.zeros((8,), dtype=torch.float64, device=self.param.device)   # two slots {t, beta1^t, beta2^t, -}
         if fresh or not create_only:
+            # beta^t of the betas AS THE KERNELS SEE THEM (float arguments widened to double: rd_adam_step's pow() and the device's
+            # running product both start from those) -- 0.999 as a double instead of 0.999f moves 1 - beta2^t by 1e-5 relative
             t = float(self.t)
-            self.step_cell.copy_(torch.tensor([t, float(self.betas[0]) ** t, float(self.betas[1]) ** t, 0.0, -1.0, 0.0, 0.0, 0.0],
-                                              dtype=torch.float64))
+            b1, b2 = (ctypes.c_float(float(b)).value for b in self.betas)
+            self.step_cell.copy_(torch.tensor([t, b1 ** t, b2 ** t, 0.0, -1.0, 0.0, 0.0, 0.0], dtype=torch.float64))
 
     def device_steps(self):
         """steps taken according to the device state (the larger of the two slots' counts)"""
