@@ -31,6 +31,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // RD_DW_WAVES: 4 = one wave per SIMD, three register buffers (two tiles in flight under the third's products; 312 registers);
 // 8 = two waves per SIMD at <= 256 registers, two buffers each (the same tiles in flight per SIMD; one wave's requests issue under
 // the other's products).  Measured in round 5 (profiles/r05_kdw_waves_ab.txt).
+#ifndef RD_DW_SPREAD
+#define RD_DW_SPREAD 1
+#endif
 #ifndef RD_DW_WAVES
 #define RD_DW_WAVES 4
 #endif
@@ -80,35 +83,41 @@ __global__ __launch_bounds__(DW_THR) void k_dw(DwArgs a) {
   const __bf16* tA = layer ? a.tpD2 : a.tpD1;
   const __bf16* tB = layer ? a.tpY1 : a.tpX;
 
-  // operand tile pointers of reduction tile 0 (+ lane offset) and their per-tile stride.  The k-tile with index nct
-  // is the constant "ones" tile (column 0 = 1: its output column is the bias gradient), same source every step.
-  // Tiles beyond the operand's range map to a valid tile; their products are computed and dropped.
-  const size_t step = (size_t)nct * 2 * TILE;
-  const __bf16 *pa[4], *pb[4]; size_t sb[4];
+  // Operand addressing (as rd_tile_wgrad.hip, where the measurement is described): every tile part is read at [wave-uniform base] +
+  // lane * 16 bytes, the bases are scalar byte offsets from the zero tile + tile * stride.  The k-tile with index nct is the
+  // constant "ones" tile (column 0 = 1: its output column is the bias gradient), same source every step.  Tiles beyond the
+  // operand's range map to a valid tile; their products are computed and dropped.
+  // Tile i of this wave is reduction tile s0 + wave + DW_NW i; i >= nst is a GHOST tile: its A operands come from the zero tile
+  // (an AND with an opaque mask, not a select of two addresses: the compiler made five branches per tile of that, which kept the
+  // tile's loads and its MFMAs in separate basic blocks -- a burst of 16 loads, then 48 MFMAs, instead of both units busy), so
+  // every wave runs the same branch-free trip count and the compiler's s_waitcnt bookkeeping stays exact.
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const char* zb = reinterpret_cast<const char*>(a.ones + TILE);        // [ones hi][zeros][zeros]: the zero tile
+  const long step = (long)nct * 2 * TILE * 2;                           // bytes per reduction tile
+  long dA[4], dB[4], sB[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    pa[i] = tA + (size_t)min(4 * bn + i, nct - 1) * 2 * TILE + lane * 8;
+    dA[i] = reinterpret_cast<const char*>(tA + (size_t)min(4 * bn + i, nct - 1) * 2 * TILE) - zb;
     const int kt = 4 * bk + i;
-    if (kt == nct) { pb[i] = a.ones + lane * 8; sb[i] = 0; }
-    else { pb[i] = tB + (size_t)min(kt, nct - 1) * 2 * TILE + lane * 8; sb[i] = step; }
+    if (kt == nct) { dB[i] = reinterpret_cast<const char*>(a.ones) - zb; sB[i] = 0; }
+    else { dB[i] = reinterpret_cast<const char*>(tB + (size_t)min(kt, nct - 1) * 2 * TILE) - zb; sB[i] = step; }
   }
-  // tile i of this wave (reduction tile s0 + wave + DW_NW i); i >= nst is a GHOST tile: its A operands come from a zero
-  // tile, so it adds nothing -- every wave runs the same branch-free trip count and the compiler's s_waitcnt
-  // bookkeeping stays exact (with conditional loads it fell back to vmcnt(0) inside the loop)
   const int nst = s1 - s0 > wave ? (s1 - s0 - wave + DW_NW - 1) / DW_NW : 0;      // this wave's tile count
-  const __bf16* zt = a.ones + TILE + lane * 8;                          // [ones hi][zeros][zeros]
   auto load = [&](Frag& f, int i) {
     const bool ghost = i >= nst;
+    int live32 = __builtin_amdgcn_readfirstlane(ghost ? 0 : -1);
+    asm volatile("" : "+s"(live32));
+    const long live = (long)live32;
     const int ri = sl + nsl * (wave + DW_NW * i);                     // reduction index -> tile (ghosts: tile 0)
-    const size_t s = ghost ? 0 : (size_t)(ri < nmain ? ri : ri + lbase);
+    const long s = ghost ? 0 : (long)(ri < nmain ? ri : ri + lbase);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const __bf16* qa = ghost ? zt : pa[t] + s * step;
+      const char* qa = zb + ((dA[t] + s * step) & live) + lane16;
       f.ah[t] = *reinterpret_cast<const bf16x8*>(qa);
-      f.al[t] = *reinterpret_cast<const bf16x8*>(qa + TILE);
-      const __bf16* qb = pb[t] + s * sb[t];
+      f.al[t] = *reinterpret_cast<const bf16x8*>(qa + TILE * 2);
+      const char* qb = zb + (dB[t] + s * sB[t]) + lane16;
       f.bh[t] = *reinterpret_cast<const bf16x8*>(qb);
-      f.bl[t] = *reinterpret_cast<const bf16x8*>(qb + TILE);
+      f.bl[t] = *reinterpret_cast<const bf16x8*>(qb + TILE * 2);
     }
   };
   f32x4 acc[4][4];
@@ -137,12 +146,22 @@ __global__ __launch_bounds__(DW_THR) void k_dw(DwArgs a) {
   const int nmax = (s1 - s0 + DW_NW - 1) / DW_NW;                      // tile count of wave 0 (the largest)
   if constexpr (DW_NW == 4) {
     // ring of three register buffers, two tiles (32 KB per wave) in flight under the MFMAs of the third
+    // a stage = the 16 loads of tile i + 2 and the 48 MFMAs of tile i, interleaved one load per three MFMAs
+    auto spread = [&]() {
+#if RD_DW_SPREAD
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);             // one VMEM read
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);             // three MFMAs
+      }
+#endif
+    };
     Frag f0, f1, f2;
     load(f0, 0); load(f1, 1);
     for (int it = 0; it < nmax; it += 3) {
-      load(f2, it + 2); mma(f0);
-      load(f0, it + 3); mma(f1);
-      load(f1, it + 4); mma(f2);
+      load(f2, it + 2); mma(f0); spread();
+      load(f0, it + 3); mma(f1); spread();
+      load(f1, it + 4); mma(f2); spread();
     }
   } else {
     // two buffers per wave, two waves per SIMD

@@ -30,6 +30,9 @@ constexpr int TW_THR = 256, TW_NA = 5, TW_NB = 6, TW_SLICES = 8;
 constexpr int TW_LDC = 16 * TW_NB + 4;             // fp32 row stride of a wave's block in LDS
 constexpr int TW_LDS = 4 * 16 * TW_NA * TW_LDC * 4;   // 128 KB: the four waves' blocks for the final sum
 
+#ifndef RD_TWG_SPREAD
+#define RD_TWG_SPREAD 1
+#endif
 struct Frag { bf16x8 ah[TW_NA], al[TW_NA], bh[TW_NB], bl[TW_NB]; };
 
 // ONE: the single-product arithmetic mode (RD_PREC_BF16: hi * hi only).  The lo halves of the tiles are neither read nor multiplied --
@@ -52,37 +55,49 @@ __global__ __launch_bounds__(TW_THR) void k_twg(TwArgs a) {
   const int S = sp ? min(Sb, __builtin_amdgcn_readfirstlane(*sp)) : Sb;           // chunks beyond the live rows hold nothing (never exported)
   const int ntile = S > sl ? (S - sl + TW_SLICES - 1) / TW_SLICES : 0;        // chunks of this slice: sl, sl + 8, ...
 
-  // operand tile pointers of chunk 0 (+ lane offset) and their per-chunk strides.  The B column tile with index nctB is
-  // the constant "ones" tile (stride 0).  Tiles beyond an operand's range map to a valid tile; their products are
-  // computed and dropped at the store.
-  const size_t stepA = (size_t)nctA * 2 * TILE, stepB = (size_t)nctB * 2 * TILE;
-  const __bf16 *pa[TW_NA], *pb[TW_NB]; size_t sb[TW_NB];
+  // Operand addressing: every tile part is read at [wave-uniform base] + lane * 16 bytes.  The bases are SCALAR (byte offsets from the
+  // zero tile, one per operand tile of the block, + chunk * stride), so a load is `global_load_dwordx4 v, v_lane16, s[base]` with no
+  // vector address arithmetic.  The B column tile with index nctB is the constant "ones" tile (stride 0).  Tiles beyond an operand's
+  // range map to a valid tile; their products are computed and dropped at the store.
+  // Chunk i of this wave is slice-local index wave + 4 i; i >= nst is a GHOST: its A operands come from the zero tile -- selected
+  // by an AND with an opaque all-ones / zero mask, not a ?: (round 2-5a: the compiler turned the select of the two addresses into
+  // a branch around the 64-bit multiply, five per chunk, which cut every chunk's loads and MFMAs into separate basic blocks: the
+  // wave issued its 22 loads in one burst -- stalling on the address unit's queue while the other three waves' bursts drained --
+  // and only then its 90 MFMAs; address unit (22 KB per wave and chunk at 64 B/clk = 1408 cycles per round of the four waves) and
+  // matrix cores (90 x 16 = 1440) took turns instead of overlapping).  Measured in the step, same box, two traces each: k_twg
+  // 21.7 / 21.1 -> 20.7 / 20.5 us, k_dw 11.10 / 11.03 -> 10.56 / 10.88 (profiles/r05_spread_loads_ab.txt) -- less than the model
+  // promised: at 74.7 MB per launch the stream is within ~15 % of what HBM delivers to a kernel of this length.
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const char* zb = reinterpret_cast<const char*>(a.ones + TILE);                  // [ones hi][zeros][zeros]: the zero tile
+  const long stepA = (long)nctA * 2 * TILE * 2, stepB = (long)nctB * 2 * TILE * 2;  // bytes per chunk
+  long dA[TW_NA], dB[TW_NB], sB[TW_NB];
 #pragma unroll
-  for (int i = 0; i < TW_NA; ++i) pa[i] = P.tA + (size_t)min(TW_NA * bn + i, nctA - 1) * 2 * TILE + lane * 8;
+  for (int i = 0; i < TW_NA; ++i)
+    dA[i] = reinterpret_cast<const char*>(P.tA + (size_t)min(TW_NA * bn + i, nctA - 1) * 2 * TILE) - zb;
 #pragma unroll
   for (int i = 0; i < TW_NB; ++i) {
     const int kt = TW_NB * bk + i;
-    if (kt == nctB) { pb[i] = a.ones + lane * 8; sb[i] = 0; }
-    else { pb[i] = P.tB + (size_t)min(kt, nctB - 1) * 2 * TILE + lane * 8; sb[i] = stepB; }
+    if (kt == nctB) { dB[i] = reinterpret_cast<const char*>(a.ones) - zb; sB[i] = 0; }
+    else { dB[i] = reinterpret_cast<const char*>(P.tB + (size_t)min(kt, nctB - 1) * 2 * TILE) - zb; sB[i] = stepB; }
   }
-  // chunk i of this wave is slice-local index wave + 4 i; i >= nst is a GHOST: its A operands come from a zero tile,
-  // so every wave runs the same branch-free trip count and the s_waitcnt bookkeeping stays exact (rd_msgpass_dw.hip)
   const int nst = ntile > wave ? (ntile - wave + 3) / 4 : 0;
-  const __bf16* zt = a.ones + TILE + lane * 8;                        // [ones hi][zeros][zeros]
   auto load = [&](Frag& f, int i) {
     const bool ghost = i >= nst;
-    const size_t s = (size_t)(ghost ? 0 : sl + TW_SLICES * (wave + 4 * i));
+    int live32 = __builtin_amdgcn_readfirstlane(ghost ? 0 : -1);
+    asm volatile("" : "+s"(live32));                                    // opaque: stays an AND (see above)
+    const long live = (long)live32;
+    const long s = ghost ? 0 : sl + TW_SLICES * (wave + 4 * i);
 #pragma unroll
     for (int t = 0; t < TW_NA; ++t) {
-      const __bf16* qa = ghost ? zt : pa[t] + s * stepA;
+      const char* qa = zb + ((dA[t] + s * stepA) & live) + lane16;
       f.ah[t] = *reinterpret_cast<const bf16x8*>(qa);
-      if (!ONE) f.al[t] = *reinterpret_cast<const bf16x8*>(qa + TILE);
+      if (!ONE) f.al[t] = *reinterpret_cast<const bf16x8*>(qa + TILE * 2);
     }
 #pragma unroll
     for (int t = 0; t < TW_NB; ++t) {
-      const __bf16* qb = pb[t] + s * sb[t];
+      const char* qb = zb + (dB[t] + s * sB[t]) + lane16;
       f.bh[t] = *reinterpret_cast<const bf16x8*>(qb);
-      if (!ONE) f.bl[t] = *reinterpret_cast<const bf16x8*>(qb + TILE);
+      if (!ONE) f.bl[t] = *reinterpret_cast<const bf16x8*>(qb + TILE * 2);
     }
   };
   f32x4 acc[TW_NA][TW_NB];
@@ -111,12 +126,25 @@ __global__ __launch_bounds__(TW_THR) void k_twg(TwArgs a) {
   };
 
   const int nmax = (ntile + 3) / 4;                                   // chunk count of wave 0 (the largest)
+  // One stage = the loads of chunk i + 2 and the products of chunk i, INTERLEAVED: one tile-part load per NM / NL MFMAs, so the
+  // wave's requests reach the address unit spread over the stage and its own MFMAs run under the other waves' loads.
+  constexpr int NL = (ONE ? 1 : 2) * (TW_NA + TW_NB), NM = (ONE ? 1 : 3) * TW_NA * TW_NB, PER = NM / NL;
+  auto spread = [&]() {
+#if RD_TWG_SPREAD
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);               // one VMEM read
+      __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);             // PER MFMAs
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NM - PER * NL, 0);
+#endif
+  };
   Frag f0, f1, f2;
   load(f0, 0); load(f1, 1);
   for (int it = 0; it < nmax; it += 3) {
-    load(f2, it + 2); mma(f0);
-    load(f0, it + 3); mma(f1);
-    load(f1, it + 4); mma(f2);
+    load(f2, it + 2); mma(f0); spread();
+    load(f0, it + 3); mma(f1); spread();
+    load(f1, it + 4); mma(f2); spread();
   }
 
   // ---- in-workgroup sum of the four waves' blocks (fixed wave order) -> slice partial ----
