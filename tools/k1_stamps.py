@@ -61,6 +61,9 @@ if "--step" in sys.argv:
     for _ in range(5):
         ts.run(); opt.step()
     torch.cuda.synchronize()
+    stamps.zero_()                                             # the workgroup END stamps are atomicMax'es and clock64 is per XCD: keep ONE replay's
+    ts.run(); opt.step()
+    torch.cuda.synchronize()
     tag = "in-step"
 else:
     g = m._graph(dev); shp = _lib.shape(B, 60, 34, 4)
