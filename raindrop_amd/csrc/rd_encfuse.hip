@@ -10,8 +10,16 @@
 // 15-20 us chain (load rows -> split -> multiply -> stage -> epilogue -> store) over ONE round of workgroups, with the
 // intermediate written to HBM and read back by the next.  Here a workgroup keeps its token rows in LDS through the whole chain:
 // the rows are read once, only what the backward pass (or the attention core) needs is written, and the three weight panels
-// stream from L2 behind one another.  Same arithmetic, same lane <-> element assignment, same Philox quads and same summation
-// order as the kernels it replaces (k_rowgemm<.., LN> / <.., LNB>): results are bit-identical to the unfused path.
+// stream from L2 behind one another.  Same arithmetic, same dropout quads and same summation order of every product as the
+// kernels it replaces (k_rowgemm<.., LN> / <.., LNB>); the LayerNorm row sums are grouped differently (rounding-level differences).
+//
+// Round 5 (second half): the products run with the WEIGHT fragment as the MFMA's A operand, so an accumulator is a column quad of a
+// row (one 16-byte store / one dropout quad / one gate byte) -- see mma.  The two nhid-wide products no longer pass through a
+// fp32 stage: their epilogues (bias + ReLU + dropout + split in the forward chain, the h > 0 gate in the backward chain) run on
+// the accumulators, per wave, while the other waves of the SIMD still multiply -- one barrier, one stage round trip and the index
+// arithmetic of a flat 3.4-quads-per-thread loop less per chain; the stage shrank to the D-wide products' 164 columns, and the
+// LDS it freed keeps x1 (forward) and ds2 (backward) as fp32 rows where rounds 3-4 wrote them to memory and read them back; the
+// last product of the backward chain stores d attn straight from its accumulators.
 //
 // Rows per workgroup.  A workgroup needs ~100-150 KB of LDS, so ONE fits a CU and a launch is a whole number of rounds over the
 // `ncu` CUs; these chains are latency-bound (a round costs ~20 us whether it carries 32 or 48 rows per workgroup), so the
@@ -41,7 +49,8 @@ constexpr int KPD = 32 * KCD, KPH = 32 * KCH;        // 160, 288
 // banks: the MFMA fragment read (lane: row r, 16-byte chunk G) is conflict-free exactly when the row stride is 32 bytes mod 64
 // (tools/lds_conflicts.py, measured by tools/probe_ldsfrag.hip: 235 B/clk/CU against 127 for the "+ 8 elements" of rounds 1-4).
 constexpr int LDD = KPD + 16, LDH = KPH + 16;
-constexpr int STG = KPH + 4;                         // fp32 stage row stride: all nhid <= 288 output columns of linear1 + pad
+constexpr int STG = KPD + 4;                         // fp32 stage row stride: the D-wide products' output columns + pad (the nhid-wide
+                                                     // products finish on their accumulators: no stage)
 
 template <int KC>
 struct Panel { bf16x8 h[KC], l[KC]; };
@@ -64,12 +73,20 @@ __device__ __forceinline__ void load_panel(Panel<KC>& p, const __bf16* __restric
   }
 }
 
-// acc[rt] = A[rows 16 rt .., :] * panel^T, split-bf16 (lo*hi + hi*lo + hi*hi), A planes in LDS.
+// acc[rt] = (A[rows 16 rt .., :] * panel^T)^T, split-bf16 (lo*hi + hi*lo + hi*hi), A planes in LDS.  The WEIGHT fragment is the MFMA's
+// A operand and the row fragment its B operand (both fragments have the same lane layout: index lane & 15, reduction steps
+// 8 (lane >> 4) ..), so the accumulator comes out transposed: lane (i = lane & 15, G = lane >> 4) holds the four CONSECUTIVE COLUMNS
+// 16 j + 4 G .. + 3 of row 16 rt + i -- one column quad, i.e. one 16-byte stage store, one dropout quad, one gate byte -- instead of
+// four rows of one column.  Same products in the same order: the same bits (rd_msgpass_fused.hip, round 5).
 // One (hi, lo) fragment pair is live per row tile and step: the three products of (kc, rt) are issued, then the pair of (kc + 1, rt)
 // is requested into the same registers (the rolled order of rd_msgpass_fused.hip's mma_mid) -- the LDS reads travel under the other
 // row tiles' MFMAs, and the tall variant keeps 8 fragment registers fewer alive beside its 72-register panels.
-template <int KC, int RT>
-__device__ __forceinline__ void mma(f32x4 (&acc)[RT], const __bf16* Ah, const __bf16* Al, int lda, const Panel<KC>& p, int lane, int one) {
+// mid() / mid2(): issued once behind reduction step MIDK / MIDK2 -- global loads that have no registers to live in before the panel's
+// first steps are consumed (the tall variant: the last steps of a 72-register panel, the next phase's saved rows).
+struct NoMid { __device__ __forceinline__ void operator()() const {} };
+template <int KC, int RT, int MIDK = -1, typename Mid = NoMid, int MIDK2 = -1, typename Mid2 = NoMid>
+__device__ __forceinline__ void mma(f32x4 (&acc)[RT], const __bf16* Ah, const __bf16* Al, int lda, const Panel<KC>& p, int lane, int one,
+                                    Mid mid = Mid(), Mid2 mid2 = Mid2()) {
   const int aoff = (lane & 15) * lda + 8 * (lane >> 4);
   bf16x8 ah[RT], al[RT];
 #pragma unroll
@@ -80,7 +97,9 @@ __device__ __forceinline__ void mma(f32x4 (&acc)[RT], const __bf16* Ah, const __
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * lda + aoff + kc * 32);
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.h[kc], acc[rt], 0, 0, 0);
+      for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p.h[kc], ah[rt], acc[rt], 0, 0, 0);
+      if (kc == MIDK) mid();
+      if (kc == MIDK2) mid2();
     }
     return;
   }
@@ -93,9 +112,9 @@ __device__ __forceinline__ void mma(f32x4 (&acc)[RT], const __bf16* Ah, const __
   for (int kc = 0; kc < KC; ++kc) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], p.h[kc], acc[rt], 0, 0, 0);
-      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.l[kc], acc[rt], 0, 0, 0);
-      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], p.h[kc], acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p.h[kc], al[rt], acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p.l[kc], ah[rt], acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p.h[kc], ah[rt], acc[rt], 0, 0, 0);
       if (kc + 1 < KC) {
         ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * lda + aoff + (kc + 1) * 32);
         al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * lda + aoff + (kc + 1) * 32);
@@ -108,16 +127,21 @@ __device__ __forceinline__ void mma(f32x4 (&acc)[RT], const __bf16* Ah, const __
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       }
     }
+    if (kc == MIDK || kc == MIDK2) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (kc == MIDK) mid();
+      if (kc == MIDK2) mid2();
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 }
 
-// accumulators of column tile j -> stage[row][16 j + column]
+// accumulators of column tile j (transposed form, see mma) -> stage[row][16 j + 4 G ..]: one 16-byte store per row tile.  The 16 rows of
+// a store group lie 1168 bytes apart = 16-byte chunks 9 r mod 16 of the 256-byte bank window: all different, conflict-free.
 template <int RT>
 __device__ __forceinline__ void to_stage(float* stage, const f32x4 (&acc)[RT], int j, int lane) {
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) stage[(rt * 16 + 4 * (lane >> 4) + r) * STG + j * 16 + (lane & 15)] = acc[rt][r];
+  for (int rt = 0; rt < RT; ++rt) *reinterpret_cast<f32x4*>(stage + (rt * 16 + (lane & 15)) * STG + j * 16 + 4 * (lane >> 4)) = acc[rt];
 }
 
 __device__ __forceinline__ void split_store4(__bf16* ph, __bf16* pl, const float4& v) {
@@ -168,6 +192,19 @@ __device__ __forceinline__ void zero_dead_groups(__bf16* xt, int nct, int m0, in
       const int slot = i & 31, jp = i >> 5;
       *reinterpret_cast<float4*>(xt + ((size_t)(grp >> 1) * nct * 2 + jp) * 512 + (32 * (grp & 1) + slot) * 8) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+  }
+}
+
+// The nhid-wide planes' columns beyond the last column TILE (16 ntH .. KPH: the reduction of the product that reads them runs over
+// KPH): zero, once per kernel -- the epilogues that fill the planes write whole tiles (and zeros beyond nhid inside the last one).
+template <int RT>
+__device__ __forceinline__ void zero_pad_columns(__bf16* Hh, __bf16* Hl, int ntH, int tid) {
+  const int c0 = 16 * ntH, nq = (KPH - c0) >> 2;               // uniform
+  for (int i = tid; i < 16 * RT * nq; i += EF_THR) {
+    const int r = i / nq, q = i - r * nq;
+    bf16x4 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+    *reinterpret_cast<bf16x4*>(Hh + r * LDH + c0 + 4 * q) = z;
+    *reinterpret_cast<bf16x4*>(Hl + r * LDH + c0 + 4 * q) = z;
   }
 }
 
@@ -237,11 +274,12 @@ __device__ __forceinline__ void ln_load3(float4 (&r)[LNQ], const float* src, int
 }
 
 // One pass of the LayerNorm epilogue: sv = residual + dropout(stage + bias); writes the pre-norm sum, the normalised row and the
-// statistics; normalised rows also go to the split planes (Ph != null; zeros beyond D / M: the next product reads them).
+// statistics; normalised rows also go to the split planes (Ph != null; zeros beyond D / M: the next product reads them) and, as fp32,
+// to `keep` ([rows][KPD] in LDS; null: not wanted).
 // bs / gg / bb: the bias, gamma, beta vectors in LDS (zero padded to KPD).
 __device__ __forceinline__ void ln_rows4(const float* stage, const float4 (&res)[LNQ], const float* bs, const float* gg, const float* bb, int D,
                                          int m0, int M, int wave, int lane, float p, float inv_keep, uint64_t seed, uint32_t site,
-                                         float* s_out, float* y_out, float* stats, __bf16* Ph, __bf16* Pl, float2* mr_out = nullptr) {
+                                         float* s_out, float* y_out, float* stats, __bf16* Ph, __bf16* Pl, float* keep = nullptr) {
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const int g = lane >> 4, i16 = lane & 15, rl = 4 * wave + g;
   const long m = m0 + rl;
@@ -291,9 +329,9 @@ __device__ __forceinline__ void ln_rows4(const float* stage, const float4 (&res)
       if (y_out) *reinterpret_cast<float4*>(y_out + m * D + c) = o;
     }
     if (Ph && c < KPD) split_store4(Ph + rl * LDD + c, Pl + rl * LDD + c, o);
+    if (keep && c < KPD) *reinterpret_cast<float4*>(keep + rl * KPD + c) = o;   // fp32 copy for the next LayerNorm's residual (this lane reads it back)
   }
   if (i16 == 0 && rok) { stats[2 * m] = mean; stats[2 * m + 1] = rstd; }
-  if (mr_out) *mr_out = make_float2(mean, rstd);                // every lane of the row holds the same two values
 }
 
 // DC / HC: model width and FFN width as compile-time constants (0: read from the arguments).  These chains are instruction-issue
@@ -313,7 +351,11 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
   // per-column vectors [bo | g1 | be1 | b2 | g2 | be2] (KPD each) and b1 (KPH), zero padded: fetched ONCE, first thing, so that no
   // epilogue has a global load of its own -- those queue behind the weight panel requested just before them (loads return in order)
   float* cst = stage + ROWS * STG;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // x1 (LayerNorm1's output, the residual of LayerNorm2) as fp32 [ROWS][KPD]: written and read back by the SAME lane (pass layout), so
+  // no barrier orders it.  Rounds 3-4 re-read it from memory (LEAN: the pre-norm sum, re-normalised); the stage of the nhid-wide
+  // product that stood here is gone (h_epilogue).
+  float* x1r = cst + 6 * KPD + KPH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: `if (wave < ..)` is a branch, not a mask
   const int m0 = blockIdx.x * ROWS;
   const int D = DC ? DC : a.D, H = HC ? HC : a.H;
   const int ntD = (D + 15) >> 4, ntH = (H + 15) >> 4;
@@ -335,6 +377,7 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
     fetch(a.b2, D, 3 * KPD, KPD); fetch(a.g2, D, 4 * KPD, KPD); fetch(a.be2, D, 5 * KPD, KPD);
     fetch(a.b1, H, 6 * KPD, KPH);
   }
+  zero_pad_columns<RT>(Hh, Hl, ntH, tid);                      // columns 16 ntH .. KPH of the h planes (linear2 reduces over KPH)
   // ---- attention rows -> split planes (zero padded to KPD columns, rows beyond M zero) ----
   constexpr int kq = KPD / 4;
   constexpr int NIT = (ROWS * kq + EF_THR - 1) / EF_THR;
@@ -377,73 +420,75 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
   Panel<KCD> p1;                                               // linear1 (column tiles 0..15) streams in under the LayerNorm epilogue
   load_panel<KCD, 0, KCD, true>(p1, a.W1, ntH, wave, lane);    // (requested BEHIND the barrier: issuing it blocks a wave for a while)
   // ---- + bias, dropout, + x, LayerNorm1 -> s1, x1 (global), x1 planes ----
-  float2 st1v = make_float2(0.f, 0.f);                         // LEAN: this lane's LayerNorm1 (mean, rstd), kept for the residual of LayerNorm2
   if (lnw) ln_rows4(stage, xr, cst, cst + KPD, cst + 2 * KPD, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_ao, a.s1, LEAN ? nullptr : a.x1,
-                    a.st1, Ah, Al, &st1v);
+                    a.st1, Ah, Al, x1r);
   EFSTAMP(5);
   lds_barrier();
   EFSTAMP(6);
   if (a.xt_x1) export_tiles<RT>(Ah, Al, LDD, a.xt_x1, ntD, m0, M, wave, lane);
 
-  // ---- linear1, ReLU, dropout -> h (global fp32 + planes) ----
+  // ---- linear1 -> + bias, ReLU, dropout -> h: the epilogue runs on the ACCUMULATORS (no fp32 stage, no barrier between product and
+  // epilogue) -- a lane holds the column quad 16 j + 4 G .. + 3 of row 16 rt + i (mma), which is one dropout quad, one gate byte (LEAN)
+  // or one 16-byte store of h, and one 8-byte store into each split plane.  While one wave of a SIMD is in its epilogue (VALU) the
+  // others are still multiplying: the two phases of rounds 2-4 (product -> stage -> barrier -> 3.4 quads per thread) overlap. ----
+  Panel<KCH> p2;                                               // linear2 streams in under the (last) epilogue
   {
-    f32x4 acc[RT];
-    mma<KCD, RT>(acc, Ah, Al, LDD, p1, lane, a.one);
-    // nhid > 256: the remaining column tiles (P19: tile 16, wave 0 -- the other 15 waves wait for it at the barrier).  Its panel
-    // goes into the registers the first product has just released, as ONE batch of requests in front of the stage writes: left
-    // to itself the compiler trickled the ten loads in between the first product's MFMAs, each with its own vmcnt(0) in front
-    // of the second product -- six dependent round trips on the workgroup's critical path.
-    for (int t0 = EF_WV; t0 < ntH + EF_WV; t0 += EF_WV) {
-      const bool more = t0 + wave < ntH;                       // wave-uniform
-      f32x4 prev[RT];
+    const int G = lane >> 4, i16 = lane & 15, qpr = H >> 2;
+    auto h_epilogue = [&](const f32x4 (&acc)[RT], int j) {
+      const int n = 16 * j + 4 * G;                            // < KPH (j < 18)
+      const float4 bs = *reinterpret_cast<const float4*>(cst + 6 * KPD + n);
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) prev[rt] = acc[rt];
+      for (int rt = 0; rt < RT; ++rt) {
+        const int rl = 16 * rt + i16, m = m0 + rl;
+        float4 o = zero4;
+        if (m < M && n < H) {
+          o = make_float4(fmaxf(acc[rt][0] + bs.x, 0.f), fmaxf(acc[rt][1] + bs.y, 0.f), fmaxf(acc[rt][2] + bs.z, 0.f), fmaxf(acc[rt][3] + bs.w, 0.f));
+          if (a.p > 0.f) {
+            const float4 u = uniform4(seed, a.site_fh, ((uint64_t)m * H + n) >> 2);
+            o.x = u.x >= a.p ? o.x * inv_keep : 0.f; o.y = u.y >= a.p ? o.y * inv_keep : 0.f;
+            o.z = u.z >= a.p ? o.z * inv_keep : 0.f; o.w = u.w >= a.p ? o.w * inv_keep : 0.f;
+          }
+          if (LEAN)
+            a.hgate[(long)m * qpr + (n >> 2)] = (uint8_t)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
+          else
+            *reinterpret_cast<float4*>(a.h + (long)m * H + n) = o;
+        }
+        split_store4(Hh + rl * LDH + n, Hl + rl * LDH + n, o);
+      }
+    };
+    f32x4 acc[RT];
+    mma<KCD, RT>(acc, Ah, Al, LDD, p1, lane, a.one);           // column tile `wave` (every wave has one: nhid > 256)
+    // nhid > 256: the remaining column tiles (P19: tile 16, wave 0).  Their panel goes into the registers the first product has
+    // just released, as ONE batch of requests in front of the first tile's epilogue (left to itself the compiler trickled the ten
+    // loads in between the MFMAs, each with its own vmcnt(0) in front of the second product); a wave without a second tile
+    // requests linear2's panel there instead.
+    const bool more = __builtin_amdgcn_readfirstlane(EF_WV + wave) < ntH;   // scalar condition: one of the two panels is live, not both
+    __builtin_amdgcn_sched_barrier(0);
+    // (linear2's 72-register panel in two parts: steps 0 .. PS - 1 travel under the epilogue, the rest is requested behind it --
+    // whole, it spilled 24-32 registers across the epilogue; the product consumes the steps in order, PS of them cover the rest)
+    constexpr int PS = 5;
+    // (two straight-line paths, not `if (more) request A else request B` + a common epilogue: behind that join the register
+    // allocator kept BOTH panels' registers apart -- 112 registers for one live panel)
+    if (more) {
+      load_panel<KCD>(p1, a.W1, ntH, EF_WV + wave, lane);
       __builtin_amdgcn_sched_barrier(0);
-      if (more) load_panel<KCD>(p1, a.W1, ntH, t0 + wave, lane);
+      h_epilogue(acc, wave);
+      mma<KCD, RT>(acc, Ah, Al, LDD, p1, lane, a.one);
       __builtin_amdgcn_sched_barrier(0);
-      if (t0 - EF_WV + wave < ntH) to_stage<RT>(stage, prev, t0 - EF_WV + wave, lane);
-      if (more) mma<KCD, RT>(acc, Ah, Al, LDD, p1, lane, a.one);
+      load_panel<KCH, 0, PS>(p2, a.W2, ntD, wave, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      h_epilogue(acc, EF_WV + wave);
+    } else {
+      load_panel<KCH, 0, PS>(p2, a.W2, ntD, wave, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      h_epilogue(acc, wave);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    load_panel<KCH, PS, KCH>(p2, a.W2, ntD, wave, lane);
   }
   EFSTAMP(7);
   lds_barrier();
   EFSTAMP(8);
-  Panel<KCH> p2;                                               // linear2 streams in under the epilogue
-  load_panel<KCH>(p2, a.W2, ntD, wave, lane);
-  {
-    const int qpr = H >> 2;
-    constexpr int hq = KPH / 4;
-    for (int e = tid; e < ROWS * hq; e += EF_THR) {
-      const int rl = e / hq, q = e - rl * hq;
-      const int m = m0 + rl, n = 4 * q;
-      float4 o = zero4;
-      if (m < M && q < qpr) {
-        const float4 bs = *reinterpret_cast<const float4*>(cst + 6 * KPD + n);
-        const float4 s4 = *reinterpret_cast<const float4*>(stage + rl * STG + n);
-        o = make_float4(fmaxf(s4.x + bs.x, 0.f), fmaxf(s4.y + bs.y, 0.f), fmaxf(s4.z + bs.z, 0.f), fmaxf(s4.w + bs.w, 0.f));
-        if (a.p > 0.f) {
-          const float4 u = uniform4(seed, a.site_fh, ((uint64_t)m * H + n) >> 2);
-          o.x = u.x >= a.p ? o.x * inv_keep : 0.f; o.y = u.y >= a.p ? o.y * inv_keep : 0.f;
-          o.z = u.z >= a.p ? o.z * inv_keep : 0.f; o.w = u.w >= a.p ? o.w * inv_keep : 0.f;
-        }
-        if (LEAN)
-          a.hgate[(long)m * qpr + q] = (uint8_t)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
-        else
-          *reinterpret_cast<float4*>(a.h + (long)m * H + n) = o;
-      }
-      split_store4(Hh + rl * LDH + n, Hl + rl * LDH + n, o);
-    }
-  }
-  // LayerNorm2's residual x1: read back by the very lane that stored it (pass layout).  The tall variant has no registers to carry
-  // the three quads through linear2's product beside its 72-register panel (they spilled: 23 MB of scratch writes per launch): it
-  // requests them behind the product instead.
-  // LEAN: x1 was never stored -- the lane re-reads the pre-norm sum it wrote (s1) and re-normalises with the (mean, rstd) it kept
-  // (the same expression, in the same order, as LayerNorm1's output)
-  auto load_res2 = [&]() { if (lnw) ln_load3(xr, LEAN ? a.s1 : a.x1, D, m0, M, wave, lane); };
-  if constexpr (RT < 3) load_res2();
-  EFSTAMP(9);
-  lds_barrier();
-  EFSTAMP(10);
   if (a.xt_h) export_tiles<RT>(Hh, Hl, LDH, a.xt_h, ntH, m0, M, wave, lane);
 
   // ---- linear2 ----
@@ -452,33 +497,29 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
     mma<KCH, RT>(acc, Hh, Hl, LDH, p2, lane, a.one);
     to_stage<RT>(stage, acc, wave, lane);
   }
-  if constexpr (RT >= 3) load_res2();
-  EFSTAMP(11);
+  EFSTAMP(9);
   lds_barrier();
-  EFSTAMP(12);
+  EFSTAMP(10);
   // ---- + bias, dropout, + x1, LayerNorm2 -> s2, y ----
-  if (LEAN && lnw) {
+  if (lnw) {                                                   // the residual x1: this lane's own fp32 copy (zero beyond D / M)
+    const int rl = 4 * wave + (lane >> 4);
 #pragma unroll
     for (int k = 0; k < LNQ; ++k) {
       const int c = 4 * ((lane & 15) + 16 * k);
-      if (c < D && m0 + 4 * wave + (lane >> 4) < M) {
-        const float4 g4 = *reinterpret_cast<const float4*>(cst + KPD + c), b4 = *reinterpret_cast<const float4*>(cst + 2 * KPD + c);
-        const float mean = st1v.x, rstd = st1v.y;
-        xr[k] = make_float4((xr[k].x - mean) * rstd * g4.x + b4.x, (xr[k].y - mean) * rstd * g4.y + b4.y,
-                            (xr[k].z - mean) * rstd * g4.z + b4.z, (xr[k].w - mean) * rstd * g4.w + b4.w);
-      }
+      xr[k] = zero4;
+      if (c < KPD) xr[k] = *reinterpret_cast<const float4*>(x1r + rl * KPD + c);
     }
   }
   if (lnw) ln_rows4(stage, xr, cst + 3 * KPD, cst + 4 * KPD, cst + 5 * KPD, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_fo, a.s2, a.y, a.st2,
                     nullptr, nullptr);
-  EFSTAMP(13);
+  EFSTAMP(11);
   if (a.stamps && tid == 0) { a.stamps[256 + 1024 + 2 * blockIdx.x] = wall_clock64(); a.stamps[256 + 1024 + 2 * blockIdx.x + 1] = clock64(); }
 }
 
 template <int DC, int HC, bool LEAN>
 __global__ __launch_bounds__(EF_THR) void k_enc_post_fwd(PostFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
-  RD_TOUCH_CODE(31744);                                  // own code -> L2 (rd_common.h; the smallest instantiation is 32.6 KB)
+  RD_TOUCH_CODE(40960);                                  // own code -> L2 (rd_common.h; the smallest instantiation is 41.8 KB)
   int M = a.M;
   if (a.mlive) M = min(M, __builtin_amdgcn_readfirstlane(*a.mlive));
   if (pick_rt(M, a.ncu) == 3) post_fwd_body<3, DC, HC, LEAN>(a, esm, M);
@@ -486,8 +527,10 @@ __global__ __launch_bounds__(EF_THR) void k_enc_post_fwd(PostFwdArgs a) {
 }
 
 constexpr size_t post_fwd_lds(int rt) {
-  return (size_t)2 * 16 * rt * LDD * 2 + (size_t)2 * 16 * rt * LDH * 2 + (size_t)16 * rt * STG * 4 + (size_t)(6 * KPD + KPH) * 4;
+  return (size_t)2 * 16 * rt * LDD * 2 + (size_t)2 * 16 * rt * LDH * 2 + (size_t)16 * rt * STG * 4 + (size_t)(6 * KPD + KPH) * 4 +
+         (size_t)16 * rt * KPD * 4;
 }
+static_assert(post_fwd_lds(EF_RTMAX) <= 160 * 1024, "one workgroup's LDS");
 
 // ------------------------------------------------------------------------------------------------
 // backward chain: dy -> LayerNorm2' -> linear2' (gated by h > 0) -> linear1' + ds2 -> LayerNorm1' -> out_proj' -> d attn
@@ -510,12 +553,13 @@ struct PreBwdArgs {
 };
 
 // LayerNorm backward, one pass of four rows (the layout of ln_rows4).  dyq / sq: the rows' dy and saved pre-norm quads (zero beyond
-// D or M); mean / rstd: the lane's row statistics.  Writes the unmasked gradient quads to ds_glob ([M][K]), the dropout-masked ones
+// D or M); mean / rstd: the lane's row statistics.  Writes the unmasked gradient quads to ds_glob ([M][K]; null: not wanted) and / or to
+// `keep` (fp32 [rows][KPD] in LDS, read back by the same lane; only the quads below K of live rows are written), the dropout-masked ones
 // (what the next product consumes) as split planes, and this pass's dgamma | dbeta partials, summed over row pairs in registers
 // (rowpair_sum), into lnred[2 wave + (g >> 1)].  Same arithmetic as k_rowgemm<.., LNB> (rd_rowgemm.hip) up to the order of the sums.
 __device__ __forceinline__ void lnb_rows4(const float4 (&dyq)[LNQ], const float4 (&sq)[LNQ], float mean, float rstd, const float* gg, int K,
                                           int m0, int M, int wave, int lane, float p, float inv_keep, uint64_t seed, uint32_t site,
-                                          float* ds_glob, __bf16* Ph, __bf16* Pl, float* lnred) {
+                                          float* ds_glob, float* keep, __bf16* Ph, __bf16* Pl, float* lnred) {
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const int g = lane >> 4, i16 = lane & 15, rl = 4 * wave + g;
   const long row = m0 + rl;
@@ -543,7 +587,8 @@ __device__ __forceinline__ void lnb_rows4(const float4 (&dyq)[LNQ], const float4
     if (rok && c < K) {
       const float4 v = make_float4(rstd * (dg[k].x - c1 - xh[k].x * c2), rstd * (dg[k].y - c1 - xh[k].y * c2),
                                    rstd * (dg[k].z - c1 - xh[k].z * c2), rstd * (dg[k].w - c1 - xh[k].w * c2));
-      *reinterpret_cast<float4*>(ds_glob + row * K + c) = v;
+      if (ds_glob) *reinterpret_cast<float4*>(ds_glob + row * K + c) = v;
+      if (keep) *reinterpret_cast<float4*>(keep + rl * KPD + c) = v;
       dr = v;
       if (p > 0.f) {
         const float4 u = uniform4(seed, site, ((uint64_t)row * K + c) >> 2);
@@ -572,11 +617,16 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   __bf16* Hl = Hh + ROWS * LDH;
   float* stage = reinterpret_cast<float*>(Hl + ROWS * LDH);    // [ROWS][STG]
   float* cst = stage + ROWS * STG;                             // [g2 | g1] (KPD each, zero padded)
-  // [2 NPASS row pairs][2 KPD] dgamma | dbeta partials of one LayerNorm: aliases the du planes (written only between the two uses,
-  // each use is closed by a barrier before / after the planes are touched)
-  float* lnred = reinterpret_cast<float*>(Hh);
+  // ds2 (gradient of LayerNorm2's input: the residual branch around the FFN) as fp32 [ROWS][KPD]: written by LayerNorm2' and read back
+  // by the same lane in front of LayerNorm1' -- it never leaves the CU (rounds 3-4: a 5-MB round trip through memory per layer)
+  float* dsr = cst + 2 * KPD;
+  // [2 NPASS row pairs][2 KPD] dgamma | dbeta partials of one LayerNorm.  LayerNorm2's live in the (then idle) stage; LayerNorm1's alias
+  // the du planes, which are dead by then (both uses are closed by a barrier before / after the memory is reused)
+  float* lnred2 = stage;
+  float* lnred1 = reinterpret_cast<float*>(Hh);
   static_assert((size_t)2 * 4 * RT * 2 * KPD * 4 <= (size_t)2 * ROWS * LDH * 2, "lnred must fit inside the du planes");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  static_assert((size_t)2 * 4 * RT * 2 * KPD * 4 <= (size_t)ROWS * STG * 4, "lnred must fit inside the stage");
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: `if (wave < ..)` is a branch, not a mask
   const int m0 = blockIdx.x * ROWS;
   const int D = DC ? DC : a.D, H = HC ? HC : a.H;
   const int ntD = (D + 15) >> 4, ntH = (H + 15) >> 4;
@@ -613,21 +663,8 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   if (a.seed_cell) seed += load_uniform_u64(a.seed_cell);
   lds_barrier();                                               // cst visible
   EFSTAMP(1);
-  if (lnw) lnb_rows4(dyq, sq, mean_l, rstd_l, cst, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_fo, a.ds2, Ah, Al, lnred);
-  // the FFN hidden (gate: h > 0): thread -> quads e, e + 1024, .. of the [ROWS][KPH / 4] grid; requested here, consumed behind
-  // the next product
-  constexpr int hq = KPH / 4;
-  constexpr int HIT = (ROWS * hq + EF_THR - 1) / EF_THR;
-  float4 hv[LEAN ? 1 : HIT]; uint8_t hb[LEAN ? HIT : 1];
-#pragma unroll
-  for (int it = 0; it < HIT; ++it) {
-    const int e = tid + it * EF_THR;
-    const int rl = e / hq, q = e - rl * hq;
-    // UNCONDITIONAL from a clamped address (rows >= M have a zero gradient in the stage, columns >= H and rows >= ROWS are not
-    // consumed): a conditional load is a phi of {0, value} and the compiler waited for each one right behind its request
-    if (LEAN) hb[it] = a.hgate[(long)min(m0 + min(rl, ROWS - 1), M - 1) * (H >> 2) + min(q, (H >> 2) - 1)];
-    else hv[it] = *reinterpret_cast<const float4*>(a.h + (long)min(m0 + min(rl, ROWS - 1), M - 1) * H + min(4 * q, H - 4));
-  }
+  if (lnw) lnb_rows4(dyq, sq, mean_l, rstd_l, cst, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_fo, nullptr, dsr, Ah, Al, lnred2);
+  zero_pad_columns<RT>(Hh, Hl, ntH, tid);                      // columns 16 ntH .. KPH of the du planes (linear1' reduces over KPH)
   EFSTAMP(2);
   lds_barrier();
   EFSTAMP(3);
@@ -635,82 +672,109 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
     const int col = i < D ? i : KPD + (i - D);
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < 2 * NPASS; ++w) v += lnred[w * 2 * KPD + col];
+    for (int w = 0; w < 2 * NPASS; ++w) v += lnred2[w * 2 * KPD + col];
     a.part2[(long)blockIdx.x * 2 * D + i] = v;
   }
-  if (a.xt_df) export_tiles<RT>(Ah, Al, LDD, a.xt_df, ntD, m0, M, wave, lane);
-  // ---- du = (df W2) gated by h > 0, * keep ----
-  {
-    f32x4 acc[RT];
-    mma<KCD, RT>(acc, Ah, Al, LDD, pw, lane, a.one);
-    for (int t0 = EF_WV; t0 < ntH + EF_WV; t0 += EF_WV) {       // second-round tiles: one batch of requests, see the forward chain
-      const bool more = t0 + wave < ntH;                       // wave-uniform
-      f32x4 prev[RT];
+  // the FFN hidden's gate (h > 0) for this wave's column tile, in the accumulator layout of the product that consumes it (lane: row
+  // 16 rt + i, column quad 4 j + G): requested here (behind LayerNorm2', whose registers are free again), consumed behind the
+  // product; a second tile's gates are requested behind the first tile's epilogue, into the same registers.  UNCONDITIONAL from
+  // clamped addresses (rows >= M have a zero gradient): a conditional load is a phi of {0, value} and the compiler waited for each
+  // one right behind its request
+  const int G = lane >> 4, i16 = lane & 15;
+  float4 hv[LEAN ? 1 : RT]; uint8_t hb[LEAN ? RT : 1];
+  auto load_gates = [&](int j) {
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) prev[rt] = acc[rt];
-      __builtin_amdgcn_sched_barrier(0);
-      if (more) load_panel<KCD>(pw, a.W2t, ntH, t0 + wave, lane);
-      __builtin_amdgcn_sched_barrier(0);
-      if (t0 - EF_WV + wave < ntH) to_stage<RT>(stage, prev, t0 - EF_WV + wave, lane);
-      if (more) mma<KCD, RT>(acc, Ah, Al, LDD, pw, lane, a.one);
+    for (int rt = 0; rt < RT; ++rt) {
+      const long row = min(m0 + 16 * rt + i16, M - 1);
+      const int q = min(4 * j + G, (H >> 2) - 1);
+      if (LEAN) hb[rt] = a.hgate[row * (H >> 2) + q];
+      else hv[rt] = *reinterpret_cast<const float4*>(a.h + row * H + 4 * q);
     }
-  }
-  EFSTAMP(4);
-  lds_barrier();                                               // stage complete; everybody is done with lnred (it lives in the du planes)
-  EFSTAMP(5);
-  Panel<KCH> p1;
-  // first half of linear1^T's reduction now, the rest behind the gate epilogue (the tall variant has no registers to carry a
-  // half panel through that epilogue: it requests the whole panel afterwards)
-  if constexpr (RT == 2) load_panel<KCH, 0, 5>(p1, a.W1t, ntD, wave, lane);
+  };
+  load_gates(wave);
+  if (a.xt_df) export_tiles<RT>(Ah, Al, LDD, a.xt_df, ntD, m0, M, wave, lane);
+  // ---- du = (df W2) gated by h > 0, * keep: the gate runs on the ACCUMULATORS (a lane holds a column quad of a row, see mma) and
+  // writes the split planes directly -- no fp32 stage, no barrier between product and epilogue (see the forward chain's h_epilogue) ----
+  Panel<KCH> p1;                                               // linear1^T streams in under the (last) epilogue
+  // its 72 registers in parts (see the forward chain): steps [0, PS) under the epilogue, [PS, PS2) behind it, and -- tall variant, whose
+  // product runs at the register limit (72 + 12 accumulator + 24 fragment registers) -- [PS2, KCH) INSIDE the product, once two steps
+  // are consumed: five steps of three waves' MFMAs (~2 k cycles) cover their way from L2
+  constexpr int PS = (RT >= 3 && !LEAN) ? 3 : 5, PS2 = RT >= 3 ? 7 : KCH;    // (fp32 gates take 9 registers more than gate bytes)
   {
     const float ks = a.p > 0.f ? inv_keep : 1.0f;
+    auto du_epilogue = [&](const f32x4 (&acc)[RT], int j) {
+      const int n = 16 * j + 4 * G;                            // < KPH
 #pragma unroll
-    for (int it = 0; it < HIT; ++it) {
-      const int e = tid + it * EF_THR;
-      const int rl = e / hq, q = e - rl * hq;
-      if (rl < ROWS) {
+      for (int rt = 0; rt < RT; ++rt) {
+        const int rl = 16 * rt + i16;
         float4 o = zero4;
-        if (4 * q < H) {
-          const float4 s4 = *reinterpret_cast<const float4*>(stage + rl * STG + 4 * q);
-          if (LEAN)
-            o = make_float4((hb[it] & 1) ? s4.x * ks : 0.f, (hb[it] & 2) ? s4.y * ks : 0.f, (hb[it] & 4) ? s4.z * ks : 0.f,
-                            (hb[it] & 8) ? s4.w * ks : 0.f);
-          else
-            o = make_float4(hv[it].x > 0.f ? s4.x * ks : 0.f, hv[it].y > 0.f ? s4.y * ks : 0.f, hv[it].z > 0.f ? s4.z * ks : 0.f,
-                            hv[it].w > 0.f ? s4.w * ks : 0.f);
+        if (n < H) {
+          if (LEAN) {
+            const uint8_t b = hb[rt];
+            o = make_float4((b & 1) ? acc[rt][0] * ks : 0.f, (b & 2) ? acc[rt][1] * ks : 0.f, (b & 4) ? acc[rt][2] * ks : 0.f,
+                            (b & 8) ? acc[rt][3] * ks : 0.f);
+          } else {
+            const float4 h4 = hv[rt];
+            o = make_float4(h4.x > 0.f ? acc[rt][0] * ks : 0.f, h4.y > 0.f ? acc[rt][1] * ks : 0.f, h4.z > 0.f ? acc[rt][2] * ks : 0.f,
+                            h4.w > 0.f ? acc[rt][3] * ks : 0.f);
+          }
         }
-        split_store4(Hh + rl * LDH + 4 * q, Hl + rl * LDH + 4 * q, o);
+        split_store4(Hh + rl * LDH + n, Hl + rl * LDH + n, o);
       }
+    };
+    f32x4 acc[RT];
+    mma<KCD, RT>(acc, Ah, Al, LDD, pw, lane, a.one);           // column tile `wave` (every wave has one: nhid > 256)
+    const bool more = __builtin_amdgcn_readfirstlane(EF_WV + wave) < ntH;   // scalar condition: one of the two panels is live, not both
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) {                                                // two straight-line paths: see the forward chain
+      load_panel<KCD>(pw, a.W2t, ntH, EF_WV + wave, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      du_epilogue(acc, wave);
+      __builtin_amdgcn_sched_barrier(0);
+      load_gates(EF_WV + wave);
+      __builtin_amdgcn_sched_barrier(0);
+      mma<KCD, RT>(acc, Ah, Al, LDD, pw, lane, a.one);
+      __builtin_amdgcn_sched_barrier(0);
+      load_panel<KCH, 0, PS>(p1, a.W1t, ntD, wave, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      du_epilogue(acc, EF_WV + wave);
+    } else {
+      load_panel<KCH, 0, PS>(p1, a.W1t, ntD, wave, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      du_epilogue(acc, wave);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    load_panel<KCH, PS, PS2>(p1, a.W1t, ntD, wave, lane);      // (tall variant: the last two steps inside the product, below)
   }
-  // LayerNorm1's saved rows and the residual-branch gradient ds2 (read back by the thread that stored it): requested here,
-  // consumed after the next product
-  float4 rq[LNQ];
+  // LayerNorm1's saved rows: requested here (the tall variant: inside the next product, once four reduction steps of its 72-register
+  // panel are consumed -- carried through the whole product they spilled), consumed after the product
   auto load_ln1 = [&]() {
     load_stats(a.st1);
 #pragma unroll
-    for (int k = 0; k < LNQ; ++k) { sq[k] = zero4; rq[k] = zero4; }
-    if (lnw) { ln_load3(sq, a.s1, D, m0, M, wave, lane); ln_load3(rq, a.ds2, D, m0, M, wave, lane); }   // ds2: read back by the lane that stored it
+    for (int k = 0; k < LNQ; ++k) sq[k] = zero4;
+    if (lnw) ln_load3(sq, a.s1, D, m0, M, wave, lane);
   };
-  // (the tall variant cannot carry these 30 registers through the next product beside the 72-register panel: they spilled,
-  // 41 MB of scratch traffic per launch; it requests them behind the product)
   if constexpr (RT < 3) load_ln1();
-  if constexpr (RT == 2) load_panel<KCH, 5, KCH>(p1, a.W1t, ntD, wave, lane);
-  else load_panel<KCH>(p1, a.W1t, ntD, wave, lane);
-  EFSTAMP(6);
-  lds_barrier();
-  EFSTAMP(7);
+  EFSTAMP(4);
+  lds_barrier();                                               // du planes complete; everybody is done with the stage (lnred2)
+  EFSTAMP(5);
   if (a.xt_du) export_tiles<RT>(Hh, Hl, LDH, a.xt_du, ntH, m0, M, wave, lane);
   // ---- dx1 = du W1 + ds2 ----
   if (wave < ntD) {
     f32x4 acc[RT];
-    mma<KCH, RT>(acc, Hh, Hl, LDH, p1, lane, a.one);
+    if constexpr (RT >= 3) {
+      auto rest = [&]() { load_panel<KCH, PS2, KCH>(p1, a.W1t, ntD, wave, lane); };
+      mma<KCH, RT, 1, decltype(rest), 3, decltype(load_ln1)>(acc, Hh, Hl, LDH, p1, lane, a.one, rest, load_ln1);
+    } else {
+      mma<KCH, RT>(acc, Hh, Hl, LDH, p1, lane, a.one);
+    }
     to_stage<RT>(stage, acc, wave, lane);
+  } else if constexpr (RT >= 3) {
+    load_ln1();
   }
-  if constexpr (RT >= 3) load_ln1();
-  EFSTAMP(8);
-  lds_barrier();                                               // stage complete; the du planes are dead (lnred may be rewritten)
-  EFSTAMP(9);
+  EFSTAMP(6);
+  lds_barrier();                                               // stage complete; the du planes are dead (lnred1 may be written)
+  EFSTAMP(7);
   Panel<KCD> po;
   load_panel<KCD>(po, a.Wot, ntD, wave, lane);
   if (lnw) {
@@ -721,40 +785,36 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
       dyq[k] = zero4;
       if (cq < D && m0 + rl < M) {
         const float4 t = *reinterpret_cast<const float4*>(stage + rl * STG + cq);
-        dyq[k] = make_float4(t.x + rq[k].x, t.y + rq[k].y, t.z + rq[k].z, t.w + rq[k].w);
+        const float4 r4 = *reinterpret_cast<const float4*>(dsr + rl * KPD + cq);   // ds2: this lane's own copy
+        dyq[k] = make_float4(t.x + r4.x, t.y + r4.y, t.z + r4.z, t.w + r4.w);
       }
     }
-    lnb_rows4(dyq, sq, mean_l, rstd_l, cst + KPD, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_ao, a.ds1, Ah, Al, lnred);
+    lnb_rows4(dyq, sq, mean_l, rstd_l, cst + KPD, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_ao, a.ds1, nullptr, Ah, Al, lnred1);
   }
-  EFSTAMP(10);
+  EFSTAMP(8);
   lds_barrier();
-  EFSTAMP(11);
+  EFSTAMP(9);
   for (int i = tid; i < 2 * D; i += EF_THR) {
     const int col = i < D ? i : KPD + (i - D);
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < 2 * NPASS; ++w) v += lnred[w * 2 * KPD + col];
+    for (int w = 0; w < 2 * NPASS; ++w) v += lnred1[w * 2 * KPD + col];
     a.part1[(long)blockIdx.x * 2 * D + i] = v;
   }
   if (a.xt_dout) export_tiles<RT>(Ah, Al, LDD, a.xt_dout, ntD, m0, M, wave, lane);
-  // ---- d attn = dout Wo ----
+  // ---- d attn = dout Wo: straight from the accumulators (a lane holds four consecutive columns of a row: one 16-byte store; the 16
+  // lanes of a group write 64 contiguous bytes of 16 rows, the neighbouring column tile's wave the other half of each line) ----
   if (wave < ntD) {
     f32x4 acc[RT];
     mma<KCD, RT>(acc, Ah, Al, LDD, po, lane, a.one);
-    to_stage<RT>(stage, acc, wave, lane);
-  }
-  EFSTAMP(12);
-  lds_barrier();
-  EFSTAMP(13);
-  {
-    const int qpr = D >> 2;
-    for (int e = tid; e < ROWS * qpr; e += EF_THR) {
-      const int rl = e / qpr, q = e - rl * qpr;
-      if (m0 + rl < M)
-        *reinterpret_cast<float4*>(a.da + (long)(m0 + rl) * D + 4 * q) = *reinterpret_cast<const float4*>(stage + rl * STG + 4 * q);
+    const int c = 16 * wave + 4 * G;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const long m = m0 + 16 * rt + i16;
+      if (m < M && c < D) *reinterpret_cast<f32x4*>(a.da + m * D + c) = acc[rt];
     }
   }
-  EFSTAMP(14);
+  EFSTAMP(10);
 }
 
 // Workgroups >= nmain are RIDERS (rd_trailing.h): they run a parked trailing launch -- the head's weight-gradient tiles, the
@@ -762,7 +822,7 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
 template <int DC, int HC, bool LEAN>
 __global__ __launch_bounds__(EF_THR) void k_enc_pre_bwd(PreBwdArgs a, RiderArgs rider, int nmain) {
   extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
-  RD_TOUCH_CODE(40960);                                  // own code -> L2, the riders' bodies included (smallest instantiation: 41.9 KB)
+  RD_TOUCH_CODE(43008);                                  // own code -> L2, the riders' bodies included (smallest instantiation: 43.9 KB)
   if ((int)blockIdx.x >= nmain) { rider_body(rider, (int)blockIdx.x - nmain, esm); return; }
   int M = a.M;
   if (a.mlive) M = min(M, __builtin_amdgcn_readfirstlane(*a.mlive));
@@ -779,8 +839,10 @@ static int ef_specialize(int D, int H) {
 }
 
 constexpr size_t pre_bwd_lds(int rt) {
-  return (size_t)2 * 16 * rt * LDD * 2 + (size_t)2 * 16 * rt * LDH * 2 + (size_t)16 * rt * STG * 4 + (size_t)2 * KPD * 4;
+  return (size_t)2 * 16 * rt * LDD * 2 + (size_t)2 * 16 * rt * LDH * 2 + (size_t)16 * rt * STG * 4 + (size_t)2 * KPD * 4 +
+         (size_t)16 * rt * KPD * 4;
 }
+static_assert(pre_bwd_lds(EF_RTMAX) <= 160 * 1024, "one workgroup's LDS");
 
 int device_cus() {
   static const int n = [] {
@@ -855,9 +917,10 @@ int launch_enc_pre_bwd(long M, int D, int H, const float* dy, const float* s2, c
   a.ds2 = ds2; a.ds1 = ds1; a.da = da; a.part2 = part2; a.part1 = part1;
   a.xt_df = (__bf16*)xt_df; a.xt_du = (__bf16*)xt_du; a.xt_dout = (__bf16*)xt_dout;
   a.M = (int)M; a.D = D; a.H = H; a.ncu = ef_ncu(); a.p = p; a.seed = seed; a.site_fo = site_fo; a.site_ao = site_ao;
-  a.seed_cell = seed_cell(); a.mlive = mlive; a.one = precision() == RD_PREC_BF16; a.stamps = g_ef_stamps;
+  a.seed_cell = seed_cell(); a.mlive = mlive; a.one = precision() == RD_PREC_BF16;
+  a.stamps = g_ef_stamps ? g_ef_stamps + 4096 : nullptr;   // debug: the backward chain's stamps behind the forward chain's (8192 words)
   constexpr size_t lds = pre_bwd_lds(EF_RTMAX);
-  static_assert(lds >= 4 * HW_GROUP_LDS, "the riders' LDS must fit the chain's");
+  static_assert(lds >= 4 * HW_GROUP_LDS, "the riders' LDS must fit the chain's");   // (otherwise: launch with the larger of the two)
   const int spec = ef_specialize(D, H);
   a.hgate = (const uint8_t*)hgate;
   const RiderArgs rider = trailing_take();             // a parked trailing launch (or kind 0) rides in this one

@@ -19,11 +19,11 @@ shp = _lib.shape(B, T, F, 4, nhead=2, nhid=nhid)
 dy = torch.randn(T, B, D, device=dev)
 for _ in range(3):
     y = ops.encoder_layer(x, mask, shp, 0, 0.2, 5, pd); y.backward(dy)
-stamps = torch.zeros(16 * 16, dtype=torch.int64, device=dev)
+stamps = torch.zeros(8192, dtype=torch.int64, device=dev)      # forward chain [0, 4096), backward chain [4096, 8192)
 
 
-def show(tag, n):
-    s = stamps.cpu().view(16, 16)
+def show(tag, n, off=0):
+    s = stamps.cpu()[off:off + 256].view(16, 16)
     t0 = int(s[:, 0].min())
     print(tag, "cycles since the first wave started: min .. max over the 16 waves")
     for i in range(n):
@@ -39,4 +39,4 @@ stamps.zero_()
 y.backward(dy)
 torch.cuda.synchronize()
 lib.rd_debug_set_encfuse_stamps(None)
-show("pre_bwd", 16)
+show("pre_bwd", 16, 4096)
