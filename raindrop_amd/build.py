@@ -30,7 +30,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # a load past the end of the last kernel of a code object is a memory fault -- so the build itself checks them against the linked
 # library (check_code_touch, called by build() and build_variant()) and FAILS on violation; tests/test_kernel_resources.py re-checks.
 CODE_TOUCH = [("k_msg_fwd_fused", 12544), ("k_msg_bwd_fused", 9728), ("k_attn_fwd_fused", 12800), ("k_attn_bwd_fused", 28672),
-              ("k_enc_post_fwd", 40960), ("k_enc_pre_bwd", 43008), ("4k_dwE", 6144), ("k_dw_reduce", 9216), ("6k_adam", 2432), ("10k_adam_dev", 2432),
+              ("k_enc_post_fwd", 40960), ("k_enc_pre_bwd", 44032), ("4k_dwE", 6144), ("k_dw_reduce", 9216), ("6k_adam", 2432), ("10k_adam_dev", 2432),
               ("k_wsplit", 4096), ("5k_twgI", 7936), ("k_head_rowsILi1ELi12ELi3E", 14848), ("k_head_rowsILi1ELi16ELi4E", 16384)]
 # the kernels outside the P19 step (RD_TOUCH_CODE_X)
 CODE_TOUCH_X = [("6k_gemmI", 25088), ("13k_gemm_bf16x3I", 28160), ("12k_gemm_panelI", 28160), ("9k_rowgemmI", 4096),

@@ -208,6 +208,30 @@ __device__ __forceinline__ void zero_pad_columns(__bf16* Hh, __bf16* Hl, int ntH
   }
 }
 
+// Dropout keep bits of a LayerNorm epilogue, made by the waves that IDLE in the phase before it -- the six waves without a column tile
+// while the other ten run a D-wide product (out_proj, linear2, linear1'), the waves without a LayerNorm pass while the others wait
+// for their rows at the start of the backward chain -- instead of inside the LayerNorm passes, which are bound by the vector ALUs
+// (three Threefry calls = 141 of a pass's ~450 vector instructions, three waves per SIMD in a pass).  Used where the phase before is
+// long enough to hide ~100 instructions per quad on two helper waves per SIMD: LayerNorm2 (behind linear2, 7.5 k cycles) and
+// LayerNorm1' (behind linear1', 7.5 k).  Measured slower, and therefore still Threefry calls inside the pass: LayerNorm1 (out_proj
+// is 4.1 k cycles: +1.2 k there for 0.9 k), LayerNorm2' (nothing in front of it but the first phase's wait for the rows: +3.9 k for
+// 1.8 k by the four pass-less waves); all of a kernel's dropout decisions by all waves in its first phase: +7.4 k for 5.6 k.
+// mk: [16 RT rows][MKQ] bytes, bit c of byte q = element 4 q + c of the row is kept (same quads, same comparison as
+// uniform4(..) >= p: the masks, and with them every result, are unchanged); idx / nthr: this thread's index among the helpers.
+constexpr int MKQ = KPD / 4;                          // mask bytes per row (one per column quad, D <= KPD)
+// NW: helper waves (idx = 0 .. 64 NW - 1).  A rolled loop, one quad per trip: four quads per trip as independent straight-line chains
+// (to hide a lone wave's dependent-issue latency) measured SLOWER -- the helpers are bound by vector-ALU throughput (~100
+// instructions per quad with the index arithmetic), and the fixed trip count added wasted quads.
+template <int RT, int NW>
+__device__ __forceinline__ void drop_masks(uint8_t* mk, uint64_t seed, uint32_t site, int D, int m0, float p, int idx) {
+  const int qpr = D >> 2, per = 16 * RT * qpr;
+  for (int e = idx; e < per; e += 64 * NW) {
+    const int r = e / qpr, q = e - r * qpr;
+    const float4 v = uniform4(seed, site, (uint64_t)(m0 + r) * qpr + q);
+    mk[r * MKQ + q] = (uint8_t)((v.x >= p ? 1 : 0) | (v.y >= p ? 2 : 0) | (v.z >= p ? 4 : 0) | (v.w >= p ? 8 : 0));
+  }
+}
+
 __device__ __forceinline__ float wsum(float v) { return wave_sum64_dpp(v); }
 
 static unsigned long long* g_ef_stamps = nullptr;    // debug (tools/encfuse_timing.py): clock64 per phase, every wave of workgroup 0
@@ -277,9 +301,11 @@ __device__ __forceinline__ void ln_load3(float4 (&r)[LNQ], const float* src, int
 // statistics; normalised rows also go to the split planes (Ph != null; zeros beyond D / M: the next product reads them) and, as fp32,
 // to `keep` ([rows][KPD] in LDS; null: not wanted).
 // bs / gg / bb: the bias, gamma, beta vectors in LDS (zero padded to KPD).
+// PRE: the dropout keep bits come from mk (drop_masks); otherwise from Threefry calls here (seed, site).
+template <bool PRE>
 __device__ __forceinline__ void ln_rows4(const float* stage, const float4 (&res)[LNQ], const float* bs, const float* gg, const float* bb, int D,
-                                         int m0, int M, int wave, int lane, float p, float inv_keep, uint64_t seed, uint32_t site,
-                                         float* s_out, float* y_out, float* stats, __bf16* Ph, __bf16* Pl, float* keep = nullptr) {
+                                         int m0, int M, int wave, int lane, float p, float inv_keep, const uint8_t* mk, uint64_t seed,
+                                         uint32_t site, float* s_out, float* y_out, float* stats, __bf16* Ph, __bf16* Pl, float* keep = nullptr) {
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const int g = lane >> 4, i16 = lane & 15, rl = 4 * wave + g;
   const long m = m0 + rl;
@@ -296,10 +322,16 @@ __device__ __forceinline__ void ln_rows4(const float* stage, const float4 (&res)
       const float4 b4 = *reinterpret_cast<const float4*>(bs + c);
       t.x += b4.x; t.y += b4.y; t.z += b4.z; t.w += b4.w;
     }
-    if (p > 0.f) {
-      const float4 u = uniform4(seed, site, ((uint64_t)m * D + c) >> 2);
-      t.x *= u.x >= p ? inv_keep : 0.f; t.y *= u.y >= p ? inv_keep : 0.f;
-      t.z *= u.z >= p ? inv_keep : 0.f; t.w *= u.w >= p ? inv_keep : 0.f;
+    if (p > 0.f && c < D) {
+      if constexpr (PRE) {                            // keep bits made by the idle waves of the phase before (drop_masks)
+        const unsigned kb = mk[rl * MKQ + (c >> 2)];
+        t.x *= (kb & 1) ? inv_keep : 0.f; t.y *= (kb & 2) ? inv_keep : 0.f;
+        t.z *= (kb & 4) ? inv_keep : 0.f; t.w *= (kb & 8) ? inv_keep : 0.f;
+      } else {
+        const float4 u = uniform4(seed, site, ((uint64_t)m * D + c) >> 2);
+        t.x *= u.x >= p ? inv_keep : 0.f; t.y *= u.y >= p ? inv_keep : 0.f;
+        t.z *= u.z >= p ? inv_keep : 0.f; t.w *= u.w >= p ? inv_keep : 0.f;
+      }
     }
     sv[k] = zero4;
     if (ok) {
@@ -348,13 +380,14 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
   __bf16* Hh = Al + ROWS * LDD;                                // [ROWS][LDH]: h
   __bf16* Hl = Hh + ROWS * LDH;
   float* stage = reinterpret_cast<float*>(Hl + ROWS * LDH);    // [ROWS][STG]
-  // per-column vectors [bo | g1 | be1 | b2 | g2 | be2] (KPD each) and b1 (KPH), zero padded: fetched ONCE, first thing, so that no
-  // epilogue has a global load of its own -- those queue behind the weight panel requested just before them (loads return in order)
+  // per-column vectors [bo | g1 | be1 | b2 | g2 | be2] (KPD each) and b1 (KPH), zero padded: fetched ONCE, in the first phase, so that
+  // no epilogue has a global load of its own -- those queue behind the weight panel requested just before them (loads return in order)
   float* cst = stage + ROWS * STG;
   // x1 (LayerNorm1's output, the residual of LayerNorm2) as fp32 [ROWS][KPD]: written and read back by the SAME lane (pass layout), so
   // no barrier orders it.  Rounds 3-4 re-read it from memory (LEAN: the pre-norm sum, re-normalised); the stage of the nhid-wide
   // product that stood here is gone (h_epilogue).
   float* x1r = cst + 6 * KPD + KPH;
+  uint8_t* mk = reinterpret_cast<uint8_t*>(x1r + ROWS * KPD);  // dropout keep bits of LayerNorm2 (drop_masks: by idle waves)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: `if (wave < ..)` is a branch, not a mask
   const int m0 = blockIdx.x * ROWS;
   const int D = DC ? DC : a.D, H = HC ? HC : a.H;
@@ -368,15 +401,6 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   EFSTAMP(0);
   if (a.stamps && tid == 0) { a.stamps[256 + 2 * blockIdx.x] = wall_clock64(); a.stamps[256 + 2 * blockIdx.x + 1] = clock64(); }
-  {   // one masked load per vector and thread, each from ITS kernel argument: a per-lane select among the seven pointers made the
-      // compiler keep a pointer table in scratch (7 stores per lane at kernel entry = 10 MB of scratch writes per launch)
-    auto fetch = [&](const float* src, int lim, int base, int n) {
-      if (tid < n) { float val = 0.f; if (tid < lim) val = src[tid]; cst[base + tid] = val; }
-    };
-    fetch(a.bo, D, 0, KPD); fetch(a.g1, D, KPD, KPD); fetch(a.be1, D, 2 * KPD, KPD);
-    fetch(a.b2, D, 3 * KPD, KPD); fetch(a.g2, D, 4 * KPD, KPD); fetch(a.be2, D, 5 * KPD, KPD);
-    fetch(a.b1, H, 6 * KPD, KPH);
-  }
   zero_pad_columns<RT>(Hh, Hl, ntH, tid);                      // columns 16 ntH .. KPH of the h planes (linear2 reduces over KPH)
   // ---- attention rows -> split planes (zero padded to KPD columns, rows beyond M zero) ----
   constexpr int kq = KPD / 4;
@@ -391,20 +415,47 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
   }
   Panel<KCD> po;
   load_panel<KCD>(po, a.Wo, ntD, wave, lane);
+  // The per-column vectors, requested BEHIND the rows and the panel and written to LDS behind the row split (first read: LayerNorm1).
+  // 23 wave-wide slots of 64 elements -- 3 per D-wide vector, 5 for b1 --, wave w takes slot w and (w < 7) slot 16 + w: the vector of
+  // a slot is wave-uniform (scalar pointer select: a per-LANE select among the seven pointers became a pointer table in scratch),
+  // every load is unconditional from a clamped address.  Rounds 3-4 fetched them first thing, one vector after the other, each
+  // load waited for before its LDS store: four dependent round trips (the first one cold: ~2.6 k cycles, ~0.85 k each after
+  // that) in front of the row loads of waves 0-4, which every other wave then waited for at the first barrier.
+  float cval[2]; int cdst[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int sl = min(wave + 16 * r, 22);                     // scalar (round 2: waves 7 .. 15 repeat slot 22, not stored)
+    const int vec = sl < 18 ? sl / 3 : 6, part = sl < 18 ? sl - 3 * vec : sl - 18;
+    const float* src = vec == 0 ? a.bo : vec == 1 ? a.g1 : vec == 2 ? a.be1 : vec == 3 ? a.b2 : vec == 4 ? a.g2 : vec == 5 ? a.be2 : a.b1;
+    const int lim = vec < 6 ? D : H, n = vec < 6 ? KPD : KPH, e = 64 * part + lane;
+    cval[r] = src[min(e, lim - 1)];
+    if (e >= lim) cval[r] = 0.f;
+    cdst[r] = (e < n && wave + 16 * r <= 22) ? vec * KPD + e : -1;
+  }
   __builtin_amdgcn_sched_barrier(0);
   if (a.seed_cell) seed += load_uniform_u64(a.seed_cell);
+  // the second-round (tile, row tile) unit of this wave in the nhid-wide product, if any (see linear1 below)
+  const int unit = EF_WV - 1 - wave;                           // scalar
+  const bool more = unit < (ntH - EF_WV) * RT;                 // scalar
+  const int j2 = EF_WV + unit / RT, rt2 = unit - (unit / RT) * RT;
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int i = tid + it * EF_THR;
     const int r = i / kq, k = 4 * (i - r * kq);
     if (r < ROWS) split_store4(Ah + r * LDD + k, Al + r * LDD + k, v[it]);
   }
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+    if (cdst[r] >= 0) cst[cdst[r]] = cval[r];
   EFSTAMP(1);
   lds_barrier();
   EFSTAMP(2);
   if (a.xt_attn) export_tiles<RT>(Ah, Al, LDD, a.xt_attn, ntD, m0, M, wave, lane);
 
   // ---- out_proj ----
+  constexpr int HW0 = 10, NHW = EF_WV - HW0;                    // helper waves 10 .. 15: no column tile in a D-wide product (D <= 160)
+  const int hidx = (wave - HW0) * 64 + lane;
   if (wave < ntD) {
     f32x4 acc[RT];
     mma<KCD, RT>(acc, Ah, Al, LDD, po, lane, a.one);
@@ -420,7 +471,7 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
   Panel<KCD> p1;                                               // linear1 (column tiles 0..15) streams in under the LayerNorm epilogue
   load_panel<KCD, 0, KCD, true>(p1, a.W1, ntH, wave, lane);    // (requested BEHIND the barrier: issuing it blocks a wave for a while)
   // ---- + bias, dropout, + x, LayerNorm1 -> s1, x1 (global), x1 planes ----
-  if (lnw) ln_rows4(stage, xr, cst, cst + KPD, cst + 2 * KPD, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_ao, a.s1, LEAN ? nullptr : a.x1,
+  if (lnw) ln_rows4<false>(stage, xr, cst, cst + KPD, cst + 2 * KPD, D, m0, M, wave, lane, a.p, inv_keep, nullptr, seed, a.site_ao, a.s1, LEAN ? nullptr : a.x1,
                     a.st1, Ah, Al, x1r);
   EFSTAMP(5);
   lds_barrier();
@@ -434,50 +485,53 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
   Panel<KCH> p2;                                               // linear2 streams in under the (last) epilogue
   {
     const int G = lane >> 4, i16 = lane & 15, qpr = H >> 2;
-    auto h_epilogue = [&](const f32x4 (&acc)[RT], int j) {
+    auto h_epi1 = [&](const f32x4& acc, int j, int rt) {       // one row tile of column tile j
       const int n = 16 * j + 4 * G;                            // < KPH (j < 18)
       const float4 bs = *reinterpret_cast<const float4*>(cst + 6 * KPD + n);
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        const int rl = 16 * rt + i16, m = m0 + rl;
-        float4 o = zero4;
-        if (m < M && n < H) {
-          o = make_float4(fmaxf(acc[rt][0] + bs.x, 0.f), fmaxf(acc[rt][1] + bs.y, 0.f), fmaxf(acc[rt][2] + bs.z, 0.f), fmaxf(acc[rt][3] + bs.w, 0.f));
-          if (a.p > 0.f) {
-            const float4 u = uniform4(seed, a.site_fh, ((uint64_t)m * H + n) >> 2);
-            o.x = u.x >= a.p ? o.x * inv_keep : 0.f; o.y = u.y >= a.p ? o.y * inv_keep : 0.f;
-            o.z = u.z >= a.p ? o.z * inv_keep : 0.f; o.w = u.w >= a.p ? o.w * inv_keep : 0.f;
-          }
-          if (LEAN)
-            a.hgate[(long)m * qpr + (n >> 2)] = (uint8_t)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
-          else
-            *reinterpret_cast<float4*>(a.h + (long)m * H + n) = o;
+      const int rl = 16 * rt + i16, m = m0 + rl;
+      float4 o = zero4;
+      if (m < M && n < H) {
+        o = make_float4(fmaxf(acc[0] + bs.x, 0.f), fmaxf(acc[1] + bs.y, 0.f), fmaxf(acc[2] + bs.z, 0.f), fmaxf(acc[3] + bs.w, 0.f));
+        if (a.p > 0.f) {
+          const float4 u = uniform4(seed, a.site_fh, ((uint64_t)m * H + n) >> 2);
+          o.x = u.x >= a.p ? o.x * inv_keep : 0.f; o.y = u.y >= a.p ? o.y * inv_keep : 0.f;
+          o.z = u.z >= a.p ? o.z * inv_keep : 0.f; o.w = u.w >= a.p ? o.w * inv_keep : 0.f;
         }
-        split_store4(Hh + rl * LDH + n, Hl + rl * LDH + n, o);
+        if (LEAN)
+          a.hgate[(long)m * qpr + (n >> 2)] = (uint8_t)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
+        else
+          *reinterpret_cast<float4*>(a.h + (long)m * H + n) = o;
       }
+      split_store4(Hh + rl * LDH + n, Hl + rl * LDH + n, o);
+    };
+    auto h_epilogue = [&](const f32x4 (&acc)[RT], int j) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) h_epi1(acc[rt], j, rt);
     };
     f32x4 acc[RT];
     mma<KCD, RT>(acc, Ah, Al, LDD, p1, lane, a.one);           // column tile `wave` (every wave has one: nhid > 256)
-    // nhid > 256: the remaining column tiles (P19: tile 16, wave 0).  Their panel goes into the registers the first product has
-    // just released, as ONE batch of requests in front of the first tile's epilogue (left to itself the compiler trickled the ten
-    // loads in between the MFMAs, each with its own vmcnt(0) in front of the second product); a wave without a second tile
-    // requests linear2's panel there instead.
-    const bool more = __builtin_amdgcn_readfirstlane(EF_WV + wave) < ntH;   // scalar condition: one of the two panels is live, not both
-    __builtin_amdgcn_sched_barrier(0);
+    // nhid > 256: the column tiles beyond the 16th (P19: tile 16) are split into (tile, row tile) UNITS, one each for the LAST waves
+    // (P19, tall blocks: waves 15, 14, 13 -- which have no D-wide tile, no LayerNorm pass and therefore nothing else to carry).  A
+    // whole second tile on wave 0 (rounds 3-5) was 5 k cycles of product + epilogue that the other 15 waves spent at the barrier
+    // (stamps in the step: 23.3 k .. 28.5 k).  The unit's panel goes into the registers the first product has just released, as ONE
+    // batch of requests in front of the first tile's epilogue (which covers its way from L2); a wave without a unit requests the
+    // first part of linear2's panel there instead.
     // (linear2's 72-register panel in two parts: steps 0 .. PS - 1 travel under the epilogue, the rest is requested behind it --
     // whole, it spilled 24-32 registers across the epilogue; the product consumes the steps in order, PS of them cover the rest)
     constexpr int PS = 5;
+    // (`more` is a scalar condition: one of the two panels is live, not both)
     // (two straight-line paths, not `if (more) request A else request B` + a common epilogue: behind that join the register
     // allocator kept BOTH panels' registers apart -- 112 registers for one live panel)
     if (more) {
-      load_panel<KCD>(p1, a.W1, ntH, EF_WV + wave, lane);
+      load_panel<KCD>(p1, a.W1, ntH, j2, lane);
       __builtin_amdgcn_sched_barrier(0);
       h_epilogue(acc, wave);
-      mma<KCD, RT>(acc, Ah, Al, LDD, p1, lane, a.one);
+      f32x4 acc1[1];
+      mma<KCD, 1>(acc1, Ah + rt2 * 16 * LDD, Al + rt2 * 16 * LDD, LDD, p1, lane, a.one);
       __builtin_amdgcn_sched_barrier(0);
       load_panel<KCH, 0, PS>(p2, a.W2, ntD, wave, lane);
       __builtin_amdgcn_sched_barrier(0);
-      h_epilogue(acc, EF_WV + wave);
+      h_epi1(acc1[0], j2, rt2);
     } else {
       load_panel<KCH, 0, PS>(p2, a.W2, ntD, wave, lane);
       __builtin_amdgcn_sched_barrier(0);
@@ -491,11 +545,13 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
   EFSTAMP(8);
   if (a.xt_h) export_tiles<RT>(Hh, Hl, LDH, a.xt_h, ntH, m0, M, wave, lane);
 
-  // ---- linear2 ----
+  // ---- linear2; LayerNorm2's dropout decisions by the waves without a column tile ----
   if (wave < ntD) {
     f32x4 acc[RT];
     mma<KCH, RT>(acc, Hh, Hl, LDH, p2, lane, a.one);
     to_stage<RT>(stage, acc, wave, lane);
+  } else if (a.p > 0.f && wave >= HW0) {
+    drop_masks<RT, NHW>(mk, seed, a.site_fo, D, m0, a.p, hidx);
   }
   EFSTAMP(9);
   lds_barrier();
@@ -510,7 +566,7 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
       if (c < KPD) xr[k] = *reinterpret_cast<const float4*>(x1r + rl * KPD + c);
     }
   }
-  if (lnw) ln_rows4(stage, xr, cst + 3 * KPD, cst + 4 * KPD, cst + 5 * KPD, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_fo, a.s2, a.y, a.st2,
+  if (lnw) ln_rows4<true>(stage, xr, cst + 3 * KPD, cst + 4 * KPD, cst + 5 * KPD, D, m0, M, wave, lane, a.p, inv_keep, mk, 0, 0, a.s2, a.y, a.st2,
                     nullptr, nullptr);
   EFSTAMP(11);
   if (a.stamps && tid == 0) { a.stamps[256 + 1024 + 2 * blockIdx.x] = wall_clock64(); a.stamps[256 + 1024 + 2 * blockIdx.x + 1] = clock64(); }
@@ -519,7 +575,7 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
 template <int DC, int HC, bool LEAN>
 __global__ __launch_bounds__(EF_THR) void k_enc_post_fwd(PostFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
-  RD_TOUCH_CODE(40960);                                  // own code -> L2 (rd_common.h; the smallest instantiation is 41.8 KB)
+  RD_TOUCH_CODE(40960);                                  // own code -> L2 (rd_common.h; the smallest instantiation is 43.5 KB)
   int M = a.M;
   if (a.mlive) M = min(M, __builtin_amdgcn_readfirstlane(*a.mlive));
   if (pick_rt(M, a.ncu) == 3) post_fwd_body<3, DC, HC, LEAN>(a, esm, M);
@@ -528,7 +584,7 @@ __global__ __launch_bounds__(EF_THR) void k_enc_post_fwd(PostFwdArgs a) {
 
 constexpr size_t post_fwd_lds(int rt) {
   return (size_t)2 * 16 * rt * LDD * 2 + (size_t)2 * 16 * rt * LDH * 2 + (size_t)16 * rt * STG * 4 + (size_t)(6 * KPD + KPH) * 4 +
-         (size_t)16 * rt * KPD * 4;
+         (size_t)16 * rt * KPD * 4 + (size_t)16 * rt * MKQ;
 }
 static_assert(post_fwd_lds(EF_RTMAX) <= 160 * 1024, "one workgroup's LDS");
 
@@ -557,9 +613,11 @@ struct PreBwdArgs {
 // `keep` (fp32 [rows][KPD] in LDS, read back by the same lane; only the quads below K of live rows are written), the dropout-masked ones
 // (what the next product consumes) as split planes, and this pass's dgamma | dbeta partials, summed over row pairs in registers
 // (rowpair_sum), into lnred[2 wave + (g >> 1)].  Same arithmetic as k_rowgemm<.., LNB> (rd_rowgemm.hip) up to the order of the sums.
+// PRE: the dropout keep bits come from mk (drop_masks); otherwise from Threefry calls here (seed, site).
+template <bool PRE>
 __device__ __forceinline__ void lnb_rows4(const float4 (&dyq)[LNQ], const float4 (&sq)[LNQ], float mean, float rstd, const float* gg, int K,
-                                          int m0, int M, int wave, int lane, float p, float inv_keep, uint64_t seed, uint32_t site,
-                                          float* ds_glob, float* keep, __bf16* Ph, __bf16* Pl, float* lnred) {
+                                          int m0, int M, int wave, int lane, float p, float inv_keep, const uint8_t* mk, uint64_t seed,
+                                          uint32_t site, float* ds_glob, float* keep, __bf16* Ph, __bf16* Pl, float* lnred) {
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const int g = lane >> 4, i16 = lane & 15, rl = 4 * wave + g;
   const long row = m0 + rl;
@@ -591,9 +649,15 @@ __device__ __forceinline__ void lnb_rows4(const float4 (&dyq)[LNQ], const float4
       if (keep) *reinterpret_cast<float4*>(keep + rl * KPD + c) = v;
       dr = v;
       if (p > 0.f) {
-        const float4 u = uniform4(seed, site, ((uint64_t)row * K + c) >> 2);
-        dr.x *= u.x >= p ? inv_keep : 0.f; dr.y *= u.y >= p ? inv_keep : 0.f;
-        dr.z *= u.z >= p ? inv_keep : 0.f; dr.w *= u.w >= p ? inv_keep : 0.f;
+        if constexpr (PRE) {                          // keep bits made by the idle waves of the phase before (drop_masks)
+          const unsigned kb = mk[rl * MKQ + (c >> 2)];
+          dr.x *= (kb & 1) ? inv_keep : 0.f; dr.y *= (kb & 2) ? inv_keep : 0.f;
+          dr.z *= (kb & 4) ? inv_keep : 0.f; dr.w *= (kb & 8) ? inv_keep : 0.f;
+        } else {
+          const float4 u = uniform4(seed, site, ((uint64_t)row * K + c) >> 2);
+          dr.x *= u.x >= p ? inv_keep : 0.f; dr.y *= u.y >= p ? inv_keep : 0.f;
+          dr.z *= u.z >= p ? inv_keep : 0.f; dr.w *= u.w >= p ? inv_keep : 0.f;
+        }
       }
     }
     if (c < KPD) split_store4(Ph + rl * LDD + c, Pl + rl * LDD + c, dr);
@@ -620,6 +684,7 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   // ds2 (gradient of LayerNorm2's input: the residual branch around the FFN) as fp32 [ROWS][KPD]: written by LayerNorm2' and read back
   // by the same lane in front of LayerNorm1' -- it never leaves the CU (rounds 3-4: a 5-MB round trip through memory per layer)
   float* dsr = cst + 2 * KPD;
+  uint8_t* mk = reinterpret_cast<uint8_t*>(dsr + ROWS * KPD);  // dropout keep bits of LayerNorm1' (drop_masks: by idle waves)
   // [2 NPASS row pairs][2 KPD] dgamma | dbeta partials of one LayerNorm.  LayerNorm2's live in the (then idle) stage; LayerNorm1's alias
   // the du planes, which are dead by then (both uses are closed by a barrier before / after the memory is reused)
   float* lnred2 = stage;
@@ -639,11 +704,6 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   const float inv_keep = 1.0f / (1.0f - a.p);
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   EFSTAMP(0);
-  if (tid < KPD) {                                             // each vector from its own kernel argument (no pointer select)
-    float v2 = 0.f, v1 = 0.f;
-    if (tid < D) { v2 = a.g2[tid]; v1 = a.g1[tid]; }
-    cst[tid] = v2; cst[KPD + tid] = v1;
-  }
   // ---- rows of dy, s2 and their statistics, in the LayerNorm pass layout (four rows per wave, waves 0 .. NPASS - 1) ----
   constexpr int NPASS = 4 * RT;
   const bool lnw = wave < NPASS;
@@ -659,11 +719,15 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   load_stats(a.st2);
   Panel<KCD> pw;
   load_panel<KCD, 0, KCD, true>(pw, a.W2t, ntH, wave, lane);
+  // the two gamma vectors: requested BEHIND the rows (rounds 3-4: in front of them and waited for -- a second cold round trip in
+  // front of the LayerNorm waves' row loads), unconditional from clamped addresses, each from its own kernel argument
+  float gv2 = a.g2[min(tid, D - 1)], gv1 = a.g1[min(tid, D - 1)];
   __builtin_amdgcn_sched_barrier(0);
   if (a.seed_cell) seed += load_uniform_u64(a.seed_cell);
+  if (tid < KPD) { cst[tid] = tid < D ? gv2 : 0.f; cst[KPD + tid] = tid < D ? gv1 : 0.f; }
   lds_barrier();                                               // cst visible
   EFSTAMP(1);
-  if (lnw) lnb_rows4(dyq, sq, mean_l, rstd_l, cst, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_fo, nullptr, dsr, Ah, Al, lnred2);
+  if (lnw) lnb_rows4<false>(dyq, sq, mean_l, rstd_l, cst, D, m0, M, wave, lane, a.p, inv_keep, nullptr, seed, a.site_fo, nullptr, dsr, Ah, Al, lnred2);
   zero_pad_columns<RT>(Hh, Hl, ntH, tid);                      // columns 16 ntH .. KPH of the du planes (linear1' reduces over KPH)
   EFSTAMP(2);
   lds_barrier();
@@ -677,67 +741,68 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   }
   // the FFN hidden's gate (h > 0) for this wave's column tile, in the accumulator layout of the product that consumes it (lane: row
   // 16 rt + i, column quad 4 j + G): requested here (behind LayerNorm2', whose registers are free again), consumed behind the
-  // product; a second tile's gates are requested behind the first tile's epilogue, into the same registers.  UNCONDITIONAL from
+  // product; a second-round unit's gate is requested behind the first tile's epilogue, into the same registers.  UNCONDITIONAL from
   // clamped addresses (rows >= M have a zero gradient): a conditional load is a phi of {0, value} and the compiler waited for each
   // one right behind its request
   const int G = lane >> 4, i16 = lane & 15;
   float4 hv[LEAN ? 1 : RT]; uint8_t hb[LEAN ? RT : 1];
-  auto load_gates = [&](int j) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const long row = min(m0 + 16 * rt + i16, M - 1);
-      const int q = min(4 * j + G, (H >> 2) - 1);
-      if (LEAN) hb[rt] = a.hgate[row * (H >> 2) + q];
-      else hv[rt] = *reinterpret_cast<const float4*>(a.h + row * H + 4 * q);
-    }
+  auto load_gate1 = [&](int j, int rt, int slot) {
+    const long row = min(m0 + 16 * rt + i16, M - 1);
+    const int q = min(4 * j + G, (H >> 2) - 1);
+    if (LEAN) hb[slot] = a.hgate[row * (H >> 2) + q];
+    else hv[slot] = *reinterpret_cast<const float4*>(a.h + row * H + 4 * q);
   };
-  load_gates(wave);
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) load_gate1(wave, rt, rt);
   if (a.xt_df) export_tiles<RT>(Ah, Al, LDD, a.xt_df, ntD, m0, M, wave, lane);
   // ---- du = (df W2) gated by h > 0, * keep: the gate runs on the ACCUMULATORS (a lane holds a column quad of a row, see mma) and
   // writes the split planes directly -- no fp32 stage, no barrier between product and epilogue (see the forward chain's h_epilogue) ----
   Panel<KCH> p1;                                               // linear1^T streams in under the (last) epilogue
-  // its 72 registers in parts (see the forward chain): steps [0, PS) under the epilogue, [PS, PS2) behind it, and -- tall variant, whose
-  // product runs at the register limit (72 + 12 accumulator + 24 fragment registers) -- [PS2, KCH) INSIDE the product, once two steps
-  // are consumed: five steps of three waves' MFMAs (~2 k cycles) cover their way from L2
-  constexpr int PS = (RT >= 3 && !LEAN) ? 3 : 5, PS2 = RT >= 3 ? 7 : KCH;    // (fp32 gates take 9 registers more than gate bytes)
+  // its 72 registers in parts (see the forward chain): steps [0, PS) under the epilogue, [PS, PS2) behind it, and [PS2, KCH) INSIDE the
+  // product, once two steps are consumed (the product runs at the register limit: 72 + 12 accumulator + 24 fragment registers in the
+  // tall variant; the low one carries LayerNorm1's saved rows through it): five steps of three waves' MFMAs (~2 k cycles) cover their
+  // way from L2
+  constexpr int PS = (RT >= 3 && !LEAN) ? 3 : 5, PS2 = 7;    // (fp32 gates take 9 registers more than gate bytes)
   {
     const float ks = a.p > 0.f ? inv_keep : 1.0f;
-    auto du_epilogue = [&](const f32x4 (&acc)[RT], int j) {
+    auto du_epi1 = [&](const f32x4& acc, int j, int rt, int slot) {   // one row tile of column tile j, gate in hb / hv[slot]
       const int n = 16 * j + 4 * G;                            // < KPH
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        const int rl = 16 * rt + i16;
-        float4 o = zero4;
-        if (n < H) {
-          if (LEAN) {
-            const uint8_t b = hb[rt];
-            o = make_float4((b & 1) ? acc[rt][0] * ks : 0.f, (b & 2) ? acc[rt][1] * ks : 0.f, (b & 4) ? acc[rt][2] * ks : 0.f,
-                            (b & 8) ? acc[rt][3] * ks : 0.f);
-          } else {
-            const float4 h4 = hv[rt];
-            o = make_float4(h4.x > 0.f ? acc[rt][0] * ks : 0.f, h4.y > 0.f ? acc[rt][1] * ks : 0.f, h4.z > 0.f ? acc[rt][2] * ks : 0.f,
-                            h4.w > 0.f ? acc[rt][3] * ks : 0.f);
-          }
+      const int rl = 16 * rt + i16;
+      float4 o = zero4;
+      if (n < H) {
+        if (LEAN) {
+          const uint8_t b = hb[slot];
+          o = make_float4((b & 1) ? acc[0] * ks : 0.f, (b & 2) ? acc[1] * ks : 0.f, (b & 4) ? acc[2] * ks : 0.f, (b & 8) ? acc[3] * ks : 0.f);
+        } else {
+          const float4 h4 = hv[slot];
+          o = make_float4(h4.x > 0.f ? acc[0] * ks : 0.f, h4.y > 0.f ? acc[1] * ks : 0.f, h4.z > 0.f ? acc[2] * ks : 0.f,
+                          h4.w > 0.f ? acc[3] * ks : 0.f);
         }
-        split_store4(Hh + rl * LDH + n, Hl + rl * LDH + n, o);
       }
+      split_store4(Hh + rl * LDH + n, Hl + rl * LDH + n, o);
+    };
+    auto du_epilogue = [&](const f32x4 (&acc)[RT], int j) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) du_epi1(acc[rt], j, rt, rt);
     };
     f32x4 acc[RT];
     mma<KCD, RT>(acc, Ah, Al, LDD, pw, lane, a.one);           // column tile `wave` (every wave has one: nhid > 256)
-    const bool more = __builtin_amdgcn_readfirstlane(EF_WV + wave) < ntH;   // scalar condition: one of the two panels is live, not both
-    __builtin_amdgcn_sched_barrier(0);
+    const int unit = EF_WV - 1 - wave;                         // scalar; second-round (tile, row tile) units: see the forward chain
+    const bool more = unit < (ntH - EF_WV) * RT;
     if (more) {                                                // two straight-line paths: see the forward chain
-      load_panel<KCD>(pw, a.W2t, ntH, EF_WV + wave, lane);
+      const int j2 = EF_WV + unit / RT, rt2 = unit - (unit / RT) * RT;
+      load_panel<KCD>(pw, a.W2t, ntH, j2, lane);
       __builtin_amdgcn_sched_barrier(0);
       du_epilogue(acc, wave);
       __builtin_amdgcn_sched_barrier(0);
-      load_gates(EF_WV + wave);
+      load_gate1(j2, rt2, 0);
       __builtin_amdgcn_sched_barrier(0);
-      mma<KCD, RT>(acc, Ah, Al, LDD, pw, lane, a.one);
+      f32x4 acc1[1];
+      mma<KCD, 1>(acc1, Ah + rt2 * 16 * LDD, Al + rt2 * 16 * LDD, LDD, pw, lane, a.one);
       __builtin_amdgcn_sched_barrier(0);
       load_panel<KCH, 0, PS>(p1, a.W1t, ntD, wave, lane);
       __builtin_amdgcn_sched_barrier(0);
-      du_epilogue(acc, EF_WV + wave);
+      du_epi1(acc1[0], j2, rt2, 0);
     } else {
       load_panel<KCH, 0, PS>(p1, a.W1t, ntD, wave, lane);
       __builtin_amdgcn_sched_barrier(0);
@@ -762,15 +827,13 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   // ---- dx1 = du W1 + ds2 ----
   if (wave < ntD) {
     f32x4 acc[RT];
-    if constexpr (RT >= 3) {
-      auto rest = [&]() { load_panel<KCH, PS2, KCH>(p1, a.W1t, ntD, wave, lane); };
-      mma<KCH, RT, 1, decltype(rest), 3, decltype(load_ln1)>(acc, Hh, Hl, LDH, p1, lane, a.one, rest, load_ln1);
-    } else {
-      mma<KCH, RT>(acc, Hh, Hl, LDH, p1, lane, a.one);
-    }
+    auto rest = [&]() { load_panel<KCH, PS2, KCH>(p1, a.W1t, ntD, wave, lane); };
+    if constexpr (RT >= 3) mma<KCH, RT, 1, decltype(rest), 3, decltype(load_ln1)>(acc, Hh, Hl, LDH, p1, lane, a.one, rest, load_ln1);
+    else mma<KCH, RT, 1, decltype(rest)>(acc, Hh, Hl, LDH, p1, lane, a.one, rest);
     to_stage<RT>(stage, acc, wave, lane);
-  } else if constexpr (RT >= 3) {
-    load_ln1();
+  } else {                                                     // no column tile: LayerNorm1's dropout decisions meanwhile
+    if constexpr (RT >= 3) load_ln1();
+    if (a.p > 0.f && wave >= 10) drop_masks<RT, EF_WV - 10>(mk, seed, a.site_ao, D, m0, a.p, (wave - 10) * 64 + lane);   // waves 10 .. 15: D <= 160
   }
   EFSTAMP(6);
   lds_barrier();                                               // stage complete; the du planes are dead (lnred1 may be written)
@@ -789,7 +852,7 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
         dyq[k] = make_float4(t.x + r4.x, t.y + r4.y, t.z + r4.z, t.w + r4.w);
       }
     }
-    lnb_rows4(dyq, sq, mean_l, rstd_l, cst + KPD, D, m0, M, wave, lane, a.p, inv_keep, seed, a.site_ao, a.ds1, nullptr, Ah, Al, lnred1);
+    lnb_rows4<true>(dyq, sq, mean_l, rstd_l, cst + KPD, D, m0, M, wave, lane, a.p, inv_keep, mk, 0, 0, a.ds1, nullptr, Ah, Al, lnred1);
   }
   EFSTAMP(8);
   lds_barrier();
@@ -822,7 +885,7 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
 template <int DC, int HC, bool LEAN>
 __global__ __launch_bounds__(EF_THR) void k_enc_pre_bwd(PreBwdArgs a, RiderArgs rider, int nmain) {
   extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
-  RD_TOUCH_CODE(43008);                                  // own code -> L2, the riders' bodies included (smallest instantiation: 43.9 KB)
+  RD_TOUCH_CODE(44032);                                  // own code -> L2, the riders' bodies included (smallest instantiation: 46.2 KB)
   if ((int)blockIdx.x >= nmain) { rider_body(rider, (int)blockIdx.x - nmain, esm); return; }
   int M = a.M;
   if (a.mlive) M = min(M, __builtin_amdgcn_readfirstlane(*a.mlive));
@@ -840,7 +903,7 @@ static int ef_specialize(int D, int H) {
 
 constexpr size_t pre_bwd_lds(int rt) {
   return (size_t)2 * 16 * rt * LDD * 2 + (size_t)2 * 16 * rt * LDH * 2 + (size_t)16 * rt * STG * 4 + (size_t)2 * KPD * 4 +
-         (size_t)16 * rt * KPD * 4;
+         (size_t)16 * rt * KPD * 4 + (size_t)16 * rt * MKQ;
 }
 static_assert(pre_bwd_lds(EF_RTMAX) <= 160 * 1024, "one workgroup's LDS");
 
