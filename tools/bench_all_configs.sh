@@ -2,7 +2,7 @@
 # the bench lines of every configuration (rounds 4-5) (P19 full line; P12 both bf16 modes at B = 256 with rooflines; PAM; SYN256)
 out=$GRAFT_REPO_ROOT/gpurun_out/$1; mkdir -p $out
 cd $GRAFT_REPO_ROOT
-timeout 600 python bench.py --steps 50 --warmup 10 > $out/bench_P19.json 2> $out/bench_P19.err
+[ -n "$SKIP_P19" ] || timeout 600 python bench.py --steps 50 --warmup 10 > $out/bench_P19.json 2> $out/bench_P19.err
 timeout 600 python bench.py --config P12 --batch 256 --precision bf16 --steps 30 --warmup 5 --no-cpu-baseline > $out/bench_P12_bf16.json 2> $out/bench_P12_bf16.err
 timeout 600 python bench.py --config P12 --batch 256 --precision bf16x3 --steps 30 --warmup 5 --no-cpu-baseline > $out/bench_P12_bf16x3.json 2> $out/bench_P12_bf16x3.err
 timeout 600 python bench.py --config PAM --batch 64 --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_PAM.json 2> $out/bench_PAM.err
