@@ -49,8 +49,8 @@ constexpr int KPD = 32 * KCD, KPH = 32 * KCH;        // 160, 288
 // banks: the MFMA fragment read (lane: row r, 16-byte chunk G) is conflict-free exactly when the row stride is 32 bytes mod 64
 // (tools/lds_conflicts.py, measured by tools/probe_ldsfrag.hip: 235 B/clk/CU against 127 for the "+ 8 elements" of rounds 1-4).
 constexpr int LDD = KPD + 16, LDH = KPH + 16;
-constexpr int STG = KPD + 4;                         // fp32 stage row stride: the D-wide products' output columns + pad (the nhid-wide
-                                                     // products finish on their accumulators: no stage)
+constexpr int STG = KPD + 8;                         // fp32 stage row stride: the D-wide products' output columns + 32 bytes (the
+                                                     // nhid-wide products finish on their accumulators: no stage)
 
 template <int KC>
 struct Panel { bf16x8 h[KC], l[KC]; };
@@ -136,8 +136,11 @@ __device__ __forceinline__ void mma(f32x4 (&acc)[RT], const __bf16* Ah, const __
   }
 }
 
-// accumulators of column tile j (transposed form, see mma) -> stage[row][16 j + 4 G ..]: one 16-byte store per row tile.  The 16 rows of
-// a store group lie 1168 bytes apart = 16-byte chunks 9 r mod 16 of the 256-byte bank window: all different, conflict-free.
+// accumulators of column tile j (transposed form, see mma) -> stage[row][16 j + 4 G ..]: one 16-byte store per row tile.  Rows of
+// 672 bytes = 42 chunks: in gfx950's 16-lane groups {rows 0-3, 12-15 of chunk G; rows 4-11 of chunk G + 1} the chunks 10 r (+ 1) mod 16
+// of the 256-byte bank window are all different (tools/lds_conflicts.py's model, tests/test_lds_layouts.py; with KPD + 4 floats the
+// group was 2-way conflicted).  The LayerNorm passes' reads of the stage (a 16-lane row reads 16 consecutive chunks of one stage row)
+// stay 2-way against the neighbouring row -- three reads per lane and pass.
 template <int RT>
 __device__ __forceinline__ void to_stage(float* stage, const f32x4 (&acc)[RT], int j, int lane) {
 #pragma unroll
@@ -480,8 +483,8 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
 
   // ---- linear1 -> + bias, ReLU, dropout -> h: the epilogue runs on the ACCUMULATORS (no fp32 stage, no barrier between product and
   // epilogue) -- a lane holds the column quad 16 j + 4 G .. + 3 of row 16 rt + i (mma), which is one dropout quad, one gate byte (LEAN)
-  // or one 16-byte store of h, and one 8-byte store into each split plane.  While one wave of a SIMD is in its epilogue (VALU) the
-  // others are still multiplying: the two phases of rounds 2-4 (product -> stage -> barrier -> 3.4 quads per thread) overlap. ----
+  // or one 16-byte store of h, and one 8-byte store into each split plane.  Rounds 2-4: product -> stage -> barrier -> a flat loop of
+  // 3.4 quads per thread -> barrier (9 k cycles for the loop alone; product + epilogue are 10.9 k now). ----
   Panel<KCH> p2;                                               // linear2 streams in under the (last) epilogue
   {
     const int G = lane >> 4, i16 = lane & 15, qpr = H >> 2;

@@ -66,3 +66,17 @@ def test_transposed_planes_reads_are_conflict_free_with_the_swizzle():
         for k0 in (0, 32):
             assert L.cycles(lambda l: new(row0 + (l & 15), k0 + 8 * (l >> 4))) == 4
             assert L.cycles(lambda l: old(row0 + (l & 15), k0 + 8 * (l >> 4))) == 8
+
+
+def test_chain_stage_rows_take_the_accumulator_stores_without_conflicts():
+    """rd_encfuse.hip `to_stage` (round 5, second half): an accumulator of the swapped-operand product is four consecutive columns of
+    one row -- lane (row l & 15, chunk 4 j + (l >> 4)) stores 16 bytes into the fp32 stage.  Rows of KPD + 8 floats (672 bytes) are
+    conflict-free in the 16-lane group model; KPD + 4 (the first version of that change) was 2-way, plain KPD rows 4-way."""
+    KPD = 160
+
+    def store(stg, j):
+        return L.cycles(lambda l: (l & 15) * stg * 4 + (4 * j + (l >> 4)) * 16)
+    for j in range(10):
+        assert store(KPD + 8, j) == 4
+        assert store(KPD + 4, j) == 8
+        assert store(KPD, j) == 16
