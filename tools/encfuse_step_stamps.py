@@ -48,7 +48,7 @@ def show(tag, s, n, off=0):
 s = run("both")
 show("in-step k_enc_post_fwd (layer 1): 0 start | 1 rows split | 2 barrier | 3 out_proj staged | 4 barrier | 5 LN1 done | 6 barrier | "
      "7 linear1 + h epilogue done | 8 barrier | 9 linear2 staged | 10 barrier | 11 LN2 done   (before the accumulator epilogues: 7 linear1 "
-     "staged | 8 barrier | 9 h done | 10 barrier | 11 linear2 staged | 12 barrier | 13 LN2 done)", s, 14)
+     "staged | 8 barrier | 9 h done | 10 barrier | 11 linear2 staged | 12 barrier | 13 LN2 done)", s, 12)
 show("in-step k_enc_pre_bwd (layer 0): 0 start | 1 barrier | 2 LN2' done | 3 barrier | 4 du product + gate done | 5 barrier | 6 dx1 staged | "
      "7 barrier | 8 LN1' done | 9 barrier | 10 d attn stored   (before: 4 du staged | 5 barrier | 6 gate done | 7 barrier | 8 dx1 staged | "
-     "9 barrier | 10 LN1' done | 11 barrier | 12 d attn staged | 13 barrier | 14 stored)", s, 15, 4096)
+     "9 barrier | 10 LN1' done | 11 barrier | 12 d attn staged | 13 barrier | 14 stored)", s, 11, 4096)

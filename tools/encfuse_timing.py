@@ -34,9 +34,11 @@ def show(tag, n, off=0):
 lib.rd_debug_set_encfuse_stamps(stamps.data_ptr())
 y = ops.encoder_layer(x, mask, shp, 0, 0.2, 5, pd)
 torch.cuda.synchronize()
-show("post_fwd: 14 = W1 panel issued, 15 = LN1 row 0 done; 0 start | 1 rows split | 2 barrier | 3 out_proj staged | 4 barrier | 5 LN1 done | 6 barrier | 7 linear1 staged | 8 barrier | 9 h done | 10 barrier | 11 linear2 staged | 12 barrier | 13 LN2 done", 16)
+show("post_fwd: 0 start | 1 rows split | 2 barrier | 3 out_proj staged | 4 barrier | 5 LN1 done | 6 barrier | 7 linear1 + h epilogue done | "
+     "8 barrier | 9 linear2 staged | 10 barrier | 11 LN2 done", 12)
 stamps.zero_()
 y.backward(dy)
 torch.cuda.synchronize()
 lib.rd_debug_set_encfuse_stamps(None)
-show("pre_bwd", 16, 4096)
+show("pre_bwd: 0 start | 1 barrier | 2 LN2' done | 3 barrier | 4 du product + gate done | 5 barrier | 6 dx1 staged | 7 barrier | 8 LN1' done | "
+     "9 barrier | 10 d attn stored", 11, 4096)
