@@ -9,9 +9,9 @@ timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_token_plan_gpu.
 tail -3 $out/pytest_enc.txt
 libs=(base default "$@")
 lp() { if [ "$1" = default ]; then echo ""; else echo "RD_LIB_PATH=raindrop_amd/_ab/lib_$1.so"; fi; }
-# QUICK=1: stamps of the default library only, one trace and two step times per library
+# QUICK=1: stamps of the LAST library only, one trace and two step times per library
 for v in "${libs[@]}"; do
-  if [ -n "$QUICK" ] && [ $v != default ]; then echo "(skipped)" > $out/stamps_$v.txt; continue; fi
+  if [ -n "$QUICK" ] && [ $v != "${libs[-1]}" ]; then echo "(skipped)" > $out/stamps_$v.txt; continue; fi
   env $(lp $v) timeout 120 python tools/encfuse_step_stamps.py 2>&1 | grep -v amdgpu > $out/stamps_$v.txt
 done
 for rep in 1 ${QUICK:+} $([ -z "$QUICK" ] && echo 2); do
