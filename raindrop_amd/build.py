@@ -29,28 +29,36 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # loads must stay inside the kernel's code in EVERY instantiation -- a different compiler version or flag set can shrink a kernel, and
 # a load past the end of the last kernel of a code object is a memory fault -- so the build itself checks them against the linked
 # library (check_code_touch, called by build() and build_variant()) and FAILS on violation; tests/test_kernel_resources.py re-checks.
-CODE_TOUCH = [("k_msg_fwd_fused", 12544), ("k_msg_bwd_fused", 9728), ("k_attn_fwd_fused", 12800), ("k_attn_bwd_fused", 28672),
-              ("k_enc_post_fwd", 40960), ("k_enc_pre_bwd", 44032), ("4k_dwE", 6144), ("k_dw_reduce", 9216), ("6k_adam", 2432), ("10k_adam_dev", 2432),
-              ("k_wsplit", 4096), ("5k_twgI", 7936), ("k_head_rowsILi1ELi12ELi3E", 14848), ("k_head_rowsILi1ELi16ELi4E", 16384)]
+CODE_TOUCH = [("k_msg_fwd_fused", 12544), ("k_msg_bwd_fused", 9728), ("k_attn_fwd_fused", 13952), ("k_attn_bwd_fused", 31872),
+              ("k_enc_post_fwdILi152ELi272ELb1", 44160), ("k_enc_post_fwdILi152ELi272ELb0", 43776), ("k_enc_post_fwdILi160ELi288ELb1", 43648),
+              ("k_enc_post_fwdILi160ELi288ELb0", 43136), ("k_enc_post_fwdILi0ELi0ELb1", 55680), ("k_enc_post_fwdILi0ELi0ELb0", 58752),
+              ("k_enc_pre_bwdILi152ELi272ELb1", 46592), ("k_enc_pre_bwdILi152ELi272ELb0", 46208), ("k_enc_pre_bwdILi160ELi288ELb1", 46080),
+              ("k_enc_pre_bwdILi160ELi288ELb0", 45696), ("k_enc_pre_bwdILi0ELi0ELb1", 63104), ("k_enc_pre_bwdILi0ELi0ELb0", 62976),
+              ("4k_dwE", 6144), ("k_dw_reduce", 9216), ("6k_adam", 2816), ("10k_adam_dev", 3200),
+              ("k_wsplit", 4992), ("5k_twgILb0E", 10496), ("5k_twgILb1E", 8704), ("k_head_rowsILi1ELi12ELi3E", 15616), ("k_head_rowsILi1ELi16ELi4E", 17024)]
 # the kernels outside the P19 step (RD_TOUCH_CODE_X)
 CODE_TOUCH_X = [("6k_gemmI", 25088), ("13k_gemm_bf16x3I", 28160), ("12k_gemm_panelI", 28160), ("9k_rowgemmI", 4096),
                 ("19k_attn_fwd_one_b16wI", 5632), ("19k_attn_bwd_one_b16wI", 6144), ("14k_attn_fwd_b16I", 6912),
                 ("17k_attn_bwd_dq_b16I", 7040), ("18k_attn_bwd_dkv_b16I", 6016), ("14k_add_ln_fwd_vE", 5120), ("10k_ln_bwd_rI", 5120),
                 ("10k_ln_bwd_vE", 6144)]
-CODE_TOUCH_SLACK = 384          # bytes allowed for the prologue in front of the s_getpc_b64
+CODE_TOUCH_SLACK = 384          # bytes allowed for the prologue in front of the s_getpc_b64 when the disassembler is not there to say
+CODE_TOUCH_MARGIN = 8           # bytes kept free behind the last touched line (the s_getpc's own length + the last dword)
 
 
 def check_code_touch(lib=None):
-    """Raise if any touched range could leave its kernel (see CODE_TOUCH)."""
+    """Raise if any touched range could leave its kernel (see CODE_TOUCH): [s_getpc offset, + touch) must lie inside the kernel's code.
+    The s_getpc offsets come from the disassembly (getpc_offsets); without the disassembler CODE_TOUCH_SLACK bytes are assumed."""
     sizes = kernel_code_sizes(lib)
+    offs = getpc_offsets(lib)
     bad = []
     for frag, touch in CODE_TOUCH + CODE_TOUCH_X:
         ks = {k: v for k, v in sizes.items() if frag in k}
         if not ks:
             bad.append("%s: no such kernel in the library" % frag)
         for k, v in ks.items():
-            if v < touch + CODE_TOUCH_SLACK:
-                bad.append("%s: %d bytes of code, touches %d (+%d slack)" % (k, v, touch, CODE_TOUCH_SLACK))
+            slack = offs[k] + CODE_TOUCH_MARGIN if k in offs else CODE_TOUCH_SLACK
+            if v < touch + slack:
+                bad.append("%s: %d bytes of code, touches %d (+%d slack)" % (k, v, touch, slack))
     if bad:
         raise RuntimeError("own-code touch lengths exceed the built kernels (rd_common.h touch_own_code; raindrop_amd/build.py "
                            "CODE_TOUCH):\n  " + "\n  ".join(bad))

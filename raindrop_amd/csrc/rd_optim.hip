@@ -9,7 +9,7 @@ namespace {
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g,
                                               float* __restrict__ m, float* __restrict__ v, long n, float lr,
                                               float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
-  RD_TOUCH_CODE_FIRST(2432, blockIdx.x, 64);             // own code -> L2 by the first workgroups (rd_common.h; 3.0 KB kernel)
+  RD_TOUCH_CODE_FIRST(2816, blockIdx.x, 64);             // own code -> L2 by the first workgroups (rd_common.h; 3 012-byte kernel)
   const long i4 = (blockIdx.x * (long)blockDim.x + threadIdx.x) * 4;
   if (i4 >= n) return;
   const float step_size = lr / bc1;
@@ -49,7 +49,7 @@ struct AdamState { double t, p1, p2, pad; };
 __global__ __launch_bounds__(256) void k_adam_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                   float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
                                                   AdamState* __restrict__ state) {
-  RD_TOUCH_CODE_FIRST(2432, blockIdx.x, 64);
+  RD_TOUCH_CODE_FIRST(3200, blockIdx.x, 64);             // (3 352-byte kernel)
   const AdamState s0 = state[0], s1 = state[1];
   const bool cur1 = s1.t > s0.t;
   const AdamState c = cur1 ? s1 : s0;

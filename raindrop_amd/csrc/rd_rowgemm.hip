@@ -72,7 +72,7 @@ struct SplitJobs { SplitJob j[WS_MAXJOBS]; int n; __bf16* ones[WS_MAXONES];   //
 // base of the tile array, `lo` is unused (kept for the job layout).  One workgroup row per job; a wave converts one
 // (ntile, kc) tile per iteration.
 __global__ __launch_bounds__(256) void k_wsplit(SplitJobs jobs) {
-  RD_TOUCH_CODE_FIRST(4096, blockIdx.y * gridDim.x + blockIdx.x, 64);   // own code -> L2 by the first workgroups (rd_common.h; 5.2 KB kernel)
+  RD_TOUCH_CODE_FIRST(4992, blockIdx.y * gridDim.x + blockIdx.x, 64);   // own code -> L2 by the first workgroups (rd_common.h; 5 220-byte kernel)
   // rd_step_begin: one block row is the token plan (+ seed bump): its workgroups each take a share of the samples
   // (rd_plan.h: token_plan_part).  First row by default (RD_PLAN_FIRST=0: last, as in rounds 3-4 when the plan was ONE
   // workgroup's ~10-us chain that started behind ~2600 split workgroups: the launch took the sum of both).
