@@ -809,7 +809,7 @@ def main():
                                      "set that stays in the 256 MiB Infinity Cache"}
             k1["frac_isolated"] = k1["frac"]
             # Three in-step figures, all on the line.  `frac` is the one a reader can recompute from the committed kernel trace
-            # (profiles/r05_step_kernel_stats.txt): the rocprofv3 kernel sum -- the profiler cannot run inside this process, so it
+            # (profiles/r05c_step_kernel_stats_final.txt): the rocprofv3 kernel sum -- the profiler cannot run inside this process, so it
             # comes from raindrop_amd/k1_rocprof.json, valid only while the kernel sources are the ones it was taken on (sha1 stamp).
             # The LIVE figures of this run are the HIP-event ones: `frac_events` = the K1 segments as measured (each interval
             # contains the start of a hipGraph, ~10 us: conservative), `frac_events_boundary_corrected` = with (segmented step -

@@ -29,12 +29,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # loads must stay inside the kernel's code in EVERY instantiation -- a different compiler version or flag set can shrink a kernel, and
 # a load past the end of the last kernel of a code object is a memory fault -- so the build itself checks them against the linked
 # library (check_code_touch, called by build() and build_variant()) and FAILS on violation; tests/test_kernel_resources.py re-checks.
-CODE_TOUCH = [("k_msg_fwd_fused", 12544), ("k_msg_bwd_fused", 9728), ("k_attn_fwd_fused", 13952), ("k_attn_bwd_fused", 31872),
+CODE_TOUCH = [("k_msg_fwd_fusedILi3ELi34ELi60E", 13056), ("k_msg_bwd_fusedILi3ELi34ELi60E", 10368), ("k_msg_fwd_fusedILi1ELi0", 12544), ("k_msg_fwd_fusedILi2ELi0", 12544),
+              ("k_msg_fwd_fusedILi3ELi0", 12544), ("k_msg_bwd_fusedILi1ELi0", 9728), ("k_msg_bwd_fusedILi2ELi0", 9728), ("k_msg_bwd_fusedILi3ELi0", 9728), ("k_attn_fwd_fused", 13952), ("k_attn_bwd_fused", 31872),
               ("k_enc_post_fwdILi152ELi272ELb1", 44160), ("k_enc_post_fwdILi152ELi272ELb0", 43776), ("k_enc_post_fwdILi160ELi288ELb1", 43648),
               ("k_enc_post_fwdILi160ELi288ELb0", 43136), ("k_enc_post_fwdILi0ELi0ELb1", 55680), ("k_enc_post_fwdILi0ELi0ELb0", 58752),
               ("k_enc_pre_bwdILi152ELi272ELb1", 46592), ("k_enc_pre_bwdILi152ELi272ELb0", 46208), ("k_enc_pre_bwdILi160ELi288ELb1", 46080),
               ("k_enc_pre_bwdILi160ELi288ELb0", 45696), ("k_enc_pre_bwdILi0ELi0ELb1", 63104), ("k_enc_pre_bwdILi0ELi0ELb0", 62976),
-              ("4k_dwE", 6144), ("k_dw_reduce", 9216), ("6k_adam", 2816), ("10k_adam_dev", 3200),
+              ("4k_dwE", 7424), ("k_dw_reduce", 9984), ("6k_adam", 2816), ("10k_adam_dev", 3200),
               ("k_wsplit", 4992), ("5k_twgILb0E", 10496), ("5k_twgILb1E", 8704), ("k_head_rowsILi1ELi12ELi3E", 15616), ("k_head_rowsILi1ELi16ELi4E", 17024)]
 # the kernels outside the P19 step (RD_TOUCH_CODE_X)
 CODE_TOUCH_X = [("6k_gemmI", 25088), ("13k_gemm_bf16x3I", 28160), ("12k_gemm_panelI", 28160), ("9k_rowgemmI", 4096),

@@ -114,15 +114,15 @@ def test_own_code_touch_stays_inside_the_kernel(frag, touch):
 
 
 def test_step_kernels_outside_the_message_passing_stage_touch_all_of_their_code():
-    """Not more than 256 bytes of any of them lie behind the touched range (the message-passing kernels keep round 4's lengths: their
-    profile files are stamped with the sources' hash, and their tails are 9-22 lines)."""
+    """Not more than 256 bytes of any kernel of the P19 step lie behind the touched range (the generic-shape instantiations of the fused
+    message passing, which no benchmark configuration runs, keep one length below the smallest of them)."""
     build.build(verbose=False)
     offs = build.getpc_offsets()
     if not offs:
         pytest.skip("llvm-objdump not installed")
     sizes = build.kernel_code_sizes()
     for frag, touch in CODE_TOUCH:
-        if any(frag.startswith(p) or p in frag for p in ("k_msg_", "4k_dwE", "k_dw_reduce")):
+        if "k_msg_" in frag and "ELi0" in frag:
             continue
         for k, v in sizes.items():
             if frag in k:
