@@ -18,6 +18,17 @@ def usage():
     return u
 
 
+_CACHE = {}
+
+
+def _sizes_and_offsets():
+    """kernel code sizes and s_getpc offsets of the built library, once per test session (the disassembly takes seconds)"""
+    if "v" not in _CACHE:
+        build.build(verbose=False)
+        _CACHE["v"] = (build.kernel_code_sizes(), build.getpc_offsets())
+    return _CACHE["v"]
+
+
 def _find(usage, *parts):
     hits = [(k, v) for k, v in usage.items() if all(p in k for p in parts)]
     assert hits, "no kernel matching %r" % (parts,)
@@ -102,10 +113,9 @@ def test_own_code_touch_stays_inside_the_kernel(frag, touch):
     instruction look-ahead fetches cold, line by line (the tall chain body's LayerNorm2: 9 k cycles instead of 5 k)."""
     import os
     import re
-    build.build(verbose=False)
-    sizes = {k: v for k, v in build.kernel_code_sizes().items() if frag in k}
+    all_sizes, offs = _sizes_and_offsets()
+    sizes = {k: v for k, v in all_sizes.items() if frag in k}
     assert sizes, frag
-    offs = build.getpc_offsets()
     for k, v in sizes.items():
         slack = offs[k] + build.CODE_TOUCH_MARGIN if k in offs else build.CODE_TOUCH_SLACK
         assert v >= touch + slack, (k, v, touch, slack)
@@ -116,11 +126,9 @@ def test_own_code_touch_stays_inside_the_kernel(frag, touch):
 def test_step_kernels_outside_the_message_passing_stage_touch_all_of_their_code():
     """Not more than 256 bytes of any kernel of the P19 step lie behind the touched range (the generic-shape instantiations of the fused
     message passing, which no benchmark configuration runs, keep one length below the smallest of them)."""
-    build.build(verbose=False)
-    offs = build.getpc_offsets()
+    sizes, offs = _sizes_and_offsets()
     if not offs:
         pytest.skip("llvm-objdump not installed")
-    sizes = build.kernel_code_sizes()
     for frag, touch in CODE_TOUCH:
         if "k_msg_" in frag and "ELi0" in frag:
             continue
