@@ -2,6 +2,7 @@
 
     python -m raindrop_amd.build            # incremental
     python -m raindrop_amd.build --force
+    python -m raindrop_amd.build --touch-table    # code size / own-code touch length / uncovered tail of every kernel
 
 hipcc cross-compiles without a GPU; each translation unit becomes an object under
 `raindrop_amd/csrc/_build/` and the objects are linked into `raindrop_amd/libraindrop_hip.so`.
@@ -245,8 +246,26 @@ def getpc_offsets(lib=None):
     return out
 
 
+def touch_table(lib=None):
+    """[(kernel, code bytes, s_getpc offset, touched bytes, bytes of the kernel's tail NOT touched)] for every kernel with an own-code
+    touch -- `python -m raindrop_amd.build --touch-table`.  The uncovered tail is what a box without instruction look-ahead fetches
+    cold, one 64-byte line per trip to memory (round 5: 1-3 KB per kernel of the step had been left uncovered by lengths kept below
+    the smallest instantiation of each template; DESIGN.md "Round 5 in ten lines", item 10)."""
+    sizes, offs = kernel_code_sizes(lib), getpc_offsets(lib)
+    rows = []
+    for frag, touch in CODE_TOUCH + CODE_TOUCH_X:
+        for k, v in sorted(sizes.items()):
+            if frag in k:
+                rows.append((k, v, offs.get(k), touch, v - touch - (offs.get(k) or 0)))
+    return rows
+
+
 if __name__ == "__main__":
-    if "--variant" in sys.argv:                     # python -m raindrop_amd.build --variant philox -DRD_RNG_PHILOX
+    if "--touch-table" in sys.argv:
+        build()
+        for k, v, o, t, u in touch_table():
+            print("%-90s size %6d  s_getpc @%4s  touch %6d  uncovered %6d" % (k[:90], v, o, t, u))
+    elif "--variant" in sys.argv:                     # python -m raindrop_amd.build --variant philox -DRD_RNG_PHILOX
         i = sys.argv.index("--variant")
         build_variant(sys.argv[i + 1], sys.argv[i + 2:])
     else:
