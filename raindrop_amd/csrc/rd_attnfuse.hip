@@ -319,7 +319,7 @@ __device__ __forceinline__ void zero_pad_rows(__bf16* Tp, int tid) {
 template <int NTH, int KCX>
 __global__ __launch_bounds__(AF_THR) void k_attn_fwd_fused(FAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
-  RD_TOUCH_CODE(13952);                                      // own code -> L2 (rd_common.h; 14 140-byte kernel: ALL of it -- an uncovered tail is fetched cold, line by line, on the pool's slow boxes)
+  RD_TOUCH_CODE(RD_TL_ATTN_FWD);                                      // own code -> L2 (rd_common.h; 14 140-byte kernel: ALL of it -- an uncovered tail is fetched cold, line by line, on the pool's slow boxes)
   constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDX = 32 * KCX + 16, NA = (NTH + 1) / 2;
   constexpr int LDO = 16 * NTH + 4;                          // fp32 row stride of the output stage
   __bf16* Xh = reinterpret_cast<__bf16*>(fsm);
@@ -557,7 +557,7 @@ __device__ __forceinline__ void dx_phase(f32x4 (&dxa)[2][4], DxPanel<(16 * NTH +
 template <int NTH, int KCX>
 __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
-  RD_TOUCH_CODE(31872);                                      // own code -> L2 (32 028-byte kernel, all of it)
+  RD_TOUCH_CODE(RD_TL_ATTN_BWD);                                      // own code -> L2 (32 028-byte kernel, all of it)
   constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDX = 32 * KCX + 16, NA = (NTH + 1) / 2, KB = HDP / 32, LDB = HDP + 16;
   constexpr int NCT = 2 * KCX;                               // 16-column tiles of D (padded to 32 KCX)
   constexpr int LDS_DX = 32 * KCX + 4;                       // fp32 row stride of the dx stage

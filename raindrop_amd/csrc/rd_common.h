@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 #include "../../include/raindrop_hip.h"
+#include "rd_touch_gen.h"      // GENERATED own-code touch lengths (raindrop_amd/build.py TOUCH_SITES)
 
 namespace rd {
 

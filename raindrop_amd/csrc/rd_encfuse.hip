@@ -42,18 +42,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 // own-code touch lengths (bytes behind the s_getpc_b64) of the twelve instantiations: kernel size - prologue - 64, rounded down to 128
-#define RD_EF_POST_P19L_TOUCH 44160
-#define RD_EF_POST_P19_TOUCH 43776
-#define RD_EF_POST_P12L_TOUCH 43648
-#define RD_EF_POST_P12_TOUCH 43136
-#define RD_EF_POST_RTL_TOUCH 55680
-#define RD_EF_POST_RT_TOUCH 58752
-#define RD_EF_PRE_P19L_TOUCH 46592
-#define RD_EF_PRE_P19_TOUCH 46208
-#define RD_EF_PRE_P12L_TOUCH 46080
-#define RD_EF_PRE_P12_TOUCH 45696
-#define RD_EF_PRE_RTL_TOUCH 63104
-#define RD_EF_PRE_RT_TOUCH 62976
 constexpr int EF_WV = 16, EF_THR = 64 * EF_WV;
 constexpr int EF_RTMAX = 3;                          // row tiles of the tall variant
 constexpr int KCD = 5, KCH = 9;                      // reduction steps of 32 for D and nhid
@@ -594,8 +582,8 @@ __global__ __launch_bounds__(EF_THR) void k_enc_post_fwd(PostFwdArgs a) {
   // own code -> L2 (rd_common.h), ALL of it, per instantiation (raindrop_amd/build.py CODE_TOUCH checks each against the linked kernel): the
   // tall body -- the one the step runs -- is laid out LAST, and with one length below the smallest instantiation its LayerNorm2 sat in
   // the uncovered 3 KB: 9 k cycles instead of 5 k on a box whose instruction fetch does not look ahead
-  RD_TOUCH_CODE(DC == 152 ? (LEAN ? RD_EF_POST_P19L_TOUCH : RD_EF_POST_P19_TOUCH) : DC == 160 ? (LEAN ? RD_EF_POST_P12L_TOUCH : RD_EF_POST_P12_TOUCH)
-                          : (LEAN ? RD_EF_POST_RTL_TOUCH : RD_EF_POST_RT_TOUCH));
+  RD_TOUCH_CODE(DC == 152 ? (LEAN ? RD_TL_EF_POST_P19L : RD_TL_EF_POST_P19) : DC == 160 ? (LEAN ? RD_TL_EF_POST_P12L : RD_TL_EF_POST_P12)
+                          : (LEAN ? RD_TL_EF_POST_RTL : RD_TL_EF_POST_RT));
   int M = a.M;
   if (a.mlive) M = min(M, __builtin_amdgcn_readfirstlane(*a.mlive));
   if (pick_rt(M, a.ncu) == 3) post_fwd_body<3, DC, HC, LEAN>(a, esm, M);
@@ -906,8 +894,8 @@ template <int DC, int HC, bool LEAN>
 __global__ __launch_bounds__(EF_THR) void k_enc_pre_bwd(PreBwdArgs a, RiderArgs rider, int nmain) {
   extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
   // own code -> L2, the riders' bodies included, all of it, per instantiation (see k_enc_post_fwd)
-  RD_TOUCH_CODE(DC == 152 ? (LEAN ? RD_EF_PRE_P19L_TOUCH : RD_EF_PRE_P19_TOUCH) : DC == 160 ? (LEAN ? RD_EF_PRE_P12L_TOUCH : RD_EF_PRE_P12_TOUCH)
-                          : (LEAN ? RD_EF_PRE_RTL_TOUCH : RD_EF_PRE_RT_TOUCH));
+  RD_TOUCH_CODE(DC == 152 ? (LEAN ? RD_TL_EF_PRE_P19L : RD_TL_EF_PRE_P19) : DC == 160 ? (LEAN ? RD_TL_EF_PRE_P12L : RD_TL_EF_PRE_P12)
+                          : (LEAN ? RD_TL_EF_PRE_RTL : RD_TL_EF_PRE_RT));
   if ((int)blockIdx.x >= nmain) { rider_body(rider, (int)blockIdx.x - nmain, esm); return; }
   int M = a.M;
   if (a.mlive) M = min(M, __builtin_amdgcn_readfirstlane(*a.mlive));

@@ -111,7 +111,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x4 (&acc)[2][2], 
 
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
-  RD_TOUCH_CODE_X(25088, blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y, 512);
+  RD_TOUCH_CODE_X(RD_TL_GEMM, blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y, 512);
   __shared__ __attribute__((aligned(16))) float As[BM * LDT];
   __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -466,7 +466,7 @@ static unsigned long long* g_gemm_stamps = nullptr;
 template <bool A_KC, bool B_KC, int MI, int NI, int NPRE>
 __global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
   constexpr int TM = 32 * MI, TN = 32 * NI;
-  RD_TOUCH_CODE_X(28160, blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y, 512);
+  RD_TOUCH_CODE_X(RD_TL_GEMM_X3, blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y, 512);
   GSTAMP(0);
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   __bf16* Ah = reinterpret_cast<__bf16*>(gsm);
@@ -684,7 +684,7 @@ int launch_bf16x3(const GemmArgs& g, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 template <int NJ>
 __global__ __launch_bounds__(512) void k_gemm_panel(GemmArgs g) {
-  RD_TOUCH_CODE_X(28160, blockIdx.x, 512);
+  RD_TOUCH_CODE_X(RD_TL_GEMM_PANEL, blockIdx.x, 512);
   constexpr int RT = 4, TM = 16 * RT, TN = 64 * NJ, PLANE = TM * LDB;
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   __bf16* Pb = reinterpret_cast<__bf16*>(gsm);                  // [2 groups][2 buffers][hi, lo][TM][LDB]

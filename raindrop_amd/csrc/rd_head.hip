@@ -478,8 +478,8 @@ static int head_launch(int mode, const rd_shape* s, int32_t D, int32_t d_static,
   // (rounds 2 and 4) and is no longer built (its hid phase spilled at 128 registers).
   // W0 fetched as 192 x 192 where that covers it (P19: dh = 186), else 256 x 256 (RD_HEAD_NARROW=0: always the latter)
   static const int narrow = [] { const char* e = getenv("RD_HEAD_NARROW"); return e ? atoi(e) : 1; }();
-  if (narrow && dh <= 192) { a.touch_bytes = touch ? 15616 : 0; hipLaunchKernelGGL((k_head_rows<1, 12, 3>), dim3(B), dim3(HR_THR), 0, st, a); }
-  else { a.touch_bytes = touch ? 17024 : 0; hipLaunchKernelGGL((k_head_rows<1, HR_RJ, HR_KI>), dim3(B), dim3(HR_THR), 0, st, a); }
+  if (narrow && dh <= 192) { a.touch_bytes = touch ? RD_TL_HEAD_P19 : 0; hipLaunchKernelGGL((k_head_rows<1, 12, 3>), dim3(B), dim3(HR_THR), 0, st, a); }
+  else { a.touch_bytes = touch ? RD_TL_HEAD : 0; hipLaunchKernelGGL((k_head_rows<1, HR_RJ, HR_KI>), dim3(B), dim3(HR_THR), 0, st, a); }
   int rc = check_launch("k_head_rows");
   if (rc || mode == 1) return rc;
   HwArgs h{};

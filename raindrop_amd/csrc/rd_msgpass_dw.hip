@@ -53,7 +53,7 @@ struct Frag { bf16x8 ah[4], al[4], bh[4], bl[4]; };
 
 __global__ __launch_bounds__(DW_THR) void k_dw(DwArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-  RD_TOUCH_CODE(7424);                                   // own code -> L2 (rd_common.h; all of the 7 536-byte kernel)
+  RD_TOUCH_CODE(RD_TL_DW);                                   // own code -> L2 (rd_common.h; all of the 7 536-byte kernel)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // ---- which (layer, slice, block) ----
   const int nmem = a.nbn * a.nbk;
@@ -214,7 +214,7 @@ struct RedArgs {
 // of its own.
 __global__ __launch_bounds__(1024) void k_dw_reduce(RedArgs a, RiderArgs rider, int nmain) {
   __shared__ float rlds[16][64];
-  RD_TOUCH_CODE(9984);                                   // own code -> L2, the rider's body included (all of the 10 096-byte kernel)
+  RD_TOUCH_CODE(RD_TL_DW_REDUCE);                                   // own code -> L2, the rider's body included (all of the 10 096-byte kernel)
   if ((int)blockIdx.x >= nmain) { rider_body(rider, (int)blockIdx.x - nmain, reinterpret_cast<unsigned char*>(rlds)); return; }
   const int nb4 = (a.nblk_dw + 3) >> 2;
   const int tid = threadIdx.x & 255;

@@ -55,11 +55,7 @@
 #ifndef RD_K1_ALATE
 #define RD_K1_ALATE 0
 #endif
-#define RD_K1_FWD_TOUCH 12544
-#define RD_K1_BWD_TOUCH 9728
 // the P19 instantiation <3, 34, 60>: ALL of its 13 172 / 10 512 bytes (an uncovered tail is fetched cold, line by line, on the pool's slow boxes)
-#define RD_K1_FWD_P19_TOUCH 13056
-#define RD_K1_BWD_P19_TOUCH 10368
 
 namespace rd {
 namespace {
@@ -504,7 +500,7 @@ __device__ __forceinline__ void tstore_leftover_planes(const __bf16* Ph, const _
 template <int RT, int FC, int TC>
 __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  RD_TOUCH_CODE(FC == 34 && TC == 60 ? RD_K1_FWD_P19_TOUCH : RD_K1_FWD_TOUCH);   // own code -> L2 (rd_common.h)
+  RD_TOUCH_CODE(FC == 34 && TC == 60 ? RD_TL_K1_FWD_P19 : RD_TL_K1_FWD);   // own code -> L2 (rd_common.h)
   constexpr int ROWS = RT * 16;
   constexpr size_t PLANES = (size_t)4 * ROWS * LDX * sizeof(__bf16);
   __bf16* Xh = reinterpret_cast<__bf16*>(smem_raw);
@@ -753,7 +749,7 @@ __global__ __launch_bounds__(NTHR) void k_msg_fwd_fused(FusedArgs a) {
 template <int RT, int FC, int TC>
 __global__ __launch_bounds__(NTHR) void k_msg_bwd_fused(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  RD_TOUCH_CODE(FC == 34 && TC == 60 ? RD_K1_BWD_P19_TOUCH : RD_K1_BWD_TOUCH);   // own code -> L2 (rd_common.h)
+  RD_TOUCH_CODE(FC == 34 && TC == 60 ? RD_TL_K1_BWD_P19 : RD_TL_K1_BWD);   // own code -> L2 (rd_common.h)
   constexpr int ROWS = RT * 16;
   constexpr size_t PLANES = (size_t)4 * ROWS * LDX * sizeof(__bf16);
   __bf16* Dh = reinterpret_cast<__bf16*>(smem_raw);

@@ -72,7 +72,7 @@ struct SplitJobs { SplitJob j[WS_MAXJOBS]; int n; __bf16* ones[WS_MAXONES];   //
 // base of the tile array, `lo` is unused (kept for the job layout).  One workgroup row per job; a wave converts one
 // (ntile, kc) tile per iteration.
 __global__ __launch_bounds__(256) void k_wsplit(SplitJobs jobs) {
-  RD_TOUCH_CODE_FIRST(4992, blockIdx.y * gridDim.x + blockIdx.x, 64);   // own code -> L2 by the first workgroups (rd_common.h; 5 220-byte kernel)
+  RD_TOUCH_CODE_FIRST(RD_TL_WSPLIT, blockIdx.y * gridDim.x + blockIdx.x, 64);   // own code -> L2 by the first workgroups (rd_common.h; 5 220-byte kernel)
   // rd_step_begin: one block row is the token plan (+ seed bump): its workgroups each take a share of the samples
   // (rd_plan.h: token_plan_part).  First row by default (RD_PLAN_FIRST=0: last, as in rounds 3-4 when the plan was ONE
   // workgroup's ~10-us chain that started behind ~2600 split workgroups: the launch took the sum of both).
@@ -153,7 +153,7 @@ __device__ __forceinline__ void rg_load_panel_part(RPanel<KP, RG_NJ>& p, const _
 
 template <int KC, int RG_ROWS, int RG_NJ, bool LN, bool LNB, int WV>
 __global__ __launch_bounds__(64 * WV) void k_rowgemm(RowGemmArgs a) {
-  RD_TOUCH_CODE_X(4096, blockIdx.x, 512);
+  RD_TOUCH_CODE_X(RD_TL_ROWGEMM, blockIdx.x, 512);
   // SPLIT (the K = 3D = 456 input gradient of the QKV projection): the 15-step weight panel is 120 VGPRs -- with them the kernel
   // needs 178, ONE 8-wave workgroup per CU, and the 266 32-row workgroups of 8497 live rows run in two rounds on 256 CUs (the
   // second for 10 of them).  Holding half a panel at a time keeps the kernel under 128 registers: two workgroups per CU, one round.

@@ -993,7 +993,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_one_b16(AttnArgs a, int one) {
 // between the halves.  Loads: waves 0-3 fetch Q and K, waves 4-7 V.
 template <int NTH, bool VEC>
 __global__ __launch_bounds__(512) void k_attn_fwd_one_b16w(AttnArgs a, int one) {
-  RD_TOUCH_CODE_X(5632, blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y, 512);
+  RD_TOUCH_CODE_X(RD_TL_ATTN_FWD_ONE, blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y, 512);
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
   constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 16, NA = (NTH + 1) / 2;
   __bf16* Qh = reinterpret_cast<__bf16*>(bsm);
@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(512) void k_attn_fwd_one_b16w(AttnArgs a, int one) 
 // workgroup overlap a little instead of not at all (nothing needs a cross-wave reduction: the backward uses the saved LSE).
 template <int NTH, bool VEC>
 __global__ __launch_bounds__(512) void k_attn_bwd_one_b16w(AttnArgs a, int one) {
-  RD_TOUCH_CODE_X(6144, blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y, 512);
+  RD_TOUCH_CODE_X(RD_TL_ATTN_BWD_ONE, blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y, 512);
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
   constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 16, NA = (NTH + 1) / 2;
   __bf16* Qh = reinterpret_cast<__bf16*>(bsm);
@@ -1412,7 +1412,7 @@ __device__ __forceinline__ void store_cols4(float* __restrict__ dst, int c, int 
 
 template <int NTH, bool VEC, bool ONE>
 __global__ __launch_bounds__(64 * QW) void k_attn_fwd_b16(AttnArgs a) {
-  RD_TOUCH_CODE_X(6912, blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y, 512);
+  RD_TOUCH_CODE_X(RD_TL_ATTN_FWD_B16, blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y, 512);
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
   constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 16, NKS = HDP / 32;
   __bf16* Kh = reinterpret_cast<__bf16*>(bsm);
@@ -1515,7 +1515,7 @@ __global__ __launch_bounds__(64 * QW) void k_attn_fwd_b16(AttnArgs a) {
 // dQ (and delta = rowsum(dO * O)): grid (query super-tiles, B*H); a wave owns 16 queries
 template <int NTH, bool VEC, bool ONE>
 __global__ __launch_bounds__(64 * QW) void k_attn_bwd_dq_b16(AttnArgs a) {
-  RD_TOUCH_CODE_X(7040, blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y, 512);
+  RD_TOUCH_CODE_X(RD_TL_ATTN_BWD_DQ, blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y, 512);
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
   constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 16, NKS = HDP / 32;
   __bf16* Kh = reinterpret_cast<__bf16*>(bsm);
@@ -1617,7 +1617,7 @@ __global__ __launch_bounds__(64 * QW) void k_attn_bwd_dq_b16(AttnArgs a) {
 // A workgroup whose 128 keys are all dead writes zeros and leaves; a wave whose 16 keys are all dead only helps with the tiles.
 template <int NTH, bool VEC, bool ONE>
 __global__ __launch_bounds__(64 * QW) void k_attn_bwd_dkv_b16(AttnArgs a) {
-  RD_TOUCH_CODE_X(6016, blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y, 512);
+  RD_TOUCH_CODE_X(RD_TL_ATTN_BWD_DKV, blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y, 512);
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
   constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDB = HDP + 16, NKS = HDP / 32;
   __bf16* Qh = reinterpret_cast<__bf16*>(bsm);
@@ -2071,7 +2071,7 @@ __global__ __launch_bounds__(256) void k_add_ln_fwd_v(const float* __restrict__ 
                                                       float* __restrict__ s_out, float* __restrict__ y,
                                                       float* __restrict__ stats, int M, int D, float p_drop,
                                                       uint64_t seed, uint32_t site, const uint64_t* cell) {
-  RD_TOUCH_CODE_X(5120, blockIdx.x, 512);
+  RD_TOUCH_CODE_X(RD_TL_ADD_LN_FWD, blockIdx.x, 512);
   seed = eff_seed(seed, cell);
   const int lane = threadIdx.x & 63;
   const long row0 = (blockIdx.x * 4L + (threadIdx.x >> 6)) * LNV_RPW;
@@ -2190,7 +2190,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd_r(const float* __restrict__ dy, 
                                                   float* __restrict__ ds_out, float* __restrict__ dr_out,
                                                   float* __restrict__ part, int M, int D, float p_drop,
                                                   uint64_t seed, uint32_t site, const uint64_t* cell) {
-  RD_TOUCH_CODE_X(5120, blockIdx.x, 512);
+  RD_TOUCH_CODE_X(RD_TL_LN_BWD_R, blockIdx.x, 512);
   seed = eff_seed(seed, cell);
   extern __shared__ float red[];             // [4][2*D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2265,7 +2265,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd_v(const float* __restrict__ dy, 
                                                   float* __restrict__ ds_out, float* __restrict__ dr_out,
                                                   float* __restrict__ part, int M, int D, float p_drop,
                                                   uint64_t seed, uint32_t site, const uint64_t* cell) {
-  RD_TOUCH_CODE_X(6144, blockIdx.x, 512);
+  RD_TOUCH_CODE_X(RD_TL_LN_BWD_V, blockIdx.x, 512);
   seed = eff_seed(seed, cell);
   extern __shared__ float red[];             // [4][2*D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -40,7 +40,7 @@ struct Frag { bf16x8 ah[TW_NA], al[TW_NA], bh[TW_NB], bl[TW_NB]; };
 template <bool ONE>
 __global__ __launch_bounds__(TW_THR) void k_twg(TwArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
-  RD_TOUCH_CODE(ONE ? 8704 : 10496);                 // own code -> L2 (rd_common.h; 8 860 / 10 592 bytes: all of it)
+  RD_TOUCH_CODE(ONE ? RD_TL_TWG_ONE : RD_TL_TWG);                 // own code -> L2 (rd_common.h; 8 860 / 10 592 bytes: all of it)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   TwProb P = a.p[0];                                // uniform selects (a dynamic index would move the table to scratch)
 #pragma unroll

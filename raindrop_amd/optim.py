@@ -25,8 +25,12 @@ class FlatAdam:
         self._cell_stale = False
 
     def hyper(self):
-        """the values a captured launch holds as constants (TrainStep.run_full captures again when they change)"""
-        return (float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay))
+        """the values a captured launch holds as CONSTANTS (TrainStep.run_full captures again when they change): betas and eps.
+        lr and weight_decay live in the device step cell (cell_hyper): changing them is a small copy, not a new capture."""
+        return (float(self.betas[0]), float(self.betas[1]), float(self.eps))
+
+    def cell_hyper(self):
+        return (float(self.lr), float(self.weight_decay))
 
     def step(self):
         self.t += 1
@@ -37,30 +41,41 @@ class FlatAdam:
                   self.t, ops._stream())
 
     def step_captured(self):
-        """The update as ONE launch a hipGraph can hold (rd_adam_step_dev: the step count and beta^t live on the device, two slots,
-        every launch advances them).  Call it inside a capture (raindrop_amd.step.TrainStep.capture_full); every replay is one
-        step -- the owner of the graph keeps `self.t` in step (`note_replay`)."""
+        """The update as ONE launch a hipGraph can hold (rd_adam_step_dev: step count, beta^t, lr and weight decay live on the
+        device; the launch's last workgroup advances the count).  Call it inside a capture
+        (raindrop_amd.step.TrainStep.capture_full); every replay is one step -- the owner of the graph keeps `self.t` in step
+        (`note_replay`) and pushes a changed lr / weight decay with `sync_cell_hyper` (no new capture)."""
         self.sync_step_cell(create_only=True)
         p, g = self.param.data, self.param.grad
         _lib.call("rd_adam_step_dev", p.numel(), ops._ptr(p), ops._ptr(g), ops._ptr(self.exp_avg), ops._ptr(self.exp_avg_sq),
-                  float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
-                  ops._ptr(self.step_cell), ops._stream())
+                  float(self.betas[0]), float(self.betas[1]), float(self.eps), ops._ptr(self.step_cell), ops._stream())
 
     def sync_step_cell(self, create_only=False):
-        """Make the device step state agree with `self.t` (before capturing, after load_state_dict, after eager steps)."""
+        """Make the device step state agree with `self.t`, `self.lr`, `self.weight_decay` (before capturing, after load_state_dict,
+        after eager steps).  Layout (include/raindrop_hip.h rd_adam_step_dev): {t, beta1^t, beta2^t, lr, ticket = 0, wd, 0, 0}."""
         fresh = getattr(self, "step_cell", None) is None
         if fresh:
-            self.step_cell = torch.zeros((8,), dtype=torch.float64, device=self.param.device)   # two slots {t, beta1^t, beta2^t, -}
+            self.step_cell = torch.zeros((8,), dtype=torch.float64, device=self.param.device)
         if fresh or not create_only:
             # beta^t of the betas AS THE KERNELS SEE THEM (float arguments widened to double: rd_adam_step's pow() and the device's
             # running product both start from those) -- 0.999 as a double instead of 0.999f moves 1 - beta2^t by 1e-5 relative
             t = float(self.t)
             b1, b2 = (ctypes.c_float(float(b)).value for b in self.betas)
-            self.step_cell.copy_(torch.tensor([t, b1 ** t, b2 ** t, 0.0, -1.0, 0.0, 0.0, 0.0], dtype=torch.float64))
+            self.step_cell.copy_(torch.tensor([t, b1 ** t, b2 ** t, float(self.lr), 0.0, float(self.weight_decay), 0.0, 0.0],
+                                              dtype=torch.float64))
+            self._cell_hyper = self.cell_hyper()
+
+    def sync_cell_hyper(self):
+        """lr / weight decay changed on the host (ReduceLROnPlateau, a warm-up or cosine schedule): two 8-byte cells, stream-ordered
+        with the replays around it."""
+        if self.step_cell is not None and getattr(self, "_cell_hyper", None) != self.cell_hyper():
+            self.step_cell[3:6:2] = torch.tensor([float(self.lr), float(self.weight_decay)], dtype=torch.float64,
+                                                 device=self.step_cell.device)
+            self._cell_hyper = self.cell_hyper()
 
     def device_steps(self):
-        """steps taken according to the device state (the larger of the two slots' counts)"""
-        return int(max(float(self.step_cell[0]), float(self.step_cell[4])))
+        """steps taken according to the device state"""
+        return int(float(self.step_cell[0]))
 
     def note_replay(self):
         self.t += 1

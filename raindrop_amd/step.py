@@ -628,17 +628,19 @@ class TrainStep:
         self._with_cell(cap)
         opt.sync_step_cell()                                               # the warm-up did not step the optimizer; neither did the capture
         self._full_opt = opt
-        self._full_hyper = opt.hyper()                                     # lr, betas, eps, weight decay are launch arguments: baked into the graph
+        self._full_hyper = opt.hyper()                                     # betas, eps are launch arguments: baked into the graph (lr, weight decay: device cell)
         return self.graph_full
 
     def run_full(self):
         """One replay of capture_full's graph = one training step including the optimizer; returns the loss tensor."""
         if self._param_ptrs() != self._ptrs:
             raise _lib.RaindropHipError("TrainStep: a parameter or gradient buffer moved since construction: build a new TrainStep")
-        if self._full_opt.hyper() != self._full_hyper:                     # e.g. ReduceLROnPlateau (code/Raindrop.py:257-259) lowered lr:
-            cell = self.seed_cell.clone()                                  # a replay would go on with the captured value -- capture again
+        if self._full_opt.hyper() != self._full_hyper:                     # betas / eps changed: launch constants of the captured
+            cell = self.seed_cell.clone()                                  # Adam -- capture again
             self.capture_full(self._full_opt)                              # (the warm-up passes advance the dropout stream: put it back)
             self.seed_cell.copy_(cell)
+        self._full_opt.sync_cell_hyper()                                   # lr / weight decay (ReduceLROnPlateau, code/Raindrop.py:257-259;
+                                                                           # warm-up / cosine schedules): an 8-byte copy, no new capture
         if getattr(self._full_opt, "_cell_stale", False):                  # host-side steps were taken since: device state follows self.t
             self._full_opt.sync_step_cell()
             self._full_opt._cell_stale = False

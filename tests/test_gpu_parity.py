@@ -700,6 +700,39 @@ def test_flat_adam_matches_torch_adam():
     assert np.abs(a_ - b_).max() <= 4e-7 * max(1.0, np.abs(b_).max())
 
 
+def test_captured_adam_is_race_free_beyond_one_round_of_workgroups():
+    """the device-state Adam must not advance {t, beta^t} while workgroups of the same launch can still read
+    them.  6 M elements = ~5 900 workgroups, several scheduling rounds on 256 CUs (P19's 494 fit in one, which hid the race of the
+    two-slot form): three captured steps against three host-state steps, EVERY element; the launch replayed from the same state
+    gives the same bits; a learning-rate change is a cell update, not a new launch constant."""
+    from raindrop_amd.optim import FlatAdam
+    n = 6_000_011
+    g_ = torch.Generator(device="cpu").manual_seed(5)
+    p0 = torch.randn(n, generator=g_)
+    host = torch.nn.Parameter(p0.clone().to(DEV)); host.grad = torch.zeros(n, device=DEV)
+    devp = torch.nn.Parameter(p0.clone().to(DEV)); devp.grad = torch.zeros(n, device=DEV)
+    fa, fb = FlatAdam(host, lr=1e-3), FlatAdam(devp, lr=1e-3)
+    fb.sync_step_cell()
+    for s in range(3):
+        g = (torch.randn(n, generator=g_) * (0.5 + s)).to(DEV)
+        if s == 2:
+            fa.lr = fb.lr = 2.5e-4
+            fb.sync_cell_hyper()
+        host.grad.copy_(g); fa.step()
+        devp.grad.copy_(g); fb.step_captured(); fb.note_replay()
+        torch.cuda.synchronize()
+        assert fb.device_steps() == s + 1 and int(fb.step_cell.view(torch.int64)[4]) == 0      # count advanced once, ticket cleared
+        d = (devp.detach() - host.detach()).abs().max().item()
+        assert d <= 4e-7 * max(1.0, float(host.detach().abs().max())), (s, d)
+    # determinism: the same launch from the same state twice
+    snap = (devp.detach().clone(), fb.exp_avg.clone(), fb.exp_avg_sq.clone(), fb.step_cell.clone())
+    fb.step_captured(); torch.cuda.synchronize()
+    first = devp.detach().clone()
+    devp.data.copy_(snap[0]); fb.exp_avg.copy_(snap[1]); fb.exp_avg_sq.copy_(snap[2]); fb.step_cell.copy_(snap[3])
+    fb.step_captured(); torch.cuda.synchronize()
+    assert torch.equal(first, devp.detach())
+
+
 def test_seed_cell_changes_masks_per_replay():
     """The device seed cell (what a captured hipGraph bumps between replays) is added to every
     by-value dropout seed: same cell value -> identical output, advanced cell -> different masks."""

@@ -77,17 +77,17 @@ def test_legacy_raindrop_surface_matches_reference():
 
 
 def test_flat_adam_host_state():
-    """FlatAdam's host side (no launch): the constants a captured step holds (`hyper`), and `load_state_dict` in place -- the moment
+    """FlatAdam's host side (no launch): the constants a captured step holds (`hyper`: betas, eps), what lives in the device cell (`cell_hyper`: lr, weight decay), and `load_state_dict` in place -- the moment
     buffers keep their addresses (a captured step stays valid) and the device step state is marked for a re-sync."""
     from raindrop_amd.optim import FlatAdam
     p = torch.nn.Parameter(torch.zeros(8))
     p.grad = torch.zeros(8)
     a = FlatAdam(p, lr=1e-4)
-    assert a.hyper() == (1e-4, 0.9, 0.999, 1e-8, 0.0) and a.step_cell is None and not a._cell_stale
+    assert a.hyper() == (0.9, 0.999, 1e-8) and a.cell_hyper() == (1e-4, 0.0) and a.step_cell is None and not a._cell_stale
     m_ptr, v_ptr = a.exp_avg.data_ptr(), a.exp_avg_sq.data_ptr()
     sd = dict(a.state_dict(), t=7, lr=5e-5, exp_avg=torch.ones(8), exp_avg_sq=torch.full((8,), 2.0))
     a.load_state_dict(sd)
-    assert a.t == 7 and a.hyper()[0] == 5e-5 and a._cell_stale
+    assert a.t == 7 and a.cell_hyper()[0] == 5e-5 and a._cell_stale
     assert a.exp_avg.data_ptr() == m_ptr and a.exp_avg_sq.data_ptr() == v_ptr
     assert float(a.exp_avg.sum()) == 8.0 and float(a.exp_avg_sq.sum()) == 16.0
     with pytest.raises(ValueError):

@@ -90,80 +90,88 @@ def test_resource_remark_parser_keeps_real_warnings():
     assert "unused variable" in rest and "int x;" in rest and "remark" not in rest and "float b1" not in rest
 
 
-# (kernel name fragment, bytes of its own code the kernel requests into L2 at its start: rd_common.h touch_own_code) -- the table lives in
-# raindrop_amd/build.py, which also checks it against the linked library at BUILD time (check_code_touch)
-CODE_TOUCH = build.CODE_TOUCH
+# Own-code touch lengths (rd_common.h touch_own_code): GENERATED by the build from the linked code objects (raindrop_amd/build.py
+# TOUCH_SITES -> csrc/rd_touch_gen.h), checked before the library is moved into place.
+SITES = build.TOUCH_SITES
 
 
-def test_build_checks_code_touch_lengths(monkeypatch):
-    """The build fails when a touched range would leave its kernel."""
+def test_build_checks_code_touch_lengths():
+    """The check the build runs on a freshly linked library fails when a touched range would leave its kernel, and the generated
+    table IS the fixed point for the library that is in place."""
     build.build(verbose=False)
+    table = build.read_touch_table()
+    assert set(table) == {s for s, _, _ in SITES}
     build.check_code_touch()
-    monkeypatch.setattr(build, "CODE_TOUCH", [("4k_dwE", 1 << 20)])
     with pytest.raises(RuntimeError, match="own-code touch"):
-        build.check_code_touch()
+        build.check_code_touch(table=dict(table, DW=1 << 20))
+    assert build.ideal_touch_table(build.LIB, *_sizes_and_offsets()) == table
 
 
-@pytest.mark.parametrize("frag,touch", CODE_TOUCH, ids=[c[0] for c in CODE_TOUCH])
-def test_own_code_touch_stays_inside_the_kernel(frag, touch):
-    """touch_own_code reads [pc, pc + bytes) behind the kernel's s_getpc_b64: the range must end inside EVERY instantiation the entry
-    names (the s_getpc's offset from the disassembly + 8 bytes, or 384 bytes of slack without the disassembler -- the rule of
-    build.check_code_touch), and the constant in the source must be the one listed here.  Round 5's last change: the lengths of the
-    kernels outside the message-passing stage cover their WHOLE code (per instantiation) -- an uncovered tail is what a box without
-    instruction look-ahead fetches cold, line by line (the tall chain body's LayerNorm2: 9 k cycles instead of 5 k)."""
+@pytest.mark.parametrize("site,pat,kind", SITES, ids=[c[0] for c in SITES])
+def test_own_code_touch_stays_inside_the_kernel(site, pat, kind):
+    """touch_own_code reads [pc, pc + bytes) behind the kernel's s_getpc_b64: the range must end inside EVERY instantiation the site's
+    pattern matches (the s_getpc's offset from the disassembly + 8 bytes, or 384 bytes of slack without the disassembler -- the rule
+    of build.check_code_touch), and the source must take its length from the generated macro, not from a literal."""
     import os
     import re
     all_sizes, offs = _sizes_and_offsets()
-    sizes = {k: v for k, v in all_sizes.items() if frag in k}
-    assert sizes, frag
+    touch = build.read_touch_table()[site]
+    sizes = {k: v for k, v in all_sizes.items() if re.search(pat, k)}
+    assert sizes, site
     for k, v in sizes.items():
         slack = offs[k] + build.CODE_TOUCH_MARGIN if k in offs else build.CODE_TOUCH_SLACK
         assert v >= touch + slack, (k, v, touch, slack)
     src = "".join(open(os.path.join(build.CSRC, f)).read() for f in sorted(os.listdir(build.CSRC)) if f.endswith(".hip"))
-    assert re.search(r"(RD_TOUCH_CODE(_FIRST)?\((\w+ \? )?(\d+ : )?%d\b|touch \? %d :|#define RD_\w+_TOUCH %d\b)" % (touch, touch, touch), src), (frag, touch)
+    assert re.search(r"\bRD_TL_%s\b" % site, src), site
+    assert not re.search(r"RD_TOUCH_CODE(_FIRST|_X)?\(\d", src), "a literal touch length is back in the sources"
 
 
-def test_step_kernels_outside_the_message_passing_stage_touch_all_of_their_code():
-    """Not more than 256 bytes of any kernel of the P19 step lie behind the touched range (the generic-shape instantiations of the fused
-    message passing, which no benchmark configuration runs, keep one length below the smallest of them)."""
+def test_step_kernels_touch_all_of_their_code():
+    """Not more than 256 bytes of any kernel of the P19 step lie behind the touched range (round 5: an uncovered tail is what a box
+    without instruction look-ahead fetches cold, line by line -- the tall chain body's LayerNorm2 ran 9 k cycles instead of 5 k).
+    The generic-shape instantiations of the fused message passing share one length (the smallest of three)."""
+    import re
     sizes, offs = _sizes_and_offsets()
     if not offs:
         pytest.skip("llvm-objdump not installed")
-    for frag, touch in CODE_TOUCH:
-        if "k_msg_" in frag and "ELi0" in frag:
+    table = build.read_touch_table()
+    for site, pat, kind in SITES:
+        if kind != "step" or site in ("K1_FWD", "K1_BWD"):
             continue
         for k, v in sizes.items():
-            if frag in k:
-                assert v - offs[k] - touch <= 256, (k, v, offs[k], touch)
-
-
-# the same prologue in the kernels outside the P19 step (rd_common.h RD_TOUCH_CODE_X: written in round 4, measured and made the default in
-# round 5)
-CODE_TOUCH_X = build.CODE_TOUCH_X
-
-
-@pytest.mark.parametrize("frag,touch", CODE_TOUCH_X, ids=[c[0] for c in CODE_TOUCH_X])
-def test_optional_code_touch_lengths_fit(frag, touch):
-    import os
-    import re
-    build.build(verbose=False)
-    sizes = [v for k, v in build.kernel_code_sizes().items() if frag in k]
-    assert sizes, frag
-    assert min(sizes) >= touch + 384, (frag, min(sizes), touch)
-    src = "".join(open(os.path.join(build.CSRC, f)).read() for f in sorted(os.listdir(build.CSRC)) if f.endswith(".hip"))
-    assert re.search(r"RD_TOUCH_CODE_X\(%d\b" % touch, src), (frag, touch)
+            if re.search(pat, k):
+                assert v - offs[k] - table[site] <= 256, (k, v, offs[k], table[site])
 
 
 def test_own_code_touch_starts_right_behind_the_entry():
-    """The touched range is [address behind s_getpc_b64, + bytes): the s_getpc must sit within the slack the length tests leave
-    (384 bytes) of the kernel's entry in EVERY instantiation -- the compiler is free to schedule the prologue in front of it."""
-    build.build(verbose=False)
-    offs = build.getpc_offsets()
+    """The touched range is [address behind s_getpc_b64, + bytes): the s_getpc must sit close to the kernel's entry in EVERY
+    instantiation -- the compiler is free to schedule the prologue in front of it, and what lies in front is not touched."""
+    import re
+    sizes, offs = _sizes_and_offsets()
     if not offs:
         pytest.skip("llvm-objdump not installed")
-    sizes = build.kernel_code_sizes()
-    touched = [k for k in offs if any(f in k for f, _ in CODE_TOUCH)]
-    assert len(touched) >= 20, touched
-    for k in touched:
-        t = max(t for f, t in CODE_TOUCH if f in k)
-        assert offs[k] <= 256 and offs[k] + 8 + t <= sizes[k], (k, offs[k], t, sizes[k])
+    table = build.read_touch_table()
+    n = 0
+    for site, pat, kind in SITES:
+        for k in sizes:
+            if re.search(pat, k) and k in offs:
+                n += 1
+                assert offs[k] <= 384 and offs[k] + 8 + table[site] <= sizes[k], (k, offs[k], table[site], sizes[k])
+    assert n >= 40, n
+
+
+def test_stale_or_unchecked_library_is_relinked(tmp_path, monkeypatch):
+    """the library in place is always one that passed the touch check -- it is linked under a temporary name and
+    renamed afterwards, and its stamp (hash of the objects it was linked from) makes build() relink when it does not match."""
+    import os
+    build.build(verbose=False)
+    stamp = build.LIB + ".stamp"
+    good = open(stamp).read()
+    try:
+        with open(stamp, "w") as fh:
+            fh.write("not the objects' hash")
+        build.build(verbose=False)
+        assert open(stamp).read() == good and not os.path.exists(build.LIB + ".tmp")
+    finally:
+        with open(stamp, "w") as fh:
+            fh.write(good)
