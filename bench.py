@@ -428,6 +428,101 @@ def _k1_rocprof(alg_bytes, shape):
         return None
 
 
+def trace_kernel_table(db_path):
+    """{kernel display name: (calls, average duration in us)} of a rocprofv3 rocpd database (`rocprofv3 --kernel-trace`)."""
+    import sqlite3
+    c = sqlite3.connect(db_path)
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    disp = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    sym = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    cols = [r[1] for r in c.execute("pragma table_info(%s)" % sym)]
+    name_col = "display_name" if "display_name" in cols else "kernel_name"
+    rows = c.execute("select s.%s, count(*), avg(d.end-d.start) from %s d join %s s on d.kernel_id = s.id group by s.%s"
+                     % (name_col, disp, sym, name_col)).fetchall()
+    return {name: (calls, avg / 1e3) for name, calls, avg in rows}
+
+
+# what belongs to K1 in a kernel trace of the captured step: (substring of the kernel name, weight | "share" = K1's share of the step's
+# first launch by tile elements, required).  k_dw_reduce is counted WHOLE although it carries encoder layer 0's parked slice reduce
+# as a rider (conservative); where the slice sum is folded into the optimizer launch (TrainStep.capture_full, round 6) the launch does
+# not exist and K1 is charged the GROWTH of the optimizer launch instead (k1_sum_from_table: adam_base_us).
+K1_TRACE_KERNELS = (("k_msg_fwd_fused", 1.0, True), ("k_msg_bwd_fused", 1.0, True), ("k_dw(", 1.0, True), ("k_dw_reduce", 1.0, False),
+                    ("k_wsplit", "share", False), ("k_plan", 0.0, False))
+
+
+def k1_first_launch_share(K=240, D=152, H=272, nl=2):
+    k1_el, enc_el = 4 * K * K, nl * 2 * (3 * D * D + D * D + 2 * D * H)
+    return k1_el / float(k1_el + enc_el)
+
+
+def k1_sum_from_table(table, share):
+    """us of K1 per step from a kernel table of the captured step + the per-kernel figures that went in."""
+    us, total, steps = {}, 0.0, None
+    for frag, w, required in K1_TRACE_KERNELS:
+        hit = [(n, v) for n, v in table.items() if frag in n]
+        if not hit:
+            if required:
+                raise RuntimeError("kernel %r missing from the trace" % frag)
+            continue
+        calls, avg = hit[0][1]
+        if frag == "k_msg_fwd_fused":
+            steps = calls
+        us[frag.rstrip("(")] = round(avg, 2)
+        total += (share if w == "share" else w) * avg
+    return total, us, steps
+
+
+def live_k1_rocprof(args, cfg, alg_bytes, keep=None):
+    """roofline.frac as a MEASUREMENT OF THIS BOX: after the timed region, `rocprofv3 --kernel-trace -- python
+    tools/step_only.py` as a child process (the profiler cannot attach to the timed process; the child runs the same captured step on
+    the same batch seed, one hipGraph per step incl. Adam), K1's kernel sum read from its rocpd database.  Returns the dict for
+    roofline.rocprof or {"error": ..}; never raises.  keep: directory that receives the per-kernel table as text (profiles)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if cfg["name"] != "P19":
+        return {"error": "tools/step_only.py runs the P19 step only"}
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return {"error": "rocprofv3 not on PATH"}
+    tmp = tempfile.mkdtemp(prefix="rd_trace_", dir="/tmp")
+    try:
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        env.update(RD_FULL="1", TMPDIR="/tmp")
+        cmd = [exe, "--kernel-trace", "-d", tmp, "-o", "step", "--", sys.executable, os.path.join(ROOT, "tools", "step_only.py"), "100",
+               str(args.batch)]
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd="/tmp")
+        dbs = [os.path.join(r, f) for r, _, fs in os.walk(tmp) for f in fs if f.endswith(".db")]
+        if res.returncode != 0 or not dbs:
+            return {"error": "rocprofv3 child failed (rc %d): %s" % (res.returncode, (res.stderr or res.stdout)[-300:])}
+        table = trace_kernel_table(dbs[0])
+        share = k1_first_launch_share(cfg["max_len"] * cfg["d_ob"], cfg["d_inp"] * cfg["d_ob"] + 16, cfg["nhid"], cfg["nlayers"])
+        total, us, steps = k1_sum_from_table(table, share)
+        step_line = [ln for ln in res.stdout.splitlines() if ln.startswith("loss ")]
+        out = {"us": round(total, 2), "frac": round(alg_bytes / (total * 1e-6) / 1e9 / HBM_PEAK_GBS, 5), "kernels_us": us, "steps": steps,
+               "k1_share_of_first_launch": round(share, 3),
+               "kernel_sum_us_per_step": round(sum(c * a for c, a in table.values() if c >= (steps or 1)) / max(steps or 1, 1), 1),
+               "child": step_line[-1] if step_line else None,
+               "source": "rocprofv3 --kernel-trace -- python tools/step_only.py 100 %d (RD_FULL=1), spawned by THIS bench.py run after its timed "
+                         "region: average kernel durations of the captured step on this box" % args.batch}
+        if keep:
+            try:
+                os.makedirs(keep, exist_ok=True)
+                rows = sorted(table.items(), key=lambda kv: -kv[1][0] * kv[1][1])
+                tot = sum(c * a for c, a in table.values()) or 1.0
+                with open(os.path.join(keep, "bench_step_kernel_stats.txt"), "w") as fh:
+                    fh.write("%-92s %7s %12s %10s %6s\n" % ("kernel", "calls", "total_us", "avg_us", "%"))
+                    for n, (c, a) in rows[:40]:
+                        fh.write("%-92s %7d %12.1f %10.2f %6.2f\n" % (n[:92], c, c * a, a, 100.0 * c * a / tot))
+            except Exception:
+                pass
+        return out
+    except Exception as e:
+        return {"error": repr(e)[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def _pmc_traffic(B, F, K):
     """HBM bytes per K1 step from the committed PMC passes (rocprofv3 --pmc cannot run inside the timed
     process: FETCH_SIZE and WRITE_SIZE need separate passes; tools/k1_traffic_json.py).  Only valid for the
@@ -988,16 +1083,40 @@ def main():
                 line["roofline"] = roofline_isolated(args) or k1_roofline_events(model, cfg, batch)
                 if isinstance(line["roofline"], dict) and "encoder_layer" in line["roofline"]:
                     line["roofline_encoder_layer"] = line["roofline"].pop("encoder_layer")   # second object: the other ~85 % of the step
+                rl = line["roofline"]
+                if world == 1 and isinstance(rl, dict) and "algorithmic_bytes" in rl and os.environ.get("RD_BENCH_LIVE_TRACE", "1") != "0":
+                    # frac = the rocprofv3 kernel sum of the captured step ON THIS BOX, taken by a child of this run; the committed
+                    # trace (raindrop_amd/k1_rocprof.json, another box) stays as frac_stamped; if the child fails frac is the
+                    # CONSERVATIVE live figure (HIP events, graph starts included), not the boundary-corrected one
+                    live = live_k1_rocprof(args, cfg, rl["algorithmic_bytes"], keep=os.environ.get("RD_BENCH_KEEP_TRACE"))
+                    rl["frac_stamped"] = rl.pop("frac_rocprof", None)
+                    rl["rocprof_stamped"] = rl.pop("rocprof", None)
+                    rl["rocprof"] = live
+                    if live.get("frac"):
+                        rl["frac"], rl["achieved"] = live["frac"], round(live["frac"] * HBM_PEAK_GBS, 2)
+                        rl["frac_source"] = "rocprofv3 --kernel-trace child of THIS run (roofline.rocprof): K1 kernel sum of the captured step on this box"
+                    elif rl.get("frac_events"):
+                        rl["frac"], rl["achieved"] = rl["frac_events"], round(rl["frac_events"] * HBM_PEAK_GBS, 2)
+                        rl["frac_source"] = "HIP events of this run, graph starts included (conservative): the rocprofv3 child failed: %s" % live.get("error")
             except Exception as e:                                       # pragma: no cover
                 line["roofline"] = {"error": repr(e)[:200]}
             if world == 1:
                 line["config"]["box"] = box_kind()
+                if isinstance(line.get("roofline"), dict) and isinstance(line["roofline"].get("rocprof"), dict):
+                    line["roofline"]["rocprof"]["box"] = line["config"]["box"]      # the trace is of THIS box
                 line["config"]["fp32_mode_ms_per_step"] = fp32_mode_ms(args)
                 if token_plan_on:
                     line["config"]["padded_layout_ms_per_step"] = padded_layout_ms(args)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, gs, B, args.cpu_reps)
             line["cpu_baseline"]["reference_o1"] = recorded_o1(cfg["name"], B)
+            # what the baseline IS, where a reader of `config` sees it: the restatement (port) with dropout OFF on this
+            # host's cores; the reference's own files (O1, dropout 0.2) cannot run here (/root/reference is not on the GPU box) and
+            # their figure is a recording from the build container
+            line["config"]["cpu_baseline_kind"] = ("port (oracle/restatement.py, reference evaluation order), dropout off, %d threads of THIS host; "
+                                                   "cpu_baseline.reference_o1 = the reference's own files, dropout 0.2, RECORDED in the build "
+                                                   "container (8 cores), not measured here" % line["cpu_baseline"]["cores"])
+            line["cpu_baseline"]["kind"] = "port"
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()                           # rank 0 measured the roofline after the timed region: tear down together

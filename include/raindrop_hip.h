@@ -317,15 +317,18 @@ int rd_masked_mean_bwd(const rd_shape* s, int32_t D, const float* dout, int32_t 
 int rd_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
                  float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream);
 /* The same update with the optimizer's step state on the DEVICE -- ONE launch a hipGraph can replay.  `state`: 64 bytes, 16-byte
- * aligned, eight 8-byte cells {t, beta1^t, beta2^t, lr, ticket, weight_decay, 0, 0}: doubles but for `ticket`, an unsigned 64-bit
- * counter the caller zeroes.  Every workgroup reads {t, beta^t, lr, weight_decay} and derives step t + 1's bias corrections; the
- * launch's LAST workgroup (by an arrival ticket) writes {t + 1, beta1^(t+1), beta2^(t+1)} and clears the ticket -- nothing is
- * written while another workgroup of the launch may still read it.  lr / weight_decay are read from the cell so that a learning-
- * rate schedule (code/Raindrop.py:257-259) is an 8-byte copy into it, not a new capture; beta1, beta2, eps are launch constants.
+ * aligned, eight doubles {t, beta1^t, beta2^t, lr, 0, weight_decay, 0, 0} OF THE STEP BEING APPLIED; the launch only reads it (no
+ * workgroup of a launch ever sees a state another workgroup of the same launch wrote).  The state is advanced once per step by an
+ * EARLIER launch: rd_adam_state_advance (one thread: t += 1, beta^t *= beta), or -- no extra launch -- by the step's first launch:
+ * rd_set_adam_state registers the cell on this host thread and rd_step_begin (enqueued while it is registered) advances it next
+ * to the dropout seed bump.  lr / weight_decay are read from the cell so that a learning-rate schedule (code/Raindrop.py:257-259)
+ * is an 8-byte copy into it, not a new capture; beta1, beta2, eps are launch constants.
  * Initialise {steps taken so far, beta1^t, beta2^t, lr, 0, weight_decay, 0, 0}.
  * raindrop_amd.optim.FlatAdam.step_captured / raindrop_amd.step.TrainStep.capture_full. */
 int rd_adam_step_dev(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float beta1, float beta2,
-                     float eps, void* state, void* stream);
+                     float eps, const void* state, void* stream);
+int rd_adam_state_advance(void* state, float beta1, float beta2, void* stream);
+int rd_set_adam_state(void* state, float beta1, float beta2);      /* NULL: unregister */
 
 /* ---- generic dense pieces (used by the temporal encoder, the head and the large-K path) ---- */
 

@@ -92,6 +92,8 @@ SIGNATURES = {
     "rd_adam_step": (c_int32, [ctypes.c_int64, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float,
                                 ctypes.c_int64, _P]),
     "rd_adam_step_dev": (c_int32, [ctypes.c_int64, _P, _P, _P, _P, c_float, c_float, c_float, _P, _P]),
+    "rd_adam_state_advance": (c_int32, [_P, c_float, c_float, _P]),
+    "rd_set_adam_state": (c_int32, [_P, c_float, c_float]),
     "rd_linear_fwd": (c_int32, [c_int32, c_int32, c_int32, _P, c_int32, _P, _P, _P, c_int32, c_int32, _P]),
     "rd_linear_bwd_input": (c_int32, [c_int32, c_int32, c_int32, _P, c_int32, _P, _P, c_int32, _P]),
     "rd_linear_bwd_input_gated": (c_int32, [c_int32, c_int32, c_int32, _P, c_int32, _P, _P, c_int32, _P, c_int32, _P]),

@@ -18,6 +18,8 @@ char* err_buf() {
 // keeps the pointer it was captured with, so callers register the cell around the enqueue / capture only.
 static thread_local const uint64_t* g_seed_cell = nullptr;
 const uint64_t* seed_cell() { return g_seed_cell; }
+static thread_local AdamCellReg g_adam_cell = {nullptr, 0.f, 0.f};
+AdamCellReg adam_cell() { return g_adam_cell; }
 
 static int g_precision = -1;
 int precision() {
@@ -103,6 +105,11 @@ namespace {
 __global__ void k_seed_advance(uint64_t* cell, uint64_t delta) { *cell += delta; }
 }
 extern "C" int rd_set_seed_cell(const uint64_t* device_cell) { g_seed_cell = device_cell; return RD_OK; }
+extern "C" int rd_set_adam_state(void* state, float beta1, float beta2) {
+  RD_REQUIRE((reinterpret_cast<uintptr_t>(state) & 15) == 0, "misaligned optimizer state");
+  g_adam_cell = AdamCellReg{(double*)state, beta1, beta2};
+  return RD_OK;
+}
 // Switching the mode OFF discards whatever is still parked: the slot holds raw device pointers of the step that parked it, and a
 // caller that leaves the mode through an error path (a capture that raised) must not have them enqueued -- or baked into a later
 // graph -- by the next chain launch of this host thread.  A normal caller has flushed (rd_flush_trailing) before, so nothing is lost.

@@ -91,6 +91,15 @@ __device__ __forceinline__ void load_uniform_2xi32(const int32_t* p, const int32
   asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(x), "=&s"(y) : "s"(p), "s"(q) : "memory");
 }
 
+// Device-side Adam step state (rd_optim.hip): {t, beta1^t, beta2^t, lr, -, weight_decay, -, -}; one thread advances it once per step
+// in a launch that precedes the update (rd_adam_state_advance, or the plan workgroup of rd_step_begin).
+__device__ __forceinline__ void adam_state_advance(double* st, float b1, float b2) {
+  st[0] += 1.0; st[1] *= (double)b1; st[2] *= (double)b2;
+}
+// the cell registered by rd_set_adam_state on this host thread (nullptr: none); read when rd_step_begin is ENQUEUED
+struct AdamCellReg { double* state; float b1, b2; };
+AdamCellReg adam_cell();
+
 // Request this kernel's OWN code into the L2 of the XCD it runs on: lane t asks for one dword of the t-th 128-byte line after the
 // current PC (`bytes` <= the code that follows; lanes past the range sit out), then the requesting waves wait once.  Why: a kernel
 // of the step runs once per step, ~0.9 GB of traffic after its previous run -- its code is in no cache, and on the pool's SLOW boxes

@@ -40,25 +40,25 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
 // compiler can fold --, one wave, clock64 around it: cold (its code in no cache) about 80 ticks per 64-byte line where the hardware
 // fetches instructions ahead, 400-450 where it does not; warm 45-55 / 75-95.  tools/probe_clocks.hip is the standalone form.
 // The same update with the optimizer's step state on the DEVICE: a captured launch cannot carry the host's bias corrections (they
-// change every step), and an extra one-thread launch in front of the update costs the step 3 % (measured: a kernel boundary + two
-// double-precision pow() on one lane).  The state is ONE slot of eight 8-byte cells {t, beta1^t, beta2^t, lr, ticket, weight_decay,
-// -, -}: every workgroup READS {t, beta^t, lr, wd} and derives step t + 1's corrections with one multiply each; nobody writes them
-// while the launch's workgroups may still read -- each workgroup takes a ticket when it is done (all of its reads are behind it),
-// and the one that draws the LAST ticket writes {t + 1, beta1^(t+1), beta2^(t+1)} and clears the ticket.  (Rounds 5's two-slot
-// form let workgroup 0 write the "other" slot at once: a workgroup dispatched after that write became visible took the new slot
-// as current and applied step t + 2's corrections -- a race at every size that does not fit the device in one round.)
+// change every step).  The state is eight doubles {t, beta1^t, beta2^t, lr, -, weight_decay, -, -} holding the values OF THE STEP
+// BEING APPLIED; this kernel only READS it.  The state is advanced -- t += 1, beta^t *= beta -- by an earlier launch of the same
+// step: the step's first launch where there is one (rd_set_adam_state registers the cell, rd_step_begin's plan workgroup does it
+// next to the dropout seed bump), else rd_adam_state_advance (one thread).  Rounds 5's form advanced a second slot from workgroup 0
+// of THIS launch: workgroups dispatched after that store became visible applied step t + 2's corrections (a race wherever the grid
+// does not fit the device in one round).  Round 6's first fix -- an arrival ticket, the last workgroup advances -- was
+// race-free and cost 4.5 us per step (profiles/r06_adam_ticket_vs_begin.txt: 9.85 against 5.4 us: every workgroup waits for the
+// return of a device-scope atomic on ONE line, the last one for a fence and a second atomic on top).
 // lr and weight_decay live in the cell too: a learning-rate schedule is an 8-byte copy, not a new capture.
 // (beta^t by repeated multiplication differs from pow() by ~t 2^-53 relative: far below the float the correction is rounded to.)
-struct AdamState { double t, p1, p2, lr; unsigned long long ticket; double wd, pad0, pad1; };
+struct AdamState { double t, p1, p2, lr, pad0, wd, pad1, pad2; };
 __global__ __launch_bounds__(256) void k_adam_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                   float* __restrict__ v, long n, float b1, float b2, float eps,
-                                                  AdamState* __restrict__ state) {
+                                                  const AdamState* __restrict__ state) {
   RD_TOUCH_CODE_FIRST(RD_TL_ADAM_DEV, blockIdx.x, 64);
-  const double st = state->t, sp1 = state->p1, sp2 = state->p2;
   const float lr = (float)state->lr, wd = (float)state->wd;
-  const double np1 = sp1 * (double)b1, np2 = sp2 * (double)b2;
-  const float bc1 = (float)(1.0 - np1), bc2_sqrt = (float)sqrt(1.0 - np2);
+  const float bc1 = (float)(1.0 - state->p1), bc2_sqrt = (float)sqrt(1.0 - state->p2);
   const long i4 = (blockIdx.x * (long)blockDim.x + threadIdx.x) * 4;
+  if (i4 >= n) return;
   const float step_size = lr / bc1;
   if (i4 + 3 < n) {
     float4 pp = *reinterpret_cast<float4*>(p + i4), gg = *reinterpret_cast<const float4*>(g + i4);
@@ -81,17 +81,8 @@ __global__ __launch_bounds__(256) void k_adam_dev(float* __restrict__ p, const f
       p[i] -= step_size * m[i] / (sqrtf(v[i]) / bc2_sqrt + eps);
     }
   }
-  // every thread's state reads were consumed above (bc1, step_size feed its stores); behind the barrier the workgroup is done reading
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned long long k = atomicAdd(&state->ticket, 1ull);
-    if (k == (unsigned long long)gridDim.x - 1ull) {       // the last workgroup of the launch: nobody reads the state any more
-      state->t = st + 1.0; state->p1 = np1; state->p2 = np2;
-      __threadfence();
-      atomicExch(&state->ticket, 0ull);
-    }
-  }
 }
+__global__ void k_adam_advance(double* state, float b1, float b2) { adam_state_advance(state, b1, b2); }
 
 __global__ __launch_bounds__(64) void k_ifetch_probe(float* out, unsigned long long* t, float a, float b) {
   float x = (float)threadIdx.x;
@@ -130,16 +121,23 @@ extern "C" int rd_adam_step(int64_t n, float* param, const float* grad, float* e
   return check_launch("k_adam");
 }
 
-// rd_adam_step with the step state on the device: `state` = 64 bytes {t, beta1^t, beta2^t, lr, ticket (u64, 0), weight_decay, 0, 0}
-// (doubles but for the ticket) -- ONE launch a hipGraph can replay; the launch's last workgroup advances {t, beta^t}.
+// rd_adam_step with the step state on the device: `state` = 64 bytes {t, beta1^t, beta2^t, lr, -, weight_decay, -, -} (doubles) OF THE
+// STEP BEING APPLIED (advanced beforehand: rd_adam_state_advance, or the step's first launch after rd_set_adam_state) -- ONE launch a
+// hipGraph can replay, read-only on the state.
 extern "C" int rd_adam_step_dev(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                                float beta1, float beta2, float eps, void* state, void* stream) {
+                                float beta1, float beta2, float eps, const void* state, void* stream) {
   RD_REQUIRE(n > 0 && state != nullptr, "bad n / NULL optimizer state");
   RD_REQUIRE(param && grad && exp_avg && exp_avg_sq, "NULL tensor");
   RD_REQUIRE(((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
                reinterpret_cast<uintptr_t>(exp_avg_sq) | reinterpret_cast<uintptr_t>(state)) & 15) == 0, "buffers must be 16-byte aligned");
   const long threads = (n + 3) / 4;
   hipLaunchKernelGGL(k_adam_dev, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, grad,
-                     exp_avg, exp_avg_sq, (long)n, beta1, beta2, eps, (AdamState*)state);
+                     exp_avg, exp_avg_sq, (long)n, beta1, beta2, eps, (const AdamState*)state);
   return check_launch("k_adam_dev");
+}
+
+extern "C" int rd_adam_state_advance(void* state, float beta1, float beta2, void* stream) {
+  RD_REQUIRE(state != nullptr && (reinterpret_cast<uintptr_t>(state) & 15) == 0, "NULL / misaligned optimizer state");
+  hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, (double*)state, beta1, beta2);
+  return check_launch("k_adam_advance");
 }

@@ -65,7 +65,9 @@ struct SplitJob { const float* W; int N, K, transpose; __bf16* hi; __bf16* lo; i
 constexpr int WS_MAXJOBS = 48, WS_MAXONES = 4;
 struct SplitJobs { SplitJob j[WS_MAXJOBS]; int n; __bf16* ones[WS_MAXONES];   // ones: constant tiles of the weight-gradient streams (or null)
                    // optional: the step's token plan (rd_plan.h) by the workgroup (0, n) of the same launch (rd_step_begin)
-                   const int64_t* plan_lengths; int32_t* plan_out; int plan_B, plan_T, plan_first; uint64_t* seed_cell; uint64_t seed_delta; };
+                   const int64_t* plan_lengths; int32_t* plan_out; int plan_B, plan_T, plan_first; uint64_t* seed_cell; uint64_t seed_delta;
+                   // optional: the optimizer's device step state (rd_set_adam_state), advanced once per launch next to the seed bump
+                   double* adam_state; float adam_b1, adam_b2; };
 
 // Output: NATIVE MFMA operand tiles [ntile = rows/16][kc = cols_p/32][hi, lo][64 lanes][8] (one contiguous kilobyte per
 // wave-load; rd_k1_layout.h has the measurement: 61 B/clk/CU against 16 B/clk for a row-major plane).  `hi` is the
@@ -79,6 +81,7 @@ __global__ __launch_bounds__(256) void k_wsplit(SplitJobs jobs) {
   const int job = (jobs.plan_out && jobs.plan_first) ? (int)blockIdx.y - 1 : (int)blockIdx.y;
   if (job < 0 || job == jobs.n) {
     extern __shared__ __attribute__((aligned(16))) int wsm_plan[];
+    if (blockIdx.x == 0 && threadIdx.x == 64 && jobs.adam_state) adam_state_advance(jobs.adam_state, jobs.adam_b1, jobs.adam_b2);
     plan::token_plan_part(jobs.plan_lengths, jobs.plan_out, jobs.plan_B, jobs.plan_T, jobs.seed_cell, jobs.seed_delta, wsm_plan, blockIdx.x, gridDim.x);
     return;
   }
@@ -500,6 +503,7 @@ int launch_wsplit_plan(int njobs, const WsplitSpec* specs, int nones, void* cons
   static const int plan_first = [] { const char* e = getenv("RD_PLAN_FIRST"); return !(e && atoi(e) == 0); }();
   jobs.plan_first = plan_first;
   jobs.plan_lengths = lengths; jobs.plan_out = plan_out; jobs.plan_B = B; jobs.plan_T = T; jobs.seed_cell = seed_cell_dev; jobs.seed_delta = delta;
+  if (plan_out) { const AdamCellReg ac = adam_cell(); jobs.adam_state = ac.state; jobs.adam_b1 = ac.b1; jobs.adam_b2 = ac.b2; }
   for (int i = 0; i < nones; ++i) jobs.ones[i] = (__bf16*)ones[i];
   for (int i = 0; i < njobs; ++i) {
     SplitJob& j = jobs.j[i];

@@ -167,5 +167,12 @@ def forward(model, src, static, times, lengths):
             return None
         runners[key] = r
     if r.busy():                                                       # the previous captured call may still be backpropagated: leave its activations alone
+        r.busy_hits = getattr(r, "busy_hits", 0) + 1
+        if r.busy_hits == 8:                                           # e.g. a loop that appends un-detached logits to a list: say so once
+            import warnings
+            warnings.warn("raindrop_amd.graph_module: 8 training forwards in a row found the previous captured call still waiting for "
+                          "its backward (its output is kept alive without loss.backward()): these calls run operator by operator, "
+                          "~3x slower.  Detach what you keep (outputs.detach()), or set model.graph_step = False to silence this.")
         return None
+    r.busy_hits = 0
     return _GraphStep.apply(r, src, static, times, lengths, *r.params)

@@ -40,19 +40,29 @@ class FlatAdam:
                   float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
                   self.t, ops._stream())
 
-    def step_captured(self):
-        """The update as ONE launch a hipGraph can hold (rd_adam_step_dev: step count, beta^t, lr and weight decay live on the
-        device; the launch's last workgroup advances the count).  Call it inside a capture
-        (raindrop_amd.step.TrainStep.capture_full); every replay is one step -- the owner of the graph keeps `self.t` in step
+    def step_captured(self, advance=True):
+        """The update as launches a hipGraph can hold (rd_adam_step_dev: step count, beta^t, lr and weight decay live on the device).
+        advance=True: a one-thread launch first moves the device state to this step (rd_adam_state_advance); advance=False: the
+        caller's step already did (raindrop_amd.step.TrainStep.capture_full registers the cell -- `register_cell` -- and its first
+        launch advances it: no extra launch).  Every replay is one step -- the owner of the graph keeps `self.t` in step
         (`note_replay`) and pushes a changed lr / weight decay with `sync_cell_hyper` (no new capture)."""
         self.sync_step_cell(create_only=True)
         p, g = self.param.data, self.param.grad
+        if advance:
+            _lib.call("rd_adam_state_advance", ops._ptr(self.step_cell), float(self.betas[0]), float(self.betas[1]), ops._stream())
         _lib.call("rd_adam_step_dev", p.numel(), ops._ptr(p), ops._ptr(g), ops._ptr(self.exp_avg), ops._ptr(self.exp_avg_sq),
                   float(self.betas[0]), float(self.betas[1]), float(self.eps), ops._ptr(self.step_cell), ops._stream())
 
+    def register_cell(self, on=True):
+        """(Un)register the device step state with this host thread's next rd_step_begin launches (include/raindrop_hip.h
+        rd_set_adam_state): the step's first launch then advances it."""
+        self.sync_step_cell(create_only=True)
+        _lib.call("rd_set_adam_state", ops._ptr(self.step_cell) if on else None, float(self.betas[0]), float(self.betas[1]))
+
     def sync_step_cell(self, create_only=False):
         """Make the device step state agree with `self.t`, `self.lr`, `self.weight_decay` (before capturing, after load_state_dict,
-        after eager steps).  Layout (include/raindrop_hip.h rd_adam_step_dev): {t, beta1^t, beta2^t, lr, ticket = 0, wd, 0, 0}."""
+        after eager steps).  Layout (include/raindrop_hip.h rd_adam_step_dev): {t, beta1^t, beta2^t, lr, 0, wd, 0, 0} with t = steps TAKEN (the step's
+        advance launch moves it to the step being applied)."""
         fresh = getattr(self, "step_cell", None) is None
         if fresh:
             self.step_cell = torch.zeros((8,), dtype=torch.float64, device=self.param.device)

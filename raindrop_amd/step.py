@@ -611,19 +611,29 @@ class TrainStep:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(g):
-                if self.split:
-                    off = self.early_grad_offset()
-                    self._body("a")
-                    h1 = flat.allreduce_range_async(off, flat.flat.numel())
-                    self._body("b")
-                    h0 = flat.allreduce_range_async(0, off)
-                    flat.allreduce_wait(h1)
-                    flat.allreduce_wait(h0)
-                else:
-                    self._body()
-                    flat.allreduce()
-                opt.step_captured()
+            # the optimizer's device step state is advanced by the step's FIRST launch (rd_step_begin, next to the seed bump) where
+            # the step has that launch -- registered for the capture only --, else by a one-thread launch in front of the update
+            begin_adv = self.plan is not None and (self.prep_enc or self.prep_k1) and self.one_begin
+            try:
+                with torch.no_grad(), torch.cuda.graph(g):
+                    if begin_adv:
+                        opt.register_cell(True)
+                    if self.split:
+                        off = self.early_grad_offset()
+                        self._body("a")
+                        opt.register_cell(False)
+                        h1 = flat.allreduce_range_async(off, flat.flat.numel())
+                        self._body("b")
+                        h0 = flat.allreduce_range_async(0, off)
+                        flat.allreduce_wait(h1)
+                        flat.allreduce_wait(h0)
+                    else:
+                        self._body()
+                        opt.register_cell(False)
+                        flat.allreduce()
+                    opt.step_captured(advance=not begin_adv)
+            finally:
+                opt.register_cell(False)
             self.graph_full = g
         self._with_cell(cap)
         opt.sync_step_cell()                                               # the warm-up did not step the optimizer; neither did the capture

@@ -36,7 +36,8 @@ def golden_dir():
 def _eager_operator_surface(request, monkeypatch):
     """The parity tests of this suite exercise the operator-by-operator surface of the module (one C-ABI call per operator under
     autograd); since round 5 a training call takes the captured step by default (raindrop_amd/graph_module.py), which
-    tests/test_graph_module_gpu.py covers -- that file manages the switch itself, every other test runs with it off."""
-    if "test_graph_module_gpu" not in request.node.nodeid:
+    tests/test_graph_module_gpu.py covers -- that file and tests/test_trajectory_gpu.py manage the switch themselves, the golden /
+    reference-parity tests of tests/test_gpu_parity.py run BOTH ways (model.graph_step False / True), every other test with it off."""
+    if "test_graph_module_gpu" not in request.node.nodeid and "test_trajectory_gpu" not in request.node.nodeid:
         monkeypatch.setenv("RD_MODULE_GRAPH", "0")
     yield

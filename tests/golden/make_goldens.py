@@ -44,7 +44,7 @@ MODEL_CASES = [
     # heads of 520): two samples are what the CPU reference finishes in minutes
     ("syn256_b2", "SYN256", 2, "sparse", 8, 10),
 ]
-FULL_LIMIT = {"p19_b256": 4096, "p12_b32": 4096, "syn256_b2": 4096, "p19_beta_sparse": 4096, "p19_beta_ones": 4096,
+FULL_LIMIT = {"p19_x3_sparse": 4096, "p19_b256": 4096, "p12_b32": 4096, "syn256_b2": 4096, "p19_beta_sparse": 4096, "p19_beta_ones": 4096,
               "p12_beta_sparse": 4096, "wide80_beta_sparse": 4096}
 # the paper's branch: the reference with its `use_beta = False` literal (code/models_rd.py:317) flipped IN MEMORY by
 # oracle/ref_loader.load_models_rd_with_beta(); Raindrop_v2(use_beta=True, compute_distance=True) here
@@ -54,6 +54,62 @@ BETA_CASES = [
     ("p12_beta_sparse", "P12", 3, "sparse", 15, 16),
     ("wide80_beta_sparse", "WIDE80", 3, "sparse", 17, 18),     # 80 sensors: the graph operator's workspace form at model level
 ]
+
+
+# Weights at 3x the init scale (matrices ~ U(+-3/sqrt(fan_in))): activations, scores and gradients an order of magnitude above
+# the other fixtures' -- where the margin of the split-bf16 products and of the softmax / LayerNorm rounding would show first
+# (reduced-precision margins "must be re-checked" away from init-scale weights).
+SCALED_CASES = [("p19_x3_sparse", "P19", 32, "sparse", 31, 32, 3.0)]
+# Trajectory: TRAJ_STEPS steps of the reference's own loop body (code/Raindrop.py:319-324: forward, zero_grad, CrossEntropyLoss,
+# backward, Adam step) on TRAJ_STEPS different batches, dropout 0; lr 1e-3 (10x the script's) so that 20 steps MOVE the weights.
+TRAJ_STEPS, TRAJ_LR, TRAJ_B = 20, 1e-3, 32
+TRAJ_WEIGHTS = ("R_u", "ob_propagation.lin_value.weight", "ob_propagation_layer2.lin_value.bias",
+                "transformer_encoder.layers.0.self_attn.in_proj_weight", "transformer_encoder.layers.1.linear2.weight",
+                "transformer_encoder.layers.1.norm2.weight", "mlp_static.0.weight", "mlp_static.2.weight", "emb.weight")
+
+
+def traj_case(name="p19_traj20", cfg_name="P19", kind="sparse", pseed=41, bseed0=300):
+    """Trained-weight parity (VERDICT r5 missing #3): the state after TRAJ_STEPS optimizer steps of the REFERENCE's model under the
+    reference's loop body, every step on a new batch.  Stored: the loss of every step, the logits of the last step's forward, the
+    eval-mode logits of a held-out batch under the final weights, and the final values of TRAJ_WEIGHTS (strided samples)."""
+    cfg = synth.make_config(cfg_name)
+    gs = synth.make_structure(cfg, kind)
+    model = ref_loader.build_raindrop_v2(cfg, gs.clone())
+    synth.fill_params_(model, seed=pseed)
+    zero_dropout(model)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=TRAJ_LR)                  # code/Raindrop.py:256
+    crit = torch.nn.CrossEntropyLoss()                                     # :255
+    losses, last = [], None
+    for i in range(TRAJ_STEPS):
+        b = synth.make_batch(cfg, TRAJ_B, seed=bseed0 + i)
+        outputs, _, _ = ref_loader.forward(model, b["src"], b["static"], b["times"], b["lengths"])   # :319
+        opt.zero_grad()                                                    # :321
+        loss = crit(outputs, b["y"])                                       # :322
+        loss.backward()                                                    # :323
+        opt.step()                                                         # :324
+        losses.append(float(loss))
+        last = outputs.detach()
+    held = synth.make_batch(cfg, TRAJ_B, seed=bseed0 + 1000)
+    model.eval()
+    with torch.no_grad():
+        held_logits, _, _ = ref_loader.forward(model, held["src"], held["static"], held["times"], held["lengths"])
+    params = dict(model.named_parameters())
+    init = {n: synth.param_values(n, params[n].shape, pseed) for n in TRAJ_WEIGHTS}
+    out = dict(meta=json.dumps(dict(name=name, cfg=cfg_name, batch=TRAJ_B, structure=kind, param_seed=pseed, batch_seed0=bseed0,
+                                    held_out_seed=bseed0 + 1000, steps=TRAJ_STEPS, lr=TRAJ_LR, torch=torch.__version__)),
+               losses=np.array(losses, dtype=np.float64), last_logits=last.numpy(), held_logits=held_logits.numpy())
+    for n in TRAJ_WEIGHTS:
+        s_, st = strided(params[n].detach(), full_limit=4096)
+        out["w/" + n] = s_
+        out["wstride/" + n] = np.int64(st)
+        out["wmoved/" + n] = np.float64((params[n].detach() - init[n]).double().norm().item())   # how far 20 steps moved it
+        out["wnorm/" + n] = np.float64(params[n].detach().double().norm().item())
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-12s %d steps, loss %.5f -> %.5f, moved %s -> %s (%.1f KB)" % (
+        name, TRAJ_STEPS, losses[0], losses[-1], {n.split(".")[-2] if "." in n else n: "%.3g" % out["wmoved/" + n] for n in TRAJ_WEIGHTS[:3]},
+        os.path.basename(path), os.path.getsize(path) / 1024))
 
 
 def strided(t, n=SAMPLE, full_limit=70_000):
@@ -73,11 +129,11 @@ def zero_dropout(model):
             mod.dropout = 0.0
 
 
-def model_case(name, cfg_name, B, kind, pseed, bseed, use_beta=False):
+def model_case(name, cfg_name, B, kind, pseed, bseed, use_beta=False, scale=1.0):
     cfg = synth.make_config(cfg_name)
     gs = synth.make_structure(cfg, kind)
     model = ref_loader.build_raindrop_v2(cfg, gs.clone(), use_beta=use_beta)
-    synth.fill_params_(model, seed=pseed)
+    synth.fill_params_(model, seed=pseed, scale=scale)
     zero_dropout(model)
     b = synth.make_batch(cfg, B, seed=bseed)
 
@@ -111,7 +167,7 @@ def model_case(name, cfg_name, B, kind, pseed, bseed, use_beta=False):
 
     ei, ew = O2.build_graph(gs.numpy())
     out = dict(
-        meta=json.dumps(dict(name=name, cfg=cfg_name, batch=B, structure=kind, param_seed=pseed,
+        meta=json.dumps(dict(name=name, cfg=cfg_name, batch=B, structure=kind, param_seed=pseed, param_scale=scale,
                              batch_seed=bseed, o2_vs_o1_logit=e_logit, o2_vs_o1_grad_rel=e_grad,
                              torch=torch.__version__)),
         logits=logits.detach().numpy(), logits_eval=logits_eval.numpy(),
@@ -371,3 +427,8 @@ if __name__ == "__main__":
     for case in BETA_CASES:
         if not only or case[0] in only:
             model_case(*case, use_beta=True)
+    for case in SCALED_CASES:
+        if not only or case[0] in only:
+            model_case(*case[:6], scale=case[6])
+    if not only or "p19_traj20" in only:
+        traj_case()

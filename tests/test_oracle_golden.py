@@ -19,7 +19,7 @@ def _params(cfg, gs, meta, live):
     import os
     from tests.helpers import GOLDEN
     surf = json.load(open(os.path.join(GOLDEN, "state_dict_surface.json")))[meta["cfg"]]
-    return {k: synth.param_values(k, surf[k], meta["param_seed"]).requires_grad_(True)
+    return {k: synth.param_values(k, surf[k], meta["param_seed"], float(meta.get("param_scale", 1.0))).requires_grad_(True)
             for k in sorted(surf) if k in live}
 
 
