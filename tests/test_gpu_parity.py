@@ -35,19 +35,47 @@ def _rel2(a, b):
     return float(np.linalg.norm((a - b).ravel().astype(np.float64)) / (np.linalg.norm(b.ravel().astype(np.float64)) + 1e-30))
 
 
-def _grad_close(a, b, tol, name=""):
-    """Gradient comparison.  fp32 mode: max-norm relative error < tol.  Split-bf16 mode: forward
-    values differ from the reference at the 1e-5 level, so the few ReLU gates whose pre-activation
-    lies within ~1e-5 of zero open/close differently.  ReLU's derivative is discontinuous there:
-    ONE flipped gate moves one row of a weight gradient by |dh|*|x| (measured: 3e-3..8e-3 of the
-    matrix's L2 norm at a few hundred tokens) while every other entry agrees to ~1e-5.  The
-    criterion in that mode is therefore a 2 % relative-L2 bound plus a max-norm bound that still
-    catches any layout / indexing bug (those produce O(1) errors); the exact-fp32 mode keeps the
-    tight bound on the very same kernels and code paths."""
+def _grad_close(a, b, tol, name="", clear=None, tight=False):
+    """Gradient comparison against a reference gradient (O1 fixture).  fp32 mode: max-norm relative error < tol.
+    Split-bf16 mode: forward values differ from the reference at the 1e-5 level, so the few ReLU gates whose pre-activation lies
+    within ~1e-5 of zero open / close differently.  ReLU's derivative is discontinuous there: ONE flipped gate moves the row of
+    that unit in its Linear's weight gradient by |dh| |x| (measured: 1e-3..8e-3 of the matrix's L2 norm at a few hundred rows),
+    and -- through the input gradient of that one row -- every gradient upstream by a little, while all other entries agree to
+    ~1e-5.  Operator-level comparisons at a few hundred rows keep rounds 1-5's bounds for that mode (relative L2 < 2e-2,
+    max-norm < 0.25: one flip among 360 tokens is 8e-3 / 7e-2; layout / indexing bugs produce O(1) errors).  `tight` -- the
+    whole-model comparisons against the O1 fixtures at B >= 32 (numbers: tools/grad_gate_diag.py,
+    profiles/r06_grad_gate_diag.txt):
+      * all entries: relative L2 < 5e-3 and max-norm < 2e-2 (measured worst 3.3e-3 / 8.6e-3 over the fixtures);
+      * `clear` (bool per sampled entry: the entry's unit is NOT on a ReLU fence by the fp32 restatement, tests/helpers
+        .gate_unit_masks): relative L2 over those entries < 1e-3 for the encoder's and the head's Linear layers (measured 7e-6..
+        3e-4; their own flipped rows were the whole 1e-3 error).  The two message-passing layers get no tighter bound from the
+        mask: a flipped layer-2 gate perturbs one (sample, sensor) row of dZ1 and with it EVERY unit's row of dW1, and only
+        ~10 of a sample's 34 sensor rows carry observations -- a few hundred effective rows in the sum (measured 3e-4..3.3e-3
+        with or without the fenced units).
+    The exact-fp32 mode keeps the tight max-norm bound on the very same kernels and code paths."""
     if TOL["x"] == 1.0:
         assert _rel(a, b) < tol, (name, _rel(a, b))
-    else:
+        return
+    if not tight:
         assert _rel2(a, b) < 2e-2 and _rel(a, b) < 0.25, (name, _rel2(a, b), _rel(a, b))
+        return
+    assert _rel2(a, b) < 5e-3 and _rel(a, b) < 2e-2, (name, _rel2(a, b), _rel(a, b))
+    if clear is not None and clear.any() and not name.startswith("ob_propagation"):
+        assert _rel2(a[clear], b[clear]) < 1e-3, (name, "entries of units off the ReLU fences", _rel2(a[clear], b[clear]), int((~clear).sum()))
+
+
+def _clear_entries(masks, name, param, stride, n):
+    """bool [n]: sampled entry i (flat index i * stride of `param`) belongs to a unit that is not on a ReLU fence; None if the
+    parameter feeds no ReLU."""
+    if masks is None or name not in masks:
+        return None
+    cols = param.shape[1] if param.dim() == 2 else 1
+    unit = (np.arange(n) * stride) // cols
+    return ~masks[name][unit]
+
+
+def _grad_close_masked(a, b, tol, name):
+    return _grad_close(a, b, tol, name, tight=True)
 
 
 @pytest.mark.parametrize("F,kind", [(1, "ones"), (5, "sparse"), (17, "ones"), (34, "sparse"), (36, "ones"),
@@ -185,9 +213,12 @@ def test_model_vs_golden(name, graph_step):
     params = dict(m.named_parameters())
     live = [str(x) for x in g["live"]]
     assert sorted(n for n, p in params.items() if p.grad is not None) == sorted(live)
+    from tests.helpers import gate_unit_masks
+    tight = meta["cfg"] in ("P19", "P12") and meta["batch"] >= 32          # TINY / PAM / SYN256 fixtures are 2-4 samples: a flip weighs more
+    masks = gate_unit_masks(meta) if (TOL["x"] != 1.0 and tight) else None
     for n in live:
         exp, got = golden_grad(g, n, params[n].grad)
-        _grad_close(got, exp, 1e-3, n)
+        _grad_close(got, exp, 1e-3, n, _clear_entries(masks, n, params[n], int(g["gradstride/" + n]), exp.size), tight=tight)
         gn = float(g["gradnorm/" + n])
         assert abs(params[n].grad.double().norm().item() - gn) <= 1e-3 * gn + 1e-12, n
     m.eval()
