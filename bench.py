@@ -828,21 +828,43 @@ def main():
         from raindrop_amd.step import TrainStep
         tstep = TrainStep(model, flat, batch)
 
-    # The whole step -- forward + loss + backward, the all-reduce(s) and Adam -- as ONE hipGraph (TrainStep.capture_full, round 5): the
-    # default on one GPU (same kernels, one replay per step on the host); at N > 1 opt-in (RD_STEP_FULL=1: RCCL collectives under
-    # stream capture are tested on a one-rank group only -- tests/test_dp_gpu.py -- so the default there stays two graphs + eager
-    # collectives + the Adam launch).  A failed capture falls back to that form.
+    # The whole step -- forward + loss + backward, the all-reduce(s) and Adam -- as ONE hipGraph (TrainStep.capture_full): one replay
+    # per step on the host.  Round 5: default on one GPU, opt-in at N > 1.  Round 6: the default at every N (RD_STEP_FULL=0: the
+    # two-graph step with eager collectives + the Adam launch) -- behind two guards, because RCCL under stream capture has only run
+    # on a one-rank group here (tests/test_dp_gpu.py): (1) the capture is tried per rank and the outcome agreed by an all-reduce(MIN),
+    # so either every rank replays the whole-step graph or none does; (2) the first replays are checked: three whole-step replays
+    # must leave finite losses on every rank, else all ranks drop back to the two-graph form (the parameters are restored first).
     full_graph = [False]
-    if tstep is not None and not args.no_optimizer and os.environ.get("RD_STEP_FULL", "1" if world == 1 else "0") == "1":
+    if tstep is not None and not args.no_optimizer and os.environ.get("RD_STEP_FULL", "1") == "1":
+        snap = None
         try:
+            if world > 1:
+                snap = (opt.param.detach().clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.t, tstep.seed_cell.clone())
             tstep.capture_full(opt)
             full_graph[0] = True
         except Exception as e:                                   # pragma: no cover
             print("capture_full failed (%r): two-part step" % (e,), file=sys.stderr, flush=True)
-    if world > 1:                                               # a collective decision, like the probe above
-        fk = torch.tensor([1.0 if full_graph[0] else 0.0], dtype=torch.float64, device=dev)
-        dist.all_reduce(fk, op=dist.ReduceOp.MIN)
-        full_graph[0] = bool(fk.item() > 0.5)
+        if world > 1:                                            # a collective decision, like the probe above
+            fk = torch.tensor([1.0 if full_graph[0] else 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(fk, op=dist.ReduceOp.MIN)
+            full_graph[0] = bool(fk.item() > 0.5)
+            if full_graph[0]:                                    # guard (2): probe replays
+                ok = 1.0
+                try:
+                    for _ in range(3):
+                        l_ = tstep.run_full()
+                    torch.cuda.synchronize()
+                    ok = 1.0 if bool(torch.isfinite(l_).item()) else 0.0
+                except Exception as e:                           # pragma: no cover
+                    print("whole-step graph replay failed (%r): two-part step" % (e,), file=sys.stderr, flush=True)
+                    ok = 0.0
+                fk = torch.tensor([ok], dtype=torch.float64, device=dev)
+                dist.all_reduce(fk, op=dist.ReduceOp.MIN)
+                if fk.item() < 0.5:
+                    full_graph[0] = False
+                    with torch.no_grad():
+                        opt.param.data.copy_(snap[0]); opt.exp_avg.copy_(snap[1]); opt.exp_avg_sq.copy_(snap[2])
+                    opt.t = snap[3]; tstep.seed_cell.copy_(snap[4]); opt._cell_stale = True
 
     def graph_step():
         if feed_next is not None:

@@ -335,6 +335,10 @@ int rd_set_adam_state(void* state, float beta1, float beta2);      /* NULL: unre
 /* y[M,N] = act(x[M,K] W[N,K]^T + b)   (torch.nn.functional.linear; act: 0 none, 1 relu). */
 int rd_linear_fwd(int32_t M, int32_t N, int32_t K, const float* x, int32_t ldx, const float* W,
                   const float* b, float* y, int32_t ldy, int32_t act, void* stream);
+/* The same product on the exact-fp32 matrix instruction whatever the process's arithmetic mode (rd_set_precision): for values that
+ * feed index work (code/Ob_propagation.py:161-185: edge scores -> top-K pruning).  Affects this call only, on this host thread. */
+int rd_linear_fwd_fp32(int32_t M, int32_t N, int32_t K, const float* x, int32_t ldx, const float* W,
+                       const float* b, float* y, int32_t ldy, int32_t act, void* stream);
 /* dx[M,K] = dy[M,N] W[N,K]   (optionally masked by relu_src > 0 when relu_src != NULL). */
 int rd_linear_bwd_input(int32_t M, int32_t N, int32_t K, const float* dy, int32_t lddy,
                         const float* W, float* dx, int32_t lddx, void* stream);

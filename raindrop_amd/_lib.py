@@ -95,6 +95,7 @@ SIGNATURES = {
     "rd_adam_state_advance": (c_int32, [_P, c_float, c_float, _P]),
     "rd_set_adam_state": (c_int32, [_P, c_float, c_float]),
     "rd_linear_fwd": (c_int32, [c_int32, c_int32, c_int32, _P, c_int32, _P, _P, _P, c_int32, c_int32, _P]),
+    "rd_linear_fwd_fp32": (c_int32, [c_int32, c_int32, c_int32, _P, c_int32, _P, _P, _P, c_int32, c_int32, _P]),
     "rd_linear_bwd_input": (c_int32, [c_int32, c_int32, c_int32, _P, c_int32, _P, _P, c_int32, _P]),
     "rd_linear_bwd_input_gated": (c_int32, [c_int32, c_int32, c_int32, _P, c_int32, _P, _P, c_int32, _P, c_int32, _P]),
     "rd_softmax_xent": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _P]),

@@ -22,7 +22,10 @@ static thread_local AdamCellReg g_adam_cell = {nullptr, 0.f, 0.f};
 AdamCellReg adam_cell() { return g_adam_cell; }
 
 static int g_precision = -1;
+// per-call override on THIS host thread (rd_linear_fwd_fp32): the mode is read when a launch is chosen, at enqueue
+static thread_local int g_precision_override = -1;
 int precision() {
+  if (g_precision_override >= 0) return g_precision_override;
   if (g_precision < 0) {
     const char* e = getenv("RD_PRECISION");
     g_precision = (e && strcmp(e, "fp32") == 0) ? RD_PREC_FP32 : ((e && strcmp(e, "bf16") == 0) ? RD_PREC_BF16 : RD_PREC_BF16X3);
@@ -180,6 +183,15 @@ extern "C" int rd_linear_fwd(int32_t M, int32_t N, int32_t K, const float* x, in
   g.C = y; g.sc_m = ldy;
   g.bias = b; g.relu = act;
   return launch_gemm(g, (hipStream_t)stream);
+}
+
+// rd_linear_fwd on the exact-fp32 matrix instruction whatever the process's arithmetic mode: for values that feed INDEX work (the
+// use_beta branch's edge scores -> top-K pruning; index work is bit-exact by contract).  The override is thread-local and lasts for
+// this enqueue only: no other host thread ever sees a changed mode (the Python side used to toggle rd_set_precision).
+extern "C" int rd_linear_fwd_fp32(int32_t M, int32_t N, int32_t K, const float* x, int32_t ldx,
+                                  const float* W, const float* b, float* y, int32_t ldy, int32_t act, void* stream) {
+  struct Scope { Scope() { g_precision_override = RD_PREC_FP32; } ~Scope() { g_precision_override = -1; } } scope;
+  return rd_linear_fwd(M, N, K, x, ldx, W, b, y, ldy, act, stream);
 }
 
 extern "C" int rd_linear_bwd_input(int32_t M, int32_t N, int32_t K, const float* dy, int32_t lddy,

@@ -166,17 +166,11 @@ class _Linear(torch.autograd.Function):
         x2 = x.reshape(-1, K)
         M = x2.shape[0]
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        # exact: the product on the fp32 matrix instruction (bitwise an fmaf chain) whatever the process's precision mode -- for values
-        # that feed INDEX work (the use_beta branch's edge scores -> top-K pruning): a few MFLOP, and index work is bit-exact by contract.
-        # The mode is read when a launch is chosen (host side, at enqueue), so switching it around one call is safe on one host thread.
-        prev = _lib.load().rd_get_precision() if exact else None
-        if exact and prev != 0:
-            _lib.call("rd_set_precision", 0)
-        try:
-            _lib.call("rd_linear_fwd", M, N, K, _ptr(x2), K, _ptr(W), _ptr(b), _ptr(y), N, int(act), _stream())
-        finally:
-            if exact and prev != 0:
-                _lib.call("rd_set_precision", prev)
+        # exact: the product on the fp32 matrix instruction (bitwise an fmaf chain) whatever the process's precision mode
+        # (rd_linear_fwd_fp32: a per-call, per-thread override inside the library; round 5 toggled the process-wide mode around the
+        # call) -- for values that feed INDEX work (the use_beta branch's edge scores -> top-K pruning): a few MFLOP, and index work is
+        # bit-exact by contract
+        _lib.call("rd_linear_fwd_fp32" if exact else "rd_linear_fwd", M, N, K, _ptr(x2), K, _ptr(W), _ptr(b), _ptr(y), N, int(act), _stream())
         ctx.act = int(act)
         ctx.has_bias = b is not None
         ctx.save_for_backward(x2, W, y if act else None)
