@@ -835,7 +835,9 @@ def main():
     # so either every rank replays the whole-step graph or none does; (2) the first replays are checked: three whole-step replays
     # must leave finite losses on every rank, else all ranks drop back to the two-graph form (the parameters are restored first).
     full_graph = [False]
-    if tstep is not None and not args.no_optimizer and os.environ.get("RD_STEP_FULL", "1") == "1":
+    # (only RCCL collectives can be captured: the gloo group of the RD_BENCH_ONE_GPU test mode synchronises on the host)
+    can_capture = world == 1 or dist.get_backend() == "nccl"
+    if tstep is not None and not args.no_optimizer and can_capture and os.environ.get("RD_STEP_FULL", "1") == "1":
         snap = None
         try:
             if world > 1:

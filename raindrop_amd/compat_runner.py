@@ -14,7 +14,8 @@ via `runpy`, inside a scratch workspace that provides
 and with process-level compat patches that do not touch the script: `ReduceLROnPlateau` drops the
 removed `verbose` kwarg (`code/Raindrop.py:257-259`), `utils_rd.getStats` gets a numpy-2-safe
 scalar max (`code/utils_rd.py:160` fails on numpy >= 1.24), numpy is seeded (the script only seeds
-torch), and `wandb` stays disabled.
+torch), `torch.optim.Adam` gets torch's own fused implementation where every parameter is a CUDA tensor (same algorithm, one or two
+launches instead of a dozen), and `wandb` stays disabled.
 
 The writer half (`write_dataset`) is validated against the reference's own loader in
 `tests/test_compat_dataset.py`.  The end-to-end run with the HIP model needs BOTH a GPU and the reference
@@ -131,6 +132,20 @@ def _compat_patches(seed):
     def init(self, *a, verbose=None, **k):      # kwarg removed in torch >= 2.7 (code/Raindrop.py:259)
         return orig(self, *a, **k)
     torch.optim.lr_scheduler.ReduceLROnPlateau.__init__ = init
+    # torch.optim.Adam(model.parameters(), lr=..) (code/Raindrop.py:256) picks the multi-tensor "foreach" implementation by default:
+    # ~12 launches and 0.28 ms of host time per step over this model's 100+ parameter tensors, as much as the whole captured
+    # forward + backward.  torch's own FUSED implementation (same algorithm, one or two launches) is selected instead when every
+    # parameter is a CUDA tensor and the script did not choose an implementation itself (RD_COMPAT_FUSED_ADAM=0: leave the default).
+    if os.environ.get("RD_COMPAT_FUSED_ADAM", "1") != "0":
+        orig_adam = torch.optim.Adam.__init__
+
+        def adam_init(self, params, *a, **k):
+            params = list(params)
+            flat = [q for p in params for q in (p["params"] if isinstance(p, dict) else [p])]
+            if "fused" not in k and "foreach" not in k and flat and all(isinstance(q, torch.Tensor) and q.is_cuda and q.is_floating_point() for q in flat):
+                k["fused"] = True
+            return orig_adam(self, params, *a, **k)
+        torch.optim.Adam.__init__ = adam_init
 
 
 def run(root, dataset, n_samples, reference, seed=0, extra_argv=(), model_shim=None):

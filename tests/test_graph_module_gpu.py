@@ -194,3 +194,43 @@ def test_module_graph_step_keeps_a_bounded_number_of_runners(monkeypatch):
         assert abs(loss_g - loss_e) < 5e-6 and all(_close(g_g[n], g_e[n]) for n in live)
         assert len(m._graph_runners) <= 2
     assert sorted(k[1] for k in m._graph_runners) == [4, 8]      # 6 was the oldest when 4 came back
+
+
+@pytest.mark.parametrize("views", ["1", "0"], ids=["grad_views", "returned_clones"])
+def test_module_graph_step_keeps_autograd_s_accumulation_semantics(views, monkeypatch):
+    """Round 6: the captured backward node SETS each p.grad to a persistent view of its flat gradient buffer instead of returning 35
+    fresh views to autograd (RD_MODULE_GRAD_VIEWS=0: the round-5 form).  Whatever the form, the loop-visible semantics are
+    autograd's: (a) a second forward + backward without zero_grad adds to the gradients that are there, (b) zero_grad(set_to_none=
+    False) zeroes in place and the next backward starts from zero, (c) a gradient another loss term left in p.grad is added to."""
+    monkeypatch.setenv("RD_MODULE_GRAD_VIEWS", views)
+    cfg = synth.make_config("P19")
+    m = build_ours(cfg, synth.make_structure(cfg, "ones"), DEV, 7).train()
+    live = sorted(synth.live_parameter_names(cfg))
+    named = dict(m.named_parameters())
+    A, Bb = _batch(cfg, 16, 51), _batch(cfg, 16, 52)
+    _, _, gA, _ = _loop_step(m, A, False)
+    _, _, gB, _ = _loop_step(m, Bb, False)
+
+    def fb(dv):
+        m.graph_step = True
+        logits, _, _ = m(dv["src"], dv["static"], dv["times"], dv["lengths"])
+        torch.nn.functional.cross_entropy(logits, dv["y"]).backward()
+
+    for p in m.parameters():
+        p.grad = None
+    fb(A); fb(Bb)                                                  # (a) no zero_grad in between
+    for n in live:
+        assert _close(named[n].grad, gA[n] + gB[n]), ("accumulate", n)
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)
+    opt.zero_grad(set_to_none=False)                               # (b) zeroed in place
+    fb(A)
+    for n in live:
+        assert _close(named[n].grad, gA[n]), ("zero_grad in place", n)
+    opt.zero_grad(set_to_none=True)
+    n0 = "mlp_static.2.weight"
+    named[n0].grad = torch.ones_like(named[n0])                    # (c) a foreign gradient
+    fb(Bb)
+    assert _close(named[n0].grad, gB[n0] + 1.0)
+    for n in live:
+        if n != n0:
+            assert _close(named[n].grad, gB[n]), ("fresh", n)
