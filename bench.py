@@ -61,6 +61,8 @@ def parse():
                     help="arithmetic of the dense contractions (default: RD_PRECISION or bf16x3); bf16 = one product, the "
                          "'P12 bf16' configuration of BASELINE.json")
     ap.add_argument("--no-roofline", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--use-beta", action="store_true",
+                    help="the paper's branch (use_beta=True: top-K pruned, per-sample graph) as a captured step: prints tools/bench_use_beta.py's line")
     ap.add_argument("--no-graph", action="store_true",
                     help="eager autograd step instead of the hipGraph-captured static step")
     return ap.parse_args()
@@ -726,6 +728,11 @@ def main():
     import faulthandler
     faulthandler.dump_traceback_later(900, exit=True)      # never hang a GPU box silently
     args = parse()
+    if args.use_beta:                                         # a different step (AutogradStep over the composed operators): its own line
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_use_beta
+        bench_use_beta.main(["--batch", str(args.batch), "--steps", str(args.steps), "--warmup", str(args.warmup)])
+        return
     if args.precision:
         os.environ["RD_PRECISION"] = args.precision           # read by the library at its first call; children inherit it
     prec = os.environ.get("RD_PRECISION", "bf16x3")

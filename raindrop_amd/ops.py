@@ -446,6 +446,9 @@ def _colsum_rows(x):
     return dW
 
 
+_EDGES_CHECKED = set()
+
+
 def graph_beta(V, H, map_w, p_t, edge_index, edge_weights, d_ob=4):
     """use_beta branch of Observation_progation.message, batched (include/raindrop_hip.h: rd_graph_beta_fwd).  V [B,N,K],
     H [B,N,T*32], map_w [N,16], p_t [B or 1, T, 16], edge_index int64 [2,E], edge_weights [B or 1, E].  Shapes and edge
@@ -466,9 +469,19 @@ def graph_beta(V, H, map_w, p_t, edge_index, edge_weights, d_ob=4):
     if edge_weights.dim() != 2 or edge_weights.shape[0] not in (1, B) or edge_weights.shape[1] != E:
         raise ValueError("graph_beta: edge_weights must be [1 or B, E], got %s" % (tuple(edge_weights.shape),))
     if E > 0:
-        lo, hi = int(edge_index.min()), int(edge_index.max())
-        if lo < 0 or hi >= N:
-            raise IndexError("graph_beta: edge endpoint out of range [0, %d): min %d, max %d" % (N, lo, hi))
+        # validated once per edge list (keyed by storage, version and size: the model passes its cached graph every call) -- the
+        # device read would otherwise sync every step, and is not permitted while a hipGraph is being captured (AutogradStep)
+        key = (edge_index.data_ptr(), edge_index._version, E, N, str(edge_index.device))
+        if key not in _EDGES_CHECKED:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.RaindropHipError("graph_beta: this edge list has not been validated yet and a stream capture is in progress; "
+                                            "run one eager step first")
+            lo, hi = int(edge_index.min()), int(edge_index.max())
+            if lo < 0 or hi >= N:
+                raise IndexError("graph_beta: edge endpoint out of range [0, %d): min %d, max %d" % (N, lo, hi))
+            if len(_EDGES_CHECKED) > 64:
+                _EDGES_CHECKED.clear()
+            _EDGES_CHECKED.add(key)
     return _GraphBeta.apply(V.contiguous(), H.contiguous(), map_w.contiguous(), p_t.contiguous(), edge_index.contiguous(),
                             edge_weights.contiguous(), int(d_ob))
 

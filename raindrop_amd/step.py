@@ -154,6 +154,16 @@ class TrainStep:
             if lo < 0 or hi >= model.n_classes:
                 raise _lib.RaindropHipError("TrainStep: labels must lie in [0, %d), got [%d, %d]" % (model.n_classes, lo, hi))
 
+    @staticmethod
+    def _validate_shapes_only(model, batch):
+        """dtype / contiguity / device / shape / label checks of `_validate` without its refusal of the paper's branch (AutogradStep)"""
+        ub, cd = getattr(model, "use_beta", False), getattr(model, "compute_distance", False)
+        try:
+            model.use_beta, model.compute_distance = False, False
+            TrainStep._validate(model, batch)
+        finally:
+            model.use_beta, model.compute_distance = ub, cd
+
     def _param_ptrs(self):
         return tuple(p.data_ptr() for p in self.P.values()) + tuple(g.data_ptr() for g in self.G.values())
 
@@ -665,3 +675,70 @@ class TrainStep:
         self.graph_full = None
         self.graph = None
         self.graph_b = None
+
+
+class AutogradStep:
+    """Any `Raindrop_v2` -- the paper's branch (`use_beta=True` / `compute_distance=True`), which `TrainStep` refuses, included -- as ONE
+    hipGraph per training step: `model.forward -> CrossEntropyLoss -> loss.backward() -> Adam` exactly as code/Raindrop.py:319-324
+    runs them, through the module's own autograd surface (one C-ABI call per operator), captured once with static input buffers and
+    replayed.  Same kernels, same results as the eager loop (the capture only removes the host from the replay path); dropout masks
+    change per replay through a device seed cell the graph bumps itself, as in `TrainStep`.
+
+    This is the composed form of the use_beta path (obs embed -> lin_value / increase_dim -> LDS graph operator -> per-sample edge
+    softmax -> layer 2 -> tokens: ~7 launches for the sensor stage, DESIGN.md (e')), not a fused kernel; `bench.py --use-beta`
+    times it.  The optimizer is torch's own Adam in its capturable fused form over the model's parameters (the reference's
+    `torch.optim.Adam(model.parameters(), lr)`, code/Raindrop.py:256), inside the graph; `lr` is a device tensor there, so a
+    scheduler can change it without a new capture."""
+
+    def __init__(self, model, batch, lr=1e-4, optimizer=True, seed=1234):
+        self.model, self.batch = model, batch
+        self.dev = batch["src"].device
+        TrainStep._validate_shapes_only(model, batch)
+        self.seed_cell = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.opt = None
+        if optimizer:
+            self.opt = torch.optim.Adam(self.params, lr=torch.tensor(float(lr), device=self.dev), capturable=True, fused=True)
+        self.loss = torch.zeros((), dtype=torch.float32, device=self.dev)
+        self.logits = None
+        self.distance = None
+        model.graph_step = False                                  # the operator surface is what gets captured
+        self._capture()
+
+    def _one(self):
+        b = self.batch
+        logits, distance, _ = self.model(b["src"], b["static"], b["times"], b["lengths"])
+        loss = torch.nn.functional.cross_entropy(logits, b["y"])
+        loss.backward()
+        if self.opt is not None:
+            self.opt.step()
+        return logits, distance, loss
+
+    def _capture(self):
+        _lib.call("rd_set_seed_cell", _p(self.seed_cell))
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):                                 # warm-up: lazy initialisations, the optimizer's state tensors
+                    for p in self.params:
+                        p.grad = None
+                    self._one()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            for p in self.params:
+                p.grad = None                                      # the captured backward ALLOCATES the gradients (static addresses)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                _lib.call("rd_seed_cell_advance", _p(self.seed_cell), 1, ops._stream())
+                logits, distance, loss = self._one()
+                self.loss_static, self.logits, self.distance = loss.detach(), logits.detach(), distance.detach()
+        finally:
+            _lib.call("rd_set_seed_cell", None)
+
+    def run(self):
+        self.graph.replay()
+        return self.loss_static
+
+    def close(self):
+        self.graph = None

@@ -234,3 +234,39 @@ def test_module_graph_step_keeps_autograd_s_accumulation_semantics(views, monkey
     for n in live:
         if n != n0:
             assert _close(named[n].grad, gB[n]), ("fresh", n)
+
+
+def test_autograd_step_captures_the_paper_s_branch():
+    """`AutogradStep`: Raindrop_v2(use_beta=True, compute_distance=True) -- which `TrainStep` refuses -- as one hipGraph per step over
+    the module's autograd surface.  Dropout off: three replays on three batches (copied into the static buffers) give the eager loop's
+    losses, logits and gradients bit for bit (same kernels, same order); p19_beta_sparse's golden logits within 1e-4."""
+    from raindrop_amd.step import AutogradStep
+    from tests.helpers import load_golden, case_inputs
+    g, meta = load_golden("p19_beta_sparse")
+    cfg, gs, batch = case_inputs(meta)
+    outs = []
+    for graph in (True, False):
+        m = build_ours(cfg, gs, DEV, meta["param_seed"], use_beta=True, compute_distance=True).train()
+        m.graph_step = False
+        buf = {k: (None if v is None else v.to(DEV).clone()) for k, v in batch.items()}
+        st = AutogradStep(m, buf, optimizer=False) if graph else None
+        res = []
+        for seed in (meta["batch_seed"], 77, 78):
+            nb = synth.make_batch(cfg, meta["batch"], seed=seed)
+            for k, v in nb.items():
+                if v is not None:
+                    buf[k].copy_(v)
+            if graph:
+                loss = float(st.run()); lg = st.logits.clone()
+            else:
+                for p in m.parameters():
+                    p.grad = None
+                lg, _, _ = m(buf["src"], buf["static"], buf["times"], buf["lengths"])
+                l_ = torch.nn.functional.cross_entropy(lg, buf["y"]); l_.backward(); loss = float(l_); lg = lg.detach().clone()
+            res.append((loss, lg, {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}))
+        outs.append(res)
+    assert np.abs(outs[0][0][1].cpu().numpy() - g["logits"]).max() < 1e-4
+    for (l0, lg0, g0), (l1, lg1, g1) in zip(*outs):
+        assert l0 == l1 and torch.equal(lg0, lg1) and set(g0) == set(g1)
+        for n in g0:
+            assert torch.equal(g0[n], g1[n]), n
