@@ -61,6 +61,7 @@ def parse():
                     help="arithmetic of the dense contractions (default: RD_PRECISION or bf16x3); bf16 = one product, the "
                          "'P12 bf16' configuration of BASELINE.json")
     ap.add_argument("--no-roofline", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--lite", action="store_true", help=argparse.SUPPRESS)     # child of other_configs(): the line + its roofline object, no extras
     ap.add_argument("--use-beta", action="store_true",
                     help="the paper's branch (use_beta=True: top-K pruned, per-sample graph) as a captured step: prints tools/bench_use_beta.py's line")
     ap.add_argument("--no-graph", action="store_true",
@@ -653,6 +654,45 @@ def recorded_o1(cfg_name, B):
         return None
 
 
+OTHER_CONFIGS = (   # BASELINE.json's other configurations as bounded child runs of this script: (label, argv, seconds)
+    ("P12 (36 sensors, T=215) bf16, B=256 [configs[1]]", ["--config", "P12", "--precision", "bf16", "--batch", "256", "--steps", "20", "--warmup", "5"], 200),
+    ("PAM (17 sensors, T=600), B=128 [configs[0] shape on the GPU]", ["--config", "PAM", "--batch", "128", "--steps", "10", "--warmup", "3"], 200),
+    ("synthetic 256 sensors x 512 steps, B=16 per GPU [configs[4]]", ["--config", "SYN256", "--batch", "16", "--steps", "5", "--warmup", "2"], 240),
+)
+
+
+def other_configs(budget_s=420.0):
+    """BASELINE.json names five configurations; the line's metric is quoted on one (P19).  The others run here as CHILD processes
+    after the timed region, each bounded, so that the driver's line carries them too (VERDICT r5 #6d): ms/step, samples/s, step mode,
+    the message-passing roofline object's MFMA / HBM fractions.  RD_BENCH_OTHER=0 skips them; a child that fails or runs out of time
+    leaves an `error` entry, never costs the line."""
+    import subprocess
+    out, t_start = [], time.perf_counter()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RD_PRECISION")}
+    env.update(RD_BENCH_OTHER="0", RD_BENCH_LIVE_TRACE="0")
+    for label, argv, limit in OTHER_CONFIGS:
+        left = budget_s - (time.perf_counter() - t_start)
+        if left < 30:
+            out.append({"config": label, "error": "skipped: the time budget of the other-configuration runs (%.0f s) is spent" % budget_s})
+            continue
+        try:
+            res = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--lite"] + argv, capture_output=True,
+                                 text=True, timeout=min(limit, left), env=env)
+            ln = [x for x in res.stdout.splitlines() if x.startswith("{")]
+            if not ln:
+                out.append({"config": label, "error": "rc %d: %s" % (res.returncode, (res.stderr or "")[-200:])})
+                continue
+            d = json.loads(ln[-1])
+            rl = d.get("roofline") if isinstance(d.get("roofline"), dict) else {}
+            out.append({"config": label, "ms_per_step": d["ms_per_step"], "samples_per_s": d["value"], "dtype": d["dtype"],
+                        "step_mode": d["config"].get("step_mode"), "token_plan": str(d["config"].get("token_plan"))[:60],
+                        "k1_hbm_frac": rl.get("frac"), "k1_mfma_frac_issued": (rl.get("mfma") or {}).get("frac_issued"),
+                        "k1_bound": rl.get("bound")})
+        except Exception as e:
+            out.append({"config": label, "error": repr(e)[:200]})
+    return out
+
+
 def graph_probe_ok(args, world):
     import subprocess
     if world > 1 and int(os.environ.get("RANK", "0")) != 0:
@@ -1048,7 +1088,7 @@ def main():
     # -> loss.backward() -> flat.finish() + Adam, the model's forward and backward as two hipGraphs behind the nn.Module surface.
     # Measured after the timed region, same batch; never allowed to cost the line.
     t_module = None
-    if world == 1 and not args.no_roofline:
+    if world == 1 and not args.no_roofline and not args.lite:
         try:
             model.graph_step = None                                       # the module's default: what an unchanged loop gets
             os.environ.pop("RD_MODULE_GRAPH", None)
@@ -1135,9 +1175,12 @@ def main():
                 line["config"]["box"] = box_kind()
                 if isinstance(line.get("roofline"), dict) and isinstance(line["roofline"].get("rocprof"), dict):
                     line["roofline"]["rocprof"]["box"] = line["config"]["box"]      # the trace is of THIS box
-                line["config"]["fp32_mode_ms_per_step"] = fp32_mode_ms(args)
-                if token_plan_on:
-                    line["config"]["padded_layout_ms_per_step"] = padded_layout_ms(args)
+                if not args.lite:
+                    line["config"]["fp32_mode_ms_per_step"] = fp32_mode_ms(args)
+                    if token_plan_on:
+                        line["config"]["padded_layout_ms_per_step"] = padded_layout_ms(args)
+                    if (cfg["name"], B) == ("P19", 256) and os.environ.get("RD_BENCH_OTHER", "1") != "0":
+                        line["config"]["other_configs"] = other_configs()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, gs, B, args.cpu_reps)
             line["cpu_baseline"]["reference_o1"] = recorded_o1(cfg["name"], B)
