@@ -269,3 +269,37 @@ def test_graph_beta_rejects_malformed_input():
         ops.graph_beta(V, H, torch.zeros(n, 8, device=DEV), pt, ei_ok, ew, d)  # map_weights not [N,16]
     with pytest.raises(ValueError):
         ops.graph_beta(V, H, mw, torch.zeros(3, T, 16, device=DEV), ei_ok, ew, d)   # p_t batch neither 1 nor B
+
+
+@pytest.mark.parametrize("n,T,B", [(34, 60, 7), (36, 215, 3), (17, 600, 2), (6, 5, 4)])
+def test_v2_kernels_equal_v1_bit_for_bit(n, T, B, monkeypatch):
+    """Round 6's 16-wave kernels (every (edge, step) quantity formed once, lists by a wave per node, 16-byte accesses) keep the order
+    of every sum of rounds 2-5's kernels (RD_BETA_V1=1): outputs, pruned lists, scores and ALL gradients -- d edge weight included --
+    are the same bits, at the three dataset shapes and a tiny graph, on random sparse structures."""
+    d = 4
+    K = T * d
+    rng = np.random.default_rng(n * 7 + T)
+    adj = (rng.random((n, n)) < 0.4).astype(np.float32) * rng.uniform(0.5, 1.5, (n, n)).astype(np.float32)
+    ei, ew = O2.build_graph(adj)
+    op = Observation_progation(K, K, n_nodes=n, ob_dim=d, heads=1)
+    synth.fill_params_(op, seed=9)
+    op = op.to(DEV)
+    X0 = torch.from_numpy((rng.standard_normal((B, n, K)) * 0.5).astype(np.float32)).to(DEV)
+    PT = torch.from_numpy(rng.standard_normal((B, T, 16)).astype(np.float32)).to(DEV)
+    R = torch.from_numpy(rng.standard_normal((B, n, K)).astype(np.float32)).to(DEV)
+    outs = []
+    for v1 in ("1", "0"):
+        monkeypatch.setenv("RD_BETA_V1", v1)
+        X = X0.clone().requires_grad_(True)
+        V = ops.linear(X.reshape(B * n, K), op.lin_value.weight, op.lin_value.bias, act=1).view(B, n, K)
+        H = ops.linear(X.reshape(B * n, K), op.increase_dim.weight, op.increase_dim.bias, exact=True).view(B, n, T * 32)
+        ewd = _t(ew).reshape(1, -1).clone().requires_grad_(True)
+        Y, ei2, alpha = ops.graph_beta(V, H, op.map_weights, PT, _t(ei), ewd, d)
+        grads = torch.autograd.grad((Y * R).sum(), [X, op.lin_value.weight, op.increase_dim.weight, op.map_weights, ewd])
+        outs.append((Y.detach(), ei2, alpha.detach(), [g_.detach() for g_ in grads]))
+    monkeypatch.delenv("RD_BETA_V1", raising=False)
+    (Y1, e1, a1, g1), (Y2, e2, a2, g2) = outs
+    assert torch.equal(e1, e2) and torch.equal(a1, a2)
+    assert torch.equal(Y1, Y2), float((Y1 - Y2).abs().max())
+    for name, x, y in zip(["X", "Wv", "Wi", "map", "ew"], g1, g2):
+        assert torch.equal(x, y), (name, float((x - y).abs().max()))
