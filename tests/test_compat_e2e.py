@@ -25,7 +25,7 @@ ORACLE_SHIM = ("# test-only shim: the reference's own model (oracle O1) behind t
 
 def test_unmodified_script_runs_end_to_end(tmp_path, capsys):
     import torch
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(4, os.cpu_count() or 1))      # (all cores: 109 s alone, but 10 x that on a busy host -- OpenMP spin-waits; 4: ~130 s either way)
     root = str(tmp_path)
     with ref_loader._patched():                      # .cuda() -> identity etc.: the script is CUDA-only (Raindrop.py:253,310)
         g = compat_runner.run(root, "P19", 200, ref_loader.reference_root(), seed=3, model_shim=ORACLE_SHIM)
