@@ -38,6 +38,6 @@ d=json.loads(open("$out/bench_P19.json").read().strip().splitlines()[-1])
 r=d["roofline"]; e=d.get("roofline_encoder_layer") or {}
 print("P19", d["ms_per_step"], d["value"], "K1 frac", r.get("frac"), "corrected", r.get("frac_boundary_corrected"), "rocprof", r.get("frac_rocprof"),
       "iso", r.get("frac_isolated"), "traffic", r.get("traffic"), "| enc us", e.get("us"), "frac", e.get("frac"), "traffic", e.get("traffic"),
-      "| loop default", d["config"].get("eager_ms_per_step"), "ops", d["config"].get("operator_by_operator_ms_per_step"), d["config"].get("box", {}).get("kind"))
+      "| loop default", d["config"].get("module_default_ms_per_step"), "ops", d["config"].get("operator_by_operator_ms_per_step"), d["config"].get("box", {}).get("kind"))
 PY
 cat $out/box.txt; head -14 $out/step_kernel_stats.txt | cut -c1-60,90-150
