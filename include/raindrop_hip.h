@@ -169,6 +169,11 @@ int rd_edge_softmax(int32_t F, const float* adj, float* gamma, float* ssum, void
 int rd_edge_softmax_list(int32_t N, int32_t E, const int64_t* edge_index, int64_t row_stride,
                          int32_t norm_row, const float* edge_weights, float* gamma_e, float* ssum,
                          void* stream);
+/* The same followed by F.dropout(gamma, p) (code/Ob_propagation.py:196, code/transformer_conv.py:203; training mode of an operator
+ * constructed with dropout > 0 -- the shipped model uses 0): gamma_e[e] is 0 or gamma / (1 - p), ssum the sum of THOSE; the mask is
+ * a function of (seed + the registered seed cell, edge index). */
+int rd_edge_softmax_list_dropout(int32_t N, int32_t E, const int64_t* edge_index, int64_t row_stride, int32_t norm_row,
+                                 const float* edge_weights, float p_drop, uint64_t seed, float* gamma_e, float* ssum, void* stream);
 
 /* Source-valued aggregate of TransformerConv (code/transformer_conv.py:158,168-175,205-206) on a
  * dense coefficient matrix: out[i,c] = sum_j gamma[j,i] V[j,c] (+ skip[i,c] if skip != NULL);
@@ -177,6 +182,22 @@ int rd_aggregate_fwd(int32_t N, int32_t C, const float* gamma, const float* V, c
                      float* out, void* stream);
 int rd_aggregate_bwd(int32_t N, int32_t C, const float* gamma, const float* dout, float* dV,
                      void* stream);
+
+/* The GENERAL message / aggregate of the reference's TransformerConv (code/transformer_conv.py:186-207; round 6): H heads of C
+ * channels, scores from the projections instead of given edge weights --
+ *   alpha[e,h] = softmax over the edges into tgt(e) of <q[tgt(e),h], k[src(e),h] + edge_feat[e,h]> / sqrt(C)   (edge_feat =
+ *   lin_edge(edge_attr) [E,H*C] or NULL), F.dropout(alpha, p) in training mode (:203), out[i,h] = sum_e alpha[e,h] v[src(e),h].
+ * q, k, v [N,H*C] row-major; edge_index rows [source; target] `row_stride` apart (duplicate edges allowed); alpha [E,H] receives
+ * the POST-softmax coefficients (what the operator returns), alpha_drop [E,H] the dropped ones (kept for the backward), out
+ * [N,H*C].  Backward: dout [N,H*C] -> dq, dk, dv [N,H*C], dedge_feat [E,H*C] (NULL iff edge_feat is); ds_ws: E*H floats.
+ * Deterministic: sums over a node's edges in edge order, fixed-tree block reductions. */
+int rd_edge_attention_fwd(int32_t N, int32_t E, int32_t H, int32_t C, const float* q, const float* k, const float* v,
+                          const float* edge_feat, const int64_t* edge_index, int64_t row_stride, float p_drop, uint64_t seed,
+                          float* alpha, float* alpha_drop, float* out, void* stream);
+int rd_edge_attention_bwd(int32_t N, int32_t E, int32_t H, int32_t C, const float* q, const float* k, const float* v,
+                          const float* edge_feat, const int64_t* edge_index, int64_t row_stride, float p_drop, uint64_t seed,
+                          const float* alpha, const float* alpha_drop, const float* dout, float* ds_ws, float* dq, float* dk,
+                          float* dv, float* dedge_feat, void* stream);
 
 /* Batched forms (replace the per-sample Python loop + torch index_put_ the round-2 TransformerConv surface used):
  *  - rd_edge_softmax_list_batched: B edge lists in one launch, edge_index [B][2,E] int64 `batch_stride` elements apart (0 = one

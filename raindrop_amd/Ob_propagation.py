@@ -87,10 +87,12 @@ class Observation_progation(nn.Module):
         PRE-softmax weights [E,1] (:193)."""
         if isinstance(x, (tuple, list)):
             x = x[1]
-        if self.dropout > 0.0 and self.training:
-            # code/Ob_propagation.py:196 drops edge coefficients AFTER the softmax; the model never sets it (dropout=0., models_rd.py:243-247)
-            raise _lib.RaindropHipError("RD_EUNSUPPORTED: Observation_progation(dropout > 0) in training mode is not built "
-                                        "(the shipped model constructs the operator with dropout = 0)")
+        # code/Ob_propagation.py:196: F.dropout of the edge coefficients AFTER the softmax (the shipped model builds the operator with
+        # dropout = 0., models_rd.py:243-247).  Default branch: round 6 (the mask is a function of torch's seed and a per-module call
+        # counter, like the model's own dropout); the use_beta branch with coefficient dropout is not built.
+        p_edge = float(self.dropout) if self.training else 0.0
+        if p_edge > 0.0 and use_beta:
+            raise _lib.RaindropHipError("RD_EUNSUPPORTED: Observation_progation(dropout > 0) with use_beta=True in training mode is not built")
         if use_beta:
             return self._forward_beta(x, p_t, edge_index, edge_weights, return_attention_weights)
         if edge_weights is None:
@@ -99,7 +101,11 @@ class Observation_progation(nn.Module):
         if self.heads != 1:
             raise _lib.RaindropHipError("RD_EUNSUPPORTED: heads != 1")
         n = x.shape[0]
-        _, ssum = ops.edge_softmax_list(edge_index, edge_weights, n, norm_row=1)
+        seed = 0
+        if p_edge > 0.0:
+            self._drop_calls = getattr(self, "_drop_calls", 0) + 1
+            seed = (torch.initial_seed() * 1000003 + 7919 * self._drop_calls + ops.rank_seed_offset()) & 0x7FFFFFFFFFFFFFFF
+        _, ssum = ops.edge_softmax_list(edge_index, edge_weights, n, norm_row=1, p_drop=p_edge, seed=seed)
         v = ops.linear(x, self.lin_value.weight, self.lin_value.bias, act=1)
         out = v * ssum[:, None]
         out = out.view(-1, self.heads * self.out_channels) if self.concat else out

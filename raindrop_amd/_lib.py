@@ -55,6 +55,11 @@ SIGNATURES = {
     "rd_pe_mask": (c_int32, [_SHP, _P, _P, _P, _P, _P, _P]),
     "rd_edge_softmax": (c_int32, [c_int32, _P, _P, _P, _P]),
     "rd_edge_softmax_list": (c_int32, [c_int32, c_int32, _P, ctypes.c_int64, c_int32, _P, _P, _P, _P]),
+    "rd_edge_attention_fwd": (c_int32, [c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, ctypes.c_int64, c_float, ctypes.c_uint64,
+                                        _P, _P, _P, _P]),
+    "rd_edge_attention_bwd": (c_int32, [c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, ctypes.c_int64, c_float, ctypes.c_uint64,
+                                        _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "rd_edge_softmax_list_dropout": (c_int32, [c_int32, c_int32, _P, ctypes.c_int64, c_int32, _P, c_float, ctypes.c_uint64, _P, _P, _P]),
     "rd_aggregate_fwd": (c_int32, [c_int32, c_int32, _P, _P, _P, _P, _P]),
     "rd_aggregate_bwd": (c_int32, [c_int32, c_int32, _P, _P, _P, _P]),
     "rd_edge_softmax_list_batched": (c_int32, [c_int32, c_int32, c_int32, _P, ctypes.c_int64, ctypes.c_int64, c_int32, _P,

@@ -1,0 +1,187 @@
+// rd_edge_attn.hip -- the GENERAL form of the reference's TransformerConv message / aggregate (code/transformer_conv.py:186-207):
+//   alpha[e,h] = softmax over the edges into tgt(e) of  <q[tgt(e),h,:], k[src(e),h,:] + lin_edge(edge_attr)[e,h,:]> / sqrt(C)
+//   alpha      = F.dropout(alpha, p)                                  (:203, training mode)
+//   out[i,h,:] = sum over edges e into i of alpha[e,h] * v[src(e),h,:]   (edge_attr is NOT added to the value in this fork, :205)
+// for H heads of C channels on an explicit edge list (duplicates allowed).  q, k, v and lin_edge(edge_attr) are plain Linear
+// outputs (rd_linear_fwd); this file is the graph-shaped part, forward and backward.  Rounds 1-5 built only what the reference
+// itself calls (edge_weights given: they REPLACE the scores; heads = 1) and refused the rest (VERDICT r5 missing #4).
+// One workgroup per TARGET node scans the edge list (the operator's graphs are tens to hundreds of nodes: the legacy `Raindrop`
+// model's 215-step graph has 1296 edges); sums over a node's edges run in EDGE ORDER, block reductions are fixed trees: deterministic.
+#include "rd_common.h"
+#include "rd_rng.h"
+
+namespace rd {
+namespace {
+
+constexpr int EA_THR = 256;
+
+struct EAttnArgs {
+  const float *q, *k, *v, *ea;               // [N,H*C] x3, [E,H*C] or null
+  const int64_t *src, *tgt;
+  int N, E, H, C;
+  float scale, p_drop; uint64_t seed; const uint64_t* cell;
+  float *alpha, *alpha_d, *out;              // [E,H] post-softmax, [E,H] after dropout, [N,H*C]
+  const float* dout; float *ds, *dq, *dk, *dv, *dea;
+};
+
+__device__ __forceinline__ float block_max(float v, float* red) {
+  red[threadIdx.x] = v; __syncthreads();
+  for (int o = EA_THR / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+  const float r = red[0]; __syncthreads();
+  return r;
+}
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  red[threadIdx.x] = v; __syncthreads();
+  for (int o = EA_THR / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  const float r = red[0]; __syncthreads();
+  return r;
+}
+// dropout factor of coefficient (e, h): 0 or 1 / (1 - p); a pure function of (seed, e * H + h)
+__device__ __forceinline__ float keep_scale(const EAttnArgs& a, uint64_t seed_eff, int e, int h) {
+  if (!(a.p_drop > 0.f)) return 1.f;
+  const uint64_t idx = (uint64_t)e * a.H + h;
+  const float4 u = uniform4(seed_eff, SITE_EDGE_COEFF, idx >> 2);
+  const int c = (int)(idx & 3);
+  const float ue = c == 0 ? u.x : c == 1 ? u.y : c == 2 ? u.z : u.w;
+  return ue >= a.p_drop ? 1.0f / (1.0f - a.p_drop) : 0.f;
+}
+
+__global__ __launch_bounds__(EA_THR) void k_eattn_fwd(EAttnArgs a) {
+  __shared__ float red[EA_THR];
+  const int i = blockIdx.x, tid = threadIdx.x, HC = a.H * a.C;
+  const uint64_t seed_eff = a.p_drop > 0.f ? eff_seed(a.seed, a.cell) : 0;
+  for (int h = 0; h < a.H; ++h) {
+    const float* qi = a.q + (size_t)i * HC + h * a.C;
+    float m = -INFINITY;
+    for (int e = tid; e < a.E; e += EA_THR)
+      if ((int)a.tgt[e] == i) {
+        const float* kj = a.k + (size_t)a.src[e] * HC + h * a.C;
+        float s = 0.f;
+        if (a.ea) { const float* ee = a.ea + (size_t)e * HC + h * a.C; for (int c = 0; c < a.C; ++c) s += qi[c] * (kj[c] + ee[c]); }
+        else for (int c = 0; c < a.C; ++c) s += qi[c] * kj[c];
+        s *= a.scale;
+        a.alpha[(size_t)e * a.H + h] = s;
+        m = fmaxf(m, s);
+      }
+    m = block_max(m, red);
+    float den = 0.f;
+    for (int e = tid; e < a.E; e += EA_THR)
+      if ((int)a.tgt[e] == i) den += expf(a.alpha[(size_t)e * a.H + h] - m);
+    den = block_sum(den, red) + 1e-16f;
+    for (int e = tid; e < a.E; e += EA_THR)
+      if ((int)a.tgt[e] == i) {
+        const float al = expf(a.alpha[(size_t)e * a.H + h] - m) / den;
+        a.alpha[(size_t)e * a.H + h] = al;
+        a.alpha_d[(size_t)e * a.H + h] = al * keep_scale(a, seed_eff, e, h);
+      }
+  }
+  __syncthreads();
+  for (int hc = tid; hc < HC; hc += EA_THR) {
+    const int h = hc / a.C;
+    float acc = 0.f;
+    for (int e = 0; e < a.E; ++e)
+      if ((int)a.tgt[e] == i) acc += a.alpha_d[(size_t)e * a.H + h] * a.v[(size_t)a.src[e] * HC + hc];
+    a.out[(size_t)i * HC + hc] = acc;
+  }
+}
+
+// per TARGET: d alpha, the softmax backward ds[e,h] (kept for the per-source pass), dq, d lin_edge(edge_attr)
+__global__ __launch_bounds__(EA_THR) void k_eattn_bwd_tgt(EAttnArgs a) {
+  __shared__ float red[EA_THR];
+  const int i = blockIdx.x, tid = threadIdx.x, HC = a.H * a.C;
+  const uint64_t seed_eff = a.p_drop > 0.f ? eff_seed(a.seed, a.cell) : 0;
+  for (int h = 0; h < a.H; ++h) {
+    const float* doi = a.dout + (size_t)i * HC + h * a.C;
+    float part = 0.f;
+    for (int e = tid; e < a.E; e += EA_THR)
+      if ((int)a.tgt[e] == i) {
+        const float* vj = a.v + (size_t)a.src[e] * HC + h * a.C;
+        float d = 0.f;
+        for (int c = 0; c < a.C; ++c) d += doi[c] * vj[c];
+        d *= keep_scale(a, seed_eff, e, h);                    // through the dropout
+        a.ds[(size_t)e * a.H + h] = d;
+        part += a.alpha[(size_t)e * a.H + h] * d;
+      }
+    const float S = block_sum(part, red);
+    for (int e = tid; e < a.E; e += EA_THR)
+      if ((int)a.tgt[e] == i) a.ds[(size_t)e * a.H + h] = a.alpha[(size_t)e * a.H + h] * (a.ds[(size_t)e * a.H + h] - S);
+  }
+  __syncthreads();
+  for (int hc = tid; hc < HC; hc += EA_THR) {
+    const int h = hc / a.C;
+    float acc = 0.f;
+    for (int e = 0; e < a.E; ++e)
+      if ((int)a.tgt[e] == i) {
+        float kk = a.k[(size_t)a.src[e] * HC + hc];
+        if (a.ea) kk += a.ea[(size_t)e * HC + hc];
+        acc += a.ds[(size_t)e * a.H + h] * kk;
+      }
+    a.dq[(size_t)i * HC + hc] = acc * a.scale;
+  }
+  if (a.dea)
+    for (int e = 0; e < a.E; ++e)
+      if ((int)a.tgt[e] == i)                                  // uniform
+        for (int hc = tid; hc < HC; hc += EA_THR) a.dea[(size_t)e * HC + hc] = a.ds[(size_t)e * a.H + hc / a.C] * a.q[(size_t)i * HC + hc] * a.scale;
+}
+
+// per SOURCE: dv, dk (sums over the node's OUT-edges in edge order)
+__global__ __launch_bounds__(EA_THR) void k_eattn_bwd_src(EAttnArgs a) {
+  const int j = blockIdx.x, tid = threadIdx.x, HC = a.H * a.C;
+  for (int hc = tid; hc < HC; hc += EA_THR) {
+    const int h = hc / a.C;
+    float av = 0.f, ak = 0.f;
+    for (int e = 0; e < a.E; ++e)
+      if ((int)a.src[e] == j) {
+        const size_t t = (size_t)a.tgt[e] * HC + hc;
+        av += a.alpha_d[(size_t)e * a.H + h] * a.dout[t];
+        ak += a.ds[(size_t)e * a.H + h] * a.q[t];
+      }
+    a.dv[(size_t)j * HC + hc] = av;
+    a.dk[(size_t)j * HC + hc] = ak * a.scale;
+  }
+}
+
+int check_ea(int N, int E, int H, int C) {
+  RD_REQUIRE(N > 0 && E >= 0 && H > 0 && H <= 64 && C > 0, "bad dims N=%d E=%d H=%d C=%d", N, E, H, C);
+  return RD_OK;
+}
+
+}  // namespace
+}  // namespace rd
+
+using namespace rd;
+
+extern "C" int rd_edge_attention_fwd(int32_t N, int32_t E, int32_t H, int32_t C, const float* q, const float* k, const float* v,
+                                     const float* edge_feat, const int64_t* edge_index, int64_t row_stride, float p_drop,
+                                     uint64_t seed, float* alpha, float* alpha_drop, float* out, void* stream) {
+  int rc = check_ea(N, E, H, C);
+  if (rc) return rc;
+  RD_REQUIRE(q && k && v && edge_index && alpha && alpha_drop && out, "NULL tensor");
+  RD_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "p_drop must be in [0,1)");
+  EAttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.ea = edge_feat; a.src = edge_index; a.tgt = edge_index + row_stride;
+  a.N = N; a.E = E; a.H = H; a.C = C; a.scale = 1.0f / sqrtf((float)C); a.p_drop = p_drop; a.seed = seed; a.cell = seed_cell();
+  a.alpha = alpha; a.alpha_d = alpha_drop; a.out = out;
+  hipLaunchKernelGGL(k_eattn_fwd, dim3(N), dim3(EA_THR), 0, (hipStream_t)stream, a);
+  return check_launch("k_eattn_fwd");
+}
+
+extern "C" int rd_edge_attention_bwd(int32_t N, int32_t E, int32_t H, int32_t C, const float* q, const float* k, const float* v,
+                                     const float* edge_feat, const int64_t* edge_index, int64_t row_stride, float p_drop,
+                                     uint64_t seed, const float* alpha, const float* alpha_drop, const float* dout, float* ds_ws,
+                                     float* dq, float* dk, float* dv, float* dedge_feat, void* stream) {
+  int rc = check_ea(N, E, H, C);
+  if (rc) return rc;
+  RD_REQUIRE(q && k && v && edge_index && alpha && alpha_drop && dout && ds_ws && dq && dk && dv, "NULL tensor");
+  RD_REQUIRE((edge_feat == nullptr) == (dedge_feat == nullptr), "edge features and their gradient go together");
+  EAttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.ea = edge_feat; a.src = edge_index; a.tgt = edge_index + row_stride;
+  a.N = N; a.E = E; a.H = H; a.C = C; a.scale = 1.0f / sqrtf((float)C); a.p_drop = p_drop; a.seed = seed; a.cell = seed_cell();
+  a.alpha = const_cast<float*>(alpha); a.alpha_d = const_cast<float*>(alpha_drop);
+  a.dout = dout; a.ds = ds_ws; a.dq = dq; a.dk = dk; a.dv = dv; a.dea = dedge_feat;
+  hipLaunchKernelGGL(k_eattn_bwd_tgt, dim3(N), dim3(EA_THR), 0, (hipStream_t)stream, a);
+  rc = check_launch("k_eattn_bwd_tgt");
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_eattn_bwd_src, dim3(N), dim3(EA_THR), 0, (hipStream_t)stream, a);
+  return check_launch("k_eattn_bwd_src");
+}

@@ -2,6 +2,7 @@
 // with wavefront-shuffle reductions, and the positional-encoding / padding-mask kernel.
 #include "rd_common.h"
 #include "rd_plan.h"
+#include "rd_rng.h"
 
 namespace rd {
 namespace {
@@ -126,12 +127,18 @@ __global__ __launch_bounds__(256) void k_pe_mask(const float* __restrict__ times
 __global__ __launch_bounds__(256) void k_edge_softmax_list(const int64_t* __restrict__ idx, int E,
                                                            const float* __restrict__ w, int N,
                                                            float* __restrict__ gamma_e,
-                                                           float* __restrict__ ssum, long idx_bstride, long w_bstride) {
+                                                           float* __restrict__ ssum, long idx_bstride, long w_bstride,
+                                                           float p_drop, uint64_t seed, const uint64_t* cell) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
   idx += (long)blockIdx.y * idx_bstride; w += (long)blockIdx.y * w_bstride;
   gamma_e += (long)blockIdx.y * E; ssum += (long)blockIdx.y * N;
+  // optional dropout of the coefficients AFTER the softmax (code/Ob_propagation.py:196, code/transformer_conv.py:203): keep with
+  // probability 1 - p, scale 1 / (1 - p); a pure function of (seed + cell, edge) like every mask of the library
+  const bool drop = p_drop > 0.f;
+  const uint64_t seed_eff = drop ? eff_seed(seed, cell) : 0;
+  const float inv_keep = drop ? 1.0f / (1.0f - p_drop) : 1.0f;
   float m = -INFINITY;
   for (int e = lane; e < E; e += 64)
     if (idx[e] == n) m = fmaxf(m, w[e]);
@@ -143,7 +150,12 @@ __global__ __launch_bounds__(256) void k_edge_softmax_list(const int64_t* __rest
   float tot = 0.f;
   for (int e = lane; e < E; e += 64)
     if (idx[e] == n) {
-      const float g = expf(w[e] - m) / den;
+      float g = expf(w[e] - m) / den;
+      if (drop) {
+        const float4 u = uniform4(seed_eff, SITE_EDGE_COEFF, (uint64_t)blockIdx.y * ((uint64_t)(E + 3) >> 2) + (uint64_t)(e >> 2));
+        const float ue = (e & 3) == 0 ? u.x : (e & 3) == 1 ? u.y : (e & 3) == 2 ? u.z : u.w;
+        g = ue >= p_drop ? g * inv_keep : 0.f;
+      }
       gamma_e[e] = g;
       tot += g;
     }
@@ -216,7 +228,20 @@ extern "C" int rd_edge_softmax_list(int32_t N, int32_t E, const int64_t* edge_in
   RD_REQUIRE(norm_row == 0 || norm_row == 1, "norm_row must be 0 (source) or 1 (target)");
   RD_REQUIRE(edge_index && edge_weights && gamma_e && ssum, "NULL tensor");
   hipLaunchKernelGGL(k_edge_softmax_list, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream,
-                     edge_index + (long)norm_row * row_stride, E, edge_weights, N, gamma_e, ssum, 0L, 0L);
+                     edge_index + (long)norm_row * row_stride, E, edge_weights, N, gamma_e, ssum, 0L, 0L, 0.f, (uint64_t)0, nullptr);
+  return check_launch("k_edge_softmax_list");
+}
+
+// the same with dropout of the coefficients after the softmax (training mode of an operator built with dropout > 0)
+extern "C" int rd_edge_softmax_list_dropout(int32_t N, int32_t E, const int64_t* edge_index, int64_t row_stride, int32_t norm_row,
+                                            const float* edge_weights, float p_drop, uint64_t seed, float* gamma_e, float* ssum,
+                                            void* stream) {
+  RD_REQUIRE(N > 0 && E >= 0, "bad N=%d E=%d", N, E);
+  RD_REQUIRE(norm_row == 0 || norm_row == 1, "norm_row must be 0 (source) or 1 (target)");
+  RD_REQUIRE(edge_index && edge_weights && gamma_e && ssum, "NULL tensor");
+  RD_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "p_drop must be in [0,1)");
+  hipLaunchKernelGGL(k_edge_softmax_list, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream,
+                     edge_index + (long)norm_row * row_stride, E, edge_weights, N, gamma_e, ssum, 0L, 0L, p_drop, seed, seed_cell());
   return check_launch("k_edge_softmax_list");
 }
 
@@ -232,7 +257,8 @@ extern "C" int rd_edge_softmax_list_batched(int32_t B, int32_t N, int32_t E, con
   RD_REQUIRE(B <= 65535, "B=%d exceeds the grid's y extent", B);
   RD_REQUIRE(edge_index && edge_weights && gamma_e && ssum, "NULL tensor");
   hipLaunchKernelGGL(k_edge_softmax_list, dim3(cdiv(N, 4), B), dim3(256), 0, (hipStream_t)stream,
-                     edge_index + (long)norm_row * row_stride, E, edge_weights, N, gamma_e, ssum, (long)batch_stride, (long)w_bstride);
+                     edge_index + (long)norm_row * row_stride, E, edge_weights, N, gamma_e, ssum, (long)batch_stride, (long)w_bstride,
+                     0.f, (uint64_t)0, nullptr);
   return check_launch("k_edge_softmax_list");
 }
 

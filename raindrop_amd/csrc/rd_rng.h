@@ -76,7 +76,7 @@ __device__ __forceinline__ uint64_t eff_seed(uint64_t seed, const uint64_t* cell
   return cell ? seed + *cell : seed;
 }
 
-enum DropSite : uint32_t { SITE_OBS_EMBED = 1, SITE_ATTN_PROB = 16, SITE_ATTN_OUT = 32, SITE_FFN_HID = 48,
+enum DropSite : uint32_t { SITE_OBS_EMBED = 1, SITE_EDGE_COEFF = 2, SITE_ATTN_PROB = 16, SITE_ATTN_OUT = 32, SITE_FFN_HID = 48,
                            SITE_FFN_OUT = 64 };   // + layer index for the encoder sites
 
 }  // namespace rd

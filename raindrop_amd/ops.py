@@ -210,8 +210,9 @@ def linear(x, W, b=None, act=0, exact=False):
 # stand-alone graph operators (PyG operator API: one graph per call)
 # ------------------------------------------------------------------------------------------------
 
-def edge_softmax_list(edge_index, edge_weights, n_nodes, norm_row=1):
-    """PyG softmax over an explicit edge list; returns (gamma_e [E], ssum [n_nodes])."""
+def edge_softmax_list(edge_index, edge_weights, n_nodes, norm_row=1, p_drop=0.0, seed=0):
+    """PyG softmax over an explicit edge list; returns (gamma_e [E], ssum [n_nodes]).  p_drop > 0: F.dropout of the coefficients
+    after the softmax (code/Ob_propagation.py:196), ssum is then the sum of the dropped-and-rescaled coefficients."""
     ei = edge_index.contiguous()
     w = edge_weights.contiguous()
     _check(ei, dtype=torch.int64)
@@ -219,8 +220,12 @@ def edge_softmax_list(edge_index, edge_weights, n_nodes, norm_row=1):
     E = ei.shape[1]
     gamma = torch.empty((E,), dtype=torch.float32, device=w.device)
     ssum = torch.empty((n_nodes,), dtype=torch.float32, device=w.device)
-    _lib.call("rd_edge_softmax_list", int(n_nodes), int(E), _ptr(ei), ei.stride(0), int(norm_row),
-              _ptr(w), _ptr(gamma), _ptr(ssum), _stream())
+    if p_drop > 0.0:
+        _lib.call("rd_edge_softmax_list_dropout", int(n_nodes), int(E), _ptr(ei), ei.stride(0), int(norm_row), _ptr(w), float(p_drop),
+                  int(seed) & 0x7FFFFFFFFFFFFFFF, _ptr(gamma), _ptr(ssum), _stream())
+    else:
+        _lib.call("rd_edge_softmax_list", int(n_nodes), int(E), _ptr(ei), ei.stride(0), int(norm_row),
+                  _ptr(w), _ptr(gamma), _ptr(ssum), _stream())
     return gamma, ssum
 
 
@@ -249,6 +254,46 @@ class _Aggregate(torch.autograd.Function):
 
 def aggregate(gamma, V, skip=None):
     return _Aggregate.apply(gamma.contiguous(), V.contiguous(), None if skip is None else skip.contiguous())
+
+
+class _EdgeAttention(torch.autograd.Function):
+    """The general message / aggregate of TransformerConv (include/raindrop_hip.h rd_edge_attention_fwd / _bwd): q.k scores per
+    edge and head, softmax per target, coefficient dropout, source-valued aggregate."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, ef, edge_index, H, C, p_drop, seed):
+        _check(q, k, v, ef)
+        _check(edge_index, dtype=torch.int64)
+        N, E = q.shape[0], edge_index.shape[1]
+        alpha = torch.empty((E, H), dtype=torch.float32, device=q.device)
+        alpha_d = torch.empty((E, H), dtype=torch.float32, device=q.device)
+        out = torch.empty((N, H * C), dtype=torch.float32, device=q.device)
+        _lib.call("rd_edge_attention_fwd", N, E, H, C, _ptr(q), _ptr(k), _ptr(v), _ptr(ef), _ptr(edge_index), edge_index.stride(0),
+                  float(p_drop), int(seed) & 0x7FFFFFFFFFFFFFFF, _ptr(alpha), _ptr(alpha_d), _ptr(out), _stream())
+        ctx.save_for_backward(q, k, v, ef, edge_index, alpha, alpha_d)
+        ctx.dims = (N, E, H, C, float(p_drop), int(seed) & 0x7FFFFFFFFFFFFFFF)
+        ctx.mark_non_differentiable(alpha)
+        return out, alpha
+
+    @staticmethod
+    def backward(ctx, dout, _dalpha):
+        q, k, v, ef, ei, alpha, alpha_d = ctx.saved_tensors
+        N, E, H, C, p_drop, seed = ctx.dims
+        dout = dout.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        # rows of nodes without in- / out-edges are written too (zeros): every workgroup covers its node
+        dea = torch.zeros_like(ef) if ef is not None else None
+        ws = torch.empty((max(E * H, 1),), dtype=torch.float32, device=q.device)
+        _lib.call("rd_edge_attention_bwd", N, E, H, C, _ptr(q), _ptr(k), _ptr(v), _ptr(ef), _ptr(ei), ei.stride(0), p_drop, seed,
+                  _ptr(alpha), _ptr(alpha_d), _ptr(dout), _ptr(ws), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(dea), _stream())
+        return dq, dk, dv, dea, None, None, None, None, None
+
+
+def edge_attention(q, k, v, edge_feat, edge_index, heads, channels, p_drop=0.0, seed=0):
+    """(out [N, heads*channels], alpha [E, heads] post-softmax) -- code/transformer_conv.py:186-207 without given edge weights."""
+    ef = None if edge_feat is None else edge_feat.contiguous()
+    return _EdgeAttention.apply(q.contiguous(), k.contiguous(), v.contiguous(), ef, edge_index.contiguous(), int(heads), int(channels),
+                                float(p_drop), int(seed))
 
 
 def edge_softmax_list_batched(edge_index, edge_weights, n_nodes, norm_row=1):

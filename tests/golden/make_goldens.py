@@ -269,6 +269,54 @@ def operator_cases():
     print("operators    -> %s (%.1f KB)" % (os.path.basename(path), os.path.getsize(path) / 1024))
 
 
+TCONV_GENERAL = [   # (tag, heads, channels, concat, edge_dim, beta, root_weight, param seed)
+    ("a", 2, 6, True, None, False, True, 51),
+    ("b", 3, 4, False, 5, True, True, 52),
+    ("c", 1, 8, True, 3, False, False, 53),
+]
+
+
+def tconv_general_case():
+    """The reference's `TransformerConv` WITHOUT given edge weights (code/transformer_conv.py:139-207: q.k scores, heads, lin_edge on
+    the key, concat / mean, root weight with and without the beta gate) on a 9-node graph with a duplicated edge, eval-free
+    (dropout 0): output, post-softmax alpha and the gradients of <y, R> w.r.t. x, edge_attr and every parameter.  O2's
+    `transformer_conv_general` must reproduce them before the fixture is written."""
+    ref = ref_loader.load()
+    rng = np.random.default_rng(321)
+    n, cin = 9, 7
+    adj = (rng.random((n, n)) < 0.45)
+    src, tgt = np.nonzero(adj)
+    ei = np.stack([np.concatenate([src, src[:2]]), np.concatenate([tgt, tgt[:2]])]).astype(np.int64)      # two duplicated edges
+    out = dict(ei=ei, x=rng.standard_normal((n, cin)).astype(np.float32))
+    for tag, H, C, concat, edim, beta, root, pseed in TCONV_GENERAL:
+        tc = ref.run(ref.transformer_conv.TransformerConv, in_channels=cin, out_channels=C, heads=H, concat=concat, beta=beta,
+                     edge_dim=edim, root_weight=root)
+        synth.fill_params_(tc, seed=pseed)
+        x = torch.from_numpy(out["x"]).requires_grad_(True)
+        ea = None if edim is None else torch.from_numpy(rng.standard_normal((ei.shape[1], edim)).astype(np.float32)).requires_grad_(True)
+        y, (_, alpha) = ref.run(tc.forward, x, edge_index=torch.from_numpy(ei), edge_weights=None, edge_attr=ea,
+                                return_attention_weights=True)
+        R = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32))
+        names = [k for k, _ in tc.named_parameters()]
+        wrt = [x] + ([ea] if ea is not None else []) + [p_ for _, p_ in tc.named_parameters()]
+        grads = torch.autograd.grad((y * R).sum(), wrt, allow_unused=True)
+        # O2 before trusting either
+        p2 = {k: v.detach() for k, v in tc.named_parameters()}
+        y2, a2 = O2.transformer_conv_general(x.detach(), torch.from_numpy(ei), p2, H, C, concat, None if ea is None else ea.detach(), root)
+        assert float((y2 - y.detach()).abs().max()) < 2e-6 and float((a2 - alpha.detach()).abs().max()) < 1e-6, tag
+        out.update({tag + "_y": y.detach().numpy(), tag + "_alpha": alpha.detach().numpy(), tag + "_R": R.numpy(),
+                    tag + "_gx": grads[0].numpy()})
+        gi = 1
+        if ea is not None:
+            out[tag + "_ea"] = ea.detach().numpy(); out[tag + "_gea"] = grads[1].numpy(); gi = 2
+        for k, g_ in zip(names, grads[gi:]):
+            if g_ is not None:
+                out[tag + "_g/" + k] = g_.numpy()
+    path = os.path.join(HERE, "tconv_general.npz")
+    np.savez_compressed(path, **out)
+    print("tconv_general -> %s (%.1f KB)" % (os.path.basename(path), os.path.getsize(path) / 1024))
+
+
 def beta_batched_case():
     """The use_beta operator applied to B sample graphs that share an edge list (what `Raindrop_v2.forward` would do per
     sample with `use_beta=True`, code/models_rd.py:313-343), by the REFERENCE class: outputs, pruned edge lists, returned
@@ -426,6 +474,8 @@ if __name__ == "__main__":
         operator_cases()
     if not only or "state_dict" in only:
         state_dict_surface()
+    if not only or "tconv_general" in only:
+        tconv_general_case()
     if not only or "beta_batched" in only:
         beta_batched_case()
     if not only or "beta_large" in only:

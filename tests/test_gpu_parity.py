@@ -1206,3 +1206,95 @@ def test_plain_bf16_mode_against_golden(name):
             assert _rel2(got, exp) < 0.15, (n, _rel2(got, exp))      # R_u (the deepest, smallest gradient) measures 6 %
     finally:
         _lib.call("rd_set_precision", 1)
+
+
+def test_edge_coefficient_dropout_of_the_operator():
+    """code/Ob_propagation.py:196: `gamma = F.dropout(gamma, p, training)` AFTER the softmax (the shipped model builds the operator with
+    dropout 0; refused until round 6).  RNG streams cannot match torch's, so the test pins the semantics: every dropped-and-rescaled
+    coefficient is 0 or gamma / (1 - p), the kept fraction is ~1 - p, the output is relu(lin_value(x)) times the per-target SUM of
+    those coefficients, a fixed seed reproduces the mask, eval mode and p = 0 are the plain softmax."""
+    from raindrop_amd import ops
+    from raindrop_amd.Ob_propagation import Observation_progation
+    rng = np.random.default_rng(3)
+    n, K, p = 34, 240, 0.3
+    adj = (rng.random((n, n)) < 0.6).astype(np.float32) * rng.uniform(0.5, 1.5, (n, n)).astype(np.float32)
+    ei_np, ew_np = O2.build_graph(adj)
+    ei, ew = torch.from_numpy(ei_np).to(DEV), torch.from_numpy(ew_np).to(DEV)
+    g0, s0 = ops.edge_softmax_list(ei, ew, n, norm_row=1)
+    g1, s1 = ops.edge_softmax_list(ei, ew, n, norm_row=1, p_drop=p, seed=11)
+    g2, s2 = ops.edge_softmax_list(ei, ew, n, norm_row=1, p_drop=p, seed=11)
+    g3, _ = ops.edge_softmax_list(ei, ew, n, norm_row=1, p_drop=p, seed=12)
+    assert torch.equal(g1, g2) and torch.equal(s1, s2) and not torch.equal(g1, g3)
+    kept = g1 != 0
+    assert abs(float(kept.float().mean()) - (1 - p)) < 0.05
+    assert float((g1[kept] - g0[kept] / (1 - p)).abs().max()) < 1e-6
+    ref_sum = torch.zeros(n, device=DEV).index_add_(0, ei[1], g1)
+    assert float((s1 - ref_sum).abs().max()) < 1e-5
+    op = Observation_progation(K, K, n_nodes=n, ob_dim=4, heads=1, dropout=p)
+    synth.fill_params_(op, seed=4)
+    op = op.to(DEV).train()
+    x = torch.from_numpy(rng.standard_normal((n, K)).astype(np.float32)).to(DEV)
+    torch.manual_seed(5); op._drop_calls = 0
+    y1 = op(x, p_t=None, edge_index=ei, edge_weights=ew)
+    torch.manual_seed(5); op._drop_calls = 0
+    y2 = op(x, p_t=None, edge_index=ei, edge_weights=ew)
+    y3 = op(x, p_t=None, edge_index=ei, edge_weights=ew)                     # next call: another mask
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+    v = torch.relu(torch.nn.functional.linear(x, op.lin_value.weight, op.lin_value.bias))
+    ratio = (y1 / v.clamp_min(1e-20))[v > 1e-3]                              # = the target's dropped coefficient sum, per row
+    assert float(ratio.min()) >= -1e-4 and float(ratio.max()) <= 1.0 / (1 - p) + 1e-3
+    op.eval()
+    ye = op(x, p_t=None, edge_index=ei, edge_weights=ew)
+    assert float((ye - v * s0[:, None]).abs().max()) <= 2e-4 * float(v.abs().max())
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_transformer_conv_general_form_vs_reference_fixture(tag):
+    """Round 6 (VERDICT r5 missing #4): `TransformerConv` WITHOUT given edge weights -- q.k scores per edge and head, `lin_edge` on
+    the key, concat / head mean, root weight with and without the beta gate -- against the reference's own class
+    (tests/golden/tconv_general.npz, make_goldens.py TCONV_GENERAL; a 9-node graph with two duplicated edges): output, the returned
+    post-softmax coefficients, gradients w.r.t. x, edge_attr and every parameter.  Training-mode coefficient dropout: determinism,
+    kept fraction, and the eval path unchanged."""
+    import os
+    from raindrop_amd.transformer_conv import TransformerConv
+    from tests.helpers import GOLDEN
+    from tests.golden.make_goldens import TCONV_GENERAL
+    g = np.load(os.path.join(GOLDEN, "tconv_general.npz"))
+    _, H, C, concat, edim, beta, root, pseed = next(c for c in TCONV_GENERAL if c[0] == tag)
+    tc = TransformerConv(7, C, heads=H, concat=concat, beta=beta, edge_dim=edim, root_weight=root)
+    synth.fill_params_(tc, seed=pseed)
+    tc = tc.to(DEV).train()
+    x = torch.from_numpy(g["x"]).to(DEV).requires_grad_(True)
+    ei = torch.from_numpy(g["ei"]).to(DEV)
+    ea = torch.from_numpy(g[tag + "_ea"]).to(DEV).requires_grad_(True) if edim is not None else None
+    y, (ei_o, alpha) = tc(x, ei, edge_weights=None, edge_attr=ea, return_attention_weights=True)
+    tol = 2e-5 * TOL["x"]
+    assert torch.equal(ei_o, ei)
+    assert np.abs(alpha.detach().cpu().numpy() - g[tag + "_alpha"]).max() < tol
+    assert _rel(y.detach().cpu().numpy(), g[tag + "_y"]) < tol
+    names = [k for k, _ in tc.named_parameters()]
+    wrt = [x] + ([ea] if ea is not None else []) + [p_ for _, p_ in tc.named_parameters()]
+    grads = torch.autograd.grad((y * torch.from_numpy(g[tag + "_R"]).to(DEV)).sum(), wrt, allow_unused=True)
+    assert _rel(grads[0].cpu().numpy(), g[tag + "_gx"]) < 5 * tol
+    gi = 1
+    if ea is not None:
+        assert _rel(grads[1].cpu().numpy(), g[tag + "_gea"]) < 5 * tol
+        gi = 2
+    for k, got in zip(names, grads[gi:]):
+        key = tag + "_g/" + k
+        if key not in g.files:
+            continue
+        if k == "lin_key.bias":                  # the softmax is shift-invariant per target: analytically zero, rounding noise on both sides
+            assert got is not None and float(got.abs().max()) < 1e-5 and np.abs(g[key]).max() < 1e-5
+        else:
+            assert got is not None and _rel(got.cpu().numpy(), g[key]) < 5 * tol, k
+    # coefficient dropout (code/transformer_conv.py:203): masks are a function of (torch seed, call counter)
+    tc.dropout = 0.4
+    torch.manual_seed(3); tc._drop_calls = 0
+    y1 = tc(x, ei, edge_attr=ea)
+    torch.manual_seed(3); tc._drop_calls = 0
+    y2 = tc(x, ei, edge_attr=ea)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y)
+    tc.eval()
+    ye = tc(x, ei, edge_attr=ea)
+    assert float((ye - y).abs().max()) <= 1e-6 * max(1.0, float(y.abs().max()))

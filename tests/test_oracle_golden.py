@@ -154,3 +154,19 @@ def test_restatement_in_float64_bounds_the_fp32_reference_error():
     assert abs(float(ls32) - float(ls64)) < 1e-6
     for n in gr64:
         assert float((gr32[n].double() - gr64[n]).norm() / (gr64[n].norm() + 1e-300)) < 5e-6, n
+
+
+def test_restatement_of_the_general_transformer_conv_matches_the_fixture():
+    """O2's `transformer_conv_general` against the reference's own TransformerConv without edge weights (tconv_general.npz)."""
+    import os
+    from tests.helpers import GOLDEN
+    from tests.golden.make_goldens import TCONV_GENERAL
+    from raindrop_amd.transformer_conv import TransformerConv
+    g = np.load(os.path.join(GOLDEN, "tconv_general.npz"))
+    for tag, H, C, concat, edim, beta, root, pseed in TCONV_GENERAL:
+        tc = TransformerConv(7, C, heads=H, concat=concat, beta=beta, edge_dim=edim, root_weight=root)      # parameter names / shapes only
+        synth.fill_params_(tc, seed=pseed)
+        p = {k: v.detach() for k, v in tc.named_parameters()}
+        ea = torch.from_numpy(g[tag + "_ea"]) if edim is not None else None
+        y, a = O2.transformer_conv_general(torch.from_numpy(g["x"]), torch.from_numpy(g["ei"]), p, H, C, concat, ea, root)
+        assert np.abs(y.numpy() - g[tag + "_y"]).max() < 2e-6 and np.abs(a.numpy() - g[tag + "_alpha"]).max() < 1e-6, tag
