@@ -178,26 +178,60 @@ class TrainStep:
         f32 = dict(dtype=torch.float32, device=dev)
         # zero-filled: with a token plan parts of these buffers are never written, and a ghost product (x 0) of an uninitialised
         # NaN pattern would not be 0
-        u8 = lambda n: torch.zeros(max(int(n), 256), dtype=torch.uint8, device=dev)
-        self.z = torch.zeros((T, B, D), **f32)
+        # Every buffer of the step is carved out of ONE allocation (round 6; RD_STEP_ARENA=0: separate torch allocations, A/B): the
+        # large ones on 2-MB boundaries, the small ones packed into a common region.  Why: the K1 backward kernel's duration was
+        # bimodal BETWEEN PROCESSES (16.4 vs 18.6 us, HISTORY round 5: "it follows how the process's memory is mapped") -- with one
+        # contiguous mapping it is 16.2-16.6 us in every process and the step's kernel sum drops 0.6 % (four processes each,
+        # alternating, one call: profiles/r06_step_arena_ab.txt).  Every kernel of a step starts on cold translations (~1 GB of
+        # traffic since its last run); fewer, larger mappings are fewer walks.
+        arena = os.environ.get("RD_STEP_ARENA", "1") == "1"
+        if arena:
+            nl_ = len(m.transformer_encoder.layers)
+            al = lambda n: (max(int(n), 256) + (1 << 21) - 1) >> 21 << 21
+            sizes = [al(T * B * D * 4)] * (1 + nl_ + 2) + [al(lib.rd_msgpass_saved_bytes(sp)), al(lib.rd_msgpass_workspace_bytes(sp))] + \
+                    [al(lib.rd_encoder_layer_saved_bytes(sp))] * nl_ + [al(lib.rd_encoder_layer_workspace_bytes(sp))] * nl_
+            small_cap = 16 << 20                                  # the small buffers' common region (head workspace, features, plan, ...)
+            self._arena = torch.zeros(sum(sizes) + small_cap + (1 << 21), dtype=torch.uint8, device=dev)
+            self._arena_off = (-self._arena.data_ptr()) % (1 << 21)
+            self._small_off, self._small_end = self._arena_off, self._arena_off + small_cap
+            self._arena_off += small_cap
+
+            def carve(nbytes):
+                n = max(int(nbytes), 256)
+                if n < (1 << 20) and self._small_off + n <= self._small_end:
+                    o = self._small_off
+                    self._small_off += (n + 255) >> 8 << 8
+                else:
+                    o = self._arena_off
+                    self._arena_off += al(n)
+                    if self._arena_off > self._arena.numel():     # (sizes above are exact; a shape this list missed falls back)
+                        return torch.zeros(n, dtype=torch.uint8, device=dev)
+                return self._arena[o:o + n]
+            u8 = carve
+            zeros_f = lambda shape: carve(int(torch.Size(shape).numel()) * 4)[:int(torch.Size(shape).numel()) * 4].view(torch.float32).view(shape)
+        else:
+            u8 = lambda n: torch.zeros(max(int(n), 256), dtype=torch.uint8, device=dev)
+            zeros_f = lambda shape: torch.zeros(shape, **f32)
+        self._u8, self._zeros_f = u8, zeros_f
+        self.z = zeros_f((T, B, D))
         self.mask = torch.empty((B, T), dtype=torch.bool, device=dev)
         self.k1_saved = u8(lib.rd_msgpass_saved_bytes(sp))
         self.k1_ws = u8(lib.rd_msgpass_workspace_bytes(sp))
         self.nl = len(m.transformer_encoder.layers)
-        self.x = [self.z] + [torch.zeros((T, B, D), **f32) for _ in range(self.nl)]
+        self.x = [self.z] + [zeros_f((T, B, D)) for _ in range(self.nl)]
         self.enc_saved = [u8(lib.rd_encoder_layer_saved_bytes(sp)) for _ in range(self.nl)]
         # one workspace per layer: a layer's trailing reduce launch (side branch, rd_set_side_stream) reads its partials while the
         # next layer's backward already writes its own
         self.enc_wss = [u8(lib.rd_encoder_layer_workspace_bytes(sp)) for _ in range(self.nl)]
         self.enc_ws = self.enc_wss[0]
-        self.dx = [torch.zeros((T, B, D), **f32) for _ in range(2)]        # ping-pong gradient buffers
+        self.dx = [zeros_f((T, B, D)) for _ in range(2)]                   # ping-pong gradient buffers
         self.Fe = m.d_inp if m.static else 0
-        self.feat = torch.empty((B, D + self.Fe), **f32)
-        self.dfeat = torch.empty((B, D + self.Fe), **f32)
-        self.hid = torch.empty((B, D + self.Fe), **f32)
-        self.dhid = torch.empty((B, D + self.Fe), **f32)
-        self.logits = torch.empty((B, m.n_classes), **f32)
-        self.dlogits = torch.empty((B, m.n_classes), **f32)
+        self.feat = zeros_f((B, D + self.Fe))
+        self.dfeat = zeros_f((B, D + self.Fe))
+        self.hid = zeros_f((B, D + self.Fe))
+        self.dhid = zeros_f((B, D + self.Fe))
+        self.logits = zeros_f((B, m.n_classes))
+        self.dlogits = zeros_f((B, m.n_classes))
         self.loss = torch.zeros((), **f32)
         dh = D + self.Fe
         self.wg_ws = u8(max(lib.rd_linear_bwd_weight_workspace_bytes(B, dh, dh),
