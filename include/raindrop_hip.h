@@ -190,7 +190,9 @@ int rd_aggregate_bwd(int32_t N, int32_t C, const float* gamma, const float* dout
  * q, k, v [N,H*C] row-major; edge_index rows [source; target] `row_stride` apart (duplicate edges allowed); alpha [E,H] receives
  * the POST-softmax coefficients (what the operator returns), alpha_drop [E,H] the dropped ones (kept for the backward), out
  * [N,H*C].  Backward: dout [N,H*C] -> dq, dk, dv [N,H*C], dedge_feat [E,H*C] (NULL iff edge_feat is); ds_ws: E*H floats.
- * Deterministic: sums over a node's edges in edge order, fixed-tree block reductions. */
+ * Deterministic: sums over a node's edges in edge order, fixed-tree block reductions.  Endpoints must lie in [0,N): the host
+ * mirror validates each edge list once (IndexError, like the reference's index_select); the kernels clamp what they index with, so
+ * a bad list gives unspecified coefficients for that edge, not a wild read.  E = 0 is legal (out = 0). */
 int rd_edge_attention_fwd(int32_t N, int32_t E, int32_t H, int32_t C, const float* q, const float* k, const float* v,
                           const float* edge_feat, const int64_t* edge_index, int64_t row_stride, float p_drop, uint64_t seed,
                           float* alpha, float* alpha_drop, float* out, void* stream);

@@ -24,6 +24,10 @@ struct EAttnArgs {
   const float* dout; float *ds, *dq, *dk, *dv, *dea;
 };
 
+// source endpoint, clamped into [0, N): the host mirror validates the list (ops._validate_edges raises IndexError like the
+// reference's index_select); a raw C-ABI caller with a bad list gets unspecified coefficients for that edge, never a wild read
+__device__ __forceinline__ int src_of(const EAttnArgs& a, int e) { return min(max((int)a.src[e], 0), a.N - 1); }
+
 __device__ __forceinline__ float block_max(float v, float* red) {
   red[threadIdx.x] = v; __syncthreads();
   for (int o = EA_THR / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(EA_THR) void k_eattn_fwd(EAttnArgs a) {
     float m = -INFINITY;
     for (int e = tid; e < a.E; e += EA_THR)
       if ((int)a.tgt[e] == i) {
-        const float* kj = a.k + (size_t)a.src[e] * HC + h * a.C;
+        const float* kj = a.k + (size_t)src_of(a, e) * HC + h * a.C;
         float s = 0.f;
         if (a.ea) { const float* ee = a.ea + (size_t)e * HC + h * a.C; for (int c = 0; c < a.C; ++c) s += qi[c] * (kj[c] + ee[c]); }
         else for (int c = 0; c < a.C; ++c) s += qi[c] * kj[c];
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(EA_THR) void k_eattn_fwd(EAttnArgs a) {
     const int h = hc / a.C;
     float acc = 0.f;
     for (int e = 0; e < a.E; ++e)
-      if ((int)a.tgt[e] == i) acc += a.alpha_d[(size_t)e * a.H + h] * a.v[(size_t)a.src[e] * HC + hc];
+      if ((int)a.tgt[e] == i) acc += a.alpha_d[(size_t)e * a.H + h] * a.v[(size_t)src_of(a, e) * HC + hc];
     a.out[(size_t)i * HC + hc] = acc;
   }
 }
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(EA_THR) void k_eattn_bwd_tgt(EAttnArgs a) {
     float part = 0.f;
     for (int e = tid; e < a.E; e += EA_THR)
       if ((int)a.tgt[e] == i) {
-        const float* vj = a.v + (size_t)a.src[e] * HC + h * a.C;
+        const float* vj = a.v + (size_t)src_of(a, e) * HC + h * a.C;
         float d = 0.f;
         for (int c = 0; c < a.C; ++c) d += doi[c] * vj[c];
         d *= keep_scale(a, seed_eff, e, h);                    // through the dropout
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(EA_THR) void k_eattn_bwd_tgt(EAttnArgs a) {
     float acc = 0.f;
     for (int e = 0; e < a.E; ++e)
       if ((int)a.tgt[e] == i) {
-        float kk = a.k[(size_t)a.src[e] * HC + hc];
+        float kk = a.k[(size_t)src_of(a, e) * HC + hc];
         if (a.ea) kk += a.ea[(size_t)e * HC + hc];
         acc += a.ds[(size_t)e * a.H + h] * kk;
       }
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(EA_THR) void k_eattn_bwd_src(EAttnArgs a) {
     float av = 0.f, ak = 0.f;
     for (int e = 0; e < a.E; ++e)
       if ((int)a.src[e] == j) {
-        const size_t t = (size_t)a.tgt[e] * HC + hc;
+        const size_t t = (size_t)min(max((int)a.tgt[e], 0), a.N - 1) * HC + hc;
         av += a.alpha_d[(size_t)e * a.H + h] * a.dout[t];
         ak += a.ds[(size_t)e * a.H + h] * a.q[t];
       }
@@ -156,7 +160,7 @@ extern "C" int rd_edge_attention_fwd(int32_t N, int32_t E, int32_t H, int32_t C,
                                      uint64_t seed, float* alpha, float* alpha_drop, float* out, void* stream) {
   int rc = check_ea(N, E, H, C);
   if (rc) return rc;
-  RD_REQUIRE(q && k && v && edge_index && alpha && alpha_drop && out, "NULL tensor");
+  RD_REQUIRE(q && k && v && out && (E == 0 || (edge_index && alpha && alpha_drop)), "NULL tensor");
   RD_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "p_drop must be in [0,1)");
   EAttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.ea = edge_feat; a.src = edge_index; a.tgt = edge_index + row_stride;
@@ -172,8 +176,8 @@ extern "C" int rd_edge_attention_bwd(int32_t N, int32_t E, int32_t H, int32_t C,
                                      float* dq, float* dk, float* dv, float* dedge_feat, void* stream) {
   int rc = check_ea(N, E, H, C);
   if (rc) return rc;
-  RD_REQUIRE(q && k && v && edge_index && alpha && alpha_drop && dout && ds_ws && dq && dk && dv, "NULL tensor");
-  RD_REQUIRE((edge_feat == nullptr) == (dedge_feat == nullptr), "edge features and their gradient go together");
+  RD_REQUIRE(q && k && v && dout && dq && dk && dv && (E == 0 || (edge_index && alpha && alpha_drop && ds_ws)), "NULL tensor");
+  RD_REQUIRE(E == 0 || (edge_feat == nullptr) == (dedge_feat == nullptr), "edge features and their gradient go together");
   EAttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.ea = edge_feat; a.src = edge_index; a.tgt = edge_index + row_stride;
   a.N = N; a.E = E; a.H = H; a.C = C; a.scale = 1.0f / sqrtf((float)C); a.p_drop = p_drop; a.seed = seed; a.cell = seed_cell();

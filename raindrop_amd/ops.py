@@ -291,6 +291,16 @@ class _EdgeAttention(torch.autograd.Function):
 
 def edge_attention(q, k, v, edge_feat, edge_index, heads, channels, p_drop=0.0, seed=0):
     """(out [N, heads*channels], alpha [E, heads] post-softmax) -- code/transformer_conv.py:186-207 without given edge weights."""
+    if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise ValueError("edge_attention: edge_index [2,E] expected, got %s" % (tuple(edge_index.shape),))
+    N, HC = q.shape[0], int(heads) * int(channels)
+    for name, t in (("q", q), ("k", k), ("v", v)):
+        if tuple(t.shape) != (N, HC):
+            raise ValueError("edge_attention: %s must be [N, heads*channels] = %s, got %s" % (name, (N, HC), tuple(t.shape)))
+    if edge_feat is not None and tuple(edge_feat.shape) != (edge_index.shape[1], HC):
+        raise ValueError("edge_attention: edge features must be [E, heads*channels] = %s, got %s"
+                         % ((edge_index.shape[1], HC), tuple(edge_feat.shape)))
+    _validate_edges(edge_index, N, "edge_attention")
     ef = None if edge_feat is None else edge_feat.contiguous()
     return _EdgeAttention.apply(q.contiguous(), k.contiguous(), v.contiguous(), ef, edge_index.contiguous(), int(heads), int(channels),
                                 float(p_drop), int(seed))
@@ -494,6 +504,27 @@ def _colsum_rows(x):
 _EDGES_CHECKED = set()
 
 
+def _validate_edges(edge_index, N, who):
+    """Edge endpoints in [0, N): one device read per edge LIST (keyed by storage, version and size -- the models pass their cached
+    graph every call), because the read syncs and is not permitted while a hipGraph is being captured (AutogradStep).  The
+    reference's index_select raises IndexError at the same point."""
+    E = edge_index.shape[1]
+    if E == 0:
+        return
+    key = (edge_index.data_ptr(), edge_index._version, E, N, str(edge_index.device))
+    if key in _EDGES_CHECKED:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        raise _lib.RaindropHipError("%s: this edge list has not been validated yet and a stream capture is in progress; "
+                                    "run one eager step first" % who)
+    lo, hi = int(edge_index.min()), int(edge_index.max())
+    if lo < 0 or hi >= N:
+        raise IndexError("%s: edge endpoint out of range [0, %d): min %d, max %d" % (who, N, lo, hi))
+    if len(_EDGES_CHECKED) > 64:
+        _EDGES_CHECKED.clear()
+    _EDGES_CHECKED.add(key)
+
+
 def graph_beta(V, H, map_w, p_t, edge_index, edge_weights, d_ob=4):
     """use_beta branch of Observation_progation.message, batched (include/raindrop_hip.h: rd_graph_beta_fwd).  V [B,N,K],
     H [B,N,T*32], map_w [N,16], p_t [B or 1, T, 16], edge_index int64 [2,E], edge_weights [B or 1, E].  Shapes and edge
@@ -513,20 +544,7 @@ def graph_beta(V, H, map_w, p_t, edge_index, edge_weights, d_ob=4):
         raise ValueError("graph_beta: p_t must be [1 or B, T, 16], got %s" % (tuple(p_t.shape),))
     if edge_weights.dim() != 2 or edge_weights.shape[0] not in (1, B) or edge_weights.shape[1] != E:
         raise ValueError("graph_beta: edge_weights must be [1 or B, E], got %s" % (tuple(edge_weights.shape),))
-    if E > 0:
-        # validated once per edge list (keyed by storage, version and size: the model passes its cached graph every call) -- the
-        # device read would otherwise sync every step, and is not permitted while a hipGraph is being captured (AutogradStep)
-        key = (edge_index.data_ptr(), edge_index._version, E, N, str(edge_index.device))
-        if key not in _EDGES_CHECKED:
-            if torch.cuda.is_current_stream_capturing():
-                raise _lib.RaindropHipError("graph_beta: this edge list has not been validated yet and a stream capture is in progress; "
-                                            "run one eager step first")
-            lo, hi = int(edge_index.min()), int(edge_index.max())
-            if lo < 0 or hi >= N:
-                raise IndexError("graph_beta: edge endpoint out of range [0, %d): min %d, max %d" % (N, lo, hi))
-            if len(_EDGES_CHECKED) > 64:
-                _EDGES_CHECKED.clear()
-            _EDGES_CHECKED.add(key)
+    _validate_edges(edge_index, N, "graph_beta")
     return _GraphBeta.apply(V.contiguous(), H.contiguous(), map_w.contiguous(), p_t.contiguous(), edge_index.contiguous(),
                             edge_weights.contiguous(), int(d_ob))
 

@@ -1241,7 +1241,7 @@ def test_edge_coefficient_dropout_of_the_operator():
     y3 = op(x, p_t=None, edge_index=ei, edge_weights=ew)                     # next call: another mask
     assert torch.equal(y1, y2) and not torch.equal(y1, y3)
     v = torch.relu(torch.nn.functional.linear(x, op.lin_value.weight, op.lin_value.bias))
-    ratio = (y1 / v.clamp_min(1e-20))[v > 1e-3]                              # = the target's dropped coefficient sum, per row
+    ratio = (y1 / v.clamp_min(1e-20))[v > 1e-3].detach()                           # = the target's dropped coefficient sum, per row
     assert float(ratio.min()) >= -1e-4 and float(ratio.max()) <= 1.0 / (1 - p) + 1e-3
     op.eval()
     ye = op(x, p_t=None, edge_index=ei, edge_weights=ew)
@@ -1298,3 +1298,54 @@ def test_transformer_conv_general_form_vs_reference_fixture(tag):
     tc.eval()
     ye = tc(x, ei, edge_attr=ea)
     assert float((ye - y).abs().max()) <= 1e-6 * max(1.0, float(y.abs().max()))
+
+
+def test_transformer_conv_general_form_edge_cases():
+    """The general form on the lists the fixture does not hold: an EMPTY edge list (out = root weight only, alpha [0, H]), nodes
+    without in-edges (their aggregate is zero) next to a node with 300 in-edges (more than one pass of the 256-thread scan), and an
+    endpoint out of range (IndexError, as the reference's index_select raises).  Checked against the same sums written with torch
+    scatter operations in fp64."""
+    from raindrop_amd.transformer_conv import TransformerConv
+    N, H, C = 11, 3, 5
+    tc = TransformerConv(7, C, heads=H, concat=True, root_weight=True)
+    synth.fill_params_(tc, seed=5)
+    tc = tc.to(DEV).eval()
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(N, 7, generator=gen).to(DEV).requires_grad_(True)
+    # (1) empty list
+    e0 = torch.zeros((2, 0), dtype=torch.int64, device=DEV)
+    y0, (_, a0) = tc(x, e0, return_attention_weights=True)
+    skip = torch.nn.functional.linear(x.double(), tc.lin_skip.weight.double(), tc.lin_skip.bias.double())
+    assert tuple(a0.shape) == (0, H)
+    assert float((y0.double() - skip).abs().max()) < 2e-5 * TOL["x"] * float(skip.abs().max())
+    g0, = torch.autograd.grad(y0.sum(), x)
+    assert float((g0.double() - tc.lin_skip.weight.double().sum(0)[None, :]).abs().max()) < 1e-4
+    # (2) 300 edges into node 4, a few into node 9, none into the others (duplicates included)
+    src = torch.randint(0, N, (310,), generator=gen)
+    tgt = torch.cat([torch.full((300,), 4), torch.full((10,), 9)])
+    ei = torch.stack([src, tgt]).to(DEV)
+    y, (_, al) = tc(x, ei, return_attention_weights=True)
+    xd = x.double()
+    q = torch.nn.functional.linear(xd, tc.lin_query.weight.double(), tc.lin_query.bias.double()).view(N, H, C)
+    k = torch.nn.functional.linear(xd, tc.lin_key.weight.double(), tc.lin_key.bias.double()).view(N, H, C)
+    v = torch.nn.functional.linear(xd, tc.lin_value.weight.double(), tc.lin_value.bias.double()).view(N, H, C)
+    s = (q[ei[1]] * k[ei[0]]).sum(-1) / C ** 0.5                                  # [E, H]
+    ref_al = torch.zeros_like(s)
+    for t in (4, 9):
+        m = ei[1] == t
+        ref_al[m] = torch.softmax(s[m], dim=0)
+    agg = torch.zeros(N, H, C, dtype=torch.float64, device=DEV).index_add_(0, ei[1], ref_al[:, :, None] * v[ei[0]])
+    ref = agg.view(N, H * C) + skip
+    assert float((al.double() - ref_al).abs().max()) < 2e-5 * TOL["x"]
+    assert float((y.double() - ref).abs().max()) < 2e-5 * TOL["x"] * float(ref.abs().max())
+    R = torch.randn(N, H * C, generator=gen).to(DEV)
+    gx, = torch.autograd.grad((y * R).sum(), x)
+    gref, = torch.autograd.grad((ref * R.double()).sum(), x)
+    assert float((gx.double() - gref).abs().max()) < 1e-4 * TOL["x"] * float(gref.abs().max())
+    # (3) an endpoint out of range
+    bad = ei.clone(); bad[0, 7] = N
+    with pytest.raises(IndexError):
+        tc(x, bad)
+    bad = ei.clone(); bad[1, 3] = -1
+    with pytest.raises(IndexError):
+        tc(x, bad)
