@@ -54,6 +54,7 @@ def parse():
                     help="CPU baseline sample cap in batches (it stops after ~15 s of wall clock anyway)")
     ap.add_argument("--k1-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--graph-probe", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--full-graph-probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--feed", action="store_true",
                     help="draw every step's batch from a device-resident dataset with rd_batch_gather (SURVEY 8f "
                          "rank 1) instead of re-using one resident batch (the default, as the metric is defined)")
@@ -708,6 +709,44 @@ def graph_probe_ok(args, world):
         return False
 
 
+def full_graph_probe_ok(args, world, rank, dev, limit_s=300.0):
+    """N > 1, guard (0) of the whole-step graph: RCCL collectives under stream capture between REAL peers have never run on this
+    pool (one-rank groups only), and a capture or a replay that HANGS cannot be caught in-process.  So every rank first starts a
+    CHILD of this script (`--full-graph-probe`) on its own GPU; the children form their own process group on a fresh port, capture
+    the whole step and replay it three times.  A child that fails, or is still running after `limit_s` (killed by exact pid), costs
+    the whole-step graph -- all ranks then take the two-graph step with eager collectives -- never the benchmark line."""
+    import socket
+    import subprocess
+    port = torch.zeros(1, dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    if rank == 0:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port[0] = sk.getsockname()[1]
+    dist.broadcast(port, 0)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC") and k != "TORCH_NCCL_ASYNC_ERROR_HANDLING"}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(int(port.item())), RD_BENCH_OTHER="0", RD_BENCH_LIVE_TRACE="0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--full-graph-probe", "--gpus", str(world), "--batch", str(args.batch),
+           "--config", args.config, "--no-cpu-baseline"]
+    ok = False
+    try:
+        child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+        try:
+            out, err = child.communicate(timeout=limit_s)
+            ok = any(ln.startswith("FULLPROBE ok") for ln in out.splitlines())
+            if not ok:
+                print("rank %d: whole-step graph probe failed (rc %s): %s" % (rank, child.returncode, (err or "")[-300:]),
+                      file=sys.stderr, flush=True)
+        except subprocess.TimeoutExpired:
+            child.kill()
+            child.communicate()
+            print("rank %d: whole-step graph probe still running after %.0f s: killed" % (rank, limit_s), file=sys.stderr, flush=True)
+    except Exception as e:                                           # pragma: no cover
+        print("rank %d: whole-step graph probe could not run (%r)" % (rank, e), file=sys.stderr, flush=True)
+    fk = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=port.device)
+    dist.all_reduce(fk, op=dist.ReduceOp.MIN)
+    return bool(fk.item() > 0.5)
+
+
 def usable_cores():
     """Cores this process may really use: affinity mask capped by the cgroup CPU quota (a container
     can report 256 CPUs and be throttled to 8; an OpenMP team sized by cpu_count() then crawls)."""
@@ -825,7 +864,7 @@ def main():
     # --feed: every step first gathers a fresh batch INTO the resident buffers (one extra launch) from a
     # device-resident dataset, the way code/Raindrop.py:310-317 slices its training tensors on the host
     feed_next = None
-    if args.feed and not args.k1_child and not args.graph_probe:
+    if args.feed and not args.k1_child and not args.graph_probe and not args.full_graph_probe:
         from raindrop_amd import feed as rfeed
         n_feed = 8192
         big = synth.make_batch(cfg, n_feed, seed=200 + rank)
@@ -866,6 +905,19 @@ def main():
         torch.cuda.synchronize()
         print("GRAPHPROBE ok %.6f" % float(ts_.loss), flush=True)
         return
+    if args.full_graph_probe:                  # child of full_graph_probe_ok: own process group (the parent's ranks, a fresh port)
+        from raindrop_amd.step import TrainStep
+        ts_ = TrainStep(model, flat, batch)
+        ts_.capture_full(opt)
+        for _ in range(3):
+            l_ = ts_.run_full()
+        torch.cuda.synchronize()
+        fin = bool(torch.isfinite(l_).item())
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        print("FULLPROBE %s %.6f" % ("ok" if fin else "nonfinite", float(l_)), flush=True)
+        return
     probe_ok = bool(use_graph and graph_probe_ok(args, world))
     if world > 1:                               # the step mode is a collective decision: every rank must take
         pk = torch.tensor([1.0 if probe_ok else 0.0], dtype=torch.float64, device=dev)   # the same branches below
@@ -877,13 +929,17 @@ def main():
 
     # The whole step -- forward + loss + backward, the all-reduce(s) and Adam -- as ONE hipGraph (TrainStep.capture_full): one replay
     # per step on the host.  Round 5: default on one GPU, opt-in at N > 1.  Round 6: the default at every N (RD_STEP_FULL=0: the
-    # two-graph step with eager collectives + the Adam launch) -- behind two guards, because RCCL under stream capture has only run
-    # on a one-rank group here (tests/test_dp_gpu.py): (1) the capture is tried per rank and the outcome agreed by an all-reduce(MIN),
+    # two-graph step with eager collectives + the Adam launch) -- behind three guards, because RCCL under stream capture has only run
+    # on a one-rank group here (tests/test_dp_gpu.py): (0) children of the ranks try capture + replay first in a group of their own
+    # (full_graph_probe_ok: a HANG there is killed after 300 s); (1) the capture is tried per rank and the outcome agreed by an all-reduce(MIN),
     # so either every rank replays the whole-step graph or none does; (2) the first replays are checked: three whole-step replays
     # must leave finite losses on every rank, else all ranks drop back to the two-graph form (the parameters are restored first).
     full_graph = [False]
     # (only RCCL collectives can be captured: the gloo group of the RD_BENCH_ONE_GPU test mode synchronises on the host)
     can_capture = world == 1 or dist.get_backend() == "nccl"
+    want_full = tstep is not None and not args.no_optimizer and os.environ.get("RD_STEP_FULL", "1") == "1"
+    if world > 1 and want_full and (can_capture or os.environ.get("RD_BENCH_FORCE_FULL_PROBE") == "1"):
+        can_capture = full_graph_probe_ok(args, world, rank, dev) and can_capture      # guard (0): hangs are caught in a child
     if tstep is not None and not args.no_optimizer and can_capture and os.environ.get("RD_STEP_FULL", "1") == "1":
         snap = None
         try:

@@ -210,6 +210,33 @@ def test_bench_two_ranks_launch_line_on_one_gpu():
     assert "all-reduce" in d["config"]["workload"]
 
 
+def test_bench_whole_step_graph_probe_child_and_its_failure_path():
+    """Guard (0) of the whole-step graph at N > 1 (bench.full_graph_probe_ok): every rank's CHILD tries capture + replay in a
+    process group of its own, so that a hang costs the graph, not the line.  (a) The child itself (`--full-graph-probe`, here as a
+    single process) captures the whole step, replays it and reports a finite loss.  (b) Two ranks as the driver launches them, on
+    one GPU over gloo with the probe forced: the children get a fresh port, form their group, FAIL (gloo collectives cannot be
+    captured), every rank reports it, and the parents still print the one JSON line with the two-graph step."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--full-graph-probe", "--gpus", "1", "--batch", "32",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert res.returncode == 0 and any(ln.startswith("FULLPROBE ok") for ln in res.stdout.splitlines()), (res.stdout[-1000:], res.stderr[-2000:])
+    env.update(RD_BENCH_ONE_GPU="1", RD_BENCH_FORCE_FULL_PROBE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--batch", "32", "--no-roofline", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert res.returncode == 0 and len(lines) == 1, (res.returncode, res.stdout[-2000:], res.stderr[-2000:])
+    assert res.stderr.count("whole-step graph probe failed") == 2, res.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "ONE hipGraph per step" not in str(d["config"].get("step_mode"))
+
+
 def _rccl_worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
