@@ -252,6 +252,8 @@ struct Stage {
       }
     }
   }
+  // LO = false (one-product bf16 mode, where the lo plane is never read): the residual's arithmetic and its LDS store are skipped
+  template <bool LO = true>
   __device__ static __forceinline__ void store(const float (&r)[NREG], unsigned long long ok, __bf16* __restrict__ Th,
                                                __bf16* __restrict__ Tl, int tid) {
     if (KC) {
@@ -262,11 +264,11 @@ struct Stage {
         for (int j = 0; j < 4; ++j) {
           const float x = ((ok >> (4 * p + j)) & 1ull) ? r[p * 4 + j] : 0.f;
           h[j] = (__bf16)x;
-          l[j] = (__bf16)(x - (float)h[j]);
+          if (LO) l[j] = (__bf16)(x - (float)h[j]);
         }
         const int o = (p * 16 + (tid >> 4)) * LDB + (tid & 15) * 4;
         *reinterpret_cast<bf16x4*>(Th + o) = h;
-        *reinterpret_cast<bf16x4*>(Tl + o) = l;
+        if (LO) *reinterpret_cast<bf16x4*>(Tl + o) = l;
       }
     } else {
 #pragma unroll
@@ -276,11 +278,11 @@ struct Stage {
         for (int j = 0; j < 8; ++j) {
           const float x = r[q * 8 + j];
           h[j] = (__bf16)x;
-          l[j] = (__bf16)(x - (float)h[j]);
+          if (LO) l[j] = (__bf16)(x - (float)h[j]);
         }
         const int o = (tid % ROWS) * LDB + (tid / ROWS) * KPT + q * 8;
         *reinterpret_cast<bf16x8*>(Th + o) = h;
-        *reinterpret_cast<bf16x8*>(Tl + o) = l;
+        if (LO) *reinterpret_cast<bf16x8*>(Tl + o) = l;
       }
     }
   }
@@ -584,6 +586,10 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
     if (!g.one_product) mma_steps(std::true_type{});
     else mma_steps(std::false_type{});
   };
+  auto stage_store = [&](int t) {                      // one-product mode never reads the lo planes: not computed, not stored
+    if (!g.one_product) { SA::store(ra[t], oka[t], Ah, Al, tid); SB::store(rb[t], okb[t], Bh, Bl, tid); }
+    else { SA::template store<false>(ra[t], oka[t], Ah, Al, tid); SB::template store<false>(rb[t], okb[t], Bh, Bl, tid); }
+  };
 
   if (NPRE > 0) {
 #pragma unroll
@@ -593,8 +599,7 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
 #pragma unroll
           for (int i = 0; i < SA::NREG; ++i) rsum += ra[t][i];
         }
-        SA::store(ra[t], oka[t], Ah, Al, tid);
-        SB::store(rb[t], okb[t], Bh, Bl, tid);
+        stage_store(t);
         __syncthreads();
         if (t == 0) GSTAMP(1);
         mma_tile();
@@ -607,8 +612,7 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < SA::NREG; ++i) rsum += ra[0][i];
       }
-      SA::store(ra[0], oka[0], Ah, Al, tid);
-      SB::store(rb[0], okb[0], Bh, Bl, tid);
+      stage_store(0);
       __syncthreads();
       if (k0 == kbeg) GSTAMP(1);
       if (k0 + BK2 < kend) {
@@ -778,7 +782,8 @@ __global__ __launch_bounds__(512) void k_gemm_panel(GemmArgs g) {
     if (!g.one_product) products(Ah, Ah + PLANE, cur, std::true_type{});
     else products(Ah, Ah + PLANE, cur, std::false_type{});
     __bf16* Nh = Pg + (size_t)((i + 1) & 1) * 2 * PLANE;
-    SA::store(ra, oka, Nh, Nh + PLANE, gt);           // round i+1's chunk
+    if (!g.one_product) SA::store(ra, oka, Nh, Nh + PLANE, gt);           // round i+1's chunk
+    else SA::template store<false>(ra, oka, Nh, Nh + PLANE, gt);
     load_a(2 * (i + 2) + grp);
     lds_barrier();                                    // buffer i & 1 is free for round i+2; buffer (i+1) & 1 is complete
   };
@@ -786,7 +791,8 @@ __global__ __launch_bounds__(512) void k_gemm_panel(GemmArgs g) {
   load_a(grp);
   load_b(b0, grp);
   if (tid < TN) bias_s[tid] = (g.bias && n0 + tid < g.N) ? g.bias[n0 + tid] : 0.f;
-  SA::store(ra, oka, Pg, Pg + PLANE, gt);
+  if (!g.one_product) SA::store(ra, oka, Pg, Pg + PLANE, gt);
+  else SA::template store<false>(ra, oka, Pg, Pg + PLANE, gt);
   load_a(2 + grp);
   lds_barrier();
   PSTAMP(1);
