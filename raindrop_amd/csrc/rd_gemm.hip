@@ -823,13 +823,151 @@ __global__ __launch_bounds__(512) void k_gemm_panel(GemmArgs g) {
 #undef PSTAMP
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide panel product (round 6): the same product on a 128 x 256 workgroup tile -- eight waves side by side, each ALL 128 rows x 32
+// columns (RT = 8 row tiles x NJ = 2: 48 MFMAs per 32 k and wave), no split of K inside the workgroup.  Why: an ablation of
+// k_gemm_panel at the 2048-wide shapes (profiles/r06_panel_ablation.txt) showed its parts ADD UP instead of overlapping -- MFMAs 49 %
+// of the time, the fp32 -> split-bf16 conversion of A 23 %, the weight-fragment loads 14 %, the A loads 12 % -- and all but the
+// MFMAs scale with 1 / tile width (A is converted once per COLUMN block) or 1 / tile height (a weight fragment feeds RT MFMAs per
+// product).  Twice the width and twice the height halve all three per MFMA.  One workgroup per CU (82 KB of planes, <= 256
+// registers at two waves per SIMD), so it pays only where the tile count fits the chip's 256 CUs well: panel_wide_pays() below.
+// A is staged by both halves of the workgroup (threads 0-255: rows 0-63, 256-511: rows 64-127; double-buffered hi/lo planes, one
+// LDS-only barrier per 64 k); the epilogue runs twice over 64-row halves (its transpose stage must fit the dead planes).
+// Sums over k run in chunk order here (k_gemm_panel: even / odd chunks in two accumulator sets): same products, another fp32
+// rounding order -- both within the split-bf16 bound the tests hold every product to.
+// ------------------------------------------------------------------------------------------------
+template <int NJ>
+__global__ __launch_bounds__(512) void k_gemm_panel_wide(GemmArgs g) {
+  RD_TOUCH_CODE_X(RD_TL_GEMM_PANEL_WIDE, blockIdx.x, 512);
+  constexpr int RT = 8, TM = 16 * RT, HM = TM / 2, TN = 128 * NJ, PLANE = TM * LDB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+  __bf16* Pb = reinterpret_cast<__bf16*>(gsm);                  // [2 buffers][hi, lo][TM][LDB]
+  constexpr size_t PLANES_B = (size_t)4 * PLANE * sizeof(__bf16), STAGE_B = (size_t)HM * (TN + 4) * sizeof(float);
+  static_assert(STAGE_B <= PLANES_B, "the epilogue's half-tile stage must fit the dead planes");
+  float* bias_s = reinterpret_cast<float*>(gsm + PLANES_B);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = tid >> 8, gt = tid & 255;
+  const int ncb = (g.N + TN - 1) / TN, tiles = ncb * ((g.M + TM - 1) / TM), per = (tiles + 7) / 8;     // XCD order: as k_gemm_panel
+  const int lin = g.xcd_swizzle ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (lin >= tiles || (g.xcd_swizzle && (int)(blockIdx.x >> 3) >= per)) return;
+  const int rblk = lin / ncb, cblk = lin - rblk * ncb;
+  const int m0 = rblk * TM, n0 = cblk * TN;
+  const int nkc = g.bt_nkc;
+  const __bf16* Bt = reinterpret_cast<const __bf16*>(g.Btiles);
+  size_t toff[NJ];
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) toff[jj] = (size_t)min(n0 / 16 + wave * NJ + jj, g.bt_ntile - 1) * nkc * 1024 + lane * 8;
+  using SA = Stage<true, HM>;                                   // each half of the workgroup stages its 64 rows
+  float ra[SA::NREG]; unsigned long long oka;
+  const int nch = (g.K + BK2 - 1) / BK2;
+  f32x4 acc[RT][NJ];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  struct BFr { bf16x8 h[NJ][2], l[NJ][2]; };
+  auto load_b = [&](BFr& b, int c) {                            // unconditional look-ahead (past the end: the last chunk again)
+    const int cc = min(c, nch - 1);
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const __bf16* t = Bt + toff[jj] + (size_t)min(2 * cc + ks, nkc - 1) * 1024;
+        b.h[jj][ks] = *reinterpret_cast<const bf16x8*>(t);
+        b.l[jj][ks] = *reinterpret_cast<const bf16x8*>(t + 512);
+      }
+  };
+  auto load_a = [&](int c) {
+    SA::load(ra, oka, g.A, g.sa_m, 1, m0 + half * HM, g.M, min(c, nch - 1) * BK2, g.K, gt, true);
+    if (c >= nch) oka = 0ull;
+  };
+  auto store_a = [&](__bf16* Ph) {                               // Ph: the buffer's hi plane; this half's rows
+    __bf16* h = Ph + (size_t)half * HM * LDB;
+    if (!g.one_product) SA::store(ra, oka, h, h + PLANE, gt);
+    else SA::template store<false>(ra, oka, h, h + PLANE, gt);
+  };
+  const int aoff = (lane & 15) * LDB + 8 * (lane >> 4);
+  auto products = [&](const __bf16* Ah, const __bf16* Al, const BFr& b, auto three_tag) {
+    constexpr bool THREE = decltype(three_tag)::value;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ah[RT], al[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * LDB + aoff + ks * 32);
+        if (THREE) al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * LDB + aoff + ks * 32);
+      }
+      if (THREE) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) acc[rt][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], b.h[jj][ks], acc[rt][jj], 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) acc[rt][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], b.l[jj][ks], acc[rt][jj], 0, 0, 0);
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) acc[rt][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], b.h[jj][ks], acc[rt][jj], 0, 0, 0);
+    }
+  };
+  // round i: chunk i on buffer i & 1 with fragments `cur`; chunk i+1 is converted into the other buffer, chunk i+2's loads leave
+  auto step = [&](int i, const BFr& cur, BFr& nxt) {
+    __bf16* Ah = Pb + (size_t)(i & 1) * 2 * PLANE;
+    load_b(nxt, i + 1);
+    if (!g.one_product) products(Ah, Ah + PLANE, cur, std::true_type{});
+    else products(Ah, Ah + PLANE, cur, std::false_type{});
+    store_a(Pb + (size_t)((i + 1) & 1) * 2 * PLANE);
+    load_a(i + 2);
+    lds_barrier();
+  };
+  BFr b0, b1;
+  load_a(0);
+  load_b(b0, 0);
+  if (tid < TN) bias_s[tid] = (g.bias && n0 + tid < g.N) ? g.bias[n0 + tid] : 0.f;
+  store_a(Pb);
+  load_a(1);
+  lds_barrier();
+  int i = 0;
+  for (; i + 1 < nch; i += 2) { step(i, b0, b1); step(i + 1, b1, b0); }
+  if (i < nch) step(i, b0, b1);
+  // epilogue over the two 64-row halves of the tile (the stage aliases the planes: every wave is past its last fragment read)
+  float* stage = reinterpret_cast<float*>(gsm);
+  epilogue_t<RT / 2, NJ, 1, 8, 512>(g, reinterpret_cast<f32x4(&)[RT / 2][NJ]>(acc[0]), stage, bias_s, m0, n0, 0, wave, 0, tid, lane);
+  __syncthreads();
+  epilogue_t<RT / 2, NJ, 1, 8, 512>(g, reinterpret_cast<f32x4(&)[RT / 2][NJ]>(acc[RT / 2]), stage, bias_s, m0 + HM, n0, 0, wave, 0, tid, lane);
+}
+
 // the panel form applies: pre-split weight tiles given, A k-contiguous with 16-byte rows, one plain pass
 static bool panel_ok(const GemmArgs& g) {
   static const bool on = [] { const char* e = getenv("RD_GEMM_PANEL"); return !(e && atoi(e) == 0); }();
   return on && g.Btiles && g.sa_k == 1 && (g.sa_m & 3) == 0 && (reinterpret_cast<uintptr_t>(g.A) & 15) == 0 && g.nsplit <= 1 &&
          g.nbatch <= 1 && !g.A2 && !g.rowsum && g.K >= 64;
 }
+// Where the wide tile pays.  Both forms run one workgroup per CU (204 / 249 registers at two waves per SIMD); a 128 x 256 workgroup
+// does four 64 x 128 tiles' worth in RD_PANEL_WIDE_COST percent of one small workgroup's time (default 280; measured 2.8-3.0:
+// profiles/r06_panel_wide.txt).  Cost = rounds over the chip's 256 CUs x time per round, so the wide tile's coarser quantisation
+// is priced in; RD_PANEL_WIDE = 0 / 1 forces the choice (tests, A/B).
+static bool panel_wide_pays(const GemmArgs& g) {
+  const char* fe = getenv("RD_PANEL_WIDE");                      // read per call: tests compare the two forms in one process
+  const int force = fe ? atoi(fe) : -1;
+  static const int cost = [] { const char* e = getenv("RD_PANEL_WIDE_COST"); return e ? atoi(e) : 280; }();
+  if (force >= 0) return force != 0;
+  const long ts = (long)cdiv(g.M, 64) * cdiv(g.N, 128), tw = (long)cdiv(g.M, 128) * cdiv(g.N, 256);
+  const long cs = ((ts + 255) / 256) * 100, cw = ((tw + 255) / 256) * cost;
+  return cw * 100 < cs * 95;
+}
+static int launch_panel_wide(const GemmArgs& g, hipStream_t st) {
+  constexpr int NJ = 2, TM = 128, TN = 128 * NJ;
+  const size_t lds = (size_t)4 * TM * LDB * sizeof(__bf16) + TN * sizeof(float);
+  const dim3 grid(8 * cdiv(cdiv(g.M, TM) * cdiv(g.N, TN), 8));
+  RD_LDS_ATTR((k_gemm_panel_wide<NJ>), lds);
+  hipLaunchKernelGGL((k_gemm_panel_wide<NJ>), grid, dim3(512), lds, st, g);
+  return check_launch("k_gemm_panel_wide");
+}
 static int launch_panel(const GemmArgs& g, hipStream_t st) {
+  if (panel_wide_pays(g)) return launch_panel_wide(g, st);
   constexpr int NJ = 2, TM = 64, TN = 64 * NJ;
   const size_t lds = (size_t)8 * TM * LDB * sizeof(__bf16) + TN * sizeof(float);      // planes (stage and hand-over alias them) + bias
   const dim3 grid(8 * cdiv(cdiv(g.M, TM) * cdiv(g.N, TN), 8));
