@@ -732,7 +732,7 @@ __global__ __launch_bounds__(512) void k_gemm_panel(GemmArgs g) {
   // Every look-ahead load is UNCONDITIONAL (past the end: the last chunk again, with the A rows masked to zero): behind a
   // branch, the compiler's wait-count bookkeeping has to assume the path that issued nothing, and then waits for the NEWEST
   // loads -- the ones just requested -- before the products on the current fragments.
-  auto load_b = [&](BFr& b, int c) {
+  auto load_b = [&](BFr& b, int c) __attribute__((always_inline)) {
     const int cc = min(c, nch - 1);
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj)
@@ -743,12 +743,12 @@ __global__ __launch_bounds__(512) void k_gemm_panel(GemmArgs g) {
         b.l[jj][ks] = *reinterpret_cast<const bf16x8*>(t + 512);
       }
   };
-  auto load_a = [&](int c) {
+  auto load_a = [&](int c) __attribute__((always_inline)) {
     SA::load(ra, oka, g.A, g.sa_m, 1, m0, g.M, min(c, nch - 1) * BK2, g.K, gt, true);
     if (c >= nch) oka = 0ull;                         // no such chunk: the planes get zeros
   };
   const int aoff = (lane & 15) * LDB + 8 * (lane >> 4);
-  auto products = [&](const __bf16* Ah, const __bf16* Al, const BFr& b, auto three_tag) {
+  auto products = [&](const __bf16* Ah, const __bf16* Al, const BFr& b, auto three_tag) __attribute__((always_inline)) {
     constexpr bool THREE = decltype(three_tag)::value;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -776,29 +776,31 @@ __global__ __launch_bounds__(512) void k_gemm_panel(GemmArgs g) {
   };
   __bf16* Pg = Pb + (size_t)grp * 4 * PLANE;          // this group's two buffers
   // round i: the group's chunk 2 i + grp on buffer i & 1 with fragments `cur`; the chunk of round i+1 arrives meanwhile
-  auto step = [&](int i, const BFr& cur, BFr& nxt) {
+  // (split-bf16 | plain bf16 is decided once, outside the loop: k_gemm_panel_wide below has the reason)
+  auto step = [&](int i, const BFr& cur, BFr& nxt, auto three_tag) __attribute__((always_inline)) {
     __bf16* Ah = Pg + (size_t)(i & 1) * 2 * PLANE;
     load_b(nxt, 2 * (i + 1) + grp);
-    if (!g.one_product) products(Ah, Ah + PLANE, cur, std::true_type{});
-    else products(Ah, Ah + PLANE, cur, std::false_type{});
+    products(Ah, Ah + PLANE, cur, three_tag);
     __bf16* Nh = Pg + (size_t)((i + 1) & 1) * 2 * PLANE;
-    if (!g.one_product) SA::store(ra, oka, Nh, Nh + PLANE, gt);           // round i+1's chunk
-    else SA::template store<false>(ra, oka, Nh, Nh + PLANE, gt);
+    SA::template store<decltype(three_tag)::value>(ra, oka, Nh, Nh + PLANE, gt);   // round i+1's chunk
     load_a(2 * (i + 2) + grp);
     lds_barrier();                                    // buffer i & 1 is free for round i+2; buffer (i+1) & 1 is complete
   };
   BFr b0, b1;
+  auto run = [&](auto three_tag) __attribute__((always_inline)) {
+    SA::template store<decltype(three_tag)::value>(ra, oka, Pg, Pg + PLANE, gt);
+    load_a(2 + grp);
+    lds_barrier();
+    PSTAMP(1);
+    int i = 0;
+    for (; i + 1 < niter; i += 2) { step(i, b0, b1, three_tag); step(i + 1, b1, b0, three_tag); }
+    if (i < niter) step(i, b0, b1, three_tag);
+  };
   load_a(grp);
   load_b(b0, grp);
   if (tid < TN) bias_s[tid] = (g.bias && n0 + tid < g.N) ? g.bias[n0 + tid] : 0.f;
-  if (!g.one_product) SA::store(ra, oka, Pg, Pg + PLANE, gt);
-  else SA::template store<false>(ra, oka, Pg, Pg + PLANE, gt);
-  load_a(2 + grp);
-  lds_barrier();
-  PSTAMP(1);
-  int i = 0;
-  for (; i + 1 < niter; i += 2) { step(i, b0, b1); step(i + 1, b1, b0); }
-  if (i < niter) step(i, b0, b1);
+  if (!g.one_product) run(std::true_type{});
+  else run(std::false_type{});
   PSTAMP(2);
   // group 1 hands its accumulators over, lane for lane; group 0 adds them (fixed order) and owns the epilogue's stage writes
   if (grp == 1) {
@@ -865,7 +867,7 @@ __global__ __launch_bounds__(512) void k_gemm_panel_wide(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   struct BFr { bf16x8 h[NJ][2], l[NJ][2]; };
-  auto load_b = [&](BFr& b, int c) {                            // unconditional look-ahead (past the end: the last chunk again)
+  auto load_b = [&](BFr& b, int c) __attribute__((always_inline)) {                            // unconditional look-ahead (past the end: the last chunk again)
     const int cc = min(c, nch - 1);
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj)
@@ -876,17 +878,19 @@ __global__ __launch_bounds__(512) void k_gemm_panel_wide(GemmArgs g) {
         b.l[jj][ks] = *reinterpret_cast<const bf16x8*>(t + 512);
       }
   };
-  auto load_a = [&](int c) {
+  auto load_a = [&](int c) __attribute__((always_inline)) {
     SA::load(ra, oka, g.A, g.sa_m, 1, m0 + half * HM, g.M, min(c, nch - 1) * BK2, g.K, gt, true);
     if (c >= nch) oka = 0ull;
   };
-  auto store_a = [&](__bf16* Ph) {                               // Ph: the buffer's hi plane; this half's rows
+  // `three_tag` (split-bf16: three products, hi and lo planes | plain bf16: one product, hi planes only) is decided ONCE, outside the
+  // loop: with the branch inside, the products and the next chunk's conversion were separate basic blocks -- a burst of MFMAs, then a
+  // burst of VALU -- and the ablation's parts added up; in one block the conversion issues in the MFMAs' shadow
+  auto store_a = [&](__bf16* Ph, auto three_tag) __attribute__((always_inline)) {               // Ph: the buffer's hi plane; this half's rows
     __bf16* h = Ph + (size_t)half * HM * LDB;
-    if (!g.one_product) SA::store(ra, oka, h, h + PLANE, gt);
-    else SA::template store<false>(ra, oka, h, h + PLANE, gt);
+    SA::template store<decltype(three_tag)::value>(ra, oka, h, h + PLANE, gt);
   };
   const int aoff = (lane & 15) * LDB + 8 * (lane >> 4);
-  auto products = [&](const __bf16* Ah, const __bf16* Al, const BFr& b, auto three_tag) {
+  auto products = [&](const __bf16* Ah, const __bf16* Al, const BFr& b, auto three_tag) __attribute__((always_inline)) {
     constexpr bool THREE = decltype(three_tag)::value;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -913,25 +917,28 @@ __global__ __launch_bounds__(512) void k_gemm_panel_wide(GemmArgs g) {
     }
   };
   // round i: chunk i on buffer i & 1 with fragments `cur`; chunk i+1 is converted into the other buffer, chunk i+2's loads leave
-  auto step = [&](int i, const BFr& cur, BFr& nxt) {
+  auto step = [&](int i, const BFr& cur, BFr& nxt, auto three_tag) __attribute__((always_inline)) {
     __bf16* Ah = Pb + (size_t)(i & 1) * 2 * PLANE;
     load_b(nxt, i + 1);
-    if (!g.one_product) products(Ah, Ah + PLANE, cur, std::true_type{});
-    else products(Ah, Ah + PLANE, cur, std::false_type{});
-    store_a(Pb + (size_t)((i + 1) & 1) * 2 * PLANE);
+    products(Ah, Ah + PLANE, cur, three_tag);
+    store_a(Pb + (size_t)((i + 1) & 1) * 2 * PLANE, three_tag);
     load_a(i + 2);
     lds_barrier();
   };
   BFr b0, b1;
+  auto run = [&](auto three_tag) __attribute__((always_inline)) {
+    store_a(Pb, three_tag);
+    load_a(1);
+    lds_barrier();
+    int i = 0;
+    for (; i + 1 < nch; i += 2) { step(i, b0, b1, three_tag); step(i + 1, b1, b0, three_tag); }
+    if (i < nch) step(i, b0, b1, three_tag);
+  };
   load_a(0);
   load_b(b0, 0);
   if (tid < TN) bias_s[tid] = (g.bias && n0 + tid < g.N) ? g.bias[n0 + tid] : 0.f;
-  store_a(Pb);
-  load_a(1);
-  lds_barrier();
-  int i = 0;
-  for (; i + 1 < nch; i += 2) { step(i, b0, b1); step(i + 1, b1, b0); }
-  if (i < nch) step(i, b0, b1);
+  if (!g.one_product) run(std::true_type{});
+  else run(std::false_type{});
   // epilogue over the two 64-row halves of the tile (the stage aliases the planes: every wave is past its last fragment read)
   float* stage = reinterpret_cast<float*>(gsm);
   epilogue_t<RT / 2, NJ, 1, 8, 512>(g, reinterpret_cast<f32x4(&)[RT / 2][NJ]>(acc[0]), stage, bias_s, m0, n0, 0, wave, 0, tid, lane);
