@@ -40,13 +40,14 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 TOUCH_SITES = [
     ("K1_FWD_P19", r"k_msg_fwd_fusedILi3ELi34ELi60E", "step"), ("K1_BWD_P19", r"k_msg_bwd_fusedILi3ELi34ELi60E", "step"),
     ("K1_FWD", r"k_msg_fwd_fusedILi\dELi0E", "step"), ("K1_BWD", r"k_msg_bwd_fusedILi\dELi0E", "step"),
-    ("ATTN_FWD", r"k_attn_fwd_fused", "step"), ("ATTN_BWD", r"k_attn_bwd_fused", "step"),
-    ("EF_POST_P19L", r"k_enc_post_fwdILi152ELi272ELb1", "step"), ("EF_POST_P19", r"k_enc_post_fwdILi152ELi272ELb0", "step"),
-    ("EF_POST_P12L", r"k_enc_post_fwdILi160ELi288ELb1", "step"), ("EF_POST_P12", r"k_enc_post_fwdILi160ELi288ELb0", "step"),
-    ("EF_POST_RTL", r"k_enc_post_fwdILi0ELi0ELb1", "step"), ("EF_POST_RT", r"k_enc_post_fwdILi0ELi0ELb0", "step"),
-    ("EF_PRE_P19L", r"k_enc_pre_bwdILi152ELi272ELb1", "step"), ("EF_PRE_P19", r"k_enc_pre_bwdILi152ELi272ELb0", "step"),
-    ("EF_PRE_P12L", r"k_enc_pre_bwdILi160ELi288ELb1", "step"), ("EF_PRE_P12", r"k_enc_pre_bwdILi160ELi288ELb0", "step"),
-    ("EF_PRE_RTL", r"k_enc_pre_bwdILi0ELi0ELb1", "step"), ("EF_PRE_RT", r"k_enc_pre_bwdILi0ELi0ELb0", "step"),
+    ("ATTN_FWD", r"k_attn_fwd_fusedILi\d+ELi\d+ELb0E", "step"), ("ATTN_BWD", r"k_attn_bwd_fusedILi\d+ELi\d+ELb0E", "step"),
+    ("ATTN_FWD_B", r"k_attn_fwd_fusedILi\d+ELi\d+ELb1E", "step"), ("ATTN_BWD_B", r"k_attn_bwd_fusedILi\d+ELi\d+ELb1E", "step"),
+    ("EF_POST_P19L", r"k_enc_post_fwdILi152ELi272ELb1ELb0E", "step"), ("EF_POST_P19L_B", r"k_enc_post_fwdILi152ELi272ELb1ELb1E", "step"), ("EF_POST_P19", r"k_enc_post_fwdILi152ELi272ELb0ELb0E", "step"), ("EF_POST_P19_B", r"k_enc_post_fwdILi152ELi272ELb0ELb1E", "step"),
+    ("EF_POST_P12L", r"k_enc_post_fwdILi160ELi288ELb1ELb0E", "step"), ("EF_POST_P12L_B", r"k_enc_post_fwdILi160ELi288ELb1ELb1E", "step"), ("EF_POST_P12", r"k_enc_post_fwdILi160ELi288ELb0ELb0E", "step"), ("EF_POST_P12_B", r"k_enc_post_fwdILi160ELi288ELb0ELb1E", "step"),
+    ("EF_POST_RTL", r"k_enc_post_fwdILi0ELi0ELb1ELb0E", "step"), ("EF_POST_RTL_B", r"k_enc_post_fwdILi0ELi0ELb1ELb1E", "step"), ("EF_POST_RT", r"k_enc_post_fwdILi0ELi0ELb0ELb0E", "step"), ("EF_POST_RT_B", r"k_enc_post_fwdILi0ELi0ELb0ELb1E", "step"),
+    ("EF_PRE_P19L", r"k_enc_pre_bwdILi152ELi272ELb1ELb0E", "step"), ("EF_PRE_P19L_B", r"k_enc_pre_bwdILi152ELi272ELb1ELb1E", "step"), ("EF_PRE_P19", r"k_enc_pre_bwdILi152ELi272ELb0ELb0E", "step"), ("EF_PRE_P19_B", r"k_enc_pre_bwdILi152ELi272ELb0ELb1E", "step"),
+    ("EF_PRE_P12L", r"k_enc_pre_bwdILi160ELi288ELb1ELb0E", "step"), ("EF_PRE_P12L_B", r"k_enc_pre_bwdILi160ELi288ELb1ELb1E", "step"), ("EF_PRE_P12", r"k_enc_pre_bwdILi160ELi288ELb0ELb0E", "step"), ("EF_PRE_P12_B", r"k_enc_pre_bwdILi160ELi288ELb0ELb1E", "step"),
+    ("EF_PRE_RTL", r"k_enc_pre_bwdILi0ELi0ELb1ELb0E", "step"), ("EF_PRE_RTL_B", r"k_enc_pre_bwdILi0ELi0ELb1ELb1E", "step"), ("EF_PRE_RT", r"k_enc_pre_bwdILi0ELi0ELb0ELb0E", "step"), ("EF_PRE_RT_B", r"k_enc_pre_bwdILi0ELi0ELb0ELb1E", "step"),
     ("DW", r"4k_dwE", "step"), ("DW_REDUCE", r"k_dw_reduce", "step"), ("ADAM", r"6k_adamE", "step"), ("ADAM_DEV", r"10k_adam_devE", "step"),
     ("WSPLIT", r"k_wsplit", "step"), ("TWG", r"5k_twgILb0E", "step"), ("TWG_ONE", r"5k_twgILb1E", "step"),
     ("HEAD_P19", r"k_head_rowsILi1ELi12ELi3E", "step"), ("HEAD", r"k_head_rowsILi1ELi16ELi4E", "step"),

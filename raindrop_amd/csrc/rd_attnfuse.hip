@@ -316,10 +316,12 @@ __device__ __forceinline__ void zero_pad_rows(__bf16* Tp, int tid) {
 // ------------------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------------------
-template <int NTH, int KCX>
+// ONE: RD_PREC_BF16's one-product form as its own instantiation (a runtime flag put a branch in front of every product: rd_encfuse.hip
+// k_enc_post_fwd has the measurement)
+template <int NTH, int KCX, bool ONE>
 __global__ __launch_bounds__(AF_THR) void k_attn_fwd_fused(FAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
-  RD_TOUCH_CODE(RD_TL_ATTN_FWD);                                      // own code -> L2 (rd_common.h; 14 140-byte kernel: ALL of it -- an uncovered tail is fetched cold, line by line, on the pool's slow boxes)
+  RD_TOUCH_CODE(ONE ? RD_TL_ATTN_FWD_B : RD_TL_ATTN_FWD);                                      // own code -> L2 (rd_common.h; 14 140-byte kernel: ALL of it -- an uncovered tail is fetched cold, line by line, on the pool's slow boxes)
   constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDX = 32 * KCX + 16, NA = (NTH + 1) / 2;
   constexpr int LDO = 16 * NTH + 4;                          // fp32 row stride of the output stage
   __bf16* Xh = reinterpret_cast<__bf16*>(fsm);
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(AF_THR) void k_attn_fwd_fused(FAttnArgs a) {
   lds_barrier();
   AFSTAMP(2);
   const float inv_keep = 1.0f / (1.0f - a.p_drop);
-  const bool one = a.one != 0;
+  constexpr bool one = ONE;
   const int qr0 = wq * 16 + 4 * (lane >> 4);                 // first of this lane's four query rows
   for (int h = 0; h < a.H; ++h) {
     const int bh = b * a.H + h;
@@ -554,10 +556,10 @@ __device__ __forceinline__ void dx_phase(f32x4 (&dxa)[2][4], DxPanel<(16 * NTH +
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int NTH, int KCX>
+template <int NTH, int KCX, bool ONE>
 __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
-  RD_TOUCH_CODE(RD_TL_ATTN_BWD);                                      // own code -> L2 (32 028-byte kernel, all of it)
+  RD_TOUCH_CODE(ONE ? RD_TL_ATTN_BWD_B : RD_TL_ATTN_BWD);                                      // own code -> L2 (32 028-byte kernel, all of it)
   constexpr int HDP = 32 * ((16 * NTH + 31) / 32), LDX = 32 * KCX + 16, NA = (NTH + 1) / 2, KB = HDP / 32, LDB = HDP + 16;
   constexpr int NCT = 2 * KCX;                               // 16-column tiles of D (padded to 32 KCX)
   constexpr int LDS_DX = 32 * KCX + 4;                       // fp32 row stride of the dx stage
@@ -588,7 +590,7 @@ __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
   uint64_t seedv = a.seed;
   if (a.p_drop > 0.f && a.seed_cell) seedv += load_uniform_u64(a.seed_cell);
   const float inv_keep = 1.0f / (1.0f - a.p_drop);
-  const bool one = a.one != 0;
+  constexpr bool one = ONE;
   // dx accumulators: wave w owns the column tiles w and w + 8 (< NCT) of dx and all four row tiles, over BOTH heads
   f32x4 dxa[2][4];
 #pragma unroll
@@ -883,8 +885,10 @@ int launch_attn_fused_fwd(const float* x, const void* wf, const float* bias, con
   fill_args(a, x, wf, nullptr, bias, plan, T, B, D, H, hd, p_drop, seed, site);
   a.out = out; a.lse = lse;
   constexpr size_t lds = fwd_lds<AF_NTH, AF_KCX>();
-  RD_LDS_ATTR((k_attn_fwd_fused<AF_NTH, AF_KCX>), lds);
-  hipLaunchKernelGGL((k_attn_fwd_fused<AF_NTH, AF_KCX>), dim3(B), dim3(AF_THR), lds, st, a);
+  if (a.one) { RD_LDS_ATTR((k_attn_fwd_fused<AF_NTH, AF_KCX, true>), lds);
+               hipLaunchKernelGGL((k_attn_fwd_fused<AF_NTH, AF_KCX, true>), dim3(B), dim3(AF_THR), lds, st, a); }
+  else { RD_LDS_ATTR((k_attn_fwd_fused<AF_NTH, AF_KCX, false>), lds);
+         hipLaunchKernelGGL((k_attn_fwd_fused<AF_NTH, AF_KCX, false>), dim3(B), dim3(AF_THR), lds, st, a); }
   return check_launch("k_attn_fwd_fused");
 }
 
@@ -897,8 +901,10 @@ int launch_attn_fused_bwd(const float* x, const void* wf, const void* wb, const 
   a.out = const_cast<float*>(out); a.lse = const_cast<float*>(lse); a.dout = dout; a.ds1 = ds1; a.dx = dx;
   a.xt = (__bf16*)xt; a.dt = (__bf16*)dt;
   constexpr size_t lds = bwd_lds<AF_NTH, AF_KCX>();
-  RD_LDS_ATTR((k_attn_bwd_fused<AF_NTH, AF_KCX>), lds);
-  hipLaunchKernelGGL((k_attn_bwd_fused<AF_NTH, AF_KCX>), dim3(B), dim3(AF_THR), lds, st, a);
+  if (a.one) { RD_LDS_ATTR((k_attn_bwd_fused<AF_NTH, AF_KCX, true>), lds);
+               hipLaunchKernelGGL((k_attn_bwd_fused<AF_NTH, AF_KCX, true>), dim3(B), dim3(AF_THR), lds, st, a); }
+  else { RD_LDS_ATTR((k_attn_bwd_fused<AF_NTH, AF_KCX, false>), lds);
+         hipLaunchKernelGGL((k_attn_bwd_fused<AF_NTH, AF_KCX, false>), dim3(B), dim3(AF_THR), lds, st, a); }
   return check_launch("k_attn_bwd_fused");
 }
 

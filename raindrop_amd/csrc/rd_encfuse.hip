@@ -376,7 +376,7 @@ __device__ __forceinline__ void ln_rows4(const float* stage, const float4 (&res)
 // or the chain itself would read is not written -- the FFN hidden h leaves as row tiles (weight gradient) and as one gate BYTE
 // per column quad (the backward needs h > 0, nothing else: 9.2 MB of fp32 written and read back per layer at P19), and the
 // normalised x1 (residual of LayerNorm2) is recomputed from the saved pre-norm sum and statistics instead of stored and re-read.
-template <int RT, int DC, int HC, bool LEAN>
+template <int RT, int DC, int HC, bool LEAN, bool ONE>
 __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned char* esm, int M) {
   constexpr int ROWS = 16 * RT;
   __bf16* Ah = reinterpret_cast<__bf16*>(esm);                 // [ROWS][LDD]: attn, then x1
@@ -462,7 +462,7 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
   const int hidx = (wave - HW0) * 64 + lane;
   if (wave < ntD) {
     f32x4 acc[RT];
-    mma<KCD, RT>(acc, Ah, Al, LDD, po, lane, a.one);
+    mma<KCD, RT>(acc, Ah, Al, LDD, po, lane, (int)ONE);
     to_stage<RT>(stage, acc, wave, lane);
   }
   EFSTAMP(3);
@@ -513,7 +513,7 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
       for (int rt = 0; rt < RT; ++rt) h_epi1(acc[rt], j, rt);
     };
     f32x4 acc[RT];
-    mma<KCD, RT>(acc, Ah, Al, LDD, p1, lane, a.one);           // column tile `wave` (every wave has one: nhid > 256)
+    mma<KCD, RT>(acc, Ah, Al, LDD, p1, lane, (int)ONE);           // column tile `wave` (every wave has one: nhid > 256)
     // nhid > 256: the column tiles beyond the 16th (P19: tile 16) are split into (tile, row tile) UNITS, one each for the LAST waves
     // (P19, tall blocks: waves 15, 14, 13 -- which have no D-wide tile, no LayerNorm pass and therefore nothing else to carry).  A
     // whole second tile on wave 0 (rounds 3-5) was 5 k cycles of product + epilogue that the other 15 waves spent at the barrier
@@ -531,7 +531,7 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
       __builtin_amdgcn_sched_barrier(0);
       h_epilogue(acc, wave);
       f32x4 acc1[1];
-      mma<KCD, 1>(acc1, Ah + rt2 * 16 * LDD, Al + rt2 * 16 * LDD, LDD, p1, lane, a.one);
+      mma<KCD, 1>(acc1, Ah + rt2 * 16 * LDD, Al + rt2 * 16 * LDD, LDD, p1, lane, (int)ONE);
       __builtin_amdgcn_sched_barrier(0);
       load_panel<KCH, 0, PS>(p2, a.W2, ntD, wave, lane);
       __builtin_amdgcn_sched_barrier(0);
@@ -552,7 +552,7 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
   // ---- linear2; LayerNorm2's dropout decisions by the waves without a column tile ----
   if (wave < ntD) {
     f32x4 acc[RT];
-    mma<KCH, RT>(acc, Hh, Hl, LDH, p2, lane, a.one);
+    mma<KCH, RT>(acc, Hh, Hl, LDH, p2, lane, (int)ONE);
     to_stage<RT>(stage, acc, wave, lane);
   } else if (a.p > 0.f && wave >= HW0) {
     drop_masks<RT, NHW>(mk, seed, a.site_fo, D, m0, a.p, hidx);
@@ -576,18 +576,23 @@ __device__ __forceinline__ void post_fwd_body(const PostFwdArgs& a, unsigned cha
   if (a.stamps && tid == 0) { a.stamps[256 + 1024 + 2 * blockIdx.x] = wall_clock64(); a.stamps[256 + 1024 + 2 * blockIdx.x + 1] = clock64(); }
 }
 
-template <int DC, int HC, bool LEAN>
+// ONE (round 6): RD_PREC_BF16's one-product form as an instantiation of its own.  As a runtime flag every product of the chain began
+// with a branch -- a basic-block boundary the scheduler does not move the next phase's loads or the previous epilogue's stores across
+// (in-step A/B against a build with the flag folded to 0: post_fwd 22.1 -> 21.3 us, pre_bwd 23.8 -> 22.6).
+template <int DC, int HC, bool LEAN, bool ONE>
 __global__ __launch_bounds__(EF_THR) void k_enc_post_fwd(PostFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
   // own code -> L2 (rd_common.h), ALL of it, per instantiation (raindrop_amd/build.py CODE_TOUCH checks each against the linked kernel): the
   // tall body -- the one the step runs -- is laid out LAST, and with one length below the smallest instantiation its LayerNorm2 sat in
   // the uncovered 3 KB: 9 k cycles instead of 5 k on a box whose instruction fetch does not look ahead
-  RD_TOUCH_CODE(DC == 152 ? (LEAN ? RD_TL_EF_POST_P19L : RD_TL_EF_POST_P19) : DC == 160 ? (LEAN ? RD_TL_EF_POST_P12L : RD_TL_EF_POST_P12)
-                          : (LEAN ? RD_TL_EF_POST_RTL : RD_TL_EF_POST_RT));
+  RD_TOUCH_CODE(ONE ? (DC == 152 ? (LEAN ? RD_TL_EF_POST_P19L_B : RD_TL_EF_POST_P19_B) : DC == 160 ? (LEAN ? RD_TL_EF_POST_P12L_B : RD_TL_EF_POST_P12_B)
+                                 : (LEAN ? RD_TL_EF_POST_RTL_B : RD_TL_EF_POST_RT_B))
+                    : (DC == 152 ? (LEAN ? RD_TL_EF_POST_P19L : RD_TL_EF_POST_P19) : DC == 160 ? (LEAN ? RD_TL_EF_POST_P12L : RD_TL_EF_POST_P12)
+                                 : (LEAN ? RD_TL_EF_POST_RTL : RD_TL_EF_POST_RT)));
   int M = a.M;
   if (a.mlive) M = min(M, __builtin_amdgcn_readfirstlane(*a.mlive));
-  if (pick_rt(M, a.ncu) == 3) post_fwd_body<3, DC, HC, LEAN>(a, esm, M);
-  else post_fwd_body<2, DC, HC, LEAN>(a, esm, M);
+  if (pick_rt(M, a.ncu) == 3) post_fwd_body<3, DC, HC, LEAN, ONE>(a, esm, M);
+  else post_fwd_body<2, DC, HC, LEAN, ONE>(a, esm, M);
 }
 
 constexpr size_t post_fwd_lds(int rt) {
@@ -680,7 +685,7 @@ __device__ __forceinline__ void lnb_rows4(const float4 (&dyq)[LNQ], const float4
   }
 }
 
-template <int RT, int DC, int HC, bool LEAN>
+template <int RT, int DC, int HC, bool LEAN, bool ONE>
 __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char* esm, int M) {
   constexpr int ROWS = 16 * RT;
   __bf16* Ah = reinterpret_cast<__bf16*>(esm);                 // [ROWS][LDD]: df, then dout
@@ -794,7 +799,7 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
       for (int rt = 0; rt < RT; ++rt) du_epi1(acc[rt], j, rt, rt);
     };
     f32x4 acc[RT];
-    mma<KCD, RT>(acc, Ah, Al, LDD, pw, lane, a.one);           // column tile `wave` (every wave has one: nhid > 256)
+    mma<KCD, RT>(acc, Ah, Al, LDD, pw, lane, (int)ONE);           // column tile `wave` (every wave has one: nhid > 256)
     const int unit = EF_WV - 1 - wave;                         // scalar; second-round (tile, row tile) units: see the forward chain
     const bool more = unit < (ntH - EF_WV) * RT;
     if (more) {                                                // two straight-line paths: see the forward chain
@@ -806,7 +811,7 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
       load_gate1(j2, rt2, 0);
       __builtin_amdgcn_sched_barrier(0);
       f32x4 acc1[1];
-      mma<KCD, 1>(acc1, Ah + rt2 * 16 * LDD, Al + rt2 * 16 * LDD, LDD, pw, lane, a.one);
+      mma<KCD, 1>(acc1, Ah + rt2 * 16 * LDD, Al + rt2 * 16 * LDD, LDD, pw, lane, (int)ONE);
       __builtin_amdgcn_sched_barrier(0);
       load_panel<KCH, 0, PS>(p1, a.W1t, ntD, wave, lane);
       __builtin_amdgcn_sched_barrier(0);
@@ -836,8 +841,8 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   if (wave < ntD) {
     f32x4 acc[RT];
     auto rest = [&]() { load_panel<KCH, PS2, KCH>(p1, a.W1t, ntD, wave, lane); };
-    if constexpr (RT >= 3) mma<KCH, RT, 1, decltype(rest), 3, decltype(load_ln1)>(acc, Hh, Hl, LDH, p1, lane, a.one, rest, load_ln1);
-    else mma<KCH, RT, 1, decltype(rest)>(acc, Hh, Hl, LDH, p1, lane, a.one, rest);
+    if constexpr (RT >= 3) mma<KCH, RT, 1, decltype(rest), 3, decltype(load_ln1)>(acc, Hh, Hl, LDH, p1, lane, (int)ONE, rest, load_ln1);
+    else mma<KCH, RT, 1, decltype(rest)>(acc, Hh, Hl, LDH, p1, lane, (int)ONE, rest);
     to_stage<RT>(stage, acc, wave, lane);
   } else {                                                     // no column tile: LayerNorm1's dropout decisions meanwhile
     if constexpr (RT >= 3) load_ln1();
@@ -877,7 +882,7 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
   // lanes of a group write 64 contiguous bytes of 16 rows, the neighbouring column tile's wave the other half of each line) ----
   if (wave < ntD) {
     f32x4 acc[RT];
-    mma<KCD, RT>(acc, Ah, Al, LDD, po, lane, a.one);
+    mma<KCD, RT>(acc, Ah, Al, LDD, po, lane, (int)ONE);
     const int c = 16 * wave + 4 * G;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -890,17 +895,19 @@ __device__ __forceinline__ void pre_bwd_body(const PreBwdArgs& a, unsigned char*
 
 // Workgroups >= nmain are RIDERS (rd_trailing.h): they run a parked trailing launch -- the head's weight-gradient tiles, the
 // previous layer's slice reduce -- on the CUs this chain leaves idle (178-266 workgroups of one per CU on 256 CUs).
-template <int DC, int HC, bool LEAN>
+template <int DC, int HC, bool LEAN, bool ONE>
 __global__ __launch_bounds__(EF_THR) void k_enc_pre_bwd(PreBwdArgs a, RiderArgs rider, int nmain) {
   extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
   // own code -> L2, the riders' bodies included, all of it, per instantiation (see k_enc_post_fwd)
-  RD_TOUCH_CODE(DC == 152 ? (LEAN ? RD_TL_EF_PRE_P19L : RD_TL_EF_PRE_P19) : DC == 160 ? (LEAN ? RD_TL_EF_PRE_P12L : RD_TL_EF_PRE_P12)
-                          : (LEAN ? RD_TL_EF_PRE_RTL : RD_TL_EF_PRE_RT));
+  RD_TOUCH_CODE(ONE ? (DC == 152 ? (LEAN ? RD_TL_EF_PRE_P19L_B : RD_TL_EF_PRE_P19_B) : DC == 160 ? (LEAN ? RD_TL_EF_PRE_P12L_B : RD_TL_EF_PRE_P12_B)
+                                 : (LEAN ? RD_TL_EF_PRE_RTL_B : RD_TL_EF_PRE_RT_B))
+                    : (DC == 152 ? (LEAN ? RD_TL_EF_PRE_P19L : RD_TL_EF_PRE_P19) : DC == 160 ? (LEAN ? RD_TL_EF_PRE_P12L : RD_TL_EF_PRE_P12)
+                                 : (LEAN ? RD_TL_EF_PRE_RTL : RD_TL_EF_PRE_RT)));
   if ((int)blockIdx.x >= nmain) { rider_body(rider, (int)blockIdx.x - nmain, esm); return; }
   int M = a.M;
   if (a.mlive) M = min(M, __builtin_amdgcn_readfirstlane(*a.mlive));
-  if (pick_rt(M, a.ncu) == 3) pre_bwd_body<3, DC, HC, LEAN>(a, esm, M);
-  else pre_bwd_body<2, DC, HC, LEAN>(a, esm, M);
+  if (pick_rt(M, a.ncu) == 3) pre_bwd_body<3, DC, HC, LEAN, ONE>(a, esm, M);
+  else pre_bwd_body<2, DC, HC, LEAN, ONE>(a, esm, M);
 }
 
 // Widths compiled in for the two datasets that fit these kernels: 1 = P19 (152, 272), 2 = P12 (160, 288); 0 = runtime widths.
@@ -964,17 +971,19 @@ int launch_enc_post_fwd(long M, int D, int H, const float* attn, const float* x,
   constexpr size_t lds = post_fwd_lds(EF_RTMAX);
   const int spec = ef_specialize(D, H);
   a.hgate = (uint8_t*)hgate;
+#define RD_POST_FWD1(DCV, HCV, LEANV, ONEV)                                                                          \
+  do { RD_LDS_ATTR((k_enc_post_fwd<DCV, HCV, LEANV, ONEV>), lds);                                                    \
+       hipLaunchKernelGGL((k_enc_post_fwd<DCV, HCV, LEANV, ONEV>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a); } while (0)
 #define RD_POST_FWD(DCV, HCV)                                                                                        \
   do {                                                                                                               \
-    if (hgate) { RD_LDS_ATTR((k_enc_post_fwd<DCV, HCV, true>), lds);                                                 \
-                 hipLaunchKernelGGL((k_enc_post_fwd<DCV, HCV, true>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a); }   \
-    else { RD_LDS_ATTR((k_enc_post_fwd<DCV, HCV, false>), lds);                                                      \
-           hipLaunchKernelGGL((k_enc_post_fwd<DCV, HCV, false>), dim3(cdiv((int)M, 32)), dim3(EF_THR), lds, st, a); } \
+    if (hgate) { if (a.one) RD_POST_FWD1(DCV, HCV, true, true); else RD_POST_FWD1(DCV, HCV, true, false); }          \
+    else { if (a.one) RD_POST_FWD1(DCV, HCV, false, true); else RD_POST_FWD1(DCV, HCV, false, false); }              \
   } while (0)
   if (spec == 1) RD_POST_FWD(152, 272);
   else if (spec == 2) RD_POST_FWD(160, 288);
   else RD_POST_FWD(0, 0);
 #undef RD_POST_FWD
+#undef RD_POST_FWD1
   return check_launch("k_enc_post_fwd");
 }
 
@@ -998,17 +1007,19 @@ int launch_enc_pre_bwd(long M, int D, int H, const float* dy, const float* s2, c
   a.hgate = (const uint8_t*)hgate;
   const RiderArgs rider = trailing_take();             // a parked trailing launch (or kind 0) rides in this one
   const int nmain = cdiv((int)M, 32), grid = nmain + (rider.kind != RIDER_NONE ? rider.nblocks : 0);
+#define RD_PRE_BWD1(DCV, HCV, LEANV, ONEV)                                                                          \
+  do { RD_LDS_ATTR((k_enc_pre_bwd<DCV, HCV, LEANV, ONEV>), lds);                                                    \
+       hipLaunchKernelGGL((k_enc_pre_bwd<DCV, HCV, LEANV, ONEV>), dim3(grid), dim3(EF_THR), lds, st, a, rider, nmain); } while (0)
 #define RD_PRE_BWD(DCV, HCV)                                                                                        \
   do {                                                                                                              \
-    if (hgate) { RD_LDS_ATTR((k_enc_pre_bwd<DCV, HCV, true>), lds);                                                 \
-                 hipLaunchKernelGGL((k_enc_pre_bwd<DCV, HCV, true>), dim3(grid), dim3(EF_THR), lds, st, a, rider, nmain); }   \
-    else { RD_LDS_ATTR((k_enc_pre_bwd<DCV, HCV, false>), lds);                                                      \
-           hipLaunchKernelGGL((k_enc_pre_bwd<DCV, HCV, false>), dim3(grid), dim3(EF_THR), lds, st, a, rider, nmain); } \
+    if (hgate) { if (a.one) RD_PRE_BWD1(DCV, HCV, true, true); else RD_PRE_BWD1(DCV, HCV, true, false); }           \
+    else { if (a.one) RD_PRE_BWD1(DCV, HCV, false, true); else RD_PRE_BWD1(DCV, HCV, false, false); }               \
   } while (0)
   if (spec == 1) RD_PRE_BWD(152, 272);
   else if (spec == 2) RD_PRE_BWD(160, 288);
   else RD_PRE_BWD(0, 0);
 #undef RD_PRE_BWD
+#undef RD_PRE_BWD1
   return check_launch("k_enc_pre_bwd");
 }
 
