@@ -370,6 +370,13 @@ __global__ __launch_bounds__(AF_THR) void k_attn_fwd_fused(FAttnArgs a) {
     lds_barrier();
     AFSTAMP(4 + 8 * h);
     // ---- S = Q K^T: query tile wq, key tiles 2 wh, 2 wh + 1 ----
+    // The dropout keeps of this lane's 2 x 4 probabilities are a function of indices only: computed HERE, unconditionally (p = 0
+    // gives 1.0 everywhere), in the same basic block as the S products -- ~100 VALU instructions that issue in the MFMAs' shadow
+    // instead of behind the row-max barrier (behind `if (p > 0)` they were a block of their own)
+    float kp[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      attn_keep4(kp[j], seedv, a.site, bh, a.T, qr0, min(16 * (2 * wh + j) + (lane & 15), a.T - 1), a.p_drop, inv_keep);
     f32x4 s[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -398,14 +405,12 @@ __global__ __launch_bounds__(AF_THR) void k_attn_fwd_fused(FAttnArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int key = 16 * (2 * wh + j) + (lane & 15);
-      float k4[4] = {1.f, 1.f, 1.f, 1.f};
-      if (a.p_drop > 0.f) attn_keep4(k4, seedv, a.site, bh, a.T, qr0, min(key, a.T - 1), a.p_drop, inv_keep);
       float pv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float p = (s[j][r] == -INFINITY) ? 0.f : __expf(s[j][r] - m_i[r]);
         rsum[r] += p;
-        pv[r] = p * k4[r];
+        pv[r] = p * kp[j][r];
       }
       store_t4(Ph, Pl, key, qr0, pv);
     }
@@ -694,6 +699,10 @@ __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
     int l1 = lane;
     asm volatile("" : "+v"(l1));
     const int qr1 = wq * 16 + 4 * (l1 >> 4);
+    float kp[2][4];                                          // dropout keeps: index-only, in the products' shadow (see the forward)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      attn_keep4(kp[j], seedv, a.site, bh, a.T, qr1, min(16 * (2 * wh + j) + (l1 & 15), a.T - 1), a.p_drop, inv_keep);
     f32x4 s[2], dp[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) { s[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[j] = s[j]; }
@@ -703,8 +712,7 @@ __global__ __launch_bounds__(AF_THR) void k_attn_bwd_fused(FAttnArgs a) {
     for (int j = 0; j < 2; ++j) {
       const int key = 16 * (2 * wh + j) + (l1 & 15);
       const bool dead = key >= Tv;
-      float k4[4] = {1.f, 1.f, 1.f, 1.f};
-      if (a.p_drop > 0.f) attn_keep4(k4, seedv, a.site, bh, a.T, qr1, min(key, a.T - 1), a.p_drop, inv_keep);
+      const float (&k4)[4] = kp[j];
       float pm[4], ds[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
