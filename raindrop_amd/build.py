@@ -51,7 +51,7 @@ TOUCH_SITES = [
     ("DW", r"4k_dwE", "step"), ("DW_REDUCE", r"k_dw_reduce", "step"), ("ADAM", r"6k_adamE", "step"), ("ADAM_DEV", r"10k_adam_devE", "step"),
     ("WSPLIT", r"k_wsplit", "step"), ("TWG", r"5k_twgILb0E", "step"), ("TWG_ONE", r"5k_twgILb1E", "step"),
     ("HEAD_P19", r"k_head_rowsILi1ELi12ELi3E", "step"), ("HEAD", r"k_head_rowsILi1ELi16ELi4E", "step"),
-    ("GEMM", r"6k_gemmI", "x"), ("GEMM_X3", r"13k_gemm_bf16x3I", "x"), ("GEMM_PANEL", r"12k_gemm_panelI", "x"), ("GEMM_PANEL_WIDE", r"17k_gemm_panel_wideI", "x"), ("ROWGEMM", r"9k_rowgemmI", "x"),
+    ("GEMM", r"6k_gemmI", "x"), ("GEMM_X3", r"13k_gemm_bf16x3I", "x"), ("GEMM_PANEL", r"12k_gemm_panelI", "x"), ("GEMM_PANEL_WIDE", r"17k_gemm_panel_wideI", "x"), ("GEMM_PANEL_PC", r"15k_gemm_panel_pcI", "x"), ("ROWGEMM", r"9k_rowgemmI", "x"),
     ("ATTN_FWD_ONE", r"19k_attn_fwd_one_b16wI", "x"), ("ATTN_BWD_ONE", r"19k_attn_bwd_one_b16wI", "x"), ("ATTN_FWD_B16", r"14k_attn_fwd_b16I", "x"),
     ("ATTN_BWD_DQ", r"17k_attn_bwd_dq_b16I", "x"), ("ATTN_BWD_DKV", r"18k_attn_bwd_dkv_b16I", "x"), ("ADD_LN_FWD", r"14k_add_ln_fwd_vE", "x"),
     ("LN_BWD_R", r"10k_ln_bwd_rI", "x"), ("LN_BWD_V", r"10k_ln_bwd_vE", "x"),

@@ -952,18 +952,155 @@ static bool panel_ok(const GemmArgs& g) {
   return on && g.Btiles && g.sa_k == 1 && (g.sa_m & 3) == 0 && (reinterpret_cast<uintptr_t>(g.A) & 15) == 0 && g.nsplit <= 1 &&
          g.nbatch <= 1 && !g.A2 && !g.rowsum && g.K >= 64;
 }
-// Where the wide tile pays.  Both forms run one workgroup per CU (204 / 249 registers at two waves per SIMD); a 128 x 256 workgroup
-// does four 64 x 128 tiles' worth in RD_PANEL_WIDE_COST percent of one small workgroup's time (default 280; measured 2.8-3.0:
-// profiles/r06_panel_wide.txt).  Cost = rounds over the chip's 256 CUs x time per round, so the wide tile's coarser quantisation
-// is priced in; RD_PANEL_WIDE = 0 / 1 forces the choice (tests, A/B).
-static bool panel_wide_pays(const GemmArgs& g) {
-  const char* fe = getenv("RD_PANEL_WIDE");                      // read per call: tests compare the two forms in one process
-  const int force = fe ? atoi(fe) : -1;
-  static const int cost = [] { const char* e = getenv("RD_PANEL_WIDE_COST"); return e ? atoi(e) : 280; }();
-  if (force >= 0) return force != 0;
-  const long ts = (long)cdiv(g.M, 64) * cdiv(g.N, 128), tw = (long)cdiv(g.M, 128) * cdiv(g.N, 256);
-  const long cs = ((ts + 255) / 256) * 100, cw = ((tw + 255) / 256) * cost;
-  return cw * 100 < cs * 95;
+// ------------------------------------------------------------------------------------------------
+// Producer / consumer panel product (round 6): 128 x 128 workgroup tile, eight waves with TWO ROLES.  Waves 0-3 (one per SIMD) are
+// consumers: each all 128 rows x 32 columns, weight fragments straight from L2, A fragments from LDS, nothing but MFMAs and fragment
+// reads.  Waves 4-7 (the other wave of each SIMD) are producers: they load the NEXT 64-k chunk of A, convert it to split-bf16 and
+// store the planes -- VALU work that issues between the consumer's MFMAs on the same SIMD instead of in front of them.  The ablation
+// (profiles/r06_panel_ablation.txt) had shown conversion, loads and MFMAs of k_gemm_panel adding up; here they belong to different
+// waves by construction.  One LDS-only barrier per chunk (double-buffered planes).  Tile 128 x 128: the conversion count per element
+// of the 64 x 128 form, the weight-fragment traffic per MFMA of the wide one, and P12's 72 x 7 = 504 tiles fill two rounds of 256.
+// ------------------------------------------------------------------------------------------------
+template <int NJ>
+__global__ __launch_bounds__(512) void k_gemm_panel_pc(GemmArgs g) {
+  RD_TOUCH_CODE_X(RD_TL_GEMM_PANEL_PC, blockIdx.x, 512);
+  constexpr int RT = 8, TM = 16 * RT, HM = TM / 2, TN = 64 * NJ, PLANE = TM * LDB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+  __bf16* Pb = reinterpret_cast<__bf16*>(gsm);                  // [2 buffers][hi, lo][TM][LDB]
+  constexpr size_t PLANES_B = (size_t)4 * PLANE * sizeof(__bf16), STAGE_B = (size_t)HM * (TN + 4) * sizeof(float);
+  static_assert(STAGE_B <= PLANES_B, "the epilogue's half-tile stage must fit the dead planes");
+  float* bias_s = reinterpret_cast<float*>(gsm + PLANES_B);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), gt = tid & 255;
+  const bool consumer = wave < 4;
+  const int cw = wave & 3;
+  const int ncb = (g.N + TN - 1) / TN, tiles = ncb * ((g.M + TM - 1) / TM), per = (tiles + 7) / 8;     // XCD order: as k_gemm_panel
+  const int lin = g.xcd_swizzle ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (lin >= tiles || (g.xcd_swizzle && (int)(blockIdx.x >> 3) >= per)) return;
+  const int rblk = lin / ncb, cblk = lin - rblk * ncb;
+  const int m0 = rblk * TM, n0 = cblk * TN;
+  const int nkc = g.bt_nkc;
+  const int nch = (g.K + BK2 - 1) / BK2;
+  if (tid < TN) bias_s[tid] = (g.bias && n0 + tid < g.N) ? g.bias[n0 + tid] : 0.f;
+  f32x4 acc[RT][NJ];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (!consumer) {
+    // ---- producers: 256 threads stage 128 rows x 64 k per chunk; chunk c + 1 is in registers while chunk c is converted ----
+    using SA = Stage<true, TM>;
+    float ra[SA::NREG]; unsigned long long oka;
+    auto load_a = [&](int c) __attribute__((always_inline)) {
+      SA::load(ra, oka, g.A, g.sa_m, 1, m0, g.M, min(c, nch - 1) * BK2, g.K, gt, true);
+      if (c >= nch) oka = 0ull;
+    };
+    auto run = [&](auto three_tag) __attribute__((always_inline)) {
+      load_a(0);
+      SA::template store<decltype(three_tag)::value>(ra, oka, Pb, Pb + PLANE, gt);
+      load_a(1);
+      lds_barrier();                                             // buffer 0 complete
+      for (int i = 0; i < nch; ++i) {
+        __bf16* Nh = Pb + (size_t)((i + 1) & 1) * 2 * PLANE;     // consumers read buffer i & 1 now; (i + 1) & 1 was released by the barrier
+        SA::template store<decltype(three_tag)::value>(ra, oka, Nh, Nh + PLANE, gt);
+        load_a(i + 2);
+        lds_barrier();
+      }
+    };
+    if (!g.one_product) run(std::true_type{}); else run(std::false_type{});
+  } else {
+    // ---- consumers ----
+    const __bf16* Bt = reinterpret_cast<const __bf16*>(g.Btiles);
+    size_t toff[NJ];
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) toff[jj] = (size_t)min(n0 / 16 + cw * NJ + jj, g.bt_ntile - 1) * nkc * 1024 + lane * 8;
+    struct BFr { bf16x8 h[NJ][2], l[NJ][2]; };
+    auto load_b = [&](BFr& b, int c) __attribute__((always_inline)) {
+      const int cc = min(c, nch - 1);
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const __bf16* t = Bt + toff[jj] + (size_t)min(2 * cc + ks, nkc - 1) * 1024;
+          b.h[jj][ks] = *reinterpret_cast<const bf16x8*>(t);
+          b.l[jj][ks] = *reinterpret_cast<const bf16x8*>(t + 512);
+        }
+    };
+    const int aoff = (lane & 15) * LDB + 8 * (lane >> 4);
+    auto products = [&](const __bf16* Ah, const __bf16* Al, const BFr& b, auto three_tag) __attribute__((always_inline)) {
+      constexpr bool THREE = decltype(three_tag)::value;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 ah[RT], al[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          ah[rt] = *reinterpret_cast<const bf16x8*>(Ah + rt * 16 * LDB + aoff + ks * 32);
+          if (THREE) al[rt] = *reinterpret_cast<const bf16x8*>(Al + rt * 16 * LDB + aoff + ks * 32);
+        }
+        if (THREE) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) acc[rt][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], b.h[jj][ks], acc[rt][jj], 0, 0, 0);
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) acc[rt][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], b.l[jj][ks], acc[rt][jj], 0, 0, 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) acc[rt][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], b.h[jj][ks], acc[rt][jj], 0, 0, 0);
+      }
+    };
+    BFr b0, b1;
+    auto run = [&](auto three_tag) __attribute__((always_inline)) {
+      load_b(b0, 0);
+      lds_barrier();                                             // buffer 0 complete
+      int i = 0;
+      for (; i + 1 < nch; i += 2) {
+        load_b(b1, i + 1);
+        products(Pb, Pb + PLANE, b0, three_tag);
+        lds_barrier();
+        load_b(b0, i + 2);
+        products(Pb + 2 * PLANE, Pb + 3 * PLANE, b1, three_tag);
+        lds_barrier();
+      }
+      if (i < nch) {
+        load_b(b1, i + 1);
+        products(Pb, Pb + PLANE, b0, three_tag);
+        lds_barrier();
+      }
+    };
+    if (!g.one_product) run(std::true_type{}); else run(std::false_type{});
+  }
+  // epilogue over the two 64-row halves (the stage aliases the planes: behind the loop's last barrier nobody reads them).  All 512
+  // threads store; the consumers (waves 0-3) hold the accumulators.
+  float* stage = reinterpret_cast<float*>(gsm);
+  epilogue_t<RT / 2, NJ, 1, 4, 512>(g, reinterpret_cast<f32x4(&)[RT / 2][NJ]>(acc[0]), stage, bias_s, m0, n0, 0, cw, 0, tid, lane, consumer);
+  __syncthreads();
+  epilogue_t<RT / 2, NJ, 1, 4, 512>(g, reinterpret_cast<f32x4(&)[RT / 2][NJ]>(acc[RT / 2]), stage, bias_s, m0 + HM, n0, 0, cw, 0, tid, lane, consumer);
+}
+
+// Which panel form.  All three run one workgroup per CU, so a launch costs (rounds over the chip's 256 CUs) x (time of one round), and
+// the time of a round relative to the 64 x 128 form's was measured: 128 x 256 (four tiles' worth) 2.8-3.0, 128 x 128 producer /
+// consumer (two tiles' worth) 1.6-1.8 (profiles/r06_panel_wide.txt).  A bigger tile has to be >= 5 % cheaper to be taken; its coarser
+// quantisation is priced in by the rounds.  RD_PANEL_WIDE / RD_PANEL_PC = 0 / 1 exclude / force a form (read per call: tests, A/B);
+// RD_PANEL_WIDE_COST / RD_PANEL_PC_COST (percent) override the measured ratios.
+enum PanelForm { PANEL_SMALL = 0, PANEL_WIDE = 1, PANEL_PC = 2 };
+static PanelForm panel_form(const GemmArgs& g) {
+  const char* fw = getenv("RD_PANEL_WIDE");
+  const char* fp = getenv("RD_PANEL_PC");
+  const int force_w = fw ? atoi(fw) : -1, force_p = fp ? atoi(fp) : -1;
+  static const int cost_w = [] { const char* e = getenv("RD_PANEL_WIDE_COST"); return e ? atoi(e) : 280; }();
+  static const int cost_p = [] { const char* e = getenv("RD_PANEL_PC_COST"); return e ? atoi(e) : 180; }();
+  if (force_p == 1) return PANEL_PC;
+  if (force_w == 1) return PANEL_WIDE;
+  auto rounds = [&](int tm, int tn) { return ((long)cdiv(g.M, tm) * cdiv(g.N, tn) + 255) / 256; };
+  const long cs = rounds(64, 128) * 100, cw = rounds(128, 256) * cost_w, cp = rounds(128, 128) * cost_p;
+  PanelForm best = PANEL_SMALL; long bc = cs * 95;                 // in units of 1 / 100: a bigger tile must beat 0.95 x small
+  if (force_w != 0 && cw * 100 < bc) { best = PANEL_WIDE; bc = cw * 100; }
+  if (force_p != 0 && cp * 100 < bc) { best = PANEL_PC; bc = cp * 100; }
+  return best;
 }
 static int launch_panel_wide(const GemmArgs& g, hipStream_t st) {
   constexpr int NJ = 2, TM = 128, TN = 128 * NJ;
@@ -973,8 +1110,18 @@ static int launch_panel_wide(const GemmArgs& g, hipStream_t st) {
   hipLaunchKernelGGL((k_gemm_panel_wide<NJ>), grid, dim3(512), lds, st, g);
   return check_launch("k_gemm_panel_wide");
 }
+static int launch_panel_pc(const GemmArgs& g, hipStream_t st) {
+  constexpr int NJ = 2, TM = 128, TN = 64 * NJ;
+  const size_t lds = (size_t)4 * TM * LDB * sizeof(__bf16) + TN * sizeof(float);
+  const dim3 grid(8 * cdiv(cdiv(g.M, TM) * cdiv(g.N, TN), 8));
+  RD_LDS_ATTR((k_gemm_panel_pc<NJ>), lds);
+  hipLaunchKernelGGL((k_gemm_panel_pc<NJ>), grid, dim3(512), lds, st, g);
+  return check_launch("k_gemm_panel_pc");
+}
 static int launch_panel(const GemmArgs& g, hipStream_t st) {
-  if (panel_wide_pays(g)) return launch_panel_wide(g, st);
+  const PanelForm form = panel_form(g);
+  if (form == PANEL_WIDE) return launch_panel_wide(g, st);
+  if (form == PANEL_PC) return launch_panel_pc(g, st);
   constexpr int NJ = 2, TM = 64, TN = 64 * NJ;
   const size_t lds = (size_t)8 * TM * LDB * sizeof(__bf16) + TN * sizeof(float);      // planes (stage and hand-over alias them) + bias
   const dim3 grid(8 * cdiv(cdiv(g.M, TM) * cdiv(g.N, TN), 8));

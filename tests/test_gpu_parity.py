@@ -147,17 +147,22 @@ def test_linear_fwd_bwd(M, N, K, act):
 
 @pytest.mark.parametrize("cfg_name,B,kind,panel", [("TINY", 1, "sparse", None), ("TINY", 5, "ones", None), ("P19", 9, "sparse", None),
                                                    ("P12", 3, "ones", "0"), ("P12", 5, "sparse", "0"), ("PAM", 2, "sparse", "0"),
-                                                   ("P12", 5, "sparse", "1"), ("P12", 9, "ones", "1"), ("PAM", 9, "sparse", "1")])
+                                                   ("P12", 5, "sparse", "1"), ("P12", 9, "ones", "1"), ("PAM", 9, "sparse", "1"),
+                                                   ("P12", 5, "sparse", "pc"), ("P12", 9, "ones", "pc"), ("PAM", 9, "sparse", "pc")])
 def test_sensor_stage_vs_oracle(cfg_name, B, kind, panel, monkeypatch):
     """Observation embedding + both Observation_progation layers + PE concat, forward and backward,
     against the faithful (per-sample, per-edge) restatement of the reference.  P12 (K = 860: ragged in rows, columns and
     reduction chunks) and PAM (K = 2400, 34 rows: less than one row block) run the panel products of rd_gemm.hip with
-    the d_ob = 4 scatter and the gate-mask epilogues -- `panel`: RD_PANEL_WIDE, "0" the 64 x 128 workgroup tile, "1" round 6's
-    128 x 256 one (ragged in both halves of its rows at 180 / 324 / 153 rows, in its last column block at 860 and 2400 columns);
+    the d_ob = 4 scatter and the gate-mask epilogues -- `panel`: "0" the 64 x 128 workgroup tile, "1" round 6's 128 x 256 one, "pc" its
+    128 x 128 producer / consumer one (ragged in both halves of their rows at 180 / 324 / 153 rows, in the last column block at 860
+    and 2400 columns);
     P19 the fused kernels; TINY the tiled GEMM."""
     from raindrop_amd import _lib, ops
-    if panel is not None:
+    if panel == "pc":                                     # the 128 x 128 producer / consumer form (waves 4-7 convert, waves 0-3 multiply)
+        monkeypatch.setenv("RD_PANEL_PC", "1")
+    elif panel is not None:
         monkeypatch.setenv("RD_PANEL_WIDE", panel)
+        monkeypatch.setenv("RD_PANEL_PC", "0")
     cfg = synth.make_config(cfg_name)
     gs = synth.make_structure(cfg, kind)
     b = synth.make_batch(cfg, B, seed=21)

@@ -46,7 +46,7 @@ HOT = [
     (("k_attn_fwd_fusedILi5ELi5E",), 256), (("k_attn_bwd_fusedILi5ELi5E",), 256),             # 8 waves per workgroup, one workgroup per CU
     (("k_attn_fwd_one_b16wILi5ELb1E",), 128), (("k_attn_bwd_one_b16wILi5ELb1E",), 128),
     (("k_attn_fwd_b16ILi5ELb1ELb0E",), 256), (("k_attn_bwd_dq_b16ILi5ELb1ELb0E",), 256), (("k_attn_bwd_dkv_b16ILi5ELb1ELb0E",), 256),
-    (("k_head_rowsILi1E",), 128), (("k_head_wgrad",), None), (("k_gemm_panelILi2E",), 256), (("k_gemm_panel_wideILi2E",), 256), (("k_adam",), None), (("k_wsplit",), None),
+    (("k_head_rowsILi1E",), 128), (("k_head_wgrad",), None), (("k_gemm_panelILi2E",), 256), (("k_gemm_panel_wideILi2E",), 256), (("k_gemm_panel_pcILi2E",), 256), (("k_adam",), None), (("k_wsplit",), None),
 ]
 
 
